@@ -1,0 +1,206 @@
+"""Golden-vector generator (test infrastructure; runs ONLY in the build container).
+
+Imports the in-tree reference modules from /root/reference through import shims
+(the reference's own third-party imports -- pytorch_lightning, omegaconf,
+torchaudio, hearbaseline, ... -- are absent from this image) and
+records small input/output fixtures under tests/golden/.  Weights are produced
+by the oracle's own seeded generators and loaded into the reference modules with
+load_state_dict, so the fixtures hold inputs + expected outputs only.
+
+Nothing here travels to the GPU box except the .npz files it writes.
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True          # never drop __pycache__ into /root/reference
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import ref_cnn14, ref_hdemucs, ref_losses, ref_tcn  # noqa: E402
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_shims():
+    """Stub the third-party packages the reference imports at module import time."""
+    ident = lambda f=None, *a, **k: f
+    pl = _mod("pytorch_lightning", LightningModule=_Lightning, LightningDataModule=object,
+              Callback=object, Trainer=object, seed_everything=lambda s: torch.manual_seed(s))
+    pl.utilities = _mod("pytorch_lightning.utilities", rank_zero_only=ident)
+    pl.loggers = _mod("pytorch_lightning.loggers", WandbLogger=object, CSVLogger=object)
+    pl.loggers.logger = _mod("pytorch_lightning.loggers.logger", Logger=object)
+    pl.callbacks = _mod("pytorch_lightning.callbacks", ModelCheckpoint=object)
+    _mod("omegaconf", DictConfig=dict)
+    ta = _mod("torchaudio")
+    ta.functional = _mod("torchaudio.functional", resample=None)
+    ta.transforms = _mod("torchaudio.transforms", MelSpectrogram=_MelStandIn, Resample=nn.Identity,
+                         FrequencyMasking=lambda *a, **k: nn.Identity(),
+                         TimeMasking=lambda *a, **k: nn.Identity())
+    ta.models = _mod("torchaudio.models", HDemucs=ref_hdemucs.HDemucs)
+    for n in ("hearbaseline", "hearbaseline.vggish", "hearbaseline.wav2vec2", "wav2clip_hear",
+              "panns_hear", "pedalboard", "pyloudnorm", "torchvision", "torchvision.transforms",
+              "asteroid", "asteroid.models", "umx", "umx.openunmix", "wandb"):
+        _mod(n)
+    sys.modules["hearbaseline"].vggish = sys.modules["hearbaseline.vggish"]
+    sys.modules["hearbaseline"].wav2vec2 = sys.modules["hearbaseline.wav2vec2"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["asteroid"].models = sys.modules["asteroid.models"]
+    _mod("umx.openunmix.model", OpenUnmix=object, Separator=object)
+    tm = _mod("torchmetrics")
+    tm.classification = _mod("torchmetrics.classification", Accuracy=lambda **k: nn.Identity(),
+                             MultilabelF1Score=lambda *a, **k: nn.Identity())
+    al = _mod("auraloss")
+    al.time = _mod("auraloss.time", SISDRLoss=_SISDR)
+    al.freq = _mod("auraloss.freq", MultiResolutionSTFTLoss=_MRSTFT)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+class _Lightning(nn.Module):
+    """pl.LightningModule stand-in: an nn.Module that records self.log calls."""
+    def __init__(self):
+        super().__init__()
+        self.logged = {}
+
+    def log(self, name, value, **kw):
+        self.logged[name] = float(value)
+
+
+class _MelStandIn(nn.Module):
+    """torchaudio.transforms.MelSpectrogram stand-in backed by the oracle mel."""
+    def __init__(self, sample_rate, n_fft, hop_length=None, n_mels=128):
+        super().__init__()
+        self.a = (sample_rate, n_fft, hop_length, n_mels)
+
+    def forward(self, x):
+        return ref_cnn14.mel_spectrogram(x, *self.a)
+
+
+class _MRSTFT(nn.Module):
+    def __init__(self, **kw):
+        super().__init__()
+
+    def forward(self, x, y):
+        return ref_losses.mrstft_loss(x, y)
+
+
+class _SISDR(nn.Module):
+    def forward(self, x, y):
+        return ref_losses.sisdr_loss(x, y)
+
+
+def gen_utils():
+    import remfx.utils as ru
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 1, 8192, generator=g)
+    S = ru.spectrogram(x, torch.hann_window(512), 512, 128, 0.3)
+    a = torch.arange(40.0).reshape(2, 20)
+    np.savez_compressed(os.path.join(OUT, "utils_small.npz"), x=x.numpy(), spec=S.numpy(),
+                        crop_in=a.numpy(), center7=ru.center_crop(a, 7).numpy(),
+                        causal7=ru.causal_crop(a, 7).numpy())
+    print("utils_small", tuple(S.shape))
+
+
+def gen_tcn():
+    from remfx.tcn import TCN
+    cases = {
+        "tcn_small": dict(cfg=dict(ninputs=1, noutputs=1, nblocks=4, channel_width=8, kernel_size=7,
+                                   stack_size=10, dilation_growth=2, causal=False), B=2, T=2048, seed=3),
+        "tcn_mid": dict(cfg=dict(ninputs=1, noutputs=1, nblocks=12, channel_width=32, kernel_size=7,
+                                 stack_size=10, dilation_growth=2, causal=False), B=1, T=8192, seed=4),
+        "tcn_causal": dict(cfg=dict(ninputs=2, noutputs=2, nblocks=3, channel_width=16, kernel_size=5,
+                                    stack_size=2, dilation_growth=3, causal=True), B=2, T=1024, seed=5),
+    }
+    for name, c in cases.items():
+        cfg = c["cfg"]
+        net = TCN(**cfg).eval()
+        sd = ref_tcn.tcn_init_state_dict(cfg["ninputs"], cfg["noutputs"], cfg["nblocks"],
+                                         cfg["channel_width"], cfg["kernel_size"], seed=c["seed"])
+        for k in [k for k in sd if k.endswith("relu.weight")]:   # non-trivial PReLU slopes
+            sd[k] = torch.linspace(0.05, 0.45, sd[k].numel())
+        net.load_state_dict(sd)
+        g = torch.Generator().manual_seed(100 + c["seed"])
+        x = torch.randn(c["B"], cfg["ninputs"], c["T"], generator=g)
+        with torch.no_grad():
+            y = net(x)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), x=x.numpy(), y=y.numpy(),
+                            rf=np.int64(net.receptive_field), seed=np.int64(c["seed"]),
+                            **{"cfg_" + k: np.asarray(v) for k, v in cfg.items()})
+        print(name, tuple(y.shape), "rf", net.receptive_field)
+    # full config: receptive field, parameter count, key list (cheap known answers)
+    import yaml
+    full = yaml.safe_load(open(os.path.join(REF, "cfg/model/tcn.yaml")))["model"]["network"]
+    for k in ("_target_", "sample_rate", "num_bins"):
+        full.pop(k)
+    net = TCN(**full)
+    np.savez_compressed(os.path.join(OUT, "tcn_full_kat.npz"), rf=np.int64(net.receptive_field),
+                        nparams=np.int64(sum(p.numel() for p in net.parameters())),
+                        keys=np.array(list(net.state_dict().keys())))
+    print("tcn_full rf", net.receptive_field, sum(p.numel() for p in net.parameters()))
+
+
+def gen_cnn14():
+    from remfx.classifier import Cnn14
+    net = Cnn14(num_classes=5, sample_rate=48000, model_sample_rate=48000, n_fft=2048,
+                hop_length=512, n_mels=128).eval()
+    sd = ref_cnn14.cnn14_init_state_dict(seed=7)
+    # BN with non-trivial affine + running stats so eval mode is exercised
+    g = torch.Generator().manual_seed(8)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.05
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) * 0.5 + 0.75
+        elif ".bn" in k and k.endswith("weight"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) * 0.4 + 0.8
+        elif ".bn" in k and k.endswith("bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.05
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing
+    for k in list(sd):                       # spread the head logits away from 0
+        if k.startswith("heads.") and k.endswith("weight"):
+            sd[k] = sd[k] * 40.0
+    net.load_state_dict(sd, strict=False)
+    t = torch.arange(32768) / 48000.0
+    x = torch.stack([torch.randn(32768, generator=g) * 0.1,
+                     0.3 * torch.sin(2 * torch.pi * (200.0 + 4000.0 * t) * t) +
+                     0.1 * torch.sin(2 * torch.pi * 9000.0 * t)])[:, None, :]
+    taps = {}
+    hooks = [net.conv_block2.register_forward_hook(lambda m, i, o: taps.__setitem__("cb2", o.detach().clone())),
+             net.fc1.register_forward_hook(lambda m, i, o: taps.__setitem__("fc1", o.detach().clone()))]
+    with torch.no_grad():
+        mel = net.melspec(x)
+        out_eval = torch.hstack(net(x))
+        cb2_eval, fc1_eval = taps["cb2"], taps["fc1"]
+        net.train()     # BatchNorm batch statistics; dropout off because train=False arg
+        out_bnbatch = torch.hstack(net(x, train=False))
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(OUT, "cnn14_full.npz"), x=x.numpy(), mel=mel.numpy(),
+                        out_eval=out_eval.numpy(), out_bnbatch=out_bnbatch.numpy(),
+                        cb2_eval=cb2_eval[:, ::16, ::4, ::8].numpy(), fc1_eval=fc1_eval[:, ::8].numpy(),
+                        nparams=np.int64(sum(p.numel() for p in net.parameters())),
+                        keys=np.array(list(net.state_dict().keys())))
+    print("cnn14_full", out_eval.numpy().round(4), out_bnbatch.numpy().round(4))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    install_shims()
+    gen_utils()
+    gen_tcn()
+    gen_cnn14()

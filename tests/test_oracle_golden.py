@@ -1,0 +1,112 @@
+"""CPU: the oracle restatement vs golden vectors recorded from the imported
+reference modules (oracle/gen_golden.py).  Pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cnn14, ref_hdemucs, ref_losses, ref_tcn, ref_utils
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_spectrogram_and_crops(golden_dir):
+    g = _load(golden_dir, "utils_small.npz")
+    S = ref_utils.spectrogram(torch.from_numpy(g["x"]), torch.hann_window(512), 512, 128, 0.3)
+    np.testing.assert_allclose(S.numpy(), g["spec"], rtol=1e-5, atol=1e-6)
+    a = torch.from_numpy(g["crop_in"])
+    assert np.array_equal(ref_utils.center_crop(a, 7).numpy(), g["center7"])
+    assert np.array_equal(ref_utils.causal_crop(a, 7).numpy(), g["causal7"])
+    # Q1: causal crop drops the last sample
+    assert ref_utils.causal_crop(torch.arange(10), 4).tolist() == [5, 6, 7, 8]
+    assert ref_utils.center_crop(torch.arange(10), 4).tolist() == [3, 4, 5, 6]
+
+
+@pytest.mark.parametrize("name", ["tcn_small", "tcn_mid", "tcn_causal"])
+def test_tcn_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name + ".npz")
+    cfg = {k[4:]: g[k].item() for k in g.files if k.startswith("cfg_")}
+    sd = ref_tcn.tcn_init_state_dict(cfg["ninputs"], cfg["noutputs"], cfg["nblocks"],
+                                     cfg["channel_width"], cfg["kernel_size"], seed=int(g["seed"]))
+    for k in [k for k in sd if k.endswith("relu.weight")]:
+        sd[k] = torch.linspace(0.05, 0.45, sd[k].numel())
+    y = ref_tcn.tcn_forward(torch.from_numpy(g["x"]), sd, cfg["nblocks"], cfg["stack_size"],
+                            cfg["dilation_growth"], bool(cfg["causal"]))
+    assert y.shape == g["y"].shape
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6)
+    assert ref_tcn.tcn_receptive_field(cfg["nblocks"], cfg["kernel_size"], cfg["stack_size"],
+                                       cfg["dilation_growth"]) == int(g["rf"])
+
+
+def test_tcn_full_known_answers(golden_dir):
+    g = _load(golden_dir, "tcn_full_kat.npz")
+    assert int(g["rf"]) == 12277 == ref_tcn.tcn_receptive_field(20, 7, 10, 2)
+    sd = ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7)
+    assert sum(v.numel() for v in sd.values()) == int(g["nparams"]) == 9974017
+    assert sorted(sd.keys()) == sorted(g["keys"].tolist())
+
+
+def test_cnn14_matches_reference(golden_dir):
+    g = _load(golden_dir, "cnn14_full.npz")
+    sd = ref_cnn14.cnn14_init_state_dict(seed=7)
+    gen = torch.Generator().manual_seed(8)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.05
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=gen) * 0.5 + 0.75
+        elif ".bn" in k and k.endswith("weight"):
+            sd[k] = torch.rand(sd[k].shape, generator=gen) * 0.4 + 0.8
+        elif ".bn" in k and k.endswith("bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.05
+    for k in list(sd):
+        if k.startswith("heads.") and k.endswith("weight"):
+            sd[k] = sd[k] * 40.0
+    nparams = sum(v.numel() for k, v in sd.items() if "running" not in k) + 2 * 128  # + unused bn0
+    assert nparams == int(g["nparams"]) == 79684165
+    mel = torch.from_numpy(g["mel"])
+    with torch.no_grad():
+        out = torch.hstack(ref_cnn14.cnn14_from_mel(mel, sd))
+        outb = torch.hstack(ref_cnn14.cnn14_from_mel(mel, sd, bn_train=True))
+        out_wave = torch.hstack(ref_cnn14.cnn14_forward(torch.from_numpy(g["x"]), sd))
+    np.testing.assert_allclose(out.numpy(), g["out_eval"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(outb.numpy(), g["out_bnbatch"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(out_wave.numpy(), g["out_eval"], rtol=1e-4, atol=1e-5)
+    # bit-exact thresholded labels (models.py:61-64)
+    assert np.array_equal(out.numpy() > 0.5, g["out_eval"] > 0.5)
+
+
+def test_hdemucs_known_answers():
+    torch.manual_seed(0)
+    m = ref_hdemucs.HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
+    assert sum(p.numel() for p in m.parameters()) == 83630131
+    # spec -> ispec round trip: interior is near-exact only up to the dropped Nyquist bin
+    x = torch.randn(1, 1, 16384)
+    z = m._spec(x)
+    assert z.shape == (1, 1, 2048, 16)
+    xr = m._ispec(z, 16384)
+    assert xr.shape == x.shape
+    lo = torch.stft(x[0], 4096, 1024, window=torch.hann_window(4096), return_complex=True, normalized=True)
+    assert torch.isfinite(xr).all()
+    # small-T forward keeps the (B, S, C, T) contract
+    m2 = ref_hdemucs.HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=8)
+    with torch.no_grad():
+        y = m2(torch.randn(2, 1, 20000))
+    assert y.shape == (2, 1, 1, 20000)
+
+
+def test_losses_basic():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 1, 16384, generator=g)
+    y = torch.randn(2, 1, 16384, generator=g)
+    assert ref_losses.mrstft_loss(y, y).item() == pytest.approx(0.0, abs=1e-6)
+    l = ref_losses.removal_loss(x, y)
+    assert torch.isfinite(l) and l.item() > 0
+    # SI-SDR is scale invariant in the estimate and = +inf-ish for identical signals
+    a = ref_losses.sisdr_loss(x, y)
+    b = ref_losses.sisdr_loss(3.0 * x, y)
+    assert a.item() == pytest.approx(b.item(), rel=1e-4)
+    assert ref_losses.sisdr_loss(y, y).item() < -60
