@@ -1,0 +1,168 @@
+/*
+ * remfx_hip.h -- C ABI of libremfx_hip.so, the MI355X (gfx950) kernels behind the
+ * RemFX effect-removal hot path.
+ *
+ * The reference (mhrice/RemFx) has no FFI of its own: its hot path is a sequence
+ * of ATen op calls issued from Python.  Each entry point below
+ * therefore cites the reference call site(s) whose ATen ops it replaces.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes only; no torch types.
+ *   - the CALLER owns every buffer (inputs, outputs, workspaces); the library
+ *     never allocates, frees, synchronises or changes the current device.
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void*).
+ *   - return value: 0 on success, negative on bad arguments (-1) or a failed
+ *     launch (-2 - hipError).  No exceptions cross the ABI.
+ *   - tensors are fp32 unless stated; strides are in ELEMENTS.
+ */
+#ifndef REMFX_HIP_H
+#define REMFX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFX_ABI_VERSION 1
+
+/* ---- activations usable in fused epilogues ---------------------------------- */
+enum rfx_act {
+  RFX_ACT_NONE = 0,
+  RFX_ACT_RELU = 1,   /* classifier.py:271-272 */
+  RFX_ACT_GELU = 2,   /* exact erf GELU: HDemucs enc/dec, DConv */
+  RFX_ACT_TANH = 3,   /* tcn.py:129 */
+  RFX_ACT_PRELU = 4,  /* per-output-channel slope: tcn.py:47,51 */
+  RFX_ACT_LEAKY = 5,  /* slope 0.01: DCUNet */
+  RFX_ACT_SIGMOID = 6 /* classifier.py:231 */
+};
+
+/* ---- gather-GEMM descriptor -------------------------------------------------
+ * One descriptor describes  Out[n, m, a', b'] = epi( sum_k A[k][m] * In(n, k, a, b) )
+ * for a in [0,OA), b in [0,OB):
+ *   In(n,k,a,b) = in[n*in_ns + ktab[k].off + (a*SA)*in_as + (b*SB)*in_bs]
+ *                 if 0 <= a*SA + ktab[k].da < IA and 0 <= b*SB + ktab[k].db < IB, else 0
+ *                 (ktab[k].off already contains channel*in_cs + da*in_as + db*in_bs)
+ *   a' = a*out_sa + out_a0,  b' = b*out_sb + out_b0
+ * Every convolution of the hot path (Conv1d/2d forward, their input gradients,
+ * ConvTranspose1d/2d forward and input gradients, one descriptor per stride
+ * phase) is expressed this way by the host-side planner (remfx_amd/convplan.py).
+ * Replaces: F.conv1d tcn.py:50,54,129; HDemucs / DCUNet / Cnn14 conv stacks
+ * (models.py:319,358; classifier.py:271-272).
+ */
+typedef struct rfx_ktab_entry {
+  int32_t off;   /* element offset relative to the sample base */
+  int32_t da;    /* tap displacement along a (for the bounds test) */
+  int32_t db;    /* tap displacement along b */
+  int32_t flags; /* bit0: constant-one column (bias-gradient row in wgrad) */
+} rfx_ktab_entry;
+
+typedef struct rfx_gemm_desc {
+  int32_t N, M, K;       /* batch, output rows (channels), reduction length */
+  int32_t OA, OB;        /* output position grid */
+  int32_t IA, IB;        /* input extent for the bounds test */
+  int32_t SA, SB;        /* input position stride */
+  int32_t Mpad, Kpad;    /* packed-A geometry: A is [Kpad][Mpad], Mpad%4==0, Kpad%16==0 */
+  int32_t out_a0, out_b0, out_sa, out_sb;
+  int64_t in_ns, in_as, in_bs;
+  int64_t out_ns, out_cs, out_as, out_bs;
+} rfx_gemm_desc;
+
+/* Epilogue: v = acc + bias[m]; v = act(v); [second GEMM phase accumulates into
+ * act(v)]; v += res[...] ; out = v.  All pointers may be NULL. */
+typedef struct rfx_epilogue {
+  const float* bias;      /* [M] */
+  int32_t act;            /* enum rfx_act, applied after bias (after phase 1) */
+  const float* act_param; /* PReLU slopes [M] */
+  const float* res;       /* residual added last, indexed with out coordinates */
+  int64_t res_ns, res_cs, res_as, res_bs;
+  int32_t act2;           /* activation applied at the very end (after phase 2 / residual) */
+  /* backward-of-activation mode (bwd != 0): the GEMM recomputes the pre-activation
+   * v = acc + bias, `res` holds the incoming gradient G (out coordinates) and the
+   * kernel writes out = G * act'(v); for PReLU, gparam[m] += sum G * min(v, 0).
+   * Used to re-materialise PReLU(conv1(x)) in the TCN backward instead of
+   * storing a second 256 x T activation per block. */
+  int32_t bwd;
+  float* gparam;
+} rfx_epilogue;
+
+/* A[k][m] = w[m*w_ms + woff[k]]  (k < K), zero padded to [Kpad][Mpad]. */
+int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
+               int32_t Mpad, int32_t Kpad, float* apack, void* stream);
+/* w[m*w_ms + woff[k]] += dapack[k][m]   (inverse of rfx_pack_a, accumulating). */
+int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
+                   int32_t Mpad, float* dw, void* stream);
+
+/* Forward gather-GEMM on the fp32 MFMA path (v_mfma_f32_32x32x2_f32).
+ * Optional second phase (apack2/ktab2/K2 != 0): after phase 1 the epilogue
+ * activation is applied to the accumulators, then phase 2 keeps accumulating
+ * (TCNBlock: PReLU(conv1(x)) + res(x), tcn.py:48-59, in one launch). */
+int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rfx_ktab_entry* ktab,
+                 const float* in, float* out, const rfx_epilogue* epi,
+                 const float* apack2, const rfx_ktab_entry* ktab2, int32_t K2, int32_t Kpad2,
+                 const float* in2 /* phase-2 input, same strides as `in`; NULL = `in` */,
+                 void* stream);
+
+/* Weight gradient of the same descriptor:
+ * dapack[k][m] += sum_{n,a,b} g[n*g_ns + m*g_cs + a'*g_as + b'*g_bs] * In(n,k,a,b)
+ * (g indexed with OUT coordinates/strides of the descriptor: out_* fields).
+ * Rows k with ktab flag bit0 use In == 1 (bias gradient).  dapack must be
+ * zero-initialised by the caller; partial sums are combined with fp32 atomics. */
+int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const float* in,
+                   const float* g, float* dapack, void* stream);
+
+/* ---- framed FFT front end ---------------------------------------------------
+ * STFT as torch.stft(center=True, pad_mode="reflect", onesided) computes it:
+ * utils.py:148-154 (spectrogram), HDemucs _spec, auraloss STFTLoss, Separator,
+ * MelSpectrogram.  x: [R][T]; frame f covers x_padded[f*hop : f*hop+n_fft] with
+ * reflect padding n_fft/2 and a hann window of `win` samples centred in n_fft.
+ */
+enum rfx_stft_out {
+  RFX_STFT_COMPLEX = 0, /* out[R][bins][frames][2] (torch view_as_real layout) */
+  RFX_STFT_CAC = 1,     /* out[R][2][bins][frames]: real plane, imag plane (HDemucs _magnitude) */
+  RFX_STFT_MAG = 2,     /* out[R][bins][frames] = sqrt(max(re^2+im^2, eps)) (auraloss) */
+  RFX_STFT_POW = 3,     /* out[R][bins][frames] = re^2+im^2 (MelSpectrogram power=2) */
+  RFX_STFT_MAGPOW = 4   /* out = (sqrt(re^2+im^2) + eps) ^ alpha (utils.py:159) */
+};
+typedef struct rfx_stft_desc {
+  int32_t R, T;           /* rows (batch*channels), samples per row */
+  int32_t n_fft, hop, win;
+  int32_t frames;         /* 1 + T / hop */
+  int32_t bins;           /* bins written: n_fft/2+1, or n_fft/2 to drop Nyquist (HDemucs) */
+  int32_t frame0;         /* first frame written (HDemucs keeps [2 : 2+le]) */
+  int32_t frames_out;     /* number of frames written */
+  int32_t mode;           /* enum rfx_stft_out */
+  int32_t extra_pad_l, extra_pad_r; /* additional reflect padding applied first (HDemucs _spec) */
+  float scale;            /* 1/sqrt(n_fft) for normalized=True, else 1 */
+  float eps, alpha;
+} rfx_stft_desc;
+
+int rfx_stft_fwd(const rfx_stft_desc* d, const float* x, const float* window, float* out, void* stream);
+/* gx[R][T] = adjoint of rfx_stft_fwd in RFX_STFT_COMPLEX / RFX_STFT_CAC mode applied to gout. */
+int rfx_stft_bwd(const rfx_stft_desc* d, const float* gout, const float* window, float* gx, void* stream);
+
+/* ---- elementwise / reductions ------------------------------------------------ */
+/* y = act(x) elementwise over n contiguous floats; PReLU/bias not supported here. */
+int rfx_act_fwd(const float* x, float* y, int64_t n, int32_t act, void* stream);
+/* gx = gy * act'(x) */
+int rfx_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int32_t act, void* stream);
+/* PReLU with per-channel slope over [N][C][L] contiguous: gx, and gslope[C] (+=, atomics). */
+int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx, float* gslope,
+                  int64_t N, int64_t C, int64_t L, void* stream);
+
+/* out[c] += sum over (n, a, b) of x[n*ns + c*cs + a*as + b*bs]  (bias gradients) */
+int rfx_channel_sum(const float* x, int32_t N, int32_t C, int32_t A, int32_t B, int64_t ns, int64_t cs,
+                    int64_t as, int64_t bs, float* out, void* stream);
+
+/* sum |a-b| over n elements -> *out (+=, caller zeroes).  nn.L1Loss numerator, models.py:320 */
+int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream);
+
+int rfx_abi_version(void);
+/* channel tiles per wave the MFMA forward kernel will use for M output rows (0 = thin path);
+ * the packed A matrix must have Mpad = ceil(M / (32*R)) * 32*R  (R=0: Mpad = 8). */
+int rfx_gemm_pick_r(int32_t M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REMFX_HIP_H */

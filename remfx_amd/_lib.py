@@ -1,0 +1,134 @@
+"""Loader / builder for libremfx_hip.so (the C-ABI boundary, include/remfx_hip.h).
+
+The library is built IN-TREE (remfx_amd/_C/libremfx_hip.so) with
+``hipcc --offload-arch=gfx950`` so it travels to the GPU box with the repo
+snapshot.  There is deliberately NO fallback: if the library is missing or a
+symbol declared in the header is absent, importing the op layer raises.
+"""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(_ROOT, "include")
+LIBDIR = os.path.join(_HERE, "_C")
+LIBPATH = os.path.join(LIBDIR, "libremfx_hip.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+               "-I" + INCLUDE, "-I" + CSRC]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIBPATH):
+        return True
+    t = os.path.getmtime(LIBPATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into one shared library (object per
+    file so unchanged files are not recompiled)."""
+    if not force and not _stale():
+        return LIBPATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    hdr_t = max([os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.h")) +
+                 glob.glob(os.path.join(INCLUDE, "*.h"))] or [0])
+    procs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > hdr_t):
+            continue
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    return LIBPATH
+
+
+# ---- ctypes mirrors of the header structs ----------------------------------------
+class KtabEntry(C.Structure):
+    _fields_ = [("off", C.c_int32), ("da", C.c_int32), ("db", C.c_int32), ("flags", C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "M", "K", "OA", "OB", "IA", "IB", "SA", "SB", "Mpad",
+                                         "Kpad", "out_a0", "out_b0", "out_sa", "out_sb")] + \
+               [(n, C.c_int64) for n in ("in_ns", "in_as", "in_bs", "out_ns", "out_cs", "out_as", "out_bs")]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("act", C.c_int32), ("act_param", C.c_void_p),
+                ("res", C.c_void_p), ("res_ns", C.c_int64), ("res_cs", C.c_int64),
+                ("res_as", C.c_int64), ("res_bs", C.c_int64), ("act2", C.c_int32), ("bwd", C.c_int32),
+                ("gparam", C.c_void_p)]
+
+
+class StftDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("R", "T", "n_fft", "hop", "win", "frames", "bins", "frame0",
+                                         "frames_out", "mode", "extra_pad_l", "extra_pad_r")] + \
+               [(n, C.c_float) for n in ("scale", "eps", "alpha")]
+
+
+_P, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
+# name -> argtypes; every symbol include/remfx_hip.h declares must be listed here
+SIGNATURES = {
+    "rfx_abi_version": [],
+    "rfx_gemm_pick_r": [_I32],
+    "rfx_pack_a": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P],
+    "rfx_unpack_add": [_P, _P, _I64, _I32, _I32, _I32, _P, _P],
+    "rfx_gemm_fwd": [C.POINTER(GemmDesc), _P, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _I32, _I32, _P, _P],
+    "rfx_gemm_wgrad": [C.POINTER(GemmDesc), _P, _P, _P, _P, _P],
+    "rfx_act_fwd": [_P, _P, _I64, _I32, _P],
+    "rfx_act_bwd": [_P, _P, _P, _I64, _I32, _P],
+    "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
+    "rfx_l1_sum": [_P, _P, _I64, _P, _P],
+    "rfx_channel_sum": [_P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _P, _P],
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (never builds implicitly on a box without hipcc sources
+    newer than the .so).  Raises if it is missing: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise RuntimeError(
+            f"{LIBPATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  remfx_amd has no CPU fallback.")
+    L = C.CDLL(LIBPATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError if the export is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if L.rfx_abi_version() != 1:
+        raise RuntimeError("libremfx_hip ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")

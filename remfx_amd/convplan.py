@@ -1,0 +1,214 @@
+"""Host-side planner: turns every convolution of the hot path into gather-GEMM
+descriptors (include/remfx_hip.h: rfx_gemm_desc + rfx_ktab_entry tables).
+
+All tensors are viewed as 4-D (N, C, A, B); 1-D convolutions use A == 1.
+A plan is pure host data (numpy); ``remfx_amd.ops`` uploads the tables once per
+(shape, stride) key and caches them.
+
+Covered (reference call sites):
+  conv forward            F.conv1d/conv2d        tcn.py:50,54,129; HDemucs enc; Cnn14; DCUNet
+  conv input gradient     autograd of the above  (one descriptor per stride phase)
+  conv_transpose forward  HDemucs / DCUNet decoders (one descriptor per stride phase, crop folded in)
+  conv_transpose dgrad    = plain strided conv of the output gradient
+  weight gradients        rfx_gemm_wgrad over the forward (conv) / dgrad (conv_transpose) descriptor
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+INVALID_DA = -(1 << 30)
+
+
+def pick_r(M):
+    """Mirror of rfx_gemm_pick_r (csrc/gemm.hip): channel tiles per wave."""
+    if M <= 8:
+        return 0
+    if M <= 32:
+        return 1
+    best, best_pad = 4, -(-M // 128) * 128
+    for r in (3, 2):
+        pad = -(-M // (32 * r)) * 32 * r
+        if pad < best_pad:
+            best, best_pad = r, pad
+    return best
+
+
+def mpad_for(M):
+    r = pick_r(M)
+    return 8 if r == 0 else -(-M // (32 * r)) * 32 * r
+
+
+@dataclass
+class GemmPlan:
+    N: int
+    M: int
+    K: int
+    OA: int
+    OB: int
+    IA: int
+    IB: int
+    SA: int
+    SB: int
+    in_ns: int
+    in_as: int
+    in_bs: int
+    out_ns: int
+    out_cs: int
+    out_as: int
+    out_bs: int
+    out_a0: int = 0
+    out_b0: int = 0
+    out_sa: int = 1
+    out_sb: int = 1
+    ktab: np.ndarray = None      # [Kpad, 4] int32 (off, da, db, flags)
+    woff: np.ndarray = None      # [K] int32 weight gather offsets
+    w_ms: int = 0                # weight stride per output row m
+    Mpad: int = 0
+    Kpad: int = 0
+    extra: dict = field(default_factory=dict)
+
+    def finalize(self, bias_row=False):
+        """Pad the tables.  bias_row appends a constant-one column (flags bit0) used
+        by the weight-gradient kernel to produce the bias gradient."""
+        kt = np.asarray(self.ktab, dtype=np.int64).reshape(-1, 4)
+        K = kt.shape[0]
+        if bias_row:
+            kt = np.concatenate([kt, np.array([[0, 0, 0, 1]], dtype=np.int64)], 0)
+        Kall = kt.shape[0]
+        self.K = Kall
+        self.Kpad = -(-Kall // 16) * 16
+        pad = np.zeros((self.Kpad - Kall, 4), dtype=np.int64)
+        pad[:, 1] = INVALID_DA
+        kt = np.concatenate([kt, pad], 0)
+        assert np.abs(kt[:, 0]).max(initial=0) < 2 ** 31
+        self.ktab = kt.astype(np.int32)
+        self.Mpad = mpad_for(self.M)
+        self.woff = np.asarray(self.woff, dtype=np.int32).reshape(-1)
+        assert self.woff.shape[0] == K
+        self.extra["n_weight_rows"] = K
+        return self
+
+
+def _out_len(i, k, s, p, d):
+    return (i + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def conv_fwd_plan(xshape, xstrides, wshape, stride, padding, dilation, ystrides, bias_row=False):
+    """Conv2d forward:  y[n,co,oa,ob] = sum w[co,ci,ka,kb] x[n,ci,oa*SA-PA+ka*DA, ob*SB-PB+kb*DB]."""
+    N, Cin, IA, IB = xshape
+    Cout, Cin_w, KA, KB = wshape
+    assert Cin_w == Cin
+    (SA, SB), (PA, PB), (DA, DB) = stride, padding, dilation
+    OA, OB = _out_len(IA, KA, SA, PA, DA), _out_len(IB, KB, SB, PB, DB)
+    ns, cs, as_, bs = xstrides
+    ci, ka, kb = np.meshgrid(np.arange(Cin), np.arange(KA), np.arange(KB), indexing="ij")
+    da, db = ka * DA - PA, kb * DB - PB
+    ktab = np.stack([ci * cs + da * as_ + db * bs, da, db, np.zeros_like(da)], -1).reshape(-1, 4)
+    woff = (ci * KA * KB + ka * KB + kb).reshape(-1)
+    p = GemmPlan(N=N, M=Cout, K=ktab.shape[0], OA=OA, OB=OB, IA=IA, IB=IB, SA=SA, SB=SB,
+                 in_ns=ns, in_as=as_, in_bs=bs, out_ns=ystrides[0], out_cs=ystrides[1],
+                 out_as=ystrides[2], out_bs=ystrides[3], ktab=ktab, woff=woff, w_ms=Cin * KA * KB)
+    p.extra["out_shape"] = (N, Cout, OA, OB)
+    return p.finalize(bias_row)
+
+
+def _phase_taps(phi, K, S, P, D):
+    """taps k with (phi + P - k*D) % S == 0 and their input shift c = (phi + P - k*D) // S."""
+    return [(k, (phi + P - k * D) // S) for k in range(K) if (phi + P - k * D) % S == 0]
+
+
+def conv_dgrad_plans(xshape, xstrides, wshape, stride, padding, dilation, gshape, gstrides):
+    """Input gradient of conv_fwd_plan: one descriptor per stride phase.
+    dx[n,ci,ia,ib] = sum_{co,ka,kb} w[co,ci,ka,kb] g[n,co,(ia+PA-ka*DA)/SA,(ib+PB-kb*DB)/SB]."""
+    N, Cin, IA, IB = xshape
+    Cout, _, KA, KB = wshape
+    (SA, SB), (PA, PB), (DA, DB) = stride, padding, dilation
+    _, _, OA, OB = gshape
+    gns, gcs, gas, gbs = gstrides
+    plans = []
+    for pa in range(min(SA, IA)):
+        ta = _phase_taps(pa, KA, SA, PA, DA)
+        QA = -(-(IA - pa) // SA)
+        for pb in range(min(SB, IB)):
+            tb = _phase_taps(pb, KB, SB, PB, DB)
+            QB = -(-(IB - pb) // SB)
+            rows, woff = [], []
+            for co in range(Cout):
+                for (ka, ca) in ta:
+                    for (kb, cb) in tb:
+                        rows.append((co * gcs + ca * gas + cb * gbs, ca, cb, 0))
+                        woff.append(co * Cin * KA * KB + ka * KB + kb)
+            p = GemmPlan(N=N, M=Cin, K=len(rows), OA=QA, OB=QB, IA=OA, IB=OB, SA=1, SB=1,
+                         in_ns=gns, in_as=gas, in_bs=gbs, out_ns=xstrides[0], out_cs=xstrides[1],
+                         out_as=xstrides[2], out_bs=xstrides[3], out_a0=pa, out_b0=pb, out_sa=SA,
+                         out_sb=SB, ktab=np.array(rows, dtype=np.int64).reshape(-1, 4), woff=woff,
+                         w_ms=KA * KB)
+            plans.append(p.finalize())
+    return plans
+
+
+def convT_out_len(i, k, s, d, output_padding=0):
+    return (i - 1) * s + d * (k - 1) + 1 + output_padding
+
+
+def convT_fwd_plans(xshape, xstrides, wshape, stride, dilation, crop_lo, out_len, ystrides):
+    """ConvTranspose2d forward with the output crop folded in (HDemucs decoders:
+    z[..., pad:pad+length]; padding=p of nn.ConvTranspose is the same thing with
+    crop_lo = p).  w: [Cin][Cout][KA][KB].
+    y[n,co,o_a,o_b] = sum_{ci,ka,kb} w[ci,co,ka,kb] x[n,ci,(o_a+lo_a-ka*DA)/SA, ...]."""
+    N, Cin, IA, IB = xshape
+    Cin_w, Cout, KA, KB = wshape
+    assert Cin_w == Cin
+    (SA, SB), (DA, DB) = stride, dilation
+    (la, lb), (LA, LB) = crop_lo, out_len
+    ns, cs, as_, bs = xstrides
+
+    def phase(phi, K, S, D, lo, L):
+        qmin = max(0, -(-(lo - phi) // S))
+        qmax = (L - 1 + lo - phi) // S
+        taps = [(k, qmin + (phi - k * D) // S) for k in range(K) if (phi - k * D) % S == 0]
+        return qmax - qmin + 1, S * qmin + phi - lo, taps
+
+    plans = []
+    for pa in range(SA):
+        QA, a0, ta = phase(pa, KA, SA, DA, la, LA)
+        if QA <= 0:
+            continue
+        for pb in range(SB):
+            QB, b0, tb = phase(pb, KB, SB, DB, lb, LB)
+            if QB <= 0:
+                continue
+            rows, woff = [], []
+            for ci in range(Cin):
+                for (ka, da) in ta:
+                    for (kb, db) in tb:
+                        rows.append((ci * cs + da * as_ + db * bs, da, db, 0))
+                        woff.append(ci * Cout * KA * KB + ka * KB + kb)
+            p = GemmPlan(N=N, M=Cout, K=len(rows), OA=QA, OB=QB, IA=IA, IB=IB, SA=1, SB=1,
+                         in_ns=ns, in_as=as_, in_bs=bs, out_ns=ystrides[0], out_cs=ystrides[1],
+                         out_as=ystrides[2], out_bs=ystrides[3], out_a0=a0, out_b0=b0, out_sa=SA,
+                         out_sb=SB, ktab=np.array(rows, dtype=np.int64).reshape(-1, 4), woff=woff,
+                         w_ms=KA * KB)
+            plans.append(p.finalize())
+    return plans
+
+
+def convT_dgrad_plan(xshape, xstrides, wshape, stride, dilation, crop_lo, gshape, gstrides,
+                     bias_row=False):
+    """Input gradient of convT_fwd_plans = a strided conv of g with padding crop_lo:
+    dx[n,ci,ia,ib] = sum_{co,ka,kb} w[ci,co,ka,kb] g[n,co,ia*SA+ka*DA-lo_a, ib*SB+kb*DB-lo_b].
+    Its weight-gradient (rfx_gemm_wgrad with in=g, gout=x) yields dW of the transposed conv."""
+    N, Cin, IA, IB = xshape
+    _, Cout, KA, KB = wshape
+    (SA, SB), (DA, DB) = stride, dilation
+    la, lb = crop_lo
+    _, _, GA, GB = gshape
+    gns, gcs, gas, gbs = gstrides
+    co, ka, kb = np.meshgrid(np.arange(Cout), np.arange(KA), np.arange(KB), indexing="ij")
+    da, db = ka * DA - la, kb * DB - lb
+    ktab = np.stack([co * gcs + da * gas + db * gbs, da, db, np.zeros_like(da)], -1).reshape(-1, 4)
+    woff = (co * KA * KB + ka * KB + kb).reshape(-1)
+    p = GemmPlan(N=N, M=Cin, K=ktab.shape[0], OA=IA, OB=IB, IA=GA, IB=GB, SA=SA, SB=SB,
+                 in_ns=gns, in_as=gas, in_bs=gbs, out_ns=xstrides[0], out_cs=xstrides[1],
+                 out_as=xstrides[2], out_bs=xstrides[3], ktab=ktab, woff=woff, w_ms=Cout * KA * KB)
+    return p.finalize(bias_row)

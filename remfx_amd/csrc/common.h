@@ -1,0 +1,60 @@
+// Shared device helpers for libremfx_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "remfx_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RFX_CHECK_LAUNCH()                                  \
+  do {                                                      \
+    hipError_t e_ = hipGetLastError();                      \
+    if (e_ != hipSuccess) return -2 - (int)e_;              \
+  } while (0)
+
+__device__ __forceinline__ float rfx_gelu(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float rfx_gelu_grad(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+__device__ __forceinline__ float rfx_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+__device__ __forceinline__ float rfx_act_apply(float v, int act, float slope) {
+  switch (act) {
+    case RFX_ACT_RELU: return v > 0.f ? v : 0.f;
+    case RFX_ACT_GELU: return rfx_gelu(v);
+    case RFX_ACT_TANH: return tanhf(v);
+    case RFX_ACT_PRELU: return v >= 0.f ? v : slope * v;
+    case RFX_ACT_LEAKY: return v >= 0.f ? v : 0.01f * v;
+    case RFX_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+// derivative wrt the pre-activation x
+__device__ __forceinline__ float rfx_act_grad(float x, int act, float slope) {
+  switch (act) {
+    case RFX_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case RFX_ACT_GELU: return rfx_gelu_grad(x);
+    case RFX_ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
+    case RFX_ACT_PRELU: return x >= 0.f ? 1.f : slope;
+    case RFX_ACT_LEAKY: return x >= 0.f ? 1.f : 0.01f;
+    case RFX_ACT_SIGMOID: { float s = 1.0f / (1.0f + expf(-x)); return s * (1.f - s); }
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float rfx_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double rfx_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,139 @@
+// Elementwise activations and small reductions (HBM-bound, float4 grid-stride).
+// Replaces F.gelu / F.relu / torch.tanh / nn.PReLU backward / nn.L1Loss call
+// sites of the hot path (tcn.py:51,129; models.py:320; HDemucs enc/dec).
+#include "common.h"
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = rfx_act_apply(v[c], act, 0.f);
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = rfx_act_apply(x[i], act, 0.f);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                               float* __restrict__ gx, int64_t n, int act) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 g = reinterpret_cast<const f32x4*>(gy)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) g[c] *= rfx_act_grad(v[c], act, 0.f);
+    reinterpret_cast<f32x4*>(gx)[i] = g;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    gx[i] = gy[i] * rfx_act_grad(x[i], act, 0.f);
+}
+
+// x, gy: [N][C][L] contiguous; one block per (n-chunk, c) row set.
+__global__ void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                 const float* __restrict__ slope, float* __restrict__ gx,
+                                 float* __restrict__ gslope, int64_t N, int64_t C, int64_t L) {
+  const int64_t row = blockIdx.x;  // n*C + c
+  const int c = (int)(row % C);
+  const float s = slope[c];
+  const float* xr = x + row * L;
+  const float* gr = gy + row * L;
+  float* gxr = gx + row * L;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < L; i += blockDim.x) {
+    const float v = xr[i], g = gr[i];
+    gxr[i] = v >= 0.f ? g : s * g;
+    acc += v >= 0.f ? 0.f : g * v;
+  }
+  acc = rfx_wave_sum(acc);
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(gslope + c, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void l1_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                              float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    acc += (double)fabsf(a[i] - b[i]);
+  acc = rfx_wave_sum_d(acc);
+  __shared__ double part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (float)(part[0] + part[1] + part[2] + part[3]));
+}
+
+// out[c] += sum_{n,a,b} x[...]; grid = (C, chunks)
+__global__ void channel_sum_kernel(const float* __restrict__ x, int N, int Cn, int A, int B, int64_t ns,
+                                   int64_t cs, int64_t as, int64_t bs, float* __restrict__ out) {
+  const int c = blockIdx.x;
+  const int64_t per = (int64_t)A * B, total = (int64_t)N * per;
+  const int64_t chunk = (total + gridDim.y - 1) / gridDim.y;
+  const int64_t q0 = (int64_t)blockIdx.y * chunk, q1 = q0 + chunk < total ? q0 + chunk : total;
+  double acc = 0.0;
+  for (int64_t q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+    const int n = (int)(q / per);
+    const int64_t r = q - (int64_t)n * per;
+    const int a = (int)(r / B), b = (int)(r - (int64_t)a * B);
+    acc += (double)x[n * ns + c * cs + a * as + b * bs];
+  }
+  acc = rfx_wave_sum_d(acc);
+  __shared__ double part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out + c, (float)(part[0] + part[1] + part[2] + part[3]));
+}
+
+static int grid_for(int64_t n) {
+  const int64_t b = (n + 1023) / 1024;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+extern "C" int rfx_act_fwd(const float* x, float* y, int64_t n, int32_t act, void* stream) {
+  if (!x || !y || n < 0) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int32_t act, void* stream) {
+  if (!x || !gy || !gx || n < 0) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, n, act);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx,
+                             float* gslope, int64_t N, int64_t C, int64_t L, void* stream) {
+  if (!x || !gy || !slope || !gx || !gslope || N <= 0 || C <= 0 || L <= 0) return -1;
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, x, gy,
+                     slope, gx, gslope, N, C, L);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  if (!a || !b || !out || n < 0) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(l1_sum_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rfx_channel_sum(const float* x, int32_t N, int32_t Cn, int32_t A, int32_t B, int64_t ns,
+                               int64_t cs, int64_t as, int64_t bs, float* out, void* stream) {
+  if (!x || !out || N <= 0 || Cn <= 0 || A <= 0 || B <= 0) return -1;
+  const int64_t total = (int64_t)N * A * B;
+  int chunks = (int)(total / 16384);
+  chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(Cn, chunks), dim3(256), 0, (hipStream_t)stream, x, N, Cn, A, B,
+                     ns, cs, as, bs, out);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

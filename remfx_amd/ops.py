@@ -1,0 +1,281 @@
+"""torch.autograd glue over the C-ABI kernels (include/remfx_hip.h).
+
+PyTorch is used here only for device memory, streams and the autograd tape; every
+op below launches hand-written HIP kernels from libremfx_hip.so.  There is no CPU
+or ATen fallback: tensors must be fp32 CUDA(HIP) tensors and the library must load.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, convplan
+from ._lib import Epilogue, GemmDesc, check
+
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "tanh": 3, "prelu": 4, "leaky": 5, "sigmoid": 6}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _req(t, name="tensor"):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise ValueError(f"{name}: remfx_amd ops need fp32 tensors on the GPU (got {t.dtype}, {t.device}); "
+                         "there is no CPU fallback")
+
+
+# ---- plan cache (tables live on the device next to the tensors) -------------------
+class DevPlan:
+    def __init__(self, plan, device):
+        self.p = plan
+        self.ktab = torch.from_numpy(np.ascontiguousarray(plan.ktab)).to(device)
+        self.woff = torch.from_numpy(np.ascontiguousarray(plan.woff)).to(device)
+        d = GemmDesc()
+        for f, _ in GemmDesc._fields_:
+            setattr(d, f, int(getattr(plan, f)))
+        self.desc = d
+
+    def set_io(self, x=None, out=None):
+        """Refresh strides for a new tensor with the same geometry key (cheap)."""
+        return self
+
+
+_PLANS = {}
+
+
+def _plans(key, device, builder):
+    k = (key, str(device))
+    v = _PLANS.get(k)
+    if v is None:
+        built = builder()
+        v = [DevPlan(p, device) for p in built] if isinstance(built, list) else DevPlan(built, device)
+        _PLANS[k] = v
+    return v
+
+
+def pack_a(dp, w):
+    """Gather the weight tensor into the packed [Kpad][Mpad] A matrix of a plan."""
+    p = dp.p
+    apack = torch.empty((max(p.Kpad, 1), p.Mpad), device=w.device, dtype=torch.float32)
+    nrows = p.extra["n_weight_rows"]
+    if p.Kpad:
+        check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff), p.w_ms, p.M, nrows, p.Mpad, p.Kpad,
+                                    _ptr(apack), _stream()), "rfx_pack_a")
+    return apack
+
+
+def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, act2=None,
+             dp2=None, apack2=None, in2=None, bwd=False, gparam=None):
+    e = Epilogue()
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.act = ACT[act]
+    e.act_param = act_param.data_ptr() if act_param is not None else None
+    if res is not None:
+        e.res = res.data_ptr()
+        e.res_ns, e.res_cs, e.res_as, e.res_bs = res.stride()
+    e.act2 = ACT[act2]
+    e.bwd = 1 if bwd else 0
+    e.gparam = gparam.data_ptr() if gparam is not None else None
+    if dp2 is not None:
+        a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.ktab), dp2.p.K, dp2.p.Kpad
+    else:
+        a2, k2, K2, Kpad2 = None, None, 0, 0
+    check(_lib.lib().rfx_gemm_fwd(C.byref(dp.desc), _ptr(apack), _ptr(dp.ktab), _ptr(x), _ptr(out),
+                                  C.byref(e), a2, k2, K2, Kpad2, _ptr(in2), _stream()), "rfx_gemm_fwd")
+    return out
+
+
+def gemm_wgrad(dp, x, g, dapack):
+    check(_lib.lib().rfx_gemm_wgrad(C.byref(dp.desc), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(dapack),
+                                    _stream()), "rfx_gemm_wgrad")
+
+
+def unpack_add(dp, dapack, dw):
+    p = dp.p
+    check(_lib.lib().rfx_unpack_add(_ptr(dapack), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"],
+                                    p.Mpad, _ptr(dw), _stream()), "rfx_unpack_add")
+
+
+# ---- convolution (4-D view: N, C, A, B) ----------------------------------------------
+def _key(*a):
+    return tuple(tuple(x) if isinstance(x, (list, tuple, torch.Size)) else x for x in a)
+
+
+def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=None, out=None):
+    _req(x, "x"); _req(w, "weight")
+    N, Cin, IA, IB = x.shape
+    Cout, _, KA, KB = w.shape
+    OA = convplan._out_len(IA, KA, stride[0], padding[0], dilation[0])
+    OB = convplan._out_len(IB, KB, stride[1], padding[1], dilation[1])
+    if out is None:
+        out = torch.empty((N, Cout, OA, OB), device=x.device, dtype=torch.float32)
+    key = _key("cf", x.shape, x.stride(), w.shape, stride, padding, dilation, out.stride())
+    dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
+        tuple(x.shape), x.stride(), tuple(w.shape), stride, padding, dilation, out.stride()))
+    wc = w.contiguous()
+    gemm_fwd(dp, pack_a(dp, wc), x, out, bias=bias, act=act, act_param=act_param)
+    return out
+
+
+def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None):
+    if dx is None:
+        dx = torch.empty_strided(xshape, xstrides, device=g.device, dtype=torch.float32)
+    key = _key("cd", xshape, xstrides, w.shape, stride, padding, dilation, g.shape, g.stride())
+    dps = _plans(key, g.device, lambda: convplan.conv_dgrad_plans(
+        tuple(xshape), tuple(xstrides), tuple(w.shape), stride, padding, dilation, tuple(g.shape), g.stride()))
+    wc = w.contiguous()
+    for dp in dps:
+        gemm_fwd(dp, pack_a(dp, wc), g, dx)
+    return dx
+
+
+def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias):
+    key = _key("cw", x.shape, x.stride(), wshape, stride, padding, dilation, g.stride(), need_bias)
+    dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
+        tuple(x.shape), x.stride(), tuple(wshape), stride, padding, dilation, g.stride(), bias_row=need_bias))
+    p = dp.p
+    dapack = torch.zeros((p.Kpad, p.Mpad), device=x.device, dtype=torch.float32)
+    gemm_wgrad(dp, x, g, dapack)
+    dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
+    unpack_add(dp, dapack, dw)
+    db = dapack[p.K - 1, :p.M].clone() if need_bias else None
+    return dw, db
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d / nn.Conv1d (A == 1) forward + backward on the gather-GEMM kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, dilation):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, dilation, bias is not None)
+        return conv2d_forward(x, w, bias, stride, padding, dilation)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, has_bias = ctx.cfg
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(g, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
+    return Conv2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation))
+
+
+def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1):
+    y = Conv2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation))
+    return y.squeeze(2)
+
+
+# ---- transposed convolution -----------------------------------------------------------
+def convT2d_forward(x, w, bias, stride, dilation, crop_lo, out_len, act=None):
+    _req(x, "x"); _req(w, "weight")
+    N, Cin, IA, IB = x.shape
+    _, Cout, KA, KB = w.shape
+    out = torch.empty((N, Cout, out_len[0], out_len[1]), device=x.device, dtype=torch.float32)
+    key = _key("tf", x.shape, x.stride(), w.shape, stride, dilation, crop_lo, out_len, out.stride())
+    dps = _plans(key, x.device, lambda: convplan.convT_fwd_plans(
+        tuple(x.shape), x.stride(), tuple(w.shape), stride, dilation, crop_lo, out_len, out.stride()))
+    wc = w.contiguous()
+    for dp in dps:
+        gemm_fwd(dp, pack_a(dp, wc), x, out, bias=bias, act=act)
+    return out
+
+
+class ConvT2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d / 1d followed by the crop [lo : lo+len] on each axis."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, dilation, crop_lo, out_len):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, dilation, crop_lo, out_len, bias is not None)
+        return convT2d_forward(x, w, bias, stride, dilation, crop_lo, out_len)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, dilation, crop_lo, out_len, has_bias = ctx.cfg
+        g = g if g.is_contiguous() else g.contiguous()
+        key = _key("td", x.shape, x.stride(), w.shape, stride, dilation, crop_lo, g.shape, g.stride())
+        dx = dw = db = None
+        need_w = ctx.needs_input_grad[1]
+        if ctx.needs_input_grad[0] or need_w:
+            xs = tuple(x.stride())
+            dp = _plans(key, x.device, lambda: convplan.convT_dgrad_plan(
+                tuple(x.shape), xs, tuple(w.shape), stride, dilation, crop_lo, tuple(g.shape), g.stride()))
+            wc = w.contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_strided(tuple(x.shape), xs, device=x.device, dtype=torch.float32)
+                gemm_fwd(dp, pack_a(dp, wc), g, dx)
+            if need_w:
+                p = dp.p
+                dapack = torch.zeros((p.Kpad, p.Mpad), device=x.device, dtype=torch.float32)
+                gemm_wgrad(dp, g, x, dapack)
+                dw = torch.zeros_like(wc)
+                unpack_add(dp, dapack, dw)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = channel_sum(g)
+        return dx, dw, db, None, None, None, None
+
+
+def conv_transpose2d(x, w, bias=None, stride=(1, 1), dilation=(1, 1), crop_lo=(0, 0), out_len=None):
+    if out_len is None:
+        out_len = tuple(convplan.convT_out_len(x.shape[2 + i], w.shape[2 + i], stride[i], dilation[i]) - crop_lo[i]
+                        for i in range(2))
+    return ConvT2dFn.apply(x, w, bias, tuple(stride), tuple(dilation), tuple(crop_lo), tuple(out_len))
+
+
+def conv_transpose1d(x, w, bias=None, stride=1, dilation=1, crop_lo=0, out_len=None):
+    if out_len is None:
+        out_len = convplan.convT_out_len(x.shape[-1], w.shape[-1], stride, dilation) - crop_lo
+    y = ConvT2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (1, dilation), (0, crop_lo),
+                        (1, out_len))
+    return y.squeeze(2)
+
+
+# ---- small reductions / elementwise ----------------------------------------------------
+def channel_sum(g):
+    """sum over (N, A, B) of a (N, C, A, B) tensor -> (C,)"""
+    g4 = g if g.dim() == 4 else g.unsqueeze(2)
+    out = torch.zeros(g4.shape[1], device=g.device, dtype=torch.float32)
+    N, Cc, A, B = g4.shape
+    s = g4.stride()
+    check(_lib.lib().rfx_channel_sum(_ptr(g4), N, Cc, A, B, s[0], s[1], s[2], s[3], _ptr(out), _stream()),
+          "rfx_channel_sum")
+    return out
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        _req(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(_lib.lib().rfx_act_fwd(_ptr(x), _ptr(y), x.numel(), ACT[act], _stream()), "rfx_act_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        check(_lib.lib().rfx_act_bwd(_ptr(x), _ptr(gy), _ptr(gx), x.numel(), ACT[ctx.act], _stream()),
+              "rfx_act_bwd")
+        return gx, None
+
+
+def activation(x, act):
+    return ActFn.apply(x, act)

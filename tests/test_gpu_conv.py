@@ -1,0 +1,159 @@
+"""GPU parity: gather-GEMM conv kernels (through the C ABI) vs torch fp32 CPU ops
+and vs the TCN golden vectors recorded from the imported reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _rms(a, b):
+    return float(((a - b) ** 2).mean().sqrt())
+
+
+CASES = [
+    # Cin, Cout, (IA, IB), (KA, KB), stride, padding, dilation, N
+    (3, 5, (1, 500), (1, 7), (1, 1), (0, 0), (1, 4), 2),
+    (16, 48, (1, 3000), (1, 7), (1, 1), (0, 0), (1, 16), 2),
+    (64, 256, (1, 2100), (1, 7), (1, 1), (0, 0), (1, 2), 1),     # R=4, 2 M tiles
+    (2, 48, (64, 40), (8, 1), (4, 1), (2, 0), (1, 1), 2),        # HDemucs freq enc 0
+    (48, 96, (32, 40), (8, 1), (4, 1), (2, 0), (1, 1), 2),       # R=3
+    (1, 48, (1, 4096), (1, 8), (1, 4), (0, 2), (1, 1), 2),       # HDemucs time enc 0
+    (24, 33, (17, 23), (3, 3), (1, 1), (1, 1), (1, 1), 2),       # 3x3
+    (8, 45, (40, 30), (7, 5), (2, 2), (3, 2), (1, 1), 2),        # DCUNet R=2
+    (12, 7, (9, 18), (5, 3), (2, 1), (2, 1), (1, 1), 2),         # thin M<=8
+    (40, 2, (1, 700), (1, 1), (1, 1), (0, 0), (1, 1), 3),        # thin 1x1
+    (96, 192, (8, 64), (1, 1), (1, 1), (0, 0), (1, 1), 2),       # 1x1 rewrite
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d_fwd_bwd(case):
+    from remfx_amd import ops
+    dev = _dev()
+    Cin, Cout, (IA, IB), (KA, KB), stride, padding, dilation, N = case
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, Cin, IA, IB, generator=g)
+    w = torch.randn(Cout, Cin, KA, KB, generator=g) / (Cin * KA * KB) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y = F.conv2d(xr, wr, br, stride, padding, dilation)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    yd = ops.conv2d(xd, wd, bd, stride, padding, dilation)
+    assert yd.shape == y.shape
+    yd.backward(gy.to(dev))
+    assert _rms(yd.detach().cpu(), y.detach()) < 1e-5 * max(1.0, float(y.detach().abs().max()))
+    for got, ref, name in ((xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw"), (bd.grad, br.grad, "db")):
+        scale = max(1.0, float(ref.abs().max()))
+        assert _rms(got.cpu(), ref) < 2e-5 * scale, (name, _rms(got.cpu(), ref), scale)
+
+
+TCASES = [
+    # Cin, Cout, (IA, IB), (KA, KB), stride, crop_lo, crop_hi, N
+    (48, 24, (16, 40), (8, 1), (4, 1), (2, 0), (2, 0), 2),
+    (48, 1, (1, 300), (1, 8), (1, 4), (0, 2), (0, 5), 2),       # thin output
+    (64, 48, (1, 257), (1, 4), (1, 2), (0, 1), (0, 1), 2),
+    (20, 45, (9, 17), (5, 3), (2, 1), (2, 1), (2, 1), 2),
+    (12, 9, (6, 7), (7, 5), (2, 2), (3, 2), (3, 2), 2),
+    (40, 33, (1, 50), (8, 1), (4, 1), (0, 0), (0, 0), 2),
+]
+
+
+@pytest.mark.parametrize("case", TCASES)
+def test_convT_fwd_bwd(case):
+    from remfx_amd import ops
+    dev = _dev()
+    Cin, Cout, (IA, IB), (KA, KB), stride, lo, hi, N = case
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Cin, IA, IB, generator=g)
+    w = torch.randn(Cin, Cout, KA, KB, generator=g) / (Cin * KA * KB) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    full = F.conv_transpose2d(xr, wr, br, stride)
+    LA, LB = full.shape[2] - lo[0] - hi[0], full.shape[3] - lo[1] - hi[1]
+    y = full[:, :, lo[0]:lo[0] + LA, lo[1]:lo[1] + LB]
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    yd = ops.conv_transpose2d(xd, wd, bd, stride, (1, 1), lo, (LA, LB))
+    yd.backward(gy.to(dev))
+    assert _rms(yd.detach().cpu(), y.detach()) < 1e-5 * max(1.0, float(y.detach().abs().max()))
+    for got, ref, name in ((xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw"), (bd.grad, br.grad, "db")):
+        scale = max(1.0, float(ref.abs().max()))
+        assert _rms(got.cpu(), ref) < 2e-5 * scale, (name, _rms(got.cpu(), ref), scale)
+
+
+def test_strided_input_view():
+    """DConv on the HDemucs freq branch: (1,3) dilated conv directly on (B, C, Fr, T)."""
+    from remfx_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 48, 16, 64, generator=g)
+    w = torch.randn(12, 48, 1, 3, generator=g) * 0.1
+    ref = F.conv2d(x, w, None, 1, (0, 2), (1, 2))
+    got = ops.conv2d(x.to(dev), w.to(dev), None, (1, 1), (0, 2), (1, 2))
+    assert _rms(got.cpu(), ref) < 1e-5
+    xt = x.permute(0, 1, 3, 2)              # non-contiguous view as input
+    ref2 = F.conv2d(xt, w.permute(0, 1, 3, 2), None, 1, (2, 0), (2, 1))
+    got2 = ops.conv2d(x.to(dev).permute(0, 1, 3, 2), w.to(dev).permute(0, 1, 3, 2).contiguous(), None,
+                      (1, 1), (2, 0), (2, 1))
+    assert _rms(got2.cpu(), ref2) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["tcn_small", "tcn_mid", "tcn_causal"])
+def test_tcn_golden(golden_dir, name):
+    """HIP TCN vs outputs of the imported reference remfx.tcn.TCN (tests/golden)."""
+    from oracle import ref_tcn
+    from remfx_amd.tcn import TCN
+    dev = _dev()
+    gd = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = {k[4:]: gd[k].item() for k in gd.files if k.startswith("cfg_")}
+    sd = ref_tcn.tcn_init_state_dict(cfg["ninputs"], cfg["noutputs"], cfg["nblocks"], cfg["channel_width"],
+                                     cfg["kernel_size"], seed=int(gd["seed"]))
+    for k in [k for k in sd if k.endswith("relu.weight")]:
+        sd[k] = torch.linspace(0.05, 0.45, sd[k].numel())
+    net = TCN(**{k: (bool(v) if k == "causal" else v) for k, v in cfg.items()})
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    with torch.no_grad():
+        y = net(torch.from_numpy(gd["x"]).to(dev)).cpu().numpy()
+    assert y.shape == gd["y"].shape
+    assert float(np.sqrt(((y - gd["y"]) ** 2).mean())) < 1e-5
+
+
+def test_tcn_backward_vs_oracle():
+    """fwd + all gradients of a reduced TCN vs autograd over the CPU oracle."""
+    from oracle import ref_tcn
+    from remfx_amd.tcn import TCN
+    dev = _dev()
+    cfg = dict(ninputs=1, noutputs=1, nblocks=5, channel_width=40, kernel_size=7, stack_size=3,
+               dilation_growth=2, causal=False)
+    sd = ref_tcn.tcn_init_state_dict(1, 1, 5, 40, 7, seed=11)
+    for k in [k for k in sd if k.endswith("relu.weight")]:
+        sd[k] = torch.linspace(0.05, 0.45, sd[k].numel())
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 3000, generator=g)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y = ref_tcn.tcn_forward(x, sdr, 5, 3, 2, False)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    net = TCN(**cfg)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    yd = net(x.to(dev))
+    yd.backward(gy.to(dev))
+    assert _rms(yd.detach().cpu(), y.detach()) < 1e-5
+    for k, p in net.named_parameters():
+        ref = sdr[k].grad
+        scale = max(1e-3, float(ref.abs().max()))
+        assert _rms(p.grad.cpu(), ref) < 1e-4 * scale, (k, _rms(p.grad.cpu(), ref), scale)
