@@ -86,7 +86,10 @@ typedef struct rfx_epilogue {
   float* gparam;
 } rfx_epilogue;
 
-/* A[k][m] = w[m*w_ms + woff[k]]  (k < K), zero padded to [Kpad][Mpad]. */
+/* A[k][m] = w[m*w_ms + woff[k]]  (k < K), zero padded to [Kpad + 16][Mpad]: the packed
+ * matrix carries one extra all-zero K step and every ktab passed to rfx_gemm_fwd
+ * carries Kpad + 32 rows (the tail rows invalid: da = -2^30) so that the MFMA kernel's
+ * operand prefetch is branch-free. */
 int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
                int32_t Mpad, int32_t Kpad, float* apack, void* stream);
 /* w[m*w_ms + woff[k]] += dapack[k][m]   (inverse of rfx_pack_a, accumulating). */

@@ -114,6 +114,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime instance that is
+    # resident before our library is dlopen()ed, otherwise two runtimes coexist and
+    # launches on torch's streams fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     if not os.path.exists(LIBPATH):
         raise RuntimeError(
             f"{LIBPATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "

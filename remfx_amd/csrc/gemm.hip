@@ -34,7 +34,7 @@ struct FwdArgs {
 __global__ void pack_a_kernel(const float* __restrict__ w, const int32_t* __restrict__ woff,
                               int64_t w_ms, int M, int K, int Mpad, int Kpad,
                               float* __restrict__ apack) {
-  const int64_t total = (int64_t)Kpad * Mpad;
+  const int64_t total = (int64_t)(Kpad + 16) * Mpad;   // one extra all-zero K step (branch-free prefetch)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(i / Mpad), m = (int)(i % Mpad);
@@ -66,20 +66,27 @@ struct LaneCtx {
   bool jvalid;
 };
 
-__device__ __forceinline__ void load_b8(const rfx_gemm_desc& d, const rfx_ktab_entry* __restrict__ ktab,
-                                        int kbase, int h, const LaneCtx& c, float (&b)[8]) {
+// A zero the invalid lanes can load instead of masking the loaded value: any VALU op
+// on the result forces s_waitcnt vmcnt(0) right after the load and exposes the full
+// memory latency every K step (measured: 47 -> see profiles/ after the change).
+__device__ float rfx_zero_f32[4] = {0.f, 0.f, 0.f, 0.f};
+
+// ktl: the 16 tap entries of this K step, staged in LDS (scalar loads of the table
+// serialise on lgkmcnt(0) per entry; LDS broadcast reads do not).
+__device__ __forceinline__ void load_b8(const rfx_gemm_desc& d, const int4* ktl, int h, const LaneCtx& c,
+                                        float (&b)[8]) {
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const rfx_ktab_entry e0 = ktab[kbase + 2 * kk];      // wave-uniform -> scalar loads
-    const rfx_ktab_entry e1 = ktab[kbase + 2 * kk + 1];
-    const int off = h ? e1.off : e0.off;
-    const int da = h ? e1.da : e0.da;
-    const int db = h ? e1.db : e0.db;
-    const bool ok = c.jvalid && (unsigned)(c.ia0 + da) < (unsigned)d.IA &&
-                    (unsigned)(c.ib0 + db) < (unsigned)d.IB;
-    const float* p = ok ? (c.inb + off) : c.safe;
-    const float v = *p;
-    b[kk] = ok ? v : 0.f;
+  for (int half = 0; half < 2; ++half) {
+    int4 e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = ktl[2 * (half * 4 + q) + h];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = c.jvalid & ((unsigned)(c.ia0 + e[q].y) < (unsigned)d.IA) &
+                      ((unsigned)(c.ib0 + e[q].z) < (unsigned)d.IB);
+      const float* p = ok ? (c.inb + e[q].x) : c.safe;
+      b[half * 4 + q] = *p;
+    }
   }
 }
 
@@ -90,8 +97,9 @@ __device__ __forceinline__ void stage_a_load(const float* __restrict__ apack, in
   constexpr int NV = 16 * BM / 4;  // float4 per tile
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int idx = tid + i * 256;
-    if (idx < NV) {
+    if (i * 256 < NV) {            // compile-time
+      int idx = tid + i * 256;
+      idx = idx < NV ? idx : NV - 1;   // branch-free: surplus threads re-read the last vector
       const int kk = idx / (BM / 4), c4 = idx % (BM / 4);
       r[i] = *reinterpret_cast<const f32x4*>(apack + (int64_t)(k0 + kk) * Mpad + m0 + 4 * c4);
     }
@@ -104,59 +112,81 @@ __device__ __forceinline__ void stage_a_store(float* as, int tid, const f32x4 (&
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + i * 256;
-    if (idx < NV) {
+    if (i * 256 < NV && idx < NV) {
       const int kk = idx / (BM / 4), c4 = idx % (BM / 4);
       *reinterpret_cast<f32x4*>(as + kk * BM + 4 * c4) = r[i];
     }
   }
 }
 
+// One 16-deep K step: issue next step's operands (A -> regs, B gathers -> bn), run the
+// 8*R MFMAs of this step on (LDS A[cur], bc), publish A[cur^1] / table rows, barrier.
+// The body is BRANCH-FREE: the packed A matrix carries one extra all-zero K step and
+// the tap table two extra all-invalid steps, so the prefetch of step ks+1 / ks+2 is
+// unconditional.  (With `if (more)` around the loads hipcc's waitcnt pass merges the
+// two paths and drains vmcnt to 0 in front of the MFMAs: every gather's latency exposed.)
+// bc/bn ping-pong between two register sets, so the only vmcnt wait is the counted one
+// in front of the NEXT step's MFMAs.
+template <int R>
+__device__ __forceinline__ void k_step(const rfx_gemm_desc& d, const float* __restrict__ apack,
+                                       const int4* __restrict__ kt4, int ks, int m0,
+                                       const LaneCtx& c, float* as, int4* kts, f32x16 (&acc)[R],
+                                       const float (&bc)[8], float (&bn)[8]) {
+  constexpr int BM = 32 * R;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int cur = ks & 1;
+  const float* a_lds = as + cur * 16 * BM;
+  float afrag[8][R];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt) afrag[kk][mt] = a_lds[(2 * kk + h) * BM + mt * 32 + l31];
+  f32x4 areg[2];
+  stage_a_load<R>(apack, d.Mpad, (ks + 1) * 16, m0, tid, areg);
+  load_b8(d, kts + ((ks + 1) % 3) * 16, h, c, bn);
+  const int4 ktreg = kt4[(ks + 2) * 16 + (tid & 15)];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[kk][mt], bc[kk], acc[mt], 0, 0, 0);
+  }
+  stage_a_store<R>(as + (cur ^ 1) * 16 * BM, tid, areg);
+  if (tid < 16) kts[((ks + 2) % 3) * 16 + tid] = ktreg;
+  __syncthreads();
+}
+
 template <int R>
 __device__ __forceinline__ void run_phase(const rfx_gemm_desc& d, const float* __restrict__ apack,
                                           const rfx_ktab_entry* __restrict__ ktab, int Kpad, int m0,
                                           const LaneCtx& c, float* as /* [2][16][BM] */,
-                                          f32x16 (&acc)[R]) {
-  constexpr int BM = 32 * R;
+                                          int4* kts /* [3][16] */, f32x16 (&acc)[R]) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int h = (tid & 63) >> 5;
   const int nk = Kpad / 16;
   if (nk == 0) return;
-  float bcur[8], bnext[8];
+  const int4* kt4 = reinterpret_cast<const int4*>(ktab);
+  float b0[8], b1[8];
   f32x4 areg[2];
   stage_a_load<R>(apack, d.Mpad, 0, m0, tid, areg);
-  load_b8(d, ktab, 0, h, c, bcur);
+  if (tid < 32) kts[tid] = kt4[tid];     // table rows of K steps 0 and 1 (table is padded)
   stage_a_store<R>(as, tid, areg);
   __syncthreads();
-  int cur = 0;
-  for (int ks = 0; ks < nk; ++ks) {
-    const bool more = ks + 1 < nk;
-    if (more) {
-      stage_a_load<R>(apack, d.Mpad, (ks + 1) * 16, m0, tid, areg);
-      load_b8(d, ktab, (ks + 1) * 16, h, c, bnext);
-    }
-    const float* a_lds = as + cur * 16 * BM;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-#pragma unroll
-      for (int mt = 0; mt < R; ++mt) {
-        const float a = a_lds[(2 * kk + h) * BM + mt * 32 + l31];
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcur[kk], acc[mt], 0, 0, 0);
-      }
-    }
-    if (more) {
-      stage_a_store<R>(as + (cur ^ 1) * 16 * BM, tid, areg);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) bcur[kk] = bnext[kk];
-    }
-    __syncthreads();
-    cur ^= 1;
+  load_b8(d, kts, h, c, b0);
+  int ks = 0;
+  for (; ks + 1 < nk; ks += 2) {
+    k_step<R>(d, apack, kt4, ks, m0, c, as, kts, acc, b0, b1);
+    k_step<R>(d, apack, kt4, ks + 1, m0, c, as, kts, acc, b1, b0);
   }
+  if (ks < nk) k_step<R>(d, apack, kt4, ks, m0, c, as, kts, acc, b0, b1);
 }
 
 template <int R>
 __global__ __launch_bounds__(256) void gemm_fwd_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R;
   __shared__ __attribute__((aligned(16))) float as[2 * 16 * BM];
+  __shared__ __attribute__((aligned(16))) int4 kts[3 * 16];
   const rfx_gemm_desc& d = g.d;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -170,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(const FwdArgs g) {
   const int a = jj / d.OB, b = jj - a * d.OB;
   c.ia0 = a * d.SA;
   c.ib0 = b * d.SB;
-  c.safe = g.in;
+  c.safe = rfx_zero_f32;
   c.inb = g.in + (int64_t)n * d.in_ns + (int64_t)c.ia0 * d.in_as + (int64_t)c.ib0 * d.in_bs;
 
   f32x16 acc[R];
@@ -179,7 +209,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(const FwdArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  run_phase<R>(d, g.apack, g.ktab, d.Kpad, m0, c, as, acc);
+  run_phase<R>(d, g.apack, g.ktab, d.Kpad, m0, c, as, kts, acc);
 
   const rfx_epilogue& e = g.e;
   const bool two = g.apack2 != nullptr;
@@ -203,10 +233,9 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(const FwdArgs g) {
   if (two) {
     LaneCtx c2 = c;
     if (g.in2) {
-      c2.safe = g.in2;
       c2.inb = g.in2 + (c.inb - g.in);
     }
-    run_phase<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, acc);
+    run_phase<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
   }
 
   const int64_t opos = (int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
@@ -259,6 +288,29 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(const FwdArgs g) {
 // last HDemucs decoders).  HBM-bound: one thread per position, K loop with
 // wave-uniform weights, coalesced gathers.
 template <int MM>
+__device__ __forceinline__ void thin_phase(const rfx_gemm_desc& d, const rfx_ktab_entry* __restrict__ kt,
+                                           const float* __restrict__ ap, int K, const float* inb,
+                                           const float* safe, bool jvalid, int ia0, int ib0,
+                                           float (&acc)[MM]) {
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    float bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const rfx_ktab_entry e = kt[k0 + u];  // Kpad is a multiple of 16: always readable
+      const bool ok = jvalid && (unsigned)(ia0 + e.da) < (unsigned)d.IA &&
+                      (unsigned)(ib0 + e.db) < (unsigned)d.IB;
+      const float* p = ok ? inb + e.off : safe;
+      const float v = *p;
+      bv[u] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int m = 0; m < MM; ++m) acc[m] = fmaf(ap[(int64_t)(k0 + u) * d.Mpad + m], bv[u], acc[m]);
+  }
+}
+
+template <int MM>
 __global__ __launch_bounds__(256) void gemm_thin_fwd_kernel(const FwdArgs g) {
   const rfx_gemm_desc& d = g.d;
   const int P = d.OA * d.OB;
@@ -268,43 +320,46 @@ __global__ __launch_bounds__(256) void gemm_thin_fwd_kernel(const FwdArgs g) {
   const int jj = jvalid ? j : 0;
   const int a = jj / d.OB, b = jj - a * d.OB;
   const int ia0 = a * d.SA, ib0 = b * d.SB;
-  const float* inb = g.in + (int64_t)n * d.in_ns + (int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs;
+  const int64_t ioff = (int64_t)n * d.in_ns + (int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs;
   float acc[MM];
 #pragma unroll
   for (int m = 0; m < MM; ++m) acc[m] = 0.f;
-  const rfx_ktab_entry* __restrict__ kt = g.ktab;
-  const float* __restrict__ ap = g.apack;
-  for (int k0 = 0; k0 < d.K; k0 += 4) {
-    float bv[4];
+  thin_phase<MM>(d, g.ktab, g.apack, d.K, g.in + ioff, g.in, jvalid, ia0, ib0, acc);
+  const rfx_epilogue& e = g.e;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const rfx_ktab_entry e = kt[k0 + u];  // Kpad is a multiple of 16: always readable
-      const bool ok = jvalid && (unsigned)(ia0 + e.da) < (unsigned)d.IA &&
-                      (unsigned)(ib0 + e.db) < (unsigned)d.IB;
-      const float* p = ok ? inb + e.off : g.in;
-      const float v = *p;
-      bv[u] = ok ? v : 0.f;
+  for (int m = 0; m < MM; ++m) {
+    if (m < d.M) {
+      float v = acc[m];
+      if (e.bias) v += e.bias[m];
+      if (e.act != RFX_ACT_NONE && !e.bwd)
+        v = rfx_act_apply(v, e.act, e.act == RFX_ACT_PRELU ? e.act_param[m] : 0.f);
+      acc[m] = v;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int m = 0; m < MM; ++m) acc[m] = fmaf(ap[(int64_t)(k0 + u) * d.Mpad + m], bv[u], acc[m]);
+  }
+  if (g.apack2) {
+    const float* in2 = g.in2 ? g.in2 : g.in;
+    thin_phase<MM>(d, g.ktab2, g.apack2, g.Kpad2, in2 + ioff, in2, jvalid, ia0, ib0, acc);
   }
   if (!jvalid) return;
-  const rfx_epilogue& e = g.e;
   const int64_t opos = (int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
   float* outp = g.out + (int64_t)n * d.out_ns + opos;
 #pragma unroll
   for (int m = 0; m < MM; ++m) {
     if (m < d.M) {
       float v = acc[m];
-      if (e.bias) v += e.bias[m];
-      if (e.act != RFX_ACT_NONE) v = rfx_act_apply(v, e.act, e.act == RFX_ACT_PRELU ? e.act_param[m] : 0.f);
+      float r = 0.f;
       if (e.res)
-        v += e.res[(int64_t)n * e.res_ns + (int64_t)m * e.res_cs +
-                   (int64_t)(a * d.out_sa + d.out_a0) * e.res_as + (int64_t)(b * d.out_sb + d.out_b0) * e.res_bs];
-      if (e.act2 != RFX_ACT_NONE) v = rfx_act_apply(v, e.act2, 0.f);
-      outp[(int64_t)m * d.out_cs] = v;
+        r = e.res[(int64_t)n * e.res_ns + (int64_t)m * e.res_cs +
+                  (int64_t)(a * d.out_sa + d.out_a0) * e.res_as + (int64_t)(b * d.out_sb + d.out_b0) * e.res_bs];
+      if (e.bwd) {
+        const float s = (e.act == RFX_ACT_PRELU) ? e.act_param[m] : 0.f;
+        outp[(int64_t)m * d.out_cs] = r * rfx_act_grad(v, e.act, s);
+        if (e.gparam && v < 0.f) atomicAdd(e.gparam + m, r * v);
+      } else {
+        v += r;
+        if (e.act2 != RFX_ACT_NONE) v = rfx_act_apply(v, e.act2, 0.f);
+        outp[(int64_t)m * d.out_cs] = v;
+      }
     }
   }
 }
@@ -475,7 +530,7 @@ extern "C" int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 extern "C" int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
                           int32_t Mpad, int32_t Kpad, float* apack, void* stream) {
   if (!w || !woff || !apack || M <= 0 || K < 0 || Mpad < M || Kpad < K) return -1;
-  const int64_t total = (int64_t)Kpad * Mpad;
+  const int64_t total = (int64_t)(Kpad + 16) * Mpad;
   if (total == 0) return 0;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_a_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, woff, w_ms, M, K,
@@ -523,12 +578,12 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   g.apack = apack; g.ktab = ktab; g.in = in; g.out = out;
   if (epi) g.e = *epi;
   else { g.e = rfx_epilogue{}; }
+  if (g.e.bwd && !g.e.res) return -1;
   g.apack2 = apack2; g.ktab2 = ktab2; g.Kpad2 = apack2 ? Kpad2 : 0; g.in2 = in2;
   const int P = d->OA * d->OB;
   const int r = pick_r(d->M);
   hipStream_t s = (hipStream_t)stream;
   if (r == 0) {
-    if (apack2 || g.e.bwd) return -1;
     dim3 grid((P + 255) / 256, d->N);
     if (d->M <= 1) hipLaunchKernelGGL(gemm_thin_fwd_kernel<1>, grid, dim3(256), 0, s, g);
     else if (d->M <= 2) hipLaunchKernelGGL(gemm_thin_fwd_kernel<2>, grid, dim3(256), 0, s, g);

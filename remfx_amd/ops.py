@@ -61,9 +61,9 @@ def _plans(key, device, builder):
 def pack_a(dp, w):
     """Gather the weight tensor into the packed [Kpad][Mpad] A matrix of a plan."""
     p = dp.p
-    apack = torch.empty((max(p.Kpad, 1), p.Mpad), device=w.device, dtype=torch.float32)
+    apack = torch.empty((p.Kpad + 16, p.Mpad), device=w.device, dtype=torch.float32)
     nrows = p.extra["n_weight_rows"]
-    if p.Kpad:
+    if True:
         check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff), p.w_ms, p.M, nrows, p.Mpad, p.Kpad,
                                     _ptr(apack), _stream()), "rfx_pack_a")
     return apack
