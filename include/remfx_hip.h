@@ -114,35 +114,44 @@ int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rfx_ktab_entr
 int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const float* in,
                    const float* g, float* dapack, void* stream);
 
-/* ---- framed FFT front end ---------------------------------------------------
- * STFT as torch.stft(center=True, pad_mode="reflect", onesided) computes it:
- * utils.py:148-154 (spectrogram), HDemucs _spec, auraloss STFTLoss, Separator,
- * MelSpectrogram.  x: [R][T]; frame f covers x_padded[f*hop : f*hop+n_fft] with
- * reflect padding n_fft/2 and a hann window of `win` samples centred in n_fft.
+/* ---- framed FFT front / back end ---------------------------------------------
+ * rfx_fft_analysis : frames -> window -> real FFT -> epilogue.  As STFT it reproduces
+ *   torch.stft(center=True, pad_mode="reflect", onesided) : utils.py:148-154
+ *   (spectrogram), HDemucs _spec, auraloss STFTLoss, Separator, MelSpectrogram.
+ *   With in_mode=1 / herm=1 it is the backward of the iSTFT.
+ * rfx_fft_synthesis: spectrum -> inverse real FFT -> window -> overlap-add (fp32
+ *   atomics into a zero-initialised output).  With herm=1 / in_mode=1 it is
+ *   torch.istft (HDemucs _ispec, Separator); with herm=0 / in_mode=0 it is the
+ *   backward (adjoint) of the STFT.
+ * x: [R][T]; frame f covers padded samples [f*hop, f*hop + n_fft); the hann window
+ * of `win` samples is centred in n_fft.  n_fft in {512, 1024, 2048, 4096}.
  */
 enum rfx_stft_out {
-  RFX_STFT_COMPLEX = 0, /* out[R][bins][frames][2] (torch view_as_real layout) */
-  RFX_STFT_CAC = 1,     /* out[R][2][bins][frames]: real plane, imag plane (HDemucs _magnitude) */
-  RFX_STFT_MAG = 2,     /* out[R][bins][frames] = sqrt(max(re^2+im^2, eps)) (auraloss) */
-  RFX_STFT_POW = 3,     /* out[R][bins][frames] = re^2+im^2 (MelSpectrogram power=2) */
-  RFX_STFT_MAGPOW = 4   /* out = (sqrt(re^2+im^2) + eps) ^ alpha (utils.py:159) */
+  RFX_STFT_COMPLEX = 0, /* [R][bins][frames_out][2] (torch view_as_real layout) */
+  RFX_STFT_CAC = 1,     /* [R][2][bins][frames_out]: real plane, imag plane (HDemucs _magnitude) */
+  RFX_STFT_MAG = 2,     /* [R][bins][frames_out] = sqrt(max(re^2+im^2, eps)) (auraloss) */
+  RFX_STFT_POW = 3,     /* re^2+im^2 (MelSpectrogram power=2) */
+  RFX_STFT_MAGPOW = 4   /* (sqrt(re^2+im^2) + eps) ^ alpha (utils.py:159) */
 };
 typedef struct rfx_stft_desc {
-  int32_t R, T;           /* rows (batch*channels), samples per row */
+  int32_t R, T;           /* rows (batch*channels), samples per row of the time signal */
   int32_t n_fft, hop, win;
-  int32_t frames;         /* 1 + T / hop */
-  int32_t bins;           /* bins written: n_fft/2+1, or n_fft/2 to drop Nyquist (HDemucs) */
-  int32_t frame0;         /* first frame written (HDemucs keeps [2 : 2+le]) */
-  int32_t frames_out;     /* number of frames written */
-  int32_t mode;           /* enum rfx_stft_out */
-  int32_t extra_pad_l, extra_pad_r; /* additional reflect padding applied first (HDemucs _spec) */
-  float scale;            /* 1/sqrt(n_fft) for normalized=True, else 1 */
+  int32_t bins;           /* bins stored: n_fft/2+1, or n_fft/2 to drop Nyquist (HDemucs) */
+  int32_t frame0;         /* first frame stored (HDemucs keeps [2 : 2+le]) */
+  int32_t frames_out;     /* number of frames stored */
+  int32_t mode;           /* enum rfx_stft_out (synthesis: COMPLEX or CAC = spectrum layout) */
+  int32_t extra_pad_l, extra_pad_r; /* in_mode 0: extra reflect padding applied first (HDemucs _spec) */
+  int32_t in_mode;        /* 0: sample = reflect(p - n_fft/2); 1: sample = p - in_offset, zero outside */
+  int32_t in_offset;
+  int32_t herm;           /* 1: irfft semantics (istft fwd / bwd); 0: plain one-sided rfft adjoint */
+  float scale;            /* multiplies every windowed sample */
   float eps, alpha;
 } rfx_stft_desc;
 
-int rfx_stft_fwd(const rfx_stft_desc* d, const float* x, const float* window, float* out, void* stream);
-/* gx[R][T] = adjoint of rfx_stft_fwd in RFX_STFT_COMPLEX / RFX_STFT_CAC mode applied to gout. */
-int rfx_stft_bwd(const rfx_stft_desc* d, const float* gout, const float* window, float* gx, void* stream);
+int rfx_fft_analysis(const rfx_stft_desc* d, const float* x, const float* window, const float* mul,
+                     float* out, void* stream);
+int rfx_fft_synthesis(const rfx_stft_desc* d, const float* spec, const float* window, const float* mul,
+                      float* out, void* stream);
 
 /* ---- elementwise / reductions ------------------------------------------------ */
 /* y = act(x) elementwise over n contiguous floats; PReLU/bias not supported here. */
@@ -159,6 +168,21 @@ int rfx_channel_sum(const float* x, int32_t N, int32_t C, int32_t A, int32_t B, 
 
 /* sum |a-b| over n elements -> *out (+=, caller zeroes).  nn.L1Loss numerator, models.py:320 */
 int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream);
+
+/* ---- losses -------------------------------------------------------------------
+ * auraloss STFTLoss terms on complex spectra [R][n] (n = bins*frames, view_as_real layout):
+ * sums[r] += { sum (|Y|-|X|)^2, sum |Y|^2, sum |log|X| - log|Y|| }, |.| = sqrt(max(re^2+im^2, eps)).
+ * Replaces auraloss.freq.STFTLoss.forward (models.py:299,320,362,385,107; metrics 237-255). */
+int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R, int64_t n, float eps, float* sums,
+                         void* stream);
+/* gxc = w_sc * d[sqrt(A_r)/sqrt(B_r)]/dxc + w_lm * d[sum |log|X|-log|Y||]/dxc  (A_r, B_r from sums) */
+int rfx_stft_loss_grad(const float* xc, const float* yc, int32_t R, int64_t n, float eps,
+                       const float* sums, float w_sc, float w_lm, float* gxc, void* stream);
+/* g[i] = w * sign(a[i] - b[i])   (nn.L1Loss backward) */
+int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, float* g, void* stream);
+/* per row: sums[r] += { sum x, sum t, sum x t, sum x^2, sum t^2 } in fp64 (auraloss SISDRLoss) */
+int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t L, int64_t x_rs, int64_t t_rs,
+                   double* sums, void* stream);
 
 int rfx_abi_version(void);
 /* channel tiles per wave the MFMA forward kernel will use for M output rows (0 = thin path);

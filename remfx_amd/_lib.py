@@ -84,8 +84,9 @@ class Epilogue(C.Structure):
 
 
 class StftDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("R", "T", "n_fft", "hop", "win", "frames", "bins", "frame0",
-                                         "frames_out", "mode", "extra_pad_l", "extra_pad_r")] + \
+    _fields_ = [(n, C.c_int32) for n in ("R", "T", "n_fft", "hop", "win", "bins", "frame0", "frames_out",
+                                         "mode", "extra_pad_l", "extra_pad_r", "in_mode", "in_offset",
+                                         "herm")] + \
                [(n, C.c_float) for n in ("scale", "eps", "alpha")]
 
 
@@ -98,6 +99,12 @@ SIGNATURES = {
     "rfx_unpack_add": [_P, _P, _I64, _I32, _I32, _I32, _P, _P],
     "rfx_gemm_fwd": [C.POINTER(GemmDesc), _P, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _I32, _I32, _P, _P],
     "rfx_gemm_wgrad": [C.POINTER(GemmDesc), _P, _P, _P, _P, _P],
+    "rfx_fft_analysis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
+    "rfx_fft_synthesis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
+    "rfx_stft_loss_reduce": [_P, _P, _I32, _I64, C.c_float, _P, _P],
+    "rfx_stft_loss_grad": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P],
+    "rfx_l1_grad": [_P, _P, _I64, C.c_float, _P, _P],
+    "rfx_sisdr_sums": [_P, _P, _I32, _I64, _I64, _I64, _P, _P],
     "rfx_act_fwd": [_P, _P, _I64, _I32, _P],
     "rfx_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],

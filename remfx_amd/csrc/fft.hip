@@ -1,0 +1,355 @@
+// Framed real FFT kernels: STFT / iSTFT forward and backward for every geometry
+// of the RemFX hot path (n_fft 512..4096, arbitrary hop, hann window of `win`
+// samples centred in n_fft, centre + reflect padding).
+//
+// Replaces torch.stft / torch.istft call sites: utils.py:148-154 (spectrogram),
+// HDemucs _spec/_ispec (models.py:319), auraloss STFTLoss (models.py:320 ...),
+// Open-Unmix Separator (models.py:298), MelSpectrogram (classifier.py:200).
+//
+// Structure (one workgroup = 256 threads = FB consecutive frames of one row):
+//   * a real n_fft-point transform is done as an NC = n_fft/2 point complex FFT of
+//     z[n] = x[2n] + i x[2n+1] plus the standard split/merge step;
+//   * the NC-point FFT runs IN PLACE in LDS: radix-4 decimation-in-frequency passes
+//     (+ one radix-2 pass when log2 NC is odd), natural-order input -> digit-reversed
+//     output; the inverse runs the mirrored decimation-in-time passes;
+//   * FB * NC = 8192 complex points (64 KiB) + an NC-entry twiddle table per
+//     workgroup; frames are padded by one element so that the transposing epilogue
+//     (lanes along frames -> coalesced [bin][frame] stores) is bank-conflict free;
+//   * workgroups that write the same (row, bin) lines are placed on the same XCD
+//     (block b runs on XCD b % 8) so partial-line stores merge in one L2.
+#include "common.h"
+
+struct FftArgs {
+  rfx_stft_desc d;
+  const float* x;       // analysis: signal [R][T];   synthesis: spectrum
+  const float* window;  // [win]
+  const float* mul;     // optional per padded-sample multiplier (iSTFT 1/envelope)
+  float* out;           // analysis: spectrum;       synthesis: signal [R][T] (atomic accumulate)
+  int groups_per_row;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
+  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+template <int LOGN>
+__device__ __forceinline__ int digit_pos(int k) {
+  int pos = 0, L = 1 << LOGN, kk = k;
+#pragma unroll
+  for (int s = 0; s < LOGN / 2; ++s) {
+    pos += (kk & 3) * (L >> 2);
+    kk >>= 2;
+    L >>= 2;
+  }
+  if (LOGN & 1) pos += (kk & 1);
+  return pos;
+}
+
+// In-place FFT of FB frames of NC complex points each (frame stride FS).
+template <int LOGN, bool INV>
+__device__ __forceinline__ void fft_passes(float2* data, const float2* tw, int nframes_elems /*FB*NC*/) {
+  constexpr int NC = 1 << LOGN, FS = NC + 1;
+  const int tid = threadIdx.x;
+  if (!INV) {
+    for (int L = NC; L >= 4; L >>= 2) {
+      const int q = L >> 2, tstep = NC / L;
+      for (int idx = tid; idx < nframes_elems / 4; idx += 256) {
+        const int fr = idx / (NC / 4), r = idx - fr * (NC / 4);
+        const int gI = r / q, j = r - gI * q;
+        float2* p = data + fr * FS + gI * L + j;
+        const float2 x0 = p[0], x1 = p[q], x2 = p[2 * q], x3 = p[3 * q];
+        const float2 t0 = make_float2(x0.x + x2.x, x0.y + x2.y), t1 = make_float2(x0.x - x2.x, x0.y - x2.y);
+        const float2 t2 = make_float2(x1.x + x3.x, x1.y + x3.y);
+        const float2 t3 = make_float2(x1.y - x3.y, -(x1.x - x3.x));  // (x1-x3) * (-i)
+        p[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+        p[q] = cmul(make_float2(t1.x + t3.x, t1.y + t3.y), tw[j * tstep]);
+        p[2 * q] = cmul(make_float2(t0.x - t2.x, t0.y - t2.y), tw[2 * j * tstep]);
+        p[3 * q] = cmul(make_float2(t1.x - t3.x, t1.y - t3.y), tw[3 * j * tstep]);
+      }
+      __syncthreads();
+    }
+    if (LOGN & 1) {
+      for (int idx = tid; idx < nframes_elems / 2; idx += 256) {
+        const int fr = idx / (NC / 2), r = idx - fr * (NC / 2);
+        float2* p = data + fr * FS + 2 * r;
+        const float2 a = p[0], b = p[1];
+        p[0] = make_float2(a.x + b.x, a.y + b.y);
+        p[1] = make_float2(a.x - b.x, a.y - b.y);
+      }
+      __syncthreads();
+    }
+  } else {
+    if (LOGN & 1) {
+      for (int idx = tid; idx < nframes_elems / 2; idx += 256) {
+        const int fr = idx / (NC / 2), r = idx - fr * (NC / 2);
+        float2* p = data + fr * FS + 2 * r;
+        const float2 a = p[0], b = p[1];
+        p[0] = make_float2(a.x + b.x, a.y + b.y);
+        p[1] = make_float2(a.x - b.x, a.y - b.y);
+      }
+      __syncthreads();
+    }
+    for (int L = (LOGN & 1) ? 8 : 4; L <= NC; L <<= 2) {
+      const int q = L >> 2, tstep = NC / L;
+      for (int idx = tid; idx < nframes_elems / 4; idx += 256) {
+        const int fr = idx / (NC / 4), r = idx - fr * (NC / 4);
+        const int gI = r / q, j = r - gI * q;
+        float2* p = data + fr * FS + gI * L + j;
+        const float2 u0 = p[0];
+        const float2 u1 = cmulc(p[q], tw[j * tstep]);
+        const float2 u2 = cmulc(p[2 * q], tw[2 * j * tstep]);
+        const float2 u3 = cmulc(p[3 * q], tw[3 * j * tstep]);
+        const float2 t0 = make_float2(u0.x + u2.x, u0.y + u2.y), t1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+        const float2 t2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+        const float2 t3 = make_float2(-(u1.y - u3.y), u1.x - u3.x);  // (u1-u3) * (+i)
+        p[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+        p[q] = make_float2(t1.x + t3.x, t1.y + t3.y);
+        p[2 * q] = make_float2(t0.x - t2.x, t0.y - t2.y);
+        p[3 * q] = make_float2(t1.x - t3.x, t1.y - t3.y);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// padded-signal coordinate p = f*hop + t  ->  index into x (or -1)
+__device__ __forceinline__ int map_sample(const rfx_stft_desc& d, int p) {
+  if (d.in_mode == 0) {  // centre + reflect (on top of an optional extra reflect pad)
+    const int Tp = d.T + d.extra_pad_l + d.extra_pad_r;
+    int s = p - d.n_fft / 2;
+    if (s < 0) s = -s;
+    if (s >= Tp) s = 2 * (Tp - 1) - s;
+    s -= d.extra_pad_l;
+    if (s < 0) s = -s;
+    if (s >= d.T) s = 2 * (d.T - 1) - s;
+    return (s >= 0 && s < d.T) ? s : -1;
+  }
+  const int s = p - d.in_offset;  // iSTFT: centre trim + crop folded into one offset
+  return (s >= 0 && s < d.T) ? s : -1;
+}
+
+template <int LOGN>
+__device__ __forceinline__ void block_coords(const FftArgs& a, int& row, int& f_first) {
+  constexpr int FB = 8192 >> LOGN;
+  // same-row frame groups on the same XCD (block b -> XCD b % 8), adjacent in time
+  const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+  const int slot = q / a.groups_per_row, grp = q - slot * a.groups_per_row;
+  row = slot * 8 + xcd;
+  f_first = a.d.frame0 + grp * FB;
+}
+
+template <int LOGN>
+__device__ __forceinline__ void build_twiddles(float2* tw) {
+  constexpr int NC = 1 << LOGN;
+  for (int t = threadIdx.x; t < NC; t += 256) {
+    float s, c;
+    sincospif(-2.0f * (float)t / (float)NC, &s, &c);
+    tw[t] = make_float2(c, s);
+  }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
+  constexpr int NC = 1 << LOGN, FB = 8192 >> LOGN, FS = NC + 1, N = 2 * NC;
+  __shared__ float2 data[FB * FS];
+  __shared__ float2 tw[NC];
+  const rfx_stft_desc& d = a.d;
+  int row, f_first;
+  block_coords<LOGN>(a, row, f_first);
+  if (row >= d.R) return;
+  const int tid = threadIdx.x;
+  build_twiddles<LOGN>(tw);
+  const int f_end = d.frame0 + d.frames_out;
+  const float* xr = a.x + (int64_t)row * d.T;
+  const int woff = (N - d.win) / 2;
+  for (int idx = tid; idx < FB * NC; idx += 256) {
+    const int fl = idx / NC, i = idx - fl * NC;
+    const int f = f_first + fl;
+    float2 v = make_float2(0.f, 0.f);
+    if (f < f_end) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * i + u;
+        const int wi = t - woff;
+        float val = 0.f;
+        if (wi >= 0 && wi < d.win) {
+          const int p = f * d.hop + t;
+          const int s = map_sample(d, p);
+          if (s >= 0) {
+            val = xr[s] * a.window[wi] * d.scale;
+            if (a.mul) val *= a.mul[p];
+          }
+        }
+        if (u == 0) v.x = val; else v.y = val;
+      }
+    }
+    data[fl * FS + i] = v;
+  }
+  __syncthreads();
+  fft_passes<LOGN, false>(data, tw, FB * NC);
+  // split step + transposing epilogue: lanes along frames
+  const int FO = d.frames_out;
+  for (int idx = tid; idx < d.bins * FB; idx += 256) {
+    const int k = idx / FB, fl = idx - k * FB;
+    const int f = f_first + fl;
+    if (f >= f_end) continue;
+    const float2 A = data[fl * FS + digit_pos<LOGN>(k & (NC - 1))];
+    const float2 Bq = data[fl * FS + digit_pos<LOGN>((NC - k) & (NC - 1))];
+    const float2 Bc = make_float2(Bq.x, -Bq.y);
+    const float2 E = make_float2(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
+    const float2 D = make_float2(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
+    const float2 O = make_float2(D.y, -D.x);  // D * (-i)
+    float s, c;
+    sincospif((float)k / (float)NC, &s, &c);
+    float2 X = cmul(O, make_float2(c, -s));
+    X.x += E.x;
+    X.y += E.y;
+    if (d.herm) {  // gradient of irfft: middle bins doubled, DC / Nyquist imaginary part dropped
+      if (k == 0 || k == NC) X.y = 0.f;
+      else { X.x *= 2.f; X.y *= 2.f; }
+    }
+    const int fo = f - d.frame0;
+    const int64_t rb = (int64_t)row * d.bins + k;
+    switch (d.mode) {
+      case RFX_STFT_COMPLEX:
+        reinterpret_cast<float2*>(a.out)[rb * FO + fo] = X;
+        break;
+      case RFX_STFT_CAC:
+        a.out[((int64_t)row * 2 * d.bins + k) * FO + fo] = X.x;
+        a.out[((int64_t)row * 2 * d.bins + d.bins + k) * FO + fo] = X.y;
+        break;
+      case RFX_STFT_MAG:
+        a.out[rb * FO + fo] = sqrtf(fmaxf(X.x * X.x + X.y * X.y, d.eps));
+        break;
+      case RFX_STFT_POW:
+        a.out[rb * FO + fo] = X.x * X.x + X.y * X.y;
+        break;
+      default:  // RFX_STFT_MAGPOW
+        a.out[rb * FO + fo] = powf(sqrtf(X.x * X.x + X.y * X.y) + d.eps, d.alpha);
+        break;
+    }
+  }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void fft_synthesis_kernel(const FftArgs a) {
+  constexpr int NC = 1 << LOGN, FB = 8192 >> LOGN, FS = NC + 1, N = 2 * NC;
+  __shared__ float2 data[FB * FS];
+  __shared__ float2 tw[NC];
+  const rfx_stft_desc& d = a.d;
+  int row, f_first;
+  block_coords<LOGN>(a, row, f_first);
+  if (row >= d.R) return;
+  const int tid = threadIdx.x;
+  build_twiddles<LOGN>(tw);
+  const int f_end = d.frame0 + d.frames_out;
+  const int FO = d.frames_out;
+  // merge step: Z[k] = (X[k] + conj X[NC-k]) + i e^{+i pi k/NC} (X[k] - conj X[NC-k]),  k in [0, NC)
+  for (int idx = tid; idx < NC * FB; idx += 256) {
+    const int k = idx / FB, fl = idx - k * FB;
+    const int f = f_first + fl;
+    float2 Z = make_float2(0.f, 0.f);
+    if (f < f_end) {
+      const int fo = f - d.frame0;
+      auto fetch = [&](int kk) -> float2 {
+        float2 v = make_float2(0.f, 0.f);
+        if (kk < d.bins) {
+          if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const float2*>(a.x)[((int64_t)row * d.bins + kk) * FO + fo];
+          else {
+            v.x = a.x[((int64_t)row * 2 * d.bins + kk) * FO + fo];
+            v.y = a.x[((int64_t)row * 2 * d.bins + d.bins + kk) * FO + fo];
+          }
+        }
+        if (kk == 0 || kk == NC) v.y = 0.f;           // real by construction / ignored by irfft
+        else if (!d.herm) { v.x *= 0.5f; v.y *= 0.5f; }  // adjoint of the one-sided rfft
+        return v;
+      };
+      const float2 Xk = fetch(k), Xm = fetch(NC - k);
+      const float2 Xc = make_float2(Xm.x, -Xm.y);
+      const float2 S = make_float2(Xk.x + Xc.x, Xk.y + Xc.y);
+      const float2 D = make_float2(Xk.x - Xc.x, Xk.y - Xc.y);
+      float s, c;
+      sincospif((float)k / (float)NC, &s, &c);
+      const float2 W = cmul(D, make_float2(c, s));
+      Z = make_float2(S.x - W.y, S.y + W.x);  // S + i*W
+    }
+    data[fl * FS + digit_pos<LOGN>(k)] = Z;
+  }
+  __syncthreads();
+  fft_passes<LOGN, true>(data, tw, FB * NC);
+  const int woff = (N - d.win) / 2;
+  float* outr = a.out + (int64_t)row * d.T;
+  for (int idx = tid; idx < FB * NC; idx += 256) {
+    const int fl = idx / NC, i = idx - fl * NC;
+    const int f = f_first + fl;
+    if (f >= f_end) continue;
+    const float2 z = data[fl * FS + i];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = 2 * i + u;
+      const int wi = t - woff;
+      if (wi < 0 || wi >= d.win) continue;
+      const int p = f * d.hop + t;
+      const int s = map_sample(d, p);
+      if (s < 0) continue;
+      float v = (u == 0 ? z.x : z.y) * a.window[wi] * d.scale;
+      if (a.mul) v *= a.mul[p];
+      atomicAdd(outr + s, v);
+    }
+  }
+}
+
+static bool stft_desc_ok(const rfx_stft_desc* d) {
+  if (!d) return false;
+  const int n = d->n_fft;
+  if (n != 512 && n != 1024 && n != 2048 && n != 4096) return false;
+  return d->R > 0 && d->T > 0 && d->hop > 0 && d->win > 0 && d->win <= n && d->frames_out > 0 &&
+         d->bins > 0 && d->bins <= n / 2 + 1 && d->frame0 >= 0;
+}
+
+template <bool SYN>
+static int launch_fft(const rfx_stft_desc* d, const float* x, const float* window, const float* mul,
+                      float* out, void* stream) {
+  if (!stft_desc_ok(d) || !x || !window || !out) return -1;
+  FftArgs a;
+  a.d = *d; a.x = x; a.window = window; a.mul = mul; a.out = out;
+  const int nc = d->n_fft / 2;
+  const int fb = 8192 / nc;
+  a.groups_per_row = (d->frames_out + fb - 1) / fb;
+  const int rows8 = (d->R + 7) / 8;
+  const unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->n_fft) {
+    case 512:
+      if (SYN) hipLaunchKernelGGL(fft_synthesis_kernel<8>, dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(fft_analysis_kernel<8>, dim3(grid), dim3(256), 0, s, a);
+      break;
+    case 1024:
+      if (SYN) hipLaunchKernelGGL(fft_synthesis_kernel<9>, dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(fft_analysis_kernel<9>, dim3(grid), dim3(256), 0, s, a);
+      break;
+    case 2048:
+      if (SYN) hipLaunchKernelGGL(fft_synthesis_kernel<10>, dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(fft_analysis_kernel<10>, dim3(grid), dim3(256), 0, s, a);
+      break;
+    default:
+      if (SYN) hipLaunchKernelGGL(fft_synthesis_kernel<11>, dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(fft_analysis_kernel<11>, dim3(grid), dim3(256), 0, s, a);
+      break;
+  }
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rfx_fft_analysis(const rfx_stft_desc* d, const float* x, const float* window,
+                                const float* mul, float* out, void* stream) {
+  return launch_fft<false>(d, x, window, mul, out, stream);
+}
+extern "C" int rfx_fft_synthesis(const rfx_stft_desc* d, const float* spec, const float* window,
+                                 const float* mul, float* out, void* stream) {
+  if (d && d->mode != RFX_STFT_COMPLEX && d->mode != RFX_STFT_CAC) return -1;
+  return launch_fft<true>(d, spec, window, mul, out, stream);
+}

@@ -1,0 +1,135 @@
+// Loss reductions of the hot path: auraloss STFTLoss terms (spectral convergence +
+// log-magnitude L1), waveform L1, SI-SDR sums.  All HBM-bound streaming reductions.
+// Replaces: models.py:107,299,320,362,385 (mrstft + 100*L1), models.py:227-255 (metrics).
+#include "common.h"
+
+__device__ __forceinline__ void block_atomic_add3(double a, double b, double c, float* out) {
+  a = rfx_wave_sum_d(a); b = rfx_wave_sum_d(b); c = rfx_wave_sum_d(c);
+  __shared__ double part[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { part[0][wave] = a; part[1][wave] = b; part[2][wave] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out + 0, (float)(part[0][0] + part[0][1] + part[0][2] + part[0][3]));
+    atomicAdd(out + 1, (float)(part[1][0] + part[1][1] + part[1][2] + part[1][3]));
+    atomicAdd(out + 2, (float)(part[2][0] + part[2][1] + part[2][2] + part[2][3]));
+  }
+}
+
+// xc, yc: [R][n] complex (float2); sums[r] = { sum (ym-xm)^2, sum ym^2, sum |log xm - log ym| }
+__global__ __launch_bounds__(256) void stft_loss_reduce_kernel(const float2* __restrict__ xc,
+                                                               const float2* __restrict__ yc, int64_t n,
+                                                               float eps, float* __restrict__ sums) {
+  const int r = blockIdx.y;
+  const float2* xr = xc + (int64_t)r * n;
+  const float2* yr = yc + (int64_t)r * n;
+  double a = 0, b = 0, c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float2 x = xr[i], y = yr[i];
+    const float xm = sqrtf(fmaxf(x.x * x.x + x.y * x.y, eps));
+    const float ym = sqrtf(fmaxf(y.x * y.x + y.y * y.y, eps));
+    const float dd = ym - xm;
+    a += (double)(dd * dd);
+    b += (double)(ym * ym);
+    c += (double)fabsf(logf(xm) - logf(ym));
+  }
+  block_atomic_add3(a, b, c, sums + 3 * r);
+}
+
+// gxc = d/dxc [ w_sc * sqrt(A_r)/sqrt(B_r) + w_lm * sum |log xm - log ym| ]
+//   w_sc, w_lm already contain the upstream gradient and the 1/R, 1/(R*n), 1/3 factors.
+__global__ __launch_bounds__(256) void stft_loss_grad_kernel(const float2* __restrict__ xc,
+                                                             const float2* __restrict__ yc, int64_t n,
+                                                             float eps, const float* __restrict__ sums,
+                                                             float w_sc, float w_lm, float2* __restrict__ gxc) {
+  const int r = blockIdx.y;
+  const float A = sums[3 * r], B = sums[3 * r + 1];
+  const float ksc = (A > 0.f && B > 0.f) ? w_sc / (sqrtf(A) * sqrtf(B)) : 0.f;   // d sqrt(A)/sqrt(B) / dA * 2
+  const float2* xr = xc + (int64_t)r * n;
+  const float2* yr = yc + (int64_t)r * n;
+  float2* gr = gxc + (int64_t)r * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float2 x = xr[i], y = yr[i];
+    const float px = x.x * x.x + x.y * x.y;
+    float2 g = make_float2(0.f, 0.f);
+    if (px > eps) {   // clamp(min=eps) passes no gradient below eps
+      const float xm = sqrtf(px);
+      const float ym = sqrtf(fmaxf(y.x * y.x + y.y * y.y, eps));
+      const float lg = logf(xm) - logf(ym);
+      const float dm = ksc * (xm - ym) + w_lm * (lg > 0.f ? 1.f : (lg < 0.f ? -1.f : 0.f)) / xm;
+      g.x = dm * x.x / xm;
+      g.y = dm * x.y / xm;
+    }
+    gr[i] = g;
+  }
+}
+
+// g[i] = w * sign(a[i]-b[i])
+__global__ void l1_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float w,
+                               float* __restrict__ g) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    g[i] = d > 0.f ? w : (d < 0.f ? -w : 0.f);
+  }
+}
+
+// per row r of [R][L]: sums[r] = { sum x, sum t, sum x*t, sum x*x, sum t*t }  (double accumulate)
+__global__ __launch_bounds__(256) void sisdr_sums_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                         int64_t L, int64_t xs, int64_t ts, double* __restrict__ sums) {
+  const int r = blockIdx.y;
+  const float* xr = x + (int64_t)r * xs;
+  const float* tr = t + (int64_t)r * ts;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L; i += (int64_t)gridDim.x * 256) {
+    const double a = xr[i], b = tr[i];
+    s[0] += a; s[1] += b; s[2] += a * b; s[3] += a * a; s[4] += b * b;
+  }
+  __shared__ double part[5][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const double v = rfx_wave_sum_d(s[q]);
+    if (lane == 0) part[q][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int q = threadIdx.x;
+    atomicAdd(sums + 5 * r + q, part[q][0] + part[q][1] + part[q][2] + part[q][3]);
+  }
+}
+
+static int grid_x(int64_t n) {
+  const int64_t b = (n + 2047) / 2048;
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
+extern "C" int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R, int64_t n, float eps,
+                                    float* sums, void* stream) {
+  if (!xc || !yc || !sums || R <= 0 || n <= 0) return -1;
+  hipLaunchKernelGGL(stft_loss_reduce_kernel, dim3(grid_x(n), R), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)xc, (const float2*)yc, n, eps, sums);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_stft_loss_grad(const float* xc, const float* yc, int32_t R, int64_t n, float eps,
+                                  const float* sums, float w_sc, float w_lm, float* gxc, void* stream) {
+  if (!xc || !yc || !sums || !gxc || R <= 0 || n <= 0) return -1;
+  hipLaunchKernelGGL(stft_loss_grad_kernel, dim3(grid_x(n), R), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)xc, (const float2*)yc, n, eps, sums, w_sc, w_lm, (float2*)gxc);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, float* g, void* stream) {
+  if (!a || !b || !g || n <= 0) return -1;
+  hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_x(n) * 4), dim3(256), 0, (hipStream_t)stream, a, b, n, w, g);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t L, int64_t x_rs,
+                              int64_t t_rs, double* sums, void* stream) {
+  if (!x || !t || !sums || R <= 0 || L <= 0) return -1;
+  hipLaunchKernelGGL(sisdr_sums_kernel, dim3(grid_x(L), R), dim3(256), 0, (hipStream_t)stream, x, t, L, x_rs,
+                     t_rs, sums);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,145 @@
+"""Losses and metrics of the removal path on HIP kernels.
+
+Mirrors the auraloss objects the reference instantiates (remfx/models.py:7-8,
+35-44, 171-176, 289-291, 312-314, 351-353, 374-376):
+  MultiResolutionSTFTLoss(fft 1024/2048/512, hop 120/240/50, win 600/1200/240):
+      mean over resolutions of [ ||Y|-|X||_F / ||Y||_F  +  mean |log|X| - log|Y|| ]
+  SISDRLoss(zero_mean=True, eps=1e-8)
+  nn.L1Loss
+`n_bins` / `sample_rate` kwargs are accepted and inert, as upstream with scale=None
+(SURVEY App. B Q4).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, stft
+from ._lib import check
+from .ops import _ptr, _req, _stream
+
+FFT_SIZES = (1024, 2048, 512)
+HOP_SIZES = (120, 240, 50)
+WIN_LENGTHS = (600, 1200, 240)
+
+
+class _MRSTFTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, fft_sizes, hops, wins, eps, per_example_sc):
+        _req(x, "input"); _req(y, "target")
+        L = x.shape[-1]
+        x2, y2 = x.reshape(-1, L).contiguous(), y.reshape(-1, L).contiguous()
+        R = x2.shape[0]
+        saved, total = [], None
+        for n_fft, hop, win in zip(fft_sizes, hops, wins):
+            w = stft.hann(win, x.device)
+            X = stft.stft_raw(x2, n_fft, hop, win, w, 0)
+            Y = stft.stft_raw(y2, n_fft, hop, win, w, 0)
+            n = X.shape[1] * X.shape[2]
+            sums = torch.zeros((R, 3), device=x.device, dtype=torch.float32)
+            check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), _stream()),
+                  "rfx_stft_loss_reduce")
+            if per_example_sc:
+                sc = (sums[:, 0].sqrt() / sums[:, 1].sqrt()).mean()
+            else:
+                sc = sums[:, 0].sum().sqrt() / sums[:, 1].sum().sqrt()
+            lm = sums[:, 2].sum() / (R * n)
+            term = sc + lm
+            total = term if total is None else total + term
+            saved.append((X, Y, sums, n, n_fft, hop, win))
+        ctx.saved = saved
+        ctx.meta = (x.shape, R, L, eps, per_example_sc, len(fft_sizes))
+        return total / len(fft_sizes)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, R, L, eps, per_example_sc, nres = ctx.meta
+        gx = torch.zeros((R, L), device=g.device, dtype=torch.float32)
+        gval = float(g)          # scalar upstream gradient (one host sync per backward)
+        for X, Y, sums, n, n_fft, hop, win in ctx.saved:
+            if not per_example_sc:      # whole-batch Frobenius norm: same A, B for every row
+                sums = sums.clone()
+                sums[:, 0] = sums[:, 0].sum()
+                sums[:, 1] = sums[:, 1].sum()
+                w_sc = gval / nres
+            else:
+                w_sc = gval / (nres * R)
+            w_lm = gval / (nres * R * n)
+            G = torch.empty_like(X)
+            check(_lib.lib().rfx_stft_loss_grad(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(G),
+                                                _stream()), "rfx_stft_loss_grad")
+            w = stft.hann(win, g.device)
+            d = stft._desc(R, L, n_fft, hop, win, X.shape[1], 0, X.shape[2], 0, in_mode=0, herm=0, scale=1.0)
+            check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(G), _ptr(w), None, _ptr(gx), _stream()),
+                  "rfx_fft_synthesis")
+        ctx.saved = None
+        return gx.view(shape), None, None, None, None, None, None
+
+
+class MultiResolutionSTFTLoss(nn.Module):
+    def __init__(self, fft_sizes=FFT_SIZES, hop_sizes=HOP_SIZES, win_lengths=WIN_LENGTHS, n_bins=None,
+                 sample_rate=None, eps=1e-8, per_example_sc=True, **kwargs):
+        super().__init__()
+        self.fft_sizes, self.hop_sizes, self.win_lengths = tuple(fft_sizes), tuple(hop_sizes), tuple(win_lengths)
+        self.eps, self.per_example_sc = eps, per_example_sc
+
+    def forward(self, input, target):
+        return _MRSTFTFn.apply(input, target, self.fft_sizes, self.hop_sizes, self.win_lengths, self.eps,
+                               self.per_example_sc)
+
+
+class _L1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _req(a, "input"); _req(b, "target")
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.zeros(1, device=a.device, dtype=torch.float32)
+        check(_lib.lib().rfx_l1_sum(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream()), "rfx_l1_sum")
+        ctx.save_for_backward(a, b)
+        return (out / a.numel()).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        check(_lib.lib().rfx_l1_grad(_ptr(a), _ptr(b), a.numel(), float(g) / a.numel(), _ptr(ga), _stream()),
+              "rfx_l1_grad")
+        return ga, None
+
+
+class L1Loss(nn.Module):
+    def forward(self, input, target):
+        return _L1Fn.apply(input, target)
+
+
+class SISDRLoss(nn.Module):
+    """-SI-SDR (auraloss.time.SISDRLoss, zero_mean=True, eps=1e-8, reduction='mean');
+    metric only (no gradient), models.py:227-255."""
+
+    def __init__(self, zero_mean=True, eps=1e-8):
+        super().__init__()
+        self.zero_mean, self.eps = zero_mean, eps
+
+    @torch.no_grad()
+    def forward(self, input, target):
+        _req(input, "input"); _req(target, "target")
+        L = input.shape[-1]
+        x, t = input.reshape(-1, L), target.reshape(-1, L)
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        if t.stride(-1) != 1:
+            t = t.contiguous()
+        R = x.shape[0]
+        s = torch.zeros((R, 5), device=x.device, dtype=torch.float64)
+        check(_lib.lib().rfx_sisdr_sums(_ptr(x), _ptr(t), R, L, x.stride(0), t.stride(0), _ptr(s), _stream()),
+              "rfx_sisdr_sums")
+        sx, st, sxt, sxx, stt = s.unbind(1)
+        if self.zero_mean:
+            sxt = sxt - sx * st / L
+            sxx = sxx - sx * sx / L
+            stt = stt - st * st / L
+        alpha = sxt / (stt + self.eps)
+        tt = alpha * alpha * stt
+        res = sxx - 2 * alpha * sxt + tt
+        val = 10.0 * torch.log10(tt / (res + self.eps) + self.eps)
+        return (-val.mean()).float()

@@ -1,0 +1,145 @@
+"""GPU parity: framed-FFT kernels (STFT / iSTFT fwd+bwd) and the loss kernels vs
+torch.stft / torch.istft on CPU and the CPU oracle (oracle/ref_losses.py)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+GEOMS = [  # n_fft, hop, win   
+    (4096, 1024, 4096), (2048, 512, 2048), (1024, 120, 600), (2048, 240, 1200), (512, 50, 240),
+    (512, 128, 512),
+]
+
+
+def _rms(a, b):
+    return float(((a - b) ** 2).mean().sqrt())
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_stft_forward_modes(geom):
+    from remfx_amd import stft
+    n_fft, hop, win = geom
+    g = torch.Generator().manual_seed(n_fft + hop)
+    x = torch.randn(3, 20000, generator=g)
+    ref = torch.stft(x, n_fft, hop, win, torch.hann_window(win), return_complex=True)
+    xd = x.to(DEV)
+    got = stft.stft(xd, n_fft, hop, win, mode="complex").cpu()
+    scale = float(ref.abs().max())
+    assert got.shape == tuple(ref.shape) + (2,)
+    assert _rms(got, torch.view_as_real(ref)) < 2e-6 * scale
+    cac = stft.stft(xd, n_fft, hop, win, mode="cac").cpu()
+    assert _rms(cac[:, 0], ref.real) < 2e-6 * scale and _rms(cac[:, 1], ref.imag) < 2e-6 * scale
+    mag = stft.stft(xd, n_fft, hop, win, mode="mag", eps=1e-8).cpu()
+    assert _rms(mag, torch.sqrt(torch.clamp(ref.real ** 2 + ref.imag ** 2, min=1e-8))) < 2e-6 * scale
+    pw = stft.stft(xd, n_fft, hop, win, mode="pow").cpu()
+    assert _rms(pw, ref.real ** 2 + ref.imag ** 2) < 4e-6 * scale * scale
+    mp = stft.stft(xd, n_fft, hop, win, mode="magpow", eps=1e-8, alpha=0.3).cpu()
+    assert _rms(mp, (ref.abs() + 1e-8) ** 0.3) < 1e-5
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_stft_backward(geom):
+    from remfx_amd import stft
+    n_fft, hop, win = geom
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 9000, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.view_as_real(torch.stft(xr, n_fft, hop, win, torch.hann_window(win), return_complex=True))
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    got = stft.stft(xd, n_fft, hop, win, mode="complex")
+    got.backward(gy.to(DEV))
+    scale = float(xr.grad.abs().max())
+    assert _rms(xd.grad.cpu(), xr.grad) < 5e-6 * scale
+
+
+def test_hdemucs_spec_ispec():
+    """HDemucs _spec (extra reflect pad, normalized, drop Nyquist, frames [2:2+le]) and _ispec."""
+    from oracle.ref_hdemucs import HDemucs
+    from remfx_amd import stft
+    m = HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=4, depth=6)
+    T = 30000
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 1, T, generator=g)
+    xr = x.clone().requires_grad_(True)
+    z = m._spec(xr)                                  # (2,1,2048,le) complex
+    le = z.shape[-1]
+    zr = torch.view_as_real(z).permute(0, 1, 4, 2, 3).reshape(2, 2, 2048, le)
+    gz = torch.randn(zr.shape, generator=g)
+    zr.backward(gz)
+    hl = 1024
+    pad = hl // 2 * 3
+    xd = x.to(DEV).reshape(2, T).requires_grad_(True)
+    cac = stft.stft(xd, 4096, hl, mode="cac", normalized=True, bins=2048, frame0=2, frames_out=le,
+                    extra_pad=(pad, pad + le * hl - T))
+    assert cac.shape == (2, 2, 2048, le)
+    assert _rms(cac.detach().cpu(), zr.detach()) < 2e-6 * float(zr.abs().max())
+    cac.backward(gz.to(DEV))
+    assert _rms(xd.grad.cpu().view_as(xr.grad), xr.grad) < 5e-6 * float(xr.grad.abs().max())
+    # inverse
+    zin = torch.randn(2, 1, 2048, le, 2, generator=g)
+    zc = torch.view_as_complex(zin.clone()).requires_grad_(True)
+    xo = m._ispec(zc, T)                             # (2,1,T)
+    go = torch.randn(xo.shape, generator=g)
+    xo.backward(go)
+    cin = zin[:, 0].permute(0, 3, 1, 2).contiguous().to(DEV).requires_grad_(True)   # (2,2,2048,le)
+    got = stft.istft(cin, 4096, hl, mode="cac", normalized=True, frames=le + 4, frame0=2, crop=pad, length=T)
+    assert got.shape == (2, T)
+    assert _rms(got.detach().cpu(), xo.detach()[:, 0]) < 2e-6 * float(xo.abs().max())
+    got.backward(go[:, 0].to(DEV))
+    gref = torch.view_as_real(zc.grad)[:, 0].permute(0, 3, 1, 2)
+    assert _rms(cin.grad.cpu(), gref) < 5e-6 * float(gref.abs().max())
+
+
+def test_istft_plain():
+    from remfx_amd import stft
+    g = torch.Generator().manual_seed(4)
+    T = 16384
+    x = torch.randn(2, T, generator=g)
+    spec = torch.stft(x, 2048, 512, window=torch.hann_window(2048), return_complex=True)
+    ref = torch.istft(spec, 2048, 512, window=torch.hann_window(2048), length=T)
+    got = stft.istft(torch.view_as_real(spec).contiguous().to(DEV), 2048, 512, mode="complex", length=T)
+    assert _rms(got.cpu(), ref) < 2e-6 * float(ref.abs().max())
+    assert _rms(got.cpu(), x) < 1e-5            # perfect reconstruction
+
+
+def test_mrstft_l1_sisdr_vs_oracle():
+    from oracle import ref_losses
+    from remfx_amd import losses
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 1, 24000, generator=g) * 0.3
+    y = x + 0.1 * torch.randn(3, 1, 24000, generator=g)
+    xr = x.clone().requires_grad_(True)
+    lref = ref_losses.mrstft_loss(xr, y) + 100.0 * ref_losses.l1_loss(xr, y)
+    lref.backward()
+    xd = x.to(DEV).requires_grad_(True)
+    yd = y.to(DEV)
+    mr, l1 = losses.MultiResolutionSTFTLoss(n_bins=1025, sample_rate=48000), losses.L1Loss()
+    l = mr(xd, yd) + l1(xd, yd) * 100
+    l.backward()
+    assert abs(float(l) - float(lref)) < 1e-4 * abs(float(lref))
+    assert _rms(xd.grad.cpu(), xr.grad) < 1e-4 * float(xr.grad.abs().max())
+    # whole-batch spectral convergence variant (older auraloss)
+    l2 = losses.MultiResolutionSTFTLoss(per_example_sc=False)(xd, yd)
+    assert abs(float(l2) - float(ref_losses.mrstft_loss(x, y, per_example_sc=False))) < 1e-4 * float(l2)
+    s = losses.SISDRLoss()(xd.detach(), yd)
+    assert abs(float(s) - float(ref_losses.sisdr_loss(x, y))) < 1e-3
+    # strided (cropped) inputs
+    s2 = losses.SISDRLoss()(xd.detach()[..., 5:20000], yd[..., 5:20000])
+    assert abs(float(s2) - float(ref_losses.sisdr_loss(x[..., 5:20000], y[..., 5:20000]))) < 1e-3
+
+
+def test_spectrogram_golden(golden_dir):
+    import os
+    import numpy as np
+    from remfx_amd.utils import spectrogram
+    gd = np.load(os.path.join(golden_dir, "utils_small.npz"))
+    x = torch.from_numpy(gd["x"]).to(DEV)
+    S = spectrogram(x, torch.hann_window(512).to(DEV), 512, 128, 0.3).cpu().numpy()
+    assert S.shape == gd["spec"].shape
+    assert float(np.sqrt(((S - gd["spec"]) ** 2).mean())) < 1e-5
