@@ -1,0 +1,203 @@
+"""bench.py -- one "step" = one training step (forward + backward + clip + AdamW, plus the
+no-grad metrics the reference logs every step, remfx/models.py:217-256) of a RemFX
+removal network on a batch of synthetic white-noise clips (B, 1, 262144) @ 48 kHz.
+
+    python bench.py --gpus N --steps K --warmup W [--workload demucs|tcn] [--batch B]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+one rank per GPU over RCCL; per-GPU work is fixed (weak scaling): every rank trains on its
+own B clips and the flat gradient buffer is all-reduced over xGMI every step.
+
+Prints ONE JSON line (rank 0).  metric = audio-seconds processed per second (whole job).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CLIP = 262144
+SR = 48000
+PEAK_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(workload, device):
+    from remfx_amd import models
+    torch.manual_seed(12345)                                 # cfg/config.yaml:7
+    if workload == "tcn":                                    # cfg/model/tcn.yaml
+        net = models.TCNModel(sample_rate=SR, num_bins=1025, ninputs=1, noutputs=1, nblocks=20,
+                              channel_growth=0, channel_width=256, kernel_size=7, stack_size=10,
+                              dilation_growth=2, condition=False, latent_dim=2, norm_type="identity",
+                              causal=False, estimate_loudness=False)
+    elif workload == "demucs":                               # cfg/model/demucs.yaml
+        net = models.DemucsModel(sample_rate=SR, sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
+    else:
+        raise ValueError(workload)
+    model = models.RemFX(lr=1e-4, lr_beta1=0.95, lr_beta2=0.999, lr_eps=1e-6, lr_weight_decay=1e-3,
+                         sample_rate=SR, network=net)
+    return model.to(device)
+
+
+def synthetic_batch(batch, rank, device, clip=CLIP):
+    g = torch.Generator().manual_seed(12345 + rank)
+    x = torch.randn(batch, 1, clip, generator=g) * 0.1       # ~ -20 dB white noise
+    y = torch.randn(batch, 1, clip, generator=g) * 0.1
+    lab = torch.zeros(batch, 5)
+    return tuple(t.to(device) for t in (x, y, lab, lab.clone()))
+
+
+class KernelTimer:
+    """HIP-event timing of the dominant kernel family (gather-GEMM launches) on the stream
+    they are launched on; also accumulates their algorithmic FLOPs (2*M*K*positions*N)."""
+
+    def __init__(self):
+        self.events, self.flops, self.enabled = [], 0.0, False
+
+    def install(self):
+        from remfx_amd import ops
+        orig = ops.gemm_fwd
+        timer = self
+
+        def timed(dp, apack, x, out, *a, **kw):
+            if not timer.enabled:
+                return orig(dp, apack, x, out, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(dp, apack, x, out, *a, **kw)
+            e.record()
+            p = dp.p
+            k = p.extra["n_weight_rows"] + (kw["dp2"].p.extra["n_weight_rows"] if kw.get("dp2") is not None else 0)
+            timer.flops += 2.0 * p.M * k * p.OA * p.OB * p.N
+            timer.events.append((s, e))
+            return r
+        ops.gemm_fwd = timed
+        import remfx_amd.tcn as tcn_mod
+        tcn_mod.ops.gemm_fwd = timed
+
+    def result(self):
+        ms = sum(s.elapsed_time(e) for s, e in self.events)
+        return ms, len(self.events)
+
+
+def cpu_baseline(workload):
+    """The CPU oracle (pure-torch restatement of the reference) timed on the host cores, one
+    bounded sample of the same workload: fwd + bwd of the removal network + loss."""
+    from oracle import ref_hdemucs, ref_losses, ref_tcn
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    if workload == "tcn":
+        T, B = 32768, 1
+        sd = {k: v.requires_grad_(True) for k, v in ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7).items()}
+        x, y = torch.randn(B, 1, T, generator=g) * 0.1, torch.randn(B, 1, T, generator=g) * 0.1
+        t0 = time.time()
+        out = ref_tcn.tcn_forward(x, sd, 20)
+        from oracle.ref_utils import causal_crop
+        loss = ref_losses.removal_loss(out, causal_crop(y, out.shape[-1]))
+        loss.backward()
+        dt = time.time() - t0
+        sample = f"oracle TCN (cfg/model/tcn.yaml) fwd+bwd, {B} x {T} samples"
+    else:
+        T, B = CLIP, 1
+        torch.manual_seed(0)
+        net = ref_hdemucs.HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
+        x, y = torch.randn(B, 1, T, generator=g) * 0.1, torch.randn(B, 1, T, generator=g) * 0.1
+        t0 = time.time()
+        out = net(x).squeeze(1)
+        loss = ref_losses.removal_loss(out, y)
+        loss.backward()
+        dt = time.time() - t0
+        sample = f"oracle HDemucs (cfg/model/demucs.yaml) fwd+bwd, {B} x {T} samples"
+    return {"value": round(B * T / SR / dt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("RFX_WORKLOAD", "tcn"))
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from remfx_amd import ddp
+    rank, local, world = ddp.init_from_env()
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    batch = args.batch or {"tcn": 32, "demucs": 64}[args.workload]
+
+    model = build_model(args.workload, device)
+    cfg = model.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    ddp.broadcast_parameters(opt.flat.data)
+    sync = ddp.GradSync(opt.flat)
+    data = synthetic_batch(batch, rank, device)
+    timer = KernelTimer()
+    timer.install()
+
+    def step(i):
+        opt.zero_grad()
+        loss = model.training_step(data, i)
+        loss.backward()
+        pre = sync.finish()
+        opt.step(clip_norm=10.0, grad_prescale=pre)           # cfg/config.yaml:119
+        sched.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    timer.enabled = True
+    t0 = time.time()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.time() - t0
+    timer.enabled = False
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t)
+    if rank != 0:
+        return
+    audio_s = world * batch * CLIP / SR * args.steps
+    kms, klaunches = timer.result()
+    achieved = timer.flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    out = {
+        "metric": "audio-seconds/sec fwd+bwd (whole job)", "value": round(audio_s / dt, 3),
+        "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": {"tcn": "TCN (cfg/model/tcn.yaml) train step, +exp=reverb model=tcn",
+                                "demucs": "Hybrid Demucs (cfg/model/demucs.yaml) train step, +exp=chorus_aug model=demucs"}[args.workload],
+                   "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
+                   "step": "fwd + MRSTFT+100*L1 loss + bwd + clip 10 + AdamW + per-step metrics",
+                   "parallelism": f"dp{world}", "final_loss": round(float(loss), 5)},
+        "roofline": {"bound": "mfma", "kernel": "gemm_fwd_kernel (gather-GEMM, v_mfma_f32_32x32x2_f32)",
+                     "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+                     "launches": klaunches, "avg_launch_ms": round(kms / max(klaunches, 1), 4),
+                     "share_of_step": round(kms / (dt * 1e3), 3)},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -184,6 +184,17 @@ int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, float* g, vo
 int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t L, int64_t x_rs, int64_t t_rs,
                    double* sums, void* stream);
 
+/* ---- optimiser (flat fp32 buffers) ----------------------------------------------
+ * Replaces torch.optim.AdamW.step + Lightning gradient_clip_val (models.py:185-191,
+ * cfg/config.yaml:119).  *out += sum g^2 (fp64). */
+int rfx_sumsq(const float* g, int64_t n, double* out, void* stream);
+/* *coef = min(1, max_norm / (sqrt(*sumsq) * pre + 1e-6)) * pre ; *norm_out = sqrt(*sumsq) * pre */
+int rfx_clip_coef(const double* sumsq, float max_norm, float pre, float* coef, float* norm_out, void* stream);
+/* decoupled-weight-decay Adam, torch.optim.AdamW semantics; gradients are multiplied by
+ * *gscale (device scalar, may be NULL) before use. */
+int rfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                   float eps, float wd, int32_t step, const float* gscale, void* stream);
+
 int rfx_abi_version(void);
 /* channel tiles per wave the MFMA forward kernel will use for M output rows (0 = thin path);
  * the packed A matrix must have Mpad = ceil(M / (32*R)) * 32*R  (R=0: Mpad = 8). */

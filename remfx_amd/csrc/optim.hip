@@ -1,0 +1,80 @@
+// Optimiser step of the training path on one flat parameter / gradient buffer:
+// global gradient-norm clipping (Lightning gradient_clip_val=10.0, cfg/config.yaml:119)
+// and AdamW (models.py:185-191: betas (0.95, 0.999), eps 1e-6, weight_decay 1e-3).
+// HBM-bound: 4 streams read (p, g, m, v), 3 written, float4 grid-stride.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+  double acc = 0.0;
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    acc += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += (double)g[i] * g[i];
+  acc = rfx_wave_sum_d(acc);
+  __shared__ double part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// gscale_ptr (device, optional): every gradient is multiplied by *gscale_ptr first (clip coefficient
+// and/or 1/world_size), so clipping needs no host round trip.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                    float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2, const float* __restrict__ gscale_ptr) {
+  const float gs = gscale_ptr ? *gscale_ptr : 1.f;
+  const float step = lr / bc1, rbc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] * decay - step * mi / (sqrtf(vi) * rbc2 + eps);
+  }
+}
+
+// coef = min(1, max_norm / (sqrt(sumsq * pre^2) + 1e-6)) * pre      (torch clip_grad_norm_ semantics;
+// pre = scale already owed to the gradients, e.g. 1/world_size after a summing all-reduce)
+__global__ void clip_coef_kernel(const double* __restrict__ sumsq, float max_norm, float pre, float* __restrict__ coef,
+                                 float* __restrict__ norm_out) {
+  const float norm = (float)sqrt(*sumsq) * pre;
+  if (norm_out) *norm_out = norm;
+  float c = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.f;
+  *coef = (c < 1.f ? c : 1.f) * pre;
+}
+
+static int gridn(int64_t n) {
+  const int64_t b = (n + 1023) / 1024;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+extern "C" int rfx_sumsq(const float* g, int64_t n, double* out, void* stream) {
+  if (!g || !out || n < 0) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(gridn(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_clip_coef(const double* sumsq, float max_norm, float pre, float* coef, float* norm_out,
+                             void* stream) {
+  if (!sumsq || !coef) return -1;
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, pre, coef, norm_out);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                              float b2, float eps, float wd, int32_t step, const float* gscale, void* stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return -1;
+  if (n == 0) return 0;
+  const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(gridn(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2,
+                     eps, wd, bc1, bc2, gscale);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

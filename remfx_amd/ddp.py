@@ -1,0 +1,98 @@
+"""Data-parallel gradient exchange: one process per GPU, torch.distributed (backend
+"nccl" == RCCL on ROCm) over xGMI.
+
+The path shards over independent clips: the only data-path collective is
+one SUM all-reduce of the flat gradient buffer per step.  xGMI is point-to-point
+(7 links x ~153 GB/s per GPU), so instead of many small per-tensor collectives the
+flat buffer (remfx_amd/optim.FlatParams) is cut into a few large buckets that are
+reduced asynchronously as soon as backward has produced every gradient inside them
+(deepest layers first), overlapping the remaining backward compute.  The 1/world_size
+mean is folded into the optimiser's gradient scale (no extra pass over the buffer).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the launcher (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def broadcast_parameters(flat_data, src=0):
+    """Replicas start from rank 0's weights (and buffers passed in as extra tensors)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_data, src)
+
+
+class GradSync:
+    """Bucketed async all-reduce of a FlatParams gradient buffer, overlapped with backward."""
+
+    def __init__(self, flat, bucket_mb=64.0, overlap=True):
+        self.flat = flat
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.handles = []
+        self.overlap = overlap and self.world > 1
+        # buckets over the flat buffer in REVERSE parameter order (backward produces the last
+        # layers' gradients first); boundaries fall on parameter boundaries
+        limit = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets, self.bucket_of = [], {}
+        hi = flat.numel
+        cur_lo, cur_params = hi, []
+        for idx in range(len(flat.params) - 1, -1, -1):
+            cur_lo = flat.offsets[idx]
+            cur_params.append(idx)
+            if hi - cur_lo >= limit or idx == 0:
+                b = len(self.buckets)
+                self.buckets.append({"lo": cur_lo, "hi": hi, "n": len(cur_params), "ready": 0})
+                for i in cur_params:
+                    self.bucket_of[i] = b
+                hi, cur_params = cur_lo, []
+        if self.overlap:
+            for idx, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(idx))
+
+    def _make_hook(self, idx):
+        def hook(_p):
+            b = self.buckets[self.bucket_of[idx]]
+            b["ready"] += 1
+            if b["ready"] == b["n"]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        self.handles.append(dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """Call after backward: launch whatever has not been reduced yet, wait, reset."""
+        if self.world == 1:
+            return 1.0
+        for b in self.buckets:
+            if not self.overlap or b["ready"] != b["n"]:
+                self._launch(b)       # parameters without a gradient this step never fire their hook
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        for b in self.buckets:
+            b["ready"] = 0
+        return 1.0 / self.world       # fold the mean into the optimiser's gradient scale
+
+
+def all_reduce_mean_scalar(t):
+    """sync_dist=True logging (models.py:135,144,244,254): mean of a scalar over ranks."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t /= dist.get_world_size()
+    return t

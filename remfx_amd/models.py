@@ -1,0 +1,213 @@
+"""Host-side mirror of remfx.models for the effect-removal hot path.
+
+Same class names, constructor arguments, step semantics, logged metric names and
+state_dict layout as reference remfx/models.py (RemFX :152-256, TCNModel :370-390,
+DemucsModel :307-324, RemFXChainInference :22-149), so the Hydra ``_target_``
+strings of cfg/model/*.yaml resolve to these classes.  The
+arithmetic (networks, losses, metrics) runs on the HIP kernels; this file is
+orchestration only.  pytorch_lightning is optional: without it the classes are
+plain nn.Modules driven by remfx_amd.trainer.
+"""
+import random
+
+import torch
+from torch import Tensor, nn
+
+from .losses import L1Loss, MultiResolutionSTFTLoss, SISDRLoss
+from .tcn import TCN
+from .utils import causal_crop
+
+try:  # the reference derives from pl.LightningModule; keep that when lightning is installed
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # not installed in this image
+    pl = None
+
+    class _Base(nn.Module):
+        """Minimal LightningModule surface used by the reference code paths."""
+
+        def __init__(self):
+            super().__init__()
+            self.logged = {}
+            self.trainer = None
+
+        def log(self, name, value, **kwargs):
+            self.logged[name] = value.detach() if torch.is_tensor(value) else value
+
+
+# label order of effects.Pedalboard_Effects (effects.py:699-707); class NAMES are the dict keys
+ALL_EFFECT_NAMES = ["RandomPedalboardReverb", "RandomPedalboardChorus", "RandomPedalboardDelay",
+                    "RandomPedalboardDistortion", "RandomPedalboardCompressor"]
+
+
+class RemFX(_Base):
+    def __init__(self, lr: float, lr_beta1: float, lr_beta2: float, lr_eps: float, lr_weight_decay: float,
+                 sample_rate: float, network: nn.Module):
+        super().__init__()
+        self.lr, self.lr_beta1, self.lr_beta2 = lr, lr_beta1, lr_beta2
+        self.lr_eps, self.lr_weight_decay, self.sample_rate = lr_eps, lr_weight_decay, sample_rate
+        self.model = network
+        self.metrics = nn.ModuleDict({"SISDR": SISDRLoss(), "STFT": MultiResolutionSTFTLoss()})
+        self.log_train_audio = True
+        self.output_str = "IN_SISDR,OUT_SISDR,IN_STFT,OUT_STFT\n"
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def configure_optimizers(self):
+        """models.py:185-206.  Returns the same structure; the optimiser is the flat HIP AdamW
+        when the parameters live on the GPU."""
+        from .optim import FlatAdamW, FlatParams, MultiStepLR
+        flat = FlatParams(list(self.model.parameters()))
+        optimizer = FlatAdamW(flat, lr=self.lr, betas=(self.lr_beta1, self.lr_beta2), eps=self.lr_eps,
+                              weight_decay=self.lr_weight_decay)
+        max_steps = self.trainer.max_steps if self.trainer is not None else 50000
+        sched = MultiStepLR(optimizer, [0.8 * max_steps, 0.95 * max_steps], gamma=0.1)
+        return {"optimizer": optimizer,
+                "lr_scheduler": {"scheduler": sched, "monitor": "val_loss", "interval": "step", "frequency": 1}}
+
+    def training_step(self, batch, batch_idx):
+        return self.common_step(batch, batch_idx, mode="train")
+
+    def validation_step(self, batch, batch_idx):
+        return self.common_step(batch, batch_idx, mode="valid")
+
+    def test_step(self, batch, batch_idx):
+        return self.common_step(batch, batch_idx, mode="test")
+
+    def common_step(self, batch, batch_idx, mode: str = "train"):
+        x, y, _, _ = batch                                     # (B, C, T) each
+        loss, output = self.model((x, y))
+        target = y
+        if output.shape[-1] < y.shape[-1]:                     # models.py:222-224
+            target = causal_crop(y, output.shape[-1])
+        self.log(f"{mode}_loss", loss)
+        with torch.no_grad():
+            for metric in self.metrics:
+                negate = -1 if metric == "SISDR" else 1        # SISDR loss is -SI-SDR
+                self.log(f"{mode}_{metric}", negate * self.metrics[metric](output.detach(), target),
+                         on_step=False, on_epoch=True, logger=True, prog_bar=True, sync_dist=True)
+                self.log(f"Input_{metric}", negate * self.metrics[metric](x, y),
+                         on_step=False, on_epoch=True, logger=True, prog_bar=True, sync_dist=True)
+        return loss
+
+
+class _RemovalWrapper(nn.Module):
+    """forward((x, target)) -> (loss, output); sample(x) -> output; loss = MRSTFT + 100 * L1."""
+
+    def _loss(self, output, target):
+        return self.mrstftloss(output, target) + self.l1loss(output, target) * 100
+
+
+class TCNModel(_RemovalWrapper):
+    def __init__(self, sample_rate, num_bins, **kwargs):
+        super().__init__()
+        self.model = TCN(**kwargs)
+        self.mrstftloss = MultiResolutionSTFTLoss(n_bins=num_bins, sample_rate=sample_rate)
+        self.l1loss = L1Loss()
+
+    def forward(self, batch):
+        x, target = batch
+        output = self.model(x)                                 # B x 1 x T'
+        if output.shape[-1] < target.shape[-1]:                # models.py:383-384
+            target = causal_crop(target, output.shape[-1])
+        return self._loss(output, target), output
+
+    def sample(self, x: Tensor) -> Tensor:
+        return self.model(x)
+
+
+class DemucsModel(_RemovalWrapper):
+    def __init__(self, sample_rate, **kwargs) -> None:
+        super().__init__()
+        from .hdemucs import HDemucs
+        self.model = HDemucs(**kwargs)
+        self.num_bins = kwargs["nfft"] // 2 + 1
+        self.mrstftloss = MultiResolutionSTFTLoss(n_bins=self.num_bins, sample_rate=sample_rate)
+        self.l1loss = L1Loss()
+
+    def forward(self, batch):
+        x, target = batch
+        output = self.model(x).squeeze(1)
+        return self._loss(output, target), output
+
+    def sample(self, x: Tensor) -> Tensor:
+        return self.model(x).squeeze(1)
+
+
+class RemFXChainInference(_Base):
+    """Classifier -> threshold -> per-clip ordered chain of effect-removal models
+    (models.py:22-149).  Clips that share a detected-effect signature are batched
+    together per removal model (numerically identical for GroupNorm-only networks;
+    SURVEY 3.3), instead of the reference's batch-1 python loop."""
+
+    def __init__(self, models, sample_rate, num_bins, effect_order, classifier=None,
+                 shuffle_effect_order=False, use_all_effect_models=False):
+        super().__init__()
+        self.model = models                                     # plain dict, as upstream (Q6)
+        self.mrstftloss = MultiResolutionSTFTLoss(n_bins=num_bins, sample_rate=sample_rate)
+        self.l1loss = L1Loss()
+        self.metrics = nn.ModuleDict({"SISDR": SISDRLoss(), "STFT": MultiResolutionSTFTLoss()})
+        self.sample_rate = sample_rate
+        self.effect_order = effect_order
+        self.classifier = classifier
+        self.shuffle_effect_order = shuffle_effect_order
+        self.output_str = "IN_SISDR,OUT_SISDR,IN_STFT,OUT_STFT\n"
+        self.use_all_effect_models = use_all_effect_models
+        self.last_labels = None
+
+    def forward(self, batch, batch_idx, order=None, verbose=False):
+        x, y, _, rem_fx_labels = batch
+        effects_order = order if order else self.effect_order
+        if self.classifier:
+            with torch.no_grad():
+                labels = torch.hstack(self.classifier(x))
+                rem_fx_labels = torch.where(labels > 0.5, 1.0, 0.0)    # strict >, models.py:61-64
+        self.last_labels = rem_fx_labels
+        lab = rem_fx_labels.detach().cpu()
+        if self.use_all_effect_models:
+            present = [list(ALL_EFFECT_NAMES) for _ in range(x.shape[0])]
+        else:
+            present = [[ALL_EFFECT_NAMES[i] for i, e in enumerate(row) if float(e) == 1.0] for row in lab]
+        if verbose and present:
+            print("Detected effects:", present[0])
+            print("Removing effects...")
+        chains = [tuple(e for e in effects_order if e in names) for names in present]
+        output = x.clone()
+        with torch.no_grad():
+            # group clips by their remaining chain; run each removal model on sub-batches
+            todo = {i: list(c) for i, c in enumerate(chains)}
+            while any(todo.values()):
+                groups = {}
+                for i, c in todo.items():
+                    if c:
+                        groups.setdefault(c[0], []).append(i)
+                for effect, idxs in groups.items():
+                    sel = torch.tensor(idxs, device=x.device)
+                    res = self.model[effect].model.sample(output.index_select(0, sel))
+                    output.index_copy_(0, sel, res)
+                    for i in idxs:
+                        todo[i].pop(0)
+        loss = self.mrstftloss(output, y) + self.l1loss(output, y) * 100
+        return loss, output
+
+    def test_step(self, batch, batch_idx):
+        x, y, _, _ = batch
+        if self.shuffle_effect_order:
+            random.shuffle(self.effect_order)                    # in place, as upstream (Q7)
+        loss, output = self.forward(batch, batch_idx, order=self.effect_order)
+        if output.shape[-1] < y.shape[-1]:
+            y = causal_crop(y, output.shape[-1])
+        self.log("test_loss", loss)
+        with torch.no_grad():
+            for metric in self.metrics:
+                negate = -1 if metric == "SISDR" else 1
+                self.log(f"test_{metric}", negate * self.metrics[metric](output, y), on_step=False,
+                         on_epoch=True, logger=True, prog_bar=True, sync_dist=True)
+                self.log(f"Input_{metric}", negate * self.metrics[metric](x, y), on_step=False,
+                         on_epoch=True, logger=True, prog_bar=True, sync_dist=True)
+        return loss
+
+    def sample(self, batch):
+        return self.forward(batch, 0)[1]

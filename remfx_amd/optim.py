@@ -1,0 +1,101 @@
+"""Flat-buffer optimiser for the training path (models.py:185-206, cfg/config.yaml:119).
+
+All parameters of the network are re-seated as views into ONE contiguous fp32 buffer and
+their .grad tensors as views into ONE contiguous gradient buffer.  That makes
+  * the AdamW step one HIP launch over 6..84 M elements (HBM-bound, 16 B/elt streams),
+  * global grad-norm clipping one reduction + a device-side coefficient (no host sync),
+  * the data-parallel gradient exchange a handful of large RCCL all-reduces over xGMI
+    on slices of the same buffer (remfx_amd/ddp.py) -- no per-tensor collectives.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _ptr, _stream
+
+
+class FlatParams:
+    def __init__(self, params, allow_cpu=False):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda" and not allow_cpu:   # allow_cpu: collective-plumbing tests only (gloo)
+            raise ValueError("FlatParams needs parameters on the GPU (no CPU fallback)")
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4           # keep every view 16-byte aligned
+        self.numel = n
+        self.data = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
+            v = self.data[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):      # re-seat in case something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) on FlatParams."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(flat.data)
+        self.v = torch.zeros_like(flat.data)
+        self.step_count = 0
+        dev = flat.data.device
+        self._sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+        self._coef = torch.ones(1, device=dev, dtype=torch.float32)
+        self.last_grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.param_groups = [{"lr": lr}]                 # scheduler-facing, as torch optimisers
+
+    def step(self, clip_norm=None, grad_prescale=1.0):
+        """One update.  clip_norm: global L2 norm clip (Lightning gradient_clip_val);
+        grad_prescale: factor already owed to the gradients (1/world_size after a SUM all-reduce)."""
+        L, f = _lib.lib(), self.flat
+        self.step_count += 1
+        gscale = None
+        if clip_norm or grad_prescale != 1.0:
+            self._sumsq.zero_()
+            check(L.rfx_sumsq(_ptr(f.grad), f.numel, _ptr(self._sumsq), _stream()), "rfx_sumsq")
+            check(L.rfx_clip_coef(_ptr(self._sumsq), float(clip_norm or 0.0), float(grad_prescale),
+                                  _ptr(self._coef), _ptr(self.last_grad_norm), _stream()), "rfx_clip_coef")
+            gscale = self._coef
+        lr = self.param_groups[0]["lr"]
+        check(L.rfx_adamw_step(_ptr(f.data), _ptr(f.grad), _ptr(self.m), _ptr(self.v), f.numel, lr,
+                               self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
+                               _ptr(gscale), _stream()), "rfx_adamw_step")
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"]); self.param_groups[0]["lr"] = float(sd["lr"])
+
+
+class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma), stepped per batch
+    (models.py:192-205: milestones at 80 % / 95 % of max_steps, gamma 0.1)."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1):
+        self.opt, self.milestones, self.gamma = optimizer, sorted(float(m) for m in milestones), gamma
+        self.base_lr = optimizer.param_groups[0]["lr"]
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+        k = sum(1 for m in self.milestones if self.last_epoch >= m)
+        self.opt.param_groups[0]["lr"] = self.base_lr * self.gamma ** k
