@@ -169,6 +169,24 @@ int rfx_channel_sum(const float* x, int32_t N, int32_t C, int32_t A, int32_t B, 
 /* sum |a-b| over n elements -> *out (+=, caller zeroes).  nn.L1Loss numerator, models.py:320 */
 int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream);
 
+/* ---- GroupNorm (+ fused activation) --------------------------------------------
+ * x: (N, C, S) contiguous, G groups.  mode: 0 y = gn(x); 1 y = gelu(gn(x));
+ * 2 y = glu(gn(x)) -> (N, C/2, S); 3 y = res + scale[c] * glu(gn(x))  (DConv tail).
+ * Replaces nn.GroupNorm + F.gelu / F.glu / _LayerScale inside torchaudio HDemucs
+ * (models.py:319).  mean / rstd (N*G each) are written for the backward. */
+int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C, int32_t S,
+                      int32_t G, float eps, int32_t mode, const float* res, const float* scale, float* mean,
+                      float* rstd, float* y, void* stream);
+/* dx (N, C, S); dgamma / dbeta (C) and dscale (C/2, mode 3) are accumulated with atomics into
+ * zero-initialised buffers; gsum is an (N*G, 2) workspace; the residual gradient of mode 3 is gy. */
+int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
+                      const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S, int32_t G,
+                      int32_t mode, const float* scale, float* gsum, float* dx, float* dgamma, float* dbeta,
+                      float* dscale, void* stream);
+/* GLU over the channel axis of (N, C, S): y = x[:, :C/2] * sigmoid(x[:, C/2:]) */
+int rfx_glu_fwd(const float* x, float* y, int64_t N, int64_t C, int64_t S, void* stream);
+int rfx_glu_bwd(const float* x, const float* gy, float* gx, int64_t N, int64_t C, int64_t S, void* stream);
+
 /* ---- losses -------------------------------------------------------------------
  * auraloss STFTLoss terms on complex spectra [R][n] (n = bins*frames, view_as_real layout):
  * sums[r] += { sum (|Y|-|X|)^2, sum |Y|^2, sum |log|X| - log|Y|| }, |.| = sqrt(max(re^2+im^2, eps)).

@@ -1,0 +1,365 @@
+"""Hybrid Demucs (torchaudio.models.HDemucs as RemFX configures it: reference
+remfx/models.py:307-324, cfg/model/demucs.yaml:11-16) on the HIP kernels.
+
+Same constructor signature, sub-module names and state_dict keys as the upstream
+class (freq_encoder.{i}.conv / norm1 / rewrite / norm2 / dconv.layers.{d}.{idx},
+time_encoder, freq_decoder.{j}.conv_tr / norm2 / rewrite / norm1, time_decoder,
+freq_emb.embedding.weight), so RemFX checkpoints load strictly.
+nn.Conv* / nn.GroupNorm / nn.LSTM objects are PARAMETER CONTAINERS only; the
+arithmetic goes through remfx_amd.ops / stft / nnops (HIP kernels behind the C ABI).
+
+Data layout in HBM: spectrogram branch (B, C, Fr, T) with T (256 frames) contiguous,
+time branch (B, C, L) with L contiguous -- the gather-GEMM kernels take the position
+axis from the contiguous dimension, so both branches are read coalesced.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nnops, ops, stft
+
+
+class _ScaledEmbedding(nn.Module):
+    def __init__(self, num_embeddings, embedding_dim, scale=10.0, smooth=False):
+        super().__init__()
+        self.embedding = nn.Embedding(num_embeddings, embedding_dim)
+        if smooth:
+            w = torch.cumsum(self.embedding.weight.data, dim=0)
+            w = w / torch.arange(1, num_embeddings + 1).sqrt()[:, None]
+            self.embedding.weight.data[:] = w
+        self.embedding.weight.data /= scale
+        self.scale = scale
+
+    def table(self):
+        """(num_embeddings, dim) scaled table == forward(arange(n))."""
+        return self.embedding.weight * self.scale
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, channels, init=0.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.full((channels,), float(init)))
+
+
+class _BLSTM(nn.Module):
+    def __init__(self, dim, layers=2, skip=True):
+        super().__init__()
+        self.max_steps = 200
+        self.lstm = nn.LSTM(bidirectional=True, num_layers=layers, hidden_size=dim, input_size=dim)
+        self.linear = nn.Linear(2 * dim, dim)
+        self.skip = skip
+
+    def forward(self, x):
+        B, C, T = x.shape
+        y = x
+        framed = T > self.max_steps
+        if framed:
+            width, stride = self.max_steps, self.max_steps // 2
+            nfr = math.ceil(T / stride)
+            xp = F.pad(x, (0, (nfr - 1) * stride + width - T))
+            x = xp.unfold(-1, width, stride).permute(0, 2, 1, 3).reshape(-1, C, width)
+        x = x.permute(2, 0, 1).contiguous()
+        x = nnops.lstm(self.lstm, x)
+        x = nnops.linear(x, self.linear.weight, self.linear.bias).permute(1, 2, 0)
+        if framed:
+            fr = x.reshape(B, nfr, C, width)
+            lim = stride // 2
+            parts = [fr[:, 0, :, :-lim]] + [fr[:, k, :, lim:-lim] for k in range(1, nfr - 1)] + [fr[:, nfr - 1, :, lim:]]
+            x = torch.cat(parts, -1)[..., :T]
+        return x + y if self.skip else x
+
+
+class _LocalState(nn.Module):
+    def __init__(self, channels, heads=4, ndecay=4):
+        super().__init__()
+        self.heads, self.ndecay = heads, ndecay
+        self.content = nn.Conv1d(channels, channels, 1)
+        self.query = nn.Conv1d(channels, channels, 1)
+        self.key = nn.Conv1d(channels, channels, 1)
+        self.query_decay = nn.Conv1d(channels, heads * ndecay, 1)
+        self.query_decay.weight.data *= 0.01
+        self.query_decay.bias.data[:] = -2
+        self.proj = nn.Conv1d(channels, channels, 1)
+
+    def forward(self, x):
+        B, C, T = x.shape
+        h = self.heads
+        idx = torch.arange(T, device=x.device, dtype=x.dtype)
+        delta = idx[:, None] - idx[None, :]
+        q = ops.conv1d(x, self.query.weight, self.query.bias).view(B, h, -1, T)
+        k = ops.conv1d(x, self.key.weight, self.key.bias).view(B, h, -1, T)
+        dots = nnops.einsum("bhct,bhcs->bhts", k, q) / math.sqrt(k.shape[2])
+        decays = torch.arange(1, self.ndecay + 1, device=x.device, dtype=x.dtype)
+        dq = torch.sigmoid(ops.conv1d(x, self.query_decay.weight, self.query_decay.bias).view(B, h, -1, T)) / 2
+        kern = -decays.view(-1, 1, 1) * delta.abs() / math.sqrt(self.ndecay)
+        dots = dots + nnops.einsum("fts,bhfs->bhts", kern, dq)
+        dots = dots.masked_fill(torch.eye(T, device=x.device, dtype=torch.bool), -100)
+        w = nnops.softmax(dots, dim=2)
+        c = ops.conv1d(x, self.content.weight, self.content.bias).view(B, h, -1, T)
+        res = nnops.einsum("bhts,bhct->bhcs", w, c).reshape(B, -1, T)
+        return x + ops.conv1d(res, self.proj.weight, self.proj.bias)
+
+
+class _DConv(nn.Module):
+    def __init__(self, channels, compress=4, depth=2, init=1e-4, norm_type="group_norm", attn=False,
+                 heads=4, ndecay=4, lstm=False, kernel_size=3):
+        super().__init__()
+        hidden = int(channels / compress)
+        self.layers = nn.ModuleList()
+        self.spec = []
+        for d in range(depth):
+            dil = 2 ** d
+            mods = [nn.Conv1d(channels, hidden, kernel_size, dilation=dil, padding=dil * (kernel_size // 2)),
+                    nn.GroupNorm(1, hidden), nn.GELU(), nn.Conv1d(hidden, 2 * channels, 1),
+                    nn.GroupNorm(1, 2 * channels), nn.GLU(1), _LayerScale(channels, init)]
+            if attn:
+                mods.insert(3, _LocalState(hidden, heads=heads, ndecay=ndecay))
+            if lstm:
+                mods.insert(3, _BLSTM(hidden, layers=2, skip=True))
+            self.layers.append(nn.Sequential(*mods))
+            self.spec.append((dil, dil * (kernel_size // 2), lstm, attn))
+
+    def forward(self, x):
+        for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
+            mods = list(seq)
+            y = ops.conv1d(x, mods[0].weight, mods[0].bias, 1, pad, dil)
+            y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu")
+            i = 3
+            if lstm:
+                y = mods[i](y); i += 1
+            if attn:
+                y = mods[i](y); i += 1
+            y = ops.conv1d(y, mods[i].weight, mods[i].bias)
+            x = nnops.group_norm(y, 1, mods[i + 1].weight, mods[i + 1].bias, mods[i + 1].eps,
+                                 mode="glu_scale_res", res=x, scale=mods[i + 3].scale)
+        return x
+
+
+def _norm(groups, ch, on):
+    return nn.GroupNorm(groups, ch) if on else nn.Identity()
+
+
+def _norm_act(m, x, act):
+    """act(norm(x)) with act in {none, gelu, glu}; norm may be nn.Identity."""
+    if isinstance(m, nn.GroupNorm):
+        return nnops.group_norm(x, m.num_groups, m.weight, m.bias, m.eps, mode=act)
+    if act == "gelu":
+        return nnops.gelu(x)
+    if act == "glu":
+        return nnops.glu(x, 1)
+    return x
+
+
+class _HEncLayer(nn.Module):
+    def __init__(self, chin, chout, kernel_size=8, stride=4, norm_groups=4, empty=False, freq=True,
+                 norm_type="group_norm", context=0, dconv_kw=None, pad=True):
+        super().__init__()
+        padv = kernel_size // 4 if pad else 0
+        self.freq, self.kernel_size, self.stride, self.empty, self.pad = freq, kernel_size, stride, empty, padv
+        self.context = context
+        norm = norm_type == "group_norm"
+        if freq:
+            self.conv = nn.Conv2d(chin, chout, (kernel_size, 1), (stride, 1), (padv, 0))
+        else:
+            self.conv = nn.Conv1d(chin, chout, kernel_size, stride, padv)
+        self.norm1 = _norm(norm_groups, chout, norm)
+        if empty:
+            self.rewrite, self.norm2, self.dconv = nn.Identity(), nn.Identity(), nn.Identity()
+        else:
+            klass = nn.Conv2d if freq else nn.Conv1d
+            self.rewrite = klass(chout, 2 * chout, 1 + 2 * context, 1, context)
+            self.norm2 = _norm(norm_groups, 2 * chout, norm)
+            self.dconv = _DConv(chout, **(dconv_kw or {}))
+
+    def forward(self, x, inject=None):
+        if not self.freq and x.dim() == 4:
+            x = x.reshape(x.shape[0], -1, x.shape[-1])
+        if self.freq:
+            y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0))
+        else:
+            if x.shape[-1] % self.stride:
+                x = F.pad(x, (0, self.stride - x.shape[-1] % self.stride))
+            y = ops.conv1d(x, self.conv.weight, self.conv.bias, self.stride, self.pad)
+        if self.empty:
+            return y
+        if inject is not None:
+            if inject.dim() == 3 and y.dim() == 4:
+                inject = inject[:, :, None]
+            y = y + inject
+        y = _norm_act(self.norm1, y, "gelu")
+        if self.freq:
+            B, C, Fr, T = y.shape
+            y = self.dconv(y.permute(0, 2, 1, 3).reshape(-1, C, T))
+            y = y.view(B, Fr, C, T).permute(0, 2, 1, 3)
+            c = self.context
+            z = ops.conv2d(y, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c))
+        else:
+            y = self.dconv(y)
+            z = ops.conv1d(y, self.rewrite.weight, self.rewrite.bias, 1, self.context)
+        return _norm_act(self.norm2, z, "glu")
+
+
+class _HDecLayer(nn.Module):
+    def __init__(self, chin, chout, last=False, kernel_size=8, stride=4, norm_groups=1, empty=False,
+                 freq=True, norm_type="group_norm", context=1, dconv_kw=None, pad=True):
+        super().__init__()
+        self.pad = (kernel_size - stride) // 2 if pad else 0
+        self.last, self.freq, self.chin, self.empty = last, freq, chin, empty
+        self.stride, self.kernel_size, self.context = stride, kernel_size, context
+        norm = norm_type == "group_norm"
+        if freq:
+            self.conv_tr = nn.ConvTranspose2d(chin, chout, (kernel_size, 1), (stride, 1))
+        else:
+            self.conv_tr = nn.ConvTranspose1d(chin, chout, kernel_size, stride)
+        self.norm2 = _norm(norm_groups, chout, norm)
+        if empty:
+            self.rewrite, self.norm1 = nn.Identity(), nn.Identity()
+        else:
+            klass = nn.Conv2d if freq else nn.Conv1d
+            self.rewrite = klass(chin, 2 * chin, 1 + 2 * context, 1, context)
+            self.norm1 = _norm(norm_groups, 2 * chin, norm)
+
+    def forward(self, x, skip, length):
+        if self.freq and x.dim() == 3:
+            x = x.view(x.shape[0], self.chin, -1, x.shape[-1])
+        if not self.empty:
+            x = x + skip
+            c = self.context
+            if self.freq:
+                r = ops.conv2d(x, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c))
+            else:
+                r = ops.conv1d(x, self.rewrite.weight, self.rewrite.bias, 1, c)
+            y = _norm_act(self.norm1, r, "glu")
+        else:
+            y = x
+            if skip is not None:
+                raise ValueError("skip must be None when empty is true.")
+        if self.freq:      # crop [pad : -pad] along Fr folded into the transposed-conv plan
+            full = (y.shape[2] - 1) * self.stride + self.kernel_size
+            z = ops.conv_transpose2d(y, self.conv_tr.weight, self.conv_tr.bias, (self.stride, 1), (1, 1),
+                                     (self.pad, 0), (full - 2 * self.pad, y.shape[3]))
+        else:              # crop [pad : pad + length]
+            z = ops.conv_transpose1d(y, self.conv_tr.weight, self.conv_tr.bias, self.stride, 1, self.pad, length)
+        z = _norm_act(self.norm2, z, "none" if self.last else "gelu")
+        return z, y
+
+
+class HDemucs(nn.Module):
+    def __init__(self, sources, audio_channels=2, channels=48, growth=2, nfft=4096, depth=6, freq_emb=0.2,
+                 emb_scale=10, emb_smooth=True, kernel_size=8, time_stride=2, stride=4, context=1,
+                 context_enc=0, norm_starts=4, norm_groups=4, dconv_depth=2, dconv_comp=4, dconv_attn=4,
+                 dconv_lstm=4, dconv_init=1e-4):
+        super().__init__()
+        self.depth, self.nfft, self.audio_channels, self.sources = depth, nfft, audio_channels, list(sources)
+        self.kernel_size, self.context, self.stride, self.channels = kernel_size, context, stride, channels
+        self.hop_length = nfft // 4
+        self.freq_emb = None
+        self.freq_encoder, self.freq_decoder = nn.ModuleList(), nn.ModuleList()
+        self.time_encoder, self.time_decoder = nn.ModuleList(), nn.ModuleList()
+        chin, chin_z = audio_channels, audio_channels * 2
+        chout, chout_z = channels, channels
+        freqs = nfft // 2
+        for index in range(depth):
+            lstm, attn = index >= dconv_lstm, index >= dconv_attn
+            norm_type = "group_norm" if index >= norm_starts else "none"
+            freq = freqs > 1
+            stri, ker = stride, kernel_size
+            if not freq:
+                ker, stri = time_stride * 2, time_stride
+            pad, last_freq = True, False
+            if freq and freqs <= kernel_size:
+                ker, pad, last_freq = freqs, False, True
+            kw = {"kernel_size": ker, "stride": stri, "freq": freq, "pad": pad, "norm_type": norm_type,
+                  "norm_groups": norm_groups,
+                  "dconv_kw": {"lstm": lstm, "attn": attn, "depth": dconv_depth, "compress": dconv_comp,
+                               "init": dconv_init}}
+            kwt = dict(kw, freq=False, kernel_size=kernel_size, stride=stride, pad=True)
+            kw_dec = dict(kw)
+            if last_freq:
+                chout_z = max(chout, chout_z)
+                chout = chout_z
+            self.freq_encoder.append(_HEncLayer(chin_z, chout_z, context=context_enc, **kw))
+            if freq:
+                if last_freq and nfft == 2048:
+                    kwt["stride"], kwt["kernel_size"] = 2, 4
+                self.time_encoder.append(_HEncLayer(chin, chout, context=context_enc, empty=last_freq, **kwt))
+            if index == 0:
+                chin = audio_channels * len(self.sources)
+                chin_z = chin * 2
+            self.freq_decoder.insert(0, _HDecLayer(chout_z, chin_z, last=index == 0, context=context, **kw_dec))
+            if freq:
+                self.time_decoder.insert(0, _HDecLayer(chout, chin, empty=last_freq, last=index == 0,
+                                                       context=context, **kwt))
+            chin, chin_z = chout, chout_z
+            chout, chout_z = int(growth * chout), int(growth * chout_z)
+            if freq:
+                freqs = 1 if freqs <= kernel_size else freqs // stride
+            if index == 0 and freq_emb:
+                self.freq_emb = _ScaledEmbedding(freqs, chin_z, smooth=emb_smooth, scale=emb_scale)
+                self.freq_emb_scale = freq_emb
+        for m in self.modules():                         # init-time rescale, reference = 0.1
+            if isinstance(m, (nn.Conv1d, nn.ConvTranspose1d, nn.Conv2d, nn.ConvTranspose2d)):
+                s = (m.weight.std().detach() / 0.1) ** 0.5
+                m.weight.data /= s
+                if m.bias is not None:
+                    m.bias.data /= s
+
+    def forward(self, input):
+        if input.ndim != 3 or input.shape[1] != self.audio_channels:
+            raise ValueError(f"expected (batch, {self.audio_channels}, frames), got {tuple(input.shape)}")
+        ops._req(input, "input")
+        B, Cin, length = input.shape
+        hl = self.hop_length
+        le = math.ceil(length / hl)
+        pad = hl // 2 * 3
+        # _spec + _magnitude: STFT straight into complex-as-channels (B, 2*Cin, nfft/2, le)
+        cac = stft.stft(input.reshape(B * Cin, length), self.nfft, hl, mode="cac", normalized=True,
+                        bins=self.nfft // 2, frame0=2, frames_out=le, extra_pad=(pad, pad + le * hl - length))
+        Fq = self.nfft // 2
+        x = cac.view(B, Cin, 2, Fq, le).reshape(B, Cin * 2, Fq, le)
+        mean = x.mean(dim=(1, 2, 3), keepdim=True)
+        std = x.std(dim=(1, 2, 3), keepdim=True)
+        x = (x - mean) / (1e-5 + std)
+        xt = input
+        meant = xt.mean(dim=(1, 2), keepdim=True)
+        stdt = xt.std(dim=(1, 2), keepdim=True)
+        xt = (xt - meant) / (1e-5 + stdt)
+        saved, saved_t, lengths, lengths_t = [], [], [], []
+        for idx, encode in enumerate(self.freq_encoder):
+            lengths.append(x.shape[-1])
+            inject = None
+            if idx < len(self.time_encoder):
+                lengths_t.append(xt.shape[-1])
+                tenc = self.time_encoder[idx]
+                xt = tenc(xt)
+                if not tenc.empty:
+                    saved_t.append(xt)
+                else:
+                    inject = xt
+            x = encode(x, inject)
+            if idx == 0 and self.freq_emb is not None:
+                emb = self.freq_emb.table().t()[None, :, :, None]
+                x = x + self.freq_emb_scale * emb
+            saved.append(x)
+        x = torch.zeros_like(x)
+        xt = torch.zeros_like(x)
+        offset = self.depth - len(self.time_decoder)
+        for idx, decode in enumerate(self.freq_decoder):
+            x, pre = decode(x, saved.pop(-1), lengths.pop(-1))
+            if idx >= offset:
+                tdec = self.time_decoder[idx - offset]
+                length_t = lengths_t.pop(-1)
+                if tdec.empty:
+                    xt, _ = tdec(pre[:, :, 0], None, length_t)
+                else:
+                    xt, _ = tdec(xt, saved_t.pop(-1), length_t)
+        S = len(self.sources)
+        x = x.view(B, S, -1, Fq, le) * std[:, None] + mean[:, None]
+        # _mask + _ispec: (B, S, Cin*2, Fq, le) complex-as-channels -> time, one row per (b, s, c)
+        spec = x.view(B * S * Cin, 2, Fq, le)
+        xo = stft.istft(spec, self.nfft, hl, mode="cac", normalized=True, frames=le + 4, frame0=2, crop=pad,
+                        length=length).view(B, S, Cin, length)
+        xt = xt.view(B, S, -1, length) * stdt[:, None] + meant[:, None]
+        return xt + xo

@@ -1,0 +1,66 @@
+"""GPU parity: fused GroupNorm(+GELU/GLU/LayerScale-residual) and GLU kernels vs torch CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rms(a, b):
+    return float(((a - b) ** 2).mean().sqrt())
+
+
+@pytest.mark.parametrize("shape,groups", [((1024, 2, 20), 1), ((3, 48, 7, 33), 4), ((2, 12, 5000), 1),
+                                          ((5, 96, 64), 4), ((2, 8, 3, 50), 1)])
+@pytest.mark.parametrize("mode", ["none", "gelu", "glu", "glu_scale_res"])
+def test_groupnorm_modes(shape, groups, mode):
+    from remfx_amd import nnops
+    g = torch.Generator().manual_seed(hash((shape, groups, mode)) % 1000)
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    oshape = list(shape)
+    if mode.startswith("glu"):
+        oshape[1] = C // 2
+    res = torch.randn(oshape, generator=g)
+    sc = torch.randn(oshape[1], generator=g)
+    gy = torch.randn(oshape, generator=g)
+
+    def ref(x, w, b, res, sc):
+        u = F.group_norm(x, groups, w, b, 1e-5)
+        if mode == "gelu":
+            return F.gelu(u)
+        if mode == "glu":
+            return F.glu(u, 1)
+        if mode == "glu_scale_res":
+            return res + sc.view(1, -1, *([1] * (x.dim() - 2))) * F.glu(u, 1)
+        return u
+    tr = [t.clone().requires_grad_(True) for t in (x, w, b, res, sc)]
+    ref(*tr).backward(gy)
+    td = [t.to(DEV).requires_grad_(True) for t in (x, w, b, res, sc)]
+    if mode == "glu_scale_res":
+        out = nnops.group_norm(td[0], groups, td[1], td[2], 1e-5, mode, res=td[3], scale=td[4])
+    else:
+        out = nnops.group_norm(td[0], groups, td[1], td[2], 1e-5, mode)
+    out.backward(gy.to(DEV))
+    assert _rms(out.detach().cpu(), ref(x, w, b, res, sc)) < 1e-5
+    n = 5 if mode == "glu_scale_res" else 3
+    for i in range(n):
+        r = tr[i].grad
+        scale = max(1.0, float(r.abs().max()))
+        assert _rms(td[i].grad.cpu(), r) < 2e-5 * scale, (i, _rms(td[i].grad.cpu(), r), scale)
+
+
+def test_glu_plain():
+    from remfx_amd import nnops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 10, 4, 9, generator=g)
+    gy = torch.randn(3, 5, 4, 9, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.glu(xr, 1).backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = nnops.glu(xd, 1)
+    y.backward(gy.to(DEV))
+    assert _rms(y.detach().cpu(), F.glu(x, 1)) < 1e-6
+    assert _rms(xd.grad.cpu(), xr.grad) < 1e-6
