@@ -92,9 +92,9 @@ typedef struct rfx_epilogue {
  * operand prefetch is branch-free. */
 int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
                int32_t Mpad, int32_t Kpad, float* apack, void* stream);
-/* w[m*w_ms + woff[k]] += dapack[k][m]   (inverse of rfx_pack_a, accumulating). */
+/* w[m*w_ms + woff[k]] += dapack[m][k]  (dapack is the [M][Kpad] output of rfx_gemm_wgrad). */
 int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
-                   int32_t Mpad, float* dw, void* stream);
+                   int32_t Kpad, float* dw, void* stream);
 
 /* Forward gather-GEMM on the fp32 MFMA path (v_mfma_f32_32x32x2_f32).
  * Optional second phase (apack2/ktab2/K2 != 0): after phase 1 the epilogue
@@ -107,7 +107,7 @@ int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rfx_ktab_entr
                  void* stream);
 
 /* Weight gradient of the same descriptor:
- * dapack[k][m] += sum_{n,a,b} g[n*g_ns + m*g_cs + a'*g_as + b'*g_bs] * In(n,k,a,b)
+ * dapack[m][k] += sum_{n,a,b} g[n*g_ns + m*g_cs + a'*g_as + b'*g_bs] * In(n,k,a,b)   (dapack: [M][Kpad])
  * (g indexed with OUT coordinates/strides of the descriptor: out_* fields).
  * Rows k with ktab flag bit0 use In == 1 (bias gradient).  dapack must be
  * zero-initialised by the caller; partial sums are combined with fp32 atomics. */
@@ -175,13 +175,14 @@ int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stre
  * Replaces nn.GroupNorm + F.gelu / F.glu / _LayerScale inside torchaudio HDemucs
  * (models.py:319).  mean / rstd (N*G each) are written for the backward. */
 int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C, int32_t S,
-                      int32_t G, float eps, int32_t mode, const float* res, const float* scale, float* mean,
-                      float* rstd, float* y, void* stream);
-/* dx (N, C, S); dgamma / dbeta (C) and dscale (C/2, mode 3) are accumulated with atomics into
- * zero-initialised buffers; gsum is an (N*G, 2) workspace; the residual gradient of mode 3 is gy. */
+                      int32_t G, float eps, int32_t mode, const float* res, const float* scale,
+                      double* sums /* N*G*2 fp64 workspace */, float* mean, float* rstd, float* y,
+                      void* stream);
+/* dx (N, C, S); dgamma / dbeta (C) and dscale (C/2, mode 3) are OVERWRITTEN; `work` is a
+ * caller-owned scratch of N*C*2 + N*(C/2) + N*G*2 floats; the residual gradient of mode 3 is gy. */
 int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
                       const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S, int32_t G,
-                      int32_t mode, const float* scale, float* gsum, float* dx, float* dgamma, float* dbeta,
+                      int32_t mode, const float* scale, float* work, float* dx, float* dgamma, float* dbeta,
                       float* dscale, void* stream);
 /* GLU over the channel axis of (N, C, S): y = x[:, :C/2] * sigmoid(x[:, C/2:]) */
 int rfx_glu_fwd(const float* x, float* y, int64_t N, int64_t C, int64_t S, void* stream);

@@ -45,14 +45,14 @@ __global__ void pack_a_kernel(const float* __restrict__ w, const int32_t* __rest
 }
 
 __global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_t* __restrict__ woff,
-                                  int64_t w_ms, int M, int K, int Mpad, float* __restrict__ dw) {
+                                  int64_t w_ms, int M, int K, int Kpad, float* __restrict__ dw) {
   const int64_t total = (int64_t)K * M;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i / M), m = (int)(i % M);
+    const int m = (int)(i / K), k = (int)(i % K);
     // distinct (k, m) map to distinct weight elements within one descriptor, but
     // several descriptors (stride phases) may run back to back on the stream.
-    dw[(int64_t)m * w_ms + woff[k]] += dapack[(int64_t)k * Mpad + m];
+    dw[(int64_t)m * w_ms + woff[k]] += dapack[(int64_t)m * Kpad + k];
   }
 }
 
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
           acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tk], acc[tm][tk], 0, 0, 0);
     }
   }
-  // D[i = m][j = k] -> dapack[k][m]
+  // D[i = m][j = k] -> dapack[m][k]  (k = lane axis -> 128-byte coalesced atomics)
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int k = k0 + wk * 32 * TK + tk * 32 + l31;
-        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)k * d.Mpad + m, acc[tm][tk][r]);
+        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
       }
 }
 
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void gemm_thin_wgrad_kernel(const WgradArgs w)
 #pragma unroll
   for (int m = 0; m < MM; ++m) {
     const float s = rfx_wave_sum(acc[m]);
-    if (lane == 0 && m < d.M) atomicAdd(w.dapack + (int64_t)k * d.Mpad + m, s);
+    if (lane == 0 && m < d.M) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, s);
   }
 }
 
@@ -540,13 +540,13 @@ extern "C" int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int
 }
 
 extern "C" int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
-                              int32_t K, int32_t Mpad, float* dw, void* stream) {
-  if (!dapack || !woff || !dw || M <= 0 || K < 0 || Mpad < M) return -1;
+                              int32_t K, int32_t Kpad, float* dw, void* stream) {
+  if (!dapack || !woff || !dw || M <= 0 || K < 0 || Kpad < K) return -1;
   const int64_t total = (int64_t)K * M;
   if (total == 0) return 0;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(unpack_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff,
-                     w_ms, M, K, Mpad, dw);
+                     w_ms, M, K, Kpad, dw);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -632,7 +632,7 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   const int mt = (d->M + 64 * tm - 1) / (64 * tm), kt = (d->K + 64 * tk - 1) / (64 * tk);
   // aim for ~2048 workgroups; each should still see >= 16 position tiles
   int splits = max(1, 2048 / (mt * kt));
-  splits = min(splits, max(1, w.total_tiles / 16));
+  splits = min(splits, max(1, w.total_tiles / 64));
   w.tiles_per_block = (w.total_tiles + splits - 1) / splits;
   splits = (w.total_tiles + w.tiles_per_block - 1) / w.tiles_per_block;
   dim3 grid(kt, mt, splits);

@@ -28,26 +28,41 @@ struct GnArgs {
   float eps;
 };
 
-__device__ __forceinline__ float block_sum(float v, float* sh) {
-  v = rfx_wave_sum(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) sh[wave] = v;
-  __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
+// Work decomposition of the two reductions: one WAVE per (n, channel, S-chunk of <= 4096
+// samples).  A group can be 12 x 65536 floats with only N = 64 groups in flight (time
+// branch DConv) or 768 x 128 floats with thousands of groups; a block-per-group mapping
+// left the first case at 64 workgroups on 256 CUs (rocprof r1a: 30 % of the Demucs step).
+constexpr int GN_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* __restrict__ sums, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nitems = (int64_t)a.N * a.C * nchunks;
+  if (item >= nitems) return;
+  const int sc = (int)(item % nchunks);
+  const int64_t r = item / nchunks;           // n*C + ch
+  const int ch = (int)(r % a.C), n = (int)(r / a.C);
+  const float* xr = a.x + r * a.S;
+  const int64_t s0 = (int64_t)sc * GN_CHUNK, s1 = min(s0 + GN_CHUNK, (int64_t)a.S);
+  float p = 0.f, q = 0.f;
+  for (int64_t s = s0 + lane; s < s1; s += 64) { const float v = xr[s]; p += v; q += v * v; }
+  const double dp = rfx_wave_sum_d((double)p), dq = rfx_wave_sum_d((double)q);
+  if (lane == 0) {
+    const int g = ch / (a.C / a.G);
+    atomicAdd(sums + 2 * (n * a.G + g), dp);
+    atomicAdd(sums + 2 * (n * a.G + g) + 1, dq);
+  }
 }
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
-  __shared__ float sh[4];
-  const int64_t len = (int64_t)(a.C / a.G) * a.S;
-  const float* xg = a.x + (int64_t)blockIdx.x * len;
-  float s = 0.f;
-  for (int64_t i = threadIdx.x; i < len; i += 256) s += xg[i];
-  const float mean = block_sum(s, sh) / (float)len;
-  float v = 0.f;
-  for (int64_t i = threadIdx.x; i < len; i += 256) { const float d = xg[i] - mean; v += d * d; }
-  const float var = block_sum(v, sh) / (float)len;
-  if (threadIdx.x == 0) { a.mean[blockIdx.x] = mean; a.rstd[blockIdx.x] = rsqrtf(var + a.eps); }
+__global__ void gn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
+                                   float* __restrict__ rstd, int ngroups, double len, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ngroups) return;
+  const double m = sums[2 * i] / len;
+  double var = sums[2 * i + 1] / len - m * m;
+  var = var > 0.0 ? var : 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 __device__ __forceinline__ float gn_u(const GnArgs& a, int n, int ch, int64_t s) {
@@ -73,78 +88,145 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   }
 }
 
-// du for input element (n, ch, s) given the output gradient; also returns xhat and (mode 3) g*f
-__device__ __forceinline__ float gn_du(const GnArgs& a, int n, int ch, int64_t s, float& xhat, float& gf) {
-  const int g = ch / (a.C / a.G);
-  const float xv = a.x[((int64_t)n * a.C + ch) * a.S + s];
-  xhat = (xv - a.mean[n * a.G + g]) * a.rstd[n * a.G + g];
-  const float u = xhat * a.gamma[ch] + a.beta[ch];
-  gf = 0.f;
-  if (a.mode <= GN_GELU) {
-    const float g0 = a.gy[((int64_t)n * a.C + ch) * a.S + s];
-    return a.mode == GN_GELU ? g0 * rfx_gelu_grad(u) : g0;
-  }
-  const int Co = a.C / 2;
-  const bool is_a = ch < Co;
-  const int co = is_a ? ch : ch - Co;
+// ---- backward ---------------------------------------------------------------------
+// u = gn(x) is re-materialised from x + (mean, rstd).  For the GLU modes one work item
+// owns the channel PAIR (co, co + C/2): x_a, x_b and gy are read once and both du's come
+// out of the same sigmoid.  Per-(n, channel) sums go to a small partial buffer (plain
+// stores; atomics only when S is split into chunks) and two tiny kernels reduce it over
+// channels (group sums) and over samples (dgamma / dbeta / dscale): no hot atomics.
+struct GnDu { float du_a, xh_a, du_b, xh_b, gf; };
+
+__device__ __forceinline__ GnDu gn_du_pair(const GnArgs& a, int n, int co, int64_t s) {
+  GnDu r;
+  const int Co = a.C / 2, Cg = a.C / a.G;
+  const int ga = n * a.G + co / Cg, gb = n * a.G + (co + Co) / Cg;
+  const float xa = a.x[((int64_t)n * a.C + co) * a.S + s], xb = a.x[((int64_t)n * a.C + co + Co) * a.S + s];
+  r.xh_a = (xa - a.mean[ga]) * a.rstd[ga];
+  r.xh_b = (xb - a.mean[gb]) * a.rstd[gb];
+  const float ua = r.xh_a * a.gamma[co] + a.beta[co], ub = r.xh_b * a.gamma[co + Co] + a.beta[co + Co];
   float g0 = a.gy[((int64_t)n * Co + co) * a.S + s];
-  const float other = gn_u(a, n, is_a ? ch + Co : ch - Co, s);
-  const float ua = is_a ? u : other, ub = is_a ? other : u;
   const float sg = rfx_sigmoid(ub);
-  if (a.mode == GN_GLU_SCALE_RES) {
-    if (is_a) gf = g0 * ua * sg;      // d/dscale, counted once (on the 'a' half)
-    g0 *= a.scale[co];
-  }
-  return is_a ? g0 * sg : g0 * ua * sg * (1.f - sg);
+  r.gf = 0.f;
+  if (a.mode == GN_GLU_SCALE_RES) { r.gf = g0 * ua * sg; g0 *= a.scale[co]; }
+  r.du_a = g0 * sg;
+  r.du_b = g0 * ua * sg * (1.f - sg);
+  return r;
 }
 
-// one block per (n, g); each wave walks whole channels so per-channel sums need no barrier
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a) {
-  __shared__ float sh[2][4];
-  const int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
-  const int Cg = a.C / a.G;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float s1 = 0.f, s2 = 0.f;
-  for (int cc = wave; cc < Cg; cc += 4) {
-    const int ch = g * Cg + cc;
-    float dg = 0.f, db = 0.f, ds = 0.f;
-    for (int64_t s = lane; s < a.S; s += 64) {
-      float xhat, gf;
-      const float du = gn_du(a, n, ch, s, xhat, gf);
-      dg += du * xhat; db += du; ds += gf;
+__device__ __forceinline__ float gn_du_single(const GnArgs& a, int n, int ch, int64_t s, float& xhat) {
+  const int g = n * a.G + ch / (a.C / a.G);
+  const int64_t i = ((int64_t)n * a.C + ch) * a.S + s;
+  xhat = (a.x[i] - a.mean[g]) * a.rstd[g];
+  const float g0 = a.gy[i];
+  return a.mode == GN_GELU ? g0 * rfx_gelu_grad(xhat * a.gamma[ch] + a.beta[ch]) : g0;
+}
+
+// part: (N, C, 2) = { sum du, sum du*xhat } per (n, channel);  psc: (N, C/2) = sum gy*f (mode 3)
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const GnArgs a, float* __restrict__ part,
+                                                             float* __restrict__ psc, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const bool pair = a.mode >= GN_GLU;
+  const int Cw = pair ? a.C / 2 : a.C;      // work channels
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nitems = (int64_t)a.N * Cw * nchunks;
+  if (item >= nitems) return;
+  const int sc = (int)(item % nchunks);
+  const int64_t r = item / nchunks;
+  const int cw = (int)(r % Cw), n = (int)(r / Cw);
+  const int64_t s0 = (int64_t)sc * GN_CHUNK, s1 = min(s0 + GN_CHUNK, (int64_t)a.S);
+  float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pair) {
+    for (int64_t s = s0 + lane; s < s1; s += 64) {
+      const GnDu d = gn_du_pair(a, n, cw, s);
+      v[0] += d.du_a; v[1] += d.du_a * d.xh_a; v[2] += d.du_b; v[3] += d.du_b * d.xh_b; v[4] += d.gf;
     }
-    dg = rfx_wave_sum(dg); db = rfx_wave_sum(db);
-    if (a.mode == GN_GLU_SCALE_RES) ds = rfx_wave_sum(ds);
-    if (lane == 0) {
-      atomicAdd(a.dgamma + ch, dg);
-      atomicAdd(a.dbeta + ch, db);
-      if (a.mode == GN_GLU_SCALE_RES && ch < a.C / 2) atomicAdd(a.dscale + ch, ds);
+  } else {
+    for (int64_t s = s0 + lane; s < s1; s += 64) {
+      float xh;
+      const float du = gn_du_single(a, n, cw, s, xh);
+      v[0] += du; v[1] += du * xh;
     }
-    const float gam = a.gamma[ch];
-    s1 += db * gam;      // sum dxhat       (dxhat = du * gamma)
-    s2 += dg * gam;      // sum dxhat*xhat
   }
-  if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    a.gsum[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    a.gsum[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) v[q] = rfx_wave_sum(v[q]);
+  if (lane != 0) return;
+  float* pa = part + ((int64_t)n * a.C + cw) * 2;
+  if (nchunks == 1) {
+    pa[0] = v[0]; pa[1] = v[1];
+    if (pair) {
+      float* pb = part + ((int64_t)n * a.C + cw + Cw) * 2;
+      pb[0] = v[2]; pb[1] = v[3];
+      if (a.mode == GN_GLU_SCALE_RES) psc[(int64_t)n * Cw + cw] = v[4];
+    }
+  } else {
+    atomicAdd(pa, v[0]); atomicAdd(pa + 1, v[1]);
+    if (pair) {
+      float* pb = part + ((int64_t)n * a.C + cw + Cw) * 2;
+      atomicAdd(pb, v[2]); atomicAdd(pb + 1, v[3]);
+      if (a.mode == GN_GLU_SCALE_RES) atomicAdd(psc + (int64_t)n * Cw + cw, v[4]);
+    }
+  }
+}
+
+// gsum[n*G+g] = sum_{ch in g} gamma[ch] * part[n][ch]      (one wave per group)
+__global__ __launch_bounds__(256) void gn_bwd_groupsum_kernel(const GnArgs a, const float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grp >= a.N * a.G) return;
+  const int n = grp / a.G, g = grp % a.G, Cg = a.C / a.G;
+  float s1 = 0.f, s2 = 0.f;
+  for (int cc = lane; cc < Cg; cc += 64) {
+    const int ch = g * Cg + cc;
+    const float gam = a.gamma[ch];
+    s1 += gam * part[((int64_t)n * a.C + ch) * 2];
+    s2 += gam * part[((int64_t)n * a.C + ch) * 2 + 1];
+  }
+  s1 = rfx_wave_sum(s1); s2 = rfx_wave_sum(s2);
+  if (lane == 0) { a.gsum[2 * grp] = s1; a.gsum[2 * grp + 1] = s2; }
+}
+
+// dbeta[ch] = sum_n part[n][ch][0], dgamma[ch] = sum_n part[n][ch][1], dscale[co] = sum_n psc[n][co]
+__global__ __launch_bounds__(256) void gn_bwd_chansum_kernel(const GnArgs a, const float* __restrict__ part,
+                                                             const float* __restrict__ psc) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ch >= a.C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const bool sc = a.mode == GN_GLU_SCALE_RES && ch < a.C / 2;
+  for (int n = lane; n < a.N; n += 64) {
+    s0 += part[((int64_t)n * a.C + ch) * 2];
+    s1 += part[((int64_t)n * a.C + ch) * 2 + 1];
+    if (sc) s2 += psc[(int64_t)n * (a.C / 2) + ch];
+  }
+  s0 = rfx_wave_sum(s0); s1 = rfx_wave_sum(s1); s2 = rfx_wave_sum(s2);
+  if (lane == 0) {
+    a.dbeta[ch] = s0; a.dgamma[ch] = s1;
+    if (sc) a.dscale[ch] = s2;
   }
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
-  const int64_t total = (int64_t)a.N * a.C * a.S;
-  const int Cg = a.C / a.G;
+  const bool pair = a.mode >= GN_GLU;
+  const int Cw = pair ? a.C / 2 : a.C, Cg = a.C / a.G;
+  const int64_t total = (int64_t)a.N * Cw * a.S;
   const float inv = 1.f / ((float)Cg * (float)a.S);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t s = i % a.S;
     const int64_t r = i / a.S;
-    const int ch = (int)(r % a.C), n = (int)(r / a.C);
-    const int g = ch / Cg;
-    float xhat, gf;
-    const float du = gn_du(a, n, ch, s, xhat, gf);
-    const float m1 = a.gsum[2 * (n * a.G + g)] * inv, m2 = a.gsum[2 * (n * a.G + g) + 1] * inv;
-    a.y[i] = a.rstd[n * a.G + g] * (du * a.gamma[ch] - m1 - xhat * m2);
+    const int cw = (int)(r % Cw), n = (int)(r / Cw);
+    if (pair) {
+      const GnDu d = gn_du_pair(a, n, cw, s);
+      const int ga = n * a.G + cw / Cg, gb = n * a.G + (cw + Cw) / Cg;
+      a.y[((int64_t)n * a.C + cw) * a.S + s] =
+          a.rstd[ga] * (d.du_a * a.gamma[cw] - a.gsum[2 * ga] * inv - d.xh_a * a.gsum[2 * ga + 1] * inv);
+      a.y[((int64_t)n * a.C + cw + Cw) * a.S + s] =
+          a.rstd[gb] * (d.du_b * a.gamma[cw + Cw] - a.gsum[2 * gb] * inv - d.xh_b * a.gsum[2 * gb + 1] * inv);
+    } else {
+      float xh;
+      const float du = gn_du_single(a, n, cw, s, xh);
+      const int g = n * a.G + cw / Cg;
+      a.y[i] = a.rstd[g] * (du * a.gamma[cw] - a.gsum[2 * g] * inv - xh * a.gsum[2 * g + 1] * inv);
+    }
   }
 }
 
@@ -155,7 +237,8 @@ static int gn_grid(int64_t total) {
 
 extern "C" int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
                                  int32_t S, int32_t G, float eps, int32_t mode, const float* res,
-                                 const float* scale, float* mean, float* rstd, float* y, void* stream) {
+                                 const float* scale, double* sums /* N*G*2 workspace */, float* mean,
+                                 float* rstd, float* y, void* stream) {
   if (!x || !gamma || !beta || !mean || !rstd || !y || N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return -1;
   if (mode >= GN_GLU && (C % 2)) return -1;
   if (mode == GN_GLU_SCALE_RES && (!res || !scale)) return -1;
@@ -163,7 +246,14 @@ extern "C" int rfx_groupnorm_fwd(const float* x, const float* gamma, const float
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd; a.y = y; a.res = res; a.scale = scale;
   a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode; a.eps = eps;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G), dim3(256), 0, s, a);
+  if (!sums) return -1;
+  const int nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
+  const int64_t nitems = (int64_t)N * C * nchunks;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * N * G, s) != hipSuccess) return -3;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, sums, nchunks);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + 255) / 256), dim3(256), 0, s, sums, mean, rstd, N * G,
+                     (double)(C / G) * (double)S, eps);
   RFX_CHECK_LAUNCH();
   const int64_t total = (int64_t)N * (mode >= GN_GLU ? C / 2 : C) * S;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_grid(total)), dim3(256), 0, s, a);
@@ -173,19 +263,33 @@ extern "C" int rfx_groupnorm_fwd(const float* x, const float* gamma, const float
 
 extern "C" int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
-                                 int32_t G, int32_t mode, const float* scale, float* gsum /* N*G*2 */,
-                                 float* dx, float* dgamma, float* dbeta, float* dscale, void* stream) {
-  if (!x || !gamma || !beta || !mean || !rstd || !gy || !gsum || !dx || !dgamma || !dbeta) return -1;
+                                 int32_t G, int32_t mode, const float* scale,
+                                 float* work /* N*C*2 + N*(C/2) + N*G*2 floats */, float* dx, float* dgamma,
+                                 float* dbeta, float* dscale, void* stream) {
+  if (!x || !gamma || !beta || !mean || !rstd || !gy || !work || !dx || !dgamma || !dbeta) return -1;
   if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return -1;
+  if (mode >= GN_GLU && (C % 2)) return -1;
   if (mode == GN_GLU_SCALE_RES && (!scale || !dscale)) return -1;
   GnArgs a{};
+  float* part = work;
+  float* psc = work + (int64_t)N * C * 2;
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
-  a.gy = gy; a.scale = scale; a.gsum = gsum; a.y = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.dscale = dscale;
+  a.gy = gy; a.scale = scale; a.gsum = psc + (int64_t)N * (C / 2); a.y = dx; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.dscale = dscale;
   a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * G), dim3(256), 0, s, a);
+  const int nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
+  const int Cw = mode >= GN_GLU ? C / 2 : C;
+  const int64_t nitems = (int64_t)N * Cw * nchunks;
+  if (nchunks > 1 && hipMemsetAsync(work, 0, sizeof(float) * ((int64_t)N * C * 2 + (int64_t)N * (C / 2)), s) != hipSuccess)
+    return -3;
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, part, psc, nchunks);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gn_grid((int64_t)N * C * S)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_bwd_groupsum_kernel, dim3((N * G + 3) / 4), dim3(256), 0, s, a, part);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gn_grid((int64_t)N * Cw * S)), dim3(256), 0, s, a);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -47,10 +47,12 @@ class _GroupNormFn(torch.autograd.Function):
         y = torch.empty(oshape, device=x.device, dtype=torch.float32)
         mean = torch.empty(N * groups, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        sums = torch.empty(N * groups * 2, device=x.device, dtype=torch.float64)
         if res is not None:
             res = res.contiguous()
         check(_lib.lib().rfx_groupnorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), N, Cc, S, groups, eps, mode,
-                                           _ptr(res), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(y), _stream()),
+                                           _ptr(res), _ptr(scale), _ptr(sums), _ptr(mean), _ptr(rstd), _ptr(y),
+                                           _stream()),
               "rfx_groupnorm_fwd")
         ctx.save_for_backward(x, gamma, beta, mean, rstd, scale)
         ctx.cfg = (N, Cc, S, groups, mode)
@@ -62,9 +64,9 @@ class _GroupNormFn(torch.autograd.Function):
         N, Cc, S, groups, mode = ctx.cfg
         gy = gy.contiguous()
         dx = torch.empty_like(x)
-        dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(beta)
-        dscale = torch.zeros_like(scale) if mode == 3 else None
-        gsum = torch.empty(N * groups * 2, device=x.device, dtype=torch.float32)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        dscale = torch.empty_like(scale) if mode == 3 else None
+        gsum = torch.empty(N * Cc * 2 + N * (Cc // 2) + N * groups * 2, device=x.device, dtype=torch.float32)
         check(_lib.lib().rfx_groupnorm_bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gy),
                                            N, Cc, S, groups, mode, _ptr(scale), _ptr(gsum), _ptr(dx),
                                            _ptr(dgamma), _ptr(dbeta), _ptr(dscale), _stream()),

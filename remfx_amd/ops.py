@@ -98,7 +98,7 @@ def gemm_wgrad(dp, x, g, dapack):
 def unpack_add(dp, dapack, dw):
     p = dp.p
     check(_lib.lib().rfx_unpack_add(_ptr(dapack), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"],
-                                    p.Mpad, _ptr(dw), _stream()), "rfx_unpack_add")
+                                    p.Kpad, _ptr(dw), _stream()), "rfx_unpack_add")
 
 
 # ---- convolution (4-D view: N, C, A, B) ----------------------------------------------
@@ -139,11 +139,11 @@ def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias):
     dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
         tuple(x.shape), x.stride(), tuple(wshape), stride, padding, dilation, g.stride(), bias_row=need_bias))
     p = dp.p
-    dapack = torch.zeros((p.Kpad, p.Mpad), device=x.device, dtype=torch.float32)
+    dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
     gemm_wgrad(dp, x, g, dapack)
     dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
     unpack_add(dp, dapack, dw)
-    db = dapack[p.K - 1, :p.M].clone() if need_bias else None
+    db = dapack[:, p.K - 1].clone() if need_bias else None
     return dw, db
 
 
@@ -220,7 +220,7 @@ class ConvT2dFn(torch.autograd.Function):
                 gemm_fwd(dp, pack_a(dp, wc), g, dx)
             if need_w:
                 p = dp.p
-                dapack = torch.zeros((p.Kpad, p.Mpad), device=x.device, dtype=torch.float32)
+                dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
                 gemm_wgrad(dp, g, x, dapack)
                 dw = torch.zeros_like(wc)
                 unpack_add(dp, dapack, dw)

@@ -44,7 +44,7 @@ def emulate_fwd(plan, w_flat, x_flat, out_flat, bias=None):
 
 
 def emulate_wgrad(plan, x_flat, g_flat):
-    """-> dapack [K, M]"""
+    """-> dapack [M, K] (the layout rfx_gemm_wgrad writes, include/remfx_hip.h)"""
     m = torch.arange(plan.M)
     acc = torch.zeros(plan.K, plan.M, dtype=torch.float64)
     for n in range(plan.N):
@@ -52,7 +52,7 @@ def emulate_wgrad(plan, x_flat, g_flat):
         oi = _out_index(plan, n)
         G = g_flat[(m[:, None] * plan.out_cs + oi[None, :])]
         acc += B.double() @ G.double().t()
-    return acc.float()
+    return acc.float().t().contiguous()
 
 
 def scatter_weights(plan, dapack, wshape):
@@ -60,5 +60,5 @@ def scatter_weights(plan, dapack, wshape):
     nrows = plan.extra["n_weight_rows"]
     m = torch.arange(plan.M)
     idx = m[None, :] * plan.w_ms + torch.from_numpy(plan.woff.astype(np.int64))[:, None]
-    dw.index_put_((idx.reshape(-1),), dapack[:nrows].reshape(-1), accumulate=True)
+    dw.index_put_((idx.reshape(-1),), dapack[:, :nrows].t().reshape(-1), accumulate=True)
     return dw.view(wshape)

@@ -41,7 +41,7 @@ def test_conv_fwd_dgrad_wgrad(case):
 
     dap = emulate_wgrad(plan, x.detach().reshape(-1), gy.reshape(-1))
     torch.testing.assert_close(scatter_weights(plan, dap, w.shape), w.grad, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(dap[plan.K - 1], b.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dap[:, plan.K - 1], b.grad, rtol=1e-4, atol=1e-4)
 
     dx = torch.full((x.numel(),), float("nan"))
     for p in convplan.conv_dgrad_plans(tuple(x.shape), x.stride(), tuple(w.shape), stride, padding, dilation,
