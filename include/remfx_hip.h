@@ -184,6 +184,21 @@ int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
                       const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S, int32_t G,
                       int32_t mode, const float* scale, float* work, float* dx, float* dgamma, float* dbeta,
                       float* dscale, void* stream);
+/* BatchNorm2d (+ReLU, mode 4) over (N, S) per channel -- classifier.py:271-272 (ConvBlock).
+ * use_given_stats != 0: eval mode, mean = running_mean, rstd = 1/sqrt(running_var + eps) are inputs;
+ * otherwise batch statistics are computed into mean / rstd (biased variance).  sums: C*2 fp64 workspace. */
+int rfx_batchnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C, int32_t S,
+                      float eps, int32_t mode, int32_t use_given_stats, double* sums, float* mean, float* rstd,
+                      float* y, void* stream);
+/* train-mode backward; work: N*C*2 + N*(C/2) + C*2 floats */
+int rfx_batchnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
+                      const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S, int32_t mode,
+                      float* work, float* dx, float* dgamma, float* dbeta, void* stream);
+/* F.avg_pool2d(kernel = stride = (kh, kw)) on (NC, H, W) planes -- classifier.py:275 */
+int rfx_avgpool2d_fwd(const float* x, float* y, int64_t NC, int32_t H, int32_t W, int32_t kh, int32_t kw,
+                      void* stream);
+int rfx_avgpool2d_bwd(const float* gy, float* gx, int64_t NC, int32_t H, int32_t W, int32_t kh, int32_t kw,
+                      void* stream);
 /* GLU over the channel axis of (N, C, S): y = x[:, :C/2] * sigmoid(x[:, C/2:]) */
 int rfx_glu_fwd(const float* x, float* y, int64_t N, int64_t C, int64_t S, void* stream);
 int rfx_glu_bwd(const float* x, const float* gy, float* gx, int64_t N, int64_t C, int64_t S, void* stream);

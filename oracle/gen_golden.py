@@ -198,9 +198,61 @@ def gen_cnn14():
     print("cnn14_full", out_eval.numpy().round(4), out_bnbatch.numpy().round(4))
 
 
+def gen_flow():
+    """Control flow of the reference wrappers themselves (remfx/models.py run verbatim over the
+    oracle's loss restatements): RemFX.common_step logging + crops, RemFXChainInference threshold /
+    ordering / per-clip chains."""
+    sys.modules["remfx.effects"] = _mod("remfx.effects", Pedalboard_Effects=[
+        type(n, (), {}) for n in ("RandomPedalboardReverb", "RandomPedalboardChorus", "RandomPedalboardDelay",
+                                  "RandomPedalboardDistortion", "RandomPedalboardCompressor")])
+    import remfx.models as rm
+    # 1. one training step of RemFX(TCNModel) -- logged names / values and the loss
+    cfg = dict(ninputs=1, noutputs=1, nblocks=3, channel_width=8, kernel_size=7, stack_size=10,
+               dilation_growth=2, causal=False)
+    net = rm.TCNModel(sample_rate=48000, num_bins=1025, **cfg)
+    sd = ref_tcn.tcn_init_state_dict(1, 1, 3, 8, 7, seed=21)
+    net.model.load_state_dict(sd)
+    model = rm.RemFX(1e-4, 0.95, 0.999, 1e-6, 1e-3, 48000, net)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 1, 12000, generator=g) * 0.3
+    y = x + 0.05 * torch.randn(2, 1, 12000, generator=g)
+    loss = model.training_step((x, y, None, None), 0)
+    logged = dict(model.logged)
+    # 2. chain inference with a fake classifier and tagged "removal models"
+    class Tag(nn.Module):
+        def __init__(self, mul, add):
+            super().__init__(); self.mul, self.add = mul, add
+        def sample(self, z):
+            return z * self.mul + self.add
+    class Holder(nn.Module):
+        def __init__(self, m):
+            super().__init__(); self.model = m
+    names = ["RandomPedalboardReverb", "RandomPedalboardChorus", "RandomPedalboardDelay",
+             "RandomPedalboardDistortion", "RandomPedalboardCompressor"]
+    models = {n: Holder(Tag(1.0 + 0.1 * (i + 1), 0.01 * (i + 1))) for i, n in enumerate(names)}
+    probs = torch.tensor([[0.9, 0.5, 0.2, 0.7, 0.3], [0.1, 0.6, 0.2, 0.4, 0.51], [0.0, 0.0, 0.0, 0.0, 0.0]])
+    class FakeCls(nn.Module):
+        def forward(self, z):
+            return [probs[:, k:k + 1] for k in range(5)]
+    order = ["RandomPedalboardDistortion", "RandomPedalboardCompressor", "RandomPedalboardReverb",
+             "RandomPedalboardChorus", "RandomPedalboardDelay"]       # cfg/exp/remfx_detect.yaml:80-85
+    chain = rm.RemFXChainInference(models, 48000, 1025, order, classifier=FakeCls())
+    xc = torch.randn(3, 1, 9000, generator=g) * 0.2
+    yc = torch.randn(3, 1, 9000, generator=g) * 0.2
+    closs, cout = chain.forward((xc, yc, None, None), 0)
+    chain.test_step((xc, yc, None, None), 0)
+    np.savez_compressed(os.path.join(OUT, "flow.npz"), x=x.numpy(), y=y.numpy(), loss=np.float32(loss.item()),
+                        log_names=np.array(sorted(logged)), log_vals=np.array([logged[k] for k in sorted(logged)], dtype=np.float32),
+                        probs=probs.numpy(), xc=xc.numpy(), yc=yc.numpy(), chain_out=cout.numpy(),
+                        chain_loss=np.float32(closs.item()), chain_log_names=np.array(sorted(chain.logged)),
+                        chain_log_vals=np.array([chain.logged[k] for k in sorted(chain.logged)], dtype=np.float32))
+    print("flow", sorted(logged), float(loss), sorted(chain.logged))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     gen_utils()
     gen_tcn()
     gen_cnn14()
+    gen_flow()

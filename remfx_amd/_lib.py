@@ -110,6 +110,10 @@ SIGNATURES = {
     "rfx_adamw_step": [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P, _P],
     "rfx_groupnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rfx_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "rfx_batchnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, C.c_float, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_batchnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_avgpool2d_fwd": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P],
+    "rfx_avgpool2d_bwd": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "rfx_glu_fwd": [_P, _P, _I64, _I64, _I64, _P],
     "rfx_glu_bwd": [_P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_act_fwd": [_P, _P, _I64, _I32, _P],

@@ -1,0 +1,129 @@
+"""PANNs-style Cnn14 effect classifier on the HIP kernels (mirror of reference
+remfx/classifier.py:134-284: Cnn14, ConvBlock).
+
+Same constructor arguments and state_dict keys as the reference (window,
+melspec.spectrogram.window, melspec.mel_scale.fb, bn0.*, conv_block{1..6}.{conv1,conv2}.weight,
+.bn{1,2}.*, fc1.*, heads.{k}.*).  The mel front end restates
+torchaudio.transforms.MelSpectrogram (power-2 STFT + HTK mel filterbank):
+the power spectrogram comes out of the framed-FFT kernel's epilogue and the filterbank
+is a 1025 -> n_mels 1x1 gather-GEMM.  Quirks kept: no log, per-clip
+standardisation with unbiased std and no epsilon, bn0 / window present but unused.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nnops, ops, stft
+from .utils import init_bn, init_layer
+
+
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down, up))
+
+
+class _Spectrogram(nn.Module):
+    def __init__(self, n_fft):
+        super().__init__()
+        self.register_buffer("window", torch.hann_window(n_fft))
+
+
+class _MelScale(nn.Module):
+    def __init__(self, n_mels, sample_rate, n_stft):
+        super().__init__()
+        self.register_buffer("fb", melscale_fbanks(n_stft, 0.0, float(sample_rate // 2), n_mels, int(sample_rate)))
+
+
+class MelSpectrogram(nn.Module):
+    """torchaudio.transforms.MelSpectrogram(sample_rate, n_fft, hop_length=, n_mels=) defaults."""
+
+    def __init__(self, sample_rate, n_fft, hop_length=None, n_mels=128):
+        super().__init__()
+        self.n_fft, self.hop_length, self.n_mels = n_fft, hop_length or n_fft // 2, n_mels
+        self.spectrogram = _Spectrogram(n_fft)
+        self.mel_scale = _MelScale(n_mels, sample_rate, n_fft // 2 + 1)
+
+    def forward(self, x):
+        b, c, t = x.shape
+        spec = stft.stft(x.reshape(b * c, t), self.n_fft, self.hop_length, self.n_fft,
+                         self.spectrogram.window, mode="pow")            # (b*c, bins, frames)
+        mel = ops.conv1d(spec, self.mel_scale.fb.t().unsqueeze(-1).contiguous())   # bins -> mels
+        return mel.view(b, c, self.n_mels, mel.shape[-1])
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.init_weight()
+
+    def init_weight(self):
+        init_layer(self.conv1); init_layer(self.conv2); init_bn(self.bn1); init_bn(self.bn2)
+
+    def forward(self, input, pool_size=(2, 2), pool_type="avg"):
+        if pool_type != "avg":
+            raise ValueError("Cnn14 uses avg pooling only (classifier.py:209-220)")
+        x = ops.conv2d(input, self.conv1.weight, None, (1, 1), (1, 1))
+        x = nnops.batch_norm(x, self.bn1, self.bn1.training, relu=True)
+        x = ops.conv2d(x, self.conv2.weight, None, (1, 1), (1, 1))
+        x = nnops.batch_norm(x, self.bn2, self.bn2.training, relu=True)
+        return nnops.avg_pool2d(x, pool_size)
+
+
+class Cnn14(nn.Module):
+    def __init__(self, num_classes: int, sample_rate: float, model_sample_rate: float, n_fft: int = 1024,
+                 hop_length: int = 256, n_mels: int = 128, specaugment: bool = False):
+        super().__init__()
+        self.num_classes, self.n_fft, self.hop_length = num_classes, n_fft, hop_length
+        self.sample_rate, self.model_sample_rate, self.specaugment = sample_rate, model_sample_rate, specaugment
+        self.register_buffer("window", torch.hann_window(n_fft))
+        self.melspec = MelSpectrogram(model_sample_rate, n_fft, hop_length=hop_length, n_mels=n_mels)
+        self.bn0 = nn.BatchNorm2d(n_mels)
+        widths = (64, 128, 256, 512, 1024, 2048)
+        cin = 1
+        for i, w in enumerate(widths, 1):
+            setattr(self, f"conv_block{i}", ConvBlock(cin, w))
+            cin = w
+        self.fc1 = nn.Linear(2048, 2048, bias=True)
+        self.heads = nn.ModuleList([nn.Linear(2048, 1, bias=True) for _ in range(num_classes)])
+        self.init_weight()
+        if sample_rate != model_sample_rate:
+            raise NotImplementedError("resampling front end (classifier.py:180-183) is outside the hot path: "
+                                      "every RemFX config uses sample_rate == model_sample_rate")
+        if specaugment:
+            raise NotImplementedError("specaugment masking (classifier.py:185-187) is a training-time "
+                                      "augmentation outside the hot path")
+
+    def init_weight(self):
+        init_bn(self.bn0)
+        init_layer(self.fc1)
+
+    def forward(self, x: torch.Tensor, train: bool = False):
+        x = self.melspec(x)                                                     # (B, 1, n_mels, frames)
+        # per-clip standardisation, unbiased std, no epsilon (classifier.py:207)
+        x = (x - x.mean(dim=(2, 3), keepdim=True)) / x.std(dim=(2, 3), keepdim=True)
+        for i in range(1, 7):
+            x = getattr(self, f"conv_block{i}")(x, pool_size=(2, 2) if i < 6 else (1, 1), pool_type="avg")
+            x = F.dropout(x, p=0.2, training=train)
+        x = torch.mean(x, dim=3)
+        (x1, _) = torch.max(x, dim=2)
+        x = x1 + torch.mean(x, dim=2)
+        x = F.dropout(x, p=0.5, training=train)
+        x = ops.activation(nnops.linear(x, self.fc1.weight, self.fc1.bias), "relu")
+        w = torch.cat([h.weight for h in self.heads], 0)                         # (num_classes, 2048)
+        b = torch.cat([h.bias for h in self.heads], 0)
+        out = ops.activation(nnops.linear(x, w, b), "sigmoid")                   # (B, num_classes)
+        return [out[:, k:k + 1] for k in range(self.num_classes)]

@@ -8,7 +8,8 @@
 //  (1024, 2, 20) / G=1 on this stack, scripts/debug_dconv.py -- one more reason.)
 #include "common.h"
 
-enum { GN_NONE = 0, GN_GELU = 1, GN_GLU = 2, GN_GLU_SCALE_RES = 3 };
+enum { GN_NONE = 0, GN_GELU = 1, GN_GLU = 2, GN_GLU_SCALE_RES = 3, GN_RELU = 4 };
+// bn != 0: BatchNorm statistics -- one (mean, rstd) per CHANNEL over (N, S) (classifier.py:271-272)
 
 struct GnArgs {
   const float* x;       // (N, C, S)
@@ -26,7 +27,12 @@ struct GnArgs {
   float* gsum;          // bwd (N*G, 2): sum dxhat, sum dxhat*xhat
   int N, C, S, G, mode;
   float eps;
+  int bn;
 };
+
+__device__ __forceinline__ int gn_sidx(const GnArgs& a, int n, int ch) {
+  return a.bn ? ch : n * a.G + ch / (a.C / a.G);
+}
 
 // Work decomposition of the two reductions: one WAVE per (n, channel, S-chunk of <= 4096
 // samples).  A group can be 12 x 65536 floats with only N = 64 groups in flight (time
@@ -48,9 +54,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* _
   for (int64_t s = s0 + lane; s < s1; s += 64) { const float v = xr[s]; p += v; q += v * v; }
   const double dp = rfx_wave_sum_d((double)p), dq = rfx_wave_sum_d((double)q);
   if (lane == 0) {
-    const int g = ch / (a.C / a.G);
-    atomicAdd(sums + 2 * (n * a.G + g), dp);
-    atomicAdd(sums + 2 * (n * a.G + g) + 1, dq);
+    const int g = gn_sidx(a, n, ch);
+    atomicAdd(sums + 2 * g, dp);
+    atomicAdd(sums + 2 * g + 1, dq);
   }
 }
 
@@ -66,13 +72,14 @@ __global__ void gn_finalize_kernel(const double* __restrict__ sums, float* __res
 }
 
 __device__ __forceinline__ float gn_u(const GnArgs& a, int n, int ch, int64_t s) {
-  const int g = ch / (a.C / a.G);
+  const int g = gn_sidx(a, n, ch);
   const float xv = a.x[((int64_t)n * a.C + ch) * a.S + s];
-  return (xv - a.mean[n * a.G + g]) * a.rstd[n * a.G + g] * a.gamma[ch] + a.beta[ch];
+  return (xv - a.mean[g]) * a.rstd[g] * a.gamma[ch] + a.beta[ch];
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
-  const int Co = a.mode >= GN_GLU ? a.C / 2 : a.C;
+  const bool glu = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
+  const int Co = glu ? a.C / 2 : a.C;
   const int64_t total = (int64_t)a.N * Co * a.S;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t s = i % a.S;
@@ -80,7 +87,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
     const int c = (int)(r % Co), n = (int)(r / Co);
     float v = gn_u(a, n, c, s);
     if (a.mode == GN_GELU) v = rfx_gelu(v);
-    else if (a.mode >= GN_GLU) {
+    else if (a.mode == GN_RELU) v = v > 0.f ? v : 0.f;
+    else if (a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES) {
       v = v * rfx_sigmoid(gn_u(a, n, c + Co, s));
       if (a.mode == GN_GLU_SCALE_RES) v = a.res[i] + a.scale[c] * v;
     }
@@ -98,8 +106,8 @@ struct GnDu { float du_a, xh_a, du_b, xh_b, gf; };
 
 __device__ __forceinline__ GnDu gn_du_pair(const GnArgs& a, int n, int co, int64_t s) {
   GnDu r;
-  const int Co = a.C / 2, Cg = a.C / a.G;
-  const int ga = n * a.G + co / Cg, gb = n * a.G + (co + Co) / Cg;
+  const int Co = a.C / 2;
+  const int ga = gn_sidx(a, n, co), gb = gn_sidx(a, n, co + Co);
   const float xa = a.x[((int64_t)n * a.C + co) * a.S + s], xb = a.x[((int64_t)n * a.C + co + Co) * a.S + s];
   r.xh_a = (xa - a.mean[ga]) * a.rstd[ga];
   r.xh_b = (xb - a.mean[gb]) * a.rstd[gb];
@@ -114,18 +122,20 @@ __device__ __forceinline__ GnDu gn_du_pair(const GnArgs& a, int n, int co, int64
 }
 
 __device__ __forceinline__ float gn_du_single(const GnArgs& a, int n, int ch, int64_t s, float& xhat) {
-  const int g = n * a.G + ch / (a.C / a.G);
+  const int g = gn_sidx(a, n, ch);
   const int64_t i = ((int64_t)n * a.C + ch) * a.S + s;
   xhat = (a.x[i] - a.mean[g]) * a.rstd[g];
   const float g0 = a.gy[i];
-  return a.mode == GN_GELU ? g0 * rfx_gelu_grad(xhat * a.gamma[ch] + a.beta[ch]) : g0;
+  if (a.mode == GN_GELU) return g0 * rfx_gelu_grad(xhat * a.gamma[ch] + a.beta[ch]);
+  if (a.mode == GN_RELU) return (xhat * a.gamma[ch] + a.beta[ch]) > 0.f ? g0 : 0.f;
+  return g0;
 }
 
 // part: (N, C, 2) = { sum du, sum du*xhat } per (n, channel);  psc: (N, C/2) = sum gy*f (mode 3)
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const GnArgs a, float* __restrict__ part,
                                                              float* __restrict__ psc, int nchunks) {
   const int lane = threadIdx.x & 63;
-  const bool pair = a.mode >= GN_GLU;
+  const bool pair = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
   const int Cw = pair ? a.C / 2 : a.C;      // work channels
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nitems = (int64_t)a.N * Cw * nchunks;
@@ -202,21 +212,22 @@ __global__ __launch_bounds__(256) void gn_bwd_chansum_kernel(const GnArgs a, con
   if (lane == 0) {
     a.dbeta[ch] = s0; a.dgamma[ch] = s1;
     if (sc) a.dscale[ch] = s2;
+    if (a.bn) { a.gsum[2 * ch] = a.gamma[ch] * s0; a.gsum[2 * ch + 1] = a.gamma[ch] * s1; }
   }
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
-  const bool pair = a.mode >= GN_GLU;
+  const bool pair = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
   const int Cw = pair ? a.C / 2 : a.C, Cg = a.C / a.G;
   const int64_t total = (int64_t)a.N * Cw * a.S;
-  const float inv = 1.f / ((float)Cg * (float)a.S);
+  const float inv = a.bn ? 1.f / ((float)a.N * (float)a.S) : 1.f / ((float)Cg * (float)a.S);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t s = i % a.S;
     const int64_t r = i / a.S;
     const int cw = (int)(r % Cw), n = (int)(r / Cw);
     if (pair) {
       const GnDu d = gn_du_pair(a, n, cw, s);
-      const int ga = n * a.G + cw / Cg, gb = n * a.G + (cw + Cw) / Cg;
+      const int ga = gn_sidx(a, n, cw), gb = gn_sidx(a, n, cw + Cw);
       a.y[((int64_t)n * a.C + cw) * a.S + s] =
           a.rstd[ga] * (d.du_a * a.gamma[cw] - a.gsum[2 * ga] * inv - d.xh_a * a.gsum[2 * ga + 1] * inv);
       a.y[((int64_t)n * a.C + cw + Cw) * a.S + s] =
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
     } else {
       float xh;
       const float du = gn_du_single(a, n, cw, s, xh);
-      const int g = n * a.G + cw / Cg;
+      const int g = gn_sidx(a, n, cw);
       a.y[i] = a.rstd[g] * (du * a.gamma[cw] - a.gsum[2 * g] * inv - xh * a.gsum[2 * g + 1] * inv);
     }
   }
@@ -235,40 +246,61 @@ static int gn_grid(int64_t total) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-extern "C" int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
+static int norm_fwd(int bn, int use_given_stats, const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
                                  int32_t S, int32_t G, float eps, int32_t mode, const float* res,
                                  const float* scale, double* sums /* N*G*2 workspace */, float* mean,
                                  float* rstd, float* y, void* stream) {
   if (!x || !gamma || !beta || !mean || !rstd || !y || N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return -1;
-  if (mode >= GN_GLU && (C % 2)) return -1;
+  const bool glu = mode == GN_GLU || mode == GN_GLU_SCALE_RES;
+  if (glu && (C % 2)) return -1;
   if (mode == GN_GLU_SCALE_RES && (!res || !scale)) return -1;
   GnArgs a{};
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd; a.y = y; a.res = res; a.scale = scale;
-  a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode; a.eps = eps;
+  a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode; a.eps = eps; a.bn = bn;
+  const int nstat = bn ? C : N * G;
   hipStream_t s = (hipStream_t)stream;
-  if (!sums) return -1;
-  const int nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
-  const int64_t nitems = (int64_t)N * C * nchunks;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * N * G, s) != hipSuccess) return -3;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, sums, nchunks);
-  RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + 255) / 256), dim3(256), 0, s, sums, mean, rstd, N * G,
-                     (double)(C / G) * (double)S, eps);
-  RFX_CHECK_LAUNCH();
-  const int64_t total = (int64_t)N * (mode >= GN_GLU ? C / 2 : C) * S;
+  if (!use_given_stats) {
+    if (!sums) return -1;
+    const int nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
+    const int64_t nitems = (int64_t)N * C * nchunks;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * nstat, s) != hipSuccess) return -3;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, sums, nchunks);
+    RFX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, sums, mean, rstd, nstat,
+                       bn ? (double)N * (double)S : (double)(C / G) * (double)S, eps);
+    RFX_CHECK_LAUNCH();
+  }
+  const int64_t total = (int64_t)N * (glu ? C / 2 : C) * S;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_grid(total)), dim3(256), 0, s, a);
   RFX_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
+extern "C" int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
+                                 int32_t S, int32_t G, float eps, int32_t mode, const float* res,
+                                 const float* scale, double* sums, float* mean, float* rstd, float* y,
+                                 void* stream) {
+  return norm_fwd(0, 0, x, gamma, beta, N, C, S, G, eps, mode, res, scale, sums, mean, rstd, y, stream);
+}
+// BatchNorm over (N, S) per channel.  use_given_stats: mean / rstd are inputs (eval mode:
+// running_mean, 1/sqrt(running_var + eps)); else batch statistics are computed and written.
+extern "C" int rfx_batchnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
+                                 int32_t S, float eps, int32_t mode, int32_t use_given_stats, double* sums,
+                                 float* mean, float* rstd, float* y, void* stream) {
+  if (mode != GN_NONE && mode != GN_RELU) return -1;
+  return norm_fwd(1, use_given_stats, x, gamma, beta, N, C, S, C, eps, mode, nullptr, nullptr, sums, mean, rstd, y,
+                  stream);
+}
+
+static int norm_bwd(int bn, const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t G, int32_t mode, const float* scale,
-                                 float* work /* N*C*2 + N*(C/2) + N*G*2 floats */, float* dx, float* dgamma,
+                                 float* work /* N*C*2 + N*(C/2) + max(N*G, C)*2 floats */, float* dx, float* dgamma,
                                  float* dbeta, float* dscale, void* stream) {
   if (!x || !gamma || !beta || !mean || !rstd || !gy || !work || !dx || !dgamma || !dbeta) return -1;
   if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return -1;
-  if (mode >= GN_GLU && (C % 2)) return -1;
+  const bool glu = mode == GN_GLU || mode == GN_GLU_SCALE_RES;
+  if (glu && (C % 2)) return -1;
   if (mode == GN_GLU_SCALE_RES && (!scale || !dscale)) return -1;
   GnArgs a{};
   float* part = work;
@@ -276,20 +308,85 @@ extern "C" int rfx_groupnorm_bwd(const float* x, const float* gamma, const float
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
   a.gy = gy; a.scale = scale; a.gsum = psc + (int64_t)N * (C / 2); a.y = dx; a.dgamma = dgamma; a.dbeta = dbeta;
   a.dscale = dscale;
-  a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode;
+  a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode; a.bn = bn;
   hipStream_t s = (hipStream_t)stream;
   const int nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
-  const int Cw = mode >= GN_GLU ? C / 2 : C;
+  const int Cw = glu ? C / 2 : C;
   const int64_t nitems = (int64_t)N * Cw * nchunks;
   if (nchunks > 1 && hipMemsetAsync(work, 0, sizeof(float) * ((int64_t)N * C * 2 + (int64_t)N * (C / 2)), s) != hipSuccess)
     return -3;
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, part, psc, nchunks);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_groupsum_kernel, dim3((N * G + 3) / 4), dim3(256), 0, s, a, part);
-  RFX_CHECK_LAUNCH();
+  if (!bn) {
+    hipLaunchKernelGGL(gn_bwd_groupsum_kernel, dim3((N * G + 3) / 4), dim3(256), 0, s, a, part);
+    RFX_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
   RFX_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gn_grid((int64_t)N * Cw * S)), dim3(256), 0, s, a);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
+                                 const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
+                                 int32_t G, int32_t mode, const float* scale, float* work, float* dx,
+                                 float* dgamma, float* dbeta, float* dscale, void* stream) {
+  return norm_bwd(0, x, gamma, beta, mean, rstd, gy, N, C, S, G, mode, scale, work, dx, dgamma, dbeta, dscale, stream);
+}
+// train-mode BatchNorm backward (batch statistics); work: N*C*2 + N*(C/2) + C*2 floats
+extern "C" int rfx_batchnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
+                                 const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
+                                 int32_t mode, float* work, float* dx, float* dgamma, float* dbeta, void* stream) {
+  if (mode != GN_NONE && mode != GN_RELU) return -1;
+  return norm_bwd(1, x, gamma, beta, mean, rstd, gy, N, C, S, C, mode, nullptr, work, dx, dgamma, dbeta, nullptr, stream);
+}
+
+// ---- 2x2 average pooling (classifier.py:275) ---------------------------------------------
+__global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t NC, int H, int W,
+                                    int kh, int kw) {
+  const int OH = H / kh, OW = W / kw;
+  const int64_t total = NC * OH * OW;
+  const float inv = 1.f / (float)(kh * kw);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ow = (int)(i % OW);
+    const int64_t r = i / OW;
+    const int oh = (int)(r % OH);
+    const int64_t nc = r / OH;
+    const float* p = x + (nc * H + (int64_t)oh * kh) * W + (int64_t)ow * kw;
+    float acc = 0.f;
+    for (int a = 0; a < kh; ++a)
+      for (int b = 0; b < kw; ++b) acc += p[a * W + b];
+    y[i] = acc * inv;
+  }
+}
+__global__ void avgpool2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int64_t NC, int H, int W,
+                                    int kh, int kw) {
+  const int OH = H / kh, OW = W / kw;
+  const int64_t total = NC * H * W;
+  const float inv = 1.f / (float)(kh * kw);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const int64_t r = i / W;
+    const int h = (int)(r % H);
+    const int64_t nc = r / H;
+    const int oh = h / kh, ow = w / kw;
+    gx[i] = (oh < OH && ow < OW) ? gy[(nc * OH + oh) * OW + ow] * inv : 0.f;
+  }
+}
+extern "C" int rfx_avgpool2d_fwd(const float* x, float* y, int64_t NC, int32_t H, int32_t W, int32_t kh,
+                                 int32_t kw, void* stream) {
+  if (!x || !y || NC <= 0 || H < kh || W < kw || kh <= 0 || kw <= 0) return -1;
+  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(gn_grid(NC * (H / kh) * (W / kw))), dim3(256), 0, (hipStream_t)stream,
+                     x, y, NC, H, W, kh, kw);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_avgpool2d_bwd(const float* gy, float* gx, int64_t NC, int32_t H, int32_t W, int32_t kh,
+                                 int32_t kw, void* stream) {
+  if (!gy || !gx || NC <= 0 || H < kh || W < kw || kh <= 0 || kw <= 0) return -1;
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(gn_grid(NC * H * W)), dim3(256), 0, (hipStream_t)stream, gy, gx, NC,
+                     H, W, kh, kw);
   RFX_CHECK_LAUNCH();
   return 0;
 }

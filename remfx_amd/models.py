@@ -136,6 +136,78 @@ class DemucsModel(_RemovalWrapper):
         return self.model(x).squeeze(1)
 
 
+def mixup(x: torch.Tensor, y: torch.Tensor, alpha: float = 1.0):
+    """models.py:393-420: per-item lambda ~ U(0.25, 0.75), applied with probability 0.5; labels are
+    the logical OR of the two clips (not a lambda blend)."""
+    import numpy as np
+    batch_size = x.size(0)
+    if alpha > 0:
+        lam = np.random.uniform(0.25, 0.75, batch_size)
+        lam = torch.from_numpy(lam).float().to(x.device).view(batch_size, 1, 1)
+    else:
+        lam = 1
+    if np.random.rand() > 0.5:
+        index = torch.randperm(batch_size).to(x.device)
+        mixed_x = lam * x + (1 - lam) * x[index, :]
+        mixed_y = torch.logical_or(y, y[index, :]).float()
+    else:
+        mixed_x, mixed_y = x, y
+    return mixed_x, mixed_y, lam
+
+
+class FXClassifier(_Base):
+    """models.py:423-592 (Cnn14 branch): sum over the 5 heads of BCELoss, per-effect accuracy."""
+
+    def __init__(self, lr: float, lr_weight_decay: float, sample_rate: float, network: nn.Module,
+                 mixup: bool = False, label_smoothing: float = 0.0):
+        super().__init__()
+        self.lr, self.lr_weight_decay, self.sample_rate = lr, lr_weight_decay, sample_rate
+        self.network = network
+        self.effects = ["Reverb", "Chorus", "Delay", "Distortion", "Compressor"]
+        self.mixup, self.label_smoothing = mixup, label_smoothing     # label_smoothing unused for Cnn14 (Q12)
+        self.loss_fn = torch.nn.BCELoss()
+
+    def forward(self, x: torch.Tensor, train: bool = False):
+        return self.network(x, train=train)
+
+    def common_step(self, batch, batch_idx, mode: str = "train"):
+        train = mode == "train"
+        x, y, dry_label, wet_label = batch
+        labels = wet_label
+        if train and self.mixup:
+            x, labels, _ = mixup(x, wet_label)
+        outputs = self(x, train)
+        loss = 0
+        for idx, output in enumerate(outputs):
+            loss = loss + self.loss_fn(output.squeeze(-1), labels[..., idx])
+        self.log(f"{mode}_loss", loss, on_step=True, on_epoch=True, prog_bar=True, logger=True, sync_dist=True)
+        accs = []
+        with torch.no_grad():
+            for idx, name in enumerate(self.effects[:len(outputs)]):
+                acc = ((outputs[idx].squeeze(-1) > 0.5).float() == wet_label[..., idx]).float().mean()
+                self.log(f"{mode}_{name}_acc", acc, on_step=True, on_epoch=True, prog_bar=True, logger=True,
+                         sync_dist=True)
+                accs.append(acc)
+            self.log(f"{mode}_avg_acc", torch.mean(torch.stack(accs)), on_step=True, on_epoch=True,
+                     prog_bar=True, logger=True, sync_dist=True)
+        return loss
+
+    def training_step(self, batch, batch_idx):
+        return self.common_step(batch, batch_idx, mode="train")
+
+    def validation_step(self, batch, batch_idx):
+        return self.common_step(batch, batch_idx, mode="valid")
+
+    def test_step(self, batch, batch_idx):
+        return self.common_step(batch, batch_idx, mode="test")
+
+    def configure_optimizers(self):
+        """models.py:586-592: AdamW(lr, weight_decay), default betas / eps, no scheduler."""
+        from .optim import FlatAdamW, FlatParams
+        return FlatAdamW(FlatParams(list(self.network.parameters())), lr=self.lr, betas=(0.9, 0.999), eps=1e-8,
+                         weight_decay=self.lr_weight_decay)
+
+
 class RemFXChainInference(_Base):
     """Classifier -> threshold -> per-clip ordered chain of effect-removal models
     (models.py:22-149).  Clips that share a detected-effect signature are batched

@@ -79,6 +79,91 @@ def group_norm(x, groups, weight, bias, eps=1e-5, mode="none", res=None, scale=N
     return _GroupNormFn.apply(x, weight, bias, groups, eps, GN_MODES[mode], res, scale)
 
 
+class _BatchNormFn(torch.autograd.Function):
+    """BatchNorm2d (+ReLU).  training=True: batch statistics (and running-stat update by the caller
+    from the returned mean / biased var); training=False: running statistics, forward only."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        ops._req(x, "x")
+        x = x.contiguous()
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (N * Cc)
+        y = torch.empty_like(x)
+        mode = 4 if relu else 0
+        if training:
+            mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            sums = torch.empty(Cc * 2, device=x.device, dtype=torch.float64)
+            given = 0
+        else:
+            mean = running_mean.contiguous()
+            rstd = torch.rsqrt(running_var + eps)
+            sums, given = None, 1
+        check(_lib.lib().rfx_batchnorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), N, Cc, S, eps, mode, given,
+                                           _ptr(sums), _ptr(mean), _ptr(rstd), _ptr(y), _stream()),
+              "rfx_batchnorm_fwd")
+        if training and running_mean is not None:
+            with torch.no_grad():              # C-length vectors: bookkeeping, nn.BatchNorm2d semantics
+                n = N * S
+                var = 1.0 / (rstd * rstd) - eps
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (N, Cc, S, mode, training)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, Cc, S, mode, training = ctx.cfg
+        if not training:
+            raise RuntimeError("batch_norm backward in eval mode is not on the reference's path")
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        work = torch.empty(N * Cc * 2 + N * (Cc // 2) + Cc * 2, device=x.device, dtype=torch.float32)
+        check(_lib.lib().rfx_batchnorm_bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gy),
+                                           N, Cc, S, mode, _ptr(work), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                           _stream()), "rfx_batchnorm_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm(x, bn, training, relu=False):
+    """bn: nn.BatchNorm2d parameter container (weight, bias, running_mean, running_var)."""
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum,
+                              bn.eps, relu)
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kh, kw):
+        ops._req(x, "x")
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, H // kh, W // kw), device=x.device, dtype=torch.float32)
+        check(_lib.lib().rfx_avgpool2d_fwd(_ptr(x), _ptr(y), N * Cc, H, W, kh, kw, _stream()), "rfx_avgpool2d_fwd")
+        ctx.cfg = (N, Cc, H, W, kh, kw)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, Cc, H, W, kh, kw = ctx.cfg
+        gx = torch.empty((N, Cc, H, W), device=gy.device, dtype=torch.float32)
+        check(_lib.lib().rfx_avgpool2d_bwd(_ptr(gy.contiguous()), _ptr(gx), N * Cc, H, W, kh, kw, _stream()),
+              "rfx_avgpool2d_bwd")
+        return gx, None, None
+
+
+def avg_pool2d(x, kernel_size):
+    kh, kw = kernel_size
+    if (kh, kw) == (1, 1):
+        return x
+    return _AvgPoolFn.apply(x, kh, kw)
+
+
 class _GluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

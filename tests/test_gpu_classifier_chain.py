@@ -1,0 +1,126 @@
+"""GPU parity: Cnn14 vs outputs of the imported reference module (tests/golden/cnn14_full.npz),
+and the RemFX / RemFXChainInference control flow vs a trace of the reference's own
+remfx/models.py (tests/golden/flow.npz, oracle/gen_golden.py:gen_flow)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cnn14_sd():
+    from oracle import ref_cnn14
+    sd = ref_cnn14.cnn14_init_state_dict(seed=7)
+    gen = torch.Generator().manual_seed(8)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.05
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=gen) * 0.5 + 0.75
+        elif ".bn" in k and k.endswith("weight"):
+            sd[k] = torch.rand(sd[k].shape, generator=gen) * 0.4 + 0.8
+        elif ".bn" in k and k.endswith("bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.05
+    for k in list(sd):
+        if k.startswith("heads.") and k.endswith("weight"):
+            sd[k] = sd[k] * 40.0
+    return sd
+
+
+def test_cnn14_golden(golden_dir):
+    from remfx_amd.classifier import Cnn14
+    g = np.load(os.path.join(golden_dir, "cnn14_full.npz"))
+    net = Cnn14(num_classes=5, sample_rate=48000, model_sample_rate=48000, n_fft=2048, hop_length=512, n_mels=128)
+    missing = net.load_state_dict(_cnn14_sd(), strict=False)
+    assert not missing.unexpected_keys
+    net = net.to(DEV).eval()
+    x = torch.from_numpy(g["x"]).to(DEV)
+    with torch.no_grad():
+        mel = net.melspec(x).cpu().numpy()
+        out = torch.hstack(net(x)).cpu().numpy()
+        net.train()                                   # BatchNorm batch statistics
+        outb = torch.hstack(net(x, train=False)).cpu().numpy()
+    rel = np.sqrt(((mel - g["mel"]) ** 2).mean()) / np.abs(g["mel"]).max()
+    assert rel < 1e-6, rel
+    np.testing.assert_allclose(out, g["out_eval"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(outb, g["out_bnbatch"], rtol=5e-3, atol=5e-4)
+    # bit-exact detected-effect labels (models.py:61-64)
+    assert np.array_equal(out > 0.5, g["out_eval"] > 0.5)
+    assert np.array_equal(outb > 0.5, g["out_bnbatch"] > 0.5)
+
+
+def test_cnn14_train_step_vs_oracle():
+    """FXClassifier loss + a few gradients (train-mode BN) vs autograd over the CPU oracle."""
+    from oracle import ref_cnn14
+    from remfx_amd.classifier import Cnn14
+    from remfx_amd.models import FXClassifier
+    sd = _cnn14_sd()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 1, 24000, generator=g) * 0.1
+    lab = (torch.rand(3, 5, generator=g) > 0.5).float()
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    outs = ref_cnn14.cnn14_forward(x, sdr, bn_train=True)
+    lref = sum(torch.nn.functional.binary_cross_entropy(o.squeeze(-1), lab[:, k]) for k, o in enumerate(outs))
+    lref.backward()
+    net = Cnn14(5, 48000, 48000, 2048, 512, 128)
+    net.load_state_dict(sd, strict=False)
+    model = FXClassifier(3e-4, 1e-3, 48000, net).to(DEV)
+    model.train()
+    # dropout off (p applies only with train=True): compare through the valid path on a train-mode net
+    loss = model.common_step((x.to(DEV), None, None, lab.to(DEV)), 0, mode="valid")
+    loss.backward()
+    assert abs(float(loss) - float(lref)) < 2e-4 * max(1.0, abs(float(lref)))
+    for k in ("conv_block1.conv1.weight", "conv_block3.bn1.weight", "conv_block6.conv2.weight", "fc1.weight",
+              "heads.2.weight"):
+        got, ref = dict(net.named_parameters())[k].grad.cpu(), sdr[k].grad
+        scale = max(1e-6, float(ref.abs().max()))
+        assert float(((got - ref) ** 2).mean().sqrt()) < 5e-3 * scale, k
+
+
+def test_remfx_step_and_chain_flow(golden_dir):
+    from oracle import ref_tcn
+    from remfx_amd import models
+    g = np.load(os.path.join(golden_dir, "flow.npz"))
+    net = models.TCNModel(sample_rate=48000, num_bins=1025, ninputs=1, noutputs=1, nblocks=3, channel_width=8,
+                          kernel_size=7, stack_size=10, dilation_growth=2, causal=False)
+    net.model.load_state_dict(ref_tcn.tcn_init_state_dict(1, 1, 3, 8, 7, seed=21))
+    model = models.RemFX(1e-4, 0.95, 0.999, 1e-6, 1e-3, 48000, net).to(DEV)
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    loss = model.training_step((x, y, None, None), 0)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert sorted(model.logged) == g["log_names"].tolist()
+    for k, v in zip(g["log_names"].tolist(), g["log_vals"]):
+        assert abs(float(model.logged[k]) - float(v)) < 2e-3 * max(1.0, abs(float(v))), k
+
+    class Tag(nn.Module):
+        def __init__(self, mul, add):
+            super().__init__(); self.mul, self.add = mul, add
+        def sample(self, z):
+            return z * self.mul + self.add
+    class Holder(nn.Module):
+        def __init__(self, m):
+            super().__init__(); self.model = m
+    names = models.ALL_EFFECT_NAMES
+    mods = {n: Holder(Tag(1.0 + 0.1 * (i + 1), 0.01 * (i + 1))) for i, n in enumerate(names)}
+    probs = torch.from_numpy(g["probs"]).to(DEV)
+    class FakeCls(nn.Module):
+        def forward(self, z):
+            return [probs[:, k:k + 1] for k in range(5)]
+    order = ["RandomPedalboardDistortion", "RandomPedalboardCompressor", "RandomPedalboardReverb",
+             "RandomPedalboardChorus", "RandomPedalboardDelay"]
+    chain = models.RemFXChainInference(mods, 48000, 1025, order, classifier=FakeCls())
+    xc, yc = torch.from_numpy(g["xc"]).to(DEV), torch.from_numpy(g["yc"]).to(DEV)
+    closs, cout = chain.forward((xc, yc, None, None), 0)
+    # strict > 0.5 threshold: 0.5 is NOT detected, 0.51 is
+    assert chain.last_labels.cpu().tolist() == [[1, 0, 0, 1, 0], [0, 1, 0, 0, 1], [0, 0, 0, 0, 0]]
+    np.testing.assert_allclose(cout.cpu().numpy(), g["chain_out"], rtol=1e-6, atol=1e-6)
+    assert abs(float(closs) - float(g["chain_loss"])) < 1e-4 * abs(float(g["chain_loss"]))
+    chain.test_step((xc, yc, None, None), 0)
+    assert sorted(chain.logged) == g["chain_log_names"].tolist()
+    for k, v in zip(g["chain_log_names"].tolist(), g["chain_log_vals"]):
+        assert abs(float(chain.logged[k]) - float(v)) < 2e-3 * max(1.0, abs(float(v))), k
