@@ -1,0 +1,7 @@
+"""Drop-in alias: `remfx.classifier` -> `remfx_amd.classifier` so the reference's Hydra `_target_` strings
+(cfg/model/*.yaml) and `from remfx.classifier import ...` lines resolve to the MI355X build."""
+from remfx_amd.classifier import *  # noqa: F401,F403
+from remfx_amd import classifier as _impl
+
+__all__ = [n for n in dir(_impl) if not n.startswith("__")]
+globals().update({n: getattr(_impl, n) for n in dir(_impl) if not n.startswith("__")})
