@@ -203,6 +203,27 @@ int rfx_avgpool2d_bwd(const float* gy, float* gx, int64_t NC, int32_t H, int32_t
 int rfx_glu_fwd(const float* x, float* y, int64_t N, int64_t C, int64_t S, void* stream);
 int rfx_glu_bwd(const float* x, const float* gy, float* gx, int64_t N, int64_t C, int64_t S, void* stream);
 
+/* ---- complex-valued pieces of DCUNet (asteroid DCUNet via models.py:347-367) -------
+ * Complex tensors are real tensors (N, 2C, S): channels [0,C) real parts, [C,2C) imaginary parts; a complex
+ * convolution is then ONE rfx_gemm_fwd with the block weight [[Wr,-Wi],[Wi,Wr]].
+ * sums (5, per channel c at c*5+q): sum xr, xi, xr^2, xr*xi, xi^2 in fp64 (ComplexBatchNorm statistics). */
+int rfx_cplx_moments(const float* x, int32_t N, int32_t C, int64_t S, double* sums, void* stream);
+/* gx += d(sum_q coef[q][c] * moment_q)/dx, coef: (5, C) fp32 */
+int rfx_cplx_moments_bwd(const float* x, const float* coef, int32_t N, int32_t C, int64_t S, float* gx, void* stream);
+/* out = leaky_relu(Z x + b, slope) per complex channel; coef (6, C) = Zrr, Zri, Zir, Zii, Br, Bi.
+ * out[n*out_ns + c*S + s] (real) and out[n*out_ns + (c + out_im_off)*S + s] (imag): may be a slice of a
+ * pre-allocated skip-concatenation buffer (no torch.cat copy). */
+int rfx_cplx_affine_act_fwd(const float* x, const float* coef, int32_t N, int32_t C, int64_t S, float slope,
+                            float* out, int64_t out_ns, int64_t out_im_off, void* stream);
+/* gx (N, 2C, S) written, gcoef (6, C) overwritten */
+int rfx_cplx_affine_act_bwd(const float* x, const float* coef, const float* gy, int64_t gy_ns, int64_t gy_im_off,
+                            int32_t N, int32_t C, int64_t S, float slope, float* gx, float* gcoef, void* stream);
+/* BoundComplexMask("tanh") applied to the mixture STFT: out = tanh(|m|) m/|m| (*) tf; planes (N, 2, P) */
+int rfx_bound_mask_fwd(const float* m, const float* tf, float* out, int32_t N, int64_t P, int64_t m_ns,
+                       int64_t tf_ns, int64_t out_ns, void* stream);
+int rfx_bound_mask_bwd(const float* m, const float* tf, const float* gout, float* gm, int32_t N, int64_t P,
+                       int64_t m_ns, int64_t tf_ns, int64_t g_ns, int64_t gm_ns, void* stream);
+
 /* ---- losses -------------------------------------------------------------------
  * auraloss STFTLoss terms on complex spectra [R][n] (n = bins*frames, view_as_real layout):
  * sums[r] += { sum (|Y|-|X|)^2, sum |Y|^2, sum |log|X| - log|Y|| }, |.| = sqrt(max(re^2+im^2, eps)).

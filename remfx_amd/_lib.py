@@ -114,6 +114,12 @@ SIGNATURES = {
     "rfx_batchnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_avgpool2d_fwd": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "rfx_avgpool2d_bwd": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P],
+    "rfx_cplx_moments": [_P, _I32, _I32, _I64, _P, _P],
+    "rfx_cplx_moments_bwd": [_P, _P, _I32, _I32, _I64, _P, _P],
+    "rfx_cplx_affine_act_fwd": [_P, _P, _I32, _I32, _I64, C.c_float, _P, _I64, _I64, _P],
+    "rfx_cplx_affine_act_bwd": [_P, _P, _P, _I64, _I64, _I32, _I32, _I64, C.c_float, _P, _P, _P],
+    "rfx_bound_mask_fwd": [_P, _P, _P, _I32, _I64, _I64, _I64, _I64, _P],
+    "rfx_bound_mask_bwd": [_P, _P, _P, _P, _I32, _I64, _I64, _I64, _I64, _I64, _P],
     "rfx_glu_fwd": [_P, _P, _I64, _I64, _I64, _P],
     "rfx_glu_bwd": [_P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_act_fwd": [_P, _P, _I64, _I32, _P],

@@ -1,0 +1,202 @@
+// Complex-valued pieces of DCUNet (asteroid.models.DCUNet via remfx/models.py:347-367).
+// A complex tensor is stored as a real one with the channel axis doubled: (N, 2C, S),
+// channels [0, C) = real parts, [C, 2C) = imaginary parts.  With that layout a complex
+// convolution IS one real gather-GEMM with the block weight [[Wr, -Wi], [Wi, Wr]], so only
+// the norm / activation / mask pieces need their own kernels:
+//   * raw second-order moments per complex channel (ComplexBatchNorm statistics),
+//   * y = leaky_relu(Z x + b) with a per-channel 2x2 real matrix Z (the whitening x affine
+//     product, formed on C-length vectors by the host) -- forward and backward,
+//   * the bounded mask  tanh(|m|) m/|m|  applied to the mixture STFT -- forward and backward.
+// All HBM-bound streaming kernels: lanes along the contiguous spatial axis.
+#include "common.h"
+
+constexpr int CX_CHUNK = 4096;
+
+// sums[c*5 + {0..4}] += { sum xr, sum xi, sum xr^2, sum xr*xi, sum xi^2 }   (fp64)
+__global__ __launch_bounds__(256) void cplx_moments_kernel(const float* __restrict__ x, int N, int C, int64_t S,
+                                                           int nchunks, double* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)N * C * nchunks) return;
+  const int sc = (int)(item % nchunks);
+  const int64_t r = item / nchunks;
+  const int c = (int)(r % C), n = (int)(r / C);
+  const float* xr = x + ((int64_t)n * 2 * C + c) * S;
+  const float* xi = xr + (int64_t)C * S;
+  const int64_t s0 = (int64_t)sc * CX_CHUNK, s1 = min(s0 + CX_CHUNK, S);
+  float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t s = s0 + lane; s < s1; s += 64) {
+    const float a = xr[s], b = xi[s];
+    v[0] += a; v[1] += b; v[2] += a * a; v[3] += a * b; v[4] += b * b;
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const double d = rfx_wave_sum_d((double)v[q]);
+    if (lane == 0) atomicAdd(sums + c * 5 + q, d);
+  }
+}
+
+// gx += d(sum_q coef_q * moment_q)/dx :  gxr = c0 + 2 c2 xr + c3 xi ; gxi = c1 + 2 c4 xi + c3 xr
+__global__ void cplx_moments_bwd_kernel(const float* __restrict__ x, const float* __restrict__ coef, int N, int C,
+                                        int64_t S, float* __restrict__ gx) {
+  const int64_t total = (int64_t)N * C * S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t s = i % S, r = i / S;
+    const int c = (int)(r % C), n = (int)(r / C);
+    const int64_t ir = ((int64_t)n * 2 * C + c) * S + s, ii = ir + (int64_t)C * S;
+    const float a = x[ir], b = x[ii];
+    gx[ir] += coef[c] + 2.f * coef[2 * C + c] * a + coef[3 * C + c] * b;
+    gx[ii] += coef[C + c] + 2.f * coef[4 * C + c] * b + coef[3 * C + c] * a;
+  }
+}
+
+// coef: (6, C) = Zrr, Zri, Zir, Zii, Br, Bi.  out may be a channel slice of a larger buffer:
+// out[n*out_ns + ch*S + s], ch in [0, 2C) with the imaginary half at out_im_off channels.
+__global__ void cplx_affine_act_kernel(const float* __restrict__ x, const float* __restrict__ coef, int N, int C,
+                                       int64_t S, float slope, float* __restrict__ out, int64_t out_ns,
+                                       int64_t out_im_off) {
+  const int64_t total = (int64_t)N * C * S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t s = i % S, r = i / S;
+    const int c = (int)(r % C), n = (int)(r / C);
+    const int64_t ir = ((int64_t)n * 2 * C + c) * S + s;
+    const float a = x[ir], b = x[ir + (int64_t)C * S];
+    float ur = coef[c] * a + coef[C + c] * b + coef[4 * C + c];
+    float ui = coef[2 * C + c] * a + coef[3 * C + c] * b + coef[5 * C + c];
+    ur = ur >= 0.f ? ur : slope * ur;
+    ui = ui >= 0.f ? ui : slope * ui;
+    const int64_t o = (int64_t)n * out_ns + (int64_t)c * S + s;
+    out[o] = ur;
+    out[o + out_im_off * S] = ui;
+  }
+}
+
+// backward of the above: gx (N, 2C, S) written; gcoef (6, C) accumulated with atomics (zeroed by caller)
+__global__ __launch_bounds__(256) void cplx_affine_act_bwd_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ coef,
+                                                                  const float* __restrict__ gy, int64_t gy_ns,
+                                                                  int64_t gy_im_off, int N, int C, int64_t S,
+                                                                  int nchunks, float slope, float* __restrict__ gx,
+                                                                  float* __restrict__ gcoef) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)N * C * nchunks) return;
+  const int sc = (int)(item % nchunks);
+  const int64_t r = item / nchunks;
+  const int c = (int)(r % C), n = (int)(r / C);
+  const float zrr = coef[c], zri = coef[C + c], zir = coef[2 * C + c], zii = coef[3 * C + c];
+  const float br = coef[4 * C + c], bi = coef[5 * C + c];
+  const int64_t base = ((int64_t)n * 2 * C + c) * S, gbase = (int64_t)n * gy_ns + (int64_t)c * S;
+  const int64_t s0 = (int64_t)sc * CX_CHUNK, s1 = min(s0 + CX_CHUNK, S);
+  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t s = s0 + lane; s < s1; s += 64) {
+    const float a = x[base + s], b = x[base + (int64_t)C * S + s];
+    const float ur = zrr * a + zri * b + br, ui = zir * a + zii * b + bi;
+    const float gr = gy[gbase + s] * (ur >= 0.f ? 1.f : slope);
+    const float gi = gy[gbase + gy_im_off * S + s] * (ui >= 0.f ? 1.f : slope);
+    gx[base + s] = zrr * gr + zir * gi;
+    gx[base + (int64_t)C * S + s] = zri * gr + zii * gi;
+    v[0] += gr * a; v[1] += gr * b; v[2] += gi * a; v[3] += gi * b; v[4] += gr; v[5] += gi;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const float d = rfx_wave_sum(v[q]);
+    if (lane == 0) atomicAdd(gcoef + q * C + c, d);
+  }
+}
+
+// m, tf, out: (N, 2, P) planes (sample stride given).  out = tanh(|m|)/|m| * m (*) tf   (complex product)
+__global__ void bound_mask_kernel(const float* __restrict__ m, const float* __restrict__ tf, float* __restrict__ out,
+                                  int N, int64_t P, int64_t m_ns, int64_t tf_ns, int64_t out_ns) {
+  const int64_t total = (int64_t)N * P;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i % P, n = i / P;
+    const float mr = m[n * m_ns + p], mi = m[n * m_ns + P + p];
+    const float tr = tf[n * tf_ns + p], ti = tf[n * tf_ns + P + p];
+    const float mag = sqrtf(mr * mr + mi * mi);
+    const float k = tanhf(mag) / mag;
+    const float ar = k * mr, ai = k * mi;
+    out[n * out_ns + p] = ar * tr - ai * ti;
+    out[n * out_ns + P + p] = ar * ti + ai * tr;
+  }
+}
+__global__ void bound_mask_bwd_kernel(const float* __restrict__ m, const float* __restrict__ tf,
+                                      const float* __restrict__ gout, float* __restrict__ gm, int N, int64_t P,
+                                      int64_t m_ns, int64_t tf_ns, int64_t g_ns, int64_t gm_ns) {
+  const int64_t total = (int64_t)N * P;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i % P, n = i / P;
+    const float mr = m[n * m_ns + p], mi = m[n * m_ns + P + p];
+    const float tr = tf[n * tf_ns + p], ti = tf[n * tf_ns + P + p];
+    const float gr = gout[n * g_ns + p], gi = gout[n * g_ns + P + p];
+    const float gar = gr * tr + gi * ti, gai = -gr * ti + gi * tr;   // gout (*) conj(tf)
+    const float mag = sqrtf(mr * mr + mi * mi);
+    const float th = tanhf(mag);
+    const float k = th / mag;
+    const float kp = ((1.f - th * th) * mag - th) / (mag * mag);      // dk/dmag
+    const float dot = (gar * mr + gai * mi) * kp / mag;
+    gm[n * gm_ns + p] = gar * k + dot * mr;
+    gm[n * gm_ns + P + p] = gai * k + dot * mi;
+  }
+}
+
+static int cx_grid(int64_t total) {
+  const int64_t b = (total + 1023) / 1024;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+extern "C" int rfx_cplx_moments(const float* x, int32_t N, int32_t C, int64_t S, double* sums, void* stream) {
+  if (!x || !sums || N <= 0 || C <= 0 || S <= 0) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 5 * C, s) != hipSuccess) return -3;
+  const int nchunks = (int)((S + CX_CHUNK - 1) / CX_CHUNK);
+  const int64_t items = (int64_t)N * C * nchunks;
+  hipLaunchKernelGGL(cplx_moments_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, x, N, C, S, nchunks, sums);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_cplx_moments_bwd(const float* x, const float* coef, int32_t N, int32_t C, int64_t S, float* gx,
+                                    void* stream) {
+  if (!x || !coef || !gx || N <= 0 || C <= 0 || S <= 0) return -1;
+  hipLaunchKernelGGL(cplx_moments_bwd_kernel, dim3(cx_grid((int64_t)N * C * S)), dim3(256), 0, (hipStream_t)stream, x,
+                     coef, N, C, S, gx);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_cplx_affine_act_fwd(const float* x, const float* coef, int32_t N, int32_t C, int64_t S,
+                                       float slope, float* out, int64_t out_ns, int64_t out_im_off, void* stream) {
+  if (!x || !coef || !out || N <= 0 || C <= 0 || S <= 0) return -1;
+  hipLaunchKernelGGL(cplx_affine_act_kernel, dim3(cx_grid((int64_t)N * C * S)), dim3(256), 0, (hipStream_t)stream, x,
+                     coef, N, C, S, slope, out, out_ns, out_im_off);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_cplx_affine_act_bwd(const float* x, const float* coef, const float* gy, int64_t gy_ns,
+                                       int64_t gy_im_off, int32_t N, int32_t C, int64_t S, float slope, float* gx,
+                                       float* gcoef, void* stream) {
+  if (!x || !coef || !gy || !gx || !gcoef || N <= 0 || C <= 0 || S <= 0) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(gcoef, 0, sizeof(float) * 6 * C, s) != hipSuccess) return -3;
+  const int nchunks = (int)((S + CX_CHUNK - 1) / CX_CHUNK);
+  const int64_t items = (int64_t)N * C * nchunks;
+  hipLaunchKernelGGL(cplx_affine_act_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, x, coef, gy, gy_ns,
+                     gy_im_off, N, C, S, nchunks, slope, gx, gcoef);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_bound_mask_fwd(const float* m, const float* tf, float* out, int32_t N, int64_t P, int64_t m_ns,
+                                  int64_t tf_ns, int64_t out_ns, void* stream) {
+  if (!m || !tf || !out || N <= 0 || P <= 0) return -1;
+  hipLaunchKernelGGL(bound_mask_kernel, dim3(cx_grid((int64_t)N * P)), dim3(256), 0, (hipStream_t)stream, m, tf, out, N,
+                     P, m_ns, tf_ns, out_ns);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_bound_mask_bwd(const float* m, const float* tf, const float* gout, float* gm, int32_t N, int64_t P,
+                                  int64_t m_ns, int64_t tf_ns, int64_t g_ns, int64_t gm_ns, void* stream) {
+  if (!m || !tf || !gout || !gm || N <= 0 || P <= 0) return -1;
+  hipLaunchKernelGGL(bound_mask_bwd_kernel, dim3(cx_grid((int64_t)N * P)), dim3(256), 0, (hipStream_t)stream, m, tf,
+                     gout, gm, N, P, m_ns, tf_ns, g_ns, gm_ns);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

@@ -136,6 +136,25 @@ class DemucsModel(_RemovalWrapper):
         return self.model(x).squeeze(1)
 
 
+class DCUNetModel(_RemovalWrapper):
+    def __init__(self, sample_rate, num_bins, **kwargs):
+        super().__init__()
+        from .dcunet import DCUNet
+        self.model = DCUNet(**kwargs)          # asteroid keeps its own sample_rate default (wrapper swallows it)
+        self.mrstftloss = MultiResolutionSTFTLoss(n_bins=num_bins, sample_rate=sample_rate)
+        self.l1loss = L1Loss()
+
+    def forward(self, batch):
+        x, target = batch
+        output = self.model(x.squeeze(1))                      # (B, 1, T)
+        if output.shape[-1] < target.shape[-1]:                # models.py:360-361
+            target = causal_crop(target, output.shape[-1])
+        return self._loss(output, target), output
+
+    def sample(self, x: Tensor) -> Tensor:
+        return self.model(x.squeeze(1))
+
+
 def mixup(x: torch.Tensor, y: torch.Tensor, alpha: float = 1.0):
     """models.py:393-420: per-item lambda ~ U(0.25, 0.75), applied with probability 0.5; labels are
     the logical OR of the two clips (not a lambda blend)."""
