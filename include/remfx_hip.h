@@ -224,6 +224,10 @@ int rfx_bound_mask_fwd(const float* m, const float* tf, float* out, int32_t N, i
 int rfx_bound_mask_bwd(const float* m, const float* tf, const float* gout, float* gm, int32_t N, int64_t P,
                        int64_t m_ns, int64_t tf_ns, int64_t g_ns, int64_t gm_ns, void* stream);
 
+/* Open-Unmix Separator (niter=0): out = mag * xc/|xc| over n complex bins (models.py:298,304) */
+int rfx_phase_mask_fwd(const float* mag, const float* xc, float* out, int64_t n, void* stream);
+int rfx_phase_mask_bwd(const float* xc, const float* gout, float* gmag, int64_t n, void* stream);
+
 /* ---- losses -------------------------------------------------------------------
  * auraloss STFTLoss terms on complex spectra [R][n] (n = bins*frames, view_as_real layout):
  * sums[r] += { sum (|Y|-|X|)^2, sum |Y|^2, sum |log|X| - log|Y|| }, |.| = sqrt(max(re^2+im^2, eps)).

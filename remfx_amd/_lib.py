@@ -120,6 +120,8 @@ SIGNATURES = {
     "rfx_cplx_affine_act_bwd": [_P, _P, _P, _I64, _I64, _I32, _I32, _I64, C.c_float, _P, _P, _P],
     "rfx_bound_mask_fwd": [_P, _P, _P, _I32, _I64, _I64, _I64, _I64, _P],
     "rfx_bound_mask_bwd": [_P, _P, _P, _P, _I32, _I64, _I64, _I64, _I64, _I64, _P],
+    "rfx_phase_mask_fwd": [_P, _P, _P, _I64, _P],
+    "rfx_phase_mask_bwd": [_P, _P, _P, _I64, _P],
     "rfx_glu_fwd": [_P, _P, _I64, _I64, _I64, _P],
     "rfx_glu_bwd": [_P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_act_fwd": [_P, _P, _I64, _I32, _P],

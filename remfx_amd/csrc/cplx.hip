@@ -140,6 +140,28 @@ __global__ void bound_mask_bwd_kernel(const float* __restrict__ m, const float* 
   }
 }
 
+// Open-Unmix Separator, niter = 0 "wiener": estimate = magnitude x phase of the mixture STFT
+// (models.py:298 via umx Separator).  xc, out: complex [n] (view_as_real layout); mag: [n].
+__global__ void phase_mask_kernel(const float* __restrict__ mag, const float2* __restrict__ xc,
+                                  float2* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float2 x = xc[i];
+    const float a = sqrtf(x.x * x.x + x.y * x.y);
+    const float c = a > 0.f ? x.x / a : 1.f, s = a > 0.f ? x.y / a : 0.f;   // cos / sin of atan2(im, re)
+    const float m = mag[i];
+    out[i] = make_float2(m * c, m * s);
+  }
+}
+__global__ void phase_mask_bwd_kernel(const float2* __restrict__ xc, const float2* __restrict__ gout,
+                                      float* __restrict__ gmag, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float2 x = xc[i], g = gout[i];
+    const float a = sqrtf(x.x * x.x + x.y * x.y);
+    const float c = a > 0.f ? x.x / a : 1.f, s = a > 0.f ? x.y / a : 0.f;
+    gmag[i] = g.x * c + g.y * s;
+  }
+}
+
 static int cx_grid(int64_t total) {
   const int64_t b = (total + 1023) / 1024;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -197,6 +219,21 @@ extern "C" int rfx_bound_mask_bwd(const float* m, const float* tf, const float* 
   if (!m || !tf || !gout || !gm || N <= 0 || P <= 0) return -1;
   hipLaunchKernelGGL(bound_mask_bwd_kernel, dim3(cx_grid((int64_t)N * P)), dim3(256), 0, (hipStream_t)stream, m, tf,
                      gout, gm, N, P, m_ns, tf_ns, g_ns, gm_ns);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rfx_phase_mask_fwd(const float* mag, const float* xc, float* out, int64_t n, void* stream) {
+  if (!mag || !xc || !out || n <= 0) return -1;
+  hipLaunchKernelGGL(phase_mask_kernel, dim3(cx_grid(n)), dim3(256), 0, (hipStream_t)stream, mag, (const float2*)xc,
+                     (float2*)out, n);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_phase_mask_bwd(const float* xc, const float* gout, float* gmag, int64_t n, void* stream) {
+  if (!xc || !gout || !gmag || n <= 0) return -1;
+  hipLaunchKernelGGL(phase_mask_bwd_kernel, dim3(cx_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float2*)xc,
+                     (const float2*)gout, gmag, n);
   RFX_CHECK_LAUNCH();
   return 0;
 }

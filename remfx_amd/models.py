@@ -136,6 +136,34 @@ class DemucsModel(_RemovalWrapper):
         return self.model(x).squeeze(1)
 
 
+class OpenUnmixModel(_RemovalWrapper):
+    def __init__(self, n_fft: int = 2048, hop_length: int = 512, n_channels: int = 1, alpha: float = 0.3,
+                 sample_rate: int = 22050):
+        super().__init__()
+        from .umx import OpenUnmix, Separator
+        from .utils import spectrogram
+        self._spectrogram = spectrogram
+        self.n_channels, self.n_fft, self.hop_length, self.alpha = n_channels, n_fft, hop_length, alpha
+        self.register_buffer("window", torch.hann_window(n_fft))
+        self.num_bins = n_fft // 2 + 1
+        self.sample_rate = sample_rate
+        self.model = OpenUnmix(nb_channels=n_channels, nb_bins=self.num_bins)
+        self.separator = Separator(target_models={"other": self.model}, nb_channels=n_channels,
+                                   sample_rate=sample_rate, n_fft=n_fft, n_hop=hop_length)
+        self.mrstftloss = MultiResolutionSTFTLoss(n_bins=self.num_bins, sample_rate=sample_rate)
+        self.l1loss = L1Loss()
+
+    def forward(self, batch):
+        x, target = batch
+        X = self._spectrogram(x, self.window, self.n_fft, self.hop_length, self.alpha)
+        Y = self.model(X)  # noqa: F841  dead value kept: it updates BN running stats / draws dropout (Q3)
+        sep_out = self.separator(x).squeeze(1)
+        return self._loss(sep_out, target), sep_out
+
+    def sample(self, x: Tensor) -> Tensor:
+        return self.separator(x).squeeze(1)
+
+
 class DCUNetModel(_RemovalWrapper):
     def __init__(self, sample_rate, num_bins, **kwargs):
         super().__init__()
