@@ -38,6 +38,11 @@ def build_model(workload, device):
                               causal=False, estimate_loudness=False)
     elif workload == "demucs":                               # cfg/model/demucs.yaml
         net = models.DemucsModel(sample_rate=SR, sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
+    elif workload == "dcunet":                               # cfg/model/dcunet.yaml
+        net = models.DCUNetModel(sample_rate=SR, num_bins=1025, architecture="Large-DCUNet-20",
+                                 stft_kernel_size=512, fix_length_mode="pad")
+    elif workload == "umx":                                  # cfg/model/umx.yaml
+        net = models.OpenUnmixModel(n_fft=2048, hop_length=512, n_channels=1, alpha=0.3, sample_rate=SR)
     else:
         raise ValueError(workload)
     model = models.RemFX(lr=1e-4, lr_beta1=0.95, lr_beta2=0.999, lr_eps=1e-6, lr_weight_decay=1e-3,
@@ -87,36 +92,36 @@ class KernelTimer:
 
 
 def cpu_baseline(workload):
-    """The CPU oracle (pure-torch restatement of the reference) timed on the host cores, one
-    bounded sample of the same workload: fwd + bwd of the removal network + loss."""
-    from oracle import ref_hdemucs, ref_losses, ref_tcn
-    cores = os.cpu_count() or 1
+    """The CPU oracle (pure-torch restatement of the reference) timed on the host cores: forward + loss +
+    backward of the removal network on ONE short clip (bounded: tens of seconds at most).  Threads are capped
+    at 32: torch's CPU kernels get slower, not faster, when spread over every hardware thread of the host."""
+    from oracle import ref_dcunet, ref_hdemucs, ref_losses, ref_tcn, ref_umx
+    from oracle.ref_utils import causal_crop
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)
+    T = {"tcn": 16384, "demucs": 65536, "dcunet": 32768, "umx": 65536}[workload]
+    x, y = torch.randn(1, 1, T, generator=g) * 0.1, torch.randn(1, 1, T, generator=g) * 0.1
     if workload == "tcn":
-        T, B = 32768, 1
         sd = {k: v.requires_grad_(True) for k, v in ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7).items()}
-        x, y = torch.randn(B, 1, T, generator=g) * 0.1, torch.randn(B, 1, T, generator=g) * 0.1
-        t0 = time.time()
-        out = ref_tcn.tcn_forward(x, sd, 20)
-        from oracle.ref_utils import causal_crop
-        loss = ref_losses.removal_loss(out, causal_crop(y, out.shape[-1]))
-        loss.backward()
-        dt = time.time() - t0
-        sample = f"oracle TCN (cfg/model/tcn.yaml) fwd+bwd, {B} x {T} samples"
-    else:
-        T, B = CLIP, 1
-        torch.manual_seed(0)
+        fwd = lambda: ref_tcn.tcn_forward(x, sd, 20)
+    elif workload == "demucs":
         net = ref_hdemucs.HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
-        x, y = torch.randn(B, 1, T, generator=g) * 0.1, torch.randn(B, 1, T, generator=g) * 0.1
-        t0 = time.time()
-        out = net(x).squeeze(1)
-        loss = ref_losses.removal_loss(out, y)
-        loss.backward()
-        dt = time.time() - t0
-        sample = f"oracle HDemucs (cfg/model/demucs.yaml) fwd+bwd, {B} x {T} samples"
-    return {"value": round(B * T / SR / dt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": sample}
+        fwd = lambda: net(x).squeeze(1)
+    elif workload == "dcunet":
+        net = ref_dcunet.DCUNet(stft_kernel_size=512, fix_length_mode="pad")
+        fwd = lambda: net(x.squeeze(1))
+    else:
+        net = ref_umx.OpenUnmix(nb_bins=1025, nb_channels=1)
+        fwd = lambda: ref_umx.separator(net, x).squeeze(1)
+    t0 = time.time()
+    out = fwd()
+    tgt = causal_crop(y, out.shape[-1]) if out.shape[-1] < y.shape[-1] else y
+    ref_losses.removal_loss(out, tgt).backward()
+    dt = time.time() - t0
+    return {"value": round(T / SR / dt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle {workload} forward + MRSTFT/L1 loss + backward, 1 clip x {T} samples, {dt:.1f} s"}
 
 
 def main():
@@ -124,7 +129,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("RFX_WORKLOAD", "tcn"))
+    ap.add_argument("--workload", default=os.environ.get("RFX_WORKLOAD", "demucs"),
+                    choices=["demucs", "tcn", "dcunet", "umx"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -134,7 +140,8 @@ def main():
     assert world == args.gpus or world == 1, (world, args.gpus)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    batch = args.batch or {"tcn": 32, "demucs": 64}[args.workload]
+    # BASELINE.json configs: Demucs 64 clips/GPU (headline), TCN 32, DCUNet 32 over 8 GPUs = 4/GPU, UMX 4
+    batch = args.batch or {"tcn": 32, "demucs": 64, "dcunet": 4, "umx": 4}[args.workload]
 
     model = build_model(args.workload, device)
     cfg = model.configure_optimizers()
@@ -184,10 +191,12 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": {"tcn": "TCN (cfg/model/tcn.yaml) train step, +exp=reverb model=tcn",
-                                "demucs": "Hybrid Demucs (cfg/model/demucs.yaml) train step, +exp=chorus_aug model=demucs"}[args.workload],
+                                "demucs": "Hybrid Demucs (cfg/model/demucs.yaml) train step, +exp=chorus_aug model=demucs",
+                                "dcunet": "DCUNet Large-DCUNet-20 (cfg/model/dcunet.yaml) train step, +exp=5-5_full model=dcunet",
+                                "umx": "Open-Unmix (cfg/model/umx.yaml) train step, +exp=distortion model=umx"}[args.workload],
                    "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
                    "step": "fwd + MRSTFT+100*L1 loss + bwd + clip 10 + AdamW + per-step metrics",
-                   "parallelism": f"dp{world}", "final_loss": round(float(loss), 5)},
+                   "parallelism": f"dp{world}", "final_loss": round(float(loss.detach()), 5)},
         "roofline": {"bound": "mfma", "kernel": "gemm_fwd_kernel (gather-GEMM, v_mfma_f32_32x32x2_f32)",
                      "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,

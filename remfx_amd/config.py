@@ -32,9 +32,24 @@ TARGET_ALIASES = {
 SKIP_TARGET_PREFIXES = ("pytorch_lightning.callbacks.", "remfx.callbacks.")
 
 
+class _Loader(yaml.SafeLoader):
+    """PyYAML (YAML 1.1) reads `1e-4` as a string; OmegaConf reads it as a float.  Follow OmegaConf."""
+
+
+_Loader.add_implicit_resolver(
+    "tag:yaml.org,2002:float",
+    re.compile(r"^[-+]?(?:[0-9][0-9_]*\.[0-9_]*(?:[eE][-+]?[0-9]+)?|\.[0-9_]+(?:[eE][-+]?[0-9]+)?"
+               r"|[0-9][0-9_]*[eE][-+]?[0-9]+|\.(?:inf|Inf|INF)|\.(?:nan|NaN|NAN))$"),
+    list("-+0123456789."))
+
+
+def _yaml(text):
+    return yaml.load(text, Loader=_Loader)
+
+
 def _load(path):
     with open(path) as f:
-        return yaml.safe_load(f) or {}
+        return _yaml(f.read()) or {}
 
 
 def _merge(dst, src):
@@ -48,7 +63,7 @@ def _merge(dst, src):
 
 def _parse_value(s):
     try:
-        return yaml.safe_load(s)
+        return _yaml(s)
     except yaml.YAMLError:
         return s
 

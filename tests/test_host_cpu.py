@@ -83,6 +83,7 @@ def test_config_composer(tmp_path):
     assert c["model"] == {"name": "b"} and c["net"] == {"name": "b"}          # node interpolation
     assert c["datamodule"]["train_batch_size"] == 64 and c["new"] == {"key": [1, 2]}
     assert c["trainer"] == {"accelerator": None, "max_steps": 3}
+    assert config._yaml("lr: 1e-4")["lr"] == 1e-4 and config._parse_value("3e-5") == 3e-5
     with pytest.raises(KeyError):
         config.compose(d, "config.yaml", ["nope.key=1"])
     os.environ["RFX_TEST_ROOT"] = "/x"
