@@ -70,6 +70,7 @@ struct LaneCtx {
 // on the result forces s_waitcnt vmcnt(0) right after the load and exposes the full
 // memory latency every K step (measured: 47 -> see profiles/ after the change).
 __device__ float rfx_zero_f32[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ float rfx_one_f32[4] = {1.f, 1.f, 1.f, 1.f};
 
 // ktl: the 16 tap entries of this K step, staged in LDS (scalar loads of the table
 // serialise on lgkmcnt(0) per entry; LDS broadcast reads do not).
@@ -183,7 +184,7 @@ __device__ __forceinline__ void run_phase(const rfx_gemm_desc& d, const float* _
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void gemm_fwd_kernel(const FwdArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R;
   __shared__ __attribute__((aligned(16))) float as[2 * 16 * BM];
   __shared__ __attribute__((aligned(16))) int4 kts[3 * 16];
@@ -413,7 +414,11 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
   const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
   const int prow = tid >> 5;  // 0..7: row group for loads; lane position = tid & 31
   const int pl = tid & 31;
-  for (int t = t_begin; t < t_end; ++t) {
+  float gv[RM / 8], xv[RK / 8];
+  // Gathers of one 32-position tile into registers.  Invalid lanes read a device 0 (or 1 for the
+  // bias column) instead of masking the loaded value, so nothing consumes the result until the
+  // LDS store of the NEXT iteration: the loads stay in flight under this tile's MFMAs.
+  auto load_tile = [&](int t) {
     const int n = t / w.tiles_per_sample;
     const int j = (t - n * w.tiles_per_sample) * 32 + pl;
     const bool jvalid = j < P;
@@ -423,31 +428,32 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
     const float* inb = w.in + (int64_t)n * d.in_ns + (int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs;
     const float* gb = w.g + (int64_t)n * d.out_ns + (int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
                       (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
-    float gv[RM / 8], xv[RK / 8];
 #pragma unroll
     for (int i = 0; i < RM / 8; ++i) {
       const int m = m0 + prow + 8 * i;
-      const bool ok = jvalid && m < d.M;
-      const float* p = ok ? gb + (int64_t)m * d.out_cs : w.g;
-      const float v = *p;
-      gv[i] = ok ? v : 0.f;
+      const bool ok = jvalid & (m < d.M);
+      const float* p = ok ? gb + (int64_t)m * d.out_cs : rfx_zero_f32;
+      gv[i] = *p;
     }
 #pragma unroll
     for (int i = 0; i < RK / 8; ++i) {
       const rfx_ktab_entry e = kts[prow + 8 * i];
       const bool ones = e.flags & 1;
-      const bool ok = jvalid && !ones && (unsigned)(ia0 + e.da) < (unsigned)d.IA &&
-                      (unsigned)(ib0 + e.db) < (unsigned)d.IB;
-      const float* p = ok ? inb + e.off : w.in;
-      const float v = *p;
-      xv[i] = ok ? v : ((ones && jvalid) ? 1.f : 0.f);
+      const bool ok = jvalid & !ones & ((unsigned)(ia0 + e.da) < (unsigned)d.IA) &
+                      ((unsigned)(ib0 + e.db) < (unsigned)d.IB);
+      const float* p = ok ? inb + e.off : ((ones & jvalid) ? rfx_one_f32 : rfx_zero_f32);
+      xv[i] = *p;
     }
+  };
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();  // previous tile's operand reads are done
 #pragma unroll
     for (int i = 0; i < RM / 8; ++i) gs[(prow + 8 * i) * LD + pl] = gv[i];
 #pragma unroll
     for (int i = 0; i < RK / 8; ++i) xs[(prow + 8 * i) * LD + pl] = xv[i];
     __syncthreads();
+    load_tile(t + 1 < t_end ? t + 1 : t);   // unconditional (branch-free): the last tile is re-read
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       float av[TM], bv[TK];
