@@ -86,12 +86,18 @@ typedef struct rfx_epilogue {
   float* gparam;
 } rfx_epilogue;
 
+/* Arithmetic of the MFMA gather-GEMM.  RFX_PREC_F32: v_mfma_f32_32x32x2_f32, exact fp32 products.
+ * RFX_PREC_BF16X3: every fp32 operand is split into two bf16 (hi + lo) and the product is
+ * hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- ~2^-16 relative error per
+ * product, 3/16 of the fp32 MFMA cost.  The packed buffer has the same size in both modes. */
+enum rfx_gemm_prec { RFX_PREC_F32 = 0, RFX_PREC_BF16X3 = 1 };
+
 /* A[k][m] = w[m*w_ms + woff[k]]  (k < K), zero padded to [Kpad + 16][Mpad]: the packed
  * matrix carries one extra all-zero K step and every ktab passed to rfx_gemm_fwd
  * carries Kpad + 32 rows (the tail rows invalid: da = -2^30) so that the MFMA kernel's
  * operand prefetch is branch-free. */
 int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
-               int32_t Mpad, int32_t Kpad, float* apack, void* stream);
+               int32_t Mpad, int32_t Kpad, int32_t prec, float* apack, void* stream);
 /* w[m*w_ms + woff[k]] += dapack[m][k]  (dapack is the [M][Kpad] output of rfx_gemm_wgrad). */
 int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
                    int32_t Kpad, float* dw, void* stream);
@@ -104,6 +110,7 @@ int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rfx_ktab_entr
                  const float* in, float* out, const rfx_epilogue* epi,
                  const float* apack2, const rfx_ktab_entry* ktab2, int32_t K2, int32_t Kpad2,
                  const float* in2 /* phase-2 input, same strides as `in`; NULL = `in` */,
+                 int32_t prec /* enum rfx_gemm_prec; must match the packing; thin (M <= 8) path is always fp32 */,
                  void* stream);
 
 /* Weight gradient of the same descriptor:

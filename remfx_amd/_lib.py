@@ -95,9 +95,9 @@ _P, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
 SIGNATURES = {
     "rfx_abi_version": [],
     "rfx_gemm_pick_r": [_I32],
-    "rfx_pack_a": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P],
+    "rfx_pack_a": [_P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "rfx_unpack_add": [_P, _P, _I64, _I32, _I32, _I32, _P, _P],
-    "rfx_gemm_fwd": [C.POINTER(GemmDesc), _P, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _I32, _I32, _P, _P],
+    "rfx_gemm_fwd": [C.POINTER(GemmDesc), _P, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _I32, _I32, _P, _I32, _P],
     "rfx_gemm_wgrad": [C.POINTER(GemmDesc), _P, _P, _P, _P, _P],
     "rfx_fft_analysis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
     "rfx_fft_synthesis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],

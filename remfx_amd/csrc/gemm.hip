@@ -44,6 +44,37 @@ __global__ void pack_a_kernel(const float* __restrict__ w, const int32_t* __rest
   }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// bf16x3 operand layout: two arrays (hi, lo) of [Kpad/8 + 2][Mpad] 16-byte cells, a cell = the 8
+// consecutive-k bf16 values of one output row = exactly one lane's MFMA A fragment.
+__global__ void pack_a_bf3_kernel(const float* __restrict__ w, const int32_t* __restrict__ woff,
+                                  int64_t w_ms, int M, int K, int Mpad, int Kpad, uint4* __restrict__ apack) {
+  const int64_t cells = (int64_t)(Kpad / 8 + 2) * Mpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int k8 = (int)(i / Mpad), m = (int)(i % Mpad);
+    uint32_t hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k8 * 8 + q;
+      float v = 0.f;
+      if (k < K && m < M) v = w[(int64_t)m * w_ms + woff[k]];
+      const uint32_t h = bf16_rne(v);
+      const uint32_t l = bf16_rne(v - __uint_as_float(h << 16));
+      hi[q >> 1] |= h << (16 * (q & 1));
+      lo[q >> 1] |= l << (16 * (q & 1));
+    }
+    apack[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    apack[cells + i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 __global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_t* __restrict__ woff,
                                   int64_t w_ms, int M, int K, int Kpad, float* __restrict__ dw) {
   const int64_t total = (int64_t)K * M;
@@ -183,7 +214,131 @@ __device__ __forceinline__ void run_phase(const rfx_gemm_desc& d, const float* _
   if (ks < nk) k_step<R>(d, apack, kt4, ks, m0, c, as, kts, acc, b0, b1);
 }
 
+// ---------------------------------------------------------------------------------
+// bf16x3 variant of the K loop: every fp32 operand is split x = hi + lo (two bf16) and
+// a.b ~= hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): ~2^-16
+// relative error per product instead of 2^-24, at 3/16 of the fp32-MFMA issue cost.
+// Lane (j = lane & 31, h = lane >> 5) now gathers the 8 consecutive taps k = 8h .. 8h+7 of its
+// column (one MFMA B fragment); packed weights arrive pre-split (pack_a_bf3_kernel).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void load_b8_bf3(const rfx_gemm_desc& d, const int4* ktl, int h, const LaneCtx& c,
+                                            float (&b)[8]) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    int4 e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = ktl[8 * h + half * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = c.jvalid & ((unsigned)(c.ia0 + e[q].y) < (unsigned)d.IA) &
+                      ((unsigned)(c.ib0 + e[q].z) < (unsigned)d.IB);
+      const float* p = ok ? (c.inb + e[q].x) : c.safe;
+      b[half * 4 + q] = *p;
+    }
+  }
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+  uint32_t hw[4], lw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t u0 = __float_as_uint(x[2 * q]), u1 = __float_as_uint(x[2 * q + 1]);
+    const uint32_t h0 = u0 & 0xffff0000u, h1 = u1 & 0xffff0000u;
+    const float r0 = x[2 * q] - __uint_as_float(h0), r1 = x[2 * q + 1] - __uint_as_float(h1);
+    hw[q] = (u0 >> 16) | h1;
+    lw[q] = ((__float_as_uint(r0) + 0x8000u) >> 16) | ((__float_as_uint(r1) + 0x8000u) & 0xffff0000u);
+  }
+  hi = __builtin_bit_cast(bf16x8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+}
+
 template <int R>
+__device__ __forceinline__ void stage_a_bf3_load(const uint4* __restrict__ apk, int64_t arr_stride, int Mpad,
+                                                 int k8_0, int m0, int tid, uint4 (&r)[2]) {
+  constexpr int BM = 32 * R, NV = 4 * BM;   // (hi, lo) x 2 k8 rows x BM cells
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i * 256 < NV) {
+      int idx = tid + i * 256;
+      idx = idx < NV ? idx : NV - 1;
+      const int arr = idx / (2 * BM), rem = idx % (2 * BM);
+      const int kk8 = rem / BM, mm = rem % BM;
+      r[i] = apk[arr * arr_stride + (int64_t)(k8_0 + kk8) * Mpad + m0 + mm];
+    }
+  }
+}
+template <int R>
+__device__ __forceinline__ void stage_a_bf3_store(uint4* as, int tid, const uint4 (&r)[2]) {
+  constexpr int BM = 32 * R, NV = 4 * BM;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    if (i * 256 < NV && idx < NV) as[idx] = r[i];
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void k_step_bf3(const rfx_gemm_desc& d, const uint4* __restrict__ apk,
+                                           int64_t arr_stride, const int4* __restrict__ kt4, int ks, int m0,
+                                           const LaneCtx& c, uint4* as, int4* kts, f32x16 (&acc)[R],
+                                           const float (&bc)[8], float (&bn)[8]) {
+  constexpr int BM = 32 * R;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int cur = ks & 1;
+  const uint4* a_lds = as + cur * 4 * BM;
+  uint4 ah[R], al[R];
+#pragma unroll
+  for (int mt = 0; mt < R; ++mt) {
+    ah[mt] = a_lds[h * BM + mt * 32 + l31];
+    al[mt] = a_lds[2 * BM + h * BM + mt * 32 + l31];
+  }
+  uint4 areg[2];
+  stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2 * (ks + 1), m0, tid, areg);
+  load_b8_bf3(d, kts + ((ks + 1) % 3) * 16, h, c, bn);
+  const int4 ktreg = kt4[(ks + 2) * 16 + (tid & 15)];
+  bf16x8 bh, bl;
+  split8(bc, bh, bl);
+#pragma unroll
+  for (int mt = 0; mt < R; ++mt) {
+    const bf16x8 fh = __builtin_bit_cast(bf16x8, ah[mt]), fl = __builtin_bit_cast(bf16x8, al[mt]);
+    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bh, acc[mt], 0, 0, 0);
+    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl, acc[mt], 0, 0, 0);
+    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc[mt], 0, 0, 0);
+  }
+  stage_a_bf3_store<R>(as + (cur ^ 1) * 4 * BM, tid, areg);
+  if (tid < 16) kts[((ks + 2) % 3) * 16 + tid] = ktreg;
+  __syncthreads();
+}
+
+template <int R>
+__device__ __forceinline__ void run_phase_bf3(const rfx_gemm_desc& d, const float* __restrict__ apack,
+                                              const rfx_ktab_entry* __restrict__ ktab, int Kpad, int m0,
+                                              const LaneCtx& c, float* as_f, int4* kts, f32x16 (&acc)[R]) {
+  const int tid = threadIdx.x;
+  const int h = (tid & 63) >> 5;
+  const int nk = Kpad / 16;
+  if (nk == 0) return;
+  const uint4* apk = reinterpret_cast<const uint4*>(apack);
+  const int64_t arr_stride = (int64_t)(Kpad / 8 + 2) * d.Mpad;
+  uint4* as = reinterpret_cast<uint4*>(as_f);
+  const int4* kt4 = reinterpret_cast<const int4*>(ktab);
+  float b0[8], b1[8];
+  uint4 areg[2];
+  stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 0, m0, tid, areg);
+  if (tid < 32) kts[tid] = kt4[tid];
+  stage_a_bf3_store<R>(as, tid, areg);
+  __syncthreads();
+  load_b8_bf3(d, kts, h, c, b0);
+  int ks = 0;
+  for (; ks + 1 < nk; ks += 2) {
+    k_step_bf3<R>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b1);
+    k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0);
+  }
+  if (ks < nk) k_step_bf3<R>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b1);
+}
+
+template <int R, bool BF3>
 __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R;
   __shared__ __attribute__((aligned(16))) float as[2 * 16 * BM];
@@ -210,7 +365,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  run_phase<R>(d, g.apack, g.ktab, d.Kpad, m0, c, as, kts, acc);
+  if (BF3) run_phase_bf3<R>(d, g.apack, g.ktab, d.Kpad, m0, c, as, kts, acc);
+  else run_phase<R>(d, g.apack, g.ktab, d.Kpad, m0, c, as, kts, acc);
 
   const rfx_epilogue& e = g.e;
   const bool two = g.apack2 != nullptr;
@@ -236,7 +392,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
     if (g.in2) {
       c2.inb = g.in2 + (c.inb - g.in);
     }
-    run_phase<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
+    if (BF3) run_phase_bf3<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
+    else run_phase<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
   }
 
   const int64_t opos = (int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
@@ -534,8 +691,16 @@ static bool desc_ok(const rfx_gemm_desc* d) {
 extern "C" int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 
 extern "C" int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
-                          int32_t Mpad, int32_t Kpad, float* apack, void* stream) {
+                          int32_t Mpad, int32_t Kpad, int32_t prec, float* apack, void* stream) {
   if (!w || !woff || !apack || M <= 0 || K < 0 || Mpad < M || Kpad < K) return -1;
+  if (prec == 1) {
+    const int64_t cells = (int64_t)(Kpad / 8 + 2) * Mpad;
+    const int grid = (int)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_a_bf3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, woff, w_ms, M, K, Mpad,
+                       Kpad, reinterpret_cast<uint4*>(apack));
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   const int64_t total = (int64_t)(Kpad + 16) * Mpad;
   if (total == 0) return 0;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -575,7 +740,7 @@ extern "C" int rfx_gemm_pick_r(int32_t M) { return pick_r(M); }
 extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rfx_ktab_entry* ktab,
                             const float* in, float* out, const rfx_epilogue* epi, const float* apack2,
                             const rfx_ktab_entry* ktab2, int32_t K2, int32_t Kpad2, const float* in2,
-                            void* stream) {
+                            int32_t prec, void* stream) {
   if (!desc_ok(d) || !apack || !ktab || !in || !out) return -1;
   if ((apack2 != nullptr) != (ktab2 != nullptr)) return -1;
   if (apack2 && (Kpad2 % 16 != 0 || Kpad2 < K2)) return -1;
@@ -601,11 +766,20 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   const int bm = 32 * r;
   if (d->Mpad % bm != 0) return -1;
   dim3 grid((P + 127) / 128, d->Mpad / bm, d->N);
-  switch (r) {
-    case 1: hipLaunchKernelGGL(gemm_fwd_kernel<1>, grid, dim3(256), 0, s, g); break;
-    case 2: hipLaunchKernelGGL(gemm_fwd_kernel<2>, grid, dim3(256), 0, s, g); break;
-    case 3: hipLaunchKernelGGL(gemm_fwd_kernel<3>, grid, dim3(256), 0, s, g); break;
-    default: hipLaunchKernelGGL(gemm_fwd_kernel<4>, grid, dim3(256), 0, s, g); break;
+  if (prec == 1) {
+    switch (r) {
+      case 1: hipLaunchKernelGGL((gemm_fwd_kernel<1, true>), grid, dim3(256), 0, s, g); break;
+      case 2: hipLaunchKernelGGL((gemm_fwd_kernel<2, true>), grid, dim3(256), 0, s, g); break;
+      case 3: hipLaunchKernelGGL((gemm_fwd_kernel<3, true>), grid, dim3(256), 0, s, g); break;
+      default: hipLaunchKernelGGL((gemm_fwd_kernel<4, true>), grid, dim3(256), 0, s, g); break;
+    }
+  } else {
+    switch (r) {
+      case 1: hipLaunchKernelGGL((gemm_fwd_kernel<1, false>), grid, dim3(256), 0, s, g); break;
+      case 2: hipLaunchKernelGGL((gemm_fwd_kernel<2, false>), grid, dim3(256), 0, s, g); break;
+      case 3: hipLaunchKernelGGL((gemm_fwd_kernel<3, false>), grid, dim3(256), 0, s, g); break;
+      default: hipLaunchKernelGGL((gemm_fwd_kernel<4, false>), grid, dim3(256), 0, s, g); break;
+    }
   }
   RFX_CHECK_LAUNCH();
   return 0;

@@ -12,6 +12,16 @@ import torch
 from . import _lib, convplan
 from ._lib import Epilogue, GemmDesc, check
 
+# arithmetic of the MFMA gather-GEMM: "f32" (exact fp32 MFMA) or "bf16x3" (split-bf16 emulation)
+import os as _os
+GEMM_PREC = {"f32": 0, "bf16x3": 1}[_os.environ.get("RFX_GEMM_PREC", "f32")]
+
+
+def set_gemm_precision(name):
+    global GEMM_PREC
+    GEMM_PREC = {"f32": 0, "bf16x3": 1}[name]
+
+
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "tanh": 3, "prelu": 4, "leaky": 5, "sigmoid": 6}
 
 
@@ -61,10 +71,11 @@ def _plans(key, device, builder):
 def pack_a(dp, w):
     """Gather the weight tensor into the packed [Kpad][Mpad] A matrix of a plan."""
     p = dp.p
+    prec = GEMM_PREC if p.M > 8 else 0          # thin path is always fp32
     apack = torch.empty((p.Kpad + 16, p.Mpad), device=w.device, dtype=torch.float32)
     nrows = p.extra["n_weight_rows"]
     if True:
-        check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff), p.w_ms, p.M, nrows, p.Mpad, p.Kpad,
+        check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff), p.w_ms, p.M, nrows, p.Mpad, p.Kpad, prec,
                                     _ptr(apack), _stream()), "rfx_pack_a")
     return apack
 
@@ -86,7 +97,8 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
     else:
         a2, k2, K2, Kpad2 = None, None, 0, 0
     check(_lib.lib().rfx_gemm_fwd(C.byref(dp.desc), _ptr(apack), _ptr(dp.ktab), _ptr(x), _ptr(out),
-                                  C.byref(e), a2, k2, K2, Kpad2, _ptr(in2), _stream()), "rfx_gemm_fwd")
+                                  C.byref(e), a2, k2, K2, Kpad2, _ptr(in2), GEMM_PREC, _stream()),
+          "rfx_gemm_fwd")
     return out
 
 
