@@ -119,7 +119,7 @@ int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rfx_ktab_entr
  * Rows k with ktab flag bit0 use In == 1 (bias gradient).  dapack must be
  * zero-initialised by the caller; partial sums are combined with fp32 atomics. */
 int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const float* in,
-                   const float* g, float* dapack, void* stream);
+                   const float* g, float* dapack, int32_t prec, void* stream);
 
 /* ---- framed FFT front / back end ---------------------------------------------
  * rfx_fft_analysis : frames -> window -> real FFT -> epilogue.  As STFT it reproduces

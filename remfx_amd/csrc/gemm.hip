@@ -638,6 +638,119 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
       }
 }
 
+// bf16x3 weight gradient: same tiling and gathers as gemm_wgrad_kernel, but the two LDS tiles hold
+// the operands pre-split into bf16 hi / lo halves ([row][32 positions], 80-byte rows: 16-byte aligned
+// MFMA fragments, conflict-free ds_read_b128) and the product runs on v_mfma_f32_32x32x16_bf16.
+template <int TM, int TK>
+__global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) {
+  constexpr int RM = 64 * TM, RK = 64 * TK, LDW = 40;   // bf16 elements per LDS row
+  __shared__ __attribute__((aligned(16))) unsigned short gs_hi[RM * LDW], gs_lo[RM * LDW];
+  __shared__ __attribute__((aligned(16))) unsigned short xs_hi[RK * LDW], xs_lo[RK * LDW];
+  __shared__ rfx_ktab_entry kts[RK];
+  const rfx_gemm_desc& d = w.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wk = wave & 1;
+  const int m0 = blockIdx.y * RM;
+  const int k0 = blockIdx.x * RK;
+  const int P = d.OA * d.OB;
+  for (int i = tid; i < RK; i += 256) {
+    rfx_ktab_entry e;
+    if (k0 + i < d.Kpad) e = w.ktab[k0 + i];
+    else { e.off = 0; e.da = -(1 << 30); e.db = 0; e.flags = 0; }
+    kts[i] = e;
+  }
+  __syncthreads();
+  f32x16 acc[TM][TK];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int t_begin = blockIdx.z * w.tiles_per_block;
+  const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
+  const int prow = tid >> 5, pl = tid & 31;
+  float gv[RM / 8], xv[RK / 8];
+  auto load_tile = [&](int t) {
+    const int n = t / w.tiles_per_sample;
+    const int j = (t - n * w.tiles_per_sample) * 32 + pl;
+    const bool jvalid = j < P;
+    const int jj = jvalid ? j : 0;
+    const int a = jj / d.OB, b = jj - a * d.OB;
+    const int ia0 = a * d.SA, ib0 = b * d.SB;
+    const float* inb = w.in + (int64_t)n * d.in_ns + (int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs;
+    const float* gb = w.g + (int64_t)n * d.out_ns + (int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
+                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
+#pragma unroll
+    for (int i = 0; i < RM / 8; ++i) {
+      const int m = m0 + prow + 8 * i;
+      const bool ok = jvalid & (m < d.M);
+      const float* p = ok ? gb + (int64_t)m * d.out_cs : rfx_zero_f32;
+      gv[i] = *p;
+    }
+#pragma unroll
+    for (int i = 0; i < RK / 8; ++i) {
+      const rfx_ktab_entry e = kts[prow + 8 * i];
+      const bool ones = e.flags & 1;
+      const bool ok = jvalid & !ones & ((unsigned)(ia0 + e.da) < (unsigned)d.IA) &
+                      ((unsigned)(ib0 + e.db) < (unsigned)d.IB);
+      const float* p = ok ? inb + e.off : ((ones & jvalid) ? rfx_one_f32 : rfx_zero_f32);
+      xv[i] = *p;
+    }
+  };
+  auto put = [&](unsigned short* hi, unsigned short* lo, int row, float v) {
+    const uint32_t u = __float_as_uint(v);
+    const float r = v - __uint_as_float(u & 0xffff0000u);
+    hi[row * LDW + pl] = (unsigned short)(u >> 16);
+    lo[row * LDW + pl] = (unsigned short)((__float_as_uint(r) + 0x8000u) >> 16);
+  };
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RM / 8; ++i) put(gs_hi, gs_lo, prow + 8 * i, gv[i]);
+#pragma unroll
+    for (int i = 0; i < RK / 8; ++i) put(xs_hi, xs_lo, prow + 8 * i, xv[i]);
+    __syncthreads();
+    load_tile(t + 1 < t_end ? t + 1 : t);
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      bf16x8 ah[TM], al[TM], bh[TK], bl[TK];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int off = (wm * 32 * TM + tm * 32 + l31) * LDW + 16 * ks2 + 8 * h;
+        ah[tm] = *reinterpret_cast<const bf16x8*>(gs_hi + off);
+        al[tm] = *reinterpret_cast<const bf16x8*>(gs_lo + off);
+      }
+#pragma unroll
+      for (int tk = 0; tk < TK; ++tk) {
+        const int off = (wk * 32 * TK + tk * 32 + l31) * LDW + 16 * ks2 + 8 * h;
+        bh[tk] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
+        bl[tk] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk) {
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tk], acc[tm][tk], 0, 0, 0);
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tk], acc[tm][tk], 0, 0, 0);
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tk], acc[tm][tk], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = k0 + wk * 32 * TK + tk * 32 + l31;
+        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
+      }
+}
+
 // Thin weight gradient (M <= 8): one wave per k row, lanes along positions.
 template <int MM>
 __global__ __launch_bounds__(256) void gemm_thin_wgrad_kernel(const WgradArgs w) {
@@ -786,7 +899,7 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
 }
 
 extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const float* in,
-                              const float* gout, float* dapack, void* stream) {
+                              const float* gout, float* dapack, int32_t prec, void* stream) {
   if (!desc_ok(d) || !ktab || !in || !gout || !dapack) return -1;
   if (d->K == 0) return 0;
   WgradArgs w;
@@ -816,6 +929,14 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   w.tiles_per_block = (w.total_tiles + splits - 1) / splits;
   splits = (w.total_tiles + w.tiles_per_block - 1) / w.tiles_per_block;
   dim3 grid(kt, mt, splits);
+  if (prec == 1) {
+    if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 2>), grid, dim3(256), 0, s, w);
+    else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 1>), grid, dim3(256), 0, s, w);
+    else if (tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2>), grid, dim3(256), 0, s, w);
+    else hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 1>), grid, dim3(256), 0, s, w);
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, w);
   else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, w);
   else if (tk == 2) hipLaunchKernelGGL((gemm_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, w);

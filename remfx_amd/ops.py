@@ -104,7 +104,7 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
 
 def gemm_wgrad(dp, x, g, dapack):
     check(_lib.lib().rfx_gemm_wgrad(C.byref(dp.desc), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(dapack),
-                                    _stream()), "rfx_gemm_wgrad")
+                                    GEMM_PREC, _stream()), "rfx_gemm_wgrad")
 
 
 def unpack_add(dp, dapack, dw):
