@@ -85,3 +85,25 @@ def test_hdemucs_full_forward_bf16x3():
     err = _rms(yd, y)
     print("hdemucs bf16x3 rms err", err, "output rms", float(y.pow(2).mean().sqrt()))
     assert err < 1e-4 * max(1.0, float(y.abs().max())), err
+
+
+def test_hdemucs_small_grads_bf16x3():
+    """whole-network gradients in bf16x3 mode vs autograd over the fp32 CPU oracle."""
+    from tests.test_gpu_hdemucs import _pair
+    ref, net = _pair(8)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 1, 20000, generator=g) * 0.5
+    y = ref(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    yd = net(x.to(DEV))
+    assert _rms(yd.detach().cpu(), y.detach()) < 1e-4 * max(1.0, float(y.detach().abs().max()))
+    yd.backward(gy.to(DEV))
+    refg = dict(ref.named_parameters())
+    num = den = 0.0
+    for n, p in net.named_parameters():
+        r = refg[n].grad
+        if r is None:
+            continue
+        num += float(((p.grad.cpu() - r) ** 2).sum()); den += float((r ** 2).sum())
+    assert (num / den) ** 0.5 < 3e-3, (num / den) ** 0.5
