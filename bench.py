@@ -64,7 +64,7 @@ class KernelTimer:
     they are launched on; also accumulates their algorithmic FLOPs (2*M*K*positions*N)."""
 
     def __init__(self):
-        self.events, self.flops, self.enabled = [], 0.0, False
+        self.events, self.flops, self.bytes, self.enabled = [], 0.0, 0.0, False
 
     def install(self):
         from remfx_amd import ops
@@ -81,6 +81,8 @@ class KernelTimer:
             p = dp.p
             k = p.extra["n_weight_rows"] + (kw["dp2"].p.extra["n_weight_rows"] if kw.get("dp2") is not None else 0)
             timer.flops += 2.0 * p.M * k * p.OA * p.OB * p.N
+            # algorithmic bytes: every distinct input element / weight read once, every output written once
+            timer.bytes += 4.0 * (x.numel() + out.numel() + p.M * k)
             timer.events.append((s, e))
             return r
         ops.gemm_fwd = timed
@@ -194,6 +196,17 @@ def main():
     peak = PEAK_F32_TFLOPS if args.gemm == "f32" else PEAK_BF16_TFLOPS / 3.0
     kname = ("gemm_fwd_kernel<R,false> (gather-GEMM, v_mfma_f32_32x32x2_f32)" if args.gemm == "f32" else
              "gemm_fwd_kernel<R,true> (gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per 16-deep K step)")
+    # roofline.traffic: HBM bytes per launch of the dominant kernel family from the committed PMC passes
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command, scripts/collect_pmc.py)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_demucs_b64_pmc_traffic.json")
+    if args.workload == "demucs" and batch == 64 and os.path.exists(pmc):
+        ks = json.load(open(pmc))["kernels"]
+        fam = [v for k, v in ks.items() if k.startswith("gemm_fwd_kernel")]
+        n = sum(v["launches_per_step"] for v in fam)
+        if n:
+            traffic = round(sum(v["bytes_per_step"] for v in fam) / n)
+    alg_bytes = timer.bytes / max(klaunches, 1)
     out = {
         "metric": "audio-seconds/sec fwd+bwd (whole job)", "value": round(audio_s / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,7 +222,8 @@ def main():
                    "parallelism": f"dp{world}", "final_loss": round(float(loss.detach()), 5)},
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_TFLOPS, 4),
+                     "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
                      "launches": klaunches, "avg_launch_ms": round(kms / max(klaunches, 1), 4),
                      "share_of_step": round(kms / (dt * 1e3), 3)},
     }

@@ -347,9 +347,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int P = d.OA * d.OB;
-  const int n = blockIdx.z;
-  const int m0 = blockIdx.y * BM;
-  const int j = blockIdx.x * 128 + wave * 32 + l31;
+  // XCD-aware tile order (block b runs on XCD b % 8, each XCD has its own L2): the channel tiles of one
+  // (sample, position tile) read the same input samples, so they are made consecutive ON THE SAME XCD;
+  // neighbouring position tiles are spread over the 8 XCDs.
+  const int mtiles = d.Mpad / BM, ptiles = (P + 127) / 128;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int ym = q % mtiles, pw = (q / mtiles) * 8 + xcd;      // pw: (n, position tile) work item
+  if (pw >= ptiles * d.N) return;
+  const int n = pw / ptiles;
+  const int m0 = ym * BM;
+  const int j = (pw - n * ptiles) * 128 + wave * 32 + l31;
   LaneCtx c;
   c.jvalid = j < P;
   const int jj = c.jvalid ? j : 0;
@@ -536,6 +543,7 @@ struct WgradArgs {
   int tiles_per_sample;  // ceil(P / 32)
   int total_tiles;       // N * tiles_per_sample
   int tiles_per_block;
+  int kt, mt, splits;
 };
 
 template <int TM, int TK>
@@ -548,6 +556,9 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wk = wave & 1;
+  // plain order (k tile fastest).  An XCD-grouped order (all tiles of one position split on one XCD) was
+  // measured SLOWER (132 -> 116 TF/s-eq at the TCN shape): the splits are too few / too coarse to balance.
+  const int zsplit = blockIdx.z;
   const int m0 = blockIdx.y * RM;
   const int k0 = blockIdx.x * RK;
   const int P = d.OA * d.OB;
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int t_begin = blockIdx.z * w.tiles_per_block;
+  const int t_begin = zsplit * w.tiles_per_block;
   const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
   const int prow = tid >> 5;  // 0..7: row group for loads; lane position = tid & 31
   const int pl = tid & 31;
@@ -651,6 +662,9 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wk = wave & 1;
+  // plain order (k tile fastest).  An XCD-grouped order (all tiles of one position split on one XCD) was
+  // measured SLOWER (132 -> 116 TF/s-eq at the TCN shape): the splits are too few / too coarse to balance.
+  const int zsplit = blockIdx.z;
   const int m0 = blockIdx.y * RM;
   const int k0 = blockIdx.x * RK;
   const int P = d.OA * d.OB;
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) 
     for (int b = 0; b < TK; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  const int t_begin = blockIdx.z * w.tiles_per_block;
+  const int t_begin = zsplit * w.tiles_per_block;
   const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
   const int prow = tid >> 5, pl = tid & 31;
   float gv[RM / 8], xv[RK / 8];
@@ -878,7 +892,10 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   }
   const int bm = 32 * r;
   if (d->Mpad % bm != 0) return -1;
-  dim3 grid((P + 127) / 128, d->Mpad / bm, d->N);
+  const int64_t work = (int64_t)((P + 127) / 128) * d->N;          // (sample, position tile) items
+  const int64_t nblk = ((work + 7) / 8) * 8 * (d->Mpad / bm);
+  if (nblk > 0x7fffffff) return -1;
+  dim3 grid((unsigned)nblk);
   if (prec == 1) {
     switch (r) {
       case 1: hipLaunchKernelGGL((gemm_fwd_kernel<1, true>), grid, dim3(256), 0, s, g); break;
@@ -928,6 +945,7 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   splits = min(splits, max(1, w.total_tiles / 64));
   w.tiles_per_block = (w.total_tiles + splits - 1) / splits;
   splits = (w.total_tiles + w.tiles_per_block - 1) / w.tiles_per_block;
+  w.kt = kt; w.mt = mt; w.splits = splits;
   dim3 grid(kt, mt, splits);
   if (prec == 1) {
     if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 2>), grid, dim3(256), 0, s, w);

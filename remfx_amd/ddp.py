@@ -20,7 +20,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RFX_FORCE_DEVICE" in os.environ:          # test hook: several ranks on one GPU (gloo only)
+        local = int(os.environ["RFX_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
+        backend = backend or os.environ.get("RFX_DIST_BACKEND")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
