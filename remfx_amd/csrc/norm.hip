@@ -51,7 +51,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* _
   const float* xr = a.x + r * a.S;
   const int64_t s0 = (int64_t)sc * GN_CHUNK, s1 = min(s0 + GN_CHUNK, (int64_t)a.S);
   float p = 0.f, q = 0.f;
-  for (int64_t s = s0 + lane; s < s1; s += 64) { const float v = xr[s]; p += v; q += v * v; }
+  if ((a.S & 3) == 0) {      // rows are 16-byte aligned: one dwordx4 per lane
+    for (int64_t s = s0 + 4 * lane; s < s1; s += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xr + s);
+      p += (v[0] + v[1]) + (v[2] + v[3]);
+      q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+  } else {
+    for (int64_t s = s0 + lane; s < s1; s += 64) { const float v = xr[s]; p += v; q += v * v; }
+  }
   const double dp = rfx_wave_sum_d((double)p), dq = rfx_wave_sum_d((double)q);
   if (lane == 0) {
     const int g = gn_sidx(a, n, ch);
@@ -77,22 +85,62 @@ __device__ __forceinline__ float gn_u(const GnArgs& a, int n, int ch, int64_t s)
   return (xv - a.mean[g]) * a.rstd[g] * a.gamma[ch] + a.beta[ch];
 }
 
+// V = 4: S % 4 == 0, every thread handles 4 consecutive samples of one (n, channel[-pair]) row
+template <int V>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   const bool glu = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
   const int Co = glu ? a.C / 2 : a.C;
-  const int64_t total = (int64_t)a.N * Co * a.S;
+  const int64_t SV = a.S / V;
+  const int64_t total = (int64_t)a.N * Co * SV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t s = i % a.S;
-    const int64_t r = i / a.S;
+    const int64_t s = (i % SV) * V;
+    const int64_t r = i / SV;
     const int c = (int)(r % Co), n = (int)(r / Co);
-    float v = gn_u(a, n, c, s);
-    if (a.mode == GN_GELU) v = rfx_gelu(v);
-    else if (a.mode == GN_RELU) v = v > 0.f ? v : 0.f;
-    else if (a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES) {
-      v = v * rfx_sigmoid(gn_u(a, n, c + Co, s));
-      if (a.mode == GN_GLU_SCALE_RES) v = a.res[i] + a.scale[c] * v;
+    const int ga = gn_sidx(a, n, c);
+    const float ma = a.mean[ga], ra = a.rstd[ga] * a.gamma[c], ba = a.beta[c];
+    const float* xa = a.x + ((int64_t)n * a.C + c) * a.S + s;
+    float va[V], vb[V], rs[V];
+    if (V == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(xa); va[0] = t[0]; va[1] = t[1]; va[2] = t[2]; va[3] = t[3]; }
+    else {
+#pragma unroll
+      for (int q = 0; q < V; ++q) va[q] = xa[q];
     }
-    a.y[i] = v;
+    float mb = 0.f, rb = 0.f, bb = 0.f, sc = 0.f;
+    if (glu) {
+      const int gb = gn_sidx(a, n, c + Co);
+      mb = a.mean[gb]; rb = a.rstd[gb] * a.gamma[c + Co]; bb = a.beta[c + Co];
+      const float* xb = xa + (int64_t)Co * a.S;
+      if (V == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(xb); vb[0] = t[0]; vb[1] = t[1]; vb[2] = t[2]; vb[3] = t[3]; }
+      else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) vb[q] = xb[q];
+      }
+      if (a.mode == GN_GLU_SCALE_RES) {
+        sc = a.scale[c];
+        if (V == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.res + r * a.S + s); rs[0] = t[0]; rs[1] = t[1]; rs[2] = t[2]; rs[3] = t[3]; }
+        else {
+#pragma unroll
+          for (int q = 0; q < V; ++q) rs[q] = a.res[r * a.S + s + q];
+        }
+      }
+    }
+    float o[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      float v = (va[q] - ma) * ra + ba;
+      if (a.mode == GN_GELU) v = rfx_gelu(v);
+      else if (a.mode == GN_RELU) v = v > 0.f ? v : 0.f;
+      else if (glu) {
+        v = v * rfx_sigmoid((vb[q] - mb) * rb + bb);
+        if (a.mode == GN_GLU_SCALE_RES) v = rs[q] + sc * v;
+      }
+      o[q] = v;
+    }
+    if (V == 4) { f32x4 t; t[0] = o[0]; t[1] = o[1]; t[2] = o[2]; t[3] = o[3]; *reinterpret_cast<f32x4*>(a.y + r * a.S + s) = t; }
+    else {
+#pragma unroll
+      for (int q = 0; q < V; ++q) a.y[r * a.S + s + q] = o[q];
+    }
   }
 }
 
@@ -216,27 +264,38 @@ __global__ __launch_bounds__(256) void gn_bwd_chansum_kernel(const GnArgs a, con
   }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
   const bool pair = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
   const int Cw = pair ? a.C / 2 : a.C, Cg = a.C / a.G;
-  const int64_t total = (int64_t)a.N * Cw * a.S;
+  const int64_t SV = a.S / V;
+  const int64_t total = (int64_t)a.N * Cw * SV;
   const float inv = a.bn ? 1.f / ((float)a.N * (float)a.S) : 1.f / ((float)Cg * (float)a.S);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t s = i % a.S;
-    const int64_t r = i / a.S;
+    const int64_t s = (i % SV) * V;
+    const int64_t r = i / SV;
     const int cw = (int)(r % Cw), n = (int)(r / Cw);
     if (pair) {
-      const GnDu d = gn_du_pair(a, n, cw, s);
       const int ga = gn_sidx(a, n, cw), gb = gn_sidx(a, n, cw + Cw);
-      a.y[((int64_t)n * a.C + cw) * a.S + s] =
-          a.rstd[ga] * (d.du_a * a.gamma[cw] - a.gsum[2 * ga] * inv - d.xh_a * a.gsum[2 * ga + 1] * inv);
-      a.y[((int64_t)n * a.C + cw + Cw) * a.S + s] =
-          a.rstd[gb] * (d.du_b * a.gamma[cw + Cw] - a.gsum[2 * gb] * inv - d.xh_b * a.gsum[2 * gb + 1] * inv);
+      const float ra = a.rstd[ga], rb = a.rstd[gb];
+      const float m1a = a.gsum[2 * ga] * inv, m2a = a.gsum[2 * ga + 1] * inv;
+      const float m1b = a.gsum[2 * gb] * inv, m2b = a.gsum[2 * gb + 1] * inv;
+      const float gma = a.gamma[cw], gmb = a.gamma[cw + Cw];
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const GnDu d = gn_du_pair(a, n, cw, s + q);
+        a.y[((int64_t)n * a.C + cw) * a.S + s + q] = ra * (d.du_a * gma - m1a - d.xh_a * m2a);
+        a.y[((int64_t)n * a.C + cw + Cw) * a.S + s + q] = rb * (d.du_b * gmb - m1b - d.xh_b * m2b);
+      }
     } else {
-      float xh;
-      const float du = gn_du_single(a, n, cw, s, xh);
       const int g = gn_sidx(a, n, cw);
-      a.y[i] = a.rstd[g] * (du * a.gamma[cw] - a.gsum[2 * g] * inv - xh * a.gsum[2 * g + 1] * inv);
+      const float rg = a.rstd[g], m1 = a.gsum[2 * g] * inv, m2 = a.gsum[2 * g + 1] * inv, gm = a.gamma[cw];
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        float xh;
+        const float du = gn_du_single(a, n, cw, s + q, xh);
+        a.y[r * a.S + s + q] = rg * (du * gm - m1 - xh * m2);
+      }
     }
   }
 }
@@ -271,7 +330,8 @@ static int norm_fwd(int bn, int use_given_stats, const float* x, const float* ga
     RFX_CHECK_LAUNCH();
   }
   const int64_t total = (int64_t)N * (glu ? C / 2 : C) * S;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_grid(total)), dim3(256), 0, s, a);
+  if ((S & 3) == 0) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(gn_grid(total / 4)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(gn_grid(total)), dim3(256), 0, s, a);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -323,7 +383,8 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
   }
   hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gn_grid((int64_t)N * Cw * S)), dim3(256), 0, s, a);
+  if ((S & 3) == 0) hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3(gn_grid((int64_t)N * Cw * S / 4)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(gn_grid((int64_t)N * Cw * S)), dim3(256), 0, s, a);
   RFX_CHECK_LAUNCH();
   return 0;
 }
