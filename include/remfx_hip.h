@@ -64,6 +64,7 @@ typedef struct rfx_gemm_desc {
   int32_t SA, SB;        /* input position stride */
   int32_t Mpad, Kpad;    /* packed-A geometry: A is [Kpad][Mpad], Mpad%4==0, Kpad%16==0 */
   int32_t out_a0, out_b0, out_sa, out_sb;
+  int32_t R;             /* channel tiles (32 rows) per wave chosen by the planner: rfx_gemm_pick_r(M, K); 0 = thin path */
   int64_t in_ns, in_as, in_bs;
   int64_t out_ns, out_cs, out_as, out_bs;
 } rfx_gemm_desc;
@@ -262,9 +263,10 @@ int rfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float eps, float wd, int32_t step, const float* gscale, void* stream);
 
 int rfx_abi_version(void);
-/* channel tiles per wave the MFMA forward kernel will use for M output rows (0 = thin path);
+/* channel tiles per wave the MFMA forward kernel should use for M output rows and reduction length K
+ * (0 = thin path; short-K, output-bound problems get R = 1 for occupancy);
  * the packed A matrix must have Mpad = ceil(M / (32*R)) * 32*R  (R=0: Mpad = 8). */
-int rfx_gemm_pick_r(int32_t M);
+int rfx_gemm_pick_r(int32_t M, int32_t K);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ class KtabEntry(C.Structure):
 
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "M", "K", "OA", "OB", "IA", "IB", "SA", "SB", "Mpad",
-                                         "Kpad", "out_a0", "out_b0", "out_sa", "out_sb")] + \
+                                         "Kpad", "out_a0", "out_b0", "out_sa", "out_sb", "R")] + \
                [(n, C.c_int64) for n in ("in_ns", "in_as", "in_bs", "out_ns", "out_cs", "out_as", "out_bs")]
 
 
@@ -94,7 +94,7 @@ _P, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
 # name -> argtypes; every symbol include/remfx_hip.h declares must be listed here
 SIGNATURES = {
     "rfx_abi_version": [],
-    "rfx_gemm_pick_r": [_I32],
+    "rfx_gemm_pick_r": [_I32, _I32],
     "rfx_pack_a": [_P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "rfx_unpack_add": [_P, _P, _I64, _I32, _I32, _I32, _P, _P],
     "rfx_gemm_fwd": [C.POINTER(GemmDesc), _P, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _I32, _I32, _P, _I32, _P],

@@ -19,11 +19,13 @@ import numpy as np
 INVALID_DA = -(1 << 30)
 
 
-def pick_r(M):
+def pick_r(M, K=1 << 30):
     """Mirror of rfx_gemm_pick_r (csrc/gemm.hip): channel tiles per wave."""
     if M <= 8:
         return 0
     if M <= 32:
+        return 1
+    if K <= 64:
         return 1
     best, best_pad = 4, -(-M // 128) * 128
     for r in (3, 2):
@@ -33,8 +35,8 @@ def pick_r(M):
     return best
 
 
-def mpad_for(M):
-    r = pick_r(M)
+def mpad_for(M, K=1 << 30):
+    r = pick_r(M, K)
     return 8 if r == 0 else -(-M // (32 * r)) * 32 * r
 
 
@@ -65,6 +67,7 @@ class GemmPlan:
     w_ms: int = 0                # weight stride per output row m
     Mpad: int = 0
     Kpad: int = 0
+    R: int = 0
     extra: dict = field(default_factory=dict)
 
     def finalize(self, bias_row=False):
@@ -84,7 +87,8 @@ class GemmPlan:
         kt = np.concatenate([kt, pad], 0)
         assert np.abs(kt[:, 0]).max(initial=0) < 2 ** 31
         self.ktab = kt.astype(np.int32)
-        self.Mpad = mpad_for(self.M)
+        self.R = pick_r(self.M, K)
+        self.Mpad = mpad_for(self.M, K)
         self.woff = np.asarray(self.woff, dtype=np.int32).reshape(-1)
         assert self.woff.shape[0] == K
         self.extra["n_weight_rows"] = K

@@ -851,18 +851,21 @@ extern "C" int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t 
 
 // R (channel tiles per wave) is a pure function of M so that host-side packing
 // and the kernel agree on Mpad = ceil(M / 32R) * 32R.
-static int pick_r(int M) {
+static int pick_r(int M, int K) {
   if (M <= 8) return 0;  // thin path
+  if (M <= 32) return 1;
+  // short reductions are output-write bound: one 32-row tile per wave keeps the kernel at ~100 VGPRs
+  // (4 waves per SIMD instead of 2) so more stores / gathers are in flight per CU
+  if (K <= 64) return 1;
   int best = 4, best_pad = ((M + 127) / 128) * 128;
   for (int r = 3; r >= 2; --r) {
     const int bm = 32 * r, pad = ((M + bm - 1) / bm) * bm;
     if (pad < best_pad) { best = r; best_pad = pad; }
   }
-  if (M <= 32) best = 1;
   return best;
 }
 
-extern "C" int rfx_gemm_pick_r(int32_t M) { return pick_r(M); }
+extern "C" int rfx_gemm_pick_r(int32_t M, int32_t K) { return pick_r(M, K); }
 
 extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rfx_ktab_entry* ktab,
                             const float* in, float* out, const rfx_epilogue* epi, const float* apack2,
@@ -879,7 +882,8 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   if (g.e.bwd && !g.e.res) return -1;
   g.apack2 = apack2; g.ktab2 = ktab2; g.Kpad2 = apack2 ? Kpad2 : 0; g.in2 = in2;
   const int P = d->OA * d->OB;
-  const int r = pick_r(d->M);
+  const int r = d->R;
+  if (r < 0 || r > 4 || (r == 0) != (d->M <= 8)) return -1;
   hipStream_t s = (hipStream_t)stream;
   if (r == 0) {
     dim3 grid((P + 255) / 256, d->N);

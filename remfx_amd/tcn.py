@@ -51,6 +51,7 @@ def _block_plans(x4, Cout, ksize, dilation, causal):
                                     (1, dilation), out_strides)
         p2 = _shift_plan(tuple(x4.shape), x4.stride(), Cout, start, oshape=(N, Cout, 1, Lout),
                          ostrides=out_strides)
+        p2.R, p2.Mpad = p1.R, p1.Mpad          # both phases share one launch geometry
         return [p1, p2]
     return ops._plans(key, x4.device, build), Lout, start
 
@@ -116,6 +117,7 @@ class TCNBlockFn(torch.autograd.Function):
                                        in_ns=g4.stride(0), in_as=g4.stride(2), in_bs=g4.stride(3),
                                        out_ns=x4.stride(0), out_cs=x4.stride(1), out_as=x4.stride(2),
                                        out_bs=x4.stride(3), ktab=kt, woff=co * Cin, w_ms=1).finalize()
+                pr.R, pr.Mpad = pd[0].R, pd[0].Mpad
                 return [pd[0], pr]
             dpd, dpr = ops._plans(key, x.device, build)
             ops.gemm_fwd(dpd, ops.pack_a(dpd, w1.contiguous()), g14, dx4, dp2=dpr,

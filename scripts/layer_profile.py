@@ -27,7 +27,8 @@ def wrap(name):
             d = args[0]._obj
             info = f"N={d.N} M={d.M} K={d.K} P={d.OA}x{d.OB} S=({d.SA},{d.SB})"
             fl = 2.0 * d.N * d.M * d.K * d.OA * d.OB
-            info += f" {fl / dt / 1e9:6.1f} TF/s"
+            by = 4.0 * d.N * d.OA * d.OB * (d.M + d.K / max(1, (d.K // max(d.M, 1)) if False else 1))
+            info += f" {fl / dt / 1e9:6.1f} TF/s  out {4.0 * d.N * d.M * d.OA * d.OB / 1e6:7.1f} MB"
         elif name.startswith("rfx_groupnorm"):
             if name.endswith("fwd"):
                 info = f"N={args[3]} C={args[4]} S={args[5]} G={args[6]} mode={args[8]}"
@@ -41,6 +42,8 @@ def wrap(name):
     return timed
 
 
+from remfx_amd import ops
+ops.set_gemm_precision(os.environ.get("RFX_GEMM_PREC", "bf16x3"))
 model = bench.build_model(workload, dev)
 cfg = model.configure_optimizers()
 opt = cfg["optimizer"]
@@ -62,6 +65,6 @@ for n, i, t in records:
     agg[n][0] += 1; agg[n][1] += t
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"  {n:24s} {c:5d} calls {t:9.2f} ms {100 * t / tot:5.1f}%")
-print("--- top 60 launches")
-for n, i, t in sorted(records, key=lambda r: -r[2])[:60]:
+print("--- top 70 launches")
+for n, i, t in sorted(records, key=lambda r: -r[2])[:70]:
     print(f"{t:8.3f} ms  {n:20s} {i}")

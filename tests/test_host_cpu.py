@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     assert L.rfx_abi_version() == 1
     from remfx_amd import convplan
     for M in (1, 8, 9, 32, 45, 48, 90, 96, 128, 135, 192, 256, 384, 1536, 3072):
-        assert L.rfx_gemm_pick_r(M) == convplan.pick_r(M), M
+        for K in (12, 64, 65, 1792):
+            assert L.rfx_gemm_pick_r(M, K) == convplan.pick_r(M, K), (M, K)
 
 
 def test_ops_refuse_cpu_tensors():
