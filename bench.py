@@ -127,13 +127,64 @@ def cpu_baseline(workload):
             "sample": f"oracle {workload} forward + MRSTFT/L1 loss + backward, 1 clip x {T} samples, {dt:.1f} s"}
 
 
+def bench_chain(args, rank, world, device):
+    """BASELINE config 5: RemFX-detect chain inference (Cnn14 detector + Demucs x2 + DCUNet x3 removal
+    networks, cfg/exp/remfx_detect.yaml), inference only, 16 clips per GPU; random-init weights under the
+    fixed seed (no checkpoints offline), every clip takes the chain its detected labels select."""
+    from remfx_amd import models
+    from remfx_amd.classifier import Cnn14
+    torch.manual_seed(12345)
+    batch = args.batch or 16
+    mk_d = lambda: models.RemFX(1e-4, 0.95, 0.999, 1e-6, 1e-3, SR, models.DemucsModel(
+        sample_rate=SR, sources=["mixture"], audio_channels=1, nfft=4096, channels=48)).to(device)
+    mk_u = lambda: models.RemFX(1e-4, 0.95, 0.999, 1e-6, 1e-3, SR, models.DCUNetModel(
+        sample_rate=SR, num_bins=1025, architecture="Large-DCUNet-20", stft_kernel_size=512,
+        fix_length_mode="pad")).to(device).eval()
+    nets = {"RandomPedalboardDistortion": mk_d(), "RandomPedalboardCompressor": mk_d(),
+            "RandomPedalboardReverb": mk_u(), "RandomPedalboardChorus": mk_u(), "RandomPedalboardDelay": mk_u()}
+    cls = models.FXClassifier(3e-4, 1e-3, SR, Cnn14(5, SR, SR, 2048, 512, 128)).to(device).eval()
+    order = ["RandomPedalboardDistortion", "RandomPedalboardCompressor", "RandomPedalboardReverb",
+             "RandomPedalboardChorus", "RandomPedalboardDelay"]
+    chain = models.RemFXChainInference(nets, SR, 1025, order, classifier=cls).to(device).eval()
+    data = synthetic_batch(batch, rank, device)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        for i in range(args.warmup):
+            chain.test_step(data, i)
+        fence()
+        t0 = time.time()
+        for i in range(args.steps):
+            chain.test_step(data, i)
+        fence()
+    dt = time.time() - t0
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    if rank != 0:
+        return
+    dt = float(t)
+    napplied = float(chain.last_labels.sum())
+    print(json.dumps({
+        "metric": "audio-seconds/sec chain inference (whole job)", "value": round(world * batch * CLIP / SR * args.steps / dt, 3),
+        "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "f32 via bf16x3 split MFMA (fp32 accumulate)",
+        "data": "synthetic", "config": {"workload": "RemFX-detect chain inference (+exp=remfx_detect), inference only",
+                                        "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
+                                        "removal_model_applications_per_step": napplied, "parallelism": f"dp{world}"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("RFX_WORKLOAD", "demucs"),
-                    choices=["demucs", "tcn", "dcunet", "umx"])
+                    choices=["demucs", "tcn", "dcunet", "umx", "chain"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm", default=os.environ.get("RFX_GEMM_PREC", "bf16x3"), choices=["bf16x3", "f32"],
@@ -148,8 +199,10 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # BASELINE.json configs: Demucs 64 clips/GPU (headline), TCN 32, DCUNet 32 over 8 GPUs = 4/GPU, UMX 4
-    batch = args.batch or {"tcn": 32, "demucs": 64, "dcunet": 4, "umx": 4}[args.workload]
+    batch = args.batch or {"tcn": 32, "demucs": 64, "dcunet": 4, "umx": 4, "chain": 16}[args.workload]
 
+    if args.workload == "chain":
+        return bench_chain(args, rank, world, device)
     model = build_model(args.workload, device)
     cfg = model.configure_optimizers()
     opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
