@@ -174,6 +174,15 @@ int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx
 int rfx_channel_sum(const float* x, int32_t N, int32_t C, int32_t A, int32_t B, int64_t ns, int64_t cs,
                     int64_t as, int64_t bs, float* out, void* stream);
 
+/* out = x + alpha * y, x / out contiguous (N, C, A, B), y read through element strides (0 = broadcast):
+ * skip / inject / frequency-embedding adds inside HDemucs (models.py:319). */
+int rfx_add_bcast(const float* x, const float* y, float* out, int64_t N, int32_t C, int32_t A, int32_t B,
+                  int64_t yn, int64_t yc, int64_t ya, int64_t yb, float alpha, void* stream);
+/* per-row mean / unbiased std of x[R][L] (sums: R*2 fp64 workspace) and out = x*a[r] + b[r] (b may be NULL):
+ * HDemucs input and spectrogram standardisation / de-standardisation (x.mean/std over dims 1..). */
+int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv, void* stream);
+int rfx_row_affine(const float* x, const float* a, const float* b, float* out, int32_t R, int64_t L, void* stream);
+
 /* sum |a-b| over n elements -> *out (+=, caller zeroes).  nn.L1Loss numerator, models.py:320 */
 int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream);
 

@@ -91,6 +91,59 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int Cn, i
   if (threadIdx.x == 0) atomicAdd(out + c, (float)(part[0] + part[1] + part[2] + part[3]));
 }
 
+// out[n,c,a,b] = x[n,c,a,b] + alpha * y[n*yn + c*yc + a*ya + b*yb]   (x, out contiguous; y strided, stride 0 =
+// broadcast): skip / inject / frequency-embedding adds of HDemucs (torchaudio HDemucs via models.py:319).
+__global__ void add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                                 int64_t total, int C, int A, int B, int64_t yn, int64_t yc, int64_t ya, int64_t yb,
+                                 float alpha) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % B);
+    int64_t r = i / B;
+    const int a = (int)(r % A); r /= A;
+    const int c = (int)(r % C);
+    const int64_t n = r / C;
+    out[i] = x[i] + alpha * y[n * yn + c * yc + a * ya + b * yb];
+  }
+}
+
+// per-row mean and UNBIASED std of x[R][L] (fp64 accumulation): HDemucs input / spectrogram standardisation
+__global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ x, int64_t L, double* __restrict__ sums) {
+  const int r = blockIdx.y;
+  const float* xr = x + (int64_t)r * L;
+  double p = 0.0, q = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L; i += (int64_t)gridDim.x * 256) {
+    const double v = xr[i];
+    p += v; q += v * v;
+  }
+  p = rfx_wave_sum_d(p); q = rfx_wave_sum_d(q);
+  __shared__ double part[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { part[0][wave] = p; part[1][wave] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + 2 * r, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+    atomicAdd(sums + 2 * r + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+  }
+}
+__global__ void row_moments_finalize_kernel(const double* __restrict__ sums, int R, double L, float* __restrict__ mean,
+                                            float* __restrict__ stdv) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const double m = sums[2 * r] / L;
+  double var = (sums[2 * r + 1] - L * m * m) / (L - 1.0);
+  var = var > 0.0 ? var : 0.0;
+  mean[r] = (float)m;
+  stdv[r] = (float)sqrt(var);
+}
+// out[r][i] = x[r][i] * a[r] + b[r]
+__global__ void row_affine_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
+                                  float* __restrict__ out, int64_t L, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / L;
+    out[i] = x[i] * a[r] + (b ? b[r] : 0.f);
+  }
+}
+
 static int grid_for(int64_t n) {
   const int64_t b = (n + 1023) / 1024;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -134,6 +187,37 @@ extern "C" int rfx_channel_sum(const float* x, int32_t N, int32_t Cn, int32_t A,
   chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
   hipLaunchKernelGGL(channel_sum_kernel, dim3(Cn, chunks), dim3(256), 0, (hipStream_t)stream, x, N, Cn, A, B,
                      ns, cs, as, bs, out);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rfx_add_bcast(const float* x, const float* y, float* out, int64_t N, int32_t Cn, int32_t A, int32_t B,
+                             int64_t yn, int64_t yc, int64_t ya, int64_t yb, float alpha, void* stream) {
+  if (!x || !y || !out || N <= 0 || Cn <= 0 || A <= 0 || B <= 0) return -1;
+  const int64_t total = N * Cn * A * B;
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, out, total, Cn, A,
+                     B, yn, yc, ya, yb, alpha);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv,
+                               void* stream) {
+  if (!x || !sums || !mean || !stdv || R <= 0 || L <= 1) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * R, s) != hipSuccess) return -3;
+  int gx = (int)((L + 16383) / 16384);
+  gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  hipLaunchKernelGGL(row_moments_kernel, dim3(gx, R), dim3(256), 0, s, x, L, sums);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(row_moments_finalize_kernel, dim3((R + 63) / 64), dim3(64), 0, s, sums, R, (double)L, mean, stdv);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_row_affine(const float* x, const float* a, const float* b, float* out, int32_t R, int64_t L,
+                              void* stream) {
+  if (!x || !a || !out || R <= 0 || L <= 0) return -1;
+  hipLaunchKernelGGL(row_affine_kernel, dim3(grid_for((int64_t)R * L)), dim3(256), 0, (hipStream_t)stream, x, a, b, out,
+                     L, (int64_t)R * L);
   RFX_CHECK_LAUNCH();
   return 0;
 }

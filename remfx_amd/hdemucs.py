@@ -187,7 +187,7 @@ class _HEncLayer(nn.Module):
         if inject is not None:
             if inject.dim() == 3 and y.dim() == 4:
                 inject = inject[:, :, None]
-            y = y + inject
+            y = nnops.add(y, inject)
         y = _norm_act(self.norm1, y, "gelu")
         if self.freq:
             B, C, Fr, T = y.shape
@@ -225,7 +225,7 @@ class _HDecLayer(nn.Module):
         if self.freq and x.dim() == 3:
             x = x.view(x.shape[0], self.chin, -1, x.shape[-1])
         if not self.empty:
-            x = x + skip
+            x = nnops.add(x, skip)
             c = self.context
             if self.freq:
                 r = ops.conv2d(x, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c))
@@ -319,13 +319,10 @@ class HDemucs(nn.Module):
                         bins=self.nfft // 2, frame0=2, frames_out=le, extra_pad=(pad, pad + le * hl - length))
         Fq = self.nfft // 2
         x = cac.view(B, Cin, 2, Fq, le).reshape(B, Cin * 2, Fq, le)
-        mean = x.mean(dim=(1, 2, 3), keepdim=True)
-        std = x.std(dim=(1, 2, 3), keepdim=True)
-        x = (x - mean) / (1e-5 + std)
-        xt = input
-        meant = xt.mean(dim=(1, 2), keepdim=True)
-        stdt = xt.std(dim=(1, 2), keepdim=True)
-        xt = (xt - meant) / (1e-5 + stdt)
+        if input.requires_grad:
+            raise NotImplementedError("HDemucs: gradient w.r.t. the input waveform is not on the reference's path")
+        x, mean, std = nnops.row_standardize(x.detach(), 1e-5)      # over (C, Fr, T) per clip, unbiased std
+        xt, meant, stdt = nnops.row_standardize(input, 1e-5)        # over (C, T) per clip
         saved, saved_t, lengths, lengths_t = [], [], [], []
         for idx, encode in enumerate(self.freq_encoder):
             lengths.append(x.shape[-1])
@@ -341,7 +338,7 @@ class HDemucs(nn.Module):
             x = encode(x, inject)
             if idx == 0 and self.freq_emb is not None:
                 emb = self.freq_emb.table().t()[None, :, :, None]
-                x = x + self.freq_emb_scale * emb
+                x = nnops.add(x, emb, self.freq_emb_scale)
             saved.append(x)
         x = torch.zeros_like(x)
         xt = torch.zeros_like(x)
@@ -356,10 +353,12 @@ class HDemucs(nn.Module):
                 else:
                     xt, _ = tdec(xt, saved_t.pop(-1), length_t)
         S = len(self.sources)
-        x = x.view(B, S, -1, Fq, le) * std[:, None] + mean[:, None]
+        x = nnops.row_affine(x.reshape(B, -1), std, mean)          # S == 1 for RemFX: one (std, mean) per clip
+        if S != 1:
+            raise NotImplementedError("multi-source de-standardisation")
         # _mask + _ispec: (B, S, Cin*2, Fq, le) complex-as-channels -> time, one row per (b, s, c)
         spec = x.view(B * S * Cin, 2, Fq, le)
         xo = stft.istft(spec, self.nfft, hl, mode="cac", normalized=True, frames=le + 4, frame0=2, crop=pad,
                         length=length).view(B, S, Cin, length)
-        xt = xt.view(B, S, -1, length) * stdt[:, None] + meant[:, None]
-        return xt + xo
+        xt = nnops.row_affine(xt.reshape(B, -1), stdt, meant).view(B, S, -1, length)
+        return nnops.add(xt.reshape(B, S * Cin, 1, length), xo.reshape(B, S * Cin, 1, length)).view(B, S, Cin, length)

@@ -194,6 +194,90 @@ def glu(x, dim=1):
     return _GluFn.apply(x)
 
 
+class _AddFn(torch.autograd.Function):
+    """x + alpha * y with y broadcast over any of the 4 dims (N, C, A, B); x contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, y, alpha):
+        ops._req(x, "x")
+        x = x.contiguous()
+        x4 = x if x.dim() == 4 else x.unsqueeze(2)
+        y4 = y if y.dim() == 4 else y.unsqueeze(2)
+        ye = y4.expand_as(x4)
+        out = torch.empty_like(x4)
+        N, Cc, A, B = x4.shape
+        ys = ye.stride()
+        check(_lib.lib().rfx_add_bcast(_ptr(x4), _ptr(ye), _ptr(out), N, Cc, A, B, ys[0], ys[1], ys[2], ys[3],
+                                       float(alpha), _stream()), "rfx_add_bcast")
+        ctx.cfg = (tuple(y4.shape), tuple(x4.shape), alpha, y.dim())
+        return out if x.dim() == 4 else out.squeeze(2)
+
+    @staticmethod
+    def backward(ctx, g):
+        yshape, xshape, alpha, ydim = ctx.cfg
+        gy = None
+        if ctx.needs_input_grad[1]:
+            g4 = g if g.dim() == 4 else g.unsqueeze(2)
+            if yshape == xshape:
+                gy = g4 * alpha if alpha != 1.0 else g4
+            elif yshape[0] == 1 and yshape[3] == 1 and yshape[1:3] == xshape[1:3]:
+                # reduce over (N, B): (c, a) plays the channel role of rfx_channel_sum
+                N, Cc, A, B = xshape
+                gy = ops.channel_sum(g4.contiguous().view(N, Cc * A, 1, B)).view(1, Cc, A, 1) * alpha
+            else:
+                gy = g4.sum_to_size(yshape) * alpha
+            if ydim == 3:
+                gy = gy.squeeze(2)
+        return g, gy, None
+
+
+def add(x, y, alpha=1.0):
+    return _AddFn.apply(x, y, alpha)
+
+
+def row_standardize(x, eps):
+    """(x - mean) / (eps + std) over all dims but the first, unbiased std (HDemucs forward); x carries no
+    gradient (it is the input waveform / its STFT).  Returns y, mean (R,), std (R,)."""
+    ops._req(x, "x")
+    x = x.contiguous()
+    R = x.shape[0]
+    L = x.numel() // R
+    sums = torch.empty(2 * R, device=x.device, dtype=torch.float64)
+    mean = torch.empty(R, device=x.device, dtype=torch.float32)
+    std = torch.empty_like(mean)
+    check(_lib.lib().rfx_row_moments(_ptr(x), R, L, _ptr(sums), _ptr(mean), _ptr(std), _stream()), "rfx_row_moments")
+    a = 1.0 / (eps + std)
+    b = -mean * a
+    y = torch.empty_like(x)
+    check(_lib.lib().rfx_row_affine(_ptr(x), _ptr(a), _ptr(b), _ptr(y), R, L, _stream()), "rfx_row_affine")
+    return y, mean, std
+
+
+class _RowAffineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, b):
+        x = x.contiguous()
+        R = x.shape[0]
+        y = torch.empty_like(x)
+        check(_lib.lib().rfx_row_affine(_ptr(x), _ptr(a), _ptr(b), _ptr(y), R, x.numel() // R, _stream()), "rfx_row_affine")
+        ctx.save_for_backward(a)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        g = g.contiguous()
+        R = g.shape[0]
+        gx = torch.empty_like(g)
+        check(_lib.lib().rfx_row_affine(_ptr(g), _ptr(a), None, _ptr(gx), R, g.numel() // R, _stream()), "rfx_row_affine")
+        return gx, None, None
+
+
+def row_affine(x, a, b):
+    """x * a[r] + b[r] per leading-dim row (de-standardisation); gradient flows to x only."""
+    return _RowAffineFn.apply(x, a.contiguous(), b.contiguous())
+
+
 def lstm(module, x):
     """module: nn.LSTM parameter container; x: (T, B, C)."""
     _interim("lstm")
