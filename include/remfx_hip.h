@@ -85,6 +85,9 @@ typedef struct rfx_epilogue {
    * storing a second 256 x T activation per block. */
   int32_t bwd;
   float* gparam;
+  /* optional: stat_sums[2n] += sum v, stat_sums[2n+1] += sum v^2 over the values stored for sample n (fp64;
+   * caller zeroes): GroupNorm(1, C) statistics of the NEXT layer without re-reading the tensor */
+  double* stat_sums;
 } rfx_epilogue;
 
 /* Arithmetic of the MFMA gather-GEMM.  RFX_PREC_F32: v_mfma_f32_32x32x2_f32, exact fp32 products.
@@ -193,8 +196,9 @@ int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stre
  * (models.py:319).  mean / rstd (N*G each) are written for the backward. */
 int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C, int32_t S,
                       int32_t G, float eps, int32_t mode, const float* res, const float* scale,
-                      double* sums /* N*G*2 fp64 workspace */, float* mean, float* rstd, float* y,
-                      void* stream);
+                      double* sums /* N*G*2 fp64 workspace; sums_given != 0: already holds {sum, sumsq} per
+                                      (n, g) -- e.g. from rfx_epilogue.stat_sums -- and the statistics pass is skipped */,
+                      int32_t sums_given, float* mean, float* rstd, float* y, void* stream);
 /* dx (N, C, S); dgamma / dbeta (C) and dscale (C/2, mode 3) are OVERWRITTEN; `work` is a
  * caller-owned scratch of N*C*2 + N*(C/2) + N*G*2 floats; the residual gradient of mode 3 is gy. */
 int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,

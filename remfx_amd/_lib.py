@@ -80,7 +80,7 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("act", C.c_int32), ("act_param", C.c_void_p),
                 ("res", C.c_void_p), ("res_ns", C.c_int64), ("res_cs", C.c_int64),
                 ("res_as", C.c_int64), ("res_bs", C.c_int64), ("act2", C.c_int32), ("bwd", C.c_int32),
-                ("gparam", C.c_void_p)]
+                ("gparam", C.c_void_p), ("stat_sums", C.c_void_p)]
 
 
 class StftDesc(C.Structure):
@@ -108,7 +108,7 @@ SIGNATURES = {
     "rfx_sumsq": [_P, _I64, _P, _P],
     "rfx_clip_coef": [_P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_adamw_step": [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P, _P],
-    "rfx_groupnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "rfx_groupnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
     "rfx_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rfx_batchnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, C.c_float, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_batchnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],

@@ -433,19 +433,26 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
     }
     return;
   }
-  if (!c.jvalid) return;
+  float s1 = 0.f, s2 = 0.f;      // optional per-sample moments of the stored values (GroupNorm(1, C) statistics)
+  if (c.jvalid) {
 #pragma unroll
-  for (int mt = 0; mt < R; ++mt) {
+    for (int mt = 0; mt < R; ++mt) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m < d.M) {
-        float v = acc[mt][r];
-        if (resp) v += resp[(int64_t)m * e.res_cs];
-        if (e.act2 != RFX_ACT_NONE) v = rfx_act_apply(v, e.act2, 0.f);
-        outp[(int64_t)m * d.out_cs] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < d.M) {
+          float v = acc[mt][r];
+          if (resp) v += resp[(int64_t)m * e.res_cs];
+          if (e.act2 != RFX_ACT_NONE) v = rfx_act_apply(v, e.act2, 0.f);
+          outp[(int64_t)m * d.out_cs] = v;
+          s1 += v; s2 += v * v;
+        }
       }
     }
+  }
+  if (e.stat_sums) {               // wave-uniform branch: one fp64 atomic pair per wave
+    const double d1 = rfx_wave_sum_d((double)s1), d2 = rfx_wave_sum_d((double)s2);
+    if (lane == 0) { atomicAdd(e.stat_sums + 2 * n, d1); atomicAdd(e.stat_sums + 2 * n + 1, d2); }
   }
 }
 
@@ -506,6 +513,7 @@ __global__ __launch_bounds__(256) void gemm_thin_fwd_kernel(const FwdArgs g) {
     thin_phase<MM>(d, g.ktab2, g.apack2, g.Kpad2, in2 + ioff, in2, jvalid, ia0, ib0, acc);
   }
   if (!jvalid) return;
+  float st1 = 0.f, st2 = 0.f;
   const int64_t opos = (int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
   float* outp = g.out + (int64_t)n * d.out_ns + opos;
 #pragma unroll
@@ -524,8 +532,13 @@ __global__ __launch_bounds__(256) void gemm_thin_fwd_kernel(const FwdArgs g) {
         v += r;
         if (e.act2 != RFX_ACT_NONE) v = rfx_act_apply(v, e.act2, 0.f);
         outp[(int64_t)m * d.out_cs] = v;
+        st1 += v; st2 += v * v;
       }
     }
+  }
+  if (e.stat_sums) {
+    atomicAdd(e.stat_sums + 2 * n, (double)st1);       // thin path: tiny tensors, per-thread atomics are fine
+    atomicAdd(e.stat_sums + 2 * n + 1, (double)st2);
   }
 }
 

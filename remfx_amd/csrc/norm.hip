@@ -305,7 +305,7 @@ static int gn_grid(int64_t total) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-static int norm_fwd(int bn, int use_given_stats, const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
+static int norm_fwd(int bn, int use_given_stats, int sums_given, const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
                                  int32_t S, int32_t G, float eps, int32_t mode, const float* res,
                                  const float* scale, double* sums /* N*G*2 workspace */, float* mean,
                                  float* rstd, float* y, void* stream) {
@@ -322,9 +322,11 @@ static int norm_fwd(int bn, int use_given_stats, const float* x, const float* ga
     if (!sums) return -1;
     const int nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
     const int64_t nitems = (int64_t)N * C * nchunks;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * nstat, s) != hipSuccess) return -3;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, sums, nchunks);
-    RFX_CHECK_LAUNCH();
+    if (!sums_given) {
+      if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * nstat, s) != hipSuccess) return -3;
+      hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, sums, nchunks);
+      RFX_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, sums, mean, rstd, nstat,
                        bn ? (double)N * (double)S : (double)(C / G) * (double)S, eps);
     RFX_CHECK_LAUNCH();
@@ -338,9 +340,9 @@ static int norm_fwd(int bn, int use_given_stats, const float* x, const float* ga
 
 extern "C" int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
                                  int32_t S, int32_t G, float eps, int32_t mode, const float* res,
-                                 const float* scale, double* sums, float* mean, float* rstd, float* y,
-                                 void* stream) {
-  return norm_fwd(0, 0, x, gamma, beta, N, C, S, G, eps, mode, res, scale, sums, mean, rstd, y, stream);
+                                 const float* scale, double* sums, int32_t sums_given, float* mean, float* rstd,
+                                 float* y, void* stream) {
+  return norm_fwd(0, 0, sums_given, x, gamma, beta, N, C, S, G, eps, mode, res, scale, sums, mean, rstd, y, stream);
 }
 // BatchNorm over (N, S) per channel.  use_given_stats: mean / rstd are inputs (eval mode:
 // running_mean, 1/sqrt(running_var + eps)); else batch statistics are computed and written.
@@ -348,7 +350,7 @@ extern "C" int rfx_batchnorm_fwd(const float* x, const float* gamma, const float
                                  int32_t S, float eps, int32_t mode, int32_t use_given_stats, double* sums,
                                  float* mean, float* rstd, float* y, void* stream) {
   if (mode != GN_NONE && mode != GN_RELU) return -1;
-  return norm_fwd(1, use_given_stats, x, gamma, beta, N, C, S, C, eps, mode, nullptr, nullptr, sums, mean, rstd, y,
+  return norm_fwd(1, use_given_stats, 0, x, gamma, beta, N, C, S, C, eps, mode, nullptr, nullptr, sums, mean, rstd, y,
                   stream);
 }
 

@@ -124,16 +124,18 @@ class _DConv(nn.Module):
     def forward(self, x):
         for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
             mods = list(seq)
-            y = ops.conv1d(x, mods[0].weight, mods[0].bias, 1, pad, dil)
-            y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu")
+            st = torch.zeros((x.shape[0], 2), device=x.device, dtype=torch.float64)   # GN(1, C) statistics
+            y = ops.conv1d(x, mods[0].weight, mods[0].bias, 1, pad, dil, stat_sums=st)   # come out of the GEMM epilogue
+            y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu", sums=st)
             i = 3
             if lstm:
                 y = mods[i](y); i += 1
             if attn:
                 y = mods[i](y); i += 1
-            y = ops.conv1d(y, mods[i].weight, mods[i].bias)
+            st = torch.zeros((x.shape[0], 2), device=x.device, dtype=torch.float64)
+            y = ops.conv1d(y, mods[i].weight, mods[i].bias, stat_sums=st)
             x = nnops.group_norm(y, 1, mods[i + 1].weight, mods[i + 1].bias, mods[i + 1].eps,
-                                 mode="glu_scale_res", res=x, scale=mods[i + 3].scale)
+                                 mode="glu_scale_res", res=x, scale=mods[i + 3].scale, sums=st)
         return x
 
 

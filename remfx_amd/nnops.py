@@ -36,7 +36,7 @@ class _GroupNormFn(torch.autograd.Function):
     """GroupNorm fused with GELU / GLU / (res + scale * GLU); backward re-materialises gn(x)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, mode, res, scale):
+    def forward(ctx, x, gamma, beta, groups, eps, mode, res, scale, sums=None):
         ops._req(x, "x")
         x = x.contiguous()
         N, Cc = x.shape[0], x.shape[1]
@@ -47,11 +47,13 @@ class _GroupNormFn(torch.autograd.Function):
         y = torch.empty(oshape, device=x.device, dtype=torch.float32)
         mean = torch.empty(N * groups, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        sums = torch.empty(N * groups * 2, device=x.device, dtype=torch.float64)
+        given = 1 if sums is not None else 0
+        if sums is None:
+            sums = torch.empty(N * groups * 2, device=x.device, dtype=torch.float64)
         if res is not None:
             res = res.contiguous()
         check(_lib.lib().rfx_groupnorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), N, Cc, S, groups, eps, mode,
-                                           _ptr(res), _ptr(scale), _ptr(sums), _ptr(mean), _ptr(rstd), _ptr(y),
+                                           _ptr(res), _ptr(scale), _ptr(sums), given, _ptr(mean), _ptr(rstd), _ptr(y),
                                            _stream()),
               "rfx_groupnorm_fwd")
         ctx.save_for_backward(x, gamma, beta, mean, rstd, scale)
@@ -71,12 +73,13 @@ class _GroupNormFn(torch.autograd.Function):
                                            N, Cc, S, groups, mode, _ptr(scale), _ptr(gsum), _ptr(dx),
                                            _ptr(dgamma), _ptr(dbeta), _ptr(dscale), _stream()),
               "rfx_groupnorm_bwd")
-        return dx, dgamma, dbeta, None, None, None, (gy if mode == 3 else None), dscale
+        return dx, dgamma, dbeta, None, None, None, (gy if mode == 3 else None), dscale, None
 
 
-def group_norm(x, groups, weight, bias, eps=1e-5, mode="none", res=None, scale=None):
-    """mode: none | gelu | glu | glu_scale_res (out = res + scale[c] * glu(gn(x)))."""
-    return _GroupNormFn.apply(x, weight, bias, groups, eps, GN_MODES[mode], res, scale)
+def group_norm(x, groups, weight, bias, eps=1e-5, mode="none", res=None, scale=None, sums=None):
+    """mode: none | gelu | glu | glu_scale_res (out = res + scale[c] * glu(gn(x))).
+    sums: fp64 (N*groups, 2) {sum, sum^2} already accumulated by the producing GEMM's epilogue."""
+    return _GroupNormFn.apply(x, weight, bias, groups, eps, GN_MODES[mode], res, scale, sums)
 
 
 class _BatchNormFn(torch.autograd.Function):

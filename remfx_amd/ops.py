@@ -81,7 +81,7 @@ def pack_a(dp, w):
 
 
 def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, act2=None,
-             dp2=None, apack2=None, in2=None, bwd=False, gparam=None):
+             dp2=None, apack2=None, in2=None, bwd=False, gparam=None, stat_sums=None):
     e = Epilogue()
     e.bias = bias.data_ptr() if bias is not None else None
     e.act = ACT[act]
@@ -92,6 +92,7 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
     e.act2 = ACT[act2]
     e.bwd = 1 if bwd else 0
     e.gparam = gparam.data_ptr() if gparam is not None else None
+    e.stat_sums = stat_sums.data_ptr() if stat_sums is not None else None
     if dp2 is not None:
         a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.ktab), dp2.p.K, dp2.p.Kpad
     else:
@@ -118,7 +119,7 @@ def _key(*a):
     return tuple(tuple(x) if isinstance(x, (list, tuple, torch.Size)) else x for x in a)
 
 
-def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=None, out=None):
+def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=None, out=None, stat_sums=None):
     _req(x, "x"); _req(w, "weight")
     N, Cin, IA, IB = x.shape
     Cout, _, KA, KB = w.shape
@@ -130,7 +131,7 @@ def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=No
     dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
         tuple(x.shape), x.stride(), tuple(w.shape), stride, padding, dilation, out.stride()))
     wc = w.contiguous()
-    gemm_fwd(dp, pack_a(dp, wc), x, out, bias=bias, act=act, act_param=act_param)
+    gemm_fwd(dp, pack_a(dp, wc), x, out, bias=bias, act=act, act_param=act_param, stat_sums=stat_sums)
     return out
 
 
@@ -163,10 +164,10 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d / nn.Conv1d (A == 1) forward + backward on the gather-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padding, dilation):
+    def forward(ctx, x, w, bias, stride, padding, dilation, stat_sums=None):
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, dilation, bias is not None)
-        return conv2d_forward(x, w, bias, stride, padding, dilation)
+        return conv2d_forward(x, w, bias, stride, padding, dilation, stat_sums=stat_sums)
 
     @staticmethod
     def backward(ctx, g):
@@ -178,15 +179,17 @@ class Conv2dFn(torch.autograd.Function):
             dx = conv2d_dgrad(g, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
-    return Conv2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation))
+def conv2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), stat_sums=None):
+    return Conv2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation), stat_sums)
 
 
-def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1):
-    y = Conv2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation))
+def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None):
+    """stat_sums: optional zeroed fp64 (N, 2) tensor; the GEMM epilogue adds {sum, sum^2} of every sample's
+    output into it (GroupNorm(1, C) statistics for free)."""
+    y = Conv2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation), stat_sums)
     return y.squeeze(2)
 
 
