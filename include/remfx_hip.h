@@ -164,6 +164,24 @@ int rfx_fft_analysis(const rfx_stft_desc* d, const float* x, const float* window
 int rfx_fft_synthesis(const rfx_stft_desc* d, const float* spec, const float* window, const float* mul,
                       float* out, void* stream);
 
+/* ---- LSTM recurrence ------------------------------------------------------------
+ * Bidirectional nn.LSTM layer (HDemucs DConv BLSTM through models.py:319; Open-Unmix models.py:297-298), one
+ * persistent launch per sweep.  All sequence tensors are channel-major [C][P], P = T*Bn, position p = t*Bn + b.
+ * The caller runs the dense parts as gather-GEMMs: xp = [W_ih; W_ih_reverse] x + (b_ih + b_hh) before
+ * rfx_lstm_fwd, and dX / dW_ih / dW_hh / db from dG after rfx_lstm_bwd.  Gate order i, f, g, o (PyTorch).
+ * H % 32 == 0, H <= 512.  Arithmetic: bf16x3 split products, fp32 accumulate / state. */
+/* bytes of one direction's packed W_hh (MFMA fragments for both sweeps) */
+int rfx_lstm_pack_bytes(int32_t H);
+/* whh: [4H][H] row-major -> pack (rfx_lstm_pack_bytes(H) bytes).  The two directions are packed back to back. */
+int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stream);
+/* xp [2][4H][P]; pack = both directions; out [2H][P] (forward dir rows 0..H-1, reverse H..2H-1);
+ * gates [2][4H][P] and cstate [2][H][P] are saved for the backward sweep (both NULL for inference). */
+int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_t Bn, int32_t H, float* out, float* gates,
+                 float* cstate, void* stream);
+/* gout [2H][P] -> dG [2][4H][P], the gradients of the gate pre-activations. */
+int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
+                 int32_t Bn, int32_t H, float* dG, void* stream);
+
 /* ---- elementwise / reductions ------------------------------------------------ */
 /* y = act(x) elementwise over n contiguous floats; PReLU/bias not supported here. */
 int rfx_act_fwd(const float* x, float* y, int64_t n, int32_t act, void* stream);

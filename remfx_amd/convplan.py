@@ -218,3 +218,17 @@ def convT_dgrad_plan(xshape, xstrides, wshape, stride, dilation, crop_lo, gshape
                  in_ns=gns, in_as=gas, in_bs=gbs, out_ns=xstrides[0], out_cs=xstrides[1],
                  out_as=xstrides[2], out_bs=xstrides[3], ktab=ktab, woff=woff, w_ms=Cout * KA * KB)
     return p.finalize(bias_row)
+
+
+def shift_plan(xshape, xstrides, M, shift, oshape, ostrides):
+    """1x1 conv reading x[..., b + shift] (out-of-range -> 0): ktab rows (ci*cs + shift*bs, 0, shift).
+    Used for the TCN residual crop (tcn.py:54-58) and the LSTM dW_hh product (h_{t-1} = out shifted by Bn)."""
+    N, Cin, IA, IB = xshape
+    ns, cs, as_, bs = xstrides
+    ci = np.arange(Cin)
+    ktab = np.stack([ci * cs + shift * bs, np.zeros_like(ci), np.full_like(ci, shift), np.zeros_like(ci)], -1)
+    on, oc, oa, ob = ostrides
+    p = GemmPlan(N=N, M=M, K=Cin, OA=oshape[2], OB=oshape[3], IA=IA, IB=IB, SA=1, SB=1,
+                 in_ns=ns, in_as=as_, in_bs=bs, out_ns=on, out_cs=oc, out_as=oa, out_bs=ob,
+                 ktab=ktab, woff=ci.copy(), w_ms=Cin)
+    return p.finalize()

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import nnops, ops, stft
+from . import lstm, nnops, ops, stft
 
 
 class _ScaledEmbedding(nn.Module):
@@ -60,9 +60,11 @@ class _BLSTM(nn.Module):
             nfr = math.ceil(T / stride)
             xp = F.pad(x, (0, (nfr - 1) * stride + width - T))
             x = xp.unfold(-1, width, stride).permute(0, 2, 1, 3).reshape(-1, C, width)
-        x = x.permute(2, 0, 1).contiguous()
-        x = nnops.lstm(self.lstm, x)
-        x = nnops.linear(x, self.linear.weight, self.linear.bias).permute(1, 2, 0)
+        Bn, _, W = x.shape
+        h = x.permute(1, 2, 0).reshape(1, C, W * Bn)                 # channel-major, position = t*Bn + b
+        h = lstm.blstm(self.lstm, h, W, Bn)
+        h = ops.conv1d(h, self.linear.weight.unsqueeze(-1), self.linear.bias)
+        x = h.view(C, W, Bn).permute(2, 0, 1)
         if framed:
             fr = x.reshape(B, nfr, C, width)
             lim = stride // 2

@@ -1,0 +1,118 @@
+"""Bidirectional multi-layer LSTM on the HIP kernels (csrc/lstm.hip + the gather-GEMM).
+
+Replaces ``nn.LSTM`` where the reference reaches it: torchaudio HDemucs' ``_BLSTM`` inside the DConv
+branches (remfx/models.py:319) and Open-Unmix's 3-layer BiLSTM (remfx/models.py:297-298,
+``cfg/model/umx.yaml``).  The ``nn.LSTM`` object stays the PARAMETER CONTAINER (same state_dict keys
+``weight_ih_l0``, ``weight_hh_l0_reverse`` ...).
+
+Layout: sequences are channel-major ``(1, C, T*Bn)`` with position ``p = t*Bn + b`` so that
+  * the input projection of both directions is ONE 1x1 gather-GEMM  (8H x Cin),
+  * the recurrence is one persistent launch per layer (rfx_lstm_fwd / rfx_lstm_bwd),
+  * dX, dW_ih (+ bias row) are the conv dgrad / wgrad plans, and dW_hh is a wgrad whose input operand is
+    the layer's own output shifted by one time step (convplan.shift_plan, +-Bn positions).
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, convplan, ops
+from ._lib import check
+from .ops import _ptr, _stream
+
+
+def _pack_whh(w_hh, w_hh_r):
+    H = w_hh.shape[1]
+    nb = _lib.lib().rfx_lstm_pack_bytes(H)
+    if nb <= 0:
+        raise ValueError(f"LSTM hidden size {H} unsupported (multiple of 32, <= 512)")
+    pack = torch.empty(2 * nb, device=w_hh.device, dtype=torch.uint8)
+    for d, w in enumerate((w_hh, w_hh_r)):
+        check(_lib.lib().rfx_lstm_pack(_ptr(w.contiguous()), H, C.c_void_p(pack.data_ptr() + d * nb), _stream()),
+              "rfx_lstm_pack")
+    return pack
+
+
+def _whh_plan(out4, g4, H, d, Bn):
+    """wgrad plan for dW_hh of direction d: in = out[d*H:(d+1)*H] at time t-1 (d=0) / t+1 (d=1)."""
+    xs = out4[:, d * H:(d + 1) * H]
+    gs = g4[:, d * 4 * H:(d + 1) * 4 * H]
+    shift = -Bn if d == 0 else Bn
+    key = ops._key("lstm_whh", xs.shape, xs.stride(), gs.stride(), shift)
+    dp = ops._plans(key, out4.device, lambda: convplan.shift_plan(
+        tuple(xs.shape), xs.stride(), 4 * H, shift, tuple(gs.shape), gs.stride()))
+    return dp, xs, gs
+
+
+class _LSTMLayerFn(torch.autograd.Function):
+    """One bidirectional layer.  x: (1, Cin, P) -> (1, 2H, P)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, T, Bn):
+        ops._req(x, "x")
+        H, Cin = w_hh.shape[1], w_ih.shape[1]
+        P = T * Bn
+        if x.shape != (1, Cin, P):
+            raise ValueError(f"lstm: expected (1, {Cin}, {P}) channel-major input, got {tuple(x.shape)}")
+        x = x.contiguous()
+        x4 = x.unsqueeze(2)
+        wcat = torch.cat([w_ih, w_ih_r]).view(8 * H, Cin, 1, 1)
+        bcat = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r])
+        xp = ops.conv2d_forward(x4, wcat, bcat, (1, 1), (0, 0), (1, 1))           # (1, 8H, 1, P) == [2][4H][P]
+        pack = _pack_whh(w_hh, w_hh_r)
+        out = torch.empty((1, 2 * H, P), device=x.device, dtype=torch.float32)
+        need = any(ctx.needs_input_grad)
+        gates = torch.empty((2, 4 * H, P), device=x.device, dtype=torch.float32) if need else None
+        cst = torch.empty((2, H, P), device=x.device, dtype=torch.float32) if need else None
+        check(_lib.lib().rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), _ptr(gates), _ptr(cst), _stream()),
+              "rfx_lstm_fwd")
+        if need:
+            ctx.save_for_backward(x, wcat, pack, gates, cst, out)
+            ctx.dims = (T, Bn, H, Cin)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wcat, pack, gates, cst, out = ctx.saved_tensors
+        T, Bn, H, Cin = ctx.dims
+        P = T * Bn
+        g = g.contiguous()
+        dG = torch.empty((1, 8 * H, 1, P), device=g.device, dtype=torch.float32)
+        check(_lib.lib().rfx_lstm_bwd(_ptr(g), _ptr(pack), _ptr(gates), _ptr(cst), T, Bn, H, _ptr(dG), _stream()),
+              "rfx_lstm_bwd")
+        x4 = x.unsqueeze(2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(dG, wcat, tuple(x4.shape), x4.stride(), (1, 1), (0, 0), (1, 1)).squeeze(2)
+        dwcat, dbcat = ops.conv2d_wgrad(x4, dG, tuple(wcat.shape), (1, 1), (0, 0), (1, 1), True)
+        dwcat = dwcat.view(8 * H, Cin)
+        out4 = out.unsqueeze(2)
+        dwhh = []
+        for d in range(2):
+            dp, xs, gs = _whh_plan(out4, dG, H, d, Bn)
+            dap = torch.zeros((dp.p.M, dp.p.Kpad), device=g.device, dtype=torch.float32)
+            ops.gemm_wgrad(dp, xs, gs, dap)
+            dw = torch.zeros((4 * H, H), device=g.device, dtype=torch.float32)
+            ops.unpack_add(dp, dap, dw)
+            dwhh.append(dw)
+        db0, db1 = dbcat[:4 * H], dbcat[4 * H:]
+        return (dx, dwcat[:4 * H], dwhh[0], db0, db0, dwcat[4 * H:], dwhh[1], db1, db1, None, None)
+
+
+def blstm(module, x, T, Bn):
+    """module: bidirectional ``nn.LSTM`` parameter container (batch_first irrelevant: the layout is explicit).
+    x: (1, C, T*Bn) channel-major, position = t*Bn + b.  Returns (1, 2H, T*Bn)."""
+    if not module.bidirectional:
+        raise NotImplementedError("only bidirectional LSTMs are on the hot path (cfg/model/umx.yaml, HDemucs BLSTM)")
+    if not module.bias or getattr(module, "proj_size", 0):
+        raise NotImplementedError("lstm: bias=True, proj_size=0 only")
+    h = x
+    for layer in range(module.num_layers):
+        p = [getattr(module, f"{n}_l{layer}{sfx}") for sfx in ("", "_reverse")
+             for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        h = _LSTMLayerFn.apply(h, *p, T, Bn)
+        if module.dropout > 0 and module.training and layer < module.num_layers - 1:
+            from . import nnops
+            nnops._interim("dropout")
+            h = F.dropout(h, module.dropout, True)
+    return h

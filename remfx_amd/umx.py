@@ -5,12 +5,12 @@ Same parameter names as upstream (fc1/bn1/lstm/fc2/bn2/fc3/bn3, input_mean, inpu
 output_scale, output_mean).  Layout: the network runs channel-major, (1, features, frames*batch), so
 every Linear is a 1x1 gather-GEMM with the position axis contiguous and BatchNorm1d is the same
 per-channel reduction kernel the classifier uses.  STFT / magnitude, the magnitude x mixture-phase
-product and the iSTFT are HIP kernels; the 3-layer BiLSTM still runs through torch-ROCm (nnops.INTERIM).
+product and the iSTFT are HIP kernels; the 3-layer BiLSTM is the persistent HIP recurrence of remfx_amd/lstm.py.
 """
 import torch
 import torch.nn as nn
 
-from . import _lib, nnops, ops, stft
+from . import _lib, lstm, nnops, ops, stft
 from ._lib import check
 from .ops import _ptr, _stream
 
@@ -49,9 +49,8 @@ class OpenUnmix(nn.Module):
         h = (mix + self.input_mean.view(1, -1, 1)) * self.input_scale.view(1, -1, 1)
         h = ops.conv1d(h, self.fc1.weight.unsqueeze(-1))
         h = ops.activation(nnops.batch_norm(h, self.bn1, self.bn1.training), "tanh")            # (1, 512, P)
-        seq = h.view(self.hidden_size, nf, B).permute(1, 2, 0).contiguous()                        # (F, B, 512)
-        lo = nnops.lstm(self.lstm, seq)                                                              # (F, B, 512)
-        cat = torch.cat([seq, lo], -1).permute(2, 0, 1).reshape(1, 2 * self.hidden_size, P).contiguous()
+        lo = lstm.blstm(self.lstm, h, nf, B)                                                         # (1, 512, P)
+        cat = torch.cat([h, lo], 1)
         h = nnops.batch_norm(ops.conv1d(cat, self.fc2.weight.unsqueeze(-1)), self.bn2, self.bn2.training, relu=True)
         h = nnops.batch_norm(ops.conv1d(h, self.fc3.weight.unsqueeze(-1)), self.bn3, self.bn3.training)
         h = h * self.output_scale.view(1, -1, 1) + self.output_mean.view(1, -1, 1)
