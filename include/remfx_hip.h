@@ -169,18 +169,22 @@ int rfx_fft_synthesis(const rfx_stft_desc* d, const float* spec, const float* wi
  * persistent launch per sweep.  All sequence tensors are channel-major [C][P], P = T*Bn, position p = t*Bn + b.
  * The caller runs the dense parts as gather-GEMMs: xp = [W_ih; W_ih_reverse] x + (b_ih + b_hh) before
  * rfx_lstm_fwd, and dX / dW_ih / dW_hh / db from dG after rfx_lstm_bwd.  Gate order i, f, g, o (PyTorch).
- * H % 32 == 0, H <= 512.  Arithmetic: bf16x3 split products, fp32 accumulate / state. */
+ * H % 32 == 0, H <= 512.  Arithmetic: bf16x3 split products, fp32 accumulate / state.
+ * ws: caller-owned scratch of rfx_lstm_ws_bytes(H) bytes (cluster exchange buffers + arrival counters), reusable
+ * across calls on one stream; its first int32 is a sticky error flag the caller zeroes once and may poll
+ * (non-zero = a bounded spin timed out, results invalid). */
 /* bytes of one direction's packed W_hh (MFMA fragments for both sweeps) */
 int rfx_lstm_pack_bytes(int32_t H);
+int rfx_lstm_ws_bytes(int32_t H);
 /* whh: [4H][H] row-major -> pack (rfx_lstm_pack_bytes(H) bytes).  The two directions are packed back to back. */
 int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stream);
 /* xp [2][4H][P]; pack = both directions; out [2H][P] (forward dir rows 0..H-1, reverse H..2H-1);
  * gates [2][4H][P] and cstate [2][H][P] are saved for the backward sweep (both NULL for inference). */
 int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_t Bn, int32_t H, float* out, float* gates,
-                 float* cstate, void* stream);
+                 float* cstate, void* ws, void* stream);
 /* gout [2H][P] -> dG [2][4H][P], the gradients of the gate pre-activations. */
 int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
-                 int32_t Bn, int32_t H, float* dG, void* stream);
+                 int32_t Bn, int32_t H, float* dG, void* ws, void* stream);
 
 /* ---- elementwise / reductions ------------------------------------------------ */
 /* y = act(x) elementwise over n contiguous floats; PReLU/bias not supported here. */

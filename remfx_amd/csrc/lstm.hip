@@ -5,15 +5,24 @@
 //
 // Everything around the recurrence is a plain gather-GEMM on channel-major tensors (1, C, T*Bn):
 // input projections xp = W_ih x + b, and after the backward sweep dX, dW_ih, dW_hh, db.
-// The sweep itself:
-//   * grid = (batch tiles of 32 sequences, 2 directions); a workgroup has H/32 waves and owns ALL
-//     hidden units of its sequences, so time steps need one workgroup barrier, never a grid sync;
+// The sweep itself is a *wave cluster*:
+//   * a cluster = (tile of 32 sequences, direction); it has H/32 single-wave workgroups, each owning 32 hidden
+//     units (all four gates).  Every step a wave needs its slice of W_hh (4*32*H weights) and the whole h_{t-1};
+//     one CU's vector L1 fills at 64 B/clk, so spreading a cluster's weight stream over H/32 CUs is what makes
+//     a step cost ~ the MFMA chain instead of ~ |W_hh| / 64 B/clk (measured: 30 us -> see DESIGN.md);
 //   * gates^T[4H x 32] = xp[t] + W_hh[4H x H] . h^T[H x 32] on v_mfma_f32_32x32x16_bf16 with the
 //     bf16x3 split (hi.hi + hi.lo + lo.hi, fp32 accumulate); MFMA rows = gate units, columns =
 //     sequences, so every global access is coalesced along the sequence axis of the channel-major
 //     tensors and a lane owns (16 units x 1 sequence) of all four gates -> the cell update is local;
-//   * W_hh streams from L2 every step as pre-packed MFMA A fragments (pack kernel below);
-//     h_{t-1} (resp. the gate gradients) is the B operand, kept in LDS as bf16 hi/lo rows.
+//   * h_t (resp. the gate gradients in the backward sweep) is exchanged between the waves of a cluster through a
+//     ping-pong buffer in global memory that is already in MFMA B-fragment order (bf16 hi / lo), written and
+//     read with agent-scope atomic 8-byte accesses, plus one arrival counter per cluster;
+//   * the grid never exceeds what is co-resident (<= RFX_LSTM_MAX_WAVES single-wave workgroups per launch, tiles are
+//     chunked over launches), and every spin is bounded: on time-out the wave raises the error flag and exits.
+//   Workgroup ids are laid out so that the waves of a cluster are congruent mod 8, i.e. on one XCD / one L2 when
+//   the dispatcher round-robins (performance only; correctness relies on agent scope, not on placement).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -65,6 +74,10 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, int H, uint4* __
   }
 }
 
+
+#define RFX_LSTM_MAX_WAVES 1024
+#define RFX_LSTM_SPIN_LIMIT (1 << 22)
+
 struct LstmArgs {
   const float* xp;      // [2][4H][P]   input projections (+ both biases), P = T*Bn, position = t*Bn + b
   const uint4* packA;   // per direction: fwdA (hi, lo) then bwdA (hi, lo); dir stride in uint4 = pack_stride
@@ -73,200 +86,400 @@ struct LstmArgs {
   float* cstate;        // [2][H][P]
   const float* gout;    // bwd: [2H][P]
   float* dG;            // bwd: [2][4H][P] gate pre-activation gradients
+  uint64_t* xch;        // exchange buffers, per cluster 2 x (KS k-steps x [hi|lo] x 64 lanes x 2) u64
+  uint32_t* ctr;        // arrival counters, one per cluster, 64 B apart
+  int32_t* err;         // sticky error flag (spin time-out)
   int64_t pack_stride;
   int T, Bn, H, P;
+  int tile0, nclusters;
+  int dbg;              // timing experiments only (RFX_LSTM_DBG): 1 no wait, 2 no MFMA, 4 no publish, 8 no saves, 16 no fetch
 };
 
-extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
+__device__ __forceinline__ bool lstm_wait(const uint32_t* ctr, uint32_t target) {
+  for (int it = 0; it < RFX_LSTM_SPIN_LIMIT; ++it) {
+    const uint32_t v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_readfirstlane(v) >= target) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+// all of this wave's exchange stores have been acknowledged at agent scope -> publish
+__device__ __forceinline__ void lstm_arrive(uint32_t* ctr, int lane) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): visible to the compiler's wait-count bookkeeping, unlike inline asm
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bf16x8 lstm_xch_load(const uint64_t* p) {
+  const uint64_t a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint64_t b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint4 v = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+  return __builtin_bit_cast(bf16x8, v);
+}
+// four consecutive values -> bf16 hi / lo quads
+__device__ __forceinline__ void lstm_xch_store(uint64_t* phi, uint64_t* plo, float v0, float v1, float v2, float v3) {
+  unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+  split_hi_lo(v0, h0, l0); split_hi_lo(v1, h1, l1); split_hi_lo(v2, h2, l2); split_hi_lo(v3, h3, l3);
+  const uint64_t hi = (uint64_t)h0 | ((uint64_t)h1 << 16) | ((uint64_t)h2 << 32) | ((uint64_t)h3 << 48);
+  const uint64_t lo = (uint64_t)l0 | ((uint64_t)l1 << 16) | ((uint64_t)l2 << 32) | ((uint64_t)l3 << 48);
+  __hip_atomic_store(phi, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(plo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// workgroup id -> (cluster, unit block): ids congruent mod 8 share an XCD under round-robin dispatch
+__device__ __forceinline__ bool lstm_ids(const LstmArgs& a, int& cluster, int& ub) {
+  const int nwc = a.H / 32, w = blockIdx.x, j = w >> 3;
+  cluster = (j / nwc) * 8 + (w & 7);
+  ub = j % nwc;
+  return cluster < a.nclusters;
+}
 
 struct LstmAFrag { uint4 h[4], l[4]; };
 
-// XPV: the step's input projections are fetched into their own registers at the top of the step and added in
-// the cell update, so their HBM latency hides behind the MFMA chain (needs 64 more VGPRs; H <= 256 variants).
-// Otherwise they are loaded straight into the accumulators before the previous step's barrier.
-template <int MAXT, bool XPV>
-__global__ __launch_bounds__(MAXT) void lstm_fwd_kernel(const LstmArgs a) {
+extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
+
+// n x (64 lanes x 16 B) from global (agent-coherent) straight into LDS, no registers: chunk i lands at lds + i KB
+__device__ __forceinline__ void lstm_fetch_lds(const uint64_t* src, int n, int lane) {
+  for (int i = 0; i < n; ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (i * 64 + lane) * 2),
+                                     (__attribute__((address_space(3))) void*)(lstm_smem + i * 1024), 16, 0,
+                                     16 /* sc1: agent scope */);
+}
+
+// Forward exchange (h_t as MFMA B fragments): u64 index ((ks*2 + part)*64 + L)*2 + half; L = (sequence, hhB) is the
+// lane that consumes k = 16ks + 8hhB + 4half + e (e = 0..3, 16 bits each).  The producing lane (sequence l31, hh)
+// holds units du = (r&3) + 8(r>>2) + 4hh, i.e. for r = 8*ksl + 4*hhB + e: k-step 2ub+ksl, lane l31+32hhB, half hh.
+// D = depth of the weight-fragment ring in k-steps (each k-step = 4 gates x (hi, lo) = 8 KB per wave): the L2 round trip
+// (~0.5 us) is covered only if ~4 k-steps (0.64 us of MFMA work) are in flight; D = 2 when H is not a multiple of 64.
+// NKS = H/16 at compile time (0: runtime).  Only the runtime form is instantiated: hipcc drains vmcnt(0) at the k-loop
+// header (55 instead of 32 cycles per MFMA, in-kernel stamps), but the fully unrolled form hoists ~100 fragment addresses
+// out of the time loop and spills; see DESIGN.md for the remaining head-room.
+template <int D, int NKS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_kernel(const LstmArgs a) {
+  int cluster, ub;
+  if (!lstm_ids(a, cluster, ub)) return;
   const int H = a.H, Bn = a.Bn, T = a.T, P = a.P;
-  const int dir = blockIdx.y, row0 = blockIdx.x * 32;
-  const int tid = threadIdx.x, ub = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int nks = H / 16, LDH = H + 8;
-  unsigned short* hbuf = reinterpret_cast<unsigned short*>(lstm_smem);   // [2 bufs][2 hi/lo][32][LDH]
+  const int dir = cluster & 1, row0 = (a.tile0 + (cluster >> 1)) * 32;
+  const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
+  const int nks = NKS ? NKS : H / 16, nwc = nks / 2;
   const int row = row0 + l31;
   const bool rvalid = row < Bn;
-  // invalid sequences read (finite) data of sequence 0 and never store: keeps every load unconditional
-  const int rowc = rvalid ? row : 0;
+  const int rowc = rvalid ? row : 0;      // idle lanes read sequence 0 and never store: every load stays unconditional
   const float* __restrict__ xp = a.xp + (int64_t)dir * 4 * H * P;
-  const int nf = (H / 32) * 4 * nks * 64;
-  const uint4* __restrict__ Ahi = a.packA + (int64_t)dir * a.pack_stride + ub * 4 * nks * 64 + lane;
+  const int nf = nwc * 4 * nks * 64;
+  const uint4* __restrict__ Ahi = a.packA + (int64_t)dir * a.pack_stride + ub * 4 * nks * 64;   // wave-uniform
   const uint4* __restrict__ Alo = Ahi + nf;
   float* outp = a.out + (int64_t)dir * H * P;
   float* gsave = a.gates ? a.gates + (int64_t)dir * 4 * H * P : nullptr;
   float* csave = a.gates ? a.cstate + (int64_t)dir * H * P : nullptr;
+  const int bufw = nks * 256;                                        // u64 per ping-pong buffer
+  uint64_t* xch = a.xch + (int64_t)cluster * 2 * bufw;
+  uint32_t* ctr = a.ctr + cluster * 16;
   const uint32_t uP = (uint32_t)P, HP = (uint32_t)H * uP;
   const uint32_t ubase = (uint32_t)(32 * ub + 4 * hh) * uP + (uint32_t)rowc;   // + ((r&3) + 8(r>>2)) * P + t*Bn
   auto loadA = [&](LstmAFrag& f, int ks) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f.h[g] = Ahi[(g * nks + ks) * 64];
-      f.l[g] = Alo[(g * nks + ks) * 64];
+      f.h[g] = Ahi[(g * nks + ks) * 64 + lane];
+      f.l[g] = Alo[(g * nks + ks) * 64 + lane];
     }
   };
-  auto mma = [&](f32x16* acc, const LstmAFrag& f, const unsigned short* hb, int ks) {
-    const int off = l31 * LDH + 16 * ks + 8 * hh;
-    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hb + off);
-    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hb + 32 * LDH + off);
+  auto loadB = [&](bf16x8& bh, bf16x8& bl, int ks) {
+    bh = *reinterpret_cast<const bf16x8*>(lstm_smem + ks * 2048 + lane * 16);
+    bl = *reinterpret_cast<const bf16x8*>(lstm_smem + ks * 2048 + 1024 + lane * 16);
+  };
+  // the four gate accumulators are independent: issue them round-robin so no MFMA waits on its predecessor
+  auto mma = [&](f32x16* acc, const LstmAFrag& f, const bf16x8 bh, const bf16x8 bl) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, f.h[g]);
-      const bf16x8 al = __builtin_bit_cast(bf16x8, f.l[g]);
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[g], 0, 0, 0);
-    }
+    for (int g = 0; g < 4; ++g)
+      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[g]), bh, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[g]), bl, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.l[g]), bh, acc[g], 0, 0, 0);
   };
   float c[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) c[r] = 0.f;
   f32x16 acc[4];
-  LstmAFrag f0, f1;
-  loadA(f0, 0);
-  if (!XPV) {
+  LstmAFrag f[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) loadA(f[d], d);
+  // xpv = this step's input projections, fetched one step ahead so that HBM latency hides behind the MFMA chain
+  float xpv[4][16], xpn[4][16];
+  {
     const uint32_t o0 = ubase + (uint32_t)((dir == 0 ? 0 : T - 1) * Bn);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[g][r] = xp[o0 + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
+      for (int r = 0; r < 16; ++r) xpv[g][r] = xp[o0 + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
   }
+  uint64_t* stamp = reinterpret_cast<uint64_t*>(a.err) + 8;        // RFX_LSTM_DBG & 32: 3 steps x 8 time stamps
+  const bool stamping = (a.dbg & 32) && cluster == 0 && ub == 0 && lane == 0;
+#define LSTM_STAMP(k) do { if (stamping && s >= 100 && s < 103) stamp[(s - 100) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? s : T - 1 - s;
     const uint32_t o0 = ubase + (uint32_t)(t * Bn);
-    float xpv[XPV ? 4 : 1][16];
-    if (XPV) {
+    LSTM_STAMP(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    if (s > 0) {
+      if (!(a.dbg & 1) && !lstm_wait(ctr, (uint32_t)(nwc * s))) { *a.err = 1; return; }
+      LSTM_STAMP(1);
+      if (!(a.dbg & 16)) lstm_fetch_lds(xch + ((s - 1) & 1) * bufw, 2 * nks, lane);
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): visible to the compiler's wait-count bookkeeping, unlike inline asm
+      LSTM_STAMP(2);
+    }
+    {
+      const int tn = s + 1 < T ? (dir == 0 ? s + 1 : T - 2 - s) : t;     // clamped on the last step (harmless re-read)
+      const uint32_t on = ubase + (uint32_t)(tn * Bn);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          xpv[g][r] = xp[o0 + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
-          acc[g][r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) xpn[g][r] = xp[on + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
     }
-    if (s > 0) {
-      const unsigned short* hb = hbuf + ((s - 1) & 1) * 2 * 32 * LDH;
-      for (int ks = 0; ks < nks; ks += 2) {          // nks is even; weights stay two k-steps ahead
-        loadA(f1, ks + 1);
-        mma(acc, f0, hb, ks);
-        loadA(f0, ks + 2 == nks ? 0 : ks + 2);       // wraps to the next step's first fragment
-        mma(acc, f1, hb, ks + 1);
+    LSTM_STAMP(3);
+    if (s > 0 && !(a.dbg & 2)) {
+      bf16x8 bh[2], bl[2];
+      loadB(bh[0], bl[0], 0);
+#pragma unroll
+      for (int ks = 0; ks < (NKS ? NKS : nks); ks += D) {          // nks % D == 0, D even
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const int k1 = ks + d + 1 == nks ? 0 : ks + d + 1;       // h fragments one k-step ahead (LDS latency)
+          loadB(bh[(d + 1) & 1], bl[(d + 1) & 1], k1);
+          mma(acc, f[d], bh[d & 1], bl[d & 1]);
+          const int kn = ks + d + D;                  // the slot's next occupant; wraps into the next step
+          loadA(f[d], kn >= nks ? kn - nks : kn);
+          __builtin_amdgcn_sched_barrier(0);          // keep the refill behind its MFMAs (scheduler would hoist all loads)
+        }
       }
     }
-    unsigned short* hw = hbuf + (s & 1) * 2 * 32 * LDH + l31 * LDH + 32 * ub + 4 * hh;
-    // next step's time index (clamped on the last step: a harmless re-read)
-    const int tn = s + 1 < T ? (dir == 0 ? s + 1 : T - 2 - s) : t;
-    const uint32_t on = ubase + (uint32_t)(tn * Bn);
+    asm volatile("s_nop 0" ::: "memory");
+    LSTM_STAMP(4);
+    uint64_t* hw = xch + (s & 1) * bufw;
+    float hv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int du = (r & 3) + 8 * (r >> 2);
-      float p0 = acc[0][r], p1 = acc[1][r], p2 = acc[2][r], p3 = acc[3][r];
-      if (XPV) { p0 += xpv[0][r]; p1 += xpv[1][r]; p2 += xpv[2][r]; p3 += xpv[3][r]; }
-      const float ig = lstm_sigmoid(p0), fg = lstm_sigmoid(p1);
-      const float gg = lstm_tanh(p2), og = lstm_sigmoid(p3);
+      const float ig = lstm_sigmoid(acc[0][r] + xpv[0][r]), fg = lstm_sigmoid(acc[1][r] + xpv[1][r]);
+      const float gg = lstm_tanh(acc[2][r] + xpv[2][r]), og = lstm_sigmoid(acc[3][r] + xpv[3][r]);
       c[r] = fg * c[r] + ig * gg;
-      const float hv = og * lstm_tanh(c[r]);
-      unsigned short vh, vl;
-      split_hi_lo(hv, vh, vl);
-      hw[du] = vh;
-      hw[32 * LDH + du] = vl;
-      if (rvalid) {
-        const uint32_t o = o0 + (uint32_t)du * uP;
-        outp[o] = hv;
+      hv[r] = og * lstm_tanh(c[r]);
+      acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og;
+    }
+    LSTM_STAMP(5);
+    if (s + 1 < T && !(a.dbg & 4)) {                  // publish h_t first: it is the cluster's critical path
+#pragma unroll
+      for (int ksl = 0; ksl < 2; ++ksl)
+#pragma unroll
+        for (int hb2 = 0; hb2 < 2; ++hb2) {
+          const int r0 = 8 * ksl + 4 * hb2;
+          uint64_t* d = hw + (((2 * ub + ksl) * 2) * 64 + l31 + 32 * hb2) * 2 + hh;
+          lstm_xch_store(d, d + 128, hv[r0], hv[r0 + 1], hv[r0 + 2], hv[r0 + 3]);
+        }
+      lstm_arrive(ctr, lane);
+    }
+    LSTM_STAMP(6);
+    if (rvalid && !(a.dbg & 8)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t o = o0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
+        outp[o] = hv[r];
         if (gsave) {
-          gsave[o] = ig; gsave[o + HP] = fg; gsave[o + 2 * HP] = gg; gsave[o + 3 * HP] = og;
+          gsave[o] = acc[0][r]; gsave[o + HP] = acc[1][r]; gsave[o + 2 * HP] = acc[2][r]; gsave[o + 3 * HP] = acc[3][r];
           csave[o] = c[r];
         }
       }
-      if (!XPV) {
-        const uint32_t o = on + (uint32_t)du * uP;
-        acc[0][r] = xp[o]; acc[1][r] = xp[o + HP]; acc[2][r] = xp[o + 2 * HP]; acc[3][r] = xp[o + 3 * HP];
-      }
     }
-    __syncthreads();
+    LSTM_STAMP(7);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xpv[g][r] = xpn[g][r];
   }
+#undef LSTM_STAMP
 }
 
-// backward through time.  RB = sequences per workgroup (32, or 16 when 4H bf16 hi/lo rows of 32 would not fit LDS)
-template <int RB, int MAXT>
-__global__ __launch_bounds__(MAXT) void lstm_bwd_kernel(const LstmArgs a) {
+// Backward through time.  A wave multiplies ITS gate-gradient slice (K = 4 x 32 rows of W_hh) into partial
+// dh_{t-1} for ALL hidden units and publishes the fp32 partial tiles; the owner of a unit block sums the H/32
+// partials.  Exchange (per ping-pong buffer): [consumer unit block][producer][quad j][lane][4 floats], i.e. the
+// consumer's slice is H/32 x 4 KB, contiguous, fetched straight into LDS.
+// TPC = unit-block tiles per ring refill round: the weight ring holds 8*TPC k-step fragments (hi, lo); 16 in flight
+// cover the L2 round trip (3 MFMAs per fragment), so TPC = 2 whenever H/32 is even.
+template <int TPC, int NWC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(const LstmArgs a) {
+  int cluster, ub;
+  if (!lstm_ids(a, cluster, ub)) return;
   const int H = a.H, Bn = a.Bn, T = a.T, P = a.P;
-  const int dir = blockIdx.y, row0 = blockIdx.x * RB;
-  const int tid = threadIdx.x, ub = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int nks4 = 4 * H / 16, LDG = 4 * H + 8;
-  unsigned short* gbuf = reinterpret_cast<unsigned short*>(lstm_smem);   // [2 hi/lo][RB][LDG]
-  const int lr = l31 & (RB - 1);
-  const int row = row0 + lr;
-  const bool rvalid = (l31 < RB) && row < Bn;
-  const int nks = H / 16;
-  const int nf = (H / 32) * 4 * nks * 64, nb = (H / 32) * nks4 * 64;
-  const uint4* __restrict__ Ahi = a.packA + (int64_t)dir * a.pack_stride + 2 * nf + ub * nks4 * 64;
+  const int dir = cluster & 1, row0 = (a.tile0 + (cluster >> 1)) * 32;
+  const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
+  const int nwc = NWC ? NWC : H / 32, nks = 2 * nwc, nks4 = 4 * nks;
+  const int row = row0 + l31;
+  const bool rvalid = row < Bn;
+  const int rowc = rvalid ? row : 0;
+  const int nf = nwc * 4 * nks * 64, nb = nwc * nks4 * 64;
+  // bwdA[ot][ks'][lane]: tile ot = output unit block, ks' = gate-row k-step; this wave's rows: g*nks + 2ub + {0,1}
+  const uint4* __restrict__ Ahi = a.packA + (int64_t)dir * a.pack_stride + 2 * nf + 2 * ub * 64;   // wave-uniform
   const uint4* __restrict__ Alo = Ahi + nb;
   const float* __restrict__ gates = a.gates + (int64_t)dir * 4 * H * P;
   const float* __restrict__ cst = a.cstate + (int64_t)dir * H * P;
   float* __restrict__ dG = a.dG + (int64_t)dir * 4 * H * P;
   const float* __restrict__ goutp = a.gout + (int64_t)dir * H * P;
+  const int bufw = nwc * nwc * 512;                                  // u64 per ping-pong buffer
+  uint64_t* xch = a.xch + (int64_t)cluster * 2 * bufw;
+  uint32_t* ctr = a.ctr + cluster * 16;
   const uint32_t uP = (uint32_t)P, HP = (uint32_t)H * uP;
-  const uint32_t ubase = (uint32_t)(32 * ub + 4 * hh) * uP + (uint32_t)row;
-  unsigned short* gr = gbuf + lr * LDG + 32 * ub + 4 * hh;
-  float dcc[16];
-  f32x16 dhr;
+  const uint32_t ubase = (uint32_t)(32 * ub + 4 * hh) * uP + (uint32_t)rowc;
+  constexpr int RING = 8 * TPC;
+  const int F = 8 * nwc;                                             // fragments per time step, F % RING == 0
+  auto frag_index = [&](int fi) { const int ot = fi >> 3, kk = fi & 7; return (ot * nks4 + (kk >> 1) * nks + (kk & 1)) * 64 + lane; };
+  uint4 wh[RING], wl[RING];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dcc[r] = 0.f; dhr[r] = 0.f; }
-  for (int s = T - 1; s >= 0; --s) {            // reverse of the forward processing order
-    const int t = dir == 0 ? s : T - 1 - s;
-    const int tprev = dir == 0 ? t - 1 : t + 1;   // time index of the forward sweep's previous step
-    const uint32_t o0 = ubase + (uint32_t)(t * Bn);
-    const uint32_t op0 = ubase + (uint32_t)((s > 0 ? tprev : t) * Bn);
+  for (int i = 0; i < RING; ++i) { wh[i] = Ahi[frag_index(i)]; wl[i] = Alo[frag_index(i)]; }
+  float dcc[16], ct[16];
+  float sg[4][16], cp[16], gy[16];            // this step's saved gates / c_{prev} / incoming gradient
+  float ng[4][16], ncp[16], ngy[16];          // next step's, fetched one step ahead
+  {
+    const uint32_t o0 = ubase + (uint32_t)((dir == 0 ? T - 1 : 0) * Bn);
+    const uint32_t op0 = ubase + (uint32_t)((T > 1 ? (dir == 0 ? T - 2 : 1) : (dir == 0 ? T - 1 : 0)) * Bn);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int du = (r & 3) + 8 * (r >> 2);
-      float di = 0.f, df = 0.f, dg = 0.f, dO = 0.f;
-      if (rvalid) {
-        const uint32_t o = o0 + (uint32_t)du * uP;
-        const float ig = gates[o], fg = gates[o + HP], gg = gates[o + 2 * HP], og = gates[o + 3 * HP];
-        const float ct = cst[o];
-        float cp = cst[op0 + (uint32_t)du * uP];
-        cp = s > 0 ? cp : 0.f;
-        const float dh = goutp[o] + dhr[r];
-        const float th = lstm_tanh(ct);
-        dO = dh * th * og * (1.f - og);
-        const float dc = dh * og * (1.f - th * th) + dcc[r];
-        di = dc * gg * ig * (1.f - ig);
-        df = dc * cp * fg * (1.f - fg);
-        dg = dc * ig * (1.f - gg * gg);
-        dcc[r] = dc * fg;
-        dG[o] = di; dG[o + HP] = df; dG[o + 2 * HP] = dg; dG[o + 3 * HP] = dO;
-      }
-      if (l31 < RB) {
-        unsigned short vh, vl;
-        split_hi_lo(di, vh, vl); gr[du] = vh; gr[RB * LDG + du] = vl;
-        split_hi_lo(df, vh, vl); gr[H + du] = vh; gr[RB * LDG + H + du] = vl;
-        split_hi_lo(dg, vh, vl); gr[2 * H + du] = vh; gr[RB * LDG + 2 * H + du] = vl;
-        split_hi_lo(dO, vh, vl); gr[3 * H + du] = vh; gr[RB * LDG + 3 * H + du] = vl;
-      }
+      const uint32_t du = (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
+      dcc[r] = 0.f;
+      ct[r] = cst[o0 + du];
+      sg[0][r] = gates[o0 + du]; sg[1][r] = gates[o0 + du + HP]; sg[2][r] = gates[o0 + du + 2 * HP]; sg[3][r] = gates[o0 + du + 3 * HP];
+      cp[r] = cst[op0 + du];
+      gy[r] = goutp[o0 + du];
     }
-    if (s == 0) break;
-    __syncthreads();
+  }
+  for (int s = T - 1; s >= 0; --s) {            // reverse of the forward processing order
+    const int step = T - 1 - s;                 // exchange generation
+    const int t = dir == 0 ? s : T - 1 - s;
+    const uint32_t o0 = ubase + (uint32_t)(t * Bn);
+    if (step > 0) {
+      if (!lstm_wait(ctr, (uint32_t)(nwc * step))) { *a.err = 1; return; }
+      lstm_fetch_lds(xch + ((step - 1) & 1) * bufw + ub * nwc * 512, 4 * nwc, lane);
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): visible to the compiler's wait-count bookkeeping, unlike inline asm
+    }
+    {
+      // next step (s-1): its time index and the one before it in forward order (clamped at the sequence start)
+      const int s1 = s > 0 ? s - 1 : 0, s2 = s1 > 0 ? s1 - 1 : 0;
+      const uint32_t on = ubase + (uint32_t)((dir == 0 ? s1 : T - 1 - s1) * Bn);
+      const uint32_t opn = ubase + (uint32_t)((dir == 0 ? s2 : T - 1 - s2) * Bn);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dhr[r] = 0.f;
-    for (int ks = 0; ks < nks4; ++ks) {
-      const int off = lr * LDG + 16 * ks + 8 * hh;
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(gbuf + off);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(gbuf + RB * LDG + off);
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, Ahi[ks * 64 + lane]);
-      const bf16x8 al = __builtin_bit_cast(bf16x8, Alo[ks * 64 + lane]);
-      dhr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, dhr, 0, 0, 0);
-      dhr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, dhr, 0, 0, 0);
-      dhr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, dhr, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t du = (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
+        ng[0][r] = gates[on + du]; ng[1][r] = gates[on + du + HP]; ng[2][r] = gates[on + du + 2 * HP]; ng[3][r] = gates[on + du + 3 * HP];
+        ncp[r] = cst[opn + du];
+        ngy[r] = goutp[on + du];
+      }
     }
-    __syncthreads();
+    if (step > 0) {
+      for (int p = 0; p < nwc; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(lstm_smem + (p * 4 + j) * 1024 + lane * 16);
+          gy[4 * j] += v[0]; gy[4 * j + 1] += v[1]; gy[4 * j + 2] += v[2]; gy[4 * j + 3] += v[3];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float ig = sg[0][r], fg = sg[1][r], gg = sg[2][r], og = sg[3][r];
+      const float cprev = s > 0 ? cp[r] : 0.f;
+      const float th = lstm_tanh(ct[r]);
+      const float dc = gy[r] * og * (1.f - th * th) + dcc[r];
+      sg[3][r] = gy[r] * th * og * (1.f - og);
+      sg[0][r] = dc * gg * ig * (1.f - ig);
+      sg[1][r] = dc * cprev * fg * (1.f - fg);
+      sg[2][r] = dc * ig * (1.f - gg * gg);
+      dcc[r] = dc * fg;
+      ct[r] = cp[r];
+    }
+    if (s > 0) {
+      // own gate gradients as MFMA B fragments: lane (seq, hhB) needs units 16ksl + 8hhB + q; q < 4 live in the
+      // hh = 0 lane, q >= 4 in the hh = 1 lane of the same sequence -> one cross-half exchange per packed pair
+      uint4 bh[8], bl[8];                                   // index kk = 2g + ksl
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ++ksl) {
+          uint32_t x0h[2], x0l[2], x1h[2], x1l[2];         // packed bf16 pairs of X0 = r 8ksl+0..3, X1 = r 8ksl+4..7
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            unsigned short h0, l0, h1, l1;
+            split_hi_lo(sg[g][8 * ksl + 2 * e], h0, l0); split_hi_lo(sg[g][8 * ksl + 2 * e + 1], h1, l1);
+            x0h[e] = (uint32_t)h0 | ((uint32_t)h1 << 16); x0l[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+            split_hi_lo(sg[g][8 * ksl + 4 + 2 * e], h0, l0); split_hi_lo(sg[g][8 * ksl + 4 + 2 * e + 1], h1, l1);
+            x1h[e] = (uint32_t)h0 | ((uint32_t)h1 << 16); x1l[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+          }
+          uint32_t rh[2], rl[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            rh[e] = (uint32_t)__shfl_xor((int)(hh ? x0h[e] : x1h[e]), 32, 64);
+            rl[e] = (uint32_t)__shfl_xor((int)(hh ? x0l[e] : x1l[e]), 32, 64);
+          }
+          bh[2 * g + ksl] = hh ? make_uint4(rh[0], rh[1], x1h[0], x1h[1]) : make_uint4(x0h[0], x0h[1], rh[0], rh[1]);
+          bl[2 * g + ksl] = hh ? make_uint4(rl[0], rl[1], x1l[0], x1l[1]) : make_uint4(x0l[0], x0l[1], rl[0], rl[1]);
+        }
+      uint64_t* gw = xch + (step & 1) * bufw + ub * 512;            // + ot * nwc * 512 (consumer ot, producer ub)
+#pragma unroll
+      for (int f0 = 0; f0 < (NWC ? 8 * NWC : F); f0 += RING) {
+        f32x16 acc[TPC];
+#pragma unroll
+        for (int tp = 0; tp < TPC; ++tp)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+        // the TPC tiles of a round are independent accumulators: interleave them term by term
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[kk]), Bl = __builtin_bit_cast(bf16x8, bl[kk]);
+#pragma unroll
+          for (int tp = 0; tp < TPC; ++tp)
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[tp * 8 + kk]), Bh, acc[tp], 0, 0, 0);
+#pragma unroll
+          for (int tp = 0; tp < TPC; ++tp)
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[tp * 8 + kk]), Bl, acc[tp], 0, 0, 0);
+#pragma unroll
+          for (int tp = 0; tp < TPC; ++tp)
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl[tp * 8 + kk]), Bh, acc[tp], 0, 0, 0);
+#pragma unroll
+          for (int tp = 0; tp < TPC; ++tp) {
+            const int i = tp * 8 + kk;
+            int fn = f0 + i + RING;                                 // the slot's next occupant (wraps into the next step)
+            fn = fn >= F ? fn - F : fn;
+            wh[i] = Ahi[frag_index(fn)];
+            wl[i] = Alo[frag_index(fn)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int tp = 0; tp < TPC; ++tp) {
+          uint64_t* d = gw + (int64_t)((f0 >> 3) + tp) * nwc * 512 + lane * 2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint64_t v0 = (uint64_t)__float_as_uint(acc[tp][4 * j]) | ((uint64_t)__float_as_uint(acc[tp][4 * j + 1]) << 32);
+            const uint64_t v1 = (uint64_t)__float_as_uint(acc[tp][4 * j + 2]) | ((uint64_t)__float_as_uint(acc[tp][4 * j + 3]) << 32);
+            __hip_atomic_store(d + j * 128, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d + j * 128 + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      lstm_arrive(ctr, lane);
+    }
+    if (rvalid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t o = o0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
+        dG[o] = sg[0][r]; dG[o + HP] = sg[1][r]; dG[o + 2 * HP] = sg[2][r]; dG[o + 3 * HP] = sg[3][r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sg[0][r] = ng[0][r]; sg[1][r] = ng[1][r]; sg[2][r] = ng[2][r]; sg[3][r] = ng[3][r];
+      cp[r] = ncp[r]; gy[r] = ngy[r];
+    }
   }
 }
 
@@ -274,14 +487,42 @@ static int64_t lstm_pack_uint4_per_dir(int H) {
   const int64_t nf = (int64_t)(H / 32) * 4 * (H / 16) * 64, nb = (int64_t)(H / 32) * (4 * H / 16) * 64;
   return 2 * nf + 2 * nb;
 }
+static bool lstm_bad_h(int H) { return H <= 0 || H % 32 || H > 512; }
+static size_t lstm_smem_bytes(int H) { return (size_t)(H / 32) * 4096; }   // fwd: 2*nks KB, bwd: 4*nwc KB (equal)
+// co-residency bound: every wave of a launch must be on the machine at once (they wait for each other)
+static int lstm_max_clusters(int H) {
+  static int cached[17] = {0};
+  const int nwc = H / 32;
+  if (cached[nwc]) return cached[nwc];
+  int dev = 0, ncu = 0, occ_f = 0, occ_b = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_fwd_kernel<4, 0>, 64, lstm_smem_bytes(H)) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bwd_kernel<2, 0>, 64, lstm_smem_bytes(H)) != hipSuccess)
+    return 0;
+  const int occ = occ_f < occ_b ? occ_f : occ_b;
+  int waves = ncu * occ;
+  if (waves > RFX_LSTM_MAX_WAVES) waves = RFX_LSTM_MAX_WAVES;
+  cached[nwc] = (waves / nwc) & ~7;
+  return cached[nwc];
+}
+// workspace: [0,256) error flag | counters (64 B per cluster) | exchange buffers sized for the backward sweep
+static int64_t lstm_ws_ctr_off() { return 256; }
+static int64_t lstm_ws_xch_off(int H) { return 256 + (int64_t)(RFX_LSTM_MAX_WAVES / (H / 32)) * 64; }
 
 extern "C" int rfx_lstm_pack_bytes(int32_t H) {
-  if (H <= 0 || H % 32 || H > 512) return -1;
+  if (lstm_bad_h(H)) return -1;
   return (int)(lstm_pack_uint4_per_dir(H) * 16);
 }
 
+extern "C" int rfx_lstm_ws_bytes(int32_t H) {
+  if (lstm_bad_h(H)) return -1;
+  const int64_t nwc = H / 32;
+  return (int)(lstm_ws_xch_off(H) + (RFX_LSTM_MAX_WAVES / nwc) * 2 * nwc * nwc * 4096);
+}
+
 extern "C" int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stream) {
-  if (!whh || !pack || H <= 0 || H % 32 || H > 512) return -1;
+  if (!whh || !pack || lstm_bad_h(H)) return -1;
   const int64_t nf = (int64_t)(H / 32) * 4 * (H / 16) * 64;
   uint4* p = reinterpret_cast<uint4*>(pack);
   const int64_t total = lstm_pack_uint4_per_dir(H) / 2;
@@ -291,57 +532,47 @@ extern "C" int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stre
   return 0;
 }
 
+template <typename K>
+static int lstm_launch(K kernel, LstmArgs a, void* ws, void* stream) {
+  const int H = a.H, nwc = H / 32, ntiles = (a.Bn + 31) / 32, mc = lstm_max_clusters(H);
+  if (mc < 8) return -4;
+  const size_t smem = lstm_smem_bytes(H);
+  unsigned char* w = reinterpret_cast<unsigned char*>(ws);
+  a.err = reinterpret_cast<int32_t*>(w);
+  { const char* e = getenv("RFX_LSTM_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.ctr = reinterpret_cast<uint32_t*>(w + lstm_ws_ctr_off());
+  a.xch = reinterpret_cast<uint64_t*>(w + lstm_ws_xch_off(H));
+  hipStream_t s = (hipStream_t)stream;
+  for (int t0 = 0; t0 < ntiles; t0 += mc / 2) {
+    const int nt = ntiles - t0 < mc / 2 ? ntiles - t0 : mc / 2;
+    a.tile0 = t0;
+    a.nclusters = 2 * nt;
+    if (hipMemsetAsync(a.ctr, 0, (size_t)mc * 64, s) != hipSuccess) return -3;
+    const int blocks = ((a.nclusters + 7) / 8) * 8 * nwc;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), smem, s, a);
+    RFX_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 extern "C" int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_t Bn, int32_t H, float* out,
-                            float* gates, float* cstate, void* stream) {
-  if (!xp || !pack || !out || T <= 0 || Bn <= 0 || H <= 0 || H % 32 || H > 512) return -1;
+                            float* gates, float* cstate, void* ws, void* stream) {
+  if (!xp || !pack || !out || !ws || T <= 0 || Bn <= 0 || lstm_bad_h(H)) return -1;
   if ((gates == nullptr) != (cstate == nullptr)) return -1;
   if ((int64_t)4 * H * T * Bn >= ((int64_t)1 << 31)) return -1;
   LstmArgs a{};
   a.xp = xp; a.packA = reinterpret_cast<const uint4*>(pack); a.out = out; a.gates = gates; a.cstate = cstate;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
-  const size_t smem = (size_t)2 * 2 * 32 * (H + 8) * sizeof(unsigned short);
-  const dim3 grid((Bn + 31) / 32, 2), block(64 * (H / 32));
-  hipStream_t s = (hipStream_t)stream;
-#define RFX_LSTM_FWD(MAXT, XPV)                                                                                  \
-  do {                                                                                                           \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fwd_kernel<MAXT, XPV>),                           \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -3;     \
-    hipLaunchKernelGGL((lstm_fwd_kernel<MAXT, XPV>), grid, block, smem, s, a);                                   \
-  } while (0)
-  if (block.x <= 512) RFX_LSTM_FWD(512, true);
-  else if (block.x <= 768) RFX_LSTM_FWD(768, false);
-  else RFX_LSTM_FWD(1024, false);
-#undef RFX_LSTM_FWD
-  RFX_CHECK_LAUNCH();
-  return 0;
+  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0>, a, ws, stream) : lstm_launch(lstm_fwd_kernel<2, 0>, a, ws, stream);
 }
 
 extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
-                            int32_t Bn, int32_t H, float* dG, void* stream) {
-  if (!gout || !pack || !gates || !cstate || !dG || T <= 0 || Bn <= 0 || H <= 0 || H % 32 || H > 512) return -1;
+                            int32_t Bn, int32_t H, float* dG, void* ws, void* stream) {
+  if (!gout || !pack || !gates || !cstate || !dG || !ws || T <= 0 || Bn <= 0 || lstm_bad_h(H)) return -1;
   if ((int64_t)4 * H * T * Bn >= ((int64_t)1 << 31)) return -1;
   LstmArgs a{};
   a.gout = gout; a.packA = reinterpret_cast<const uint4*>(pack); a.gates = const_cast<float*>(gates);
   a.cstate = const_cast<float*>(cstate); a.dG = dG;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
-  const int rb = (size_t)2 * 32 * (4 * H + 8) * 2 <= 150 * 1024 ? 32 : 16;
-  const size_t smem = (size_t)2 * rb * (4 * H + 8) * sizeof(unsigned short);
-  hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((Bn + rb - 1) / rb, 2), block(64 * (H / 32));
-#define RFX_LSTM_BWD(RB, MAXT)                                                                                   \
-  do {                                                                                                           \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_kernel<RB, MAXT>),                            \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -3;     \
-    hipLaunchKernelGGL((lstm_bwd_kernel<RB, MAXT>), grid, block, smem, s, a);                                    \
-  } while (0)
-  if (rb == 32) {
-    if (block.x <= 512) RFX_LSTM_BWD(32, 512);
-    else RFX_LSTM_BWD(32, 1024);
-  } else {
-    if (block.x <= 768) RFX_LSTM_BWD(16, 768);
-    else RFX_LSTM_BWD(16, 1024);
-  }
-#undef RFX_LSTM_BWD
-  RFX_CHECK_LAUNCH();
-  return 0;
+  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1, 0>, a, ws, stream);
 }

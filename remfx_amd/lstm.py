@@ -33,6 +33,27 @@ def _pack_whh(w_hh, w_hh_r):
     return pack
 
 
+_WS = {}
+
+
+def _workspace(device, H):
+    """Per (device, H) scratch for the cluster exchange; byte 0..3 = sticky error flag (see error_flag)."""
+    key = (device.index, H)
+    ws = _WS.get(key)
+    if ws is None:
+        nb = _lib.lib().rfx_lstm_ws_bytes(H)
+        if nb <= 0:
+            raise ValueError(f"LSTM hidden size {H} unsupported (multiple of 32, <= 512)")
+        ws = torch.zeros(nb, device=device, dtype=torch.uint8)
+        _WS[key] = ws
+    return ws
+
+
+def error_flag():
+    """True if any recurrence launch on this process timed out in a bounded spin (results invalid)."""
+    return any(bool(ws[:4].view(torch.int32).item()) for ws in _WS.values())
+
+
 def _whh_plan(out4, g4, H, d, Bn):
     """wgrad plan for dW_hh of direction d: in = out[d*H:(d+1)*H] at time t-1 (d=0) / t+1 (d=1)."""
     xs = out4[:, d * H:(d + 1) * H]
@@ -64,7 +85,8 @@ class _LSTMLayerFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         gates = torch.empty((2, 4 * H, P), device=x.device, dtype=torch.float32) if need else None
         cst = torch.empty((2, H, P), device=x.device, dtype=torch.float32) if need else None
-        check(_lib.lib().rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), _ptr(gates), _ptr(cst), _stream()),
+        check(_lib.lib().rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), _ptr(gates), _ptr(cst),
+                                      _ptr(_workspace(x.device, H)), _stream()),
               "rfx_lstm_fwd")
         if need:
             ctx.save_for_backward(x, wcat, pack, gates, cst, out)
@@ -78,7 +100,8 @@ class _LSTMLayerFn(torch.autograd.Function):
         P = T * Bn
         g = g.contiguous()
         dG = torch.empty((1, 8 * H, 1, P), device=g.device, dtype=torch.float32)
-        check(_lib.lib().rfx_lstm_bwd(_ptr(g), _ptr(pack), _ptr(gates), _ptr(cst), T, Bn, H, _ptr(dG), _stream()),
+        check(_lib.lib().rfx_lstm_bwd(_ptr(g), _ptr(pack), _ptr(gates), _ptr(cst), T, Bn, H, _ptr(dG),
+                                      _ptr(_workspace(g.device, H)), _stream()),
               "rfx_lstm_bwd")
         x4 = x.unsqueeze(2)
         dx = None

@@ -17,12 +17,13 @@ for H, T, Bn in shapes:
     cst = torch.empty(2, H, P, device="cuda")
     dG = torch.empty(2, 4 * H, P, device="cuda")
     g = torch.randn(2 * H, P, device="cuda")
+    ws = lstm._workspace(g.device, H)
     def fwd():
-        L.rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), _ptr(gates), _ptr(cst), _stream())
+        L.rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), _ptr(gates), _ptr(cst), _ptr(ws), _stream())
     def inf():
-        L.rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), None, None, _stream())
+        L.rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), None, None, _ptr(ws), _stream())
     def bwd():
-        L.rfx_lstm_bwd(_ptr(g), _ptr(pack), _ptr(gates), _ptr(cst), T, Bn, H, _ptr(dG), _stream())
+        L.rfx_lstm_bwd(_ptr(g), _ptr(pack), _ptr(gates), _ptr(cst), T, Bn, H, _ptr(dG), _ptr(ws), _stream())
     for name, fn in (("fwd", fwd), ("inf", inf), ("bwd", bwd)):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,3 +33,13 @@ for H, T, Bn in shapes:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         print(f"H={H} T={T} Bn={Bn} {name}: {ms:.3f} ms  {1e3 * ms / T:.2f} us/step", flush=True)
+import os
+if int(os.environ.get("RFX_LSTM_DBG", "0")) & 32:
+    for H in (192, 384):
+        ws = lstm._workspace(torch.device("cuda", 0), H)
+        st = ws[64:256].view(torch.int64).cpu().view(3, 8)
+        print("H", H, "stamps (cycles since step start):")
+        for row in st:
+            print("   ", [int(v - row[0]) for v in row], " next-step gap")
+        print("    step period:", int(st[1, 0] - st[0, 0]), int(st[2, 0] - st[1, 0]))
+print("error flag:", lstm.error_flag())

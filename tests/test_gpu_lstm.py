@@ -32,6 +32,7 @@ def _run(H, Cin, T, Bn, layers, seed=0):
     assert rel(xc.grad, x.grad.permute(2, 0, 1).reshape(1, Cin, T * Bn)) < 2e-4
     for (n, p), (_, q) in zip(dev.named_parameters(), ref.named_parameters()):
         assert rel(p.grad, q.grad) < 3e-4, n
+    assert not lstm.error_flag()            # no bounded spin of the cluster exchange timed out
 
 
 @pytest.mark.parametrize("H,Cin,T,Bn,layers", [
@@ -40,6 +41,7 @@ def _run(H, Cin, T, Bn, layers, seed=0):
     (192, 192, 50, 40, 2),      # HDemucs DConv BLSTM width (layer 4)
     (384, 384, 12, 20, 1),      # HDemucs layer 5 width: 16-sequence backward tiles
     (256, 512, 9, 4, 3),        # Open-Unmix (hidden 512 -> 256 per direction, 3 layers)
+    (64, 16, 3, 8200, 1),       # more sequence tiles than one co-resident launch holds (chunked launches)
 ])
 def test_blstm_matches_torch(H, Cin, T, Bn, layers):
     _run(H, Cin, T, Bn, layers)
