@@ -175,11 +175,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   uint32_t* ctr = a.ctr + cluster * 16;
   const uint32_t uP = (uint32_t)P, HP = (uint32_t)H * uP;
   const uint32_t ubase = (uint32_t)(32 * ub + 4 * hh) * uP + (uint32_t)rowc;   // + ((r&3) + 8(r>>2)) * P + t*Bn
+  const uint32_t lane16 = (uint32_t)lane * 16u;
   auto loadA = [&](LstmAFrag& f, int ks) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f.h[g] = Ahi[(g * nks + ks) * 64 + lane];
-      f.l[g] = Alo[(g * nks + ks) * 64 + lane];
+      // wave-uniform base + zero-extended lane offset -> scalar-base addressing (no per-fragment 64-bit VGPR address)
+      f.h[g] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Ahi + (g * nks + ks) * 64) + lane16);
+      f.l[g] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Alo + (g * nks + ks) * 64) + lane16);
     }
   };
   auto loadB = [&](bf16x8& bh, bf16x8& bl, int ks) {
