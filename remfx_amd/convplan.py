@@ -80,9 +80,9 @@ class GemmPlan:
         Kall = kt.shape[0]
         self.K = Kall
         self.Kpad = -(-Kall // 16) * 16
-        # + 2 extra all-invalid K steps: the MFMA kernel prefetches table rows of step
-        # ks+2 and gathers of step ks+1 unconditionally (branch-free main loop)
-        pad = np.zeros((self.Kpad + 32 - Kall, 4), dtype=np.int64)
+        # + 6 extra all-invalid K steps: the MFMA kernel prefetches table rows of step
+        # ks+4 and gathers of step ks+3 unconditionally (branch-free main loop)
+        pad = np.zeros((self.Kpad + 96 - Kall, 4), dtype=np.int64)
         pad[:, 1] = INVALID_DA
         kt = np.concatenate([kt, pad], 0)
         assert np.abs(kt[:, 0]).max(initial=0) < 2 ** 31

@@ -34,7 +34,7 @@ struct FwdArgs {
 __global__ void pack_a_kernel(const float* __restrict__ w, const int32_t* __restrict__ woff,
                               int64_t w_ms, int M, int K, int Mpad, int Kpad,
                               float* __restrict__ apack) {
-  const int64_t total = (int64_t)(Kpad + 16) * Mpad;   // one extra all-zero K step (branch-free prefetch)
+  const int64_t total = (int64_t)(Kpad + 32) * Mpad;   // two extra all-zero K steps (branch-free prefetch)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(i / Mpad), m = (int)(i % Mpad);
@@ -51,11 +51,11 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-// bf16x3 operand layout: two arrays (hi, lo) of [Kpad/8 + 2][Mpad] 16-byte cells, a cell = the 8
+// bf16x3 operand layout: two arrays (hi, lo) of [Kpad/8 + 4][Mpad] 16-byte cells, a cell = the 8
 // consecutive-k bf16 values of one output row = exactly one lane's MFMA A fragment.
 __global__ void pack_a_bf3_kernel(const float* __restrict__ w, const int32_t* __restrict__ woff,
                                   int64_t w_ms, int M, int K, int Mpad, int Kpad, uint4* __restrict__ apack) {
-  const int64_t cells = (int64_t)(Kpad / 8 + 2) * Mpad;
+  const int64_t cells = (int64_t)(Kpad / 8 + 4) * Mpad;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int k8 = (int)(i / Mpad), m = (int)(i % Mpad);
@@ -143,8 +143,11 @@ __device__ __forceinline__ void stage_a_store(float* as, int tid, const f32x4 (&
   constexpr int NV = 16 * BM / 4;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int idx = tid + i * 256;
-    if (i * 256 < NV && idx < NV) {
+    if (i * 256 < NV) {            // compile-time
+      // UNCONDITIONAL store (surplus threads rewrite the last vector with the same data): a store under a
+      // lane condition lets LLVM sink the global load into that branch, right in front of a vmcnt(0)
+      int idx = tid + i * 256;
+      idx = idx < NV ? idx : NV - 1;
       const int kk = idx / (BM / 4), c4 = idx % (BM / 4);
       *reinterpret_cast<f32x4*>(as + kk * BM + 4 * c4) = r[i];
     }
@@ -174,10 +177,10 @@ __device__ __forceinline__ void k_step(const rfx_gemm_desc& d, const float* __re
   for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
     for (int mt = 0; mt < R; ++mt) afrag[kk][mt] = a_lds[(2 * kk + h) * BM + mt * 32 + l31];
+  const int4 ktreg = kt4[(ks + 2) * 16 + (tid & 15)];     // consumed this step: issued before the gathers (in-order vmcnt)
   f32x4 areg[2];
   stage_a_load<R>(apack, d.Mpad, (ks + 1) * 16, m0, tid, areg);
   load_b8(d, kts + ((ks + 1) % 3) * 16, h, c, bn);
-  const int4 ktreg = kt4[(ks + 2) * 16 + (tid & 15)];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
 #pragma unroll
@@ -185,7 +188,7 @@ __device__ __forceinline__ void k_step(const rfx_gemm_desc& d, const float* __re
       acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[kk][mt], bc[kk], acc[mt], 0, 0, 0);
   }
   stage_a_store<R>(as + (cur ^ 1) * 16 * BM, tid, areg);
-  if (tid < 16) kts[((ks + 2) % 3) * 16 + tid] = ktreg;
+  kts[((ks + 2) % 3) * 16 + (tid & 15)] = ktreg;      // every thread (same value per tid & 15): no lane condition
   __syncthreads();
 }
 
@@ -215,6 +218,7 @@ __device__ __forceinline__ void run_phase(const rfx_gemm_desc& d, const float* _
 }
 
 // ---------------------------------------------------------------------------------
+#define RFX_BDIST 3   // gather look-ahead in K steps (ktab ring: 8 slots; tables are padded by 96 rows)
 // bf16x3 variant of the K loop: every fp32 operand is split x = hi + lo (two bf16) and
 // a.b ~= hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): ~2^-16
 // relative error per product instead of 2^-24, at 3/16 of the fp32-MFMA issue cost.
@@ -252,36 +256,41 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
   lo = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
 }
 
+// A stage of the bf16x3 path: (hi, lo) x 2 k8 rows x BM cells = 4*BM 16-byte cells per K step, one or two per thread.
+// Plain scalars (not arrays) so the two in-flight stages of the software pipeline stay in registers.
+struct AStage { uint4 v0, v1; };
 template <int R>
-__device__ __forceinline__ void stage_a_bf3_load(const uint4* __restrict__ apk, int64_t arr_stride, int Mpad,
-                                                 int k8_0, int m0, int tid, uint4 (&r)[2]) {
-  constexpr int BM = 32 * R, NV = 4 * BM;   // (hi, lo) x 2 k8 rows x BM cells
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (i * 256 < NV) {
-      int idx = tid + i * 256;
-      idx = idx < NV ? idx : NV - 1;
-      const int arr = idx / (2 * BM), rem = idx % (2 * BM);
-      const int kk8 = rem / BM, mm = rem % BM;
-      r[i] = apk[arr * arr_stride + (int64_t)(k8_0 + kk8) * Mpad + m0 + mm];
-    }
-  }
+__device__ __forceinline__ uint4 stage_a_bf3_cell(const uint4* __restrict__ apk, int64_t arr_stride, int Mpad,
+                                                  int k8_0, int m0, int idx) {
+  constexpr int BM = 32 * R, NV = 4 * BM;
+  idx = idx < NV ? idx : NV - 1;
+  const int arr = idx / (2 * BM), rem = idx % (2 * BM);
+  const int kk8 = rem / BM, mm = rem % BM;
+  return apk[arr * arr_stride + (int64_t)(k8_0 + kk8) * Mpad + m0 + mm];
 }
 template <int R>
-__device__ __forceinline__ void stage_a_bf3_store(uint4* as, int tid, const uint4 (&r)[2]) {
-  constexpr int BM = 32 * R, NV = 4 * BM;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = tid + i * 256;
-    if (i * 256 < NV && idx < NV) as[idx] = r[i];
-  }
+__device__ __forceinline__ AStage stage_a_bf3_load(const uint4* __restrict__ apk, int64_t arr_stride, int Mpad,
+                                                   int k8_0, int m0, int tid) {
+  constexpr int NV = 128 * R;
+  AStage s;
+  s.v0 = stage_a_bf3_cell<R>(apk, arr_stride, Mpad, k8_0, m0, tid);
+  s.v1 = NV > 256 ? stage_a_bf3_cell<R>(apk, arr_stride, Mpad, k8_0, m0, tid + 256) : s.v0;
+  return s;
+}
+template <int R>
+__device__ __forceinline__ void stage_a_bf3_store(uint4* as, int tid, const AStage& s) {
+  constexpr int NV = 128 * R;
+  // UNCONDITIONAL stores (surplus threads rewrite the last cell with the same data), see stage_a_store
+  as[tid < NV ? tid : NV - 1] = s.v0;
+  if (NV > 256) as[tid + 256 < NV ? tid + 256 : NV - 1] = s.v1;
 }
 
 template <int R>
 __device__ __forceinline__ void k_step_bf3(const rfx_gemm_desc& d, const uint4* __restrict__ apk,
                                            int64_t arr_stride, const int4* __restrict__ kt4, int ks, int m0,
                                            const LaneCtx& c, uint4* as, int4* kts, f32x16 (&acc)[R],
-                                           const float (&bc)[8], float (&bn)[8]) {
+                                           const float (&bc)[8], float (&bn)[8], const AStage& a_now,
+                                           AStage& a_next) {
   constexpr int BM = 32 * R;
   const int tid = threadIdx.x;
   const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -293,10 +302,13 @@ __device__ __forceinline__ void k_step_bf3(const rfx_gemm_desc& d, const uint4* 
     ah[mt] = a_lds[h * BM + mt * 32 + l31];
     al[mt] = a_lds[2 * BM + h * BM + mt * 32 + l31];
   }
-  uint4 areg[2];
-  stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2 * (ks + 1), m0, tid, areg);
-  load_b8_bf3(d, kts + ((ks + 1) % 3) * 16, h, c, bn);
-  const int4 ktreg = kt4[(ks + 2) * 16 + (tid & 15)];
+  // issue order matters: vmcnt retires in order and the table row + A stage are consumed (written to LDS) at
+  // the end of THIS step, so they go first; the gathers, consumed RFX_BDIST steps later, go last and stay in flight
+  const int4 ktreg = kt4[(ks + RFX_BDIST + 1) * 16 + (tid & 15)];
+  // A tile of step ks+2 -> registers now, into LDS at the end of step ks+1 (a_now was fetched one step ago): an L2
+  // round trip is longer than one K step of MFMAs
+  a_next = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2 * (ks + 2), m0, tid);
+  load_b8_bf3(d, kts + ((ks + RFX_BDIST) & 7) * 16, h, c, bn);
   bf16x8 bh, bl;
   split8(bc, bh, bl);
 #pragma unroll
@@ -306,8 +318,8 @@ __device__ __forceinline__ void k_step_bf3(const rfx_gemm_desc& d, const uint4* 
     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl, acc[mt], 0, 0, 0);
     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc[mt], 0, 0, 0);
   }
-  stage_a_bf3_store<R>(as + (cur ^ 1) * 4 * BM, tid, areg);
-  if (tid < 16) kts[((ks + 2) % 3) * 16 + tid] = ktreg;
+  stage_a_bf3_store<R>(as + (cur ^ 1) * 4 * BM, tid, a_now);
+  kts[((ks + RFX_BDIST + 1) & 7) * 16 + (tid & 15)] = ktreg;   // every thread (same value per tid & 15)
   __syncthreads();
 }
 
@@ -320,29 +332,40 @@ __device__ __forceinline__ void run_phase_bf3(const rfx_gemm_desc& d, const floa
   const int nk = Kpad / 16;
   if (nk == 0) return;
   const uint4* apk = reinterpret_cast<const uint4*>(apack);
-  const int64_t arr_stride = (int64_t)(Kpad / 8 + 2) * d.Mpad;
+  const int64_t arr_stride = (int64_t)(Kpad / 8 + 4) * d.Mpad;
   uint4* as = reinterpret_cast<uint4*>(as_f);
   const int4* kt4 = reinterpret_cast<const int4*>(ktab);
   float b0[8], b1[8];
-  uint4 areg[2];
-  stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 0, m0, tid, areg);
-  if (tid < 32) kts[tid] = kt4[tid];
+  const AStage areg = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 0, m0, tid);
+  if (tid < 16 * (RFX_BDIST + 1)) kts[tid] = kt4[tid];   // table rows of the first K steps (table is padded)
   stage_a_bf3_store<R>(as, tid, areg);
   __syncthreads();
+  // the gathers run RFX_BDIST K steps ahead of the MFMAs: one K step is ~0.2 us of matrix work, a gather that
+  // misses L2 takes ~1-2 us, and only two waves share a SIMD, so a single step of look-ahead left the kernel
+  // latency-bound (19 % MFMA utilisation in the r01 traces)
+  float b2[8], b3[8];
+  AStage a1;
+  AStage a0 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2, m0, tid);          // A tile of step 1
   load_b8_bf3(d, kts, h, c, b0);
+  load_b8_bf3(d, kts + 16, h, c, b1);
+  load_b8_bf3(d, kts + 32, h, c, b2);
   int ks = 0;
-  for (; ks + 1 < nk; ks += 2) {
-    k_step_bf3<R>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b1);
-    k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0);
+  for (; ks + 3 < nk; ks += 4) {
+    k_step_bf3<R>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b3, a0, a1);
+    k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0, a1, a0);
+    k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 2, m0, c, as, kts, acc, b2, b1, a0, a1);
+    k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 3, m0, c, as, kts, acc, b3, b2, a1, a0);
   }
-  if (ks < nk) k_step_bf3<R>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b1);
+  if (ks < nk) k_step_bf3<R>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b3, a0, a1);
+  if (ks + 1 < nk) k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0, a1, a0);
+  if (ks + 2 < nk) k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 2, m0, c, as, kts, acc, b2, b1, a0, a1);
 }
 
 template <int R, bool BF3>
 __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R;
   __shared__ __attribute__((aligned(16))) float as[2 * 16 * BM];
-  __shared__ __attribute__((aligned(16))) int4 kts[3 * 16];
+  __shared__ __attribute__((aligned(16))) int4 kts[8 * 16];
   const rfx_gemm_desc& d = g.d;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -834,14 +857,14 @@ extern "C" int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int
                           int32_t Mpad, int32_t Kpad, int32_t prec, float* apack, void* stream) {
   if (!w || !woff || !apack || M <= 0 || K < 0 || Mpad < M || Kpad < K) return -1;
   if (prec == 1) {
-    const int64_t cells = (int64_t)(Kpad / 8 + 2) * Mpad;
+    const int64_t cells = (int64_t)(Kpad / 8 + 4) * Mpad;
     const int grid = (int)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_a_bf3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, woff, w_ms, M, K, Mpad,
                        Kpad, reinterpret_cast<uint4*>(apack));
     RFX_CHECK_LAUNCH();
     return 0;
   }
-  const int64_t total = (int64_t)(Kpad + 16) * Mpad;
+  const int64_t total = (int64_t)(Kpad + 32) * Mpad;
   if (total == 0) return 0;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_a_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, woff, w_ms, M, K,
