@@ -13,6 +13,8 @@
 //     uniform and read through the scalar cache.
 // Replaces F.conv1d/conv2d/conv_transpose1d/2d call sites: tcn.py:50,54,129;
 // HDemucs / DCUNet / Cnn14 stacks (models.py:319,358; classifier.py:271-272).
+#include <stdlib.h>
+
 #include "common.h"
 
 struct FwdArgs {
@@ -242,15 +244,19 @@ __device__ __forceinline__ void load_b8_bf3(const rfx_gemm_desc& d, const int4* 
   }
 }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// x = hi + lo with hi = RNE_bf16(x), lo = RNE_bf16(x - hi): v_cvt_pk_bf16_f32 does two values per instruction and
+// the residual is one packed subtract -> 5 VALU per pair (the mask / shift / add sequence it replaces took 13)
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
   uint32_t hw[4], lw[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const uint32_t u0 = __float_as_uint(x[2 * q]), u1 = __float_as_uint(x[2 * q + 1]);
-    const uint32_t h0 = u0 & 0xffff0000u, h1 = u1 & 0xffff0000u;
-    const float r0 = x[2 * q] - __uint_as_float(h0), r1 = x[2 * q + 1] - __uint_as_float(h1);
-    hw[q] = (u0 >> 16) | h1;
-    lw[q] = ((__float_as_uint(r0) + 0x8000u) >> 16) | ((__float_as_uint(r1) + 0x8000u) & 0xffff0000u);
+    const f32x2_t v = {x[2 * q], x[2 * q + 1]};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    hw[q] = h;
+    lw[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, bf16x2_t));
   }
   hi = __builtin_bit_cast(bf16x8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
   lo = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
@@ -580,6 +586,7 @@ struct WgradArgs {
   int total_tiles;       // N * tiles_per_sample
   int tiles_per_block;
   int kt, mt, splits;
+  int xcd_grouped;       // 1: 1-D grid, all (k, m) tiles of one position split share an XCD (ids congruent mod 8)
 };
 
 template <int TM, int TK>
@@ -700,9 +707,18 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) 
   const int wm = wave >> 1, wk = wave & 1;
   // plain order (k tile fastest).  An XCD-grouped order (all tiles of one position split on one XCD) was
   // measured SLOWER (132 -> 116 TF/s-eq at the TCN shape): the splits are too few / too coarse to balance.
-  const int zsplit = blockIdx.z;
-  const int m0 = blockIdx.y * RM;
-  const int k0 = blockIdx.x * RK;
+  int zsplit = blockIdx.z, ym = blockIdx.y, xk = blockIdx.x;
+  if (w.xcd_grouped) {
+    // every (k, m) tile of a position split re-reads the same g rows / input samples: keep them behind ONE L2
+    const int nb = w.kt * w.mt, q = blockIdx.x >> 3;
+    zsplit = (q / nb) * 8 + (blockIdx.x & 7);
+    if (zsplit >= w.splits) return;
+    const int r = q % nb;
+    ym = r / w.kt;
+    xk = r - ym * w.kt;
+  }
+  const int m0 = ym * RM;
+  const int k0 = xk * RK;
   const int P = d.OA * d.OB;
   for (int i = tid; i < RK; i += 256) {
     rfx_ktab_entry e;
@@ -750,10 +766,11 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) 
     }
   };
   auto put = [&](unsigned short* hi, unsigned short* lo, int row, float v) {
-    const uint32_t u = __float_as_uint(v);
-    const float r = v - __uint_as_float(u & 0xffff0000u);
-    hi[row * LDW + pl] = (unsigned short)(u >> 16);
-    lo[row * LDW + pl] = (unsigned short)((__float_as_uint(r) + 0x8000u) >> 16);
+    const __bf16 h = (__bf16)v;                                   // v_cvt_pk_bf16_f32 (RNE)
+    const unsigned short hb = __builtin_bit_cast(unsigned short, h);
+    const __bf16 l = (__bf16)(v - __uint_as_float((uint32_t)hb << 16));
+    hi[row * LDW + pl] = hb;
+    lo[row * LDW + pl] = __builtin_bit_cast(unsigned short, l);
   };
   if (t_begin < t_end) load_tile(t_begin);
   for (int t = t_begin; t < t_end; ++t) {
@@ -987,7 +1004,13 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   splits = (w.total_tiles + w.tiles_per_block - 1) / w.tiles_per_block;
   w.kt = kt; w.mt = mt; w.splits = splits;
   dim3 grid(kt, mt, splits);
+  w.xcd_grouped = 0;
   if (prec == 1) {
+    static const int xcd_mode = getenv("RFX_WGRAD_XCD") ? atoi(getenv("RFX_WGRAD_XCD")) : 0;   // measured on Demucs B=64: 408.0 ms off, 411.8 ms on
+    if (xcd_mode > 0 && splits >= xcd_mode) {
+      w.xcd_grouped = 1;
+      grid = dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1);
+    }
     if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 2>), grid, dim3(256), 0, s, w);
     else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 1>), grid, dim3(256), 0, s, w);
     else if (tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2>), grid, dim3(256), 0, s, w);
