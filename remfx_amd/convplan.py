@@ -86,6 +86,11 @@ class GemmPlan:
         pad[:, 1] = INVALID_DA
         kt = np.concatenate([kt, pad], 0)
         assert np.abs(kt[:, 0]).max(initial=0) < 2 ** 31
+        # the bf16x3 kernels address one sample through a 32-bit byte offset (raw buffer loads, 2 GiB window)
+        reach = (int(kt[:K, 0].max(initial=0)) + (self.IA - 1) * abs(int(self.in_as))
+                 + (self.IB - 1) * abs(int(self.in_bs)))
+        if reach * 4 >= 2 ** 31:
+            raise ValueError("gather-GEMM: one sample of the input operand must span < 2 GiB")
         self.ktab = kt.astype(np.int32)
         self.R = pick_r(self.M, K)
         self.Mpad = mpad_for(self.M, K)

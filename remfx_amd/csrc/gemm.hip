@@ -97,7 +97,16 @@ struct LaneCtx {
   const float* safe; // always-valid address
   int ia0, ib0;
   bool jvalid;
+  // bf16x3 path: gathers are raw buffer loads relative to the sample base; an out-of-range offset makes the
+  // hardware return 0 without touching memory, so masking costs one 32-bit select instead of a 64-bit pointer select
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t voff;     // byte offset of this lane's position inside the sample
 };
+#define RFX_BUF_OOB 0x80000000u       // > num_records (0x7fffffff): reads as 0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rfx_sample_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+}
 
 // A zero the invalid lanes can load instead of masking the loaded value: any VALU op
 // on the result forces s_waitcnt vmcnt(0) right after the load and exposes the full
@@ -238,8 +247,8 @@ __device__ __forceinline__ void load_b8_bf3(const rfx_gemm_desc& d, const int4* 
     for (int q = 0; q < 4; ++q) {
       const bool ok = c.jvalid & ((unsigned)(c.ia0 + e[q].y) < (unsigned)d.IA) &
                       ((unsigned)(c.ib0 + e[q].z) < (unsigned)d.IB);
-      const float* p = ok ? (c.inb + e[q].x) : c.safe;
-      b[half * 4 + q] = *p;
+      const uint32_t off = ok ? c.voff + ((uint32_t)e[q].x << 2) : RFX_BUF_OOB;
+      b[half * 4 + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, off, 0, 0));
     }
   }
 }
@@ -394,6 +403,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
   c.ib0 = b * d.SB;
   c.safe = rfx_zero_f32;
   c.inb = g.in + (int64_t)n * d.in_ns + (int64_t)c.ia0 * d.in_as + (int64_t)c.ib0 * d.in_bs;
+  c.rs = rfx_sample_rsrc(g.in + (int64_t)n * d.in_ns);
+  c.voff = (uint32_t)(((int64_t)c.ia0 * d.in_as + (int64_t)c.ib0 * d.in_bs) * 4);
 
   f32x16 acc[R];
 #pragma unroll
@@ -427,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
     LaneCtx c2 = c;
     if (g.in2) {
       c2.inb = g.in2 + (c.inb - g.in);
+      c2.rs = rfx_sample_rsrc(g.in2 + (int64_t)n * d.in_ns);
     }
     if (BF3) run_phase_bf3<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
     else run_phase<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
