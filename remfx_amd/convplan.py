@@ -89,7 +89,9 @@ class GemmPlan:
         # the bf16x3 kernels address one sample through a 32-bit byte offset (raw buffer loads, 2 GiB window)
         reach = (int(kt[:K, 0].max(initial=0)) + (self.IA - 1) * abs(int(self.in_as))
                  + (self.IB - 1) * abs(int(self.in_bs)))
-        if reach * 4 >= 2 ** 31:
+        oreach = ((self.M - 1) * abs(int(self.out_cs)) + (self.OA - 1) * max(self.out_sa, 1) * abs(int(self.out_as))
+                  + (self.OB - 1) * max(self.out_sb, 1) * abs(int(self.out_bs)))
+        if reach * 4 >= 2 ** 31 or oreach * 4 >= 2 ** 31:
             raise ValueError("gather-GEMM: one sample of the input operand must span < 2 GiB")
         self.ktab = kt.astype(np.int32)
         self.R = pick_r(self.M, K)

@@ -749,32 +749,37 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) 
   const int t_begin = zsplit * w.tiles_per_block;
   const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
   const int prow = tid >> 5, pl = tid & 31;
-  float gv[RM / 8], xv[RK / 8];
-  auto load_tile = [&](int t) {
-    const int n = t / w.tiles_per_sample;
+  // operands of one position tile in flight: raw buffer loads relative to the sample bases (an out-of-range offset
+  // reads 0 in hardware: no pointer selects, no branches); the bias ("ones") row is added at staging time
+  struct Stage { float gv[RM / 8], xv[RK / 8]; float jv; };
+  float onesf[RK / 8];
+#pragma unroll
+  for (int i = 0; i < RK / 8; ++i) onesf[i] = (kts[prow + 8 * i].flags & 1) ? 1.f : 0.f;
+  auto load_tile = [&](int t, Stage& st) {
+    const int n = t / w.tiles_per_sample;                       // wave-uniform
     const int j = (t - n * w.tiles_per_sample) * 32 + pl;
     const bool jvalid = j < P;
     const int jj = jvalid ? j : 0;
     const int a = jj / d.OB, b = jj - a * d.OB;
     const int ia0 = a * d.SA, ib0 = b * d.SB;
-    const float* inb = w.in + (int64_t)n * d.in_ns + (int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs;
-    const float* gb = w.g + (int64_t)n * d.out_ns + (int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
-                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
+    const __amdgpu_buffer_rsrc_t irs = rfx_sample_rsrc(w.in + (int64_t)n * d.in_ns);
+    const __amdgpu_buffer_rsrc_t grs = rfx_sample_rsrc(w.g + (int64_t)n * d.out_ns);
+    const uint32_t voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * 4);
+    const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
+                                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs + (int64_t)(m0 + prow) * d.out_cs) * 4);
+    const uint32_t gstep = (uint32_t)(8 * d.out_cs * 4);
+    st.jv = jvalid ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < RM / 8; ++i) {
-      const int m = m0 + prow + 8 * i;
-      const bool ok = jvalid & (m < d.M);
-      const float* p = ok ? gb + (int64_t)m * d.out_cs : rfx_zero_f32;
-      gv[i] = *p;
+      const bool ok = jvalid & (m0 + prow + 8 * i < d.M);
+      st.gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < RK / 8; ++i) {
       const rfx_ktab_entry e = kts[prow + 8 * i];
-      const bool ones = e.flags & 1;
-      const bool ok = jvalid & !ones & ((unsigned)(ia0 + e.da) < (unsigned)d.IA) &
-                      ((unsigned)(ib0 + e.db) < (unsigned)d.IB);
-      const float* p = ok ? inb + e.off : ((ones & jvalid) ? rfx_one_f32 : rfx_zero_f32);
-      xv[i] = *p;
+      const bool ok = jvalid & !(e.flags & 1) & ((unsigned)(ia0 + e.da) < (unsigned)d.IA) &
+                      ((unsigned)(ib0 + e.db) < (unsigned)d.IB);     // the bias row loads nothing: it is onesf * jv
+      st.xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, ok ? voff + ((uint32_t)e.off << 2) : RFX_BUF_OOB, 0, 0));
     }
   };
   auto put = [&](unsigned short* hi, unsigned short* lo, int row, float v) {
@@ -784,15 +789,13 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) 
     hi[row * LDW + pl] = hb;
     lo[row * LDW + pl] = __builtin_bit_cast(unsigned short, l);
   };
-  if (t_begin < t_end) load_tile(t_begin);
-  for (int t = t_begin; t < t_end; ++t) {
-    __syncthreads();
+  auto stage = [&](const Stage& st) {
 #pragma unroll
-    for (int i = 0; i < RM / 8; ++i) put(gs_hi, gs_lo, prow + 8 * i, gv[i]);
+    for (int i = 0; i < RM / 8; ++i) put(gs_hi, gs_lo, prow + 8 * i, st.gv[i]);
 #pragma unroll
-    for (int i = 0; i < RK / 8; ++i) put(xs_hi, xs_lo, prow + 8 * i, xv[i]);
-    __syncthreads();
-    load_tile(t + 1 < t_end ? t + 1 : t);
+    for (int i = 0; i < RK / 8; ++i) put(xs_hi, xs_lo, prow + 8 * i, st.xv[i] + onesf[i] * st.jv);
+  };
+  auto mma_tile = [&]() {
 #pragma unroll
     for (int ks2 = 0; ks2 < 2; ++ks2) {
       bf16x8 ah[TM], al[TM], bh[TK], bl[TK];
@@ -816,6 +819,28 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) 
           acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tk], acc[tm][tk], 0, 0, 0);
           acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tk], acc[tm][tk], 0, 0, 0);
         }
+    }
+  };
+  // two tiles of operands in flight: the loads of tile t+2 are issued before the MFMAs of tile t, so an HBM round
+  // trip (~1-2 us) is covered by two tiles of matrix work instead of one (the r01 version waited at every tile)
+  Stage s0, s1;
+  const int t_last = t_end - 1;
+  if (t_begin < t_end) {
+    load_tile(t_begin, s0);
+    load_tile(min(t_begin + 1, t_last), s1);
+  }
+  for (int t = t_begin; t < t_end; t += 2) {
+    __syncthreads();
+    stage(s0);
+    __syncthreads();
+    load_tile(min(t + 2, t_last), s0);
+    mma_tile();
+    if (t + 1 < t_end) {                       // block-uniform
+      __syncthreads();
+      stage(s1);
+      __syncthreads();
+      load_tile(min(t + 3, t_last), s1);
+      mma_tile();
     }
   }
 #pragma unroll
