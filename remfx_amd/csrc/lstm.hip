@@ -21,8 +21,6 @@
 //     chunked over launches), and every spin is bounded: on time-out the wave raises the error flag and exits.
 //   Workgroup ids are laid out so that the waves of a cluster are congruent mod 8, i.e. on one XCD / one L2 when
 //   the dispatcher round-robins (performance only; correctness relies on agent scope, not on placement).
-#include <stdlib.h>
-
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -92,7 +90,6 @@ struct LstmArgs {
   int64_t pack_stride;
   int T, Bn, H, P;
   int tile0, nclusters;
-  int dbg;              // timing experiments only (RFX_LSTM_DBG): 1 no wait, 2 no MFMA, 4 no publish, 8 no saves, 16 no fetch
 };
 
 __device__ __forceinline__ bool lstm_wait(const uint32_t* ctr, uint32_t target) {
@@ -149,17 +146,17 @@ __device__ __forceinline__ void lstm_fetch_lds(const uint64_t* src, int n, int l
 // holds units du = (r&3) + 8(r>>2) + 4hh, i.e. for r = 8*ksl + 4*hhB + e: k-step 2ub+ksl, lane l31+32hhB, half hh.
 // D = depth of the weight-fragment ring in k-steps (each k-step = 4 gates x (hi, lo) = 8 KB per wave): the L2 round trip
 // (~0.5 us) is covered only if ~4 k-steps (0.64 us of MFMA work) are in flight; D = 2 when H is not a multiple of 64.
-// NKS = H/16 at compile time (0: runtime).  Only the runtime form is instantiated: hipcc drains vmcnt(0) at the k-loop
-// header (55 instead of 32 cycles per MFMA, in-kernel stamps), but the fully unrolled form hoists ~100 fragment addresses
-// out of the time loop and spills; see DESIGN.md for the remaining head-room.
-template <int D, int NKS>
+// The k loop keeps its runtime trip count: hipcc drains vmcnt(0) at its header (55 instead of 32 cycles per MFMA, in-kernel
+// s_memtime stamps), but a fully unrolled form (H as a template parameter) hoists ~100 fragment addresses out of the time
+// loop and spills; see DESIGN.md section 4.4 for the remaining head-room.
+template <int D>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_kernel(const LstmArgs a) {
   int cluster, ub;
   if (!lstm_ids(a, cluster, ub)) return;
   const int H = a.H, Bn = a.Bn, T = a.T, P = a.P;
   const int dir = cluster & 1, row0 = (a.tile0 + (cluster >> 1)) * 32;
   const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
-  const int nks = NKS ? NKS : H / 16, nwc = nks / 2;
+  const int nks = H / 16, nwc = H / 32;
   const int row = row0 + l31;
   const bool rvalid = row < Bn;
   const int rowc = rvalid ? row : 0;      // idle lanes read sequence 0 and never store: every load stays unconditional
@@ -216,23 +213,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
       for (int r = 0; r < 16; ++r) xpv[g][r] = xp[o0 + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
   }
-  uint64_t* stamp = reinterpret_cast<uint64_t*>(a.err) + 8;        // RFX_LSTM_DBG & 32: 3 steps x 8 time stamps
-  const bool stamping = (a.dbg & 32) && cluster == 0 && ub == 0 && lane == 0;
-#define LSTM_STAMP(k) do { if (stamping && s >= 100 && s < 103) stamp[(s - 100) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
   for (int s = 0; s < T; ++s) {
     const int t = dir == 0 ? s : T - 1 - s;
     const uint32_t o0 = ubase + (uint32_t)(t * Bn);
-    LSTM_STAMP(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
     if (s > 0) {
-      if (!(a.dbg & 1) && !lstm_wait(ctr, (uint32_t)(nwc * s))) { *a.err = 1; return; }
-      LSTM_STAMP(1);
-      if (!(a.dbg & 16)) lstm_fetch_lds(xch + ((s - 1) & 1) * bufw, 2 * nks, lane);
+      if (!lstm_wait(ctr, (uint32_t)(nwc * s))) { *a.err = 1; return; }
+      lstm_fetch_lds(xch + ((s - 1) & 1) * bufw, 2 * nks, lane);
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): visible to the compiler's wait-count bookkeeping, unlike inline asm
-      LSTM_STAMP(2);
     }
     {
       const int tn = s + 1 < T ? (dir == 0 ? s + 1 : T - 2 - s) : t;     // clamped on the last step (harmless re-read)
@@ -242,12 +233,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int r = 0; r < 16; ++r) xpn[g][r] = xp[on + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
     }
-    LSTM_STAMP(3);
-    if (s > 0 && !(a.dbg & 2)) {
+    if (s > 0) {
       bf16x8 bh[2], bl[2];
       loadB(bh[0], bl[0], 0);
-#pragma unroll
-      for (int ks = 0; ks < (NKS ? NKS : nks); ks += D) {          // nks % D == 0, D even
+      for (int ks = 0; ks < nks; ks += D) {          // nks % D == 0, D even
 #pragma unroll
         for (int d = 0; d < D; ++d) {
           const int k1 = ks + d + 1 == nks ? 0 : ks + d + 1;       // h fragments one k-step ahead (LDS latency)
@@ -259,8 +248,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
       }
     }
-    asm volatile("s_nop 0" ::: "memory");
-    LSTM_STAMP(4);
     uint64_t* hw = xch + (s & 1) * bufw;
     float hv[16];
 #pragma unroll
@@ -271,8 +258,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       hv[r] = og * lstm_tanh(c[r]);
       acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og;
     }
-    LSTM_STAMP(5);
-    if (s + 1 < T && !(a.dbg & 4)) {                  // publish h_t first: it is the cluster's critical path
+    if (s + 1 < T) {                  // publish h_t first: it is the cluster's critical path
 #pragma unroll
       for (int ksl = 0; ksl < 2; ++ksl)
 #pragma unroll
@@ -283,8 +269,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
       lstm_arrive(ctr, lane);
     }
-    LSTM_STAMP(6);
-    if (rvalid && !(a.dbg & 8)) {
+    if (rvalid) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t o = o0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
@@ -295,13 +280,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
       }
     }
-    LSTM_STAMP(7);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) xpv[g][r] = xpn[g][r];
   }
-#undef LSTM_STAMP
 }
 
 // Backward through time.  A wave multiplies ITS gate-gradient slice (K = 4 x 32 rows of W_hh) into partial
@@ -310,14 +293,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // consumer's slice is H/32 x 4 KB, contiguous, fetched straight into LDS.
 // TPC = unit-block tiles per ring refill round: the weight ring holds 8*TPC k-step fragments (hi, lo); 16 in flight
 // cover the L2 round trip (3 MFMAs per fragment), so TPC = 2 whenever H/32 is even.
-template <int TPC, int NWC>
+template <int TPC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(const LstmArgs a) {
   int cluster, ub;
   if (!lstm_ids(a, cluster, ub)) return;
   const int H = a.H, Bn = a.Bn, T = a.T, P = a.P;
   const int dir = cluster & 1, row0 = (a.tile0 + (cluster >> 1)) * 32;
   const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
-  const int nwc = NWC ? NWC : H / 32, nks = 2 * nwc, nks4 = 4 * nks;
+  const int nwc = H / 32, nks = 2 * nwc, nks4 = 4 * nks;
   const int row = row0 + l31;
   const bool rvalid = row < Bn;
   const int rowc = rvalid ? row : 0;
@@ -426,8 +409,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           bl[2 * g + ksl] = hh ? make_uint4(rl[0], rl[1], x1l[0], x1l[1]) : make_uint4(x0l[0], x0l[1], rl[0], rl[1]);
         }
       uint64_t* gw = xch + (step & 1) * bufw + ub * 512;            // + ot * nwc * 512 (consumer ot, producer ub)
-#pragma unroll
-      for (int f0 = 0; f0 < (NWC ? 8 * NWC : F); f0 += RING) {
+      for (int f0 = 0; f0 < F; f0 += RING) {
         f32x16 acc[TPC];
 #pragma unroll
         for (int tp = 0; tp < TPC; ++tp)
@@ -499,8 +481,8 @@ static int lstm_max_clusters(int H) {
   int dev = 0, ncu = 0, occ_f = 0, occ_b = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_fwd_kernel<4, 0>, 64, lstm_smem_bytes(H)) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bwd_kernel<2, 0>, 64, lstm_smem_bytes(H)) != hipSuccess)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_fwd_kernel<4>, 64, lstm_smem_bytes(H)) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bwd_kernel<2>, 64, lstm_smem_bytes(H)) != hipSuccess)
     return 0;
   const int occ = occ_f < occ_b ? occ_f : occ_b;
   int waves = ncu * occ;
@@ -541,7 +523,6 @@ static int lstm_launch(K kernel, LstmArgs a, void* ws, void* stream) {
   const size_t smem = lstm_smem_bytes(H);
   unsigned char* w = reinterpret_cast<unsigned char*>(ws);
   a.err = reinterpret_cast<int32_t*>(w);
-  { const char* e = getenv("RFX_LSTM_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.ctr = reinterpret_cast<uint32_t*>(w + lstm_ws_ctr_off());
   a.xch = reinterpret_cast<uint64_t*>(w + lstm_ws_xch_off(H));
   hipStream_t s = (hipStream_t)stream;
@@ -565,7 +546,7 @@ extern "C" int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_
   LstmArgs a{};
   a.xp = xp; a.packA = reinterpret_cast<const uint4*>(pack); a.out = out; a.gates = gates; a.cstate = cstate;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
-  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0>, a, ws, stream) : lstm_launch(lstm_fwd_kernel<2, 0>, a, ws, stream);
+  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4>, a, ws, stream) : lstm_launch(lstm_fwd_kernel<2>, a, ws, stream);
 }
 
 extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
@@ -576,5 +557,5 @@ extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* ga
   a.gout = gout; a.packA = reinterpret_cast<const uint4*>(pack); a.gates = const_cast<float*>(gates);
   a.cstate = const_cast<float*>(cstate); a.dG = dG;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
-  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1, 0>, a, ws, stream);
+  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1>, a, ws, stream);
 }

@@ -33,13 +33,4 @@ for H, T, Bn in shapes:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         print(f"H={H} T={T} Bn={Bn} {name}: {ms:.3f} ms  {1e3 * ms / T:.2f} us/step", flush=True)
-import os
-if int(os.environ.get("RFX_LSTM_DBG", "0")) & 32:
-    for H in (192, 384):
-        ws = lstm._workspace(torch.device("cuda", 0), H)
-        st = ws[64:256].view(torch.int64).cpu().view(3, 8)
-        print("H", H, "stamps (cycles since step start):")
-        for row in st:
-            print("   ", [int(v - row[0]) for v in row], " next-step gap")
-        print("    step period:", int(st[1, 0] - st[0, 0]), int(st[2, 0] - st[1, 0]))
 print("error flag:", lstm.error_flag())
