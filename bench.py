@@ -236,6 +236,9 @@ def main():
     fence()
     dt = time.time() - t0
     timer.enabled = False
+    from remfx_amd import lstm as _lstm
+    if _lstm.error_flag():                      # a bounded cluster-exchange spin timed out: results are invalid
+        raise RuntimeError("LSTM recurrence kernel reported a spin time-out")
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -1,0 +1,401 @@
+// Weight-gradient kernels of the gather-GEMM family (see gemm_fwd.h for the family overview).
+#include "gemm_fwd.h"
+
+__global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_t* __restrict__ woff,
+                                  int64_t w_ms, int M, int K, int Kpad, float* __restrict__ dw) {
+  const int64_t total = (int64_t)K * M;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / K), k = (int)(i % K);
+    // distinct (k, m) map to distinct weight elements within one descriptor, but
+    // several descriptors (stride phases) may run back to back on the stream.
+    dw[(int64_t)m * w_ms + woff[k]] += dapack[(int64_t)m * Kpad + k];
+  }
+}
+
+
+// ---------------------------------------------------------------------------------
+// weight-gradient MFMA kernel:  dapack[k][m] += sum_p g[m][p] * In(k, p)
+// Both operands are contiguous along the reduction axis p in memory, so both are
+// staged through LDS ([row][32 positions], stride 33 -> conflict-free operand reads).
+// ---------------------------------------------------------------------------------
+struct WgradArgs {
+  rfx_gemm_desc d;
+  const rfx_ktab_entry* ktab;
+  const float* in;
+  const float* g;
+  float* dapack;
+  int tiles_per_sample;  // ceil(P / 32)
+  int total_tiles;       // N * tiles_per_sample
+  int tiles_per_block;
+  int kt, mt, splits;
+  int xcd_grouped;       // 1: 1-D grid, all (k, m) tiles of one position split share an XCD (ids congruent mod 8)
+};
+
+template <int TM, int TK>
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
+  constexpr int RM = 64 * TM, RK = 64 * TK, LD = 33;
+  __shared__ float gs[RM * LD];
+  __shared__ float xs[RK * LD];
+  __shared__ rfx_ktab_entry kts[RK];
+  const rfx_gemm_desc& d = w.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wk = wave & 1;
+  // plain order (k tile fastest).  An XCD-grouped order (all tiles of one position split on one XCD) was
+  // measured SLOWER (132 -> 116 TF/s-eq at the TCN shape): the splits are too few / too coarse to balance.
+  const int zsplit = blockIdx.z;
+  const int m0 = blockIdx.y * RM;
+  const int k0 = blockIdx.x * RK;
+  const int P = d.OA * d.OB;
+  for (int i = tid; i < RK; i += 256) {
+    rfx_ktab_entry e;
+    if (k0 + i < d.Kpad) e = w.ktab[k0 + i];
+    else { e.off = 0; e.da = -(1 << 30); e.db = 0; e.flags = 0; }
+    kts[i] = e;
+  }
+  __syncthreads();
+
+  f32x16 acc[TM][TK];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int t_begin = zsplit * w.tiles_per_block;
+  const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
+  const int prow = tid >> 5;  // 0..7: row group for loads; lane position = tid & 31
+  const int pl = tid & 31;
+  float gv[RM / 8], xv[RK / 8];
+  // Gathers of one 32-position tile into registers.  Invalid lanes read a device 0 (or 1 for the
+  // bias column) instead of masking the loaded value, so nothing consumes the result until the
+  // LDS store of the NEXT iteration: the loads stay in flight under this tile's MFMAs.
+  auto load_tile = [&](int t) {
+    const int n = t / w.tiles_per_sample;
+    const int j = (t - n * w.tiles_per_sample) * 32 + pl;
+    const bool jvalid = j < P;
+    const int jj = jvalid ? j : 0;
+    const int a = jj / d.OB, b = jj - a * d.OB;
+    const int ia0 = a * d.SA, ib0 = b * d.SB;
+    const float* inb = w.in + (int64_t)n * d.in_ns + (int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs;
+    const float* gb = w.g + (int64_t)n * d.out_ns + (int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
+                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
+#pragma unroll
+    for (int i = 0; i < RM / 8; ++i) {
+      const int m = m0 + prow + 8 * i;
+      const bool ok = jvalid & (m < d.M);
+      const float* p = ok ? gb + (int64_t)m * d.out_cs : rfx_zero_f32;
+      gv[i] = *p;
+    }
+#pragma unroll
+    for (int i = 0; i < RK / 8; ++i) {
+      const rfx_ktab_entry e = kts[prow + 8 * i];
+      const bool ones = e.flags & 1;
+      const bool ok = jvalid & !ones & ((unsigned)(ia0 + e.da) < (unsigned)d.IA) &
+                      ((unsigned)(ib0 + e.db) < (unsigned)d.IB);
+      const float* p = ok ? inb + e.off : ((ones & jvalid) ? rfx_one_f32 : rfx_zero_f32);
+      xv[i] = *p;
+    }
+  };
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();  // previous tile's operand reads are done
+#pragma unroll
+    for (int i = 0; i < RM / 8; ++i) gs[(prow + 8 * i) * LD + pl] = gv[i];
+#pragma unroll
+    for (int i = 0; i < RK / 8; ++i) xs[(prow + 8 * i) * LD + pl] = xv[i];
+    __syncthreads();
+    load_tile(t + 1 < t_end ? t + 1 : t);   // unconditional (branch-free): the last tile is re-read
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[TM], bv[TK];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) av[tm] = gs[(wm * 32 * TM + tm * 32 + l31) * LD + 2 * kk + h];
+#pragma unroll
+      for (int tk = 0; tk < TK; ++tk) bv[tk] = xs[(wk * 32 * TK + tk * 32 + l31) * LD + 2 * kk + h];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk)
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tk], acc[tm][tk], 0, 0, 0);
+    }
+  }
+  // D[i = m][j = k] -> dapack[m][k]  (k = lane axis -> 128-byte coalesced atomics)
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = k0 + wk * 32 * TK + tk * 32 + l31;
+        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
+      }
+}
+
+// bf16x3 weight gradient: same tiling and gathers as gemm_wgrad_kernel, but the two LDS tiles hold
+// the operands pre-split into bf16 hi / lo halves ([row][32 positions], 80-byte rows: 16-byte aligned
+// MFMA fragments, conflict-free ds_read_b128) and the product runs on v_mfma_f32_32x32x16_bf16.
+template <int TM, int TK>
+__global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) {
+  constexpr int RM = 64 * TM, RK = 64 * TK, LDW = 40;   // bf16 elements per LDS row
+  __shared__ __attribute__((aligned(16))) unsigned short gs_hi[RM * LDW], gs_lo[RM * LDW];
+  __shared__ __attribute__((aligned(16))) unsigned short xs_hi[RK * LDW], xs_lo[RK * LDW];
+  __shared__ rfx_ktab_entry kts[RK];
+  const rfx_gemm_desc& d = w.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wk = wave & 1;
+  // plain order (k tile fastest).  An XCD-grouped order (all tiles of one position split on one XCD) was
+  // measured SLOWER (132 -> 116 TF/s-eq at the TCN shape): the splits are too few / too coarse to balance.
+  int zsplit = blockIdx.z, ym = blockIdx.y, xk = blockIdx.x;
+  if (w.xcd_grouped) {
+    // every (k, m) tile of a position split re-reads the same g rows / input samples: keep them behind ONE L2
+    const int nb = w.kt * w.mt, q = blockIdx.x >> 3;
+    zsplit = (q / nb) * 8 + (blockIdx.x & 7);
+    if (zsplit >= w.splits) return;
+    const int r = q % nb;
+    ym = r / w.kt;
+    xk = r - ym * w.kt;
+  }
+  const int m0 = ym * RM;
+  const int k0 = xk * RK;
+  const int P = d.OA * d.OB;
+  for (int i = tid; i < RK; i += 256) {
+    rfx_ktab_entry e;
+    if (k0 + i < d.Kpad) e = w.ktab[k0 + i];
+    else { e.off = 0; e.da = -(1 << 30); e.db = 0; e.flags = 0; }
+    kts[i] = e;
+  }
+  __syncthreads();
+  f32x16 acc[TM][TK];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int t_begin = zsplit * w.tiles_per_block;
+  const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
+  const int prow = tid >> 5, pl = tid & 31;
+  // operands of one position tile in flight: raw buffer loads relative to the sample bases (an out-of-range offset
+  // reads 0 in hardware: no pointer selects, no branches); the bias ("ones") row is added at staging time
+  struct Stage { float gv[RM / 8], xv[RK / 8]; float jv; };
+  float onesf[RK / 8];
+#pragma unroll
+  for (int i = 0; i < RK / 8; ++i) onesf[i] = (kts[prow + 8 * i].flags & 1) ? 1.f : 0.f;
+  auto load_tile = [&](int t, Stage& st) {
+    const int n = t / w.tiles_per_sample;                       // wave-uniform
+    const int j = (t - n * w.tiles_per_sample) * 32 + pl;
+    const bool jvalid = j < P;
+    const int jj = jvalid ? j : 0;
+    const int a = jj / d.OB, b = jj - a * d.OB;
+    const int ia0 = a * d.SA, ib0 = b * d.SB;
+    const __amdgpu_buffer_rsrc_t irs = rfx_sample_rsrc(w.in + (int64_t)n * d.in_ns);
+    const __amdgpu_buffer_rsrc_t grs = rfx_sample_rsrc(w.g + (int64_t)n * d.out_ns);
+    const uint32_t voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * 4);
+    const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
+                                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs + (int64_t)(m0 + prow) * d.out_cs) * 4);
+    const uint32_t gstep = (uint32_t)(8 * d.out_cs * 4);
+    st.jv = jvalid ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < RM / 8; ++i) {
+      const bool ok = jvalid & (m0 + prow + 8 * i < d.M);
+      st.gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < RK / 8; ++i) {
+      const rfx_ktab_entry e = kts[prow + 8 * i];
+      const bool ok = jvalid & !(e.flags & 1) & ((unsigned)(ia0 + e.da) < (unsigned)d.IA) &
+                      ((unsigned)(ib0 + e.db) < (unsigned)d.IB);     // the bias row loads nothing: it is onesf * jv
+      st.xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, ok ? voff + ((uint32_t)e.off << 2) : RFX_BUF_OOB, 0, 0));
+    }
+  };
+  auto put = [&](unsigned short* hi, unsigned short* lo, int row, float v) {
+    const __bf16 h = (__bf16)v;                                   // v_cvt_pk_bf16_f32 (RNE)
+    const unsigned short hb = __builtin_bit_cast(unsigned short, h);
+    const __bf16 l = (__bf16)(v - __uint_as_float((uint32_t)hb << 16));
+    hi[row * LDW + pl] = hb;
+    lo[row * LDW + pl] = __builtin_bit_cast(unsigned short, l);
+  };
+  auto stage = [&](const Stage& st) {
+#pragma unroll
+    for (int i = 0; i < RM / 8; ++i) put(gs_hi, gs_lo, prow + 8 * i, st.gv[i]);
+#pragma unroll
+    for (int i = 0; i < RK / 8; ++i) put(xs_hi, xs_lo, prow + 8 * i, st.xv[i] + onesf[i] * st.jv);
+  };
+  auto mma_tile = [&]() {
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      bf16x8 ah[TM], al[TM], bh[TK], bl[TK];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int off = (wm * 32 * TM + tm * 32 + l31) * LDW + 16 * ks2 + 8 * h;
+        ah[tm] = *reinterpret_cast<const bf16x8*>(gs_hi + off);
+        al[tm] = *reinterpret_cast<const bf16x8*>(gs_lo + off);
+      }
+#pragma unroll
+      for (int tk = 0; tk < TK; ++tk) {
+        const int off = (wk * 32 * TK + tk * 32 + l31) * LDW + 16 * ks2 + 8 * h;
+        bh[tk] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
+        bl[tk] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk) {
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tk], acc[tm][tk], 0, 0, 0);
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tk], acc[tm][tk], 0, 0, 0);
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tk], acc[tm][tk], 0, 0, 0);
+        }
+    }
+  };
+  // two tiles of operands in flight: the loads of tile t+2 are issued before the MFMAs of tile t, so an HBM round
+  // trip (~1-2 us) is covered by two tiles of matrix work instead of one (the r01 version waited at every tile)
+  Stage s0, s1;
+  const int t_last = t_end - 1;
+  if (t_begin < t_end) {
+    load_tile(t_begin, s0);
+    load_tile(min(t_begin + 1, t_last), s1);
+  }
+  for (int t = t_begin; t < t_end; t += 2) {
+    __syncthreads();
+    stage(s0);
+    __syncthreads();
+    load_tile(min(t + 2, t_last), s0);
+    mma_tile();
+    if (t + 1 < t_end) {                       // block-uniform
+      __syncthreads();
+      stage(s1);
+      __syncthreads();
+      load_tile(min(t + 3, t_last), s1);
+      mma_tile();
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = k0 + wk * 32 * TK + tk * 32 + l31;
+        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
+      }
+}
+
+// Thin weight gradient (M <= 8): one wave per k row, lanes along positions.
+template <int MM>
+__global__ __launch_bounds__(256) void gemm_thin_wgrad_kernel(const WgradArgs w) {
+  const rfx_gemm_desc& d = w.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int k = blockIdx.x * 4 + wave;
+  if (k >= d.K) return;
+  const rfx_ktab_entry e = w.ktab[k];
+  const bool ones = e.flags & 1;
+  const int P = d.OA * d.OB;
+  float acc[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+  const int64_t total = (int64_t)d.N * P;
+  const int64_t chunk = (total + gridDim.y - 1) / gridDim.y;
+  const int64_t q0 = (int64_t)blockIdx.y * chunk;
+  const int64_t q1 = min(q0 + chunk, total);
+  for (int64_t q = q0 + lane; q < q1; q += 64) {
+    const int n = (int)(q / P);
+    const int j = (int)(q - (int64_t)n * P);
+    const int a = j / d.OB, b = j - a * d.OB;
+    const int ia0 = a * d.SA, ib0 = b * d.SB;
+    float xv;
+    if (ones) xv = 1.f;
+    else {
+      const bool ok = (unsigned)(ia0 + e.da) < (unsigned)d.IA && (unsigned)(ib0 + e.db) < (unsigned)d.IB;
+      xv = ok ? w.in[(int64_t)n * d.in_ns + (int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs + e.off] : 0.f;
+    }
+    const float* gb = w.g + (int64_t)n * d.out_ns + (int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
+                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+      if (m < d.M) acc[m] = fmaf(gb[(int64_t)m * d.out_cs], xv, acc[m]);
+  }
+#pragma unroll
+  for (int m = 0; m < MM; ++m) {
+    const float s = rfx_wave_sum(acc[m]);
+    if (lane == 0 && m < d.M) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, s);
+  }
+}
+
+
+extern "C" int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
+                              int32_t K, int32_t Kpad, float* dw, void* stream) {
+  if (!dapack || !woff || !dw || M <= 0 || K < 0 || Kpad < K) return -1;
+  const int64_t total = (int64_t)K * M;
+  if (total == 0) return 0;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(unpack_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff,
+                     w_ms, M, K, Kpad, dw);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+// R (channel tiles per wave) is a pure function of M so that host-side packing
+// and the kernel agree on Mpad = ceil(M / 32R) * 32R.
+
+extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const float* in,
+                              const float* gout, float* dapack, int32_t prec, void* stream) {
+  if (!desc_ok(d) || !ktab || !in || !gout || !dapack) return -1;
+  if (d->K == 0) return 0;
+  WgradArgs w;
+  w.d = *d; w.ktab = ktab; w.in = in; w.g = gout; w.dapack = dapack;
+  const int P = d->OA * d->OB;
+  w.tiles_per_sample = (P + 31) / 32;
+  w.total_tiles = d->N * w.tiles_per_sample;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->M <= 8) {
+    const int64_t total = (int64_t)d->N * P;
+    int splits = (int)(total / 4096 < 1 ? 1 : (total / 4096 > 64 ? 64 : total / 4096));
+    dim3 grid((d->K + 3) / 4, splits);
+    w.tiles_per_block = 0;
+    if (d->M <= 1) hipLaunchKernelGGL(gemm_thin_wgrad_kernel<1>, grid, dim3(256), 0, s, w);
+    else if (d->M <= 2) hipLaunchKernelGGL(gemm_thin_wgrad_kernel<2>, grid, dim3(256), 0, s, w);
+    else if (d->M <= 4) hipLaunchKernelGGL(gemm_thin_wgrad_kernel<4>, grid, dim3(256), 0, s, w);
+    else hipLaunchKernelGGL(gemm_thin_wgrad_kernel<8>, grid, dim3(256), 0, s, w);
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
+  const int tm = d->M > 64 ? 2 : 1;
+  const int tk = d->K > 64 ? 2 : 1;
+  const int mt = (d->M + 64 * tm - 1) / (64 * tm), kt = (d->K + 64 * tk - 1) / (64 * tk);
+  // aim for ~2048 workgroups; each should still see >= 16 position tiles
+  int splits = max(1, 2048 / (mt * kt));
+  splits = min(splits, max(1, w.total_tiles / 64));
+  w.tiles_per_block = (w.total_tiles + splits - 1) / splits;
+  splits = (w.total_tiles + w.tiles_per_block - 1) / w.tiles_per_block;
+  w.kt = kt; w.mt = mt; w.splits = splits;
+  dim3 grid(kt, mt, splits);
+  w.xcd_grouped = 0;
+  if (prec == 1) {
+    static const int xcd_mode = getenv("RFX_WGRAD_XCD") ? atoi(getenv("RFX_WGRAD_XCD")) : 0;   // measured on Demucs B=64: 408.0 ms off, 411.8 ms on
+    if (xcd_mode > 0 && splits >= xcd_mode) {
+      w.xcd_grouped = 1;
+      grid = dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1);
+    }
+    if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 2>), grid, dim3(256), 0, s, w);
+    else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 1>), grid, dim3(256), 0, s, w);
+    else if (tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2>), grid, dim3(256), 0, s, w);
+    else hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 1>), grid, dim3(256), 0, s, w);
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
+  if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, w);
+  else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, w);
+  else if (tk == 2) hipLaunchKernelGGL((gemm_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, w);
+  else hipLaunchKernelGGL((gemm_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, w);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+

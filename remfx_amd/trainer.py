@@ -83,6 +83,9 @@ class Trainer:
                 self.global_step += 1
                 last = self._log(model)
             epoch += 1
+            from . import lstm as _lstm
+            if _lstm.error_flag():              # checked once per epoch (device sync): never train on a timed-out exchange
+                raise RuntimeError("LSTM recurrence kernel reported a spin time-out")
             if hasattr(datamodule, "val_dataloader"):
                 model.eval()
                 with torch.no_grad():
