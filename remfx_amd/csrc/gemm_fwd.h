@@ -377,20 +377,43 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
 
   const rfx_epilogue& e = g.e;
   const bool two = g.apack2 != nullptr;
-  // bias + activation (between the phases when there are two)
+  // bias + activation (between the phases when there are two).  All per-row loads are issued TOGETHER, unconditionally
+  // (clamped row index) and under wave-uniform tests only: with `if (e.bias) v += e.bias[m]` inside the per-element
+  // loop hipcc emitted one load + s_waitcnt vmcnt(0) per element, i.e. 16*R serial L2 round trips (~40 us) per
+  // workgroup -- more than the whole K loop of the short-K layers.
+  {
+    float bv[R][16];
+    if (e.bias) {
 #pragma unroll
-  for (int mt = 0; mt < R; ++mt) {
+      for (int mt = 0; mt < R; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m < d.M) {
-        float v = acc[mt][r];
-        if (e.bias) v += e.bias[m];
-        if (e.act != RFX_ACT_NONE && !e.bwd) {
-          const float s = (e.act == RFX_ACT_PRELU) ? e.act_param[m] : 0.f;
-          v = rfx_act_apply(v, e.act, s);
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          bv[mt][r] = e.bias[m < d.M ? m : d.M - 1];
         }
-        acc[mt][r] = v;
+#pragma unroll
+      for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] += bv[mt][r];
+    }
+    if (e.act != RFX_ACT_NONE && !e.bwd) {
+      if (e.act == RFX_ACT_PRELU) {
+#pragma unroll
+        for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            bv[mt][r] = e.act_param[m < d.M ? m : d.M - 1];
+          }
+#pragma unroll
+        for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] = acc[mt][r] >= 0.f ? acc[mt][r] : bv[mt][r] * acc[mt][r];
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] = rfx_act_apply(acc[mt][r], e.act, 0.f);
       }
     }
   }
@@ -411,19 +434,25 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
     resp = e.res + (int64_t)n * e.res_ns + (int64_t)(a * d.out_sa + d.out_a0) * e.res_as +
            (int64_t)(b * d.out_sb + d.out_b0) * e.res_bs;
   if (e.bwd) {
-    // out = G * act'(pre);  gparam[m] += sum_j G * min(pre, 0)   (PReLU slope gradient)
+    // out = G * act'(pre);  gparam[m] += sum_j G * min(pre, 0)   (PReLU slope gradient).  Loads batched as above.
 #pragma unroll
-    for (int mt = 0; mt < R; ++mt) {
+    for (int mt = 0; mt < R; ++mt) {             // one channel tile at a time: 16 + 16 loads in flight, 32 temporaries
+      float gin[16], sl[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int mc = m < d.M ? m : d.M - 1;
+        gin[r] = resp[(int64_t)mc * e.res_cs];
+        sl[r] = (e.act == RFX_ACT_PRELU) ? e.act_param[mc] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         float gs = 0.f;
         if (m < d.M && c.jvalid) {
           const float pre = acc[mt][r];
-          const float gin = resp[(int64_t)m * e.res_cs];
-          const float s = (e.act == RFX_ACT_PRELU) ? e.act_param[m] : 0.f;
-          outp[(int64_t)m * d.out_cs] = gin * rfx_act_grad(pre, e.act, s);
-          gs = pre < 0.f ? gin * pre : 0.f;
+          outp[(int64_t)m * d.out_cs] = gin[r] * rfx_act_grad(pre, e.act, sl[r]);
+          gs = pre < 0.f ? gin[r] * pre : 0.f;
         }
         if (e.gparam) {   // reduce over the 32 position lanes of this half-wave
 #pragma unroll
@@ -435,6 +464,25 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
     return;
   }
   float s1 = 0.f, s2 = 0.f;      // optional per-sample moments of the stored values (GroupNorm(1, C) statistics)
+  if (resp) {                    // wave-uniform; residual values fetched a channel tile at a time (see the bias note)
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt) {
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        rv[r] = resp[(int64_t)(m < d.M ? m : d.M - 1) * e.res_cs];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] += rv[r];
+    }
+  }
+  if (e.act2 != RFX_ACT_NONE) {
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = rfx_act_apply(acc[mt][r], e.act2, 0.f);
+  }
   if (c.jvalid) {
 #pragma unroll
     for (int mt = 0; mt < R; ++mt) {
@@ -442,9 +490,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < d.M) {
-          float v = acc[mt][r];
-          if (resp) v += resp[(int64_t)m * e.res_cs];
-          if (e.act2 != RFX_ACT_NONE) v = rfx_act_apply(v, e.act2, 0.f);
+          const float v = acc[mt][r];
           outp[(int64_t)m * d.out_cs] = v;
           s1 += v; s2 += v * v;
         }

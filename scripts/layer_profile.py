@@ -25,7 +25,7 @@ def wrap(name):
         info = ""
         if name in ("rfx_gemm_fwd", "rfx_gemm_wgrad"):
             d = args[0]._obj
-            info = f"N={d.N} M={d.M} K={d.K} P={d.OA}x{d.OB} S=({d.SA},{d.SB})"
+            info = f"N={d.N} M={d.M} K={d.K} P={d.OA}x{d.OB} S=({d.SA},{d.SB}) osa={d.out_sa}*{d.out_as} osb={d.out_sb}*{d.out_bs}"
             fl = 2.0 * d.N * d.M * d.K * d.OA * d.OB
             by = 4.0 * d.N * d.OA * d.OB * (d.M + d.K / max(1, (d.K // max(d.M, 1)) if False else 1))
             info += f" {fl / dt / 1e9:6.1f} TF/s  out {4.0 * d.N * d.M * d.OA * d.OB / 1e6:7.1f} MB"
