@@ -435,15 +435,21 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
            (int64_t)(b * d.out_sb + d.out_b0) * e.res_bs;
   if (e.bwd) {
     // out = G * act'(pre);  gparam[m] += sum_j G * min(pre, 0)   (PReLU slope gradient).  Loads batched as above.
+    float gin[R][16];                            // all incoming gradients in flight at once; slopes a channel tile at a time
 #pragma unroll
-    for (int mt = 0; mt < R; ++mt) {             // one channel tile at a time: 16 + 16 loads in flight, 32 temporaries
-      float gin[16], sl[16];
+    for (int mt = 0; mt < R; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int mc = m < d.M ? m : d.M - 1;
-        gin[r] = resp[(int64_t)mc * e.res_cs];
-        sl[r] = (e.act == RFX_ACT_PRELU) ? e.act_param[mc] : 0.f;
+        gin[mt][r] = resp[(int64_t)(m < d.M ? m : d.M - 1) * e.res_cs];
+      }
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt) {
+      float sl[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        sl[r] = (e.act == RFX_ACT_PRELU) ? e.act_param[m < d.M ? m : d.M - 1] : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -451,8 +457,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
         float gs = 0.f;
         if (m < d.M && c.jvalid) {
           const float pre = acc[mt][r];
-          outp[(int64_t)m * d.out_cs] = gin[r] * rfx_act_grad(pre, e.act, sl[r]);
-          gs = pre < 0.f ? gin[r] * pre : 0.f;
+          outp[(int64_t)m * d.out_cs] = gin[mt][r] * rfx_act_grad(pre, e.act, sl[r]);
+          gs = pre < 0.f ? gin[mt][r] * pre : 0.f;
         }
         if (e.gparam) {   // reduce over the 32 position lanes of this half-wave
 #pragma unroll
