@@ -88,6 +88,10 @@ typedef struct rfx_epilogue {
   /* optional: stat_sums[2n] += sum v, stat_sums[2n+1] += sum v^2 over the values stored for sample n (fp64;
    * caller zeroes): GroupNorm(1, C) statistics of the NEXT layer without re-reading the tensor */
   double* stat_sums;
+  /* > 1: stat_sums is [N][stat_slots][2] and workgroups spread their atomics over the slots (power of two): a sample whose
+   * positions span thousands of workgroups would otherwise serialise them on two addresses.  rfx_groupnorm_fwd takes the
+   * same count in sums_given and adds the slots up. */
+  int32_t stat_slots;
 } rfx_epilogue;
 
 /* Arithmetic of the MFMA gather-GEMM.  RFX_PREC_F32: v_mfma_f32_32x32x2_f32, exact fp32 products.
@@ -219,7 +223,8 @@ int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stre
 int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C, int32_t S,
                       int32_t G, float eps, int32_t mode, const float* res, const float* scale,
                       double* sums /* N*G*2 fp64 workspace; sums_given != 0: already holds {sum, sumsq} per
-                                      (n, g) -- e.g. from rfx_epilogue.stat_sums -- and the statistics pass is skipped */,
+                                      (n, g) -- e.g. from rfx_epilogue.stat_sums -- and the statistics pass is skipped;
+                                      sums_given = k > 1: the buffer is [N*G][k][2] partial sums (rfx_epilogue.stat_slots) */,
                       int32_t sums_given, float* mean, float* rstd, float* y, void* stream);
 /* dx (N, C, S); dgamma / dbeta (C) and dscale (C/2, mode 3) are OVERWRITTEN; `work` is a
  * caller-owned scratch of N*C*2 + N*(C/2) + N*G*2 floats; the residual gradient of mode 3 is gy. */

@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256) void gemm_thin_fwd_kernel(const FwdArgs g) {
     }
   }
   if (e.stat_sums) {
-    atomicAdd(e.stat_sums + 2 * n, (double)st1);       // thin path: tiny tensors, per-thread atomics are fine
-    atomicAdd(e.stat_sums + 2 * n + 1, (double)st2);
+    const int slots = e.stat_slots > 1 ? e.stat_slots : 1;     // thin path: tiny tensors, per-thread atomics are fine
+    double* dst = e.stat_sums + 2 * ((int64_t)n * slots + (blockIdx.x & (slots - 1)));
+    atomicAdd(dst, (double)st1);
+    atomicAdd(dst + 1, (double)st2);
   }
 }
 

@@ -505,7 +505,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
   }
   if (e.stat_sums) {               // wave-uniform branch: one fp64 atomic pair per wave
     const double d1 = rfx_wave_sum_d((double)s1), d2 = rfx_wave_sum_d((double)s2);
-    if (lane == 0) { atomicAdd(e.stat_sums + 2 * n, d1); atomicAdd(e.stat_sums + 2 * n + 1, d2); }
+    const int slots = e.stat_slots > 1 ? e.stat_slots : 1;
+    double* dst = e.stat_sums + 2 * ((int64_t)n * slots + (pw & (slots - 1)));
+    if (lane == 0) { atomicAdd(dst, d1); atomicAdd(dst + 1, d2); }
   }
 }
 

@@ -69,11 +69,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* _
 }
 
 __global__ void gn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
-                                   float* __restrict__ rstd, int ngroups, double len, float eps) {
+                                   float* __restrict__ rstd, int ngroups, double len, float eps, int slots) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ngroups) return;
-  const double m = sums[2 * i] / len;
-  double var = sums[2 * i + 1] / len - m * m;
+  double s1 = 0.0, s2 = 0.0;                     // slots > 1: partial sums a producing GEMM spread over several addresses
+  for (int k = 0; k < slots; ++k) { s1 += sums[2 * ((int64_t)i * slots + k)]; s2 += sums[2 * ((int64_t)i * slots + k) + 1]; }
+  const double m = s1 / len;
+  double var = s2 / len - m * m;
   var = var > 0.0 ? var : 0.0;
   mean[i] = (float)m;
   rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
@@ -328,7 +330,7 @@ static int norm_fwd(int bn, int use_given_stats, int sums_given, const float* x,
       RFX_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, sums, mean, rstd, nstat,
-                       bn ? (double)N * (double)S : (double)(C / G) * (double)S, eps);
+                       bn ? (double)N * (double)S : (double)(C / G) * (double)S, eps, sums_given > 1 ? sums_given : 1);
     RFX_CHECK_LAUNCH();
   }
   const int64_t total = (int64_t)N * (glu ? C / 2 : C) * S;

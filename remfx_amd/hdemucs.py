@@ -37,6 +37,10 @@ class _ScaledEmbedding(nn.Module):
         return self.embedding.weight * self.scale
 
 
+# partial-sum slots per sample for the GEMM-epilogue GroupNorm statistics (spreads same-address fp64 atomics)
+_STAT_SLOTS = 16
+
+
 class _LayerScale(nn.Module):
     def __init__(self, channels, init=0.0):
         super().__init__()
@@ -126,7 +130,7 @@ class _DConv(nn.Module):
     def forward(self, x):
         for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
             mods = list(seq)
-            st = torch.zeros((x.shape[0], 2), device=x.device, dtype=torch.float64)   # GN(1, C) statistics
+            st = torch.zeros((x.shape[0], _STAT_SLOTS, 2), device=x.device, dtype=torch.float64)   # GN(1, C) statistics
             y = ops.conv1d(x, mods[0].weight, mods[0].bias, 1, pad, dil, stat_sums=st)   # come out of the GEMM epilogue
             y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu", sums=st)
             i = 3
@@ -134,7 +138,7 @@ class _DConv(nn.Module):
                 y = mods[i](y); i += 1
             if attn:
                 y = mods[i](y); i += 1
-            st = torch.zeros((x.shape[0], 2), device=x.device, dtype=torch.float64)
+            st = torch.zeros((x.shape[0], _STAT_SLOTS, 2), device=x.device, dtype=torch.float64)
             y = ops.conv1d(y, mods[i].weight, mods[i].bias, stat_sums=st)
             x = nnops.group_norm(y, 1, mods[i + 1].weight, mods[i + 1].bias, mods[i + 1].eps,
                                  mode="glu_scale_res", res=x, scale=mods[i + 3].scale, sums=st)

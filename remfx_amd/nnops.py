@@ -47,7 +47,7 @@ class _GroupNormFn(torch.autograd.Function):
         y = torch.empty(oshape, device=x.device, dtype=torch.float32)
         mean = torch.empty(N * groups, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        given = 1 if sums is not None else 0
+        given = (sums.shape[1] if sums.dim() == 3 else 1) if sums is not None else 0     # number of partial-sum slots
         if sums is None:
             sums = torch.empty(N * groups * 2, device=x.device, dtype=torch.float64)
         if res is not None:
@@ -78,7 +78,7 @@ class _GroupNormFn(torch.autograd.Function):
 
 def group_norm(x, groups, weight, bias, eps=1e-5, mode="none", res=None, scale=None, sums=None):
     """mode: none | gelu | glu | glu_scale_res (out = res + scale[c] * glu(gn(x))).
-    sums: fp64 (N*groups, 2) {sum, sum^2} already accumulated by the producing GEMM's epilogue."""
+    sums: fp64 (N*groups, 2) or (N*groups, slots, 2) {sum, sum^2} already accumulated by the producing GEMM's epilogue."""
     return _GroupNormFn.apply(x, weight, bias, groups, eps, GN_MODES[mode], res, scale, sums)
 
 
