@@ -141,6 +141,28 @@ __device__ __forceinline__ void block_coords(const FftArgs& a, int& row, int& f_
   f_first = a.d.frame0 + grp * FB;
 }
 
+// e^{-i pi k / NC} for the split (analysis) / merge (synthesis) step: a table instead of one sincospif per output
+// element (n_fft <= 2048; the 4096-point kernels keep sincospif, their LDS is full)
+template <int LOGN>
+__device__ __forceinline__ void build_half_twiddles(float2* tw2) {
+  constexpr int NC = 1 << LOGN;
+  if (LOGN > 10) return;
+  for (int t = threadIdx.x; t < NC / 2; t += 256) {
+    float s, c;
+    sincospif(-(float)(2 * t + 1) / (float)NC, &s, &c);
+    tw2[t] = make_float2(c, s);
+  }
+}
+// k in [0, NC]: even k -> tw[k/2] = e^{-2 pi i (k/2) / NC}, odd k -> tw2[(k-1)/2]
+template <int LOGN>
+__device__ __forceinline__ float2 half_twiddle(const float2* tw, const float2* tw2, int k) {
+  constexpr int NC = 1 << LOGN;
+  if (LOGN <= 10) return ((k & 1) ? tw2 : tw)[k >> 1];
+  float s, c;
+  sincospif((float)k / (float)NC, &s, &c);
+  return make_float2(c, -s);
+}
+
 template <int LOGN>
 __device__ __forceinline__ void build_twiddles(float2* tw) {
   constexpr int NC = 1 << LOGN;
@@ -156,37 +178,51 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
   constexpr int NC = 1 << LOGN, FB = 8192 >> LOGN, FS = NC + 1, N = 2 * NC;
   __shared__ float2 data[FB * FS];
   __shared__ float2 tw[NC];
+  __shared__ float2 tw2[LOGN <= 10 ? NC / 2 : 1];     // e^{-i pi k / NC} for ODD k (even k is tw[k/2]); LDS budget: n_fft <= 2048
   const rfx_stft_desc& d = a.d;
   int row, f_first;
   block_coords<LOGN>(a, row, f_first);
   if (row >= d.R) return;
   const int tid = threadIdx.x;
   build_twiddles<LOGN>(tw);
+  build_half_twiddles<LOGN>(tw2);
   const int f_end = d.frame0 + d.frames_out;
   const float* xr = a.x + (int64_t)row * d.T;
   const int woff = (N - d.win) / 2;
-  for (int idx = tid; idx < FB * NC; idx += 256) {
-    const int fl = idx / NC, i = idx - fl * NC;
-    const int f = f_first + fl;
-    float2 v = make_float2(0.f, 0.f);
-    if (f < f_end) {
+  // Load phase, 4 complex points (8 samples) per thread and round: every index is clamped and every load is
+  // unconditional, validity is applied to the VALUE afterwards.  (With the loads inside `if (in window) if (in signal)`
+  // hipcc emitted one load + s_waitcnt vmcnt(0) per sample: 64 dependent memory round trips per thread and workgroup,
+  // which is where the r01 kernels spent their time: 0.87 ms for 3.4 GFLOP.)
+  for (int j0 = 0; j0 < (FB * NC) / 256; j0 += 4) {
+    float xs[8], ws[8], ms[8];
+    bool ok[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * (j0 + e);
+      const int fl = idx >> LOGN, i = idx & (NC - 1);
+      const int f = f_first + fl;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * i + u;
         const int wi = t - woff;
-        float val = 0.f;
-        if (wi >= 0 && wi < d.win) {
-          const int p = f * d.hop + t;
-          const int s = map_sample(d, p);
-          if (s >= 0) {
-            val = xr[s] * a.window[wi] * d.scale;
-            if (a.mul) val *= a.mul[p];
-          }
-        }
-        if (u == 0) v.x = val; else v.y = val;
+        const int pp = f * d.hop + t;
+        const int sm = map_sample(d, pp);
+        const bool v = (f < f_end) & (wi >= 0) & (wi < d.win) & (sm >= 0);
+        ok[2 * e + u] = v;
+        xs[2 * e + u] = xr[v ? sm : 0];
+        ws[2 * e + u] = a.window[v ? wi : 0];
+        ms[2 * e + u] = a.mul ? a.mul[v ? pp : 0] : 1.f;       // a.mul: wave-uniform
       }
     }
-    data[fl * FS + i] = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * (j0 + e);
+      const int fl = idx >> LOGN, i = idx & (NC - 1);
+      float2 v;
+      v.x = ok[2 * e] ? xs[2 * e] * ws[2 * e] * d.scale * ms[2 * e] : 0.f;
+      v.y = ok[2 * e + 1] ? xs[2 * e + 1] * ws[2 * e + 1] * d.scale * ms[2 * e + 1] : 0.f;
+      data[fl * FS + i] = v;
+    }
   }
   __syncthreads();
   fft_passes<LOGN, false>(data, tw, FB * NC);
@@ -202,9 +238,8 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
     const float2 E = make_float2(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
     const float2 D = make_float2(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
     const float2 O = make_float2(D.y, -D.x);  // D * (-i)
-    float s, c;
-    sincospif((float)k / (float)NC, &s, &c);
-    float2 X = cmul(O, make_float2(c, -s));
+    const float2 hw = half_twiddle<LOGN>(tw, tw2, k);      // e^{-i pi k / NC}
+    float2 X = cmul(O, hw);
     X.x += E.x;
     X.y += E.y;
     if (d.herm) {  // gradient of irfft: middle bins doubled, DC / Nyquist imaginary part dropped
@@ -239,44 +274,60 @@ __global__ __launch_bounds__(256) void fft_synthesis_kernel(const FftArgs a) {
   constexpr int NC = 1 << LOGN, FB = 8192 >> LOGN, FS = NC + 1, N = 2 * NC;
   __shared__ float2 data[FB * FS];
   __shared__ float2 tw[NC];
+  __shared__ float2 tw2[LOGN <= 10 ? NC / 2 : 1];     // e^{-i pi k / NC} for ODD k (even k is tw[k/2]); LDS budget: n_fft <= 2048
   const rfx_stft_desc& d = a.d;
   int row, f_first;
   block_coords<LOGN>(a, row, f_first);
   if (row >= d.R) return;
   const int tid = threadIdx.x;
   build_twiddles<LOGN>(tw);
+  build_half_twiddles<LOGN>(tw2);
   const int f_end = d.frame0 + d.frames_out;
   const int FO = d.frames_out;
   // merge step: Z[k] = (X[k] + conj X[NC-k]) + i e^{+i pi k/NC} (X[k] - conj X[NC-k]),  k in [0, NC)
-  for (int idx = tid; idx < NC * FB; idx += 256) {
-    const int k = idx / FB, fl = idx - k * FB;
-    const int f = f_first + fl;
-    float2 Z = make_float2(0.f, 0.f);
-    if (f < f_end) {
-      const int fo = f - d.frame0;
+  // batched, unconditional loads (see the analysis kernel): 2 points x (bin k, bin NC-k) x (re, im) per round
+  for (int j0 = 0; j0 < (NC * FB) / 256; j0 += 2) {
+    float2 xk[2], xm[2];
+    bool fv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + 256 * (j0 + e);
+      const int k = idx / FB, fl = idx - k * FB;
+      const int f = f_first + fl;
+      fv[e] = f < f_end;
+      const int fo = fv[e] ? f - d.frame0 : 0;
       auto fetch = [&](int kk) -> float2 {
-        float2 v = make_float2(0.f, 0.f);
-        if (kk < d.bins) {
-          if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const float2*>(a.x)[((int64_t)row * d.bins + kk) * FO + fo];
-          else {
-            v.x = a.x[((int64_t)row * 2 * d.bins + kk) * FO + fo];
-            v.y = a.x[((int64_t)row * 2 * d.bins + d.bins + kk) * FO + fo];
-          }
+        const bool in = kk < d.bins;
+        const int kc = in ? kk : 0;
+        float2 v;
+        if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const float2*>(a.x)[((int64_t)row * d.bins + kc) * FO + fo];   // uniform
+        else {
+          v.x = a.x[((int64_t)row * 2 * d.bins + kc) * FO + fo];
+          v.y = a.x[((int64_t)row * 2 * d.bins + d.bins + kc) * FO + fo];
         }
+        if (!in) v = make_float2(0.f, 0.f);
         if (kk == 0 || kk == NC) v.y = 0.f;           // real by construction / ignored by irfft
         else if (!d.herm) { v.x *= 0.5f; v.y *= 0.5f; }  // adjoint of the one-sided rfft
         return v;
       };
-      const float2 Xk = fetch(k), Xm = fetch(NC - k);
-      const float2 Xc = make_float2(Xm.x, -Xm.y);
-      const float2 S = make_float2(Xk.x + Xc.x, Xk.y + Xc.y);
-      const float2 D = make_float2(Xk.x - Xc.x, Xk.y - Xc.y);
-      float s, c;
-      sincospif((float)k / (float)NC, &s, &c);
-      const float2 W = cmul(D, make_float2(c, s));
-      Z = make_float2(S.x - W.y, S.y + W.x);  // S + i*W
+      xk[e] = fetch(k);
+      xm[e] = fetch(NC - k);
     }
-    data[fl * FS + digit_pos<LOGN>(k)] = Z;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + 256 * (j0 + e);
+      const int k = idx / FB, fl = idx - k * FB;
+      float2 Z = make_float2(0.f, 0.f);
+      if (fv[e]) {
+        const float2 Xc = make_float2(xm[e].x, -xm[e].y);
+        const float2 S = make_float2(xk[e].x + Xc.x, xk[e].y + Xc.y);
+        const float2 D = make_float2(xk[e].x - Xc.x, xk[e].y - Xc.y);
+        const float2 hw = half_twiddle<LOGN>(tw, tw2, k);     // e^{-i pi k/NC}; the merge needs its conjugate
+        const float2 W = cmul(D, make_float2(hw.x, -hw.y));
+        Z = make_float2(S.x - W.y, S.y + W.x);  // S + i*W
+      }
+      data[fl * FS + digit_pos<LOGN>(k)] = Z;
+    }
   }
   __syncthreads();
   fft_passes<LOGN, true>(data, tw, FB * NC);
