@@ -129,6 +129,9 @@ __device__ __forceinline__ bool lstm_ids(const LstmArgs& a, int& cluster, int& u
   return cluster < a.nclusters;
 }
 
+typedef uint32_t lstm_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) lstm_u32x4* lstm_gptr_t;     // explicit global address space
+
 struct LstmAFrag { uint4 h[4], l[4]; };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
@@ -146,24 +149,26 @@ __device__ __forceinline__ void lstm_fetch_lds(const uint64_t* src, int n, int l
 // holds units du = (r&3) + 8(r>>2) + 4hh, i.e. for r = 8*ksl + 4*hhB + e: k-step 2ub+ksl, lane l31+32hhB, half hh.
 // D = depth of the weight-fragment ring in k-steps (each k-step = 4 gates x (hi, lo) = 8 KB per wave): the L2 round trip
 // (~0.5 us) is covered only if ~4 k-steps (0.64 us of MFMA work) are in flight; D = 2 when H is not a multiple of 64.
-// The k loop keeps its runtime trip count: hipcc drains vmcnt(0) at its header (55 instead of 32 cycles per MFMA, in-kernel
-// s_memtime stamps), but a fully unrolled form (H as a template parameter) hoists ~100 fragment addresses out of the time
-// loop and spills; see DESIGN.md section 4.4 for the remaining head-room.
-template <int D>
+// NKS = H/16 at compile time (0 = runtime trip count).  With a runtime k loop hipcc drains vmcnt(0) at the loop header
+// (55 instead of 32 cycles per MFMA, in-kernel s_memtime stamps).  Fully unrolled, its wait counts are exact (24-32 loads
+// stay in flight) -- provided the fragment base pointer is made opaque once per time step (otherwise ~100 hoisted
+// addresses spill) and keeps its global address space (a laundered generic pointer turns every load into flat_load).
+template <int D, int NKS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_kernel(const LstmArgs a) {
   int cluster, ub;
   if (!lstm_ids(a, cluster, ub)) return;
   const int H = a.H, Bn = a.Bn, T = a.T, P = a.P;
   const int dir = cluster & 1, row0 = (a.tile0 + (cluster >> 1)) * 32;
   const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
-  const int nks = H / 16, nwc = H / 32;
+  const int nks = NKS ? NKS : H / 16, nwc = nks / 2;
   const int row = row0 + l31;
   const bool rvalid = row < Bn;
   const int rowc = rvalid ? row : 0;      // idle lanes read sequence 0 and never store: every load stays unconditional
   const float* __restrict__ xp = a.xp + (int64_t)dir * 4 * H * P;
   const int nf = nwc * 4 * nks * 64;
-  const uint4* __restrict__ Ahi = a.packA + (int64_t)dir * a.pack_stride + ub * 4 * nks * 64;   // wave-uniform
-  const uint4* __restrict__ Alo = Ahi + nf;
+  uint64_t abase = (uint64_t)(a.packA + (int64_t)dir * a.pack_stride + ub * 4 * nks * 64);   // wave-uniform
+  lstm_gptr_t Ahi = (lstm_gptr_t)abase;
+  lstm_gptr_t Alo = Ahi + nf;
   float* outp = a.out + (int64_t)dir * H * P;
   float* gsave = a.gates ? a.gates + (int64_t)dir * 4 * H * P : nullptr;
   float* csave = a.gates ? a.cstate + (int64_t)dir * H * P : nullptr;
@@ -177,8 +182,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       // wave-uniform base + zero-extended lane offset -> scalar-base addressing (no per-fragment 64-bit VGPR address)
-      f.h[g] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Ahi + (g * nks + ks) * 64) + lane16);
-      f.l[g] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Alo + (g * nks + ks) * 64) + lane16);
+      f.h[g] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Ahi + (g * nks + ks) * 64) + lane16));
+      f.l[g] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Alo + (g * nks + ks) * 64) + lane16));
     }
   };
   auto loadB = [&](bf16x8& bh, bf16x8& bl, int ks) {
@@ -214,6 +219,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       for (int r = 0; r < 16; ++r) xpv[g][r] = xp[o0 + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
   }
   for (int s = 0; s < T; ++s) {
+    if (NKS) { asm volatile("" : "+s"(abase)); Ahi = (lstm_gptr_t)abase; Alo = Ahi + nf; }   // opaque base, see above
+
     const int t = dir == 0 ? s : T - 1 - s;
     const uint32_t o0 = ubase + (uint32_t)(t * Bn);
 #pragma unroll
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (s > 0) {
       bf16x8 bh[2], bl[2];
       loadB(bh[0], bl[0], 0);
-      for (int ks = 0; ks < nks; ks += D) {          // nks % D == 0, D even
+      auto kstep = [&](int ks) {                    // D k-steps: MFMAs of slot d, then its refill D k-steps ahead
 #pragma unroll
         for (int d = 0; d < D; ++d) {
           const int k1 = ks + d + 1 == nks ? 0 : ks + d + 1;       // h fragments one k-step ahead (LDS latency)
@@ -246,6 +253,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           loadA(f[d], kn >= nks ? kn - nks : kn);
           __builtin_amdgcn_sched_barrier(0);          // keep the refill behind its MFMAs (scheduler would hoist all loads)
         }
+      };
+      if (NKS) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks += D) kstep(ks);
+      } else {
+        for (int ks = 0; ks < nks; ks += D) kstep(ks);              // nks % D == 0, D even
       }
     }
     uint64_t* hw = xch + (s & 1) * bufw;
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // consumer's slice is H/32 x 4 KB, contiguous, fetched straight into LDS.
 // TPC = unit-block tiles per ring refill round: the weight ring holds 8*TPC k-step fragments (hi, lo); 16 in flight
 // cover the L2 round trip (3 MFMAs per fragment), so TPC = 2 whenever H/32 is even.
-template <int TPC>
+template <int TPC, int NWC>        // NWC = H/32 at compile time (0 = runtime), as NKS in the forward kernel
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(const LstmArgs a) {
   int cluster, ub;
   if (!lstm_ids(a, cluster, ub)) return;
@@ -306,8 +319,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const int rowc = rvalid ? row : 0;
   const int nf = nwc * 4 * nks * 64, nb = nwc * nks4 * 64;
   // bwdA[ot][ks'][lane]: tile ot = output unit block, ks' = gate-row k-step; this wave's rows: g*nks + 2ub + {0,1}
-  const uint4* __restrict__ Ahi = a.packA + (int64_t)dir * a.pack_stride + 2 * nf + 2 * ub * 64;   // wave-uniform
-  const uint4* __restrict__ Alo = Ahi + nb;
+  uint64_t abase = (uint64_t)(a.packA + (int64_t)dir * a.pack_stride + 2 * nf + 2 * ub * 64);   // wave-uniform
+  lstm_gptr_t Ahi = (lstm_gptr_t)abase;
+  lstm_gptr_t Alo = Ahi + nb;
   const float* __restrict__ gates = a.gates + (int64_t)dir * 4 * H * P;
   const float* __restrict__ cst = a.cstate + (int64_t)dir * H * P;
   float* __restrict__ dG = a.dG + (int64_t)dir * 4 * H * P;
@@ -322,7 +336,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   auto frag_index = [&](int fi) { const int ot = fi >> 3, kk = fi & 7; return (ot * nks4 + (kk >> 1) * nks + (kk & 1)) * 64 + lane; };
   uint4 wh[RING], wl[RING];
 #pragma unroll
-  for (int i = 0; i < RING; ++i) { wh[i] = Ahi[frag_index(i)]; wl[i] = Alo[frag_index(i)]; }
+  for (int i = 0; i < RING; ++i) {
+    wh[i] = __builtin_bit_cast(uint4, Ahi[frag_index(i)]);
+    wl[i] = __builtin_bit_cast(uint4, Alo[frag_index(i)]);
+  }
   float dcc[16], ct[16];
   float sg[4][16], cp[16], gy[16];            // this step's saved gates / c_{prev} / incoming gradient
   float ng[4][16], ncp[16], ngy[16];          // next step's, fetched one step ahead
@@ -340,6 +357,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
   }
   for (int s = T - 1; s >= 0; --s) {            // reverse of the forward processing order
+    if (NWC) { asm volatile("" : "+s"(abase)); Ahi = (lstm_gptr_t)abase; Alo = Ahi + nb; }   // opaque base (see the forward kernel)
     const int step = T - 1 - s;                 // exchange generation
     const int t = dir == 0 ? s : T - 1 - s;
     const uint32_t o0 = ubase + (uint32_t)(t * Bn);
@@ -409,7 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           bl[2 * g + ksl] = hh ? make_uint4(rl[0], rl[1], x1l[0], x1l[1]) : make_uint4(x0l[0], x0l[1], rl[0], rl[1]);
         }
       uint64_t* gw = xch + (step & 1) * bufw + ub * 512;            // + ot * nwc * 512 (consumer ot, producer ub)
-      for (int f0 = 0; f0 < F; f0 += RING) {
+      auto round = [&](int f0) {
         f32x16 acc[TPC];
 #pragma unroll
         for (int tp = 0; tp < TPC; ++tp)
@@ -433,8 +451,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const int i = tp * 8 + kk;
             int fn = f0 + i + RING;                                 // the slot's next occupant (wraps into the next step)
             fn = fn >= F ? fn - F : fn;
-            wh[i] = Ahi[frag_index(fn)];
-            wl[i] = Alo[frag_index(fn)];
+            wh[i] = __builtin_bit_cast(uint4, Ahi[frag_index(fn)]);
+            wl[i] = __builtin_bit_cast(uint4, Alo[frag_index(fn)]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -449,6 +467,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             __hip_atomic_store(d + j * 128 + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+      };
+      if (NWC) {
+#pragma unroll
+        for (int f0 = 0; f0 < 8 * NWC; f0 += RING) round(f0);
+      } else {
+        for (int f0 = 0; f0 < F; f0 += RING) round(f0);
       }
       lstm_arrive(ctr, lane);
     }
@@ -481,8 +505,8 @@ static int lstm_max_clusters(int H) {
   int dev = 0, ncu = 0, occ_f = 0, occ_b = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_fwd_kernel<4>, 64, lstm_smem_bytes(H)) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bwd_kernel<2>, 64, lstm_smem_bytes(H)) != hipSuccess)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_fwd_kernel<4, 0>, 64, lstm_smem_bytes(H)) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bwd_kernel<2, 0>, 64, lstm_smem_bytes(H)) != hipSuccess)
     return 0;
   const int occ = occ_f < occ_b ? occ_f : occ_b;
   int waves = ncu * occ;
@@ -546,7 +570,10 @@ extern "C" int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_
   LstmArgs a{};
   a.xp = xp; a.packA = reinterpret_cast<const uint4*>(pack); a.out = out; a.gates = gates; a.cstate = cstate;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
-  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4>, a, ws, stream) : lstm_launch(lstm_fwd_kernel<2>, a, ws, stream);
+  if (H == 192) return lstm_launch(lstm_fwd_kernel<4, 12>, a, ws, stream);     // HDemucs DConv widths and Open-Unmix: unrolled k loop
+  if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16>, a, ws, stream);
+  if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24>, a, ws, stream);
+  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0>, a, ws, stream) : lstm_launch(lstm_fwd_kernel<2, 0>, a, ws, stream);
 }
 
 extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
@@ -557,5 +584,6 @@ extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* ga
   a.gout = gout; a.packA = reinterpret_cast<const uint4*>(pack); a.gates = const_cast<float*>(gates);
   a.cstate = const_cast<float*>(cstate); a.dG = dG;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
-  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1>, a, ws, stream);
+  // (the unrolled NWC forms of the backward kernel spill at 512 registers: only the runtime form is instantiated)
+  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1, 0>, a, ws, stream);
 }

@@ -65,6 +65,6 @@ for n, i, t in records:
     agg[n][0] += 1; agg[n][1] += t
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"  {n:24s} {c:5d} calls {t:9.2f} ms {100 * t / tot:5.1f}%")
-print("--- top 70 launches")
-for n, i, t in sorted(records, key=lambda r: -r[2])[:70]:
+print("--- top launches")
+for n, i, t in sorted(records, key=lambda r: -r[2])[:int(os.environ.get("RFX_TOP", "70"))]:
     print(f"{t:8.3f} ms  {n:20s} {i}")
