@@ -65,6 +65,12 @@ typedef struct rfx_gemm_desc {
   int32_t Mpad, Kpad;    /* packed-A geometry: A is [Kpad][Mpad], Mpad%4==0, Kpad%16==0 */
   int32_t out_a0, out_b0, out_sa, out_sb;
   int32_t R;             /* channel tiles (32 rows) per wave chosen by the planner: rfx_gemm_pick_r(M, K); 0 = thin path */
+  /* Phase-merged output (mg_log > 0): the G = 2^mg_log stride phases of a transposed convolution (or of the input
+   * gradient of a strided convolution) run as ONE GEMM with rows m = channel*G + phase, so the gathers are shared by G
+   * times more MFMA work.  Row m, position index i on axis mg_axis (0 = A, 1 = B) is stored at channel m >> mg_log,
+   * axis index i*G + (m & (G-1)) + mg_off if that lies in [0, mg_len); bias is indexed by the channel.  Epilogue
+   * options other than bias / act are not available in this mode, nor is the thin (M <= 8) path. */
+  int32_t mg_log, mg_axis, mg_len, mg_off;
   int64_t in_ns, in_as, in_bs;
   int64_t out_ns, out_cs, out_as, out_bs;
 } rfx_gemm_desc;

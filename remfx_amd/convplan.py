@@ -68,6 +68,10 @@ class GemmPlan:
     Mpad: int = 0
     Kpad: int = 0
     R: int = 0
+    mg_log: int = 0
+    mg_axis: int = 0
+    mg_len: int = 0
+    mg_off: int = 0
     extra: dict = field(default_factory=dict)
 
     def finalize(self, bias_row=False):
@@ -239,3 +243,26 @@ def shift_plan(xshape, xstrides, M, shift, oshape, ostrides):
                  in_ns=ns, in_as=as_, in_bs=bs, out_ns=on, out_cs=oc, out_as=oa, out_bs=ob,
                  ktab=ktab, woff=ci.copy(), w_ms=Cin)
     return p.finalize()
+
+
+def merged_phase_plan(inshape, instrides, rows, axis, G, J, off, out_len, ostrides):
+    """All G stride phases of a transposed convolution / strided-conv input gradient as ONE GEMM.
+
+    The operand `in` (N, Cin, IA, IB) is correlated with J = K/G taps along `axis` (full correlation: positions
+    i = 0 .. I+J-2, tap t reads in[i + t - (J-1)]); `rows` = G * Cout output rows ordered (channel, phase).  Row
+    (c, q) of position i lands at output axis index i*G + q + off (rfx_gemm_desc.mg_*).  The caller supplies the
+    weight as a dense (rows, Cin, J) tensor.  Positions are extended so that every output index below out_len is
+    written (taps outside the operand read as zero)."""
+    N, Cin, IA, IB = inshape
+    I = (IA, IB)[axis]
+    npos = max(I + J - 1, -(-(out_len - off) // G))
+    K = (J, 1) if axis == 0 else (1, J)
+    pad = (J - 1, 0) if axis == 0 else (0, J - 1)
+    p = conv_fwd_plan(inshape, instrides, (rows, Cin) + K, (1, 1), pad, (1, 1), ostrides)
+    if axis == 0:
+        p.OA = npos
+    else:
+        p.OB = npos
+    p.mg_log, p.mg_axis, p.mg_len, p.mg_off = int(G).bit_length() - 1, axis, out_len, off
+    p.extra["out_shape"] = None
+    return p

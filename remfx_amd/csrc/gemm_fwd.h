@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          bv[mt][r] = e.bias[m < d.M ? m : d.M - 1];
+          bv[mt][r] = e.bias[(m < d.M ? m : d.M - 1) >> d.mg_log];     // merged phases: bias per channel
         }
 #pragma unroll
       for (int mt = 0; mt < R; ++mt)
@@ -467,6 +467,26 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
         }
       }
     }
+    return;
+  }
+  if (d.mg_log) {
+    // phase-merged store (see rfx_gemm_desc.mg_*): row m = channel*G + phase, position index i on the merged axis ->
+    // axis index i*G + phase + mg_off.  A lane's 4 consecutive rows (r & 3) are the 4 phases of one channel when G = 4:
+    // consecutive output samples, and the 32 lanes cover 32 consecutive position indices -> full lines per wave.
+    const int G1 = (1 << d.mg_log) - 1;
+    const int pos = d.mg_axis ? b : a;
+    const int64_t other = d.mg_axis ? (int64_t)(a * d.out_sa + d.out_a0) * d.out_as : (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
+    const int64_t st = d.mg_axis ? d.out_bs : d.out_as;
+    float* ob = g.out + (int64_t)n * d.out_ns + other;
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int idx = (pos << d.mg_log) + (m & G1) + d.mg_off;
+        if (c.jvalid && m < d.M && (unsigned)idx < (unsigned)d.mg_len)
+          ob[(int64_t)(m >> d.mg_log) * d.out_cs + (int64_t)idx * st] = acc[mt][r];
+      }
     return;
   }
   float s1 = 0.f, s2 = 0.f;      // optional per-sample moments of the stored values (GroupNorm(1, C) statistics)

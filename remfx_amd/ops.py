@@ -136,9 +136,43 @@ def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=No
     return out
 
 
+def _merge_axis(ksize, stride, padding, dilation):
+    """Axis along which the stride phases can be merged into one GEMM (convplan.merged_phase_plan), or None:
+    exactly one strided axis with K % S == 0, S a power of two, no dilation; the other axis a plain 1-tap pass."""
+    if tuple(dilation) != (1, 1):
+        return None
+    for ax in (0, 1):
+        o = 1 - ax
+        S, K = stride[ax], ksize[ax]
+        if (S >= 2 and (S & (S - 1)) == 0 and K % S == 0 and stride[o] == 1 and ksize[o] == 1 and padding[o] == 0):
+            return ax
+    return None
+
+
+def _merged_weight(w_oik, ax, S):
+    """(O, I, KA, KB) correlation weight -> (O*S, I, J taps) rows ordered (o, phase), taps in gather order."""
+    O, I = w_oik.shape[:2]
+    J = w_oik.shape[2 + ax] // S
+    wm = w_oik.reshape(O, I, J, S).flip(2).permute(0, 3, 1, 2).reshape(O * S, I, J)      # [o*S+q][i][t] = w[o][i][q + S*(J-1-t)]
+    return (wm.unsqueeze(3) if ax == 0 else wm.unsqueeze(2)).contiguous(), J
+
+
+def _merged_launch(inp, wm, ax, S, J, off, out, bias=None):
+    key = _key("mg", inp.shape, inp.stride(), wm.shape, ax, S, off, out.shape, out.stride())
+    dp = _plans(key, inp.device, lambda: convplan.merged_phase_plan(
+        tuple(inp.shape), inp.stride(), wm.shape[0], ax, S, J, off, out.shape[2 + ax], out.stride()))
+    gemm_fwd(dp, pack_a(dp, wm), inp, out, bias=bias)
+    return out
+
+
 def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None):
     if dx is None:
         dx = torch.empty_strided(xshape, xstrides, device=g.device, dtype=torch.float32)
+    ax = _merge_axis(w.shape[2:], stride, padding, dilation)
+    if ax is not None and w.shape[1] * stride[ax] > 8:
+        # dx[ci][o] = sum g[co][i] w[co][ci][kk], o = S*i + kk - P: all S phases of o as rows (ci, q) of one GEMM over g
+        wm, J = _merged_weight(w.transpose(0, 1), ax, stride[ax])
+        return _merged_launch(g, wm, ax, stride[ax], J, -padding[ax], dx)
     key = _key("cd", xshape, xstrides, w.shape, stride, padding, dilation, g.shape, g.stride())
     dps = _plans(key, g.device, lambda: convplan.conv_dgrad_plans(
         tuple(xshape), tuple(xstrides), tuple(w.shape), stride, padding, dilation, tuple(g.shape), g.stride()))
@@ -200,6 +234,12 @@ def convT2d_forward(x, w, bias, stride, dilation, crop_lo, out_len, act=None):
     N, Cin, IA, IB = x.shape
     _, Cout, KA, KB = w.shape
     out = torch.empty((N, Cout, out_len[0], out_len[1]), device=x.device, dtype=torch.float32)
+    ax = _merge_axis(w.shape[2:], stride, (0, 0), dilation)
+    if (ax is not None and act is None and Cout * stride[ax] > 8 and crop_lo[1 - ax] == 0
+            and out_len[1 - ax] == x.shape[3 - ax]):
+        # y[co][o] = sum x[ci][i] w[ci][co][kk], o = S*i + kk: the S phases of o as rows (co, q) of one GEMM over x
+        wm, J = _merged_weight(w.transpose(0, 1), ax, stride[ax])
+        return _merged_launch(x, wm, ax, stride[ax], J, -crop_lo[ax], out, bias=bias)
     key = _key("tf", x.shape, x.stride(), w.shape, stride, dilation, crop_lo, out_len, out.stride())
     dps = _plans(key, x.device, lambda: convplan.convT_fwd_plans(
         tuple(x.shape), x.stride(), tuple(w.shape), stride, dilation, crop_lo, out_len, out.stride()))
