@@ -32,6 +32,8 @@ CASES = [
     (12, 7, (9, 18), (5, 3), (2, 1), (2, 1), (1, 1), 2),         # thin M<=8
     (40, 2, (1, 700), (1, 1), (1, 1), (0, 0), (1, 1), 3),        # thin 1x1
     (96, 192, (8, 64), (1, 1), (1, 1), (0, 0), (1, 1), 2),       # 1x1 rewrite
+    (16, 24, (1, 47), (1, 8), (1, 4), (0, 2), (1, 1), 2),        # merged-phase dgrad: tail inputs no window covers
+    (10, 12, (45, 3), (4, 1), (2, 1), (1, 0), (1, 1), 1),        # merged-phase dgrad on the A axis, stride 2
 ]
 
 
@@ -66,6 +68,8 @@ TCASES = [
     (20, 45, (9, 17), (5, 3), (2, 1), (2, 1), (2, 1), 2),
     (12, 9, (6, 7), (7, 5), (2, 2), (3, 2), (3, 2), 2),
     (40, 33, (1, 50), (8, 1), (4, 1), (0, 0), (0, 0), 2),
+    (48, 24, (1, 37), (1, 8), (1, 4), (0, 3), (0, 1), 2),       # merged phases, crop not a multiple of the stride
+    (6, 5, (3, 21), (1, 16), (1, 8), (0, 5), (0, 2), 1),        # stride 8, two taps per phase
 ]
 
 
