@@ -371,7 +371,10 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   const int mt = (d->M + 64 * tm - 1) / (64 * tm), kt = (d->K + 64 * tk - 1) / (64 * tk);
   // aim for ~2048 workgroups; each should still see >= 16 position tiles
   int splits = max(1, 2048 / (mt * kt));
-  splits = min(splits, max(1, w.total_tiles / 64));
+  // >= 64 position tiles per workgroup when there is plenty of work; short sequences (LSTM / attention projections,
+  // P ~ 8-38 k positions) would otherwise launch a few dozen workgroups on 256 CUs: go down to 16 tiles there
+  const int min_tiles = (int64_t)mt * kt * (w.total_tiles / 64) >= 512 ? 64 : 16;
+  splits = min(splits, max(1, w.total_tiles / min_tiles));
   w.tiles_per_block = (w.total_tiles + splits - 1) / splits;
   splits = (w.total_tiles + w.tiles_per_block - 1) / w.tiles_per_block;
   w.kt = kt; w.mt = mt; w.splits = splits;
