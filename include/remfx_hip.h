@@ -97,7 +97,7 @@ typedef struct rfx_epilogue {
   /* > 1: stat_sums is [N][stat_slots][2] and workgroups spread their atomics over the slots (power of two): a sample whose
    * positions span thousands of workgroups would otherwise serialise them on two addresses.  rfx_groupnorm_fwd takes the
    * same count in sums_given and adds the slots up. */
-  int32_t stat_slots;
+  int32_t stat_slots;     /* in bwd mode the same count applies to gparam: [stat_slots][M] partial sums */
 } rfx_epilogue;
 
 /* Arithmetic of the MFMA gather-GEMM.  RFX_PREC_F32: v_mfma_f32_32x32x2_f32, exact fp32 products.

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void gemm_thin_fwd_kernel(const FwdArgs g) {
       if (e.bwd) {
         const float s = (e.act == RFX_ACT_PRELU) ? e.act_param[m] : 0.f;
         outp[(int64_t)m * d.out_cs] = r * rfx_act_grad(v, e.act, s);
-        if (e.gparam && v < 0.f) atomicAdd(e.gparam + m, r * v);
+        if (e.gparam && v < 0.f)
+          atomicAdd(e.gparam + (int64_t)(e.stat_slots > 1 ? blockIdx.x & (e.stat_slots - 1) : 0) * d.M + m, r * v);
       } else {
         v += r;
         if (e.act2 != RFX_ACT_NONE) v = rfx_act_apply(v, e.act2, 0.f);

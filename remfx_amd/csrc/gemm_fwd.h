@@ -463,7 +463,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
         if (e.gparam) {   // reduce over the 32 position lanes of this half-wave
 #pragma unroll
           for (int o = 16; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
-          if (l31 == 0 && m < d.M) atomicAdd(e.gparam + m, gs);
+          // stat_slots > 1: gparam is [slots][M] partial sums (the caller adds them up): every wave of every
+          // workgroup adds into the same M addresses otherwise (2.6e5-way contention per address on the TCN shapes)
+          if (l31 == 0 && m < d.M)
+            atomicAdd(e.gparam + (int64_t)(e.stat_slots > 1 ? (pw * 4 + wave) & (e.stat_slots - 1) : 0) * d.M + m, gs);
         }
       }
     }

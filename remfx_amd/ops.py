@@ -94,6 +94,8 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
     e.gparam = gparam.data_ptr() if gparam is not None else None
     e.stat_sums = stat_sums.data_ptr() if stat_sums is not None else None
     e.stat_slots = stat_sums.shape[1] if (stat_sums is not None and stat_sums.dim() == 3) else 1
+    if gparam is not None and gparam.dim() == 2:          # [slots][M] partial sums of the slope gradient
+        e.stat_slots = gparam.shape[0]
     if dp2 is not None:
         a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.ktab), dp2.p.K, dp2.p.Kpad
     else:

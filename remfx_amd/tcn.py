@@ -87,7 +87,7 @@ class TCNBlockFn(torch.autograd.Function):
         (dp1, dp2), Lout, start = _block_plans(x4, Cout, ksize, dilation, causal)
         # 1. re-materialise pre = conv1(x)+b; g1 = g * prelu'(pre); dslope = sum g * min(pre, 0)
         g1 = torch.empty_like(g)
-        dslope = torch.zeros_like(slope)
+        dslope = torch.zeros((64, slope.numel()), device=x.device, dtype=torch.float32)   # partial sums, see gemm_fwd.h
         ops.gemm_fwd(dp1, ops.pack_a(dp1, w1.contiguous()), x4, g1, bias=b1, act="prelu", act_param=slope,
                      res=g4, bwd=True, gparam=dslope)
         g14 = g1.unsqueeze(2)
@@ -122,7 +122,7 @@ class TCNBlockFn(torch.autograd.Function):
             dpd, dpr = ops._plans(key, x.device, build)
             ops.gemm_fwd(dpd, ops.pack_a(dpd, w1.contiguous()), g14, dx4, dp2=dpr,
                          apack2=ops.pack_a(dpr, wres.contiguous()), in2=g4)
-        return dx, dw1.view_as(w1), db1, dslope, dwres, None, None
+        return dx, dw1.view_as(w1), db1, dslope.sum(0).view_as(slope), dwres, None, None
 
 
 class TCNBlock(nn.Module):
