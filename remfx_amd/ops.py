@@ -146,7 +146,7 @@ def _merge_axis(ksize, stride, padding, dilation):
     for ax in (0, 1):
         o = 1 - ax
         S, K = stride[ax], ksize[ax]
-        if (2 <= S <= 16 and (S & (S - 1)) == 0 and K % S == 0 and stride[o] == 1 and ksize[o] == 1 and padding[o] == 0):
+        if (2 <= S <= 256 and (S & (S - 1)) == 0 and K % S == 0 and stride[o] == 1 and ksize[o] == 1 and padding[o] == 0):
             return ax
     return None
 
