@@ -6,7 +6,7 @@ from remfx_amd import _lib, lstm
 from remfx_amd.ops import _ptr, _stream
 
 L = _lib.lib()
-shapes = [(192, 200, 1536), (192, 200, 192), (384, 128, 64), (256, 64, 16)]
+shapes = [(192, 200, 1536), (192, 200, 192), (384, 128, 64), (256, 64, 16), (256, 257, 4)]
 for H, T, Bn in shapes:
     P = T * Bn
     w = torch.randn(4 * H, H, device="cuda") * 0.05
