@@ -37,7 +37,21 @@ def emulate_fwd(plan, w_flat, x_flat, out_flat, bias=None):
         B = _gather(plan, x_flat, n)[:nrows]
         o = A.t().double() @ B.double()
         if bias is not None:
-            o = o + bias[:, None].double()
+            o = o + bias[m >> getattr(plan, "mg_log", 0)][:, None].double()
+        if getattr(plan, "mg_log", 0):
+            # phase-merged store (rfx_gemm_desc.mg_*): row m = channel*G + phase, position i -> axis index i*G + phase + off
+            G = 1 << plan.mg_log
+            P = plan.OA * plan.OB
+            j = torch.arange(P)
+            a, b = j // plan.OB, j % plan.OB
+            pos = b if plan.mg_axis else a
+            idx = pos[None, :] * G + (m[:, None] & (G - 1)) + plan.mg_off                      # [M, P]
+            ok = (idx >= 0) & (idx < plan.mg_len)
+            other = ((a * plan.out_sa + plan.out_a0) * plan.out_as) if plan.mg_axis else ((b * plan.out_sb + plan.out_b0) * plan.out_bs)
+            st = plan.out_bs if plan.mg_axis else plan.out_as
+            addr = n * plan.out_ns + (m[:, None] >> plan.mg_log) * plan.out_cs + other[None, :] + idx * st
+            out_flat[addr[ok]] = o.float()[ok]
+            continue
         oi = _out_index(plan, n)
         out_flat[(m[:, None] * plan.out_cs + oi[None, :])] = o.float()
     return out_flat

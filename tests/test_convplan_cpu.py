@@ -110,3 +110,60 @@ def test_strided_views_and_pick_r():
                  (135, 3), (192, 3), (256, 4), (1536, 4)]:
         assert convplan.pick_r(M) == r, (M, convplan.pick_r(M))
         assert convplan.mpad_for(M) % 4 == 0 and convplan.mpad_for(M) >= M
+
+
+MERGED_T = [
+    # Cin, Cout, (IA, IB), (KA, KB), stride, crop_lo, crop_hi, N
+    (6, 5, (1, 37), (1, 8), (1, 4), (0, 3), (0, 1), 2),
+    (4, 3, (9, 5), (8, 1), (4, 1), (2, 0), (2, 0), 1),
+    (3, 2, (1, 11), (1, 16), (1, 8), (0, 5), (0, 2), 1),
+    (5, 1, (1, 9), (1, 1024), (1, 256), (0, 0), (0, 0), 1),      # DCUNet synthesis filterbank geometry
+]
+
+
+@pytest.mark.parametrize("case", MERGED_T)
+def test_merged_phase_transposed_conv(case):
+    """All stride phases of a transposed convolution as ONE GEMM (convplan.merged_phase_plan + ops._merged_weight)."""
+    from remfx_amd import ops
+    Cin, Cout, (IA, IB), (KA, KB), stride, lo, hi, N = case
+    torch.manual_seed(0)
+    x = torch.randn(N, Cin, IA, IB)
+    w = torch.randn(Cin, Cout, KA, KB)
+    bias = torch.randn(Cout)
+    full = F.conv_transpose2d(x, w, bias, stride)
+    ref = full[:, :, lo[0]:full.shape[2] - hi[0], lo[1]:full.shape[3] - hi[1]]
+    ax = ops._merge_axis(w.shape[2:], stride, (0, 0), (1, 1))
+    assert ax is not None
+    wm, J = ops._merged_weight(w.transpose(0, 1), ax, stride[ax])
+    out = torch.full(ref.shape, float("nan"))
+    plan = convplan.merged_phase_plan(tuple(x.shape), x.stride(), wm.shape[0], ax, stride[ax], J, -lo[ax],
+                                      out.shape[2 + ax], out.stride())
+    emulate_fwd(plan, wm.reshape(-1), x.reshape(-1), out.view(-1), bias)
+    assert torch.allclose(out, ref, atol=1e-4), float((out - ref).abs().max())
+
+
+MERGED_D = [
+    # Cin, Cout, (IA, IB), (KA, KB), stride, padding, N
+    (3, 6, (1, 47), (1, 8), (1, 4), (0, 2), 2),        # inputs past the last window get a zero gradient
+    (2, 4, (45, 3), (4, 1), (2, 1), (1, 0), 1),
+]
+
+
+@pytest.mark.parametrize("case", MERGED_D)
+def test_merged_phase_conv_input_gradient(case):
+    from remfx_amd import ops
+    Cin, Cout, (IA, IB), (KA, KB), stride, padding, N = case
+    torch.manual_seed(1)
+    x = torch.randn(N, Cin, IA, IB, requires_grad=True)
+    w = torch.randn(Cout, Cin, KA, KB)
+    y = F.conv2d(x, w, None, stride, padding)
+    g = torch.randn_like(y)
+    (ref,) = torch.autograd.grad(y, x, g)
+    ax = ops._merge_axis(w.shape[2:], stride, padding, (1, 1))
+    assert ax is not None
+    wm, J = ops._merged_weight(w.transpose(0, 1), ax, stride[ax])
+    dx = torch.full(ref.shape, float("nan"))
+    plan = convplan.merged_phase_plan(tuple(g.shape), g.stride(), wm.shape[0], ax, stride[ax], J, -padding[ax],
+                                      dx.shape[2 + ax], dx.stride())
+    emulate_fwd(plan, wm.reshape(-1), g.reshape(-1), dx.view(-1))
+    assert torch.allclose(dx, ref, atol=1e-4), float((dx - ref).abs().max())
