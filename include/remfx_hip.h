@@ -106,8 +106,8 @@ typedef struct rfx_epilogue {
  * product, 3/16 of the fp32 MFMA cost.  The packed buffer has the same size in both modes. */
 enum rfx_gemm_prec { RFX_PREC_F32 = 0, RFX_PREC_BF16X3 = 1 };
 
-/* A[k][m] = w[m*w_ms + woff[k]]  (k < K), zero padded to [Kpad + 32][Mpad]: the packed
- * matrix carries two extra all-zero K steps and every ktab passed to rfx_gemm_fwd
+/* A[k][m] = w[m*w_ms + woff[k]]  (k < K), zero padded to [Kpad + 64][Mpad]: the packed
+ * matrix carries four extra all-zero K steps and every ktab passed to rfx_gemm_fwd
  * carries Kpad + 96 rows (the tail rows invalid: da = -2^30) so that the MFMA kernel's
  * operand prefetch is branch-free. */
 int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,

@@ -9,7 +9,7 @@
 __global__ void pack_a_kernel(const float* __restrict__ w, const int32_t* __restrict__ woff,
                               int64_t w_ms, int M, int K, int Mpad, int Kpad,
                               float* __restrict__ apack) {
-  const int64_t total = (int64_t)(Kpad + 32) * Mpad;   // two extra all-zero K steps (branch-free prefetch)
+  const int64_t total = (int64_t)(Kpad + 64) * Mpad;   // four extra all-zero K steps (branch-free prefetch)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(i / Mpad), m = (int)(i % Mpad);
@@ -20,11 +20,11 @@ __global__ void pack_a_kernel(const float* __restrict__ w, const int32_t* __rest
 }
 
 
-// bf16x3 operand layout: two arrays (hi, lo) of [Kpad/8 + 4][Mpad] 16-byte cells, a cell = the 8
+// bf16x3 operand layout: two arrays (hi, lo) of [Kpad/8 + 8][Mpad] 16-byte cells, a cell = the 8
 // consecutive-k bf16 values of one output row = exactly one lane's MFMA A fragment.
 __global__ void pack_a_bf3_kernel(const float* __restrict__ w, const int32_t* __restrict__ woff,
                                   int64_t w_ms, int M, int K, int Mpad, int Kpad, uint4* __restrict__ apack) {
-  const int64_t cells = (int64_t)(Kpad / 8 + 4) * Mpad;
+  const int64_t cells = (int64_t)(Kpad / 8 + 8) * Mpad;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int k8 = (int)(i / Mpad), m = (int)(i % Mpad);
@@ -141,14 +141,14 @@ extern "C" int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int
                           int32_t Mpad, int32_t Kpad, int32_t prec, float* apack, void* stream) {
   if (!w || !woff || !apack || M <= 0 || K < 0 || Mpad < M || Kpad < K) return -1;
   if (prec == 1) {
-    const int64_t cells = (int64_t)(Kpad / 8 + 4) * Mpad;
+    const int64_t cells = (int64_t)(Kpad / 8 + 8) * Mpad;
     const int grid = (int)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_a_bf3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, woff, w_ms, M, K, Mpad,
                        Kpad, reinterpret_cast<uint4*>(apack));
     RFX_CHECK_LAUNCH();
     return 0;
   }
-  const int64_t total = (int64_t)(Kpad + 32) * Mpad;
+  const int64_t total = (int64_t)(Kpad + 64) * Mpad;
   if (total == 0) return 0;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_a_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, woff, w_ms, M, K,

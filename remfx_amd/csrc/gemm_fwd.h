@@ -260,29 +260,36 @@ __device__ __forceinline__ void stage_a_bf3_store(uint4* as, int tid, const ASta
   if (NV > 256) as[tid + 256 < NV ? tid + 256 : NV - 1] = s.v1;
 }
 
-template <int R>
+// One 16-deep K step of the bf16x3 pipeline.  LDS holds the A tiles of TWO K steps per buffer, so the workgroup
+// barrier comes only after every odd step (SUB == 1): with one barrier per K step the four waves re-synchronised every
+// ~0.2 us of matrix work and 40 % of the wave time was parked (PMC); a race-y run with half the barriers
+// bounded the gain at 3 % of the Demucs step.  Per step ks:
+//   LDS -> fragments of A(ks) from buffer (ks/2)&1, half SUB;
+//   global -> registers: table row of step ks+5, A tile of step ks+4 (into the register set that held A(ks+2));
+//   gathers of step ks+3 (the 4-deep ring);  MFMAs;
+//   registers -> LDS: A(ks+2) into the OTHER buffer, table row into ring slot (ks+5)&7;  barrier if SUB.
+// Everything written in steps {2D, 2D+1} is first read in step 2D+2, i.e. behind the barrier that ends step 2D+1.
+template <int R, int SUB>
 __device__ __forceinline__ void k_step_bf3(const rfx_gemm_desc& d, const uint4* __restrict__ apk,
                                            int64_t arr_stride, const int4* __restrict__ kt4, int ks, int m0,
                                            const LaneCtx& c, uint4* as, int4* kts, f32x16 (&acc)[R],
-                                           const float (&bc)[8], float (&bn)[8], const AStage& a_now,
-                                           AStage& a_next) {
+                                           const float (&bc)[8], float (&bn)[8], AStage& a_set) {
   constexpr int BM = 32 * R;
   const int tid = threadIdx.x;
   const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int cur = ks & 1;
-  const uint4* a_lds = as + cur * 4 * BM;
+  const int buf = (ks >> 1) & 1;
+  const uint4* a_lds = as + buf * 8 * BM + SUB * 4 * BM;
   uint4 ah[R], al[R];
 #pragma unroll
   for (int mt = 0; mt < R; ++mt) {
     ah[mt] = a_lds[h * BM + mt * 32 + l31];
     al[mt] = a_lds[2 * BM + h * BM + mt * 32 + l31];
   }
-  // issue order matters: vmcnt retires in order and the table row + A stage are consumed (written to LDS) at
-  // the end of THIS step, so they go first; the gathers, consumed RFX_BDIST steps later, go last and stay in flight
-  const int4 ktreg = kt4[(ks + RFX_BDIST + 1) * 16 + (tid & 15)];
-  // A tile of step ks+2 -> registers now, into LDS at the end of step ks+1 (a_now was fetched one step ago): an L2
-  // round trip is longer than one K step of MFMAs
-  a_next = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2 * (ks + 2), m0, tid);
+  // issue order matters: vmcnt retires in order; the table row is written to LDS at the end of THIS step, so it goes
+  // first; the gathers, consumed RFX_BDIST steps later, go last and stay in flight
+  const int4 ktreg = kt4[(ks + RFX_BDIST + 2) * 16 + (tid & 15)];
+  const AStage a_now = a_set;                                         // A(ks+2), fetched two steps ago
+  a_set = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2 * (ks + 4), m0, tid);
   load_b8_bf3(d, kts + ((ks + RFX_BDIST) & 7) * 16, h, c, bn);
   bf16x8 bh, bl;
   split8(bc, bh, bl);
@@ -293,53 +300,60 @@ __device__ __forceinline__ void k_step_bf3(const rfx_gemm_desc& d, const uint4* 
     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl, acc[mt], 0, 0, 0);
     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc[mt], 0, 0, 0);
   }
-  stage_a_bf3_store<R>(as + (cur ^ 1) * 4 * BM, tid, a_now);
-  kts[((ks + RFX_BDIST + 1) & 7) * 16 + (tid & 15)] = ktreg;   // every thread (same value per tid & 15)
-  __syncthreads();
+  stage_a_bf3_store<R>(as + (buf ^ 1) * 8 * BM + SUB * 4 * BM, tid, a_now);
+  kts[((ks + RFX_BDIST + 2) & 7) * 16 + (tid & 15)] = ktreg;   // every thread (same value per tid & 15)
+  if (SUB) __syncthreads();
+  else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // keep the two steps apart in the compiler too
 }
 
 template <int R>
 __device__ __forceinline__ void run_phase_bf3(const rfx_gemm_desc& d, const float* __restrict__ apack,
                                               const rfx_ktab_entry* __restrict__ ktab, int Kpad, int m0,
                                               const LaneCtx& c, float* as_f, int4* kts, f32x16 (&acc)[R]) {
+  constexpr int BM = 32 * R;
   const int tid = threadIdx.x;
   const int h = (tid & 63) >> 5;
   const int nk = Kpad / 16;
   if (nk == 0) return;
   const uint4* apk = reinterpret_cast<const uint4*>(apack);
-  const int64_t arr_stride = (int64_t)(Kpad / 8 + 4) * d.Mpad;
+  const int64_t arr_stride = (int64_t)(Kpad / 8 + 8) * d.Mpad;
   uint4* as = reinterpret_cast<uint4*>(as_f);
   const int4* kt4 = reinterpret_cast<const int4*>(ktab);
+  __syncthreads();            // a previous phase (two-phase launches) may still be reading the LDS buffers
   float b0[8], b1[8];
-  const AStage areg = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 0, m0, tid);
-  if (tid < 16 * (RFX_BDIST + 1)) kts[tid] = kt4[tid];   // table rows of the first K steps (table is padded)
-  stage_a_bf3_store<R>(as, tid, areg);
+  {
+    const AStage s0 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 0, m0, tid);
+    const AStage s1 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2, m0, tid);
+    if (tid < 16 * (RFX_BDIST + 2)) kts[tid] = kt4[tid];   // table rows of the first K steps (table is padded)
+    stage_a_bf3_store<R>(as, tid, s0);                       // A(0), A(1) -> buffer 0
+    stage_a_bf3_store<R>(as + 4 * BM, tid, s1);
+  }
   __syncthreads();
   // the gathers run RFX_BDIST K steps ahead of the MFMAs: one K step is ~0.2 us of matrix work, a gather that
   // misses L2 takes ~1-2 us, and only two waves share a SIMD, so a single step of look-ahead left the kernel
   // latency-bound (19 % MFMA utilisation in the r01 traces)
   float b2[8], b3[8];
-  AStage a1;
-  AStage a0 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2, m0, tid);          // A tile of step 1
+  AStage a0 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 4, m0, tid);          // A(2), A(3): even / odd register set
+  AStage a1 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 6, m0, tid);
   load_b8_bf3(d, kts, h, c, b0);
   load_b8_bf3(d, kts + 16, h, c, b1);
   load_b8_bf3(d, kts + 32, h, c, b2);
   int ks = 0;
   for (; ks + 3 < nk; ks += 4) {
-    k_step_bf3<R>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b3, a0, a1);
-    k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0, a1, a0);
-    k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 2, m0, c, as, kts, acc, b2, b1, a0, a1);
-    k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 3, m0, c, as, kts, acc, b3, b2, a1, a0);
+    k_step_bf3<R, 0>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b3, a0);
+    k_step_bf3<R, 1>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0, a1);
+    k_step_bf3<R, 0>(d, apk, arr_stride, kt4, ks + 2, m0, c, as, kts, acc, b2, b1, a0);
+    k_step_bf3<R, 1>(d, apk, arr_stride, kt4, ks + 3, m0, c, as, kts, acc, b3, b2, a1);
   }
-  if (ks < nk) k_step_bf3<R>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b3, a0, a1);
-  if (ks + 1 < nk) k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0, a1, a0);
-  if (ks + 2 < nk) k_step_bf3<R>(d, apk, arr_stride, kt4, ks + 2, m0, c, as, kts, acc, b2, b1, a0, a1);
+  if (ks < nk) k_step_bf3<R, 0>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b3, a0);
+  if (ks + 1 < nk) k_step_bf3<R, 1>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0, a1);
+  if (ks + 2 < nk) k_step_bf3<R, 0>(d, apk, arr_stride, kt4, ks + 2, m0, c, as, kts, acc, b2, b1, a0);
 }
 
 template <int R, bool BF3>
 __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R;
-  __shared__ __attribute__((aligned(16))) float as[2 * 16 * BM];
+  __shared__ __attribute__((aligned(16))) float as[BF3 ? 4 * 16 * BM : 2 * 16 * BM];   // bf16x3: 2 buffers x 2 K steps
   __shared__ __attribute__((aligned(16))) int4 kts[8 * 16];
   const rfx_gemm_desc& d = g.d;
   const int tid = threadIdx.x;

@@ -72,7 +72,7 @@ def pack_a(dp, w):
     """Gather the weight tensor into the packed [Kpad][Mpad] A matrix of a plan."""
     p = dp.p
     prec = GEMM_PREC if p.M > 8 else 0          # thin path is always fp32
-    apack = torch.empty((p.Kpad + 32, p.Mpad), device=w.device, dtype=torch.float32)
+    apack = torch.empty((p.Kpad + 64, p.Mpad), device=w.device, dtype=torch.float32)
     nrows = p.extra["n_weight_rows"]
     if True:
         check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff), p.w_ms, p.M, nrows, p.Mpad, p.Kpad, prec,
