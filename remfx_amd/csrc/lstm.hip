@@ -73,7 +73,7 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, int H, uint4* __
 }
 
 
-#define RFX_LSTM_MAX_WAVES 1024
+#define RFX_LSTM_MAX_WAVES 768    /* of 1024 one-wave-per-SIMD slots: leaves a quarter of the machine to concurrent kernels (RCCL) */
 #define RFX_LSTM_SPIN_LIMIT (1 << 22)
 
 struct LstmArgs {
