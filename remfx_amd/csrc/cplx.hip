@@ -37,37 +37,47 @@ __global__ __launch_bounds__(256) void cplx_moments_kernel(const float* __restri
 }
 
 // gx += d(sum_q coef_q * moment_q)/dx :  gxr = c0 + 2 c2 xr + c3 xi ; gxi = c1 + 2 c4 xi + c3 xr
-__global__ void cplx_moments_bwd_kernel(const float* __restrict__ x, const float* __restrict__ coef, int N, int C,
-                                        int64_t S, float* __restrict__ gx) {
-  const int64_t total = (int64_t)N * C * S;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t s = i % S, r = i / S;
-    const int c = (int)(r % C), n = (int)(r / C);
-    const int64_t ir = ((int64_t)n * 2 * C + c) * S + s, ii = ir + (int64_t)C * S;
-    const float a = x[ir], b = x[ii];
-    gx[ir] += coef[c] + 2.f * coef[2 * C + c] * a + coef[3 * C + c] * b;
-    gx[ii] += coef[C + c] + 2.f * coef[4 * C + c] * b + coef[3 * C + c] * a;
+__global__ __launch_bounds__(256) void cplx_moments_bwd_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                               int N, int C, int64_t S, int nchunks,
+                                                               float* __restrict__ gx) {
+  // one workgroup = one (n, c) row chunk (no per-element index decoding, coefficients wave-uniform)
+  const int sc = blockIdx.x % nchunks;
+  const int r = blockIdx.x / nchunks;
+  const int c = r % C, n = r / C;
+  const float k0 = coef[c], k1 = coef[C + c], k2 = coef[2 * C + c], k3 = coef[3 * C + c], k4 = coef[4 * C + c];
+  const int64_t base = ((int64_t)n * 2 * C + c) * S, im = (int64_t)C * S;
+  const int64_t s0 = (int64_t)sc * CX_CHUNK, s1 = s0 + CX_CHUNK < S ? s0 + CX_CHUNK : S;
+  for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) {
+    const float a = x[base + s], b = x[base + im + s];
+    gx[base + s] += k0 + 2.f * k2 * a + k3 * b;
+    gx[base + im + s] += k1 + 2.f * k4 * b + k3 * a;
   }
 }
 
 // coef: (6, C) = Zrr, Zri, Zir, Zii, Br, Bi.  out may be a channel slice of a larger buffer:
 // out[n*out_ns + ch*S + s], ch in [0, 2C) with the imaginary half at out_im_off channels.
-__global__ void cplx_affine_act_kernel(const float* __restrict__ x, const float* __restrict__ coef, int N, int C,
-                                       int64_t S, float slope, float* __restrict__ out, int64_t out_ns,
-                                       int64_t out_im_off) {
-  const int64_t total = (int64_t)N * C * S;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t s = i % S, r = i / S;
-    const int c = (int)(r % C), n = (int)(r / C);
-    const int64_t ir = ((int64_t)n * 2 * C + c) * S + s;
-    const float a = x[ir], b = x[ir + (int64_t)C * S];
-    float ur = coef[c] * a + coef[C + c] * b + coef[4 * C + c];
-    float ui = coef[2 * C + c] * a + coef[3 * C + c] * b + coef[5 * C + c];
-    ur = ur >= 0.f ? ur : slope * ur;
-    ui = ui >= 0.f ? ui : slope * ui;
-    const int64_t o = (int64_t)n * out_ns + (int64_t)c * S + s;
-    out[o] = ur;
-    out[o + out_im_off * S] = ui;
+// One workgroup = one (n, c) row chunk: the six coefficients are wave-uniform and there is no index arithmetic per
+// element (the first version decoded (n, c, s) from a flat index with two 64-bit divisions per element and ran
+// VALU-bound: 0.7 ms per call in the chain-inference profile).
+__global__ __launch_bounds__(256) void cplx_affine_act_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                              int N, int C, int64_t S, int nchunks, float slope,
+                                                              float* __restrict__ out, int64_t out_ns, int64_t out_im_off) {
+  const int sc = blockIdx.x % nchunks;
+  const int r = blockIdx.x / nchunks;
+  const int c = r % C, n = r / C;
+  const float zrr = coef[c], zri = coef[C + c], zir = coef[2 * C + c], zii = coef[3 * C + c];
+  const float br = coef[4 * C + c], bi = coef[5 * C + c];
+  const float* xr = x + ((int64_t)n * 2 * C + c) * S;
+  const float* xi = xr + (int64_t)C * S;
+  float* orp = out + (int64_t)n * out_ns + (int64_t)c * S;
+  float* oip = orp + out_im_off * S;
+  const int64_t s0 = (int64_t)sc * CX_CHUNK, s1 = s0 + CX_CHUNK < S ? s0 + CX_CHUNK : S;
+  for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) {
+    const float a = xr[s], b = xi[s];
+    float ur = zrr * a + zri * b + br;
+    float ui = zir * a + zii * b + bi;
+    orp[s] = ur >= 0.f ? ur : slope * ur;
+    oip[s] = ui >= 0.f ? ui : slope * ui;
   }
 }
 
@@ -180,16 +190,21 @@ extern "C" int rfx_cplx_moments(const float* x, int32_t N, int32_t C, int64_t S,
 extern "C" int rfx_cplx_moments_bwd(const float* x, const float* coef, int32_t N, int32_t C, int64_t S, float* gx,
                                     void* stream) {
   if (!x || !coef || !gx || N <= 0 || C <= 0 || S <= 0) return -1;
-  hipLaunchKernelGGL(cplx_moments_bwd_kernel, dim3(cx_grid((int64_t)N * C * S)), dim3(256), 0, (hipStream_t)stream, x,
-                     coef, N, C, S, gx);
+  const int nchunks = (int)((S + CX_CHUNK - 1) / CX_CHUNK);
+  if ((int64_t)N * C * nchunks > 0x7fffffff) return -1;
+  hipLaunchKernelGGL(cplx_moments_bwd_kernel, dim3((unsigned)((int64_t)N * C * nchunks)), dim3(256), 0, (hipStream_t)stream, x,
+                     coef, N, C, S, nchunks, gx);
   RFX_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int rfx_cplx_affine_act_fwd(const float* x, const float* coef, int32_t N, int32_t C, int64_t S,
                                        float slope, float* out, int64_t out_ns, int64_t out_im_off, void* stream) {
   if (!x || !coef || !out || N <= 0 || C <= 0 || S <= 0) return -1;
-  hipLaunchKernelGGL(cplx_affine_act_kernel, dim3(cx_grid((int64_t)N * C * S)), dim3(256), 0, (hipStream_t)stream, x,
-                     coef, N, C, S, slope, out, out_ns, out_im_off);
+  const int nchunks = (int)((S + CX_CHUNK - 1) / CX_CHUNK);
+  const int64_t blocks = (int64_t)N * C * nchunks;
+  if (blocks > 0x7fffffff) return -1;
+  hipLaunchKernelGGL(cplx_affine_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, coef, N, C, S,
+                     nchunks, slope, out, out_ns, out_im_off);
   RFX_CHECK_LAUNCH();
   return 0;
 }
