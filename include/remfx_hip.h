@@ -98,6 +98,12 @@ typedef struct rfx_epilogue {
    * positions span thousands of workgroups would otherwise serialise them on two addresses.  rfx_groupnorm_fwd takes the
    * same count in sums_given and adds the slots up. */
   int32_t stat_slots;     /* in bwd mode the same count applies to gparam: [stat_slots][M] partial sums */
+  /* GLU fused into the store (HDemucs rewrite conv -> GLU, torchaudio HDemucs via models.py:319): the GEMM rows are the
+   * conv's 2C output channels INTERLEAVED, row 2c = channel c ("a"), row 2c+1 = channel C+c ("b"); the kernel stores
+   * the conv output in its natural channel order (needed by the backward) and glu_out[n*glu_ns + c*out_cs + pos] =
+   * a * sigmoid(b).  bias is indexed in natural channel order.  Not combined with res / act2 / stat_sums / bwd / merged. */
+  float* glu_out;
+  int64_t glu_ns;
 } rfx_epilogue;
 
 /* Arithmetic of the MFMA gather-GEMM.  RFX_PREC_F32: v_mfma_f32_32x32x2_f32, exact fp32 products.

@@ -80,7 +80,8 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("act", C.c_int32), ("act_param", C.c_void_p),
                 ("res", C.c_void_p), ("res_ns", C.c_int64), ("res_cs", C.c_int64),
                 ("res_as", C.c_int64), ("res_bs", C.c_int64), ("act2", C.c_int32), ("bwd", C.c_int32),
-                ("gparam", C.c_void_p), ("stat_sums", C.c_void_p), ("stat_slots", C.c_int32)]
+                ("gparam", C.c_void_p), ("stat_sums", C.c_void_p), ("stat_slots", C.c_int32),
+                ("glu_out", C.c_void_p), ("glu_ns", C.c_int64)]
 
 
 class StftDesc(C.Structure):

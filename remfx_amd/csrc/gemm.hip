@@ -187,6 +187,8 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   if (epi) g.e = *epi;
   else { g.e = rfx_epilogue{}; }
   if (g.e.bwd && !g.e.res) return -1;
+  if (g.e.glu_out && (d->R == 0 || (d->M & 1) || g.e.bwd || g.e.res || g.e.act2 != RFX_ACT_NONE || g.e.stat_sums || apack2 ||
+                      d->mg_log)) return -1;
   if (d->mg_log && (d->R == 0 || g.e.bwd || g.e.res || g.e.act2 != RFX_ACT_NONE || g.e.stat_sums || apack2 ||
                     d->mg_log > 8 || d->mg_axis < 0 || d->mg_axis > 1)) return -1;
   g.apack2 = apack2; g.ktab2 = ktab2; g.Kpad2 = apack2 ? Kpad2 : 0; g.in2 = in2;

@@ -403,7 +403,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          bv[mt][r] = e.bias[(m < d.M ? m : d.M - 1) >> d.mg_log];     // merged phases: bias per channel
+          const int mc = m < d.M ? m : d.M - 1;
+          // merged phases: bias per channel; fused GLU: rows interleaved (2c, 2c+1) <-> channels (c, C+c)
+          bv[mt][r] = e.bias[e.glu_out ? (mc & 1) * (d.M >> 1) + (mc >> 1) : (mc >> d.mg_log)];
         }
 #pragma unroll
       for (int mt = 0; mt < R; ++mt)
@@ -504,6 +506,27 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
         if (c.jvalid && m < d.M && (unsigned)idx < (unsigned)d.mg_len)
           ob[(int64_t)(m >> d.mg_log) * d.out_cs + (int64_t)idx * st] = acc[mt][r];
       }
+    return;
+  }
+  if (e.glu_out) {
+    // rows (r, r+1) of a lane are (a, b) of one GLU channel c = m >> 1: conv output in natural order + a * sigmoid(b)
+    const int Ch = d.M >> 1;
+    float* gl = e.glu_out + (int64_t)n * e.glu_ns + opos;
+    if (c.jvalid) {
+#pragma unroll
+      for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < d.M) {
+            const int ch = m >> 1;
+            const float a = acc[mt][r], b = acc[mt][r + 1];
+            outp[(int64_t)ch * d.out_cs] = a;
+            outp[(int64_t)(Ch + ch) * d.out_cs] = b;
+            gl[(int64_t)ch * d.out_cs] = a * rfx_sigmoid(b);
+          }
+        }
+    }
     return;
   }
   float s1 = 0.f, s2 = 0.f;      // optional per-sample moments of the stored values (GroupNorm(1, C) statistics)

@@ -202,9 +202,13 @@ class _HEncLayer(nn.Module):
             y = self.dconv(y.permute(0, 2, 1, 3).reshape(-1, C, T))
             y = y.view(B, Fr, C, T).permute(0, 2, 1, 3)
             c = self.context
+            if not isinstance(self.norm2, nn.GroupNorm):              # no norm between conv and GLU: GLU in the GEMM store
+                return ops.conv2d_glu(y, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c))
             z = ops.conv2d(y, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c))
         else:
             y = self.dconv(y)
+            if not isinstance(self.norm2, nn.GroupNorm):
+                return ops.conv1d_glu(y, self.rewrite.weight, self.rewrite.bias, 1, self.context)
             z = ops.conv1d(y, self.rewrite.weight, self.rewrite.bias, 1, self.context)
         return _norm_act(self.norm2, z, "glu")
 
@@ -235,11 +239,15 @@ class _HDecLayer(nn.Module):
         if not self.empty:
             x = nnops.add(x, skip)
             c = self.context
-            if self.freq:
-                r = ops.conv2d(x, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c))
+            if not isinstance(self.norm1, nn.GroupNorm):              # GLU in the GEMM store
+                y = (ops.conv2d_glu(x, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c)) if self.freq else
+                     ops.conv1d_glu(x, self.rewrite.weight, self.rewrite.bias, 1, c))
             else:
-                r = ops.conv1d(x, self.rewrite.weight, self.rewrite.bias, 1, c)
-            y = _norm_act(self.norm1, r, "glu")
+                if self.freq:
+                    r = ops.conv2d(x, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c))
+                else:
+                    r = ops.conv1d(x, self.rewrite.weight, self.rewrite.bias, 1, c)
+                y = _norm_act(self.norm1, r, "glu")
         else:
             y = x
             if skip is not None:

@@ -81,7 +81,7 @@ def pack_a(dp, w):
 
 
 def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, act2=None,
-             dp2=None, apack2=None, in2=None, bwd=False, gparam=None, stat_sums=None):
+             dp2=None, apack2=None, in2=None, bwd=False, gparam=None, stat_sums=None, glu_out=None):
     e = Epilogue()
     e.bias = bias.data_ptr() if bias is not None else None
     e.act = ACT[act]
@@ -96,6 +96,9 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
     e.stat_slots = stat_sums.shape[1] if (stat_sums is not None and stat_sums.dim() == 3) else 1
     if gparam is not None and gparam.dim() == 2:          # [slots][M] partial sums of the slope gradient
         e.stat_slots = gparam.shape[0]
+    if glu_out is not None:                               # fused GLU store (rows interleaved by the caller)
+        e.glu_out = glu_out.data_ptr()
+        e.glu_ns = glu_out.stride(0)
     if dp2 is not None:
         a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.ktab), dp2.p.K, dp2.p.Kpad
     else:
@@ -217,6 +220,58 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
         return dx, dw, db, None, None, None, None
+
+
+class ConvGlu2dFn(torch.autograd.Function):
+    """GLU(conv(x)) over the channel axis (HDemucs rewrite conv + GLU) with the GLU in the GEMM's store: the GEMM runs on
+    the weight rows interleaved (c, C+c) so a lane holds both halves; the conv output is still written (the backward
+    needs it) but never re-read in the forward pass."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, dilation):
+        _req(x, "x"); _req(w, "weight")
+        N, Cin, IA, IB = x.shape
+        C2, _, KA, KB = w.shape
+        Ch = C2 // 2
+        OA = convplan._out_len(IA, KA, stride[0], padding[0], dilation[0])
+        OB = convplan._out_len(IB, KB, stride[1], padding[1], dilation[1])
+        y2 = torch.empty((N, C2, OA, OB), device=x.device, dtype=torch.float32)
+        out = torch.empty((N, Ch, OA, OB), device=x.device, dtype=torch.float32)
+        key = _key("cf", x.shape, x.stride(), w.shape, stride, padding, dilation, y2.stride())
+        dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
+            tuple(x.shape), x.stride(), tuple(w.shape), stride, padding, dilation, y2.stride()))
+        wi = w.view(2, Ch, Cin, KA, KB).transpose(0, 1).reshape(C2, Cin, KA, KB)     # rows (c, half)
+        gemm_fwd(dp, pack_a(dp, wi), x, y2, bias=bias, glu_out=out)
+        ctx.save_for_backward(x, w, y2)
+        ctx.cfg = (stride, padding, dilation, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y2 = ctx.saved_tensors
+        stride, padding, dilation, has_bias = ctx.cfg
+        N, C2 = y2.shape[0], y2.shape[1]
+        S = y2.numel() // (N * C2)
+        g2 = torch.empty_like(y2)
+        check(_lib.lib().rfx_glu_bwd(_ptr(y2), _ptr(g.contiguous()), _ptr(g2), N, C2, S, _stream()), "rfx_glu_bwd")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(g2, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv2d_wgrad(x, g2, tuple(w.shape), stride, padding, dilation, has_bias)
+        return dx, dw, db, None, None, None
+
+
+def conv2d_glu(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
+    """GLU(conv2d(x)) over channels; falls back to conv2d + glu when the fused store does not apply."""
+    if w.shape[0] % 2 == 0 and w.shape[0] > 8:
+        return ConvGlu2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation))
+    from . import nnops
+    return nnops.glu(conv2d(x, w, bias, stride, padding, dilation), 1)
+
+
+def conv1d_glu(x, w, bias=None, stride=1, padding=0, dilation=1):
+    return conv2d_glu(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation)).squeeze(2)
 
 
 def conv2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), stat_sums=None):

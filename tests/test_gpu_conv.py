@@ -161,3 +161,28 @@ def test_tcn_backward_vs_oracle():
         ref = sdr[k].grad
         scale = max(1e-3, float(ref.abs().max()))
         assert _rms(p.grad.cpu(), ref) < 1e-4 * scale, (k, _rms(p.grad.cpu(), ref), scale)
+
+
+@pytest.mark.parametrize("case", [
+    (48, 96, (12, 40), (3, 3), (1, 1)),        # HDemucs freq rewrite conv (context 1) + GLU
+    (24, 50, (1, 700), (1, 3), (0, 1)),        # time branch; 25 GLU channels: ragged last row tile
+    (96, 192, (5, 33), (1, 1), (0, 0)),
+])
+def test_conv_glu_fused(case):
+    """GLU folded into the GEMM store (ops.conv2d_glu) vs F.glu(F.conv2d(...)): forward and all gradients."""
+    from remfx_amd import ops
+    Cin, C2, (IA, IB), (KA, KB), pad = case
+    torch.manual_seed(3)
+    x = torch.randn(2, Cin, IA, IB)
+    w = torch.randn(C2, Cin, KA, KB) / (Cin * KA * KB) ** 0.5
+    b = torch.randn(C2)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.glu(F.conv2d(xr, wr, br, 1, pad), 1)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    xd, wd, bd = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    out = ops.conv2d_glu(xd, wd, bd, (1, 1), pad)
+    out.backward(g.cuda())
+    assert _rms(out.detach().cpu(), ref.detach()) < 1e-5
+    for a, r in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert _rms(a.cpu(), r) < 1e-4 * max(1e-3, float(r.abs().max()))
