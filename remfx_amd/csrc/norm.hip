@@ -356,6 +356,114 @@ extern "C" int rfx_batchnorm_fwd(const float* x, const float* gamma, const float
                   stream);
 }
 
+// GroupNorm(1, C) backward for SMALL samples (the freq-branch DConvs normalise 32768 x (96 x 256) "samples"): one
+// workgroup owns a sample and does both passes back to back -- channel sums + the sample's two group sums, a barrier,
+// then dx -- so the operands are re-read from L2 / Infinity Cache instead of HBM, there is no per-element index decoding
+// and the per-channel constants are loaded once per row.  The wave-per-(n, channel, chunk) kernels above spend most of
+// their time on row overhead at S = 256 (2.5 TB/s measured) and stay the path for large samples.
+__global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, float* __restrict__ part,
+                                                            float* __restrict__ psc) {
+  __shared__ float red[4][2];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool pair = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
+  const int Cw = pair ? a.C / 2 : a.C;
+  const float mean = a.mean[n], rstd = a.rstd[n];
+  const float* xn = a.x + (int64_t)n * a.C * a.S;
+  const float* gyn = a.gy + (int64_t)n * Cw * a.S;
+  float* dxn = a.y + (int64_t)n * a.C * a.S;
+  float gs1 = 0.f, gs2 = 0.f;
+  // du of one element; pair modes return both halves (same formulas as gn_du_pair / gn_du_single)
+  auto du_pair = [&](float xa, float xb, float g0, float ga, float ba, float gb, float bb, float sc, float& xha,
+                     float& xhb, float& dua, float& dub, float& gf) {
+    xha = (xa - mean) * rstd; xhb = (xb - mean) * rstd;
+    const float ua = xha * ga + ba, ub = xhb * gb + bb;
+    const float sg = rfx_sigmoid(ub);
+    gf = 0.f;
+    if (a.mode == GN_GLU_SCALE_RES) { gf = g0 * ua * sg; g0 *= sc; }
+    dua = g0 * sg;
+    dub = g0 * ua * sg * (1.f - sg);
+  };
+  auto du_single = [&](float xv, float g0, float gm, float bt, float& xh) {
+    xh = (xv - mean) * rstd;
+    if (a.mode == GN_GELU) return g0 * rfx_gelu_grad(xh * gm + bt);
+    if (a.mode == GN_RELU) return (xh * gm + bt) > 0.f ? g0 : 0.f;
+    return g0;
+  };
+  for (int cw = wave; cw < Cw; cw += 4) {
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (pair) {
+      const float ga = a.gamma[cw], ba = a.beta[cw], gb = a.gamma[cw + Cw], bb = a.beta[cw + Cw];
+      const float sc = a.mode == GN_GLU_SCALE_RES ? a.scale[cw] : 1.f;
+      const float* xa = xn + (int64_t)cw * a.S;
+      const float* xb = xn + (int64_t)(cw + Cw) * a.S;
+      const float* gr = gyn + (int64_t)cw * a.S;
+      for (int s = lane; s < a.S; s += 64) {
+        float xha, xhb, dua, dub, gf;
+        du_pair(xa[s], xb[s], gr[s], ga, ba, gb, bb, sc, xha, xhb, dua, dub, gf);
+        v[0] += dua; v[1] += dua * xha; v[2] += dub; v[3] += dub * xhb; v[4] += gf;
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) v[q] = rfx_wave_sum(v[q]);
+      gs1 += ga * v[0] + gb * v[2];
+      gs2 += ga * v[1] + gb * v[3];
+      if (lane == 0) {
+        float* pa = part + ((int64_t)n * a.C + cw) * 2;
+        float* pb = part + ((int64_t)n * a.C + cw + Cw) * 2;
+        pa[0] = v[0]; pa[1] = v[1]; pb[0] = v[2]; pb[1] = v[3];
+        if (a.mode == GN_GLU_SCALE_RES) psc[(int64_t)n * Cw + cw] = v[4];
+      }
+    } else {
+      const float gm = a.gamma[cw], bt = a.beta[cw];
+      const float* xr = xn + (int64_t)cw * a.S;
+      const float* gr = gyn + (int64_t)cw * a.S;
+      for (int s = lane; s < a.S; s += 64) {
+        float xh;
+        const float du = du_single(xr[s], gr[s], gm, bt, xh);
+        v[0] += du; v[1] += du * xh;
+      }
+      v[0] = rfx_wave_sum(v[0]); v[1] = rfx_wave_sum(v[1]);
+      gs1 += gm * v[0];
+      gs2 += gm * v[1];
+      if (lane == 0) {
+        float* pa = part + ((int64_t)n * a.C + cw) * 2;
+        pa[0] = v[0]; pa[1] = v[1];
+      }
+    }
+  }
+  if (lane == 0) { red[wave][0] = gs1; red[wave][1] = gs2; }
+  __syncthreads();
+  const float inv = 1.f / ((float)a.C * (float)a.S);
+  const float m1 = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * inv;
+  const float m2 = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * inv;
+  for (int cw = wave; cw < Cw; cw += 4) {
+    if (pair) {
+      const float ga = a.gamma[cw], ba = a.beta[cw], gb = a.gamma[cw + Cw], bb = a.beta[cw + Cw];
+      const float sc = a.mode == GN_GLU_SCALE_RES ? a.scale[cw] : 1.f;
+      const float* xa = xn + (int64_t)cw * a.S;
+      const float* xb = xn + (int64_t)(cw + Cw) * a.S;
+      const float* gr = gyn + (int64_t)cw * a.S;
+      float* da = dxn + (int64_t)cw * a.S;
+      float* db = dxn + (int64_t)(cw + Cw) * a.S;
+      for (int s = lane; s < a.S; s += 64) {
+        float xha, xhb, dua, dub, gf;
+        du_pair(xa[s], xb[s], gr[s], ga, ba, gb, bb, sc, xha, xhb, dua, dub, gf);
+        da[s] = rstd * (dua * ga - m1 - xha * m2);
+        db[s] = rstd * (dub * gb - m1 - xhb * m2);
+      }
+    } else {
+      const float gm = a.gamma[cw], bt = a.beta[cw];
+      const float* xr = xn + (int64_t)cw * a.S;
+      const float* gr = gyn + (int64_t)cw * a.S;
+      float* dr = dxn + (int64_t)cw * a.S;
+      for (int s = lane; s < a.S; s += 64) {
+        float xh;
+        const float du = du_single(xr[s], gr[s], gm, bt, xh);
+        dr[s] = rstd * (du * gm - m1 - xh * m2);
+      }
+    }
+  }
+}
+
 static int norm_bwd(int bn, const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t G, int32_t mode, const float* scale,
@@ -379,6 +487,14 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
   const int64_t nitems = (int64_t)N * Cw * nchunks;
   if (nchunks > 1 && hipMemsetAsync(work, 0, sizeof(float) * ((int64_t)N * C * 2 + (int64_t)N * (C / 2)), s) != hipSuccess)
     return -3;
+  if (!bn && G == 1 && N >= 512 && (int64_t)C * S <= 65536) {
+    // many small samples: one workgroup per sample, both passes fused (gn_bwd_sample_kernel)
+    hipLaunchKernelGGL(gn_bwd_sample_kernel, dim3((unsigned)N), dim3(256), 0, s, a, part, psc);
+    RFX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, part, psc, nchunks);
   RFX_CHECK_LAUNCH();
   if (!bn) {

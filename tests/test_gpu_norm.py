@@ -12,7 +12,8 @@ def _rms(a, b):
 
 
 @pytest.mark.parametrize("shape,groups", [((1024, 2, 20), 1), ((3, 48, 7, 33), 4), ((2, 12, 5000), 1),
-                                          ((5, 96, 64), 4), ((2, 8, 3, 50), 1)])
+                                          ((5, 96, 64), 4), ((2, 8, 3, 50), 1),
+                                          ((600, 12, 150), 1)])   # 600 small samples: fused per-sample backward
 @pytest.mark.parametrize("mode", ["none", "gelu", "glu", "glu_scale_res"])
 def test_groupnorm_modes(shape, groups, mode):
     from remfx_amd import nnops
