@@ -302,6 +302,117 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
   }
 }
 
+// ---- S % 4 == 0: wave-per-(row, 256-sample chunk) forms of the two apply kernels ------------------------------
+// The grid-stride kernels above decode (n, channel, s) from a flat 64-bit index with two 64-bit divisions per
+// 4 elements, which costs about as many VALU cycles as the memory traffic takes.  Here the decode is two 32-bit
+// divisions of a wave-uniform item index, the per-channel constants are uniform (scalar) loads, and every lane moves
+// 16-byte vectors.  Same arithmetic, same results.
+struct GnRow { int n, c; int64_t s; bool ok; };
+
+__device__ __forceinline__ GnRow gn_row_item(const GnArgs& a, int Cw, uint32_t nitems, uint32_t ipr) {
+  GnRow r;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t w = blockIdx.x * 4u + wave;
+  const uint32_t row = w / ipr, ck = w - row * ipr;
+  r.n = (int)(row / (uint32_t)Cw);
+  r.c = (int)(row - (uint32_t)r.n * (uint32_t)Cw);
+  r.s = (int64_t)ck * 256 + (threadIdx.x & 63) * 4;
+  r.ok = w < nitems && r.s < a.S;
+  return r;
+}
+
+__device__ __forceinline__ f32x4 gn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const GnArgs a, uint32_t nitems, uint32_t ipr) {
+  const bool glu = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
+  const int Co = glu ? a.C / 2 : a.C;
+  const GnRow it = gn_row_item(a, Co, nitems, ipr);
+  if (!it.ok) return;
+  const int n = it.n, c = it.c;
+  const int ga = gn_sidx(a, n, c);
+  const float ma = a.mean[ga], ra = a.rstd[ga] * a.gamma[c], ba = a.beta[c];
+  const float* xa = a.x + ((int64_t)n * a.C + c) * a.S + it.s;
+  const int64_t oi = ((int64_t)n * Co + c) * a.S + it.s;
+  const f32x4 va = gn_ld4(xa);
+  f32x4 vb = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+  float mb = 0.f, rb = 0.f, bb = 0.f, sc = 0.f;
+  if (glu) {
+    const int gb = gn_sidx(a, n, c + Co);
+    mb = a.mean[gb]; rb = a.rstd[gb] * a.gamma[c + Co]; bb = a.beta[c + Co];
+    vb = gn_ld4(xa + (int64_t)Co * a.S);
+    if (a.mode == GN_GLU_SCALE_RES) { sc = a.scale[c]; rs = gn_ld4(a.res + oi); }
+  }
+  f32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v = (va[q] - ma) * ra + ba;
+    if (a.mode == GN_GELU) v = rfx_gelu(v);
+    else if (a.mode == GN_RELU) v = v > 0.f ? v : 0.f;
+    else if (glu) {
+      v = v * rfx_sigmoid((vb[q] - mb) * rb + bb);
+      if (a.mode == GN_GLU_SCALE_RES) v = rs[q] + sc * v;
+    }
+    o[q] = v;
+  }
+  *reinterpret_cast<f32x4*>(a.y + oi) = o;
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const GnArgs a, uint32_t nitems, uint32_t ipr) {
+  const bool pair = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
+  const int Cw = pair ? a.C / 2 : a.C, Cg = a.C / a.G;
+  const GnRow it = gn_row_item(a, Cw, nitems, ipr);
+  if (!it.ok) return;
+  const int n = it.n, cw = it.c;
+  const float inv = a.bn ? 1.f / ((float)a.N * (float)a.S) : 1.f / ((float)Cg * (float)a.S);
+  const int64_t xi = ((int64_t)n * a.C + cw) * a.S + it.s;
+  const f32x4 g4 = gn_ld4(a.gy + ((int64_t)n * Cw + cw) * a.S + it.s);
+  const f32x4 xa = gn_ld4(a.x + xi);
+  if (pair) {
+    const f32x4 xb = gn_ld4(a.x + xi + (int64_t)Cw * a.S);
+    const int ga = gn_sidx(a, n, cw), gb = gn_sidx(a, n, cw + Cw);
+    const float mea = a.mean[ga], meb = a.mean[gb], ra = a.rstd[ga], rb = a.rstd[gb];
+    const float m1a = a.gsum[2 * ga] * inv, m2a = a.gsum[2 * ga + 1] * inv;
+    const float m1b = a.gsum[2 * gb] * inv, m2b = a.gsum[2 * gb + 1] * inv;
+    const float gma = a.gamma[cw], gmb = a.gamma[cw + Cw], bta = a.beta[cw], btb = a.beta[cw + Cw];
+    const float sc = a.mode == GN_GLU_SCALE_RES ? a.scale[cw] : 1.f;
+    f32x4 da, db;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xha = (xa[q] - mea) * ra, xhb = (xb[q] - meb) * rb;
+      const float ua = xha * gma + bta, ub = xhb * gmb + btb;
+      const float sg = rfx_sigmoid(ub);
+      const float g0 = a.mode == GN_GLU_SCALE_RES ? g4[q] * sc : g4[q];
+      const float dua = g0 * sg, dub = g0 * ua * sg * (1.f - sg);
+      da[q] = ra * (dua * gma - m1a - xha * m2a);
+      db[q] = rb * (dub * gmb - m1b - xhb * m2b);
+    }
+    *reinterpret_cast<f32x4*>(a.y + xi) = da;
+    *reinterpret_cast<f32x4*>(a.y + xi + (int64_t)Cw * a.S) = db;
+  } else {
+    const int g = gn_sidx(a, n, cw);
+    const float me = a.mean[g], rg = a.rstd[g], m1 = a.gsum[2 * g] * inv, m2 = a.gsum[2 * g + 1] * inv;
+    const float gm = a.gamma[cw], bt = a.beta[cw];
+    f32x4 d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xh = (xa[q] - me) * rg;
+      float du = g4[q];
+      if (a.mode == GN_GELU) du = du * rfx_gelu_grad(xh * gm + bt);
+      else if (a.mode == GN_RELU) du = (xh * gm + bt) > 0.f ? du : 0.f;
+      d[q] = rg * (du * gm - m1 - xh * m2);
+    }
+    *reinterpret_cast<f32x4*>(a.y + xi) = d;
+  }
+}
+
+// rows x chunks of 256 samples; false if the item count does not fit the 32-bit decode
+static bool gn_row_items(int64_t rows, int32_t S, uint32_t* nitems, uint32_t* ipr) {
+  const int64_t per = ((int64_t)S + 255) / 256, n = rows * per;
+  if ((S & 3) || n > 0x7fffffffLL) return false;
+  *nitems = (uint32_t)n; *ipr = (uint32_t)per;
+  return true;
+}
+
 static int gn_grid(int64_t total) {
   const int64_t b = (total + 1023) / 1024;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -334,7 +445,10 @@ static int norm_fwd(int bn, int use_given_stats, int sums_given, const float* x,
     RFX_CHECK_LAUNCH();
   }
   const int64_t total = (int64_t)N * (glu ? C / 2 : C) * S;
-  if ((S & 3) == 0) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(gn_grid(total / 4)), dim3(256), 0, s, a);
+  uint32_t nrow_items = 0, ipr = 0;
+  if (gn_row_items((int64_t)N * (glu ? C / 2 : C), S, &nrow_items, &ipr))
+    hipLaunchKernelGGL(gn_apply_rows_kernel, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+  else if ((S & 3) == 0) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(gn_grid(total / 4)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(gn_grid(total)), dim3(256), 0, s, a);
   RFX_CHECK_LAUNCH();
   return 0;
@@ -503,7 +617,10 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
   }
   hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
   RFX_CHECK_LAUNCH();
-  if ((S & 3) == 0) hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3(gn_grid((int64_t)N * Cw * S / 4)), dim3(256), 0, s, a);
+  uint32_t nrow_items = 0, ipr = 0;
+  if (gn_row_items((int64_t)N * Cw, S, &nrow_items, &ipr))
+    hipLaunchKernelGGL(gn_bwd_apply_rows_kernel, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+  else if ((S & 3) == 0) hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3(gn_grid((int64_t)N * Cw * S / 4)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(gn_grid((int64_t)N * Cw * S)), dim3(256), 0, s, a);
   RFX_CHECK_LAUNCH();
   return 0;
