@@ -199,12 +199,56 @@ extern "C" int rfx_channel_sum(const float* x, int32_t N, int32_t Cn, int32_t A,
   return 0;
 }
 
+// same-shape operand: flat 16-byte vectors
+__global__ void add_flat_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                                int64_t n, float alpha) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 w = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += alpha * w[c];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = x[i] + alpha * y[i];
+}
+// broadcast operand: one wave per ((n, c, a) row, 256-sample chunk of b); the row decode is wave-uniform 32-bit
+// arithmetic instead of three 64-bit divisions per element
+__global__ __launch_bounds__(256) void add_bcast_rows_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             float* __restrict__ out, uint32_t nitems, uint32_t ipr,
+                                                             int C, int A, int B, int64_t yn, int64_t yc, int64_t ya,
+                                                             int64_t yb, float alpha) {
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t w = blockIdx.x * 4u + wave;
+  if (w >= nitems) return;
+  const uint32_t row = w / ipr, ck = w - row * ipr;
+  const uint32_t r1 = row / (uint32_t)A, a = row - r1 * (uint32_t)A;
+  const uint32_t n = r1 / (uint32_t)C, c = r1 - n * (uint32_t)C;
+  const float* xr = x + (int64_t)row * B;
+  float* orow = out + (int64_t)row * B;
+  const float* yr = y + (int64_t)n * yn + (int64_t)c * yc + (int64_t)a * ya;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int b = (int)ck * 256 + q * 64 + (int)(threadIdx.x & 63);
+    if (b < B) orow[b] = xr[b] + alpha * yr[(int64_t)b * yb];
+  }
+}
 extern "C" int rfx_add_bcast(const float* x, const float* y, float* out, int64_t N, int32_t Cn, int32_t A, int32_t B,
                              int64_t yn, int64_t yc, int64_t ya, int64_t yb, float alpha, void* stream) {
   if (!x || !y || !out || N <= 0 || Cn <= 0 || A <= 0 || B <= 0) return -1;
   const int64_t total = N * Cn * A * B;
-  hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, out, total, Cn, A,
-                     B, yn, yc, ya, yb, alpha);
+  const int64_t rows = N * Cn * A, per = ((int64_t)B + 255) / 256;
+  if (yb == 1 && ya == B && yc == (int64_t)A * B && yn == (int64_t)Cn * A * B)
+    hipLaunchKernelGGL(add_flat_kernel, dim3(grid_for(total / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, y, out, total,
+                       alpha);
+  else if (rows * per <= 0x7fffffffLL)
+    hipLaunchKernelGGL(add_bcast_rows_kernel, dim3((unsigned)((rows * per + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       y, out, (uint32_t)(rows * per), (uint32_t)per, Cn, A, B, yn, yc, ya, yb, alpha);
+  else
+    hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, out, total, Cn, A,
+                       B, yn, yc, ya, yb, alpha);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -709,15 +709,68 @@ __global__ void glu_bwd_kernel(const float* __restrict__ x, const float* __restr
     gx[ib] = g * a * sg * (1.f - sg);
   }
 }
+// L = Co * S multiple of 4: one wave per (sample n, 256-element chunk of the (Co, S) half), 16-byte vectors, the only
+// division is a wave-uniform 32-bit one (the flat kernels above divide 64-bit indices three times per element)
+__global__ __launch_bounds__(256) void glu_fwd_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           uint32_t nitems, uint32_t ipr, int64_t L) {
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t w = blockIdx.x * 4u + wave;
+  if (w >= nitems) return;
+  const uint32_t n = w / ipr, ck = w - n * ipr;
+  const int64_t o = (int64_t)ck * 256 + (threadIdx.x & 63) * 4;
+  if (o >= L) return;
+  const f32x4 a = gn_ld4(x + (int64_t)n * 2 * L + o), b = gn_ld4(x + (int64_t)n * 2 * L + L + o);
+  f32x4 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r[q] = a[q] * rfx_sigmoid(b[q]);
+  *reinterpret_cast<f32x4*>(y + (int64_t)n * L + o) = r;
+}
+__global__ __launch_bounds__(256) void glu_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           float* __restrict__ gx, uint32_t nitems, uint32_t ipr,
+                                                           int64_t L) {
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t w = blockIdx.x * 4u + wave;
+  if (w >= nitems) return;
+  const uint32_t n = w / ipr, ck = w - n * ipr;
+  const int64_t o = (int64_t)ck * 256 + (threadIdx.x & 63) * 4;
+  if (o >= L) return;
+  const int64_t ia = (int64_t)n * 2 * L + o;
+  const f32x4 a = gn_ld4(x + ia), b = gn_ld4(x + ia + L), g = gn_ld4(gy + (int64_t)n * L + o);
+  f32x4 da, db;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float sg = rfx_sigmoid(b[q]);
+    da[q] = g[q] * sg;
+    db[q] = g[q] * a[q] * sg * (1.f - sg);
+  }
+  *reinterpret_cast<f32x4*>(gx + ia) = da;
+  *reinterpret_cast<f32x4*>(gx + ia + L) = db;
+}
+static bool glu_row_items(int64_t N, int64_t L, uint32_t* nitems, uint32_t* ipr) {
+  const int64_t per = (L + 255) / 256;
+  if ((L & 3) || N * per > 0x7fffffffLL) return false;
+  *nitems = (uint32_t)(N * per); *ipr = (uint32_t)per;
+  return true;
+}
 extern "C" int rfx_glu_fwd(const float* x, float* y, int64_t N, int64_t C, int64_t S, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || (C & 1) || S <= 0) return -1;
-  hipLaunchKernelGGL(glu_fwd_kernel, dim3(gn_grid(N * (C / 2) * S)), dim3(256), 0, (hipStream_t)stream, x, y, N, C / 2, S);
+  uint32_t nitems = 0, ipr = 0;
+  if (glu_row_items(N, (C / 2) * S, &nitems, &ipr))
+    hipLaunchKernelGGL(glu_fwd_rows_kernel, dim3((nitems + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, nitems, ipr,
+                       (C / 2) * S);
+  else
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(gn_grid(N * (C / 2) * S)), dim3(256), 0, (hipStream_t)stream, x, y, N, C / 2, S);
   RFX_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int rfx_glu_bwd(const float* x, const float* gy, float* gx, int64_t N, int64_t C, int64_t S, void* stream) {
   if (!x || !gy || !gx || N <= 0 || C <= 0 || (C & 1) || S <= 0) return -1;
-  hipLaunchKernelGGL(glu_bwd_kernel, dim3(gn_grid(N * (C / 2) * S)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, N, C / 2, S);
+  uint32_t nitems = 0, ipr = 0;
+  if (glu_row_items(N, (C / 2) * S, &nitems, &ipr))
+    hipLaunchKernelGGL(glu_bwd_rows_kernel, dim3((nitems + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gy, gx, nitems,
+                       ipr, (C / 2) * S);
+  else
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(gn_grid(N * (C / 2) * S)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, N, C / 2, S);
   RFX_CHECK_LAUNCH();
   return 0;
 }

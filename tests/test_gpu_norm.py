@@ -65,3 +65,39 @@ def test_glu_plain():
     y.backward(gy.to(DEV))
     assert _rms(y.detach().cpu(), F.glu(x, 1)) < 1e-6
     assert _rms(xd.grad.cpu(), xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 10, 4, 9), (2, 6, 1030), (5, 4, 3, 7)])
+def test_glu_shapes(shape):
+    """vector path (C/2 * S multiple of 4) and the scalar fallback"""
+    from remfx_amd import nnops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(shape, generator=g)
+    oshape = list(shape)
+    oshape[1] //= 2
+    gy = torch.randn(oshape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.glu(xr, 1).backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = nnops.glu(xd, 1)
+    y.backward(gy.to(DEV))
+    assert _rms(y.detach().cpu(), F.glu(x, 1)) < 1e-6
+    assert _rms(xd.grad.cpu(), xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("xshape,yshape", [((2, 3, 4, 300), (2, 3, 4, 300)), ((2, 3, 5, 77), (1, 3, 5, 1)),
+                                           ((3, 4, 2, 513), (3, 4, 1, 513)), ((2, 5, 1001), (2, 5, 1001)),
+                                           ((2, 5, 7, 3), (1, 1, 7, 3))])
+def test_add_broadcast(xshape, yshape):
+    """x + alpha * y: flat path, row-decoded broadcast path, and their gradients (HDemucs skip / freq-embedding adds)"""
+    from remfx_amd import nnops
+    g = torch.Generator().manual_seed(2)
+    x, y, gy = torch.randn(xshape, generator=g), torch.randn(yshape, generator=g), torch.randn(xshape, generator=g)
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    (xr + 0.3 * yr).backward(gy)
+    xd, yd = x.to(DEV).requires_grad_(True), y.to(DEV).requires_grad_(True)
+    out = nnops.add(xd, yd, 0.3)
+    out.backward(gy.to(DEV))
+    assert _rms(out.detach().cpu(), x + 0.3 * y) < 1e-6
+    assert _rms(xd.grad.cpu(), xr.grad) < 1e-6
+    assert _rms(yd.grad.cpu(), yr.grad) < 1e-5
