@@ -170,9 +170,13 @@ def _merged_launch(inp, wm, ax, S, J, off, out, bias=None):
     return out
 
 
-def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None):
+def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None, res=None):
+    """res: optional tensor of x's shape added to the result in the GEMM's store (a second gradient path into x that
+    autograd would otherwise accumulate with a separate add pass); unit-stride convolutions only."""
     if dx is None:
         dx = torch.empty_strided(xshape, xstrides, device=g.device, dtype=torch.float32)
+    if res is not None and tuple(stride) != (1, 1):
+        return conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx).add_(res)
     ax = _merge_axis(w.shape[2:], stride, padding, dilation)
     if ax is not None and w.shape[1] * stride[ax] > 8:
         # dx[ci][o] = sum g[co][i] w[co][ci][kk], o = S*i + kk - P: all S phases of o as rows (ci, q) of one GEMM over g
@@ -183,7 +187,7 @@ def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None):
         tuple(xshape), tuple(xstrides), tuple(w.shape), stride, padding, dilation, tuple(g.shape), g.stride()))
     wc = w.contiguous()
     for dp in dps:
-        gemm_fwd(dp, pack_a(dp, wc), g, dx)
+        gemm_fwd(dp, pack_a(dp, wc), g, dx, res=res)
     return dx
 
 
@@ -217,6 +221,31 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(g, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
+        return dx, dw, db, None, None, None, None
+
+
+class ConvFork2dFn(torch.autograd.Function):
+    """(conv(x), x): the convolution plus a pass-through alias of its input for a residual branch that re-joins later
+    (HDemucs DConv: x + scale * branch(x)).  Routing the alias through this node hands BOTH gradients of x to one
+    backward call, so the residual gradient is added in the input-gradient GEMM's store instead of a separate
+    read-read-write accumulation pass over the activation."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, dilation, stat_sums=None):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, dilation, bias is not None)
+        return conv2d_forward(x, w, bias, stride, padding, dilation, stat_sums=stat_sums), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, gres):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, has_bias = ctx.cfg
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(g, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation, res=gres)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
         return dx, dw, db, None, None, None, None
@@ -283,6 +312,12 @@ def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None):
     output into it (GroupNorm(1, C) statistics for free)."""
     y = Conv2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation), stat_sums)
     return y.squeeze(2)
+
+
+def conv1d_fork(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None):
+    """(conv1d(x), alias of x) -- see ConvFork2dFn; use the alias for the residual connection around the branch."""
+    y, xr = ConvFork2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation), stat_sums)
+    return y.squeeze(2), xr.squeeze(2)
 
 
 # ---- transposed convolution -----------------------------------------------------------
