@@ -23,6 +23,40 @@ HOP_SIZES = (120, 240, 50)
 WIN_LENGTHS = (600, 1200, 240)
 
 
+_MEMO = None
+
+
+class stft_memo:
+    """Scope in which the spectra the MRSTFT loss / metric take are computed once per (signal, resolution).
+
+    RemFX.common_step evaluates MRSTFT three times on one batch -- loss(output, target), metric(output, target) and
+    metric(input, target) (models.py:220-255) -- i.e. the same STFT of the target three times and of the output twice.
+    Inside ``with stft_memo():`` a repeated request for the spectrum of the same storage at the same version returns
+    the tensor computed the first time.  The memo dies with the scope, so nothing is carried from one step to the next.
+    """
+
+    def __enter__(self):
+        global _MEMO
+        self._prev, _MEMO = _MEMO, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _MEMO
+        _MEMO = self._prev
+        return False
+
+
+def _spectrum(sig, n_fft, hop, win, w):
+    if _MEMO is None:
+        return stft.stft_raw(sig, n_fft, hop, win, w, 0)
+    key = (sig.data_ptr(), sig._version, tuple(sig.shape), tuple(sig.stride()), n_fft, hop, win)
+    hit = _MEMO.get(key)
+    if hit is None:
+        hit = (sig, stft.stft_raw(sig, n_fft, hop, win, w, 0))     # holding sig keeps its storage from being reused
+        _MEMO[key] = hit
+    return hit[1]
+
+
 class _MRSTFTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, fft_sizes, hops, wins, eps, per_example_sc):
@@ -33,8 +67,8 @@ class _MRSTFTFn(torch.autograd.Function):
         saved, total = [], None
         for n_fft, hop, win in zip(fft_sizes, hops, wins):
             w = stft.hann(win, x.device)
-            X = stft.stft_raw(x2, n_fft, hop, win, w, 0)
-            Y = stft.stft_raw(y2, n_fft, hop, win, w, 0)
+            X = _spectrum(x2, n_fft, hop, win, w)
+            Y = _spectrum(y2, n_fft, hop, win, w)
             n = X.shape[1] * X.shape[2]
             sums = torch.zeros((R, 3), device=x.device, dtype=torch.float32)
             check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), _stream()),

@@ -13,7 +13,7 @@ import random
 import torch
 from torch import Tensor, nn
 
-from .losses import L1Loss, MultiResolutionSTFTLoss, SISDRLoss
+from .losses import L1Loss, MultiResolutionSTFTLoss, SISDRLoss, stft_memo
 from .tcn import TCN
 from .utils import causal_crop
 
@@ -78,18 +78,19 @@ class RemFX(_Base):
 
     def common_step(self, batch, batch_idx, mode: str = "train"):
         x, y, _, _ = batch                                     # (B, C, T) each
-        loss, output = self.model((x, y))
-        target = y
-        if output.shape[-1] < y.shape[-1]:                     # models.py:222-224
-            target = causal_crop(y, output.shape[-1])
-        self.log(f"{mode}_loss", loss)
-        with torch.no_grad():
-            for metric in self.metrics:
-                negate = -1 if metric == "SISDR" else 1        # SISDR loss is -SI-SDR
-                self.log(f"{mode}_{metric}", negate * self.metrics[metric](output.detach(), target),
-                         on_step=False, on_epoch=True, logger=True, prog_bar=True, sync_dist=True)
-                self.log(f"Input_{metric}", negate * self.metrics[metric](x, y),
-                         on_step=False, on_epoch=True, logger=True, prog_bar=True, sync_dist=True)
+        with stft_memo():                                      # the loss and both STFT metrics share their spectra
+            loss, output = self.model((x, y))
+            target = y
+            if output.shape[-1] < y.shape[-1]:                 # models.py:222-224
+                target = causal_crop(y, output.shape[-1])
+            self.log(f"{mode}_loss", loss)
+            with torch.no_grad():
+                for metric in self.metrics:
+                    negate = -1 if metric == "SISDR" else 1    # SISDR loss is -SI-SDR
+                    self.log(f"{mode}_{metric}", negate * self.metrics[metric](output.detach(), target),
+                             on_step=False, on_epoch=True, logger=True, prog_bar=True, sync_dist=True)
+                    self.log(f"Input_{metric}", negate * self.metrics[metric](x, y),
+                             on_step=False, on_epoch=True, logger=True, prog_bar=True, sync_dist=True)
         return loss
 
 

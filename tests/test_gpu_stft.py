@@ -134,6 +134,34 @@ def test_mrstft_l1_sisdr_vs_oracle():
     assert abs(float(s2) - float(ref_losses.sisdr_loss(x[..., 5:20000], y[..., 5:20000]))) < 1e-3
 
 
+def test_stft_memo_scope():
+    """Inside stft_memo() repeated MRSTFT evaluations are bit-identical to the unshared ones, an in-place change of a
+    signal is seen (version bump), and nothing survives the scope."""
+    from remfx_amd import losses
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(2, 1, 16000, generator=g) * 0.3).to(DEV)
+    y = (x + 0.1 * torch.randn(2, 1, 16000, generator=g).to(DEV))
+    mr = losses.MultiResolutionSTFTLoss()
+    plain = float(mr(x, y))
+    xg = x.clone().requires_grad_(True)
+    plain_l = mr(xg, y)
+    plain_l.backward()
+    with losses.stft_memo():
+        xm = x.clone().requires_grad_(True)
+        l = mr(xm, y)
+        assert float(mr(xm.detach(), y)) == float(l) == plain          # metric(output, target) == loss term, shared spectra
+        n_entries = len(losses._MEMO)
+        assert n_entries == 6                                          # 2 signals x 3 resolutions, not 12
+        l.backward()
+        # (the adjoint STFT overlap-adds with atomics: equal up to summation order)
+        assert _rms(xm.grad.cpu(), xg.grad.cpu()) < 1e-5 * float(xg.grad.abs().max())
+        y.mul_(0.5)                                                    # version bump -> recomputed
+        assert float(mr(x, y)) != plain
+        y.mul_(2.0)
+    assert losses._MEMO is None
+    assert float(mr(x, y)) == plain
+
+
 def test_spectrogram_golden(golden_dir):
     import os
     import numpy as np
