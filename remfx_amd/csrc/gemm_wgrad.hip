@@ -138,16 +138,20 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
 // bf16x3 weight gradient: same tiling and gathers as gemm_wgrad_kernel, but the two LDS tiles hold
 // the operands pre-split into bf16 hi / lo halves ([row][32 positions], 80-byte rows: 16-byte aligned
 // MFMA fragments, conflict-free ds_read_b128) and the product runs on v_mfma_f32_32x32x16_bf16.
-template <int TM, int TK>
+// WM = waves along M: 2 -> the 4 waves form a 2 x 2 grid over a (64 TM) x (64 TK) tile; 1 (M <= 32, the DConv
+// bottleneck convs with 12 / 24 output channels) -> 1 x 4 over 32 x (128 TK), so the MFMA rows beyond M and the
+// re-loads of g by every k tile are halved.
+template <int TM, int TK, int WM = 2>
 __global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) {
-  constexpr int RM = 64 * TM, RK = 64 * TK, LDW = 40;   // bf16 elements per LDS row
+  constexpr int WK = 4 / WM;
+  constexpr int RM = 32 * WM * TM, RK = 32 * WK * TK, LDW = 40;   // bf16 elements per LDS row
   __shared__ __attribute__((aligned(16))) unsigned short gs_hi[RM * LDW], gs_lo[RM * LDW];
   __shared__ __attribute__((aligned(16))) unsigned short xs_hi[RK * LDW], xs_lo[RK * LDW];
   __shared__ rfx_ktab_entry kts[RK];
   const rfx_gemm_desc& d = w.d;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wk = wave & 1;
+  const int wm = WM == 2 ? wave >> 1 : 0, wk = WM == 2 ? wave & 1 : wave;
   // plain order (k tile fastest).  An XCD-grouped order (all tiles of one position split on one XCD) was
   // measured SLOWER (132 -> 116 TF/s-eq at the TCN shape): the splits are too few / too coarse to balance.
   int zsplit = blockIdx.z, ym = blockIdx.y, xk = blockIdx.x;
@@ -366,9 +370,11 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     RFX_CHECK_LAUNCH();
     return 0;
   }
+  const bool narrow = prec == 1 && d->M <= 32;            // 32 x (128 tk) tiles, waves 1 x 4 (see gemm_wgrad_bf3_kernel)
   const int tm = d->M > 64 ? 2 : 1;
-  const int tk = d->K > 64 ? 2 : 1;
-  const int mt = (d->M + 64 * tm - 1) / (64 * tm), kt = (d->K + 64 * tk - 1) / (64 * tk);
+  const int tk = narrow ? (d->K > 128 ? 2 : 1) : (d->K > 64 ? 2 : 1);
+  const int rm = narrow ? 32 : 64 * tm, rk = narrow ? 128 * tk : 64 * tk;
+  const int mt = (d->M + rm - 1) / rm, kt = (d->K + rk - 1) / rk;
   // aim for ~2048 workgroups; each should still see >= 16 position tiles
   int splits = max(1, 2048 / (mt * kt));
   // >= 64 position tiles per workgroup when there is plenty of work; short sequences (LSTM / attention projections,
@@ -386,7 +392,9 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
       w.xcd_grouped = 1;
       grid = dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1);
     }
-    if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 2>), grid, dim3(256), 0, s, w);
+    if (narrow && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2, 1>), grid, dim3(256), 0, s, w);
+    else if (narrow) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 1, 1>), grid, dim3(256), 0, s, w);
+    else if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 2>), grid, dim3(256), 0, s, w);
     else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 1>), grid, dim3(256), 0, s, w);
     else if (tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2>), grid, dim3(256), 0, s, w);
     else hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 1>), grid, dim3(256), 0, s, w);

@@ -34,6 +34,9 @@ CASES = [
     (96, 192, (8, 64), (1, 1), (1, 1), (0, 0), (1, 1), 2),       # 1x1 rewrite
     (16, 24, (1, 47), (1, 8), (1, 4), (0, 2), (1, 1), 2),        # merged-phase dgrad: tail inputs no window covers
     (10, 12, (45, 3), (4, 1), (2, 1), (1, 0), (1, 1), 1),        # merged-phase dgrad on the A axis, stride 2
+    (48, 12, (1, 900), (1, 3), (1, 1), (0, 2), (1, 2), 3),       # DConv bottleneck: narrow wgrad tile (M <= 32), K = 145
+    (96, 24, (1, 333), (1, 3), (1, 1), (0, 1), (1, 1), 2),       # narrow wgrad tile, two k tiles (K = 289)
+    (20, 32, (6, 50), (1, 3), (1, 1), (0, 1), (1, 1), 2),        # narrow wgrad tile, M = 32 exactly, K = 61
 ]
 
 
