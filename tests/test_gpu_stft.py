@@ -149,17 +149,18 @@ def test_stft_memo_scope():
     with losses.stft_memo():
         xm = x.clone().requires_grad_(True)
         l = mr(xm, y)
-        assert float(mr(xm.detach(), y)) == float(l) == plain          # metric(output, target) == loss term, shared spectra
+        # metric(output, target) == loss term on shared spectra (row sums use float atomics: equal to rounding)
+        assert abs(float(mr(xm.detach(), y)) - float(l)) < 1e-6 * plain and abs(float(l) - plain) < 1e-6 * plain
         n_entries = len(losses._MEMO)
         assert n_entries == 6                                          # 2 signals x 3 resolutions, not 12
         l.backward()
         # (the adjoint STFT overlap-adds with atomics: equal up to summation order)
         assert _rms(xm.grad.cpu(), xg.grad.cpu()) < 1e-5 * float(xg.grad.abs().max())
         y.mul_(0.5)                                                    # version bump -> recomputed
-        assert float(mr(x, y)) != plain
+        assert abs(float(mr(x, y)) - plain) > 1e-3 * plain
         y.mul_(2.0)
     assert losses._MEMO is None
-    assert float(mr(x, y)) == plain
+    assert abs(float(mr(x, y)) - plain) < 1e-6 * plain
 
 
 def test_spectrogram_golden(golden_dir):
