@@ -371,9 +371,11 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     return 0;
   }
   const bool narrow = prec == 1 && d->M <= 32;            // 32 x (128 tk) tiles, waves 1 x 4 (see gemm_wgrad_bf3_kernel)
+  // 96-row tiles (waves 1 x 4, three 32-row MFMA tiles each) when they pad M less than 128-row ones: M = 96, 192, 288
+  const bool rows96 = prec == 1 && d->M > 64 && d->K > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;
   const int tm = d->M > 64 ? 2 : 1;
-  const int tk = narrow ? (d->K > 128 ? 2 : 1) : (d->K > 64 ? 2 : 1);
-  const int rm = narrow ? 32 : 64 * tm, rk = narrow ? 128 * tk : 64 * tk;
+  const int tk = narrow ? (d->K > 128 ? 2 : 1) : rows96 ? 1 : (d->K > 64 ? 2 : 1);
+  const int rm = narrow ? 32 : rows96 ? 96 : 64 * tm, rk = (narrow || rows96) ? 128 * tk : 64 * tk;
   const int mt = (d->M + rm - 1) / rm, kt = (d->K + rk - 1) / rk;
   // aim for ~2048 workgroups; each should still see >= 16 position tiles
   int splits = max(1, 2048 / (mt * kt));
@@ -392,7 +394,8 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
       w.xcd_grouped = 1;
       grid = dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1);
     }
-    if (narrow && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2, 1>), grid, dim3(256), 0, s, w);
+    if (rows96) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<3, 1, 1>), grid, dim3(256), 0, s, w);
+    else if (narrow && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2, 1>), grid, dim3(256), 0, s, w);
     else if (narrow) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 1, 1>), grid, dim3(256), 0, s, w);
     else if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 2>), grid, dim3(256), 0, s, w);
     else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 1>), grid, dim3(256), 0, s, w);
