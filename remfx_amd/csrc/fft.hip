@@ -333,23 +333,32 @@ __global__ __launch_bounds__(256) void fft_synthesis_kernel(const FftArgs a) {
   fft_passes<LOGN, true>(data, tw, FB * NC);
   const int woff = (N - d.win) / 2;
   float* outr = a.out + (int64_t)row * d.T;
-  for (int idx = tid; idx < FB * NC; idx += 256) {
-    const int fl = idx / NC, i = idx - fl * NC;
-    const int f = f_first + fl;
-    if (f >= f_end) continue;
-    const float2 z = data[fl * FS + i];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int t = 2 * i + u;
-      const int wi = t - woff;
-      if (wi < 0 || wi >= d.win) continue;
-      const int p = f * d.hop + t;
-      const int s = map_sample(d, p);
-      if (s < 0) continue;
-      float v = (u == 0 ? z.x : z.y) * a.window[wi] * d.scale;
-      if (a.mul) v *= a.mul[p];
-      atomicAdd(outr + s, v);
+  // Overlap-add by GATHER inside the workgroup: its frames are consecutive, so every padded position p of their span
+  // sums the <= ceil(win / hop) frames that cover it out of LDS and issues ONE global atomic (the scatter form issued
+  // one per (frame, sample): 3.3-4.3x more, and the loss-gradient launches ran at the L2 atomic rate, 0.46 TB/s).
+  const int nf = min(FB, f_end - f_first);
+  if (nf <= 0) return;
+  const int span = (nf - 1) * d.hop + N;
+  const int64_t p0 = (int64_t)f_first * d.hop;
+  for (int q = tid; q < span; q += 256) {
+    const int qw = q - woff;                       // window index of frame 0 at this position
+    if (qw < 0) continue;
+    const int fl_hi = min(nf - 1, qw / d.hop);
+    const int lo_num = qw - d.win + 1;
+    const int fl_lo = lo_num > 0 ? (lo_num + d.hop - 1) / d.hop : 0;
+    if (fl_lo > fl_hi) continue;
+    float v = 0.f;
+    for (int fl = fl_lo; fl <= fl_hi; ++fl) {
+      const int t = q - fl * d.hop;
+      const float2 z = data[fl * FS + (t >> 1)];
+      v += ((t & 1) ? z.y : z.x) * a.window[t - woff];
     }
+    const int64_t p = p0 + q;
+    const int sidx = map_sample(d, (int)p);
+    if (sidx < 0) continue;
+    v *= d.scale;
+    if (a.mul) v *= a.mul[p];
+    atomicAdd(outr + sidx, v);
   }
 }
 
