@@ -152,7 +152,7 @@ def test_stft_memo_scope():
         # metric(output, target) == loss term on shared spectra (row sums use float atomics: equal to rounding)
         assert abs(float(mr(xm.detach(), y)) - float(l)) < 1e-6 * plain and abs(float(l) - plain) < 1e-6 * plain
         n_entries = len(losses._MEMO)
-        assert n_entries == 6                                          # 2 signals x 3 resolutions, not 12
+        assert sum(1 for k in losses._MEMO if len(k) == 7) == 6        # spectra: 2 signals x 3 resolutions, not 12
         l.backward()
         # (the adjoint STFT overlap-adds with atomics: equal up to summation order)
         assert _rms(xm.grad.cpu(), xg.grad.cpu()) < 1e-5 * float(xg.grad.abs().max())
