@@ -172,16 +172,19 @@ def _merged_launch(inp, wm, ax, S, J, off, out, bias=None):
 
 def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None, res=None):
     """res: optional tensor of x's shape added to the result in the GEMM's store (a second gradient path into x that
-    autograd would otherwise accumulate with a separate add pass); unit-stride convolutions only."""
+    autograd would otherwise accumulate with a separate add pass); in the store for unit-stride plans, a plain add otherwise."""
     if dx is None:
         dx = torch.empty_strided(xshape, xstrides, device=g.device, dtype=torch.float32)
-    if res is not None and tuple(stride) != (1, 1):
-        return conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx).add_(res)
     ax = _merge_axis(w.shape[2:], stride, padding, dilation)
     if ax is not None and w.shape[1] * stride[ax] > 8:
         # dx[ci][o] = sum g[co][i] w[co][ci][kk], o = S*i + kk - P: all S phases of o as rows (ci, q) of one GEMM over g
         wm, J = _merged_weight(w.transpose(0, 1), ax, stride[ax])
-        return _merged_launch(g, wm, ax, stride[ax], J, -padding[ax], dx)
+        out = _merged_launch(g, wm, ax, stride[ax], J, -padding[ax], dx)
+        # a residual operand in the merged-phase store was measured: the torch add it removes (-2.2 ms/step on the HDemucs
+        # skip connections) is paid back by the strided 4-byte residual loads in the GEMM (+1.5..2.5 ms): not kept
+        return out.add_(res) if res is not None else out
+    if res is not None and tuple(stride) != (1, 1):       # per-phase plans: add afterwards
+        return conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx).add_(res)
     key = _key("cd", xshape, xstrides, w.shape, stride, padding, dilation, g.shape, g.stride())
     dps = _plans(key, g.device, lambda: convplan.conv_dgrad_plans(
         tuple(xshape), tuple(xstrides), tuple(w.shape), stride, padding, dilation, tuple(g.shape), g.stride()))
@@ -312,6 +315,11 @@ def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None):
     output into it (GroupNorm(1, C) statistics for free)."""
     y = Conv2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation), stat_sums)
     return y.squeeze(2)
+
+
+def conv2d_fork(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), stat_sums=None):
+    """(conv2d(x), alias of x) -- see ConvFork2dFn."""
+    return ConvFork2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation), stat_sums)
 
 
 def conv1d_fork(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None):

@@ -189,3 +189,31 @@ def test_conv_glu_fused(case):
     assert _rms(out.detach().cpu(), ref.detach()) < 1e-5
     for a, r in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
         assert _rms(a.cpu(), r) < 1e-4 * max(1e-3, float(r.abs().max()))
+
+
+@pytest.mark.parametrize("case", [
+    # Cin, Cout, (IA, IB), (KA, KB), stride, padding
+    (48, 12, (1, 300), (1, 3), (1, 1), (0, 1)),      # unit stride: residual in the plain store
+    (16, 24, (1, 48), (1, 8), (1, 4), (0, 2)),       # merged-phase input gradient (time branch encoder)
+    (24, 40, (32, 9), (8, 1), (4, 1), (2, 0)),       # merged on the A axis (freq branch encoder)
+])
+def test_conv_fork_residual_gradient(case):
+    """ops.conv2d_fork: conv(x) plus an alias of x; the alias' gradient is added inside the input-gradient GEMM."""
+    from remfx_amd import ops
+    Cin, Cout, (IA, IB), (KA, KB), stride, padding = case
+    torch.manual_seed(4)
+    x = torch.randn(2, Cin, IA, IB)
+    w = torch.randn(Cout, Cin, KA, KB) / (Cin * KA * KB) ** 0.5
+    b = torch.randn(Cout)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride, padding)
+    g1, g2 = torch.randn(yr.shape), torch.randn(x.shape)
+    (yr * g1).sum().backward(retain_graph=True)
+    (xr * g2).sum().backward()
+    dev = _dev()
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y, alias = ops.conv2d_fork(xd, wd, bd, stride, padding)
+    ((y * g1.to(dev)).sum() + (alias * g2.to(dev)).sum()).backward()
+    assert _rms(y.detach().cpu(), yr.detach()) < 1e-5
+    for got, ref in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert _rms(got.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max()))
