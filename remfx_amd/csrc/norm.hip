@@ -578,6 +578,94 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, floa
   }
 }
 
+// Register-resident form of gn_bwd_sample_kernel for the GLU modes: 16 waves per sample, a wave owns RW channel pairs and
+// keeps their (x_a, x_b, gy) rows -- S <= 64 * SV values each -- in registers between the statistics pass and the dx
+// pass, so every operand is read exactly once (the 256-thread kernel re-reads them from L2 / Infinity Cache).
+template <int RW, int SV>
+__global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a, float* __restrict__ part,
+                                                                 float* __restrict__ psc) {
+  __shared__ float red[16][2];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Cw = a.C / 2;
+  const float mean = a.mean[n], rstd = a.rstd[n];
+  const float* xn = a.x + (int64_t)n * a.C * a.S;
+  const float* gyn = a.gy + (int64_t)n * Cw * a.S;
+  float* dxn = a.y + (int64_t)n * a.C * a.S;
+  float xa[RW][SV], xb[RW][SV], gg[RW][SV];
+#pragma unroll
+  for (int j = 0; j < RW; ++j) {
+    const int cw = wave + 16 * j;
+    const int cc = cw < Cw ? cw : Cw - 1;                       // clamped: loads unconditional, results masked below
+#pragma unroll
+    for (int q = 0; q < SV; ++q) {
+      const int s = lane + 64 * q;
+      const int ss = s < a.S ? s : a.S - 1;
+      xa[j][q] = xn[(int64_t)cc * a.S + ss];
+      xb[j][q] = xn[(int64_t)(cc + Cw) * a.S + ss];
+      gg[j][q] = gyn[(int64_t)cc * a.S + ss];
+    }
+  }
+  float gs1 = 0.f, gs2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < RW; ++j) {
+    const int cw = wave + 16 * j;
+    const bool cok = cw < Cw;
+    const int cc = cok ? cw : Cw - 1;
+    const float ga = a.gamma[cc], ba = a.beta[cc], gb = a.gamma[cc + Cw], bb = a.beta[cc + Cw];
+    const float sc = a.mode == GN_GLU_SCALE_RES ? a.scale[cc] : 1.f;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < SV; ++q) {
+      const float ok = (cok && lane + 64 * q < a.S) ? 1.f : 0.f;
+      const float xha = (xa[j][q] - mean) * rstd, xhb = (xb[j][q] - mean) * rstd;
+      const float ua = xha * ga + ba, ub = xhb * gb + bb;
+      const float sg = rfx_sigmoid(ub);
+      float g0 = gg[j][q] * ok;
+      float gf = 0.f;
+      if (a.mode == GN_GLU_SCALE_RES) { gf = g0 * ua * sg; g0 *= sc; }
+      const float dua = g0 * sg, dub = g0 * ua * sg * (1.f - sg);
+      v[0] += dua; v[1] += dua * xha; v[2] += dub; v[3] += dub * xhb; v[4] += gf;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] = rfx_wave_sum(v[q]);
+    gs1 += ga * v[0] + gb * v[2];
+    gs2 += ga * v[1] + gb * v[3];
+    if (lane == 0 && cok) {
+      float* pa = part + ((int64_t)n * a.C + cw) * 2;
+      float* pb = part + ((int64_t)n * a.C + cw + Cw) * 2;
+      pa[0] = v[0]; pa[1] = v[1]; pb[0] = v[2]; pb[1] = v[3];
+      if (a.mode == GN_GLU_SCALE_RES) psc[(int64_t)n * Cw + cw] = v[4];
+    }
+  }
+  if (lane == 0) { red[wave][0] = gs1; red[wave][1] = gs2; }
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { t1 += red[k][0]; t2 += red[k][1]; }
+  const float inv = 1.f / ((float)a.C * (float)a.S);
+  const float m1 = t1 * inv, m2 = t2 * inv;
+#pragma unroll
+  for (int j = 0; j < RW; ++j) {
+    const int cw = wave + 16 * j;
+    if (cw >= Cw) continue;
+    const float ga = a.gamma[cw], ba = a.beta[cw], gb = a.gamma[cw + Cw], bb = a.beta[cw + Cw];
+    const float sc = a.mode == GN_GLU_SCALE_RES ? a.scale[cw] : 1.f;
+#pragma unroll
+    for (int q = 0; q < SV; ++q) {
+      const int s = lane + 64 * q;
+      const float xha = (xa[j][q] - mean) * rstd, xhb = (xb[j][q] - mean) * rstd;
+      const float ua = xha * ga + ba, ub = xhb * gb + bb;
+      const float sg = rfx_sigmoid(ub);
+      const float g0 = a.mode == GN_GLU_SCALE_RES ? gg[j][q] * sc : gg[j][q];
+      const float dua = g0 * sg, dub = g0 * ua * sg * (1.f - sg);
+      if (s < a.S) {
+        dxn[(int64_t)cw * a.S + s] = rstd * (dua * ga - m1 - xha * m2);
+        dxn[(int64_t)(cw + Cw) * a.S + s] = rstd * (dub * gb - m1 - xhb * m2);
+      }
+    }
+  }
+}
+
 static int norm_bwd(int bn, const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t G, int32_t mode, const float* scale,
@@ -602,8 +690,12 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
   if (nchunks > 1 && hipMemsetAsync(work, 0, sizeof(float) * ((int64_t)N * C * 2 + (int64_t)N * (C / 2)), s) != hipSuccess)
     return -3;
   if (!bn && G == 1 && N >= 512 && (int64_t)C * S <= 65536) {
-    // many small samples: one workgroup per sample, both passes fused (gn_bwd_sample_kernel)
-    hipLaunchKernelGGL(gn_bwd_sample_kernel, dim3((unsigned)N), dim3(256), 0, s, a, part, psc);
+    // many small samples: one workgroup per sample, both passes fused (gn_bwd_sample_kernel); the GLU modes of the
+    // HDemucs freq-branch shapes keep the sample in registers (gn_bwd_sample_reg_kernel)
+    if (glu && S <= 256 && C / 2 <= 48)
+      hipLaunchKernelGGL((gn_bwd_sample_reg_kernel<3, 4>), dim3((unsigned)N), dim3(1024), 0, s, a, part, psc);
+    else
+      hipLaunchKernelGGL(gn_bwd_sample_kernel, dim3((unsigned)N), dim3(256), 0, s, a, part, psc);
     RFX_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
     RFX_CHECK_LAUNCH();
