@@ -1,0 +1,138 @@
+"""Size-independent properties at BASELINE.json's full sizes (262144-sample clips, full-width layers), where the CPU
+oracle is too slow to be the checker: round trips, linearity, normalisation invariants, time-reversal symmetry."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CLIP = 262144
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def test_stft_istft_round_trip_full_clips():
+    """iSTFT(STFT(x)) == x for 16 full clips at the HDemucs geometry (n_fft 4096, hop 1024) and at the three loss
+    resolutions' n_fft / hop with a full-length hann window (constant-overlap-add holds for hop | n_fft/2 only there)."""
+    from remfx_amd import stft
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(16, CLIP, generator=g).to(DEV)
+    for n_fft, hop in ((4096, 1024), (2048, 512), (1024, 256), (512, 128)):
+        spec = stft.stft(x, n_fft, hop, mode="complex")
+        assert spec.shape == (16, n_fft // 2 + 1, CLIP // hop + 1, 2)
+        back = stft.istft(spec, n_fft, hop, mode="complex", length=CLIP)
+        assert _rel(back, x) < 2e-6, (n_fft, hop)
+    # Parseval on the loss geometry (hann 600 in n_fft 1024, hop 120): sum_frames |X|^2 tracks the windowed energy
+    spec = stft.stft(x, 1024, 120, win=600, mode="complex")
+    e_spec = (spec[:, 1:-1] ** 2).sum(dim=(1, 2, 3)) * 2 + (spec[:, 0] ** 2).sum(dim=(1, 2)) + (spec[:, -1] ** 2).sum(dim=(1, 2))
+    w = torch.hann_window(600, periodic=True, device=DEV)
+    e_time = (x ** 2).sum(dim=1) * (w ** 2).sum() / 120 * 1024        # every sample is covered by win/hop frames
+    assert float(((e_spec - e_time).abs() / e_time).max()) < 2e-3      # edges (reflect padding) are 600 of 262144 samples
+
+
+@pytest.mark.parametrize("shape,cout,kernel,stride,padding", [
+    ((8, 4, 2048, 256), 48, (8, 1), (4, 1), (2, 0)),      # HDemucs freq encoder 0 at full size
+    ((8, 48, 1, 65536), 96, (1, 8), (1, 4), (0, 2)),      # time encoder 1 at full length
+    ((4, 96, 128, 256), 192, (3, 3), (1, 1), (1, 1)),     # freq rewrite conv (context 1)
+])
+def test_conv_linearity_full_layers(shape, cout, kernel, stride, padding):
+    """conv(a x + b y) == a conv(x) + b conv(y) (zero bias), forward and input gradient, in both arithmetic modes."""
+    from remfx_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(shape, generator=g).to(DEV), torch.randn(shape, generator=g).to(DEV)
+    w = (torch.randn(cout, shape[1], *kernel, generator=g) / (shape[1] * kernel[0] * kernel[1]) ** 0.5).to(DEV)
+    prev = ops.GEMM_PREC
+    try:
+        for prec, tol in (("f32", 2e-6), ("bf16x3", 5e-5)):
+            ops.set_gemm_precision(prec)
+            cx = ops.conv2d_forward(x, w, None, stride, padding, (1, 1))
+            cy = ops.conv2d_forward(y, w, None, stride, padding, (1, 1))
+            cz = ops.conv2d_forward(0.75 * x - 1.5 * y, w, None, stride, padding, (1, 1))
+            assert _rel(cz, 0.75 * cx - 1.5 * cy) < tol, prec
+            # adjoint identity <conv(x), g> == <x, dgrad(g)>
+            gy = torch.randn(cx.shape, generator=g).to(DEV)
+            dx = ops.conv2d_dgrad(gy, w, tuple(x.shape), tuple(x.stride()), stride, padding, (1, 1))
+            lhs, rhs = float((cx.double() * gy.double()).sum()), float((x.double() * dx.double()).sum())
+            assert abs(lhs - rhs) < 1e-3 * abs(lhs) + 0.05 * tol * float(cx.double().norm() * gy.double().norm()), prec
+    finally:
+        ops.GEMM_PREC = prev
+
+
+def test_groupnorm_invariants_full_size():
+    """GroupNorm(1, C) with unit affine: every sample of the output has mean 0 and variance 1; the backward of a
+    constant upstream gradient is 0 (the normalised output is shift invariant)."""
+    from remfx_amd import nnops
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(16, 48, 65536, generator=g) * 3 + 1.5).to(DEV).requires_grad_(True)
+    w, b = torch.ones(48, device=DEV, requires_grad=True), torch.zeros(48, device=DEV, requires_grad=True)
+    y = nnops.group_norm(x, 1, w, b, 1e-5, "none")
+    flat = y.detach().reshape(16, -1).double()
+    assert float(flat.mean(1).abs().max()) < 1e-5
+    assert float((flat.var(1, unbiased=False) - 1).abs().max()) < 1e-4
+    y.backward(torch.ones_like(y))
+    assert float(x.grad.abs().max()) < 1e-5
+    assert abs(float(b.grad.sum()) - 16 * 48 * 65536) < 1.0
+
+
+def test_blstm_time_reversal_full_size():
+    """A bidirectional LSTM with its two directions' weights swapped, fed the time-reversed sequence, returns the
+    time-reversed output with the direction halves swapped -- at the HDemucs layer-4 size (T=256, 512 sequences, H=192)."""
+    from remfx_amd import lstm
+    torch.manual_seed(3)
+    H, T, Bn = 192, 256, 512
+    m = nn.LSTM(H, H, num_layers=1, bidirectional=True).to(DEV)
+    sw = nn.LSTM(H, H, num_layers=1, bidirectional=True).to(DEV)
+    sd = m.state_dict()
+    sw.load_state_dict({(k[:-8] if k.endswith("_reverse") else k + "_reverse"): v for k, v in sd.items()})
+    x = torch.randn(1, H, T * Bn, device=DEV) * 0.5
+    with torch.no_grad():
+        y = lstm.blstm(m, x, T, Bn).view(2, H, T, Bn)
+        xr = x.view(H, T, Bn).flip(1).reshape(1, H, T * Bn).contiguous()
+        yr = lstm.blstm(sw, xr, T, Bn).view(2, H, T, Bn)
+    assert not lstm.error_flag()
+    assert _rel(yr.flip(2).flip(0), y) < 1e-5
+    assert float(y.abs().max()) <= 1.0 and float(y.abs().mean()) > 1e-3      # bounded by tanh, not degenerate
+
+
+def test_losses_identity_full_clips():
+    """loss(x, x): L1 = 0, MRSTFT = 0 with zero gradient, SI-SDR saturates -- on 16 full clips."""
+    from remfx_amd import losses
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(16, 1, CLIP, generator=g) * 0.2).to(DEV)
+    xg = x.clone().requires_grad_(True)
+    mr = losses.MultiResolutionSTFTLoss()(xg, x)
+    l1 = losses.L1Loss()(xg, x)
+    (mr + 100.0 * l1).backward()
+    assert float(mr) == 0.0 and float(l1) == 0.0
+    assert float(xg.grad.abs().max()) == 0.0 or float(xg.grad.abs().max()) < 1e-12
+    assert float(losses.SISDRLoss()(x, x)) < -60.0          # -SI-SDR in dB of a perfect estimate
+    # scale invariance of SI-SDR and the spectral-convergence term's scale covariance
+    y = x + 0.05 * torch.randn(16, 1, CLIP, generator=g).to(DEV)
+    s1, s2 = float(losses.SISDRLoss()(y, x)), float(losses.SISDRLoss()(3.0 * y, x))
+    assert abs(s1 - s2) < 1e-3
+
+
+def test_tcn_causality_and_shift_full_length():
+    """Causal TCN (reference tcn.py:94-97 crop choice) on a full clip: samples after position p cannot change outputs
+    before p, and delaying the input by d samples delays the output by d (time invariance of the conv stack)."""
+    from remfx_amd.tcn import TCN
+    torch.manual_seed(5)
+    net = TCN(ninputs=1, noutputs=1, nblocks=4, channel_width=32, kernel_size=13, dilation_growth=10, stack_size=10,
+              causal=True).to(DEV)
+    rf = net.receptive_field
+    x = torch.randn(2, 1, CLIP, device=DEV) * 0.3
+    with torch.no_grad():
+        y = net(x)
+        assert y.shape[-1] == CLIP - rf + 1
+        p = 150000
+        x2 = x.clone()
+        x2[..., p:] += torch.randn(2, 1, CLIP - p, device=DEV)
+        y2 = net(x2)
+        # output index j depends on input samples [j, j + rf): untouched while j + rf <= p
+        assert torch.equal(y[..., :p - rf + 1], y2[..., :p - rf + 1])
+        assert not torch.equal(y[..., p:], y2[..., p:])
+        d = 777
+        y3 = net(torch.roll(x, d, dims=-1))
+        assert _rel(y3[..., d:], y[..., :-d]) < 1e-6
