@@ -136,3 +136,44 @@ def test_tcn_causality_and_shift_full_length():
         d = 777
         y3 = net(torch.roll(x, d, dims=-1))
         assert _rel(y3[..., d:], y[..., :-d]) < 1e-6
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_demucs_full_config_directional_derivative(prec):
+    """Headline config (cfg/model/demucs.yaml, 83.6 M parameters, 262144-sample clips): the backward pass of the
+    training loss agrees with a central finite difference of the forward pass along the gradient direction, in the
+    exact-fp32 GEMM mode and in the bf16x3 mode bench.py runs in."""
+    from remfx_amd import models, ops
+    prev = ops.GEMM_PREC
+    ops.set_gemm_precision(prec)
+    try:
+        _directional_derivative(models)
+    finally:
+        ops.GEMM_PREC = prev
+
+
+def _directional_derivative(models):
+    torch.manual_seed(6)
+    net = models.DemucsModel(sample_rate=48000, sources=["mixture"], audio_channels=1, nfft=4096, channels=48).to(DEV)
+    assert sum(p.numel() for p in net.parameters()) == 83630131
+    g = torch.Generator().manual_seed(7)
+    y = (torch.randn(2, 1, CLIP, generator=g) * 0.1).to(DEV)
+    x = y + (torch.randn(2, 1, CLIP, generator=g) * 0.03).to(DEV)
+    params = [p for p in net.parameters() if p.requires_grad]
+    loss, _ = net((x, y))
+    loss.backward()
+    params = [p for p in params if p.grad is not None]      # HDemucs keeps a few parameters its forward never uses
+    grads = [p.grad.detach().clone() for p in params]
+    gnorm = float(torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads)))
+    assert gnorm > 0 and torch.isfinite(loss)
+    eps = 2e-3 * float(loss) / gnorm                    # first-order change of 0.2 % of the loss per side
+    vals = []
+    with torch.no_grad():
+        for sign in (1.0, -1.0):
+            for p, gr in zip(params, grads):
+                p.add_(gr, alpha=sign * eps / gnorm)
+            vals.append(float(net((x, y))[0]))
+            for p, gr in zip(params, grads):
+                p.sub_(gr, alpha=sign * eps / gnorm)
+    fd = (vals[0] - vals[1]) / (2 * eps)                # d loss / d t along the unit gradient direction = |grad|
+    assert abs(fd - gnorm) < 0.05 * gnorm, (fd, gnorm, vals, float(loss))
