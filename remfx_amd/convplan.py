@@ -264,5 +264,7 @@ def merged_phase_plan(inshape, instrides, rows, axis, G, J, off, out_len, ostrid
     else:
         p.OB = npos
     p.mg_log, p.mg_axis, p.mg_len, p.mg_off = int(G).bit_length() - 1, axis, out_len, off
+    if p.R == 0:                 # few output rows (last decoders: 1-2 channels x 4 phases): the thin kernel has no merged store;
+        p.R, p.Mpad = 1, 32      # one MFMA launch that reads the operand once beats G thin launches that each re-read it
     p.extra["out_shape"] = None
     return p

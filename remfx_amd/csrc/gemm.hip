@@ -194,7 +194,7 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   g.apack2 = apack2; g.ktab2 = ktab2; g.Kpad2 = apack2 ? Kpad2 : 0; g.in2 = in2;
   const int P = d->OA * d->OB;
   const int r = d->R;
-  if (r < 0 || r > 4 || (r == 0) != (d->M <= 8)) return -1;
+  if (r < 0 || r > 4 || (r == 0 && d->M > 8)) return -1;       // M <= 8 is normally thin (R = 0); merged-phase plans ask for R = 1
   hipStream_t s = (hipStream_t)stream;
   if (r == 0) {
     dim3 grid((P + 255) / 256, d->N);

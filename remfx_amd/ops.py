@@ -71,7 +71,7 @@ def _plans(key, device, builder):
 def pack_a(dp, w):
     """Gather the weight tensor into the packed [Kpad][Mpad] A matrix of a plan."""
     p = dp.p
-    prec = GEMM_PREC if p.M > 8 else 0          # thin path is always fp32
+    prec = GEMM_PREC if p.R > 0 else 0          # thin path is always fp32
     apack = torch.empty((p.Kpad + 64, p.Mpad), device=w.device, dtype=torch.float32)
     nrows = p.extra["n_weight_rows"]
     if True:
@@ -176,7 +176,7 @@ def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None, res
     if dx is None:
         dx = torch.empty_strided(xshape, xstrides, device=g.device, dtype=torch.float32)
     ax = _merge_axis(w.shape[2:], stride, padding, dilation)
-    if ax is not None and w.shape[1] * stride[ax] > 8:
+    if ax is not None and w.shape[1] * stride[ax] >= 4:
         # dx[ci][o] = sum g[co][i] w[co][ci][kk], o = S*i + kk - P: all S phases of o as rows (ci, q) of one GEMM over g
         wm, J = _merged_weight(w.transpose(0, 1), ax, stride[ax])
         out = _merged_launch(g, wm, ax, stride[ax], J, -padding[ax], dx)
@@ -335,7 +335,7 @@ def convT2d_forward(x, w, bias, stride, dilation, crop_lo, out_len, act=None):
     _, Cout, KA, KB = w.shape
     out = torch.empty((N, Cout, out_len[0], out_len[1]), device=x.device, dtype=torch.float32)
     ax = _merge_axis(w.shape[2:], stride, (0, 0), dilation)
-    if (ax is not None and act is None and Cout * stride[ax] > 8 and crop_lo[1 - ax] == 0
+    if (ax is not None and act is None and Cout * stride[ax] >= 4 and crop_lo[1 - ax] == 0
             and out_len[1 - ax] == x.shape[3 - ax]):
         # y[co][o] = sum x[ci][i] w[ci][co][kk], o = S*i + kk: the S phases of o as rows (co, q) of one GEMM over x
         wm, J = _merged_weight(w.transpose(0, 1), ax, stride[ax])

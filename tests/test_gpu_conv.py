@@ -73,6 +73,7 @@ TCASES = [
     (40, 33, (1, 50), (8, 1), (4, 1), (0, 0), (0, 0), 2),
     (48, 24, (1, 37), (1, 8), (1, 4), (0, 3), (0, 1), 2),       # merged phases, crop not a multiple of the stride
     (6, 5, (3, 21), (1, 16), (1, 8), (0, 5), (0, 2), 1),        # stride 8, two taps per phase
+    (48, 2, (16, 40), (8, 1), (4, 1), (2, 0), (2, 0), 2),       # last freq decoder: 2 channels x 4 phases merged on the MFMA kernel (R = 1, M = 8)
 ]
 
 
