@@ -666,6 +666,68 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
   }
 }
 
+// Tiny samples in the single-channel modes (DConv bottleneck: 12 / 24 channels x 256 frames): one WAVE owns a sample
+// and holds it in registers -- wave reductions only, no workgroup barrier, operands read once.
+template <int CMAX, int SV>
+__global__ __launch_bounds__(256) void gn_bwd_sample_wave_kernel(const GnArgs a, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= a.N) return;
+  const float mean = a.mean[n], rstd = a.rstd[n];
+  const float* xn = a.x + (int64_t)n * a.C * a.S;
+  const float* gyn = a.gy + (int64_t)n * a.C * a.S;
+  float* dxn = a.y + (int64_t)n * a.C * a.S;
+  float xv[CMAX][SV], gv[CMAX][SV];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const int cc = c < a.C ? c : a.C - 1;
+#pragma unroll
+    for (int q = 0; q < SV; ++q) {
+      const int s = lane + 64 * q;
+      const int ss = s < a.S ? s : a.S - 1;
+      xv[c][q] = xn[(int64_t)cc * a.S + ss];
+      gv[c][q] = gyn[(int64_t)cc * a.S + ss];
+    }
+  }
+  float gs1 = 0.f, gs2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const bool cok = c < a.C;
+    const int cc = cok ? c : a.C - 1;
+    const float gm = a.gamma[cc], bt = a.beta[cc];
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < SV; ++q) {
+      const float xh = (xv[c][q] - mean) * rstd;
+      float du = (cok && lane + 64 * q < a.S) ? gv[c][q] : 0.f;
+      if (a.mode == GN_GELU) du *= rfx_gelu_grad(xh * gm + bt);
+      else if (a.mode == GN_RELU) du = (xh * gm + bt) > 0.f ? du : 0.f;
+      gv[c][q] = du;                               // keep du: the dx pass needs no second activation derivative
+      v0 += du; v1 += du * xh;
+    }
+    v0 = rfx_wave_sum(v0); v1 = rfx_wave_sum(v1);
+    gs1 += gm * v0;
+    gs2 += gm * v1;
+    if (lane == 0 && cok) {
+      float* pa = part + ((int64_t)n * a.C + c) * 2;
+      pa[0] = v0; pa[1] = v1;
+    }
+  }
+  const float inv = 1.f / ((float)a.C * (float)a.S);
+  const float m1 = gs1 * inv, m2 = gs2 * inv;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    if (c >= a.C) continue;
+    const float gm = a.gamma[c];
+#pragma unroll
+    for (int q = 0; q < SV; ++q) {
+      const int s = lane + 64 * q;
+      const float xh = (xv[c][q] - mean) * rstd;
+      if (s < a.S) dxn[(int64_t)c * a.S + s] = rstd * (gv[c][q] * gm - m1 - xh * m2);
+    }
+  }
+}
+
 static int norm_bwd(int bn, const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t G, int32_t mode, const float* scale,
@@ -692,7 +754,11 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
   if (!bn && G == 1 && N >= 512 && (int64_t)C * S <= 65536) {
     // many small samples: one workgroup per sample, both passes fused (gn_bwd_sample_kernel); the GLU modes of the
     // HDemucs freq-branch shapes keep the sample in registers (gn_bwd_sample_reg_kernel)
-    if (glu && S <= 256 && C / 2 <= 48)
+    if (!glu && S <= 256 && C <= 12)
+      hipLaunchKernelGGL((gn_bwd_sample_wave_kernel<12, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, part);
+    else if (!glu && S <= 256 && C <= 24)
+      hipLaunchKernelGGL((gn_bwd_sample_wave_kernel<24, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, part);
+    else if (glu && S <= 256 && C / 2 <= 48)
       hipLaunchKernelGGL((gn_bwd_sample_reg_kernel<3, 4>), dim3((unsigned)N), dim3(1024), 0, s, a, part, psc);
     else
       hipLaunchKernelGGL(gn_bwd_sample_kernel, dim3((unsigned)N), dim3(256), 0, s, a, part, psc);
