@@ -64,7 +64,9 @@ typedef struct rfx_gemm_desc {
   int32_t SA, SB;        /* input position stride */
   int32_t Mpad, Kpad;    /* packed-A geometry: A is [Kpad][Mpad], Mpad%4==0, Kpad%16==0 */
   int32_t out_a0, out_b0, out_sa, out_sb;
-  int32_t R;             /* channel tiles (32 rows) per wave chosen by the planner: rfx_gemm_pick_r(M, K); 0 = thin path */
+  int32_t R;             /* channel tiles (32 rows) per wave chosen by the planner: rfx_gemm_pick_r(M, K); 0 = thin path
+                          * (M <= 8 only).  A phase-merged plan with M <= 8 sets R = 1, Mpad = 32: the thin kernels have no
+                          * merged store, and one MFMA launch reads the operand once instead of once per phase. */
   /* Phase-merged output (mg_log > 0): the G = 2^mg_log stride phases of a transposed convolution (or of the input
    * gradient of a strided convolution) run as ONE GEMM with rows m = channel*G + phase, so the gathers are shared by G
    * times more MFMA work.  Row m, position index i on axis mg_axis (0 = A, 1 = B) is stored at channel m >> mg_log,
