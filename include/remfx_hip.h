@@ -209,6 +209,13 @@ int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const 
 int rfx_act_fwd(const float* x, float* y, int64_t n, int32_t act, void* stream);
 /* gx = gy * act'(x) */
 int rfx_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int32_t act, void* stream);
+/* The same between row layouts: x, gy (NULL: forward, out = act(x); else out = gy * act'(x)) and out are (D0, D1, D2)
+ * grids of contiguous T-float rows with their own row strides (in floats).  Used where the reference permutes around
+ * an activation -- torchaudio HDemucs _HEncLayer: `y = gelu(norm1(conv(x)))` then `y.permute(0, 2, 1, 3).reshape(-1, C, T)`
+ * for the DConv branch (reached through remfx/models.py:319) -- so that the permuted copy is never made. */
+int rfx_act_rows(const float* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0, int64_t gs1,
+                 int64_t gs2, float* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0, int32_t D1, int32_t D2,
+                 int32_t T, int32_t act, void* stream);
 /* PReLU with per-channel slope over [N][C][L] contiguous: gx, and gslope[C] (+=, atomics). */
 int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx, float* gslope,
                   int64_t N, int64_t C, int64_t L, void* stream);

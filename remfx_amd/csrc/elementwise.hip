@@ -164,6 +164,68 @@ extern "C" int rfx_act_fwd(const float* x, float* y, int64_t n, int32_t act, voi
   RFX_CHECK_LAUNCH();
   return 0;
 }
+// Activation between two row layouts: the tensor is a (D0, D1, D2) grid of contiguous T-float rows whose row offsets
+// differ between x, gy and out (HDemucs freq branch: GELU output written as (B, Fr, C, T) so that the DConv's
+// (B*Fr, C, T) view is free, and its backward reading the gradient from that layout).  gy == nullptr: out = act(x);
+// otherwise out = gy * act'(x).  One wave per (row, 256-sample chunk), wave-uniform 32-bit decode.
+struct ActRowsArgs {
+  const float* x; const float* gy; float* out;
+  int64_t xs[3], gs[3], os[3];
+  int D1, D2, T, act;
+  uint32_t nitems, ipr;
+};
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_rows_kernel(const ActRowsArgs a) {
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t w = blockIdx.x * 4u + wave;
+  if (w >= a.nitems) return;
+  const uint32_t row = w / a.ipr, ck = w - row * a.ipr;
+  const uint32_t r1 = row / (uint32_t)a.D2, i2 = row - r1 * (uint32_t)a.D2;
+  const uint32_t i0 = r1 / (uint32_t)a.D1, i1 = r1 - i0 * (uint32_t)a.D1;
+  const float* xr = a.x + (int64_t)i0 * a.xs[0] + (int64_t)i1 * a.xs[1] + (int64_t)i2 * a.xs[2];
+  const float* gr = a.gy ? a.gy + (int64_t)i0 * a.gs[0] + (int64_t)i1 * a.gs[1] + (int64_t)i2 * a.gs[2] : nullptr;
+  float* orow = a.out + (int64_t)i0 * a.os[0] + (int64_t)i1 * a.os[1] + (int64_t)i2 * a.os[2];
+  const int lane = threadIdx.x & 63;
+  if (VEC) {
+    const int t = (int)ck * 256 + lane * 4;
+    if (t >= a.T) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + t);
+    if (gr) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gr + t);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = g[c] * rfx_act_grad(v[c], a.act, 0.f);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = rfx_act_apply(v[c], a.act, 0.f);
+    }
+    *reinterpret_cast<f32x4*>(orow + t) = v;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = (int)ck * 256 + q * 64 + lane;
+      if (t < a.T) orow[t] = gr ? gr[t] * rfx_act_grad(xr[t], a.act, 0.f) : rfx_act_apply(xr[t], a.act, 0.f);
+    }
+  }
+}
+extern "C" int rfx_act_rows(const float* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0,
+                            int64_t gs1, int64_t gs2, float* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0,
+                            int32_t D1, int32_t D2, int32_t T, int32_t act, void* stream) {
+  if (!x || !out || D0 <= 0 || D1 <= 0 || D2 <= 0 || T <= 0) return -1;
+  const int64_t rows = (int64_t)D0 * D1 * D2, per = ((int64_t)T + 255) / 256;
+  if (rows * per > 0x7fffffffLL) return -1;
+  ActRowsArgs a;
+  a.x = x; a.gy = gy; a.out = out;
+  a.xs[0] = xs0; a.xs[1] = xs1; a.xs[2] = xs2; a.gs[0] = gs0; a.gs[1] = gs1; a.gs[2] = gs2;
+  a.os[0] = os0; a.os[1] = os1; a.os[2] = os2;
+  a.D1 = D1; a.D2 = D2; a.T = T; a.act = act; a.nitems = (uint32_t)(rows * per); a.ipr = (uint32_t)per;
+  const bool vec = !(T & 3) && !((xs0 | xs1 | xs2 | os0 | os1 | os2 | (gy ? (gs0 | gs1 | gs2) : 0)) & 3) &&
+                   !((uintptr_t)x & 15) && !((uintptr_t)out & 15) && !((uintptr_t)gy & 15);
+  const dim3 grid((a.nitems + 3) / 4);
+  if (vec) hipLaunchKernelGGL(act_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(act_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int rfx_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int32_t act, void* stream) {
   if (!x || !gy || !gx || n < 0) return -1;
   if (n == 0) return 0;

@@ -196,7 +196,12 @@ class _HEncLayer(nn.Module):
             if inject.dim() == 3 and y.dim() == 4:
                 inject = inject[:, :, None]
             y = nnops.add(y, inject)
-        y = _norm_act(self.norm1, y, "gelu")
+        if self.freq and not isinstance(self.norm1, nn.GroupNorm):
+            # GELU written straight into the (B, Fr, C, T) order the DConv branch views as (B*Fr, C, T): no permuted copy,
+            # and the backward reads the branch's gradient from that order (ops.ActToFn / rfx_act_rows)
+            y = ops.activation_to(y, "gelu", (0, 2, 1))
+        else:
+            y = _norm_act(self.norm1, y, "gelu")
         if self.freq:
             B, C, Fr, T = y.shape
             y = self.dconv(y.permute(0, 2, 1, 3).reshape(-1, C, T))

@@ -435,3 +435,46 @@ class ActFn(torch.autograd.Function):
 
 def activation(x, act):
     return ActFn.apply(x, act)
+
+
+def _row_strides(t):
+    """(D0, D1, D2, T) tensor whose last axis is contiguous -> its three row strides."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError("activation_to: 4-D tensors with a contiguous last axis")
+    return t.stride()[:3]
+
+
+class ActToFn(torch.autograd.Function):
+    """act(x) written with the memory order `perm` of x's first three axes (the result is x-shaped, with permuted
+    strides): the consumer's `permute(perm).reshape(...)` is then a view.  The backward reads the incoming gradient in
+    whatever row layout it arrives (csrc rfx_act_rows) -- no `.contiguous()` copy on either side."""
+
+    @staticmethod
+    def forward(ctx, x, act, perm):
+        _req(x)
+        xs = _row_strides(x)
+        D = x.shape
+        y = torch.empty([D[p] for p in perm] + [D[3]], device=x.device, dtype=torch.float32)
+        inv = [perm.index(i) for i in range(3)]
+        y = y.permute(*inv, 3)                                  # x-shaped view of the permuted buffer
+        ys = _row_strides(y)
+        check(_lib.lib().rfx_act_rows(_ptr(x), xs[0], xs[1], xs[2], None, 0, 0, 0, _ptr(y), ys[0], ys[1], ys[2],
+                                      D[0], D[1], D[2], D[3], ACT[act], _stream()), "rfx_act_rows")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        if gy.stride(3) != 1:
+            gy = gy.contiguous()
+        xs, gs, D = _row_strides(x), _row_strides(gy), x.shape
+        gx = torch.empty_strided(x.shape, x.stride(), device=x.device, dtype=torch.float32)
+        check(_lib.lib().rfx_act_rows(_ptr(x), xs[0], xs[1], xs[2], _ptr(gy), gs[0], gs[1], gs[2], _ptr(gx), xs[0], xs[1],
+                                      xs[2], D[0], D[1], D[2], D[3], ACT[ctx.act], _stream()), "rfx_act_rows")
+        return gx, None, None
+
+
+def activation_to(x, act, perm):
+    return ActToFn.apply(x, act, tuple(perm))

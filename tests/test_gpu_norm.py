@@ -102,3 +102,25 @@ def test_add_broadcast(xshape, yshape):
     assert _rms(out.detach().cpu(), x + 0.3 * y) < 1e-6
     assert _rms(xd.grad.cpu(), xr.grad) < 1e-6
     assert _rms(yd.grad.cpu(), yr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 5, 64), (3, 4, 7, 50)])
+def test_activation_to_permuted_layout(shape):
+    """ops.activation_to: GELU written in (B, Fr, C, T) memory order (vector and scalar row paths); the consumer's
+    permute + reshape is a view and the gradient is read from that layout."""
+    from remfx_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g)
+    B, C, Fr, T = shape
+    gy = torch.randn(B * Fr, C, T, generator=g)
+    xr = x.clone().requires_grad_(True)
+    zr = F.gelu(xr).permute(0, 2, 1, 3).reshape(-1, C, T)
+    (zr * gy).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.activation_to(xd, "gelu", (0, 2, 1))
+    assert y.shape == xd.shape and y.permute(0, 2, 1, 3).is_contiguous()
+    z = y.permute(0, 2, 1, 3).reshape(-1, C, T)
+    assert z.data_ptr() == y.data_ptr()                      # a view, not a copy
+    (z * gy.to(DEV)).sum().backward()
+    assert _rms(z.detach().cpu(), zr.detach()) < 1e-6
+    assert _rms(xd.grad.cpu(), xr.grad) < 1e-6
