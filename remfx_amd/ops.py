@@ -203,7 +203,7 @@ def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias):
     gemm_wgrad(dp, x, g, dapack)
     dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
     unpack_add(dp, dapack, dw)
-    db = dapack[:, p.K - 1].clone() if need_bias else None
+    db = dapack[:, p.K - 1] if need_bias else None       # a strided view: autograd's accumulation reads it in place
     return dw, db
 
 
