@@ -123,6 +123,10 @@ int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int
 /* w[m*w_ms + woff[k]] += dapack[m][k]  (dapack is the [M][Kpad] output of rfx_gemm_wgrad). */
 int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
                    int32_t Kpad, float* dw, void* stream);
+/* Same with `=` instead of `+=`: for a plan whose K rows cover every weight element exactly once (a dense
+ * convolution's own plan) the caller need not zero-fill dw first. */
+int rfx_unpack_set(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
+                   int32_t Kpad, float* dw, void* stream);
 
 /* Forward gather-GEMM on the fp32 MFMA path (v_mfma_f32_32x32x2_f32).
  * Optional second phase (apack2/ktab2/K2 != 0): after phase 1 the epilogue

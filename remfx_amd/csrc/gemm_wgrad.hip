@@ -1,6 +1,7 @@
 // Weight-gradient kernels of the gather-GEMM family (see gemm_fwd.h for the family overview).
 #include "gemm_fwd.h"
 
+template <bool ADD>
 __global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_t* __restrict__ woff,
                                   int64_t w_ms, int M, int K, int Kpad, float* __restrict__ dw) {
   const int64_t total = (int64_t)K * M;
@@ -9,7 +10,8 @@ __global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_
     const int m = (int)(i / K), k = (int)(i % K);
     // distinct (k, m) map to distinct weight elements within one descriptor, but
     // several descriptors (stride phases) may run back to back on the stream.
-    dw[(int64_t)m * w_ms + woff[k]] += dapack[(int64_t)m * Kpad + k];
+    if (ADD) dw[(int64_t)m * w_ms + woff[k]] += dapack[(int64_t)m * Kpad + k];
+    else dw[(int64_t)m * w_ms + woff[k]] = dapack[(int64_t)m * Kpad + k];
   }
 }
 
@@ -333,16 +335,26 @@ __global__ __launch_bounds__(256) void gemm_thin_wgrad_kernel(const WgradArgs w)
 }
 
 
-extern "C" int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
-                              int32_t K, int32_t Kpad, float* dw, void* stream) {
+static int unpack_launch(bool add, const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
+                         int32_t Kpad, float* dw, void* stream) {
   if (!dapack || !woff || !dw || M <= 0 || K < 0 || Kpad < K) return -1;
   const int64_t total = (int64_t)K * M;
   if (total == 0) return 0;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(unpack_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff,
-                     w_ms, M, K, Kpad, dw);
+  if (add) hipLaunchKernelGGL(unpack_add_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff,
+                              w_ms, M, K, Kpad, dw);
+  else hipLaunchKernelGGL(unpack_add_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff,
+                          w_ms, M, K, Kpad, dw);
   RFX_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
+                              int32_t K, int32_t Kpad, float* dw, void* stream) {
+  return unpack_launch(true, dapack, woff, w_ms, M, K, Kpad, dw, stream);
+}
+extern "C" int rfx_unpack_set(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
+                              int32_t K, int32_t Kpad, float* dw, void* stream) {
+  return unpack_launch(false, dapack, woff, w_ms, M, K, Kpad, dw, stream);
 }
 
 // R (channel tiles per wave) is a pure function of M so that host-side packing

@@ -114,6 +114,13 @@ def gemm_wgrad(dp, x, g, dapack):
                                     GEMM_PREC, _stream()), "rfx_gemm_wgrad")
 
 
+def unpack_set(dp, dapack, dw):
+    """dw = unpacked dapack; only for plans whose rows cover every element of dw exactly once (dense conv plans)."""
+    p = dp.p
+    check(_lib.lib().rfx_unpack_set(_ptr(dapack), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"],
+                                    p.Kpad, _ptr(dw), _stream()), "rfx_unpack_set")
+
+
 def unpack_add(dp, dapack, dw):
     p = dp.p
     check(_lib.lib().rfx_unpack_add(_ptr(dapack), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"],
@@ -201,8 +208,8 @@ def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias):
     p = dp.p
     dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
     gemm_wgrad(dp, x, g, dapack)
-    dw = torch.zeros(wshape, device=x.device, dtype=torch.float32)
-    unpack_add(dp, dapack, dw)
+    dw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+    unpack_set(dp, dapack, dw)                             # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
     db = dapack[:, p.K - 1] if need_bias else None       # a strided view: autograd's accumulation reads it in place
     return dw, db
 
