@@ -581,7 +581,9 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, floa
 // Register-resident form of gn_bwd_sample_kernel for the GLU modes: 16 waves per sample, a wave owns RW channel pairs and
 // keeps their (x_a, x_b, gy) rows -- S <= 64 * SV values each -- in registers between the statistics pass and the dx
 // pass, so every operand is read exactly once (the 256-thread kernel re-reads them from L2 / Infinity Cache).
-template <int RW, int SV>
+// KEEPG = false (RW = 6: up to 96 channel pairs): gy is streamed in both passes (its second read comes from cache) and only
+// the two x rows stay in registers -- (x_a, x_b, gy) for six rows would spill at the 128 VGPRs a 1024-thread group has.
+template <int RW, int SV, bool KEEPG = true>
 __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a, float* __restrict__ part,
                                                                  float* __restrict__ psc) {
   __shared__ float red[16][2];
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
   const float* xn = a.x + (int64_t)n * a.C * a.S;
   const float* gyn = a.gy + (int64_t)n * Cw * a.S;
   float* dxn = a.y + (int64_t)n * a.C * a.S;
-  float xa[RW][SV], xb[RW][SV], gg[RW][SV];
+  float xa[RW][SV], xb[RW][SV], gg[KEEPG ? RW : 1][SV];
 #pragma unroll
   for (int j = 0; j < RW; ++j) {
     const int cw = wave + 16 * j;
@@ -602,9 +604,14 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
       const int ss = s < a.S ? s : a.S - 1;
       xa[j][q] = xn[(int64_t)cc * a.S + ss];
       xb[j][q] = xn[(int64_t)(cc + Cw) * a.S + ss];
-      gg[j][q] = gyn[(int64_t)cc * a.S + ss];
+      if (KEEPG) gg[j][q] = gyn[(int64_t)cc * a.S + ss];
     }
   }
+  auto gval = [&](int j, int q, int cc) {
+    if (KEEPG) return gg[j][q];
+    const int s = lane + 64 * q;
+    return gyn[(int64_t)cc * a.S + (s < a.S ? s : a.S - 1)];
+  };
   float gs1 = 0.f, gs2 = 0.f;
 #pragma unroll
   for (int j = 0; j < RW; ++j) {
@@ -620,7 +627,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
       const float xha = (xa[j][q] - mean) * rstd, xhb = (xb[j][q] - mean) * rstd;
       const float ua = xha * ga + ba, ub = xhb * gb + bb;
       const float sg = rfx_sigmoid(ub);
-      float g0 = gg[j][q] * ok;
+      float g0 = gval(j, q, cc) * ok;
       float gf = 0.f;
       if (a.mode == GN_GLU_SCALE_RES) { gf = g0 * ua * sg; g0 *= sc; }
       const float dua = g0 * sg, dub = g0 * ua * sg * (1.f - sg);
@@ -656,7 +663,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
       const float xha = (xa[j][q] - mean) * rstd, xhb = (xb[j][q] - mean) * rstd;
       const float ua = xha * ga + ba, ub = xhb * gb + bb;
       const float sg = rfx_sigmoid(ub);
-      const float g0 = a.mode == GN_GLU_SCALE_RES ? gg[j][q] * sc : gg[j][q];
+      const float gq = gval(j, q, cw);
+      const float g0 = a.mode == GN_GLU_SCALE_RES ? gq * sc : gq;
       const float dua = g0 * sg, dub = g0 * ua * sg * (1.f - sg);
       if (s < a.S) {
         dxn[(int64_t)cw * a.S + s] = rstd * (dua * ga - m1 - xha * m2);
@@ -760,6 +768,8 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
       hipLaunchKernelGGL((gn_bwd_sample_wave_kernel<24, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, part);
     else if (glu && S <= 256 && C / 2 <= 48)
       hipLaunchKernelGGL((gn_bwd_sample_reg_kernel<3, 4>), dim3((unsigned)N), dim3(1024), 0, s, a, part, psc);
+    else if (glu && S <= 256 && C / 2 <= 96)
+      hipLaunchKernelGGL((gn_bwd_sample_reg_kernel<6, 4, false>), dim3((unsigned)N), dim3(1024), 0, s, a, part, psc);
     else
       hipLaunchKernelGGL(gn_bwd_sample_kernel, dim3((unsigned)N), dim3(256), 0, s, a, part, psc);
     RFX_CHECK_LAUNCH();

@@ -14,7 +14,8 @@ def _rms(a, b):
 @pytest.mark.parametrize("shape,groups", [((1024, 2, 20), 1), ((3, 48, 7, 33), 4), ((2, 12, 5000), 1),
                                           ((5, 96, 64), 4), ((2, 8, 3, 50), 1),
                                           ((600, 12, 150), 1),    # 600 small samples: fused per-sample backward
-                                          ((520, 20, 70), 1)])    # 13-24 channels: the wider wave-per-sample variant
+                                          ((520, 20, 70), 1),     # 13-24 channels: the wider wave-per-sample variant
+                                          ((513, 130, 40), 1)])   # 65 channel pairs: register kernel that streams gy twice
 @pytest.mark.parametrize("mode", ["none", "gelu", "glu", "glu_scale_res"])
 def test_groupnorm_modes(shape, groups, mode):
     from remfx_amd import nnops
