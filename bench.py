@@ -104,7 +104,7 @@ def cpu_baseline(workload):
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     torch.manual_seed(0)
-    T = {"tcn": 16384, "demucs": 65536, "dcunet": 32768, "umx": 65536}[workload]
+    T = {"tcn": 16384, "demucs": CLIP, "dcunet": 32768, "umx": 65536}[workload]     # headline: one full 262144-sample clip
     x, y = torch.randn(1, 1, T, generator=g) * 0.1, torch.randn(1, 1, T, generator=g) * 0.1
     if workload == "tcn":
         sd = {k: v.requires_grad_(True) for k, v in ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7).items()}
