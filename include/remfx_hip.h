@@ -237,6 +237,12 @@ int rfx_add_bcast(const float* x, const float* y, float* out, int64_t N, int32_t
 int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv, void* stream);
 int rfx_row_affine(const float* x, const float* a, const float* b, float* out, int32_t R, int64_t L, void* stream);
 
+/* x[r][f][t] = 0 where f0[r] <= f < f1[r] or t0[r] <= t < t1[r], in place; x: (R, F, T) contiguous.
+ * torchaudio FrequencyMasking / TimeMasking (iid masks) as Cnn14 applies them in training when specaugment is set:
+ * classifier.py:185-187, 198-204.  Span bounds are R-length int32 device vectors drawn by the caller. */
+int rfx_span_mask(float* x, int32_t R, int32_t F, int32_t T, const int32_t* f0, const int32_t* f1, const int32_t* t0,
+                  const int32_t* t1, void* stream);
+
 /* sum |a-b| over n elements -> *out (+=, caller zeroes).  nn.L1Loss numerator, models.py:320 */
 int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream);
 

@@ -61,6 +61,28 @@ class MelSpectrogram(nn.Module):
         return mel.view(b, c, self.n_mels, mel.shape[-1])
 
 
+def _iid_span(n, size, mask_param, device):
+    """torchaudio mask_along_axis_iid bookkeeping: per row, length ~ U[0, mask_param), start ~ U[0, size - length)."""
+    value = torch.rand(n, device=device) * mask_param
+    start = (torch.rand(n, device=device) * (size - value)).long()
+    return start.int(), (start + value.long()).int()
+
+
+def spec_augment(x, freq_mask_param, time_mask_param):
+    """FrequencyMasking(freq_mask_param, iid_masks=True) then TimeMasking(time_mask_param, iid_masks=True), mask
+    value 0, one span each per (batch, channel) row.  x: (B, C, F, T); returns a masked copy (no parameters
+    upstream of the mel spectrogram, so no gradient is needed through the mask)."""
+    B, Cc, Fq, T = x.shape
+    y = x.detach().clone()
+    f0, f1 = _iid_span(B * Cc, Fq, freq_mask_param, x.device)
+    t0, t1 = _iid_span(B * Cc, T, time_mask_param, x.device)
+    from . import _lib
+    from .ops import _ptr, _stream
+    _lib.check(_lib.lib().rfx_span_mask(_ptr(y), B * Cc, Fq, T, _ptr(f0), _ptr(f1), _ptr(t0), _ptr(t1), _stream()),
+               "rfx_span_mask")
+    return y
+
+
 class ConvBlock(nn.Module):
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -100,19 +122,21 @@ class Cnn14(nn.Module):
         self.fc1 = nn.Linear(2048, 2048, bias=True)
         self.heads = nn.ModuleList([nn.Linear(2048, 1, bias=True) for _ in range(num_classes)])
         self.init_weight()
-        if sample_rate != model_sample_rate:
-            raise NotImplementedError("resampling front end (classifier.py:180-183) is outside the hot path: "
-                                      "every RemFX config uses sample_rate == model_sample_rate")
-        if specaugment:
-            raise NotImplementedError("specaugment masking (classifier.py:185-187) is a training-time "
-                                      "augmentation outside the hot path")
+        # sample_rate != model_sample_rate: polyphase resampling on the device (classifier.py:180-183);
+        # specaugment: iid frequency / time span masks in training only (classifier.py:185-187, 198-204)
+        self.freq_mask_param, self.time_mask_param = 64, 128
 
     def init_weight(self):
         init_bn(self.bn0)
         init_layer(self.fc1)
 
     def forward(self, x: torch.Tensor, train: bool = False):
+        if self.sample_rate != self.model_sample_rate:
+            from .resample import resample
+            x = resample(x, self.sample_rate, self.model_sample_rate)
         x = self.melspec(x)                                                     # (B, 1, n_mels, frames)
+        if self.specaugment and train:
+            x = spec_augment(x, self.freq_mask_param, self.time_mask_param)
         # per-clip standardisation, unbiased std, no epsilon (classifier.py:207)
         x = (x - x.mean(dim=(2, 3), keepdim=True)) / x.std(dim=(2, 3), keepdim=True)
         for i in range(1, 7):

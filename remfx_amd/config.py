@@ -26,8 +26,6 @@ TARGET_ALIASES = {
     "pytorch_lightning.Trainer": "remfx_amd.trainer.Trainer",
     "pytorch_lightning.loggers.CSVLogger": "remfx_amd.trainer.CSVLogger",
     "pytorch_lightning.loggers.csv_logs.CSVLogger": "remfx_amd.trainer.CSVLogger",
-    "remfx.datasets.EffectDatamodule": "remfx_amd.datasets.SyntheticEffectDatamodule",
-    "remfx.datasets.EffectDataset": "remfx_amd.datasets.SyntheticEffectDataset",
 }
 SKIP_TARGET_PREFIXES = ("pytorch_lightning.callbacks.", "remfx.callbacks.")
 

@@ -314,6 +314,22 @@ extern "C" int rfx_add_bcast(const float* x, const float* y, float* out, int64_t
   RFX_CHECK_LAUNCH();
   return 0;
 }
+__global__ void span_mask_kernel(float* __restrict__ x, int F, int T, const int32_t* __restrict__ f0,
+                                 const int32_t* __restrict__ f1, const int32_t* __restrict__ t0,
+                                 const int32_t* __restrict__ t1) {
+  const int r = blockIdx.y, f = blockIdx.x;
+  const bool frow = f >= f0[r] && f < f1[r];
+  const int ta = frow ? 0 : t0[r], tb = frow ? T : t1[r];
+  float* row = x + ((int64_t)r * F + f) * T;
+  for (int t = ta + threadIdx.x; t < tb; t += blockDim.x) row[t] = 0.f;
+}
+extern "C" int rfx_span_mask(float* x, int32_t R, int32_t F, int32_t T, const int32_t* f0, const int32_t* f1,
+                             const int32_t* t0, const int32_t* t1, void* stream) {
+  if (!x || !f0 || !f1 || !t0 || !t1 || R <= 0 || F <= 0 || T <= 0) return -1;
+  hipLaunchKernelGGL(span_mask_kernel, dim3(F, R), dim3(256), 0, (hipStream_t)stream, x, F, T, f0, f1, t0, t1);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv,
                                void* stream) {
   if (!x || !sums || !mean || !stdv || R <= 0 || L <= 1) return -1;

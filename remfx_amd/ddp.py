@@ -39,6 +39,15 @@ def broadcast_parameters(flat_data, src=0):
         dist.broadcast(flat_data, src)
 
 
+def broadcast_buffers(module, src=0):
+    """Module buffers (BatchNorm running mean / var / counters of Cnn14, Open-Unmix, DCUNet) from rank 0: DDP
+    broadcasts them at construction; parameters travel with the flat buffer above."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for b in module.buffers():
+            if b.numel():
+                dist.broadcast(b.data, src)
+
+
 class GradSync:
     """Bucketed async all-reduce of a FlatParams gradient buffer, overlapped with backward."""
 

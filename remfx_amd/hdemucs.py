@@ -257,13 +257,25 @@ class _HDecLayer(nn.Module):
             y = x
             if skip is not None:
                 raise ValueError("skip must be None when empty is true.")
-        if self.freq:      # crop [pad : -pad] along Fr folded into the transposed-conv plan
+        act = "none" if self.last else "gelu"
+        if isinstance(self.norm2, nn.GroupNorm):
+            # upstream order: z = norm2(conv_tr(y)) over the FULL transposed-conv output, crop afterwards -- the
+            # GroupNorm statistics include the border samples the crop drops (deep layers only: index >= norm_starts)
+            if self.freq:
+                zf = ops.conv_transpose2d(y, self.conv_tr.weight, self.conv_tr.bias, (self.stride, 1), (1, 1))
+                zf = _norm_act(self.norm2, zf, act)
+                z = zf[:, :, self.pad:zf.shape[2] - self.pad, :] if self.pad else zf
+            else:
+                zf = ops.conv_transpose1d(y, self.conv_tr.weight, self.conv_tr.bias, self.stride, 1)
+                z = _norm_act(self.norm2, zf, act)[..., self.pad:self.pad + length]
+            return z, y
+        if self.freq:      # Identity norm: crop [pad : -pad] along Fr folded into the transposed-conv plan
             full = (y.shape[2] - 1) * self.stride + self.kernel_size
             z = ops.conv_transpose2d(y, self.conv_tr.weight, self.conv_tr.bias, (self.stride, 1), (1, 1),
                                      (self.pad, 0), (full - 2 * self.pad, y.shape[3]))
         else:              # crop [pad : pad + length]
             z = ops.conv_transpose1d(y, self.conv_tr.weight, self.conv_tr.bias, self.stride, 1, self.pad, length)
-        z = _norm_act(self.norm2, z, "none" if self.last else "gelu")
+        z = _norm_act(self.norm2, z, act)
         return z, y
 
 

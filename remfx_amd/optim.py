@@ -79,23 +79,63 @@ class FlatAdamW:
         self.flat.zero_grad()
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
+        """torch.optim.AdamW.state_dict() layout ({"state": {i: {step, exp_avg, exp_avg_sq}}, "param_groups": [...]}),
+        the form Lightning stores under ckpt["optimizer_states"][0] (reference scripts/test.py:20-23 reads such files);
+        the per-parameter tensors are views of the flat moment buffers."""
+        f = self.flat
+        state = {}
+        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.m[o:o + p.numel()].view_as(p), "exp_avg_sq": self.v[o:o + p.numel()].view_as(p)}
+        group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(f.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
-        self.step_count = int(sd["step"]); self.param_groups[0]["lr"] = float(sd["lr"])
+        if "m" in sd:                                    # round-1 flat form
+            self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+            self.step_count = int(sd["step"]); self.param_groups[0]["lr"] = float(sd["lr"])
+            return
+        f = self.flat
+        if len(sd["state"]) not in (0, len(f.params)):
+            raise ValueError(f"optimizer state has {len(sd['state'])} parameters, the model {len(f.params)}")
+        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.m[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
+            self.v[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+            self.step_count = int(float(st["step"]))
+        g = sd["param_groups"][0]
+        self.param_groups[0]["lr"] = float(g["lr"])
+        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
 
 
 class MultiStepLR:
-    """torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma), stepped per batch
-    (models.py:192-205: milestones at 80 % / 95 % of max_steps, gamma 0.1)."""
+    """torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma) as `.step()` evaluates it (the chainable
+    form): the rate is multiplied by gamma ** count only on the step whose index EQUALS a milestone.  The reference
+    passes the floats 0.8 * max_steps and 0.95 * max_steps (models.py:193-197): a non-integer milestone never fires,
+    exactly as upstream.  Stepped per batch (interval "step")."""
 
     def __init__(self, optimizer, milestones, gamma=0.1):
-        self.opt, self.milestones, self.gamma = optimizer, sorted(float(m) for m in milestones), gamma
+        from collections import Counter
+        self.opt, self.milestones, self.gamma = optimizer, Counter(milestones), gamma
         self.base_lr = optimizer.param_groups[0]["lr"]
         self.last_epoch = 0
 
     def step(self):
         self.last_epoch += 1
-        k = sum(1 for m in self.milestones if self.last_epoch >= m)
-        self.opt.param_groups[0]["lr"] = self.base_lr * self.gamma ** k
+        if self.last_epoch in self.milestones:
+            self.opt.param_groups[0]["lr"] *= self.gamma ** self.milestones[self.last_epoch]
+
+    def state_dict(self):
+        lr = self.opt.param_groups[0]["lr"]
+        return {"milestones": self.milestones, "gamma": self.gamma, "base_lrs": [self.base_lr],
+                "last_epoch": self.last_epoch, "_step_count": self.last_epoch + 1, "_last_lr": [lr]}
+
+    def load_state_dict(self, sd):
+        self.milestones, self.gamma = sd["milestones"], sd["gamma"]
+        self.base_lr, self.last_epoch = sd["base_lrs"][0], int(sd["last_epoch"])
+        if sd.get("_last_lr"):
+            self.opt.param_groups[0]["lr"] = float(sd["_last_lr"][0])

@@ -1,8 +1,9 @@
 """Minimal stand-in for pytorch_lightning.Trainer, used when lightning is not installed
 (it is not in this image).  Implements exactly what scripts/train.py / chain_inference.py use
 (reference scripts/train.py:40-55, cfg/config.yaml:110-120): fit() over train batches with
-gradient-norm clipping, optimiser + per-step LR schedule, per-epoch validation, a
-{"state_dict": ...} checkpoint (the layout chain_inference.py:24-25 loads), and test().
+gradient-norm clipping, optimiser + per-step LR schedule, per-epoch validation, checkpoints in
+Lightning's on-disk layout (state_dict, optimizer_states, lr_schedulers, epoch, global_step: what
+chain_inference.py:24-25 / test.py:20-23 read), resume, and test().
 Multi-GPU: one process per GPU (torch.distributed / RCCL); gradients of the flat buffer are
 all-reduced by remfx_amd.ddp.GradSync, logged scalars are mean-reduced (sync_dist=True).
 """
@@ -32,21 +33,51 @@ class CSVLogger:
                 f.write(",".join(str(r.get(k, "")) for k in keys) + "\n")
 
 
+PRECISIONS = {"32": "f32", "32-true": "f32", "bf16-mixed": "bf16", "bf16": "bf16"}
+
+
+def _check_lstm(where):
+    from . import lstm as _lstm
+    if _lstm.error_flag():
+        raise RuntimeError(f"LSTM recurrence kernel reported a spin time-out ({where}): the step's outputs are invalid")
+
+
+def load_checkpoint_file(path, map_location="cpu"):
+    """torch.load of a Lightning / remfx_amd .ckpt; a missing file is an error, as in the reference (test.py:20).
+    RFX_ALLOW_RANDOM_INIT=1 turns it into a warning + None (throughput runs without released checkpoints)."""
+    if not path or not os.path.exists(str(path)):
+        if os.environ.get("RFX_ALLOW_RANDOM_INIT") == "1":
+            import warnings
+            warnings.warn(f"checkpoint {path!r} not found: keeping the seeded random initialisation (RFX_ALLOW_RANDOM_INIT=1)")
+            return None
+        raise FileNotFoundError(f"checkpoint {path!r} not found (set RFX_ALLOW_RANDOM_INIT=1 to run on random weights)")
+    return torch.load(path, map_location=map_location, weights_only=False)
+
+
 class Trainer:
     def __init__(self, max_steps=50000, max_epochs=-1, min_epochs=0, gradient_clip_val=None, accelerator=None,
                  devices=1, precision=32, log_every_n_steps=1, accumulate_grad_batches=1, callbacks=None,
-                 logger=None, limit_val_batches=None, limit_test_batches=None, **kwargs):
+                 logger=None, limit_val_batches=None, limit_test_batches=None, ckpt_every_n_steps=None, **kwargs):
         self.max_steps, self.max_epochs = max_steps, max_epochs
         self.gradient_clip_val = gradient_clip_val
         self.accelerator, self.devices, self.precision = accelerator, devices, precision
         self.callbacks, self.logger = callbacks or [], logger
         self.limit_val_batches, self.limit_test_batches = limit_val_batches, limit_test_batches
-        self.global_step = 0
+        self.ckpt_every_n_steps = ckpt_every_n_steps
+        self.global_step, self.current_epoch = 0, 0
         self.rank, self.local_rank, self.world = ddp.init_from_env()
-        if str(precision) not in ("32", "32-true"):
-            raise NotImplementedError("precision: the HIP path computes in fp32 this round (DESIGN.md)")
+        if str(precision) not in PRECISIONS:
+            raise ValueError(f"precision={precision!r}: supported {sorted(PRECISIONS)} (32 = exact fp32 MFMA; bf16-mixed = "
+                             "bf16 MFMA operands, fp32 accumulation / master weights / norms / FFT / losses)")
+        # "32" leaves the library's arithmetic mode alone (RFX_GEMM_PREC / ops.set_gemm_precision: f32 or bf16x3)
+        self.gemm_mode = "bf16" if PRECISIONS[str(precision)] == "bf16" else None
         self.device = torch.device("cuda", self.local_rank) if accelerator in ("gpu", "cuda") or (
             accelerator is None and torch.cuda.is_available()) else torch.device("cpu")
+
+    def _apply_precision(self):
+        if self.gemm_mode is not None:
+            from . import ops
+            ops.set_gemm_precision(self.gemm_mode)
 
     def _to(self, batch):
         return tuple(t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
@@ -58,18 +89,53 @@ class Trainer:
             self.logger.log(self.global_step, vals)
         return vals
 
-    def fit(self, model, datamodule=None, ckpt_dir=None):
+    # ---- checkpoints (Lightning's dict layout) ----------------------------------------------------
+    def checkpoint_dict(self, model, opt=None, sched=None):
+        ck = {"epoch": self.current_epoch, "global_step": self.global_step, "pytorch-lightning_version": "2.0.0",
+              "state_dict": model.state_dict(), "loops": {}, "callbacks": {},
+              "optimizer_states": [opt.state_dict()] if opt is not None else [],
+              "lr_schedulers": [sched.state_dict()] if sched is not None else []}
+        return ck
+
+    def save_checkpoint(self, path, model, opt=None, sched=None):
+        if self.rank != 0:
+            return
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        tmp = str(path) + ".tmp"
+        torch.save(self.checkpoint_dict(model, opt, sched), tmp)
+        os.replace(tmp, path)                                   # never leave a torn file behind a crash
+
+    def _resume(self, ckpt_path, model, opt, sched):
+        ck = load_checkpoint_file(ckpt_path, map_location=self.device)
+        if ck is None:
+            return
+        model.load_state_dict(ck["state_dict"])
+        if ck.get("optimizer_states"):
+            opt.load_state_dict(ck["optimizer_states"][0])
+        if sched is not None and ck.get("lr_schedulers"):
+            sched.load_state_dict(ck["lr_schedulers"][0])
+        self.global_step, self.current_epoch = int(ck.get("global_step", 0)), int(ck.get("epoch", 0))
+
+    def fit(self, model, datamodule=None, ckpt_dir=None, ckpt_path=None):
+        """ckpt_dir: where last.ckpt is written (every ckpt_every_n_steps steps when set, every epoch, and at the end);
+        ckpt_path: checkpoint to resume from (weights, AdamW moments, scheduler position, step / epoch counters)."""
+        self._apply_precision()
         model.trainer = self
         model.to(self.device)
         cfg = model.configure_optimizers()
         opt = cfg["optimizer"] if isinstance(cfg, dict) else cfg
         sched = cfg["lr_scheduler"]["scheduler"] if isinstance(cfg, dict) and "lr_scheduler" in cfg else None
+        if ckpt_path:
+            self._resume(ckpt_path, model, opt, sched)
         ddp.broadcast_parameters(opt.flat.data)
+        ddp.broadcast_buffers(model)                             # BatchNorm running statistics etc., as DDP does
         sync = ddp.GradSync(opt.flat)
-        epoch = 0
         last = {}
-        while self.global_step < self.max_steps and (self.max_epochs < 0 or epoch < self.max_epochs):
+        last_path = os.path.join(ckpt_dir, "last.ckpt") if ckpt_dir else None
+        while self.global_step < self.max_steps and (self.max_epochs < 0 or self.current_epoch < self.max_epochs):
             model.train()
+            if hasattr(datamodule, "set_epoch"):
+                datamodule.set_epoch(self.current_epoch)         # reshuffles the per-rank shards
             for i, batch in enumerate(datamodule.train_dataloader()):
                 if self.global_step >= self.max_steps:
                     break
@@ -77,15 +143,15 @@ class Trainer:
                 loss = model.training_step(self._to(batch), i)
                 loss.backward()
                 pre = sync.finish()
+                _check_lstm("before the optimiser step")         # never apply gradients of a timed-out exchange
                 opt.step(clip_norm=self.gradient_clip_val, grad_prescale=pre)
                 if sched is not None:
                     sched.step()
                 self.global_step += 1
                 last = self._log(model)
-            epoch += 1
-            from . import lstm as _lstm
-            if _lstm.error_flag():              # checked once per epoch (device sync): never train on a timed-out exchange
-                raise RuntimeError("LSTM recurrence kernel reported a spin time-out")
+                if last_path and self.ckpt_every_n_steps and self.global_step % self.ckpt_every_n_steps == 0:
+                    self.save_checkpoint(last_path, model, opt, sched)
+            self.current_epoch += 1
             if hasattr(datamodule, "val_dataloader"):
                 model.eval()
                 with torch.no_grad():
@@ -93,21 +159,25 @@ class Trainer:
                         if self.limit_val_batches is not None and i >= self.limit_val_batches:
                             break
                         model.validation_step(self._to(batch), i)
+                _check_lstm("validation")
                 last.update(self._log(model))
-        if ckpt_dir and self.rank == 0:
-            os.makedirs(ckpt_dir, exist_ok=True)
-            torch.save({"state_dict": model.state_dict(), "global_step": self.global_step, "epoch": epoch},
-                       os.path.join(ckpt_dir, "last.ckpt"))
+            if last_path:
+                self.save_checkpoint(last_path, model, opt, sched)
+        if last_path:
+            self.save_checkpoint(last_path, model, opt, sched)
         if self.logger is not None and self.rank == 0:
             self.logger.save()
         self.logged_metrics = last
         return last
 
     def test(self, model, datamodule=None, ckpt_path=None):
+        self._apply_precision()
         model.trainer = self
         model.to(self.device)
-        if ckpt_path and os.path.exists(str(ckpt_path)):
-            model.load_state_dict(torch.load(ckpt_path, map_location=self.device)["state_dict"])
+        if ckpt_path and ckpt_path != "best":                    # "best": the in-memory weights of the fit that just ended
+            ck = load_checkpoint_file(ckpt_path, map_location=self.device)
+            if ck is not None:
+                model.load_state_dict(ck["state_dict"])
         model.eval()           # registered sub-modules only: removal models kept in a plain dict stay as they are (Q6)
         sums, n = {}, 0
         with torch.no_grad():
@@ -118,6 +188,7 @@ class Trainer:
                 for k, v in model.logged.items():
                     sums[k] = sums.get(k, 0.0) + float(v)
                 n += 1
+        _check_lstm("test")
         out = {k: float(ddp.all_reduce_mean_scalar(torch.tensor(v / max(n, 1), device=self.device))) for k, v in sums.items()}
         if self.logger is not None and self.rank == 0:
             self.logger.log(self.global_step, out)

@@ -1,8 +1,8 @@
 """Chain-inference entry point, same command line as the reference scripts/chain_inference.py:11-73:
     python scripts/chain_inference.py +exp=remfx_detect
 Effect-specific removal models + the Cnn14 detector are instantiated from cfg.ckpts / cfg.classifier;
-checkpoints ({"state_dict": ...}, strict load) are read when the files exist, otherwise the networks keep
-their seeded random initialisation (no checkpoints are reachable offline; throughput / parity runs)."""
+checkpoints ({"state_dict": ...}, strict load) must exist, as upstream; RFX_ALLOW_RANDOM_INIT=1 keeps the seeded
+random initialisation instead, with a warning (no released checkpoint is reachable offline: throughput runs)."""
 import os
 import sys
 
@@ -13,22 +13,23 @@ import torch  # noqa: E402
 
 from remfx_amd import config as rcfg  # noqa: E402
 from remfx_amd.models import RemFXChainInference  # noqa: E402
+from remfx_amd.trainer import load_checkpoint_file  # noqa: E402
 
 
 def build(cfg, device):
     models = {}
     for effect, node in cfg["ckpts"].items():
         model = rcfg.instantiate(node["model"])
-        path = node.get("ckpt_path")
-        if path and os.path.exists(str(path)):
-            model.load_state_dict(torch.load(path, map_location=device)["state_dict"])      # strict, as upstream
+        ck = load_checkpoint_file(node.get("ckpt_path"), map_location=device)
+        if ck is not None:
+            model.load_state_dict(ck["state_dict"])                                          # strict, as upstream
         models[effect] = model.to(device)
     classifier = None
     if "classifier" in cfg:
         classifier = rcfg.instantiate(cfg["classifier"])
-        path = cfg.get("classifier_ckpt")
-        if path and os.path.exists(str(path)):
-            classifier.load_state_dict(torch.load(path, map_location=device)["state_dict"])
+        ck = load_checkpoint_file(cfg.get("classifier_ckpt"), map_location=device)
+        if ck is not None:
+            classifier.load_state_dict(ck["state_dict"])
         classifier.to(device)
     return RemFXChainInference(models, sample_rate=cfg["sample_rate"], num_bins=cfg["num_bins"],
                                effect_order=list(cfg["inference_effects_ordering"]), classifier=classifier,
