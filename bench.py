@@ -187,7 +187,7 @@ def main():
                     choices=["demucs", "tcn", "dcunet", "umx", "chain"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm", default=os.environ.get("RFX_GEMM_PREC", "bf16x3"), choices=["bf16x3", "f32"],
+    ap.add_argument("--gemm", default=os.environ.get("RFX_GEMM_PREC", "bf16x3"), choices=["bf16x3", "f32", "bf16"],
                     help="MFMA arithmetic of the gather-GEMMs: split-bf16 x3 with fp32 accumulate (default; "
                          "HDemucs forward within 4e-6 RMS of the fp32 oracle) or exact fp32 MFMA")
     args = ap.parse_args()

@@ -73,8 +73,15 @@ typedef struct rfx_gemm_desc {
    * axis index i*G + (m & (G-1)) + mg_off if that lies in [0, mg_len); bias is indexed by the channel.  Epilogue
    * options other than bias / act are not available in this mode, nor is the thin (M <= 8) path. */
   int32_t mg_log, mg_axis, mg_len, mg_off;
+  /* Tap-major form of the reduction axis (Kpad_t > 0; planner: every operand with >= 8 channels and <= 112 taps), used
+   * by the bf16x3 / bf16 kernels: k runs over 8-channel groups g = t * gpt + c8 (tap t, channels 8*c8 .. 8*c8+7),
+   * Kpad_t = 16 * ceil(ntaps * gpt / 2); the table passed as `ktab` then has ntaps + 16 rows (off = offset of channel 0
+   * of the tap, da, db; 16 invalid tail rows) and In(n, k, a, b) adds channel * in_cs.  in_extent = bytes spanned by one
+   * sample of the operand: reads beyond it (padded channels of the last group) return 0. */
+  int32_t Kpad_t, gpt, ntaps, tap_reserved;
   int64_t in_ns, in_as, in_bs;
   int64_t out_ns, out_cs, out_as, out_bs;
+  int64_t in_cs, in_extent;
 } rfx_gemm_desc;
 
 /* Epilogue: v = acc + bias[m]; v = act(v); [second GEMM phase accumulates into
@@ -112,9 +119,14 @@ typedef struct rfx_epilogue {
  * RFX_PREC_BF16X3: every fp32 operand is split into two bf16 (hi + lo) and the product is
  * hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- ~2^-16 relative error per
  * product, 3/16 of the fp32 MFMA cost.  The packed buffer has the same size in both modes. */
-enum rfx_gemm_prec { RFX_PREC_F32 = 0, RFX_PREC_BF16X3 = 1 };
+/* RFX_PREC_BF16: operands rounded to bf16 (RNE), one MFMA per product, fp32 accumulation -- the arithmetic of
+ * `trainer.precision=bf16-mixed` (torch autocast rounds conv / linear operands the same way; storage, accumulators,
+ * norms, FFT and losses stay fp32 here).  BF16X3 / BF16 forward launches need the tap-major form (Kpad_t > 0); the
+ * planner falls back to RFX_PREC_F32 (exact) for operands with fewer than 8 channels. */
+enum rfx_gemm_prec { RFX_PREC_F32 = 0, RFX_PREC_BF16X3 = 1, RFX_PREC_BF16 = 2 };
 
-/* A[k][m] = w[m*w_ms + woff[k]]  (k < K), zero padded to [Kpad + 64][Mpad]: the packed
+/* (woff[k] < 0: zero row -- channel padding of the tap-major order.)
+ * A[k][m] = w[m*w_ms + woff[k]]  (k < K), zero padded to [Kpad + 64][Mpad]: the packed
  * matrix carries four extra all-zero K steps and every ktab passed to rfx_gemm_fwd
  * carries Kpad + 96 rows (the tail rows invalid: da = -2^30) so that the MFMA kernel's
  * operand prefetch is branch-free. */

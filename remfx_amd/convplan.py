@@ -72,6 +72,16 @@ class GemmPlan:
     mg_axis: int = 0
     mg_len: int = 0
     mg_off: int = 0
+    # tap-major form (built by finalize when cin >= 8; consumed by the bf16x3 / bf16 MFMA kernels):
+    # the reduction axis is re-ordered (tap, channel) in groups of 8 channels, see finalize()
+    cin: int = 0                 # channels of the gathered operand (rows of ktab are channel-major: k = ci*ntaps + t)
+    in_cs: int = 0               # its channel stride (elements)
+    ntaps: int = 0
+    gpt: int = 0                 # 8-channel groups per tap = ceil(cin / 8)
+    Kpad_t: int = 0              # 16 * ceil(ntaps * gpt / 2)
+    in_extent: int = 0           # elements spanned by one sample of the operand (buffer range check)
+    tap_tab: np.ndarray = None   # [ntaps + 16, 4] int32 (off of channel 0, da, db, 0); tail rows invalid
+    woff_t: np.ndarray = None    # [Kpad_t] int32 weight gather offsets in tap-major order, -1 = zero row
     extra: dict = field(default_factory=dict)
 
     def finalize(self, bias_row=False):
@@ -79,6 +89,7 @@ class GemmPlan:
         by the weight-gradient kernel to produce the bias gradient."""
         kt = np.asarray(self.ktab, dtype=np.int64).reshape(-1, 4)
         K = kt.shape[0]
+        self._build_tap_major(kt, np.asarray(self.woff, dtype=np.int64).reshape(-1))
         if bias_row:
             kt = np.concatenate([kt, np.array([[0, 0, 0, 1]], dtype=np.int64)], 0)
         Kall = kt.shape[0]
@@ -106,6 +117,48 @@ class GemmPlan:
         return self
 
 
+def _tap_major(self, kt, woff):
+    """Tap-major re-ordering of the reduction axis for the bf16 MFMA kernels (csrc/gemm_tap.h).
+
+    The builders emit rows channel-major, k = ci * ntaps + t with off = ci * in_cs + tapoff[t]: every row of a tap
+    shares (da, db).  The kernels walk 8-CHANNEL GROUPS g = t * gpt + c8 (gpt = ceil(cin / 8)); MFMA K step ks takes
+    group 2ks on lanes 0-31 and group 2ks + 1 on lanes 32-63, so a lane does ONE bounds test and one offset add per
+    8 gathers (the channel-major table cost two tests and a select per gather) and the 8 loads differ only by a
+    multiple of the channel stride.  Channels >= cin of the last group read past the sample's extent (hardware
+    buffer range check -> 0) and meet zero weight rows (woff_t = -1)."""
+    K = kt.shape[0]
+    if self.cin < 8 or K == 0 or K % self.cin:
+        self.cin = 0
+        return
+    nt = K // self.cin
+    if nt > 112:                       # the kernels keep the whole tap table in LDS (128 slots incl. padding)
+        self.cin = 0
+        return
+    taps = kt[:nt].copy()
+    ci = np.arange(self.cin)[:, None]
+    exp_off = (taps[None, :, 0] + ci * self.in_cs).reshape(-1)
+    if not (np.array_equal(kt[:, 0], exp_off) and np.array_equal(kt[:, 1:3], np.tile(taps[:, 1:3], (self.cin, 1)))
+            and not kt[:, 3].any()):
+        raise AssertionError("gather-GEMM plan rows are not (channel, tap) ordered")
+    gpt = -(-self.cin // 8)
+    G = nt * gpt
+    self.ntaps, self.gpt, self.Kpad_t = nt, gpt, 16 * (-(-G // 2))
+    tab = np.zeros((nt + 16, 4), dtype=np.int64)
+    tab[:nt] = taps
+    tab[nt:, 1] = INVALID_DA
+    self.tap_tab = tab.astype(np.int32)
+    wt = np.full(self.Kpad_t, -1, dtype=np.int64)
+    t, c = np.meshgrid(np.arange(nt), np.arange(gpt * 8), indexing="ij")
+    ok = c < self.cin
+    wt[((t * gpt * 8) + c)[ok]] = woff[(c * nt + t)[ok]]
+    self.woff_t = wt.astype(np.int32)
+    self.in_extent = ((self.cin - 1) * abs(int(self.in_cs)) + (self.IA - 1) * abs(int(self.in_as))
+                      + (self.IB - 1) * abs(int(self.in_bs)) + 1)
+
+
+GemmPlan._build_tap_major = _tap_major
+
+
 def _out_len(i, k, s, p, d):
     return (i + 2 * p - d * (k - 1) - 1) // s + 1
 
@@ -124,7 +177,7 @@ def conv_fwd_plan(xshape, xstrides, wshape, stride, padding, dilation, ystrides,
     woff = (ci * KA * KB + ka * KB + kb).reshape(-1)
     p = GemmPlan(N=N, M=Cout, K=ktab.shape[0], OA=OA, OB=OB, IA=IA, IB=IB, SA=SA, SB=SB,
                  in_ns=ns, in_as=as_, in_bs=bs, out_ns=ystrides[0], out_cs=ystrides[1],
-                 out_as=ystrides[2], out_bs=ystrides[3], ktab=ktab, woff=woff, w_ms=Cin * KA * KB)
+                 out_as=ystrides[2], out_bs=ystrides[3], ktab=ktab, woff=woff, w_ms=Cin * KA * KB, cin=Cin, in_cs=cs)
     p.extra["out_shape"] = (N, Cout, OA, OB)
     return p.finalize(bias_row)
 
@@ -159,7 +212,7 @@ def conv_dgrad_plans(xshape, xstrides, wshape, stride, padding, dilation, gshape
                          in_ns=gns, in_as=gas, in_bs=gbs, out_ns=xstrides[0], out_cs=xstrides[1],
                          out_as=xstrides[2], out_bs=xstrides[3], out_a0=pa, out_b0=pb, out_sa=SA,
                          out_sb=SB, ktab=np.array(rows, dtype=np.int64).reshape(-1, 4), woff=woff,
-                         w_ms=KA * KB)
+                         w_ms=KA * KB, cin=Cout if ta and tb else 0, in_cs=gcs)
             plans.append(p.finalize())
     return plans
 
@@ -205,7 +258,7 @@ def convT_fwd_plans(xshape, xstrides, wshape, stride, dilation, crop_lo, out_len
                          in_ns=ns, in_as=as_, in_bs=bs, out_ns=ystrides[0], out_cs=ystrides[1],
                          out_as=ystrides[2], out_bs=ystrides[3], out_a0=a0, out_b0=b0, out_sa=SA,
                          out_sb=SB, ktab=np.array(rows, dtype=np.int64).reshape(-1, 4), woff=woff,
-                         w_ms=KA * KB)
+                         w_ms=KA * KB, cin=Cin if ta and tb else 0, in_cs=cs)
             plans.append(p.finalize())
     return plans
 
@@ -227,7 +280,7 @@ def convT_dgrad_plan(xshape, xstrides, wshape, stride, dilation, crop_lo, gshape
     woff = (co * KA * KB + ka * KB + kb).reshape(-1)
     p = GemmPlan(N=N, M=Cin, K=ktab.shape[0], OA=IA, OB=IB, IA=GA, IB=GB, SA=SA, SB=SB,
                  in_ns=gns, in_as=gas, in_bs=gbs, out_ns=xstrides[0], out_cs=xstrides[1],
-                 out_as=xstrides[2], out_bs=xstrides[3], ktab=ktab, woff=woff, w_ms=Cout * KA * KB)
+                 out_as=xstrides[2], out_bs=xstrides[3], ktab=ktab, woff=woff, w_ms=Cout * KA * KB, cin=Cout, in_cs=gcs)
     return p.finalize(bias_row)
 
 
@@ -241,7 +294,7 @@ def shift_plan(xshape, xstrides, M, shift, oshape, ostrides):
     on, oc, oa, ob = ostrides
     p = GemmPlan(N=N, M=M, K=Cin, OA=oshape[2], OB=oshape[3], IA=IA, IB=IB, SA=1, SB=1,
                  in_ns=ns, in_as=as_, in_bs=bs, out_ns=on, out_cs=oc, out_as=oa, out_bs=ob,
-                 ktab=ktab, woff=ci.copy(), w_ms=Cin)
+                 ktab=ktab, woff=ci.copy(), w_ms=Cin, cin=Cin, in_cs=cs)
     return p.finalize()
 
 

@@ -14,7 +14,7 @@ __global__ void pack_a_kernel(const float* __restrict__ w, const int32_t* __rest
        i += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(i / Mpad), m = (int)(i % Mpad);
     float v = 0.f;
-    if (k < K && m < M) v = w[(int64_t)m * w_ms + woff[k]];
+    if (k < K && m < M) { const int o = woff[k]; v = o >= 0 ? w[(int64_t)m * w_ms + o] : 0.f; }
     apack[i] = v;
   }
 }
@@ -33,7 +33,7 @@ __global__ void pack_a_bf3_kernel(const float* __restrict__ w, const int32_t* __
     for (int q = 0; q < 8; ++q) {
       const int k = k8 * 8 + q;
       float v = 0.f;
-      if (k < K && m < M) v = w[(int64_t)m * w_ms + woff[k]];
+      if (k < K && m < M) { const int o = woff[k]; v = o >= 0 ? w[(int64_t)m * w_ms + o] : 0.f; }
       const uint32_t h = bf16_rne(v);
       const uint32_t l = bf16_rne(v - __uint_as_float(h << 16));
       hi[q >> 1] |= h << (16 * (q & 1));
@@ -140,7 +140,7 @@ extern "C" int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 extern "C" int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
                           int32_t Mpad, int32_t Kpad, int32_t prec, float* apack, void* stream) {
   if (!w || !woff || !apack || M <= 0 || K < 0 || Mpad < M || Kpad < K) return -1;
-  if (prec == 1) {
+  if (prec != 0) {
     const int64_t cells = (int64_t)(Kpad / 8 + 8) * Mpad;
     const int grid = (int)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_a_bf3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, woff, w_ms, M, K, Mpad,
@@ -180,7 +180,8 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
                             int32_t prec, void* stream) {
   if (!desc_ok(d) || !apack || !ktab || !in || !out) return -1;
   if ((apack2 != nullptr) != (ktab2 != nullptr)) return -1;
-  if (apack2 && (Kpad2 % 16 != 0 || Kpad2 < K2)) return -1;
+  if (apack2 && (Kpad2 % 16 != 0 || (prec == 0 && Kpad2 < K2))) return -1;
+  if (prec < 0 || prec > 2 || (d->R == 0 && prec != 0)) return -1;
   FwdArgs g;
   g.d = *d;
   g.apack = apack; g.ktab = ktab; g.in = in; g.out = out;
@@ -192,6 +193,7 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   if (d->mg_log && (d->R == 0 || g.e.bwd || g.e.res || g.e.act2 != RFX_ACT_NONE || g.e.stat_sums || apack2 ||
                     d->mg_log > 8 || d->mg_axis < 0 || d->mg_axis > 1)) return -1;
   g.apack2 = apack2; g.ktab2 = ktab2; g.Kpad2 = apack2 ? Kpad2 : 0; g.in2 = in2;
+  g.ntaps2 = apack2 ? K2 : 0;      // tap-major launches pass the second phase's tap count in K2
   const int P = d->OA * d->OB;
   const int r = d->R;
   if (r < 0 || r > 4 || (r == 0 && d->M > 8)) return -1;       // M <= 8 is normally thin (R = 0); merged-phase plans ask for R = 1
@@ -211,7 +213,12 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   const int64_t nblk = ((work + 7) / 8) * 8 * (d->Mpad / bm);
   if (nblk > 0x7fffffff) return -1;
   dim3 grid((unsigned)nblk);
-  return prec == 1 ? rfx_launch_gemm_fwd_bf3(g, r, grid, s) : rfx_launch_gemm_fwd_f32(g, r, grid, s);
+  if (prec == 0) return rfx_launch_gemm_fwd_f32(g, r, grid, s);
+  // bf16x3 / bf16: tap-major kernels (gemm_tap.h); the caller packed A and passes the tap tables in that order
+  if (d->Kpad_t <= 0 || d->Kpad_t % 16 != 0 || d->gpt <= 0 || d->ntaps <= 0 || d->ntaps > 112 || d->in_extent <= 0 ||
+      d->in_extent > 0x7fffffffLL || d->in_cs * 4 * 8 * d->gpt > 0x7fffffffLL) return -1;
+  if (apack2 && (K2 <= 0 || K2 > 112)) return -1;
+  return prec == 1 ? rfx_launch_gemm_fwd_bf3(g, r, grid, s) : rfx_launch_gemm_fwd_bf16(g, r, grid, s);
 }
 
 

@@ -33,6 +33,7 @@ struct FwdArgs {
   const rfx_ktab_entry* ktab2;
   int32_t Kpad2;
   const float* in2;
+  int32_t ntaps2;     // tap-major launches: taps of the second phase (ktab / ktab2 are tap tables there)
 };
 
 
@@ -188,213 +189,21 @@ __device__ __forceinline__ void run_phase(const rfx_gemm_desc& d, const float* _
   if (ks < nk) k_step<R>(d, apack, kt4, ks, m0, c, as, kts, acc, b0, b1);
 }
 
-// ---------------------------------------------------------------------------------
-#define RFX_BDIST 3   // gather look-ahead in K steps (ktab ring: 8 slots; tables are padded by 96 rows)
-// bf16x3 variant of the K loop: every fp32 operand is split x = hi + lo (two bf16) and
-// a.b ~= hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): ~2^-16
-// relative error per product instead of 2^-24, at 3/16 of the fp32-MFMA issue cost.
-// Lane (j = lane & 31, h = lane >> 5) now gathers the 8 consecutive taps k = 8h .. 8h+7 of its
-// column (one MFMA B fragment); packed weights arrive pre-split (pack_a_bf3_kernel).
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ void load_b8_bf3(const rfx_gemm_desc& d, const int4* ktl, int h, const LaneCtx& c,
-                                            float (&b)[8]) {
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    int4 e[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) e[q] = ktl[8 * h + half * 4 + q];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bool ok = c.jvalid & ((unsigned)(c.ia0 + e[q].y) < (unsigned)d.IA) &
-                      ((unsigned)(c.ib0 + e[q].z) < (unsigned)d.IB);
-      const uint32_t off = ok ? c.voff + ((uint32_t)e[q].x << 2) : RFX_BUF_OOB;
-      b[half * 4 + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, off, 0, 0));
-    }
-  }
-}
+// Position / tile bookkeeping shared by the forward kernels and their epilogue.
+struct TileCtx {
+  int n, pw, m0, a, b, wave, lane, l31, h;
+  bool jvalid;
+};
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// x = hi + lo with hi = RNE_bf16(x), lo = RNE_bf16(x - hi): v_cvt_pk_bf16_f32 does two values per instruction and
-// the residual is one packed subtract -> 5 VALU per pair (the mask / shift / add sequence it replaces took 13)
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
-  uint32_t hw[4], lw[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x2_t v = {x[2 * q], x[2 * q + 1]};
-    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-    const f32x2_t hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
-    hw[q] = h;
-    lw[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, bf16x2_t));
-  }
-  hi = __builtin_bit_cast(bf16x8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
-  lo = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
-}
-
-// A stage of the bf16x3 path: (hi, lo) x 2 k8 rows x BM cells = 4*BM 16-byte cells per K step, one or two per thread.
-// Plain scalars (not arrays) so the two in-flight stages of the software pipeline stay in registers.
-struct AStage { uint4 v0, v1; };
+// bias + activation applied to the accumulators (between the phases of a two-phase launch).  All per-row loads are
+// issued TOGETHER, unconditionally (clamped row index) and under wave-uniform tests only: with `if (e.bias) v += e.bias[m]`
+// inside the per-element loop hipcc emitted one load + s_waitcnt vmcnt(0) per element, i.e. 16*R serial L2 round trips
+// (~40 us) per workgroup -- more than the whole K loop of the short-K layers.
 template <int R>
-__device__ __forceinline__ uint4 stage_a_bf3_cell(const uint4* __restrict__ apk, int64_t arr_stride, int Mpad,
-                                                  int k8_0, int m0, int idx) {
-  constexpr int BM = 32 * R, NV = 4 * BM;
-  idx = idx < NV ? idx : NV - 1;
-  const int arr = idx / (2 * BM), rem = idx % (2 * BM);
-  const int kk8 = rem / BM, mm = rem % BM;
-  return apk[arr * arr_stride + (int64_t)(k8_0 + kk8) * Mpad + m0 + mm];
-}
-template <int R>
-__device__ __forceinline__ AStage stage_a_bf3_load(const uint4* __restrict__ apk, int64_t arr_stride, int Mpad,
-                                                   int k8_0, int m0, int tid) {
-  constexpr int NV = 128 * R;
-  AStage s;
-  s.v0 = stage_a_bf3_cell<R>(apk, arr_stride, Mpad, k8_0, m0, tid);
-  s.v1 = NV > 256 ? stage_a_bf3_cell<R>(apk, arr_stride, Mpad, k8_0, m0, tid + 256) : s.v0;
-  return s;
-}
-template <int R>
-__device__ __forceinline__ void stage_a_bf3_store(uint4* as, int tid, const AStage& s) {
-  constexpr int NV = 128 * R;
-  // UNCONDITIONAL stores (surplus threads rewrite the last cell with the same data), see stage_a_store
-  as[tid < NV ? tid : NV - 1] = s.v0;
-  if (NV > 256) as[tid + 256 < NV ? tid + 256 : NV - 1] = s.v1;
-}
-
-// One 16-deep K step of the bf16x3 pipeline.  LDS holds the A tiles of TWO K steps per buffer, so the workgroup
-// barrier comes only after every odd step (SUB == 1): with one barrier per K step the four waves re-synchronised every
-// ~0.2 us of matrix work and 40 % of the wave time was parked (PMC); a race-y run with half the barriers
-// bounded the gain at 3 % of the Demucs step.  Per step ks:
-//   LDS -> fragments of A(ks) from buffer (ks/2)&1, half SUB;
-//   global -> registers: table row of step ks+5, A tile of step ks+4 (into the register set that held A(ks+2));
-//   gathers of step ks+3 (the 4-deep ring);  MFMAs;
-//   registers -> LDS: A(ks+2) into the OTHER buffer, table row into ring slot (ks+5)&7;  barrier if SUB.
-// Everything written in steps {2D, 2D+1} is first read in step 2D+2, i.e. behind the barrier that ends step 2D+1.
-template <int R, int SUB>
-__device__ __forceinline__ void k_step_bf3(const rfx_gemm_desc& d, const uint4* __restrict__ apk,
-                                           int64_t arr_stride, const int4* __restrict__ kt4, int ks, int m0,
-                                           const LaneCtx& c, uint4* as, int4* kts, f32x16 (&acc)[R],
-                                           const float (&bc)[8], float (&bn)[8], AStage& a_set) {
-  constexpr int BM = 32 * R;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int buf = (ks >> 1) & 1;
-  const uint4* a_lds = as + buf * 8 * BM + SUB * 4 * BM;
-  uint4 ah[R], al[R];
-#pragma unroll
-  for (int mt = 0; mt < R; ++mt) {
-    ah[mt] = a_lds[h * BM + mt * 32 + l31];
-    al[mt] = a_lds[2 * BM + h * BM + mt * 32 + l31];
-  }
-  // issue order matters: vmcnt retires in order; the table row is written to LDS at the end of THIS step, so it goes
-  // first; the gathers, consumed RFX_BDIST steps later, go last and stay in flight
-  const int4 ktreg = kt4[(ks + RFX_BDIST + 2) * 16 + (tid & 15)];
-  const AStage a_now = a_set;                                         // A(ks+2), fetched two steps ago
-  a_set = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2 * (ks + 4), m0, tid);
-  load_b8_bf3(d, kts + ((ks + RFX_BDIST) & 7) * 16, h, c, bn);
-  bf16x8 bh, bl;
-  split8(bc, bh, bl);
-#pragma unroll
-  for (int mt = 0; mt < R; ++mt) {
-    const bf16x8 fh = __builtin_bit_cast(bf16x8, ah[mt]), fl = __builtin_bit_cast(bf16x8, al[mt]);
-    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bh, acc[mt], 0, 0, 0);
-    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl, acc[mt], 0, 0, 0);
-    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc[mt], 0, 0, 0);
-  }
-  stage_a_bf3_store<R>(as + (buf ^ 1) * 8 * BM + SUB * 4 * BM, tid, a_now);
-  kts[((ks + RFX_BDIST + 2) & 7) * 16 + (tid & 15)] = ktreg;   // every thread (same value per tid & 15)
-  if (SUB) __syncthreads();
-  else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // keep the two steps apart in the compiler too
-}
-
-template <int R>
-__device__ __forceinline__ void run_phase_bf3(const rfx_gemm_desc& d, const float* __restrict__ apack,
-                                              const rfx_ktab_entry* __restrict__ ktab, int Kpad, int m0,
-                                              const LaneCtx& c, float* as_f, int4* kts, f32x16 (&acc)[R]) {
-  constexpr int BM = 32 * R;
-  const int tid = threadIdx.x;
-  const int h = (tid & 63) >> 5;
-  const int nk = Kpad / 16;
-  if (nk == 0) return;
-  const uint4* apk = reinterpret_cast<const uint4*>(apack);
-  const int64_t arr_stride = (int64_t)(Kpad / 8 + 8) * d.Mpad;
-  uint4* as = reinterpret_cast<uint4*>(as_f);
-  const int4* kt4 = reinterpret_cast<const int4*>(ktab);
-  __syncthreads();            // a previous phase (two-phase launches) may still be reading the LDS buffers
-  float b0[8], b1[8];
-  {
-    const AStage s0 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 0, m0, tid);
-    const AStage s1 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 2, m0, tid);
-    if (tid < 16 * (RFX_BDIST + 2)) kts[tid] = kt4[tid];   // table rows of the first K steps (table is padded)
-    stage_a_bf3_store<R>(as, tid, s0);                       // A(0), A(1) -> buffer 0
-    stage_a_bf3_store<R>(as + 4 * BM, tid, s1);
-  }
-  __syncthreads();
-  // the gathers run RFX_BDIST K steps ahead of the MFMAs: one K step is ~0.2 us of matrix work, a gather that
-  // misses L2 takes ~1-2 us, and only two waves share a SIMD, so a single step of look-ahead left the kernel
-  // latency-bound (19 % MFMA utilisation in the r01 traces)
-  float b2[8], b3[8];
-  AStage a0 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 4, m0, tid);          // A(2), A(3): even / odd register set
-  AStage a1 = stage_a_bf3_load<R>(apk, arr_stride, d.Mpad, 6, m0, tid);
-  load_b8_bf3(d, kts, h, c, b0);
-  load_b8_bf3(d, kts + 16, h, c, b1);
-  load_b8_bf3(d, kts + 32, h, c, b2);
-  int ks = 0;
-  for (; ks + 3 < nk; ks += 4) {
-    k_step_bf3<R, 0>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b3, a0);
-    k_step_bf3<R, 1>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0, a1);
-    k_step_bf3<R, 0>(d, apk, arr_stride, kt4, ks + 2, m0, c, as, kts, acc, b2, b1, a0);
-    k_step_bf3<R, 1>(d, apk, arr_stride, kt4, ks + 3, m0, c, as, kts, acc, b3, b2, a1);
-  }
-  if (ks < nk) k_step_bf3<R, 0>(d, apk, arr_stride, kt4, ks, m0, c, as, kts, acc, b0, b3, a0);
-  if (ks + 1 < nk) k_step_bf3<R, 1>(d, apk, arr_stride, kt4, ks + 1, m0, c, as, kts, acc, b1, b0, a1);
-  if (ks + 2 < nk) k_step_bf3<R, 0>(d, apk, arr_stride, kt4, ks + 2, m0, c, as, kts, acc, b2, b1, a0);
-}
-
-template <int R, bool BF3>
-__global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
-  constexpr int BM = 32 * R;
-  __shared__ __attribute__((aligned(16))) float as[BF3 ? 4 * 16 * BM : 2 * 16 * BM];   // bf16x3: 2 buffers x 2 K steps
-  __shared__ __attribute__((aligned(16))) int4 kts[8 * 16];
+__device__ __forceinline__ void fwd_epilogue_mid(const FwdArgs& g, const TileCtx& tc, f32x16 (&acc)[R]) {
   const rfx_gemm_desc& d = g.d;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int P = d.OA * d.OB;
-  // XCD-aware tile order (block b runs on XCD b % 8, each XCD has its own L2): the channel tiles of one
-  // (sample, position tile) read the same input samples, so they are made consecutive ON THE SAME XCD;
-  // neighbouring position tiles are spread over the 8 XCDs.
-  const int mtiles = d.Mpad / BM, ptiles = (P + 127) / 128;
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int ym = q % mtiles, pw = (q / mtiles) * 8 + xcd;      // pw: (n, position tile) work item
-  if (pw >= ptiles * d.N) return;
-  const int n = pw / ptiles;
-  const int m0 = ym * BM;
-  const int j = (pw - n * ptiles) * 128 + wave * 32 + l31;
-  LaneCtx c;
-  c.jvalid = j < P;
-  const int jj = c.jvalid ? j : 0;
-  const int a = jj / d.OB, b = jj - a * d.OB;
-  c.ia0 = a * d.SA;
-  c.ib0 = b * d.SB;
-  c.safe = rfx_zero_f32;
-  c.inb = g.in + (int64_t)n * d.in_ns + (int64_t)c.ia0 * d.in_as + (int64_t)c.ib0 * d.in_bs;
-  c.rs = rfx_sample_rsrc(g.in + (int64_t)n * d.in_ns);
-  c.voff = (uint32_t)(((int64_t)c.ia0 * d.in_as + (int64_t)c.ib0 * d.in_bs) * 4);
-
-  f32x16 acc[R];
-#pragma unroll
-  for (int mt = 0; mt < R; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-
-  if (BF3) run_phase_bf3<R>(d, g.apack, g.ktab, d.Kpad, m0, c, as, kts, acc);
-  else run_phase<R>(d, g.apack, g.ktab, d.Kpad, m0, c, as, kts, acc);
-
   const rfx_epilogue& e = g.e;
-  const bool two = g.apack2 != nullptr;
-  // bias + activation (between the phases when there are two).  All per-row loads are issued TOGETHER, unconditionally
-  // (clamped row index) and under wave-uniform tests only: with `if (e.bias) v += e.bias[m]` inside the per-element
-  // loop hipcc emitted one load + s_waitcnt vmcnt(0) per element, i.e. 16*R serial L2 round trips (~40 us) per
-  // workgroup -- more than the whole K loop of the short-K layers.
+  const int m0 = tc.m0, h = tc.h;
   {
     float bv[R][16];
     if (e.bias) {
@@ -433,16 +242,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
       }
     }
   }
-  if (two) {
-    LaneCtx c2 = c;
-    if (g.in2) {
-      c2.inb = g.in2 + (c.inb - g.in);
-      c2.rs = rfx_sample_rsrc(g.in2 + (int64_t)n * d.in_ns);
-    }
-    if (BF3) run_phase_bf3<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
-    else run_phase<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
-  }
+}
 
+// everything after the last K loop: residual / second activation / the store variants / statistics
+template <int R>
+__device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileCtx& tc, f32x16 (&acc)[R]) {
+  const rfx_gemm_desc& d = g.d;
+  const rfx_epilogue& e = g.e;
+  const int n = tc.n, pw = tc.pw, m0 = tc.m0, a = tc.a, b = tc.b, wave = tc.wave, lane = tc.lane, l31 = tc.l31, h = tc.h;
+  struct { bool jvalid; } c = {tc.jvalid};
   const int64_t opos = (int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
   float* outp = g.out + (int64_t)n * d.out_ns + opos;
   const float* resp = nullptr;
@@ -571,7 +379,64 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
   }
 }
 
+template <int R>
+__global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
+  constexpr int BM = 32 * R;
+  __shared__ __attribute__((aligned(16))) float as[2 * 16 * BM];
+  __shared__ __attribute__((aligned(16))) int4 kts[3 * 16];
+  const rfx_gemm_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int P = d.OA * d.OB;
+  // XCD-aware tile order (block b runs on XCD b % 8, each XCD has its own L2): the channel tiles of one
+  // (sample, position tile) read the same input samples, so they are made consecutive ON THE SAME XCD;
+  // neighbouring position tiles are spread over the 8 XCDs.
+  const int mtiles = d.Mpad / BM, ptiles = (P + 127) / 128;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int ym = q % mtiles, pw = (q / mtiles) * 8 + xcd;      // pw: (n, position tile) work item
+  if (pw >= ptiles * d.N) return;
+  const int n = pw / ptiles;
+  const int m0 = ym * BM;
+  const int j = (pw - n * ptiles) * 128 + wave * 32 + l31;
+  LaneCtx c;
+  c.jvalid = j < P;
+  const int jj = c.jvalid ? j : 0;
+  const int a = jj / d.OB, b = jj - a * d.OB;
+  c.ia0 = a * d.SA;
+  c.ib0 = b * d.SB;
+  c.safe = rfx_zero_f32;
+  c.inb = g.in + (int64_t)n * d.in_ns + (int64_t)c.ia0 * d.in_as + (int64_t)c.ib0 * d.in_bs;
+  c.rs = rfx_sample_rsrc(g.in + (int64_t)n * d.in_ns);
+  c.voff = (uint32_t)(((int64_t)c.ia0 * d.in_as + (int64_t)c.ib0 * d.in_bs) * 4);
 
-// launchers of the tiled forward kernel (defined in gemm_fwd_f32.hip / gemm_fwd_bf3.hip)
+  f32x16 acc[R];
+#pragma unroll
+  for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  run_phase<R>(d, g.apack, g.ktab, d.Kpad, m0, c, as, kts, acc);
+
+  const bool two = g.apack2 != nullptr;
+  TileCtx tc;
+  tc.n = n; tc.pw = pw; tc.m0 = m0; tc.a = a; tc.b = b; tc.wave = wave; tc.lane = lane; tc.l31 = l31; tc.h = h;
+  tc.jvalid = c.jvalid;
+  fwd_epilogue_mid<R>(g, tc, acc);
+  if (two) {
+    LaneCtx c2 = c;
+    if (g.in2) {
+      c2.inb = g.in2 + (c.inb - g.in);
+      c2.rs = rfx_sample_rsrc(g.in2 + (int64_t)n * d.in_ns);
+    }
+    __syncthreads();            // phase 1 may still be reading the LDS buffers
+    run_phase<R>(d, g.apack2, g.ktab2, g.Kpad2, m0, c2, as, kts, acc);
+  }
+
+  fwd_epilogue_store<R>(g, tc, acc);
+}
+
+// launchers of the tiled forward kernels: channel-major table, exact fp32 (gemm_fwd_f32.hip); tap-major, split bf16x3
+// (gemm_fwd_bf3.hip) and plain bf16 operands (gemm_fwd_bf16.hip) -- see gemm_tap.h
 int rfx_launch_gemm_fwd_f32(const FwdArgs& g, int r, dim3 grid, hipStream_t s);
 int rfx_launch_gemm_fwd_bf3(const FwdArgs& g, int r, dim3 grid, hipStream_t s);
+int rfx_launch_gemm_fwd_bf16(const FwdArgs& g, int r, dim3 grid, hipStream_t s);

@@ -1,0 +1,266 @@
+// Tap-major forward gather-GEMM on the bf16 matrix pipe of gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
+// every convolution with >= 8 input channels in the "bf16x3" (fp32 operands split hi + lo, 3 MFMAs per product) and
+// "bf16" (operands rounded to bf16, 1 MFMA: the bf16-mixed mode of BASELINE config 3) arithmetic modes.
+//
+// What changed against the channel-major kernel of gemm_fwd.h (which stays for exact fp32 and for Cin < 8):
+//   * the reduction axis runs (tap, channel) in 8-CHANNEL GROUPS g = t * gpt + c8 (remfx_amd/convplan.py,
+//     GemmPlan._build_tap_major).  K step ks = groups 2ks (lanes 0-31) and 2ks + 1 (lanes 32-63); a lane's MFMA B
+//     fragment = 8 consecutive channels of ONE tap at its position.  So per K step a lane does one table read, ONE
+//     bounds test and one offset add, then 8 raw buffer loads that differ by a multiple of the channel stride -- the
+//     channel-major table cost a table row, two bounds tests and a select PER GATHER (11.5 VALU per MFMA in the r01
+//     PMC run).  Out-of-range taps and the padded channels of the last group are handled by the hardware range check
+//     of the buffer descriptor (num_records = one sample's extent): those loads return 0 without touching memory.
+//   * the whole tap table (<= 112 taps + padding) sits in LDS for the kernel's lifetime; (tap, group) counters advance
+//     per lane with two compare / subtract pairs.
+//   * MODE 2 skips the hi / lo split: 4 v_cvt_pk_bf16_f32 per K step and one MFMA per channel tile, half the LDS for A.
+// Unchanged: wave w owns 32 positions x all R channel tiles, gathers go global -> VGPR coalesced along the contiguous
+// position axis (the B operand has no reuse across waves, so an LDS round trip would only add traffic), A (packed
+// weights) is staged through LDS two K steps per barrier, gathers run 3 K steps ahead in a 4-deep register ring.
+#pragma once
+#include "gemm_fwd.h"
+
+#define RFX_BDIST 3        // gather look-ahead in K steps
+#define RFX_TAP_LDS 128    // tap-table slots in LDS (ntaps + 16 padding rows must fit)
+
+struct TapLane {
+  __amdgpu_buffer_rsrc_t rs;   // one sample of the operand; num_records = its extent in bytes
+  uint32_t voff;               // byte offset of this lane's position inside the sample
+  int ia0, ib0;                // input coordinates of the position (lanes beyond P: ia0 = 2^30, every bounds test fails)
+  int t;                       // tap of this lane's NEXT gather ...
+  uint32_t goff;               // ... and byte offset of its 8-channel group inside the tap (c8 * 8 * channel stride)
+};
+
+// x = hi + lo with hi = RNE_bf16(x), lo = RNE_bf16(x - hi): v_cvt_pk_bf16_f32 does two values per instruction and
+// the residual is one packed subtract -> 5 VALU per pair
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+  uint32_t hw[4], lw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2_t v = {x[2 * q], x[2 * q + 1]};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    hw[q] = h;
+    lw[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, bf16x2_t));
+  }
+  hi = __builtin_bit_cast(bf16x8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+}
+__device__ __forceinline__ bf16x8 round8(const float (&x)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2_t v = {x[2 * q], x[2 * q + 1]};
+    w[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  }
+  return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+}
+
+// The 8 gathers of one lane for one K step + advance of its (tap, group) position by two groups.
+// gstep = 16 channel strides (two groups), gwrap = gpt * 8 channel strides (one tap), both in bytes.
+// Branch-free on purpose: with a plain `ok ? offset : OOB` hipcc sank the offset arithmetic AND the table read into a
+// branch (s_and_saveexec + ds_read + lgkmcnt(0) per K step); the empty asm makes the offset opaque, so it is computed
+// unconditionally and the select stays a v_cndmask.  A masked lane must get EXACTLY 2^31: its raw offset may be
+// "negative" (taps left of the row start), and 0xfffffff0 + i * cs4 would wrap back into the sample.
+__device__ __forceinline__ void gather8_tap(const rfx_gemm_desc& d, const int4* taps, uint32_t cs4, uint32_t gstep,
+                                            uint32_t gwrap, TapLane& c, float (&b)[8]) {
+  const int4 e = taps[c.t];          // (offset of channel 0, da, db, -): two distinct addresses per wave
+  const bool ok = ((unsigned)(c.ia0 + e.y) < (unsigned)d.IA) & ((unsigned)(c.ib0 + e.z) < (unsigned)d.IB);
+  uint32_t off = c.voff + ((uint32_t)e.x << 2) + c.goff;
+  asm volatile("" : "+v"(off));
+  // bit 31 set = beyond num_records (one sample spans < 2 GiB) = the load returns 0 and touches nothing
+  const uint32_t base = ok ? off : RFX_BUF_OOB;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, base + (uint32_t)i * cs4, 0, 0));
+  c.goff += gstep;
+  bool w = c.goff >= gwrap;          // gpt >= 1: at most two wraps
+  c.goff -= w ? gwrap : 0u; c.t += w ? 1 : 0;
+  w = c.goff >= gwrap;
+  c.goff -= w ? gwrap : 0u; c.t += w ? 1 : 0;
+}
+
+// A stage: NARR (hi [, lo]) x 2 k8 rows x BM cells of 16 bytes per K step, one or two per thread.
+// Plain scalars (not arrays) so the two in-flight stages of the software pipeline stay in registers.
+struct AStage { uint4 v0, v1; };
+template <int R, int MODE>
+__device__ __forceinline__ uint4 tap_a_cell(const uint4* __restrict__ apk, int64_t arr_stride, int Mpad, int k8_0,
+                                            int m0, int idx) {
+  constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, NV = 2 * NARR * BM;
+  idx = idx < NV ? idx : NV - 1;     // branch-free: surplus threads re-read the last cell
+  const int arr = idx / (2 * BM), rem = idx % (2 * BM);
+  const int kk8 = rem / BM, mm = rem % BM;
+  return apk[arr * arr_stride + (int64_t)(k8_0 + kk8) * Mpad + m0 + mm];
+}
+template <int R, int MODE>
+__device__ __forceinline__ AStage tap_a_load(const uint4* __restrict__ apk, int64_t arr_stride, int Mpad, int k8_0,
+                                             int m0, int tid) {
+  constexpr int NV = 2 * (MODE == 1 ? 2 : 1) * 32 * R;
+  AStage s;
+  s.v0 = tap_a_cell<R, MODE>(apk, arr_stride, Mpad, k8_0, m0, tid);
+  s.v1 = NV > 256 ? tap_a_cell<R, MODE>(apk, arr_stride, Mpad, k8_0, m0, tid + 256) : s.v0;
+  return s;
+}
+template <int R, int MODE>
+__device__ __forceinline__ void tap_a_store(uint4* as, int tid, const AStage& s) {
+  constexpr int NV = 2 * (MODE == 1 ? 2 : 1) * 32 * R;
+  // UNCONDITIONAL stores (surplus threads rewrite the last cell with the same data): a store under a lane condition lets
+  // LLVM sink the global load into that branch, right in front of a vmcnt(0)
+  as[tid < NV ? tid : NV - 1] = s.v0;
+  if (NV > 256) as[tid + 256 < NV ? tid + 256 : NV - 1] = s.v1;
+}
+
+// One 16-deep K step.  LDS holds the A tiles of TWO K steps per buffer, so the workgroup barrier comes only after every
+// odd step (SUB == 1).  Per step ks:
+//   LDS -> fragments of A(ks) from buffer (ks/2)&1, half SUB;
+//   global -> registers: A tile of step ks+4 (into the register set that held A(ks+2)), gathers of step ks+3;
+//   MFMAs;  registers -> LDS: A(ks+2) into the OTHER buffer;  barrier if SUB.
+// Everything written in steps {2D, 2D+1} is first read in step 2D+2, i.e. behind the barrier that ends step 2D+1.
+template <int R, int MODE, int SUB>
+__device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* __restrict__ apk, int64_t arr_stride,
+                                           const int4* taps, uint32_t cs4, uint32_t gstep, uint32_t gwrap, int ks, int m0, TapLane& c,
+                                           uint4* as, f32x16 (&acc)[R], const float (&bc)[8], float (&bn)[8],
+                                           AStage& a_set) {
+  constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int buf = (ks >> 1) & 1;
+  const uint4* a_lds = as + buf * 2 * CELLS + SUB * CELLS;
+  uint4 ah[R], al[R];
+#pragma unroll
+  for (int mt = 0; mt < R; ++mt) {
+    ah[mt] = a_lds[h * BM + mt * 32 + l31];
+    if (MODE == 1) al[mt] = a_lds[2 * BM + h * BM + mt * 32 + l31];
+  }
+  // issue order matters: vmcnt retires in order; the A tile is written to LDS two steps later, the gathers, consumed
+  // RFX_BDIST steps later, go last and stay in flight
+  const AStage a_now = a_set;                                         // A(ks+2), fetched two steps ago
+  a_set = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2 * (ks + 4), m0, tid);
+  gather8_tap(d, taps, cs4, gstep, gwrap, c, bn);
+  if (MODE == 1) {
+    bf16x8 bh, bl;
+    split8(bc, bh, bl);
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt) {
+      const bf16x8 fh = __builtin_bit_cast(bf16x8, ah[mt]), fl = __builtin_bit_cast(bf16x8, al[mt]);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bh, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc[mt], 0, 0, 0);
+    }
+  } else {
+    const bf16x8 bh = round8(bc);
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), bh, acc[mt], 0, 0, 0);
+  }
+  tap_a_store<R, MODE>(as + (buf ^ 1) * 2 * CELLS + SUB * CELLS, tid, a_now);
+  if (SUB) __syncthreads();
+  else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // keep the two steps apart in the compiler too
+}
+
+template <int R, int MODE>
+__device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const float* __restrict__ apack,
+                                              const rfx_ktab_entry* __restrict__ tap_tab, int ntaps, int Kpad, int m0,
+                                              TapLane c, uint4* as, int4* taps, f32x16 (&acc)[R]) {
+  constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
+  const int tid = threadIdx.x;
+  const int h = (tid & 63) >> 5;
+  const int nk = Kpad / 16;
+  if (nk == 0) return;
+  const uint4* apk = reinterpret_cast<const uint4*>(apack);
+  const int64_t arr_stride = (int64_t)(Kpad / 8 + 8) * d.Mpad;
+  const uint32_t cs4 = (uint32_t)(d.in_cs * 4);
+  const uint32_t gstep = 16u * cs4, gwrap = (uint32_t)d.gpt * 8u * cs4;
+  __syncthreads();            // a previous phase (two-phase launches) may still be reading the LDS buffers / tap table
+  {
+    const AStage s0 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 0, m0, tid);
+    const AStage s1 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2, m0, tid);
+    if (tid < ntaps + 16) taps[tid] = reinterpret_cast<const int4*>(tap_tab)[tid];   // table carries 16 invalid tail rows
+    tap_a_store<R, MODE>(as, tid, s0);                       // A(0), A(1) -> buffer 0
+    tap_a_store<R, MODE>(as + CELLS, tid, s1);
+  }
+  __syncthreads();
+  c.t = h / d.gpt;            // group g = h of K step 0
+  c.goff = (uint32_t)(h - c.t * d.gpt) * 8u * cs4;
+  // the gathers run RFX_BDIST K steps ahead of the MFMAs: one K step is ~0.1-0.2 us of matrix work, a gather that misses
+  // L2 takes ~1-2 us, and only two waves share a SIMD
+  float b0[8], b1[8], b2[8], b3[8];
+  AStage a0 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 4, m0, tid);          // A(2), A(3): even / odd register set
+  AStage a1 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 6, m0, tid);
+  gather8_tap(d, taps, cs4, gstep, gwrap, c, b0);
+  gather8_tap(d, taps, cs4, gstep, gwrap, c, b1);
+  gather8_tap(d, taps, cs4, gstep, gwrap, c, b2);
+  int ks = 0;
+  for (; ks + 3 < nk; ks += 4) {
+    k_step_tap<R, MODE, 0>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, m0, c, as, acc, b0, b3, a0);
+    k_step_tap<R, MODE, 1>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, m0, c, as, acc, b1, b0, a1);
+    k_step_tap<R, MODE, 0>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
+    k_step_tap<R, MODE, 1>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 3, m0, c, as, acc, b3, b2, a1);
+  }
+  if (ks < nk) k_step_tap<R, MODE, 0>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, m0, c, as, acc, b0, b3, a0);
+  if (ks + 1 < nk) k_step_tap<R, MODE, 1>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, m0, c, as, acc, b1, b0, a1);
+  if (ks + 2 < nk) k_step_tap<R, MODE, 0>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
+}
+
+template <int R, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_tap_kernel(const FwdArgs g) {
+  constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
+  __shared__ __attribute__((aligned(16))) uint4 smem[4 * CELLS + RFX_TAP_LDS];   // A: 2 buffers x 2 K steps; tap table
+  uint4* as = smem;
+  int4* taps = reinterpret_cast<int4*>(smem + 4 * CELLS);
+  const rfx_gemm_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int P = d.OA * d.OB;
+  // XCD-aware tile order (block b runs on XCD b % 8, each XCD has its own L2): the channel tiles of one
+  // (sample, position tile) read the same input samples, so they are made consecutive ON THE SAME XCD;
+  // neighbouring position tiles are spread over the 8 XCDs.
+  const int mtiles = d.Mpad / BM, ptiles = (P + 127) / 128;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int ym = q % mtiles, pw = (q / mtiles) * 8 + xcd;      // pw: (n, position tile) work item
+  if (pw >= ptiles * d.N) return;
+  const int n = pw / ptiles;
+  const int m0 = ym * BM;
+  const int j = (pw - n * ptiles) * 128 + wave * 32 + l31;
+  TileCtx tc;
+  tc.n = n; tc.pw = pw; tc.m0 = m0; tc.wave = wave; tc.lane = lane; tc.l31 = l31; tc.h = h;
+  tc.jvalid = j < P;
+  const int jj = tc.jvalid ? j : 0;
+  tc.a = jj / d.OB;
+  tc.b = jj - tc.a * d.OB;
+  TapLane c;
+  const int ia0 = tc.a * d.SA, ib0 = tc.b * d.SB;
+  c.ia0 = tc.jvalid ? ia0 : (1 << 30);
+  c.ib0 = ib0;
+  c.voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * 4);
+  c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.in + (int64_t)n * d.in_ns), 0, (int)d.in_extent, 0x00020000);
+  c.t = 0; c.goff = 0;
+
+  f32x16 acc[R];
+#pragma unroll
+  for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  run_phase_tap<R, MODE>(d, g.apack, g.ktab, d.ntaps, d.Kpad_t, m0, c, as, taps, acc);
+  fwd_epilogue_mid<R>(g, tc, acc);
+  if (g.apack2 != nullptr) {
+    if (g.in2) c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.in2 + (int64_t)n * d.in_ns), 0,
+                                                        (int)d.in_extent, 0x00020000);
+    run_phase_tap<R, MODE>(d, g.apack2, g.ktab2, g.ntaps2, g.Kpad2, m0, c, as, taps, acc);
+  }
+  fwd_epilogue_store<R>(g, tc, acc);
+}
+
+template <int MODE>
+static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s) {
+  switch (r) {
+    case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, MODE>), grid, dim3(256), 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, MODE>), grid, dim3(256), 0, s, g); break;
+    case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, MODE>), grid, dim3(256), 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_tap_kernel<4, MODE>), grid, dim3(256), 0, s, g); break;
+  }
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

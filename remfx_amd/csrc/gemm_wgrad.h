@@ -1,0 +1,196 @@
+// Weight-gradient kernels on the bf16 matrix pipe (shared by gemm_wgrad_bf3.hip / gemm_wgrad_bf16.hip).
+#pragma once
+#include "gemm_fwd.h"
+
+struct WgradArgs {
+  rfx_gemm_desc d;
+  const rfx_ktab_entry* ktab;
+  const float* in;
+  const float* g;
+  float* dapack;
+  int tiles_per_sample;  // ceil(P / 32)
+  int total_tiles;       // N * tiles_per_sample
+  int tiles_per_block;
+  int kt, mt, splits;
+  int xcd_grouped;       // 1: 1-D grid, all (k, m) tiles of one position split share an XCD (ids congruent mod 8)
+};
+
+// bf16x3 weight gradient: same tiling and gathers as gemm_wgrad_kernel, but the two LDS tiles hold
+// the operands pre-split into bf16 hi / lo halves ([row][32 positions], 80-byte rows: 16-byte aligned
+// MFMA fragments, conflict-free ds_read_b128) and the product runs on v_mfma_f32_32x32x16_bf16.
+// WM = waves along M: 2 -> the 4 waves form a 2 x 2 grid over a (64 TM) x (64 TK) tile; 1 (M <= 32, the DConv
+// bottleneck convs with 12 / 24 output channels) -> 1 x 4 over 32 x (128 TK), so the MFMA rows beyond M and the
+// re-loads of g by every k tile are halved.
+// MODE 1: split bf16x3 (hi + lo tiles, 3 MFMAs per product); MODE 2: operands rounded to bf16 (hi tile only, 1 MFMA).
+template <int TM, int TK, int WM, int MODE>
+__global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
+  constexpr int WK = 4 / WM;
+  constexpr int RM = 32 * WM * TM, RK = 32 * WK * TK, LDW = 40;   // bf16 elements per LDS row
+  constexpr int LO = MODE == 1 ? 1 : 0;                            // no lo tiles in bf16 mode
+  __shared__ __attribute__((aligned(16))) unsigned short gs_hi[RM * LDW], gs_lo[LO ? RM * LDW : 8];
+  __shared__ __attribute__((aligned(16))) unsigned short xs_hi[RK * LDW], xs_lo[LO ? RK * LDW : 8];
+  __shared__ rfx_ktab_entry kts[RK];
+  const rfx_gemm_desc& d = w.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wm = WM == 2 ? wave >> 1 : 0, wk = WM == 2 ? wave & 1 : wave;
+  // plain order (k tile fastest).  An XCD-grouped order (all tiles of one position split on one XCD) was
+  // measured SLOWER (132 -> 116 TF/s-eq at the TCN shape): the splits are too few / too coarse to balance.
+  int zsplit = blockIdx.z, ym = blockIdx.y, xk = blockIdx.x;
+  if (w.xcd_grouped) {
+    // every (k, m) tile of a position split re-reads the same g rows / input samples: keep them behind ONE L2
+    const int nb = w.kt * w.mt, q = blockIdx.x >> 3;
+    zsplit = (q / nb) * 8 + (blockIdx.x & 7);
+    if (zsplit >= w.splits) return;
+    const int r = q % nb;
+    ym = r / w.kt;
+    xk = r - ym * w.kt;
+  }
+  const int m0 = ym * RM;
+  const int k0 = xk * RK;
+  const int P = d.OA * d.OB;
+  for (int i = tid; i < RK; i += 256) {
+    rfx_ktab_entry e;
+    if (k0 + i < d.Kpad) e = w.ktab[k0 + i];
+    else { e.off = 0; e.da = -(1 << 30); e.db = 0; e.flags = 0; }
+    kts[i] = e;
+  }
+  __syncthreads();
+  f32x16 acc[TM][TK];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int t_begin = zsplit * w.tiles_per_block;
+  const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
+  const int prow = tid >> 5, pl = tid & 31;
+  // operands of one position tile in flight: raw buffer loads relative to the sample bases (an out-of-range offset
+  // reads 0 in hardware: no pointer selects, no branches); the bias ("ones") row is added at staging time
+  struct Stage { float gv[RM / 8], xv[RK / 8]; float jv; };
+  float onesf[RK / 8];
+#pragma unroll
+  for (int i = 0; i < RK / 8; ++i) onesf[i] = (kts[prow + 8 * i].flags & 1) ? 1.f : 0.f;
+  auto load_tile = [&](int t, Stage& st) {
+    const int n = t / w.tiles_per_sample;                       // wave-uniform
+    const int j = (t - n * w.tiles_per_sample) * 32 + pl;
+    const bool jvalid = j < P;
+    const int jj = jvalid ? j : 0;
+    const int a = jj / d.OB, b = jj - a * d.OB;
+    const int ia0 = a * d.SA, ib0 = b * d.SB;
+    const __amdgpu_buffer_rsrc_t irs = rfx_sample_rsrc(w.in + (int64_t)n * d.in_ns);
+    const __amdgpu_buffer_rsrc_t grs = rfx_sample_rsrc(w.g + (int64_t)n * d.out_ns);
+    const uint32_t voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * 4);
+    const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
+                                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs + (int64_t)(m0 + prow) * d.out_cs) * 4);
+    const uint32_t gstep = (uint32_t)(8 * d.out_cs * 4);
+    st.jv = jvalid ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < RM / 8; ++i) {
+      const bool ok = jvalid & (m0 + prow + 8 * i < d.M);
+      st.gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < RK / 8; ++i) {
+      const rfx_ktab_entry e = kts[prow + 8 * i];
+      const bool ok = jvalid & !(e.flags & 1) & ((unsigned)(ia0 + e.da) < (unsigned)d.IA) &
+                      ((unsigned)(ib0 + e.db) < (unsigned)d.IB);     // the bias row loads nothing: it is onesf * jv
+      st.xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, ok ? voff + ((uint32_t)e.off << 2) : RFX_BUF_OOB, 0, 0));
+    }
+  };
+  auto put = [&](unsigned short* hi, unsigned short* lo, int row, float v) {
+    const __bf16 h = (__bf16)v;                                   // v_cvt_pk_bf16_f32 (RNE)
+    const unsigned short hb = __builtin_bit_cast(unsigned short, h);
+    hi[row * LDW + pl] = hb;
+    if (MODE == 1) {
+      const __bf16 l = (__bf16)(v - __uint_as_float((uint32_t)hb << 16));
+      lo[row * LDW + pl] = __builtin_bit_cast(unsigned short, l);
+    }
+  };
+  auto stage = [&](const Stage& st) {
+#pragma unroll
+    for (int i = 0; i < RM / 8; ++i) put(gs_hi, gs_lo, prow + 8 * i, st.gv[i]);
+#pragma unroll
+    for (int i = 0; i < RK / 8; ++i) put(xs_hi, xs_lo, prow + 8 * i, st.xv[i] + onesf[i] * st.jv);
+  };
+  auto mma_tile = [&]() {
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      bf16x8 ah[TM], al[TM], bh[TK], bl[TK];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int off = (wm * 32 * TM + tm * 32 + l31) * LDW + 16 * ks2 + 8 * h;
+        ah[tm] = *reinterpret_cast<const bf16x8*>(gs_hi + off);
+        if (MODE == 1) al[tm] = *reinterpret_cast<const bf16x8*>(gs_lo + off);
+      }
+#pragma unroll
+      for (int tk = 0; tk < TK; ++tk) {
+        const int off = (wk * 32 * TK + tk * 32 + l31) * LDW + 16 * ks2 + 8 * h;
+        bh[tk] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
+        if (MODE == 1) bl[tk] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk) {
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tk], acc[tm][tk], 0, 0, 0);
+          if (MODE == 1) {
+            acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tk], acc[tm][tk], 0, 0, 0);
+            acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tk], acc[tm][tk], 0, 0, 0);
+          }
+        }
+    }
+  };
+  // two tiles of operands in flight: the loads of tile t+2 are issued before the MFMAs of tile t, so an HBM round
+  // trip (~1-2 us) is covered by two tiles of matrix work instead of one (the r01 version waited at every tile)
+  Stage s0, s1;
+  const int t_last = t_end - 1;
+  if (t_begin < t_end) {
+    load_tile(t_begin, s0);
+    load_tile(min(t_begin + 1, t_last), s1);
+  }
+  for (int t = t_begin; t < t_end; t += 2) {
+    __syncthreads();
+    stage(s0);
+    __syncthreads();
+    load_tile(min(t + 2, t_last), s0);
+    mma_tile();
+    if (t + 1 < t_end) {                       // block-uniform
+      __syncthreads();
+      stage(s1);
+      __syncthreads();
+      load_tile(min(t + 3, t_last), s1);
+      mma_tile();
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = k0 + wk * 32 * TK + tk * 32 + l31;
+        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
+      }
+}
+
+
+// shape: 0 = 96-row tiles (waves 1 x 4), 1 / 2 = 32-row tiles with 256 / 128 k rows, 3..6 = (64 TM) x (64 TK) tiles
+template <int MODE>
+static int rfx_launch_wgrad_bf(const WgradArgs& w, int shape, dim3 grid, hipStream_t s) {
+  switch (shape) {
+    case 0: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<3, 1, 1, MODE>), grid, dim3(256), 0, s, w); break;
+    case 1: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 2, 1, MODE>), grid, dim3(256), 0, s, w); break;
+    case 2: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 1, 1, MODE>), grid, dim3(256), 0, s, w); break;
+    case 3: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<2, 2, 2, MODE>), grid, dim3(256), 0, s, w); break;
+    case 4: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<2, 1, 2, MODE>), grid, dim3(256), 0, s, w); break;
+    case 5: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 2, 2, MODE>), grid, dim3(256), 0, s, w); break;
+    default: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 1, 2, MODE>), grid, dim3(256), 0, s, w); break;
+  }
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+int rfx_launch_wgrad_bf3(const WgradArgs& w, int shape, dim3 grid, hipStream_t s);
+int rfx_launch_wgrad_bf16(const WgradArgs& w, int shape, dim3 grid, hipStream_t s);

@@ -1,5 +1,5 @@
 // Weight-gradient kernels of the gather-GEMM family (see gemm_fwd.h for the family overview).
-#include "gemm_fwd.h"
+#include "gemm_wgrad.h"
 
 template <bool ADD>
 __global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_t* __restrict__ woff,
@@ -21,19 +21,6 @@ __global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_
 // Both operands are contiguous along the reduction axis p in memory, so both are
 // staged through LDS ([row][32 positions], stride 33 -> conflict-free operand reads).
 // ---------------------------------------------------------------------------------
-struct WgradArgs {
-  rfx_gemm_desc d;
-  const rfx_ktab_entry* ktab;
-  const float* in;
-  const float* g;
-  float* dapack;
-  int tiles_per_sample;  // ceil(P / 32)
-  int total_tiles;       // N * tiles_per_sample
-  int tiles_per_block;
-  int kt, mt, splits;
-  int xcd_grouped;       // 1: 1-D grid, all (k, m) tiles of one position split share an XCD (ids congruent mod 8)
-};
-
 template <int TM, int TK>
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
   constexpr int RM = 64 * TM, RK = 64 * TK, LD = 33;
@@ -137,161 +124,6 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
       }
 }
 
-// bf16x3 weight gradient: same tiling and gathers as gemm_wgrad_kernel, but the two LDS tiles hold
-// the operands pre-split into bf16 hi / lo halves ([row][32 positions], 80-byte rows: 16-byte aligned
-// MFMA fragments, conflict-free ds_read_b128) and the product runs on v_mfma_f32_32x32x16_bf16.
-// WM = waves along M: 2 -> the 4 waves form a 2 x 2 grid over a (64 TM) x (64 TK) tile; 1 (M <= 32, the DConv
-// bottleneck convs with 12 / 24 output channels) -> 1 x 4 over 32 x (128 TK), so the MFMA rows beyond M and the
-// re-loads of g by every k tile are halved.
-template <int TM, int TK, int WM = 2>
-__global__ __launch_bounds__(256) void gemm_wgrad_bf3_kernel(const WgradArgs w) {
-  constexpr int WK = 4 / WM;
-  constexpr int RM = 32 * WM * TM, RK = 32 * WK * TK, LDW = 40;   // bf16 elements per LDS row
-  __shared__ __attribute__((aligned(16))) unsigned short gs_hi[RM * LDW], gs_lo[RM * LDW];
-  __shared__ __attribute__((aligned(16))) unsigned short xs_hi[RK * LDW], xs_lo[RK * LDW];
-  __shared__ rfx_ktab_entry kts[RK];
-  const rfx_gemm_desc& d = w.d;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int wm = WM == 2 ? wave >> 1 : 0, wk = WM == 2 ? wave & 1 : wave;
-  // plain order (k tile fastest).  An XCD-grouped order (all tiles of one position split on one XCD) was
-  // measured SLOWER (132 -> 116 TF/s-eq at the TCN shape): the splits are too few / too coarse to balance.
-  int zsplit = blockIdx.z, ym = blockIdx.y, xk = blockIdx.x;
-  if (w.xcd_grouped) {
-    // every (k, m) tile of a position split re-reads the same g rows / input samples: keep them behind ONE L2
-    const int nb = w.kt * w.mt, q = blockIdx.x >> 3;
-    zsplit = (q / nb) * 8 + (blockIdx.x & 7);
-    if (zsplit >= w.splits) return;
-    const int r = q % nb;
-    ym = r / w.kt;
-    xk = r - ym * w.kt;
-  }
-  const int m0 = ym * RM;
-  const int k0 = xk * RK;
-  const int P = d.OA * d.OB;
-  for (int i = tid; i < RK; i += 256) {
-    rfx_ktab_entry e;
-    if (k0 + i < d.Kpad) e = w.ktab[k0 + i];
-    else { e.off = 0; e.da = -(1 << 30); e.db = 0; e.flags = 0; }
-    kts[i] = e;
-  }
-  __syncthreads();
-  f32x16 acc[TM][TK];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TK; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  const int t_begin = zsplit * w.tiles_per_block;
-  const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
-  const int prow = tid >> 5, pl = tid & 31;
-  // operands of one position tile in flight: raw buffer loads relative to the sample bases (an out-of-range offset
-  // reads 0 in hardware: no pointer selects, no branches); the bias ("ones") row is added at staging time
-  struct Stage { float gv[RM / 8], xv[RK / 8]; float jv; };
-  float onesf[RK / 8];
-#pragma unroll
-  for (int i = 0; i < RK / 8; ++i) onesf[i] = (kts[prow + 8 * i].flags & 1) ? 1.f : 0.f;
-  auto load_tile = [&](int t, Stage& st) {
-    const int n = t / w.tiles_per_sample;                       // wave-uniform
-    const int j = (t - n * w.tiles_per_sample) * 32 + pl;
-    const bool jvalid = j < P;
-    const int jj = jvalid ? j : 0;
-    const int a = jj / d.OB, b = jj - a * d.OB;
-    const int ia0 = a * d.SA, ib0 = b * d.SB;
-    const __amdgpu_buffer_rsrc_t irs = rfx_sample_rsrc(w.in + (int64_t)n * d.in_ns);
-    const __amdgpu_buffer_rsrc_t grs = rfx_sample_rsrc(w.g + (int64_t)n * d.out_ns);
-    const uint32_t voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * 4);
-    const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
-                                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs + (int64_t)(m0 + prow) * d.out_cs) * 4);
-    const uint32_t gstep = (uint32_t)(8 * d.out_cs * 4);
-    st.jv = jvalid ? 1.f : 0.f;
-#pragma unroll
-    for (int i = 0; i < RM / 8; ++i) {
-      const bool ok = jvalid & (m0 + prow + 8 * i < d.M);
-      st.gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
-    }
-#pragma unroll
-    for (int i = 0; i < RK / 8; ++i) {
-      const rfx_ktab_entry e = kts[prow + 8 * i];
-      const bool ok = jvalid & !(e.flags & 1) & ((unsigned)(ia0 + e.da) < (unsigned)d.IA) &
-                      ((unsigned)(ib0 + e.db) < (unsigned)d.IB);     // the bias row loads nothing: it is onesf * jv
-      st.xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, ok ? voff + ((uint32_t)e.off << 2) : RFX_BUF_OOB, 0, 0));
-    }
-  };
-  auto put = [&](unsigned short* hi, unsigned short* lo, int row, float v) {
-    const __bf16 h = (__bf16)v;                                   // v_cvt_pk_bf16_f32 (RNE)
-    const unsigned short hb = __builtin_bit_cast(unsigned short, h);
-    const __bf16 l = (__bf16)(v - __uint_as_float((uint32_t)hb << 16));
-    hi[row * LDW + pl] = hb;
-    lo[row * LDW + pl] = __builtin_bit_cast(unsigned short, l);
-  };
-  auto stage = [&](const Stage& st) {
-#pragma unroll
-    for (int i = 0; i < RM / 8; ++i) put(gs_hi, gs_lo, prow + 8 * i, st.gv[i]);
-#pragma unroll
-    for (int i = 0; i < RK / 8; ++i) put(xs_hi, xs_lo, prow + 8 * i, st.xv[i] + onesf[i] * st.jv);
-  };
-  auto mma_tile = [&]() {
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-      bf16x8 ah[TM], al[TM], bh[TK], bl[TK];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int off = (wm * 32 * TM + tm * 32 + l31) * LDW + 16 * ks2 + 8 * h;
-        ah[tm] = *reinterpret_cast<const bf16x8*>(gs_hi + off);
-        al[tm] = *reinterpret_cast<const bf16x8*>(gs_lo + off);
-      }
-#pragma unroll
-      for (int tk = 0; tk < TK; ++tk) {
-        const int off = (wk * 32 * TK + tk * 32 + l31) * LDW + 16 * ks2 + 8 * h;
-        bh[tk] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
-        bl[tk] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tk = 0; tk < TK; ++tk) {
-          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tk], acc[tm][tk], 0, 0, 0);
-          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tk], acc[tm][tk], 0, 0, 0);
-          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tk], acc[tm][tk], 0, 0, 0);
-        }
-    }
-  };
-  // two tiles of operands in flight: the loads of tile t+2 are issued before the MFMAs of tile t, so an HBM round
-  // trip (~1-2 us) is covered by two tiles of matrix work instead of one (the r01 version waited at every tile)
-  Stage s0, s1;
-  const int t_last = t_end - 1;
-  if (t_begin < t_end) {
-    load_tile(t_begin, s0);
-    load_tile(min(t_begin + 1, t_last), s1);
-  }
-  for (int t = t_begin; t < t_end; t += 2) {
-    __syncthreads();
-    stage(s0);
-    __syncthreads();
-    load_tile(min(t + 2, t_last), s0);
-    mma_tile();
-    if (t + 1 < t_end) {                       // block-uniform
-      __syncthreads();
-      stage(s1);
-      __syncthreads();
-      load_tile(min(t + 3, t_last), s1);
-      mma_tile();
-    }
-  }
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tk = 0; tk < TK; ++tk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int k = k0 + wk * 32 * TK + tk * 32 + l31;
-        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
-      }
-}
-
 // Thin weight gradient (M <= 8): one wave per k row, lanes along positions.
 template <int MM>
 __global__ __launch_bounds__(256) void gemm_thin_wgrad_kernel(const WgradArgs w) {
@@ -382,9 +214,9 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     RFX_CHECK_LAUNCH();
     return 0;
   }
-  const bool narrow = prec == 1 && d->M <= 32;            // 32 x (128 tk) tiles, waves 1 x 4 (see gemm_wgrad_bf3_kernel)
+  const bool narrow = prec != 0 && d->M <= 32;            // 32 x (128 tk) tiles, waves 1 x 4 (see gemm_wgrad_bf3_kernel)
   // 96-row tiles (waves 1 x 4, three 32-row MFMA tiles each) when they pad M less than 128-row ones: M = 96, 192, 288
-  const bool rows96 = prec == 1 && d->M > 64 && d->K > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;
+  const bool rows96 = prec != 0 && d->M > 64 && d->K > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;
   const int tm = d->M > 64 ? 2 : 1;
   const int tk = narrow ? (d->K > 128 ? 2 : 1) : rows96 ? 1 : (d->K > 64 ? 2 : 1);
   const int rm = narrow ? 32 : rows96 ? 96 : 64 * tm, rk = (narrow || rows96) ? 128 * tk : 64 * tk;
@@ -400,21 +232,14 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   w.kt = kt; w.mt = mt; w.splits = splits;
   dim3 grid(kt, mt, splits);
   w.xcd_grouped = 0;
-  if (prec == 1) {
+  if (prec != 0) {
     static const int xcd_mode = getenv("RFX_WGRAD_XCD") ? atoi(getenv("RFX_WGRAD_XCD")) : 0;   // measured on Demucs B=64: 408.0 ms off, 411.8 ms on
     if (xcd_mode > 0 && splits >= xcd_mode) {
       w.xcd_grouped = 1;
       grid = dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1);
     }
-    if (rows96) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<3, 1, 1>), grid, dim3(256), 0, s, w);
-    else if (narrow && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2, 1>), grid, dim3(256), 0, s, w);
-    else if (narrow) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 1, 1>), grid, dim3(256), 0, s, w);
-    else if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 2>), grid, dim3(256), 0, s, w);
-    else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<2, 1>), grid, dim3(256), 0, s, w);
-    else if (tk == 2) hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 2>), grid, dim3(256), 0, s, w);
-    else hipLaunchKernelGGL((gemm_wgrad_bf3_kernel<1, 1>), grid, dim3(256), 0, s, w);
-    RFX_CHECK_LAUNCH();
-    return 0;
+    const int shape = rows96 ? 0 : (narrow && tk == 2) ? 1 : narrow ? 2 : (tm == 2 && tk == 2) ? 3 : tm == 2 ? 4 : tk == 2 ? 5 : 6;
+    return prec == 1 ? rfx_launch_wgrad_bf3(w, shape, grid, s) : rfx_launch_wgrad_bf16(w, shape, grid, s);
   }
   if (tm == 2 && tk == 2) hipLaunchKernelGGL((gemm_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, w);
   else if (tm == 2) hipLaunchKernelGGL((gemm_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, w);

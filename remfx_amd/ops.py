@@ -12,14 +12,20 @@ import torch
 from . import _lib, convplan
 from ._lib import Epilogue, GemmDesc, check
 
-# arithmetic of the MFMA gather-GEMM: "f32" (exact fp32 MFMA) or "bf16x3" (split-bf16 emulation)
+# arithmetic of the MFMA gather-GEMMs: "f32" (exact fp32 MFMA), "bf16x3" (split-bf16 emulation of fp32 products) or
+# "bf16" (operands rounded to bf16, fp32 accumulate: trainer.precision=bf16-mixed)
 import os as _os
-GEMM_PREC = {"f32": 0, "bf16x3": 1}[_os.environ.get("RFX_GEMM_PREC", "f32")]
+PREC_NAMES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+GEMM_PREC = PREC_NAMES[_os.environ.get("RFX_GEMM_PREC", "f32")]
 
 
 def set_gemm_precision(name):
     global GEMM_PREC
-    GEMM_PREC = {"f32": 0, "bf16x3": 1}[name]
+    GEMM_PREC = PREC_NAMES[name]
+
+
+def gemm_precision():
+    return {v: k for k, v in PREC_NAMES.items()}[GEMM_PREC]
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "tanh": 3, "prelu": 4, "leaky": 5, "sigmoid": 6}
@@ -47,8 +53,19 @@ class DevPlan:
         self.woff = torch.from_numpy(np.ascontiguousarray(plan.woff)).to(device)
         d = GemmDesc()
         for f, _ in GemmDesc._fields_:
-            setattr(d, f, int(getattr(plan, f)))
+            if f not in ("tap_reserved", "in_extent"):
+                setattr(d, f, int(getattr(plan, f)))
+        d.in_extent = int(plan.in_extent) * 4              # bytes
         self.desc = d
+        self.tap = plan.cin >= 8 and plan.R > 0              # tap-major tables exist: bf16x3 / bf16 run the gemm_tap kernels
+        if self.tap:
+            self.tap_tab = torch.from_numpy(np.ascontiguousarray(plan.tap_tab)).to(device)
+            self.woff_t = torch.from_numpy(np.ascontiguousarray(plan.woff_t)).to(device)
+
+    def fwd_prec(self):
+        """Arithmetic the forward-family launch of this plan runs in: the library mode for tap-major plans, exact fp32 on
+        the channel-major kernel otherwise (fewer than 8 input channels / thin M <= 8 layers: HBM-bound either way)."""
+        return GEMM_PREC if self.tap else 0
 
     def set_io(self, x=None, out=None):
         """Refresh strides for a new tensor with the same geometry key (cheap)."""
@@ -71,11 +88,14 @@ def _plans(key, device, builder):
 def pack_a(dp, w):
     """Gather the weight tensor into the packed [Kpad][Mpad] A matrix of a plan."""
     p = dp.p
-    prec = GEMM_PREC if p.R > 0 else 0          # thin path is always fp32
-    apack = torch.empty((p.Kpad + 64, p.Mpad), device=w.device, dtype=torch.float32)
-    nrows = p.extra["n_weight_rows"]
-    if True:
-        check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff), p.w_ms, p.M, nrows, p.Mpad, p.Kpad, prec,
+    prec = dp.fwd_prec()
+    if prec == 0:
+        apack = torch.empty((p.Kpad + 64, p.Mpad), device=w.device, dtype=torch.float32)
+        check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"], p.Mpad, p.Kpad, 0,
+                                    _ptr(apack), _stream()), "rfx_pack_a")
+    else:                                       # tap-major order, bf16 hi / lo cells: 2 x [Kpad_t / 8 + 8][Mpad] x 16 bytes
+        apack = torch.empty((p.Kpad_t + 64, p.Mpad), device=w.device, dtype=torch.float32)
+        check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff_t), p.w_ms, p.M, p.Kpad_t, p.Mpad, p.Kpad_t, prec,
                                     _ptr(apack), _stream()), "rfx_pack_a")
     return apack
 
@@ -99,12 +119,18 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
     if glu_out is not None:                               # fused GLU store (rows interleaved by the caller)
         e.glu_out = glu_out.data_ptr()
         e.glu_ns = glu_out.stride(0)
-    if dp2 is not None:
+    prec = dp.fwd_prec()
+    if dp2 is not None and dp2.fwd_prec() != prec:
+        raise ValueError("two-phase gather-GEMM: both phases must use the same table form")
+    tab = dp.tap_tab if prec else dp.ktab
+    if dp2 is not None and prec:
+        a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.tap_tab), dp2.p.ntaps, dp2.p.Kpad_t
+    elif dp2 is not None:
         a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.ktab), dp2.p.K, dp2.p.Kpad
     else:
         a2, k2, K2, Kpad2 = None, None, 0, 0
-    check(_lib.lib().rfx_gemm_fwd(C.byref(dp.desc), _ptr(apack), _ptr(dp.ktab), _ptr(x), _ptr(out),
-                                  C.byref(e), a2, k2, K2, Kpad2, _ptr(in2), GEMM_PREC, _stream()),
+    check(_lib.lib().rfx_gemm_fwd(C.byref(dp.desc), _ptr(apack), _ptr(tab), _ptr(x), _ptr(out),
+                                  C.byref(e), a2, k2, K2, Kpad2, _ptr(in2), prec, _stream()),
           "rfx_gemm_fwd")
     return out
 

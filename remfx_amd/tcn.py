@@ -32,7 +32,7 @@ def _shift_plan(xshape, xstrides, M, shift, gstrides=None, oshape=None, ostrides
     on, oc, oa, ob = ostrides
     p = convplan.GemmPlan(N=N, M=M, K=Cin, OA=oshape[2], OB=oshape[3], IA=IA, IB=IB, SA=1, SB=1,
                           in_ns=ns, in_as=as_, in_bs=bs, out_ns=on, out_cs=oc, out_as=oa, out_bs=ob,
-                          ktab=ktab, woff=ci.copy(), w_ms=Cin)
+                          ktab=ktab, woff=ci.copy(), w_ms=Cin, cin=Cin, in_cs=cs)
     return p.finalize()
 
 
@@ -116,7 +116,8 @@ class TCNBlockFn(torch.autograd.Function):
                 pr = convplan.GemmPlan(N=N, M=Cin, K=Cout, OA=1, OB=L, IA=1, IB=Lout, SA=1, SB=1,
                                        in_ns=g4.stride(0), in_as=g4.stride(2), in_bs=g4.stride(3),
                                        out_ns=x4.stride(0), out_cs=x4.stride(1), out_as=x4.stride(2),
-                                       out_bs=x4.stride(3), ktab=kt, woff=co * Cin, w_ms=1).finalize()
+                                       out_bs=x4.stride(3), ktab=kt, woff=co * Cin, w_ms=1, cin=Cout,
+                                       in_cs=g4.stride(1)).finalize()
                 pr.R, pr.Mpad = pd[0].R, pd[0].Mpad
                 return [pd[0], pr]
             dpd, dpr = ops._plans(key, x.device, build)

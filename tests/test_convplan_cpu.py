@@ -17,6 +17,12 @@ CASES = [
     (3, 4, (12, 10), (7, 5), (2, 2), (3, 2), (1, 1)),     # DCUNet
     (5, 2, (9, 8), (5, 3), (2, 1), (2, 1), (1, 1)),
     (4, 4, (1, 40), (1, 3), (1, 1), (0, 2), (1, 2)),      # DConv dilated same conv
+    # >= 8 input channels: these plans also carry the tap-major tables (checked inside emulate_fwd)
+    (12, 5, (1, 40), (1, 3), (1, 1), (0, 2), (1, 2)),     # DConv 1x1-ish, Cin not a multiple of 8
+    (9, 6, (7, 11), (3, 3), (1, 1), (1, 1), (1, 1)),      # 3x3 rewrite, Cin = 9 -> two 8-channel groups per tap
+    (16, 3, (20, 6), (8, 1), (4, 1), (2, 0), (1, 1)),     # strided freq conv
+    (8, 10, (1, 70), (1, 7), (1, 1), (0, 0), (1, 3)),     # TCN dilated
+    (24, 4, (1, 33), (1, 1), (1, 1), (0, 0), (1, 1)),     # 1x1, three groups, odd group count
 ]
 
 
@@ -58,6 +64,8 @@ TCASES = [
     (4, 5, (6, 7), (5, 3), (2, 1), (2, 1), (2, 1)),      # DCUNet decoder (padding k//2)
     (2, 3, (4, 5), (7, 5), (2, 2), (3, 2), (3, 2)),
     (3, 2, (2, 3), (8, 1), (4, 1), (0, 0), (0, 0)),      # last_freq decoder, no crop
+    (12, 3, (5, 6), (8, 1), (4, 1), (2, 0), (2, 0)),     # >= 8 channels: tap-major tables
+    (10, 9, (1, 9), (1, 8), (1, 4), (0, 2), (0, 3)),
 ]
 
 

@@ -1,0 +1,123 @@
+"""GPU: parity statement of the bf16 arithmetic mode (trainer.precision=bf16-mixed, BASELINE config 3).
+
+The reference has no bf16 path of its own (cfg/config.yaml:112 is precision 32); Lightning's bf16-mixed is
+torch.autocast(bfloat16): convolutions / linear layers / LSTM cells round their operands to bf16, accumulate in fp32 and
+return bf16, norms / FFT / losses stay fp32.  The HIP mode rounds the same operands to bf16 (RNE), accumulates in fp32 and
+keeps fp32 results -- never less accurate than autocast.  So the test is: against the fp32 CPU oracle, the HIP bf16
+output is not further away than the CPU oracle run under torch.autocast("cpu", bfloat16) is, up to a factor that covers
+the different summation order.  (fp32 and bf16x3 parity to the oracle itself: every other test file, all modes.)"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = [pytest.mark.gpu, pytest.mark.one_mode]
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _bf16():
+    from remfx_amd import ops
+    old = ops.gemm_precision()
+    ops.set_gemm_precision("bf16")
+    yield
+    ops.set_gemm_precision(old)
+
+
+def _rms(a, b):
+    return float(((a.float() - b.float()) ** 2).mean().sqrt())
+
+
+CASES = [
+    (48, 96, (32, 40), (8, 1), (4, 1), (2, 0), (1, 1), 2),      # HDemucs freq encoder
+    (96, 192, (16, 64), (3, 3), (1, 1), (1, 1), (1, 1), 2),     # decoder rewrite
+    (256, 256, (1, 2100), (1, 7), (1, 1), (0, 0), (1, 2), 1),   # TCN block
+    (12, 96, (1, 256), (1, 1), (1, 1), (0, 0), (1, 1), 64),     # DConv 1x1, Cin not a multiple of 8
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bf16_not_worse_than_autocast(case):
+    from remfx_amd import ops
+    Cin, Cout, (IA, IB), (KA, KB), stride, padding, dilation, N = case
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, Cin, IA, IB, generator=g)
+    w = torch.randn(Cout, Cin, KA, KB, generator=g) / (Cin * KA * KB) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y = F.conv2d(xr, wr, br, stride, padding, dilation)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xa, wa, ba = (t.clone().requires_grad_(True) for t in (x, w, b))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ya = F.conv2d(xa, wa, ba, stride, padding, dilation)
+    ya.float().backward(gy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd = ops.conv2d(xd, wd, bd, stride, padding, dilation)
+    yd.backward(gy.to(DEV))
+    for name, got, auto, ref in (("y", yd.detach(), ya.detach(), y.detach()), ("dx", xd.grad, xa.grad, xr.grad),
+                                 ("dw", wd.grad, wa.grad, wr.grad)):
+        e_hip, e_auto = _rms(got.cpu(), ref), _rms(auto, ref)
+        scale = float(ref.abs().max())
+        assert e_hip < 1.5 * e_auto + 1e-6 * scale, (name, e_hip, e_auto, scale)
+        assert e_hip < 1e-2 * scale, (name, e_hip, scale)            # absolute sanity: operand rounding is 2^-9
+
+
+def test_hdemucs_bf16_not_worse_than_autocast():
+    """Whole network, forward and the full gradient vector (channels = 8, 20000 samples: the oracle runs in seconds)."""
+    from oracle import ref_hdemucs
+    from remfx_amd.hdemucs import HDemucs
+    torch.manual_seed(0)
+    ref = ref_hdemucs.HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=8)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if n.endswith(".scale"):
+                p.fill_(0.3)
+    net = HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=8)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 1, 20000, generator=g) * 0.5
+    y = ref(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    gref = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+    ref.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ya = ref(x)
+    ya.float().backward(gy)
+    gauto = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+    yd = net(x.to(DEV))
+    yd.backward(gy.to(DEV))
+    e_hip, e_auto = _rms(yd.detach().cpu(), y.detach()), _rms(ya.detach(), y.detach())
+    print("forward rms error vs fp32 oracle: hip bf16", e_hip, "autocast oracle", e_auto, "max |y|", float(y.abs().max()))
+    assert e_hip < 2.0 * e_auto, (e_hip, e_auto)
+    num_h = num_a = den = 0.0
+    for n, p in net.named_parameters():
+        if n not in gref:
+            continue
+        num_h += float(((p.grad.cpu() - gref[n]) ** 2).sum())
+        num_a += float(((gauto[n] - gref[n]) ** 2).sum())
+        den += float((gref[n] ** 2).sum())
+    rel_h, rel_a = (num_h / den) ** 0.5, (num_a / den) ** 0.5
+    print("global relative gradient error vs fp32 oracle: hip bf16", rel_h, "autocast oracle", rel_a)
+    assert rel_h < 2.0 * rel_a, (rel_h, rel_a)
+
+
+def test_hdemucs_full_config_bf16_forward():
+    """cfg/model/demucs.yaml geometry (83.6 M parameters), one 262144-sample clip."""
+    from oracle import ref_hdemucs
+    from remfx_amd.hdemucs import HDemucs
+    torch.manual_seed(3)
+    ref = ref_hdemucs.HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
+    net = HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV)
+    x = torch.randn(1, 1, 262144, generator=torch.Generator().manual_seed(2)) * 0.1
+    with torch.no_grad():
+        y = ref(x)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ya = ref(x).float()
+        yd = net(x.to(DEV)).cpu()
+    e_hip, e_auto = _rms(yd, y), _rms(ya, y)
+    print("full config forward rms error vs fp32 oracle: hip bf16", e_hip, "autocast oracle", e_auto, "max |y|", float(y.abs().max()))
+    assert e_hip < 2.0 * e_auto, (e_hip, e_auto)

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 import torch
+
+from tests.conftest import check, mode, tol
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
@@ -45,12 +47,14 @@ def test_cnn14_golden(golden_dir):
         net.train()                                   # BatchNorm batch statistics
         outb = torch.hstack(net(x, train=False)).cpu().numpy()
     rel = np.sqrt(((mel - g["mel"]) ** 2).mean()) / np.abs(g["mel"]).max()
-    assert rel < 1e-6, rel
-    np.testing.assert_allclose(out, g["out_eval"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(outb, g["out_bnbatch"], rtol=5e-3, atol=5e-4)
-    # bit-exact detected-effect labels (models.py:61-64)
-    assert np.array_equal(out > 0.5, g["out_eval"] > 0.5)
-    assert np.array_equal(outb > 0.5, g["out_bnbatch"] > 0.5)
+    check(rel, 1e-6, what=rel)
+    np.testing.assert_allclose(out, g["out_eval"], rtol=tol(2e-4, bf16=5e-2), atol=tol(2e-5, bf16=2e-2))
+    np.testing.assert_allclose(outb, g["out_bnbatch"], rtol=tol(5e-3, bf16=5e-2), atol=tol(5e-4, bf16=2e-2))
+    # bit-exact detected-effect labels (models.py:61-64) in the fp32-parity modes; with bf16 operands every probability
+    # further than the mode's output bound from the 0.5 threshold must still land on the reference's side
+    sure = (lambda ref: np.abs(ref - 0.5) > 2e-2) if mode() == "bf16" else (lambda ref: np.ones_like(ref, dtype=bool))
+    assert np.array_equal((out > 0.5)[sure(g["out_eval"])], (g["out_eval"] > 0.5)[sure(g["out_eval"])])
+    assert np.array_equal((outb > 0.5)[sure(g["out_bnbatch"])], (g["out_bnbatch"] > 0.5)[sure(g["out_bnbatch"])])
 
 
 def test_cnn14_train_step_vs_oracle():
@@ -74,12 +78,12 @@ def test_cnn14_train_step_vs_oracle():
     # dropout off (p applies only with train=True): compare through the valid path on a train-mode net
     loss = model.common_step((x.to(DEV), None, None, lab.to(DEV)), 0, mode="valid")
     loss.backward()
-    assert abs(float(loss) - float(lref)) < 2e-4 * max(1.0, abs(float(lref)))
+    check(abs(float(loss) - float(lref)), 2e-4, max(1.0, abs(float(lref))))
     for k in ("conv_block1.conv1.weight", "conv_block3.bn1.weight", "conv_block6.conv2.weight", "fc1.weight",
               "heads.2.weight"):
         got, ref = dict(net.named_parameters())[k].grad.cpu(), sdr[k].grad
         scale = max(1e-6, float(ref.abs().max()))
-        assert float(((got - ref) ** 2).mean().sqrt()) < 5e-3 * scale, k
+        check(float(((got - ref) ** 2).mean().sqrt()), 5e-3, scale, what=k)
 
 
 def test_remfx_step_and_chain_flow(golden_dir):
@@ -92,10 +96,10 @@ def test_remfx_step_and_chain_flow(golden_dir):
     model = models.RemFX(1e-4, 0.95, 0.999, 1e-6, 1e-3, 48000, net).to(DEV)
     x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
     loss = model.training_step((x, y, None, None), 0)
-    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    check(abs(float(loss) - float(g["loss"])), 1e-4, abs(float(g["loss"])))
     assert sorted(model.logged) == g["log_names"].tolist()
     for k, v in zip(g["log_names"].tolist(), g["log_vals"]):
-        assert abs(float(model.logged[k]) - float(v)) < 2e-3 * max(1.0, abs(float(v))), k
+        check(abs(float(model.logged[k]) - float(v)), 2e-3, max(1.0, abs(float(v))), what=k)
 
     class Tag(nn.Module):
         def __init__(self, mul, add):
@@ -119,8 +123,8 @@ def test_remfx_step_and_chain_flow(golden_dir):
     # strict > 0.5 threshold: 0.5 is NOT detected, 0.51 is
     assert chain.last_labels.cpu().tolist() == [[1, 0, 0, 1, 0], [0, 1, 0, 0, 1], [0, 0, 0, 0, 0]]
     np.testing.assert_allclose(cout.cpu().numpy(), g["chain_out"], rtol=1e-6, atol=1e-6)
-    assert abs(float(closs) - float(g["chain_loss"])) < 1e-4 * abs(float(g["chain_loss"]))
+    check(abs(float(closs) - float(g["chain_loss"])), 1e-4, abs(float(g["chain_loss"])))
     chain.test_step((xc, yc, None, None), 0)
     assert sorted(chain.logged) == g["chain_log_names"].tolist()
     for k, v in zip(g["chain_log_names"].tolist(), g["chain_log_vals"]):
-        assert abs(float(chain.logged[k]) - float(v)) < 2e-3 * max(1.0, abs(float(v))), k
+        check(abs(float(chain.logged[k]) - float(v)), 2e-3, max(1.0, abs(float(v))), what=k)

@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 import torch
+
+from tests.conftest import check, mode, tol
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -57,10 +59,10 @@ def test_conv2d_fwd_bwd(case):
     yd = ops.conv2d(xd, wd, bd, stride, padding, dilation)
     assert yd.shape == y.shape
     yd.backward(gy.to(dev))
-    assert _rms(yd.detach().cpu(), y.detach()) < 1e-5 * max(1.0, float(y.detach().abs().max()))
+    check(_rms(yd.detach().cpu(), y.detach()), 1e-5, max(1.0, float(y.detach().abs().max())))
     for got, ref, name in ((xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw"), (bd.grad, br.grad, "db")):
         scale = max(1.0, float(ref.abs().max()))
-        assert _rms(got.cpu(), ref) < 2e-5 * scale, (name, _rms(got.cpu(), ref), scale)
+        check(_rms(got.cpu(), ref), 2e-5, scale, what=(name, _rms(got.cpu(), ref), scale))
 
 
 TCASES = [
@@ -95,10 +97,10 @@ def test_convT_fwd_bwd(case):
     xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
     yd = ops.conv_transpose2d(xd, wd, bd, stride, (1, 1), lo, (LA, LB))
     yd.backward(gy.to(dev))
-    assert _rms(yd.detach().cpu(), y.detach()) < 1e-5 * max(1.0, float(y.detach().abs().max()))
+    check(_rms(yd.detach().cpu(), y.detach()), 1e-5, max(1.0, float(y.detach().abs().max())))
     for got, ref, name in ((xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw"), (bd.grad, br.grad, "db")):
         scale = max(1.0, float(ref.abs().max()))
-        assert _rms(got.cpu(), ref) < 2e-5 * scale, (name, _rms(got.cpu(), ref), scale)
+        check(_rms(got.cpu(), ref), 2e-5, scale, what=(name, _rms(got.cpu(), ref), scale))
 
 
 def test_strided_input_view():
@@ -110,12 +112,12 @@ def test_strided_input_view():
     w = torch.randn(12, 48, 1, 3, generator=g) * 0.1
     ref = F.conv2d(x, w, None, 1, (0, 2), (1, 2))
     got = ops.conv2d(x.to(dev), w.to(dev), None, (1, 1), (0, 2), (1, 2))
-    assert _rms(got.cpu(), ref) < 1e-5
+    check(_rms(got.cpu(), ref), 1e-5)
     xt = x.permute(0, 1, 3, 2)              # non-contiguous view as input
     ref2 = F.conv2d(xt, w.permute(0, 1, 3, 2), None, 1, (2, 0), (2, 1))
     got2 = ops.conv2d(x.to(dev).permute(0, 1, 3, 2), w.to(dev).permute(0, 1, 3, 2).contiguous(), None,
                       (1, 1), (2, 0), (2, 1))
-    assert _rms(got2.cpu(), ref2) < 1e-5
+    check(_rms(got2.cpu(), ref2), 1e-5)
 
 
 @pytest.mark.parametrize("name", ["tcn_small", "tcn_mid", "tcn_causal"])
@@ -136,7 +138,7 @@ def test_tcn_golden(golden_dir, name):
     with torch.no_grad():
         y = net(torch.from_numpy(gd["x"]).to(dev)).cpu().numpy()
     assert y.shape == gd["y"].shape
-    assert float(np.sqrt(((y - gd["y"]) ** 2).mean())) < 1e-5
+    check(float(np.sqrt(((y - gd["y"]) ** 2).mean())), 1e-5)
 
 
 def test_tcn_backward_vs_oracle():
@@ -160,11 +162,11 @@ def test_tcn_backward_vs_oracle():
     net = net.to(dev)
     yd = net(x.to(dev))
     yd.backward(gy.to(dev))
-    assert _rms(yd.detach().cpu(), y.detach()) < 1e-5
+    check(_rms(yd.detach().cpu(), y.detach()), 1e-5)
     for k, p in net.named_parameters():
         ref = sdr[k].grad
         scale = max(1e-3, float(ref.abs().max()))
-        assert _rms(p.grad.cpu(), ref) < 1e-4 * scale, (k, _rms(p.grad.cpu(), ref), scale)
+        check(_rms(p.grad.cpu(), ref), 1e-4, scale, what=(k, _rms(p.grad.cpu(), ref), scale))
 
 
 @pytest.mark.parametrize("case", [
@@ -187,9 +189,9 @@ def test_conv_glu_fused(case):
     xd, wd, bd = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
     out = ops.conv2d_glu(xd, wd, bd, (1, 1), pad)
     out.backward(g.cuda())
-    assert _rms(out.detach().cpu(), ref.detach()) < 1e-5
+    check(_rms(out.detach().cpu(), ref.detach()), 1e-5)
     for a, r in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
-        assert _rms(a.cpu(), r) < 1e-4 * max(1e-3, float(r.abs().max()))
+        check(_rms(a.cpu(), r), 1e-4, max(1e-3, float(r.abs().max())))
 
 
 @pytest.mark.parametrize("case", [
@@ -215,6 +217,6 @@ def test_conv_fork_residual_gradient(case):
     xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
     y, alias = ops.conv2d_fork(xd, wd, bd, stride, padding)
     ((y * g1.to(dev)).sum() + (alias * g2.to(dev)).sum()).backward()
-    assert _rms(y.detach().cpu(), yr.detach()) < 1e-5
+    check(_rms(y.detach().cpu(), yr.detach()), 1e-5)
     for got, ref in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
-        assert _rms(got.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+        check(_rms(got.cpu(), ref), 2e-5, max(1.0, float(ref.abs().max())))

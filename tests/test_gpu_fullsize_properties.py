@@ -2,6 +2,8 @@
 oracle is too slow to be the checker: round trips, linearity, normalisation invariants, time-reversal symmetry."""
 import pytest
 import torch
+
+from tests.conftest import check, mode, tol
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
@@ -13,6 +15,7 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
+@pytest.mark.one_mode
 def test_stft_istft_round_trip_full_clips():
     """iSTFT(STFT(x)) == x for 16 full clips at the HDemucs geometry (n_fft 4096, hop 1024) and at the three loss
     resolutions' n_fft / hop with a full-length hann window (constant-overlap-add holds for hop | n_fft/2 only there)."""
@@ -43,23 +46,21 @@ def test_conv_linearity_full_layers(shape, cout, kernel, stride, padding):
     g = torch.Generator().manual_seed(1)
     x, y = torch.randn(shape, generator=g).to(DEV), torch.randn(shape, generator=g).to(DEV)
     w = (torch.randn(cout, shape[1], *kernel, generator=g) / (shape[1] * kernel[0] * kernel[1]) ** 0.5).to(DEV)
-    prev = ops.GEMM_PREC
-    try:
-        for prec, tol in (("f32", 2e-6), ("bf16x3", 5e-5)):
-            ops.set_gemm_precision(prec)
-            cx = ops.conv2d_forward(x, w, None, stride, padding, (1, 1))
-            cy = ops.conv2d_forward(y, w, None, stride, padding, (1, 1))
-            cz = ops.conv2d_forward(0.75 * x - 1.5 * y, w, None, stride, padding, (1, 1))
-            assert _rel(cz, 0.75 * cx - 1.5 * cy) < tol, prec
-            # adjoint identity <conv(x), g> == <x, dgrad(g)>
-            gy = torch.randn(cx.shape, generator=g).to(DEV)
-            dx = ops.conv2d_dgrad(gy, w, tuple(x.shape), tuple(x.stride()), stride, padding, (1, 1))
-            lhs, rhs = float((cx.double() * gy.double()).sum()), float((x.double() * dx.double()).sum())
-            assert abs(lhs - rhs) < 1e-3 * abs(lhs) + 0.05 * tol * float(cx.double().norm() * gy.double().norm()), prec
-    finally:
-        ops.GEMM_PREC = prev
+    # the mode comes from the suite-wide fixture (tests/conftest.py).  bf16: the rounding of the combined input is not the
+    # combination of the roundings, so linearity holds to the operand precision (2^-9) only
+    t = tol(2e-6, bf16x3=5e-5, bf16=1e-2)
+    cx = ops.conv2d_forward(x, w, None, stride, padding, (1, 1))
+    cy = ops.conv2d_forward(y, w, None, stride, padding, (1, 1))
+    cz = ops.conv2d_forward(0.75 * x - 1.5 * y, w, None, stride, padding, (1, 1))
+    assert _rel(cz, 0.75 * cx - 1.5 * cy) < t, mode()
+    # adjoint identity <conv(x), g> == <x, dgrad(g)>
+    gy = torch.randn(cx.shape, generator=g).to(DEV)
+    dx = ops.conv2d_dgrad(gy, w, tuple(x.shape), tuple(x.stride()), stride, padding, (1, 1))
+    lhs, rhs = float((cx.double() * gy.double()).sum()), float((x.double() * dx.double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * abs(lhs) + 0.05 * t * float(cx.double().norm() * gy.double().norm()), mode()
 
 
+@pytest.mark.one_mode
 def test_groupnorm_invariants_full_size():
     """GroupNorm(1, C) with unit affine: every sample of the output has mean 0 and variance 1; the backward of a
     constant upstream gradient is 0 (the normalised output is shift invariant)."""
@@ -96,6 +97,7 @@ def test_blstm_time_reversal_full_size():
     assert float(y.abs().max()) <= 1.0 and float(y.abs().mean()) > 1e-3      # bounded by tanh, not degenerate
 
 
+@pytest.mark.one_mode
 def test_losses_identity_full_clips():
     """loss(x, x): L1 = 0, MRSTFT = 0 with zero gradient, SI-SDR saturates -- on 16 full clips."""
     from remfx_amd import losses
@@ -138,18 +140,12 @@ def test_tcn_causality_and_shift_full_length():
         assert _rel(y3[..., d:], y[..., :-d]) < 1e-6
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
-def test_demucs_full_config_directional_derivative(prec):
+def test_demucs_full_config_directional_derivative():
     """Headline config (cfg/model/demucs.yaml, 83.6 M parameters, 262144-sample clips): the backward pass of the
-    training loss agrees with a central finite difference of the forward pass along the gradient direction, in the
-    exact-fp32 GEMM mode and in the bf16x3 mode bench.py runs in."""
-    from remfx_amd import models, ops
-    prev = ops.GEMM_PREC
-    ops.set_gemm_precision(prec)
-    try:
-        _directional_derivative(models)
-    finally:
-        ops.GEMM_PREC = prev
+    training loss agrees with a central finite difference of the forward pass along the gradient direction, in every
+    arithmetic mode (the suite-wide fixture of tests/conftest.py), the one bench.py reports included."""
+    from remfx_amd import models
+    _directional_derivative(models)
 
 
 def _directional_derivative(models):
@@ -176,4 +172,6 @@ def _directional_derivative(models):
             for p, gr in zip(params, grads):
                 p.sub_(gr, alpha=sign * eps / gnorm)
     fd = (vals[0] - vals[1]) / (2 * eps)                # d loss / d t along the unit gradient direction = |grad|
-    assert abs(fd - gnorm) < 0.05 * gnorm, (fd, gnorm, vals, float(loss))
+    # bf16: the two forward evaluations carry independent operand-rounding noise of ~1e-3 of the loss each, against a
+    # first-order change of 2e-3 per side
+    assert abs(fd - gnorm) < tol(0.05, bf16=0.5) * gnorm, (fd, gnorm, vals, float(loss))

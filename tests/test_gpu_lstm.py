@@ -3,6 +3,8 @@
 Reference call sites: torchaudio HDemucs `_BLSTM` (remfx/models.py:319) and Open-Unmix (models.py:297-298)."""
 import pytest
 import torch
+
+from tests.conftest import check, mode, tol
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
@@ -28,10 +30,10 @@ def _run(H, Cin, T, Bn, layers, seed=0):
         return ((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()
 
     yc = y.detach().permute(2, 0, 1).reshape(1, 2 * H, T * Bn)
-    assert rel(out.detach(), yc) < 1e-4
-    assert rel(xc.grad, x.grad.permute(2, 0, 1).reshape(1, Cin, T * Bn)) < 2e-4
+    check(rel(out.detach(), yc), 1e-4)
+    check(rel(xc.grad, x.grad.permute(2, 0, 1).reshape(1, Cin, T * Bn)), 2e-4)
     for (n, p), (_, q) in zip(dev.named_parameters(), ref.named_parameters()):
-        assert rel(p.grad, q.grad) < 3e-4, n
+        check(rel(p.grad, q.grad), 3e-4, what=n)
     assert not lstm.error_flag()            # no bounded spin of the cluster exchange timed out
 
 
@@ -57,4 +59,4 @@ def test_blstm_inference_no_saved_state():
         dev = nn.LSTM(64, 64, num_layers=2, bidirectional=True).cuda()
         dev.load_state_dict(ref.state_dict())
         out = lstm.blstm(dev, x.permute(2, 0, 1).reshape(1, 64, 33).contiguous().cuda(), 11, 3)
-    assert torch.allclose(out.cpu(), y.permute(2, 0, 1).reshape(1, 128, 33), atol=2e-5)
+    check(float((out.cpu() - y.permute(2, 0, 1).reshape(1, 128, 33)).abs().max()), 2e-5)

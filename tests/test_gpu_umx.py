@@ -2,6 +2,8 @@
 import pytest
 import torch
 
+from tests.conftest import check, mode, tol
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -41,7 +43,7 @@ def test_umx_separator_eval():
         sep = Separator(target_models={"other": net}, nb_channels=1, sample_rate=48000, n_fft=2048, n_hop=512).to(DEV)
         yd = sep(x.to(DEV)).cpu()
     assert yd.shape == y.shape == (2, 1, 1, 30000)
-    assert _rms(yd, y) < 1e-4 * max(1.0, float(y.abs().max())), _rms(yd, y)
+    check(_rms(yd, y), 1e-4, max(1.0, float(y.abs().max())), what=_rms(yd, y))
 
 
 def test_umx_train_fwd_bwd():
@@ -58,7 +60,7 @@ def test_umx_train_fwd_bwd():
     y.backward(gy)
     sep = Separator(target_models={"other": net}, nb_channels=1, sample_rate=48000, n_fft=2048, n_hop=512).to(DEV)
     yd = sep(x.to(DEV))
-    assert _rms(yd.detach().cpu(), y.detach()) < 1e-4 * max(1.0, float(y.detach().abs().max()))
+    check(_rms(yd.detach().cpu(), y.detach()), 1e-4, max(1.0, float(y.detach().abs().max())))
     yd.backward(gy.to(DEV))
     refg = dict(ref.named_parameters())
     num = den = 0.0
@@ -66,7 +68,7 @@ def test_umx_train_fwd_bwd():
         r = refg[n].grad
         d = p.grad.cpu() - r
         num += float((d ** 2).sum()); den += float((r ** 2).sum())
-    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+    check((num / den) ** 0.5, 2e-3, what=(num / den) ** 0.5)
 
 
 def test_openunmix_model_wrapper():
