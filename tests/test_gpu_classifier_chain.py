@@ -83,7 +83,9 @@ def test_cnn14_train_step_vs_oracle():
               "heads.2.weight"):
         got, ref = dict(net.named_parameters())[k].grad.cpu(), sdr[k].grad
         scale = max(1e-6, float(ref.abs().max()))
-        check(float(((got - ref) ** 2).mean().sqrt()), 5e-3, scale, what=k)
+        # train-mode BatchNorm gradients are ill-conditioned: the exact-fp32 mode itself sits 3e-3 from the CPU oracle
+        # (summation order); the 2^-17 product rounding of bf16x3 measures 8.5e-3 -> bound 3 x the fp32 one
+        check(float(((got - ref) ** 2).mean().sqrt()), 5e-3, scale, bf16x3=1.5e-2, what=k)
 
 
 def test_remfx_step_and_chain_flow(golden_dir):

@@ -166,7 +166,10 @@ def test_tcn_backward_vs_oracle():
     for k, p in net.named_parameters():
         ref = sdr[k].grad
         scale = max(1e-3, float(ref.abs().max()))
-        check(_rms(p.grad.cpu(), ref), 1e-4, scale, what=(k, _rms(p.grad.cpu(), ref), scale))
+        # bf16x3 / bf16: the backward re-materialises PReLU'(conv1(x)); a position whose pre-activation lies within the
+        # product rounding of zero flips between slope and 1, an O(1) change of that term: measured 1e-6 (f32), 8.5e-4
+        # (bf16x3: 2^-17 products) and 2.3e-2 (bf16: 2^-9) of the gradient's scale on block 0, the end of the chain
+        check(_rms(p.grad.cpu(), ref), 1e-4, scale, bf16x3=2e-3, bf16=5e-2, what=(k, _rms(p.grad.cpu(), ref), scale))
 
 
 @pytest.mark.parametrize("case", [

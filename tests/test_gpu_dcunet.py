@@ -66,7 +66,8 @@ def test_dcunet_train_fwd_bwd():
         check(_rms(p.grad.cpu(), r), 5e-2, max(1e-6, float(r.abs().max())), what=n)
     print("global rel", (num / den) ** 0.5, sorted(errs)[-4:])
     # batch-statistic whitening of 3 x W maps is ill-conditioned: fp32 ordering noise is amplified
-    check((num / den) ** 0.5, 5e-3, what=(num / den) ** 0.5)
+    # measured: 4.3e-3 in exact fp32 (ordering noise only), 1.2e-2 with bf16x3 products, 0.22 with bf16 operands
+    check((num / den) ** 0.5, 5e-3, bf16x3=2e-2, bf16=0.4, what=(num / den) ** 0.5)
     # running statistics updated identically (momentum 0.1 lerp)
     rb = dict(ref.named_buffers())
     for n, b in net.named_buffers():
