@@ -26,6 +26,7 @@ CLIP = 262144
 SR = 48000
 PEAK_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA; the bf16x3 mode issues 3 bf16 MFMA flops per algorithmic flop
+DTYPES = {"f32": "f32", "bf16x3": "f32 via bf16x3 split MFMA (fp32 accumulate)", "bf16": "bf16 (fp32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -94,13 +95,36 @@ class KernelTimer:
         return ms, len(self.events)
 
 
+def _host_cpu():
+    """(physical cores, model name) of the host from /proc/cpuinfo (falls back to os.cpu_count())."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return (len(cores) or (os.cpu_count() or 1)), model
+
+
 def cpu_baseline(workload):
     """The CPU oracle (pure-torch restatement of the reference) timed on the host cores: forward + loss +
     backward of the removal network on ONE short clip (bounded: tens of seconds at most).  Threads are capped
     at 32: torch's CPU kernels get slower, not faster, when spread over every hardware thread of the host."""
     from oracle import ref_dcunet, ref_hdemucs, ref_losses, ref_tcn, ref_umx
     from oracle.ref_utils import causal_crop
-    cores = min(os.cpu_count() or 1, 32)
+    phys, cpu_model = _host_cpu()
+    cores = min(phys, 32)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     torch.manual_seed(0)
@@ -109,22 +133,34 @@ def cpu_baseline(workload):
     if workload == "tcn":
         sd = {k: v.requires_grad_(True) for k, v in ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7).items()}
         fwd = lambda: ref_tcn.tcn_forward(x, sd, 20)
+        params = list(sd.values())
     elif workload == "demucs":
         net = ref_hdemucs.HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
         fwd = lambda: net(x).squeeze(1)
+        params = list(net.parameters())
     elif workload == "dcunet":
         net = ref_dcunet.DCUNet(stft_kernel_size=512, fix_length_mode="pad")
         fwd = lambda: net(x.squeeze(1))
+        params = list(net.parameters())
     else:
         net = ref_umx.OpenUnmix(nb_bins=1025, nb_channels=1)
         fwd = lambda: ref_umx.separator(net, x).squeeze(1)
-    t0 = time.time()
-    out = fwd()
-    tgt = causal_crop(y, out.shape[-1]) if out.shape[-1] < y.shape[-1] else y
-    ref_losses.removal_loss(out, tgt).backward()
-    dt = time.time() - t0
+        params = list(net.parameters())
+    def one():
+        for p in params:
+            p.grad = None
+        t0 = time.time()
+        out = fwd()
+        tgt = causal_crop(y, out.shape[-1]) if out.shape[-1] < y.shape[-1] else y
+        ref_losses.removal_loss(out, tgt).backward()
+        return time.time() - t0
+    one()                                            # warm-up (allocator, MKL / oneDNN primitive caches)
+    times = sorted(one() for _ in range(3))
+    dt = times[1]                                    # median of three timed steps
     return {"value": round(T / SR / dt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle {workload} forward + MRSTFT/L1 loss + backward, 1 clip x {T} samples, {dt:.1f} s"}
+            "cpu_model": cpu_model, "physical_cores": phys,
+            "sample": f"oracle {workload} forward + MRSTFT/L1 loss + backward, 1 clip x {T} samples, 1 warm-up + median of 3 "
+                      f"timed steps ({times[0]:.1f} / {times[1]:.1f} / {times[2]:.1f} s), {cores} torch threads"}
 
 
 def bench_chain(args, rank, world, device):
@@ -172,10 +208,56 @@ def bench_chain(args, rank, world, device):
         "metric": "audio-seconds/sec chain inference (whole job)", "value": round(world * batch * CLIP / SR * args.steps / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "f32 via bf16x3 split MFMA (fp32 accumulate)",
+        "vs_baseline": None, "dtype": DTYPES[args.gemm],
         "data": "synthetic", "config": {"workload": "RemFX-detect chain inference (+exp=remfx_detect), inference only",
                                         "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
                                         "removal_model_applications_per_step": napplied, "parallelism": f"dp{world}"}}))
+
+
+def bench_demucs_fwd(args, rank, world, device):
+    """The north_star's own sub-metric: STFT + Hybrid Demucs FORWARD (model.sample: _spec, both U-Net branches, _ispec) on
+    64 x 262144-sample clips, no loss / backward.  Algorithmic work: 117.2 GFLOP and 396 MB of fp32
+    layer-boundary traffic per clip + 334 MB of weights per pass -> both roofline fractions are reported."""
+    batch = args.batch or 64
+    model = build_model("demucs", device).eval()
+    x = synthetic_batch(batch, rank, device)[0]
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model.model.sample(x)
+        fence()
+        t0 = time.time()
+        for _ in range(args.steps):
+            out = model.model.sample(x)
+        fence()
+    dt = time.time() - t0
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    if rank != 0:
+        return
+    dt = float(t) / args.steps
+    flops = batch * (117.2e9 + 0.13e9)
+    nbytes = batch * 396e6 + 334e6
+    mfma_peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[args.gemm]
+    f_hbm, f_mfma = nbytes / dt / 1e9 / PEAK_HBM_GBS, flops / dt / 1e12 / mfma_peak
+    bound = "hbm" if f_hbm >= f_mfma else "mfma"
+    print(json.dumps({
+        "metric": "audio-seconds/sec STFT + Demucs forward (whole job)", "value": round(world * batch * CLIP / SR / dt, 3),
+        "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPES[args.gemm], "data": "synthetic",
+        "config": {"workload": "Hybrid Demucs (cfg/model/demucs.yaml) forward only: STFT -> U-Net -> iSTFT, DemucsModel.sample",
+                   "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR, "parallelism": f"dp{world}",
+                   "output_rms": round(float(out.float().pow(2).mean().sqrt()), 6)},
+        "roofline": {"bound": bound, "achieved": round(nbytes / dt / 1e9, 1) if bound == "hbm" else round(flops / dt / 1e12, 2),
+                     "peak": PEAK_HBM_GBS if bound == "hbm" else mfma_peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                     "frac": round(max(f_hbm, f_mfma), 4), "frac_hbm": round(f_hbm, 4), "frac_mfma": round(f_mfma, 4),
+                     "algorithmic_bytes_per_pass": nbytes, "algorithmic_flops_per_pass": flops, "traffic": None}}))
 
 
 def main():
@@ -184,12 +266,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("RFX_WORKLOAD", "demucs"),
-                    choices=["demucs", "tcn", "dcunet", "umx", "chain"])
+                    choices=["demucs", "tcn", "dcunet", "umx", "chain", "demucs_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm", default=os.environ.get("RFX_GEMM_PREC", "bf16x3"), choices=["bf16x3", "f32", "bf16"],
-                    help="MFMA arithmetic of the gather-GEMMs: split-bf16 x3 with fp32 accumulate (default; "
-                         "HDemucs forward within 4e-6 RMS of the fp32 oracle) or exact fp32 MFMA")
+    ap.add_argument("--gemm", default=os.environ.get("RFX_GEMM_PREC", "bf16"), choices=["bf16", "bf16x3", "f32"],
+                    help="MFMA arithmetic of the gather-GEMMs.  bf16 (default): operands rounded to bf16, fp32 accumulation -- "
+                         "trainer.precision=bf16-mixed, the precision BASELINE.json's headline config names; bf16x3: fp32 "
+                         "operands split hi + lo, 3 MFMAs per product (HDemucs forward within 4e-6 RMS of the fp32 oracle); "
+                         "f32: exact fp32 MFMA")
     args = ap.parse_args()
     if args.workload == "tcn" and args.warmup < 2:
         # 32 x 262144 TCN activations fill ~190 of the 288 GB: the caching allocator settles only after its one
@@ -207,6 +291,8 @@ def main():
 
     if args.workload == "chain":
         return bench_chain(args, rank, world, device)
+    if args.workload == "demucs_fwd":
+        return bench_demucs_fwd(args, rank, world, device)
     model = build_model(args.workload, device)
     cfg = model.configure_optimizers()
     opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
@@ -253,16 +339,17 @@ def main():
     kms, klaunches = timer.result()
     achieved = timer.flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
     # algorithmic (fp32-equivalent) FLOP/s; in bf16x3 mode the matrix pipe executes 3x that in bf16
-    peak = PEAK_F32_TFLOPS if args.gemm == "f32" else PEAK_BF16_TFLOPS / 3.0
-    kname = ("gemm_fwd_kernel<R,false> (gather-GEMM, v_mfma_f32_32x32x2_f32)" if args.gemm == "f32" else
-             "gemm_fwd_kernel<R,true> (gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per 16-deep K step)")
+    peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[args.gemm]
+    kname = {"f32": "gemm_fwd_kernel<R> (gather-GEMM, v_mfma_f32_32x32x2_f32)",
+             "bf16x3": "gemm_tap_kernel<R,1> (tap-major gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per 16-deep K step)",
+             "bf16": "gemm_tap_kernel<R,2> (tap-major gather-GEMM, 1 x v_mfma_f32_32x32x16_bf16 per 16-deep K step)"}[args.gemm]
     # roofline.traffic: HBM bytes per launch of the dominant kernel family from the committed PMC passes
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command, scripts/collect_pmc.py)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_demucs_b64_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", f"r02_demucs_b64_pmc_traffic_{args.gemm}.json")
     if args.workload == "demucs" and batch == 64 and os.path.exists(pmc):
         ks = json.load(open(pmc))["kernels"]
-        fam = [v for k, v in ks.items() if k.startswith("gemm_fwd_kernel")]
+        fam = [v for k, v in ks.items() if k.startswith(("gemm_fwd_kernel", "gemm_tap_kernel"))]
         n = sum(v["launches_per_step"] for v in fam)
         if n:
             traffic = round(sum(v["bytes_per_step"] for v in fam) / n)
@@ -271,7 +358,7 @@ def main():
         "metric": "audio-seconds/sec fwd+bwd (whole job)", "value": round(audio_s / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "f32 via bf16x3 split MFMA (fp32 accumulate)",
+        "vs_baseline": None, "dtype": DTYPES[args.gemm],
         "data": "synthetic",
         "config": {"workload": {"tcn": "TCN (cfg/model/tcn.yaml) train step, +exp=reverb model=tcn",
                                 "demucs": "Hybrid Demucs (cfg/model/demucs.yaml) train step, +exp=chorus_aug model=demucs",

@@ -127,6 +127,9 @@ def _tap_major(self, kt, woff):
     multiple of the channel stride.  Channels >= cin of the last group read past the sample's extent (hardware
     buffer range check -> 0) and meet zero weight rows (woff_t = -1)."""
     K = kt.shape[0]
+    if self.cin > 0:                   # exact span of one sample of the operand: the num_records of its buffer descriptor
+        self.in_extent = ((self.cin - 1) * abs(int(self.in_cs)) + (self.IA - 1) * abs(int(self.in_as))
+                          + (self.IB - 1) * abs(int(self.in_bs)) + 1)
     if self.cin < 8 or K == 0 or K % self.cin:
         self.cin = 0
         return
@@ -152,8 +155,6 @@ def _tap_major(self, kt, woff):
     ok = c < self.cin
     wt[((t * gpt * 8) + c)[ok]] = woff[(c * nt + t)[ok]]
     self.woff_t = wt.astype(np.int32)
-    self.in_extent = ((self.cin - 1) * abs(int(self.in_cs)) + (self.IA - 1) * abs(int(self.in_as))
-                      + (self.IB - 1) * abs(int(self.in_bs)) + 1)
 
 
 GemmPlan._build_tap_major = _tap_major

@@ -1,6 +1,6 @@
 // Weight-gradient kernels on the bf16 matrix pipe (shared by gemm_wgrad_bf3.hip / gemm_wgrad_bf16.hip).
 #pragma once
-#include "gemm_fwd.h"
+#include "gemm_tap.h"
 
 struct WgradArgs {
   rfx_gemm_desc d;
@@ -13,6 +13,7 @@ struct WgradArgs {
   int tiles_per_block;
   int kt, mt, splits;
   int xcd_grouped;       // 1: 1-D grid, all (k, m) tiles of one position split share an XCD (ids congruent mod 8)
+  uint32_t in_bytes, g_bytes;   // wide kernel: exact span of one sample of each operand (buffer num_records)
 };
 
 // bf16x3 weight gradient: same tiling and gathers as gemm_wgrad_kernel, but the two LDS tiles hold
@@ -177,6 +178,180 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
 }
 
 
+// ---------------------------------------------------------------------------------
+// Wide-load weight gradient (the main path for unit-stride layers: in_bs == out_bs == 1, SB == out_sb == 1).
+//   dapack[m][k] += sum_p g[m][p] * In(k, p)
+// Both operands are contiguous along the reduction axis p, so a thread moves FOUR consecutive positions of one row per
+// instruction (raw buffer dwordx4 = 16 B per lane; a wave instruction covers 4 rows x 256 contiguous bytes), converts
+// them with two v_cvt_pk_bf16_f32 and stages them with ONE ds_write_b64 -- the 32-position kernel above issues a
+// dword load, two converts and two ds_write_b16 per ELEMENT and was bound by those (PMC r01: MFMA busy 18 %).
+// Position chunk = 64 consecutive b positions of one (n, a) output row; LDS rows are 72 bf16 (144 B = 36 dwords: the 16
+// lanes of a ds_read_b128 group land on 16 distinct 4-bank groups); 4 MFMA K steps per chunk and per wave tile.
+// Borders: a quad that starts left of its row (tap shift db < 0 at b = 0) takes four masked dword loads instead (a
+// negative offset would fail the whole dwordx4 range check, scripts/probes/bufprobe.hip); elements right of the row
+// end / beyond OB are zeroed after the load; rows whose a-coordinate is out of range load nothing (offset 2^31).
+// ---------------------------------------------------------------------------------
+template <int TM, int TK, int WM, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_wide_kernel(const WgradArgs w) {
+  constexpr int WK = 4 / WM;
+  constexpr int RM = 32 * WM * TM, RK = 32 * WK * TK, LDW = 72, PC = 64;
+  constexpr int LO = MODE == 1 ? 1 : 0;
+  constexpr int NG = RM / 16, NX = RK / 16;                         // quad loads per thread and chunk
+  __shared__ __attribute__((aligned(16))) unsigned short gs_hi[RM * LDW], gs_lo[LO ? RM * LDW : 8];
+  __shared__ __attribute__((aligned(16))) unsigned short xs_hi[RK * LDW], xs_lo[LO ? RK * LDW : 8];
+  __shared__ rfx_ktab_entry kts[RK];
+  const rfx_gemm_desc& d = w.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wm = WM == 1 ? 0 : wave / WK, wk = WM == 1 ? wave : wave % WK;
+  int zsplit = blockIdx.z, ym = blockIdx.y, xk = blockIdx.x;
+  if (w.xcd_grouped) {
+    // every (k, m) tile of a position split re-reads the same g rows / input samples: keep them behind ONE L2
+    const int nb = w.kt * w.mt, q = blockIdx.x >> 3;
+    zsplit = (q / nb) * 8 + (blockIdx.x & 7);
+    if (zsplit >= w.splits) return;
+    const int r = q % nb;
+    ym = r / w.kt;
+    xk = r - ym * w.kt;
+  }
+  const int m0 = ym * RM, k0 = xk * RK;
+  for (int i = tid; i < RK; i += 256) {
+    rfx_ktab_entry e;
+    if (k0 + i < d.Kpad) e = w.ktab[k0 + i];
+    else { e.off = 0; e.da = -(1 << 30); e.db = 0; e.flags = 0; }
+    kts[i] = e;
+  }
+  __syncthreads();
+  f32x16 acc[TM][TK];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int t_begin = zsplit * w.tiles_per_block;
+  const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
+  const int q4 = (tid & 15) * 4, r0 = tid >> 4;                    // this thread's quad inside the chunk / first row
+  const int chunks_per_row = (d.OB + PC - 1) / PC;
+  struct Stage { f32x4 gv[NG], xv[NX]; };
+  auto load_chunk = [&](int t, Stage& st) {
+    const int row = t / chunks_per_row;                            // (n, a), wave-uniform
+    const int n = row / d.OA, a = row - n * d.OA;
+    const int ob = (t - row * chunks_per_row) * PC + q4;           // first position of this thread's quad
+    const int lim = d.OB - ob;                                     // valid elements of the quad (<= 0: none)
+    // num_records = the sample's exact span: a quad that runs past the last row of the tensor reads 0 for the dwords
+    // beyond it (per-dword range check) instead of touching memory behind the allocation
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.in + (int64_t)n * d.in_ns), 0,
+                                                                         (int)w.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.g + (int64_t)n * d.out_ns), 0,
+                                                                         (int)w.g_bytes, 0x00020000);
+    const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(ob + d.out_b0) +
+                                      (int64_t)(m0 + r0) * d.out_cs) * 4);
+    const uint32_t gstep = (uint32_t)(16 * d.out_cs * 4);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const bool ok = (lim > 0) & (m0 + r0 + 16 * i < d.M);
+      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
+#pragma unroll
+      for (int e = 1; e < 4; ++e) v[e] = e < lim ? v[e] : 0.f;     // a row end inside the quad (OA == 1, OB % 4 != 0)
+      st.gv[i] = v;
+    }
+    const int ia0 = a * d.SA;
+    const uint32_t voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ob) * 4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const rfx_ktab_entry e = kts[r0 + 16 * i];
+      const bool ones = e.flags & 1;
+      const bool rowok = (lim > 0) & !ones & ((unsigned)(ia0 + e.da) < (unsigned)d.IA);
+      const int ib0 = ob + e.db;                                   // SB == 1
+      const int hi = min(lim, d.IB - ib0);                         // elements [0, hi) are inside the row on the right
+      const uint32_t off = voff + ((uint32_t)e.off << 2);
+      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (rowok & (ib0 >= 0)) ? off : RFX_BUF_OOB, 0, 0));
+      if (rowok & (ib0 < 0) & (ib0 > -4)) {                        // rare: the quad straddles the left end of its row
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, (ib0 + q >= 0) ? off + 4 * q : RFX_BUF_OOB, 0, 0));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = q < hi ? v[q] : 0.f;
+      if (ones) {                                                  // bias-gradient column: 1 at every valid position
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = q < lim ? 1.f : 0.f;
+      }
+      st.xv[i] = v;
+    }
+  };
+  auto put4 = [&](unsigned short* hi, unsigned short* lo, int row, const f32x4& v) {
+    const f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
+    const uint32_t ha = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t));
+    const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
+    *reinterpret_cast<uint2*>(hi + row * LDW + q4) = make_uint2(ha, hb);
+    if (MODE == 1) {
+      const f32x2_t fa = {__uint_as_float(ha << 16), __uint_as_float(ha & 0xffff0000u)};
+      const f32x2_t fb = {__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
+      const uint32_t la = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - fa, bf16x2_t));
+      const uint32_t lb = __builtin_bit_cast(uint32_t, __builtin_convertvector(b - fb, bf16x2_t));
+      *reinterpret_cast<uint2*>(lo + row * LDW + q4) = make_uint2(la, lb);
+    }
+  };
+  auto stage = [&](const Stage& st) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) put4(gs_hi, gs_lo, r0 + 16 * i, st.gv[i]);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) put4(xs_hi, xs_lo, r0 + 16 * i, st.xv[i]);
+  };
+  auto mma_chunk = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < PC / 16; ++ks) {
+      bf16x8 ah[TM], al[TM], bh[TK], bl[TK];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int off = (wm * 32 * TM + tm * 32 + l31) * LDW + 16 * ks + 8 * h;
+        ah[tm] = *reinterpret_cast<const bf16x8*>(gs_hi + off);
+        if (MODE == 1) al[tm] = *reinterpret_cast<const bf16x8*>(gs_lo + off);
+      }
+#pragma unroll
+      for (int tk = 0; tk < TK; ++tk) {
+        const int off = (wk * 32 * TK + tk * 32 + l31) * LDW + 16 * ks + 8 * h;
+        bh[tk] = *reinterpret_cast<const bf16x8*>(xs_hi + off);
+        if (MODE == 1) bl[tk] = *reinterpret_cast<const bf16x8*>(xs_lo + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk) {
+          acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tk], acc[tm][tk], 0, 0, 0);
+          if (MODE == 1) {
+            acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tk], acc[tm][tk], 0, 0, 0);
+            acc[tm][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tk], acc[tm][tk], 0, 0, 0);
+          }
+        }
+    }
+  };
+  // one register stage: the loads of chunk t+1 are issued right after chunk t went to LDS and stay in flight under
+  // chunk t's MFMAs (two workgroups per CU cover each other's barriers)
+  Stage st;
+  const int t_last = t_end - 1;
+  if (t_begin < t_end) load_chunk(t_begin, st);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();                       // the previous chunk's fragment reads are done
+    stage(st);
+    __syncthreads();
+    load_chunk(min(t + 1, t_last), st);    // unconditional (branch-free): the last chunk is re-read
+    mma_chunk();
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = k0 + wk * 32 * TK + tk * 32 + l31;
+        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
+      }
+}
+
 // shape: 0 = 96-row tiles (waves 1 x 4), 1 / 2 = 32-row tiles with 256 / 128 k rows, 3..6 = (64 TM) x (64 TK) tiles
 template <int MODE>
 static int rfx_launch_wgrad_bf(const WgradArgs& w, int shape, dim3 grid, hipStream_t s) {
@@ -192,5 +367,20 @@ static int rfx_launch_wgrad_bf(const WgradArgs& w, int shape, dim3 grid, hipStre
   RFX_CHECK_LAUNCH();
   return 0;
 }
+// wide-load kernel, shape: 0 = 96 x 128 (waves 1 x 4), 1 = 32 x 256, 2 = 32 x 128, 3 = 128 x 128, 4 = 64 x 128
+template <int MODE>
+static int rfx_launch_wgrad_wide(const WgradArgs& w, int shape, dim3 grid, hipStream_t s) {
+  switch (shape) {
+    case 0: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<3, 1, 1, MODE>), grid, dim3(256), 0, s, w); break;
+    case 1: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 2, 1, MODE>), grid, dim3(256), 0, s, w); break;
+    case 2: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 1, 1, MODE>), grid, dim3(256), 0, s, w); break;
+    case 3: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<2, 2, 2, MODE>), grid, dim3(256), 0, s, w); break;
+    default: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 2, 2, MODE>), grid, dim3(256), 0, s, w); break;
+  }
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+int rfx_launch_wgrad_wide_bf3(const WgradArgs& w, int shape, dim3 grid, hipStream_t s);
+int rfx_launch_wgrad_wide_bf16(const WgradArgs& w, int shape, dim3 grid, hipStream_t s);
 int rfx_launch_wgrad_bf3(const WgradArgs& w, int shape, dim3 grid, hipStream_t s);
 int rfx_launch_wgrad_bf16(const WgradArgs& w, int shape, dim3 grid, hipStream_t s);

@@ -214,6 +214,32 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     RFX_CHECK_LAUNCH();
     return 0;
   }
+  // wide-load kernel (gemm_wgrad.h): both operands contiguous and unit-stride along b, quads never straddle an output row
+  static const int wide_off = getenv("RFX_WGRAD_WIDE") ? !atoi(getenv("RFX_WGRAD_WIDE")) : 0;     // RFX_WGRAD_WIDE=0: A/B switch
+  const int64_t g_span = ((int64_t)(d->M - 1) * llabs(d->out_cs) + ((int64_t)(d->OA - 1) * d->out_sa + d->out_a0) * llabs(d->out_as) +
+                          (d->OB - 1 + d->out_b0) + 1) * 4;
+  if (prec != 0 && !wide_off && d->SB == 1 && d->in_bs == 1 && d->out_bs == 1 && d->out_sb == 1 &&
+      (d->OA == 1 || d->OB % 4 == 0) && d->in_extent > 0 && d->in_extent <= 0x7fffffffLL && g_span <= 0x7fffffffLL &&
+      d->out_cs >= 0 && d->out_as >= 0) {
+    w.in_bytes = (uint32_t)d->in_extent; w.g_bytes = (uint32_t)g_span;
+    const bool r96 = d->M > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;
+    const int shape = r96 ? 0 : d->M <= 32 ? (d->K > 128 ? 1 : 2) : d->M > 64 ? 3 : 4;
+    const int rm = shape == 0 ? 96 : shape <= 2 ? 32 : shape == 3 ? 128 : 64, rk = shape == 1 ? 256 : 128;
+    const int mt = (d->M + rm - 1) / rm, kt = (d->K + rk - 1) / rk;
+    const int chunks = d->N * d->OA * ((d->OB + 63) / 64);          // 64-position chunks of one (n, a) row
+    int splits = max(1, 2048 / (mt * kt));
+    const int min_chunks = (int64_t)mt * kt * (chunks / 32) >= 512 ? 32 : 8;
+    splits = min(splits, max(1, chunks / min_chunks));
+    w.total_tiles = chunks;
+    w.tiles_per_block = (chunks + splits - 1) / splits;
+    splits = (chunks + w.tiles_per_block - 1) / w.tiles_per_block;
+    w.kt = kt; w.mt = mt; w.splits = splits;
+    // every (k, m) tile of a position split re-reads the same g rows / input rows: group them behind one L2
+    static const int xcd_wide = getenv("RFX_WGRAD_XCD") ? atoi(getenv("RFX_WGRAD_XCD")) : 0;
+    w.xcd_grouped = xcd_wide > 0 && splits >= xcd_wide;
+    dim3 grid = w.xcd_grouped ? dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1) : dim3(kt, mt, splits);
+    return prec == 1 ? rfx_launch_wgrad_wide_bf3(w, shape, grid, s) : rfx_launch_wgrad_wide_bf16(w, shape, grid, s);
+  }
   const bool narrow = prec != 0 && d->M <= 32;            // 32 x (128 tk) tiles, waves 1 x 4 (see gemm_wgrad_bf3_kernel)
   // 96-row tiles (waves 1 x 4, three 32-row MFMA tiles each) when they pad M less than 128-row ones: M = 96, 192, 288
   const bool rows96 = prec != 0 && d->M > 64 && d->K > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;
