@@ -199,29 +199,48 @@ struct TileCtx {
 // issued TOGETHER, unconditionally (clamped row index) and under wave-uniform tests only: with `if (e.bias) v += e.bias[m]`
 // inside the per-element loop hipcc emitted one load + s_waitcnt vmcnt(0) per element, i.e. 16*R serial L2 round trips
 // (~40 us) per workgroup -- more than the whole K loop of the short-K layers.
+// FULL = false (persistent short-K kernel of gemm_tap.h): bias, residual, fused GLU store and statistics only -- the
+// launcher routes activations, the backward-of-activation mode and phase-merged stores to the tiled kernels, so those
+// paths (and their registers) are compiled out of the tile loop.
+// the per-row bias values of a lane (clamped row index; merged phases: bias per channel; fused GLU: rows interleaved
+// (2c, 2c+1) <-> channels (c, C+c))
 template <int R>
-__device__ __forceinline__ void fwd_epilogue_mid(const FwdArgs& g, const TileCtx& tc, f32x16 (&acc)[R]) {
+__device__ __forceinline__ void fwd_load_bias(const FwdArgs& g, int m0, int h, float (&bv)[R][16]) {
+  const rfx_gemm_desc& d = g.d;
+  const rfx_epilogue& e = g.e;
+#pragma unroll
+  for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int mc = m < d.M ? m : d.M - 1;
+      bv[mt][r] = e.bias[e.glu_out ? (mc & 1) * (d.M >> 1) + (mc >> 1) : (mc >> d.mg_log)];
+    }
+}
+
+template <int R, bool FULL = true>
+__device__ __forceinline__ void fwd_epilogue_mid(const FwdArgs& g, const TileCtx& tc, f32x16 (&acc)[R],
+                                                 const float (*pre)[16] = nullptr) {
   const rfx_gemm_desc& d = g.d;
   const rfx_epilogue& e = g.e;
   const int m0 = tc.m0, h = tc.h;
   {
     float bv[R][16];
     if (e.bias) {
+      if (pre) {                       // values loaded once by the caller (persistent kernel: no load inside the tile loop)
 #pragma unroll
-      for (int mt = 0; mt < R; ++mt)
+        for (int mt = 0; mt < R; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int mc = m < d.M ? m : d.M - 1;
-          // merged phases: bias per channel; fused GLU: rows interleaved (2c, 2c+1) <-> channels (c, C+c)
-          bv[mt][r] = e.bias[e.glu_out ? (mc & 1) * (d.M >> 1) + (mc >> 1) : (mc >> d.mg_log)];
-        }
+          for (int r = 0; r < 16; ++r) bv[mt][r] = pre[mt][r];
+      } else {
+        fwd_load_bias<R>(g, m0, h, bv);
+      }
 #pragma unroll
       for (int mt = 0; mt < R; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] += bv[mt][r];
     }
-    if (e.act != RFX_ACT_NONE && !e.bwd) {
+    if (FULL && e.act != RFX_ACT_NONE && !e.bwd) {
       if (e.act == RFX_ACT_PRELU) {
 #pragma unroll
         for (int mt = 0; mt < R; ++mt)
@@ -245,7 +264,7 @@ __device__ __forceinline__ void fwd_epilogue_mid(const FwdArgs& g, const TileCtx
 }
 
 // everything after the last K loop: residual / second activation / the store variants / statistics
-template <int R>
+template <int R, bool FULL = true>
 __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileCtx& tc, f32x16 (&acc)[R]) {
   const rfx_gemm_desc& d = g.d;
   const rfx_epilogue& e = g.e;
@@ -257,7 +276,7 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
   if (e.res)
     resp = e.res + (int64_t)n * e.res_ns + (int64_t)(a * d.out_sa + d.out_a0) * e.res_as +
            (int64_t)(b * d.out_sb + d.out_b0) * e.res_bs;
-  if (e.bwd) {
+  if (FULL && e.bwd) {
     // out = G * act'(pre);  gparam[m] += sum_j G * min(pre, 0)   (PReLU slope gradient).  Loads batched as above.
     float gin[R][16];                            // all incoming gradients in flight at once; slopes a channel tile at a time
 #pragma unroll
@@ -296,7 +315,7 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
     }
     return;
   }
-  if (d.mg_log) {
+  if (FULL && d.mg_log) {
     // phase-merged store (see rfx_gemm_desc.mg_*): row m = channel*G + phase, position index i on the merged axis ->
     // axis index i*G + phase + mg_off.  A lane's 4 consecutive rows (r & 3) are the 4 phases of one channel when G = 4:
     // consecutive output samples, and the 32 lanes cover 32 consecutive position indices -> full lines per wave.
@@ -351,7 +370,7 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
       for (int r = 0; r < 16; ++r) acc[mt][r] += rv[r];
     }
   }
-  if (e.act2 != RFX_ACT_NONE) {
+  if (FULL && e.act2 != RFX_ACT_NONE) {
 #pragma unroll
     for (int mt = 0; mt < R; ++mt)
 #pragma unroll

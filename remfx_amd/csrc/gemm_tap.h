@@ -253,8 +253,125 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_kernel(const FwdArgs g) {
   fwd_epilogue_store<R>(g, tc, acc);
 }
 
+// ---------------------------------------------------------------------------------
+// Short reductions (Kpad_t <= 64: at most 4 K steps -- 1x1 convolutions over <= 64 channels, the DConv bottleneck pairs).
+// These launches move far more bytes than they multiply and were LATENCY-bound in the tiled kernel above: a wave had one
+// 32-position tile (4 KB of output at 32 rows) per memory round trip and only 8-16 waves fit a CU -> 2.3-2.8 TB/s (layer
+// profile r02).  A first persistent version with the NEXT tile's gathers in flight did not help: hipcc drains
+// vmcnt(0) at the loop header / at the register hand-over, so every iteration still paid one full round trip.
+// This version raises the bytes per round trip instead: a wave owns NT consecutive 32-position tiles per iteration (all
+// their gathers are issued back to back, then the MFMAs, then 16 * NT stores per lane), workgroups are persistent over
+// position blocks (packed weights, tap table and bias are fetched once), one 32-row channel tile (R = 1).
+// ---------------------------------------------------------------------------------
+struct StreamGeo { int P, wave, lane, l31, h, m0, t0; uint32_t goff0, cs4, gstep, gwrap; int nk; };
+
+template <int MODE>
+__device__ __forceinline__ void stream_mma(const uint4* a_lds, int h, int l31, const float (&b)[8], f32x16& acc) {
+  if (MODE == 1) {
+    bf16x8 bh, bl;
+    split8(b, bh, bl);
+    const bf16x8 fh = __builtin_bit_cast(bf16x8, a_lds[h * 32 + l31]);
+    const bf16x8 fl = __builtin_bit_cast(bf16x8, a_lds[64 + h * 32 + l31]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lds[h * 32 + l31]), round8(b), acc, 0, 0, 0);
+  }
+}
+
+template <int MODE, int NT, int NKMAX>
+__global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g) {
+  constexpr int R = 1, BM = 32, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
+  __shared__ __attribute__((aligned(16))) uint4 smem[4 * CELLS + RFX_TAP_LDS];   // A of K steps 0..3; tap table
+  uint4* as = smem;
+  int4* taps = reinterpret_cast<int4*>(smem + 4 * CELLS);
+  const rfx_gemm_desc& d = g.d;
+  const int tid = threadIdx.x;
+  StreamGeo q;
+  q.wave = tid >> 6; q.lane = tid & 63; q.l31 = q.lane & 31; q.h = q.lane >> 5;
+  q.P = d.OA * d.OB;
+  const int mtiles = d.Mpad / BM;
+  const int ptiles = (q.P + 127) / 128;                          // 128-position tiles per sample
+  const int tiles = ptiles * d.N;                                // a block of NT consecutive tiles may span samples
+  const int work = (tiles + NT - 1) / NT;
+  const int ym = blockIdx.x % mtiles, w0 = blockIdx.x / mtiles, stride = gridDim.x / mtiles;
+  q.m0 = ym * BM;
+  q.nk = d.Kpad_t / 16;
+  q.cs4 = (uint32_t)(d.in_cs * 4);
+  q.gstep = 16u * q.cs4; q.gwrap = (uint32_t)d.gpt * 8u * q.cs4;
+  {
+    const uint4* apk = reinterpret_cast<const uint4*>(g.apack);
+    const int64_t arr_stride = (int64_t)(d.Kpad_t / 8 + 8) * d.Mpad;
+#pragma unroll
+    for (int ks = 0; ks < NKMAX; ++ks)                           // the packed matrix carries >= 4 zero K steps of padding
+      tap_a_store<R, MODE>(as + ks * CELLS, tid, tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2 * ks, q.m0, tid));
+    if (tid < d.ntaps + 16) taps[tid] = reinterpret_cast<const int4*>(g.ktab)[tid];
+  }
+  __syncthreads();
+  q.t0 = q.h / d.gpt;                                            // group g = h of K step 0
+  q.goff0 = (uint32_t)(q.h - q.t0 * d.gpt) * 8u * q.cs4;
+  float bias[1][16];
+  if (g.e.bias) fwd_load_bias<1>(g, q.m0, q.h, bias);
+
+  for (int pw = w0; pw < work; pw += stride) {                   // wave-uniform trip count
+    TileCtx tc[NT];
+    float b[NT][NKMAX][8];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int gt = pw * NT + nt;                               // global tile index, wave-uniform
+      const bool tv = gt < tiles;
+      const int n = tv ? gt / ptiles : 0;
+      const int j = (tv ? gt - n * ptiles : 0) * 128 + q.wave * 32 + q.l31;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.in + (int64_t)n * d.in_ns), 0,
+                                                                          (int)d.in_extent, 0x00020000);
+      tc[nt].n = n; tc[nt].pw = gt; tc[nt].m0 = q.m0; tc[nt].wave = q.wave; tc[nt].lane = q.lane;
+      tc[nt].l31 = q.l31; tc[nt].h = q.h;
+      tc[nt].jvalid = tv & (j < q.P);
+      const int jj = tc[nt].jvalid ? j : 0;
+      tc[nt].a = jj / d.OB;
+      tc[nt].b = jj - tc[nt].a * d.OB;
+      TapLane c;
+      const int ia0 = tc[nt].a * d.SA, ib0 = tc[nt].b * d.SB;
+      c.ia0 = tc[nt].jvalid ? ia0 : (1 << 30);
+      c.ib0 = ib0;
+      c.voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * 4);
+      c.rs = rs;
+      c.t = q.t0; c.goff = q.goff0;
+#pragma unroll
+      for (int ks = 0; ks < NKMAX; ++ks)
+        if (ks == 0 || ks < q.nk) gather8_tap(d, taps, q.cs4, q.gstep, q.gwrap, c, b[nt][ks]);     // wave-uniform
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x16 acc[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NKMAX; ++ks)
+        if (ks == 0 || ks < q.nk) stream_mma<MODE>(as + ks * CELLS, q.h, q.l31, b[nt][ks], acc[0]);
+      fwd_epilogue_mid<1, false>(g, tc[nt], acc, bias);
+      fwd_epilogue_store<1, false>(g, tc[nt], acc);
+    }
+  }
+}
+
 template <int MODE>
 static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s) {
+  // short single-phase reductions with enough position tiles to keep persistent workgroups busy: streaming kernel
+  static const int stream_off = getenv("RFX_GEMM_STREAM") ? !atoi(getenv("RFX_GEMM_STREAM")) : 0;   // RFX_GEMM_STREAM=0: A/B switch
+  const int64_t work = (int64_t)((g.d.OA * g.d.OB + 127) / 128) * g.d.N;
+  if (!stream_off && g.d.Kpad_t <= 64 && g.apack2 == nullptr && work >= 4096 && r == 1 && g.e.act == RFX_ACT_NONE &&
+      g.e.act2 == RFX_ACT_NONE && !g.e.bwd && g.d.mg_log == 0 && !g.e.res) {
+    const int mtiles = g.d.Mpad / 32;
+    int nw = 512 / mtiles;                                       // persistent workgroups per channel tile (2 per CU in all)
+    nw = nw < 1 ? 1 : nw;
+    dim3 sg((unsigned)(nw * mtiles));
+    if (g.d.Kpad_t <= 16) hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 4, 1>), sg, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 2, 4>), sg, dim3(256), 0, s, g);
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   switch (r) {
     case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, MODE>), grid, dim3(256), 0, s, g); break;
     case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, MODE>), grid, dim3(256), 0, s, g); break;
