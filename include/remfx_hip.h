@@ -258,6 +258,17 @@ int rfx_span_mask(float* x, int32_t R, int32_t F, int32_t T, const int32_t* f0, 
 /* sum |a-b| over n elements -> *out (+=, caller zeroes).  nn.L1Loss numerator, models.py:320 */
 int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream);
 
+/* ---- LocalState attention (torchaudio HDemucs `_LocalState` inside the DConv blocks, reached from models.py:319) ----
+ * q, k, cont: (B, heads*ch, T) contiguous, channel = head*ch + c; qd: (B, heads*nd, T) raw decay projections.
+ *   dots[t, s] = <k[:, t], q[:, s]> / sqrt(ch) - sum_f (f+1) |t-s| / sqrt(nd) * sigmoid(qd[f, s]) / 2;  dots[s, s] = -100
+ *   w = softmax over t (stored to w (B, heads, T, T) when non-NULL);  out[c, s] = sum_t w[t, s] cont[c, t]
+ * T <= 256, ch * T <= 12288, nd <= 8.  The backward returns the gradients of q, k, cont and the raw qd. */
+int rfx_localstate_fwd(const float* q, const float* k, const float* cont, const float* qd, int32_t B, int32_t heads,
+                       int32_t ch, int32_t T, int32_t nd, float* w, float* out, void* stream);
+int rfx_localstate_bwd(const float* q, const float* k, const float* cont, const float* qd, const float* w,
+                       const float* gout, int32_t B, int32_t heads, int32_t ch, int32_t T, int32_t nd, float* dq, float* dk,
+                       float* dcont, float* dqd, void* stream);
+
 /* ---- GroupNorm (+ fused activation) --------------------------------------------
  * x: (N, C, S) contiguous, G groups.  mode: 0 y = gn(x); 1 y = gelu(gn(x));
  * 2 y = glu(gn(x)) -> (N, C/2, S); 3 y = res + scale[c] * glu(gn(x))  (DConv tail).

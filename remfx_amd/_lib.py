@@ -133,6 +133,8 @@ SIGNATURES = {
     "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_l1_sum": [_P, _P, _I64, _P, _P],
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
+    "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_span_mask": [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_row_moments": [_P, _I32, _I64, _P, _P, _P, _P],
     "rfx_row_affine": [_P, _P, _P, _P, _I32, _I64, _P],

@@ -90,22 +90,12 @@ class _LocalState(nn.Module):
         self.proj = nn.Conv1d(channels, channels, 1)
 
     def forward(self, x):
-        B, C, T = x.shape
-        h = self.heads
-        idx = torch.arange(T, device=x.device, dtype=x.dtype)
-        delta = idx[:, None] - idx[None, :]
-        q = ops.conv1d(x, self.query.weight, self.query.bias).view(B, h, -1, T)
-        k = ops.conv1d(x, self.key.weight, self.key.bias).view(B, h, -1, T)
-        dots = nnops.einsum("bhct,bhcs->bhts", k, q) / math.sqrt(k.shape[2])
-        decays = torch.arange(1, self.ndecay + 1, device=x.device, dtype=x.dtype)
-        dq = torch.sigmoid(ops.conv1d(x, self.query_decay.weight, self.query_decay.bias).view(B, h, -1, T)) / 2
-        kern = -decays.view(-1, 1, 1) * delta.abs() / math.sqrt(self.ndecay)
-        dots = dots + nnops.einsum("fts,bhfs->bhts", kern, dq)
-        dots = dots.masked_fill(torch.eye(T, device=x.device, dtype=torch.bool), -100)
-        w = nnops.softmax(dots, dim=2)
-        c = ops.conv1d(x, self.content.weight, self.content.bias).view(B, h, -1, T)
-        res = nnops.einsum("bhts,bhct->bhcs", w, c).reshape(B, -1, T)
-        return x + ops.conv1d(res, self.proj.weight, self.proj.bias)
+        q = ops.conv1d(x, self.query.weight, self.query.bias)
+        k = ops.conv1d(x, self.key.weight, self.key.bias)
+        c = ops.conv1d(x, self.content.weight, self.content.bias)
+        qd = ops.conv1d(x, self.query_decay.weight, self.query_decay.bias)
+        res = nnops.local_state_attention(q, k, c, qd, self.heads, self.ndecay)
+        return nnops.add(x, ops.conv1d(res, self.proj.weight, self.proj.bias))
 
 
 class _DConv(nn.Module):

@@ -281,6 +281,44 @@ def row_affine(x, a, b):
     return _RowAffineFn.apply(x, a.contiguous(), b.contiguous())
 
 
+class _LocalStateFn(torch.autograd.Function):
+    """softmax_t(k^T q / sqrt(ch) + decay penalty, masked diagonal) applied to the content: one HIP launch per direction
+    (csrc/attention.hip) instead of two rocBLAS einsums, an ATen softmax and the (B, h, T, T) round trips."""
+
+    @staticmethod
+    def forward(ctx, q, k, cont, qd, heads, ndecay):
+        for t, n in ((q, "q"), (k, "k"), (cont, "content"), (qd, "query_decay")):
+            ops._req(t, n)
+        q, k, cont, qd = q.contiguous(), k.contiguous(), cont.contiguous(), qd.contiguous()
+        B, Ctot, T = q.shape
+        ch = Ctot // heads
+        out = torch.empty_like(q)
+        need_w = any(ctx.needs_input_grad[:4])
+        w = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32) if need_w else None
+        check(_lib.lib().rfx_localstate_fwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), B, heads, ch, T, ndecay, _ptr(w),
+                                            _ptr(out), _stream()), "rfx_localstate_fwd")
+        if need_w:
+            ctx.save_for_backward(q, k, cont, qd, w)
+        ctx.cfg = (B, heads, ch, T, ndecay)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, cont, qd, w = ctx.saved_tensors
+        B, heads, ch, T, ndecay = ctx.cfg
+        g = g.contiguous()
+        dq, dk, dc, dqd = torch.empty_like(q), torch.empty_like(k), torch.empty_like(cont), torch.empty_like(qd)
+        check(_lib.lib().rfx_localstate_bwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), _ptr(w), _ptr(g), B, heads, ch, T,
+                                            ndecay, _ptr(dq), _ptr(dk), _ptr(dc), _ptr(dqd), _stream()),
+              "rfx_localstate_bwd")
+        return dq, dk, dc, dqd, None, None
+
+
+def local_state_attention(q, k, content, query_decay, heads, ndecay):
+    """q, k, content: (B, heads*ch, T); query_decay: (B, heads*ndecay, T) raw projections -> (B, heads*ch, T)."""
+    return _LocalStateFn.apply(q, k, content, query_decay, heads, ndecay)
+
+
 def lstm(module, x):
     """module: nn.LSTM parameter container; x: (T, B, C)."""
     _interim("lstm")
