@@ -255,6 +255,14 @@ int rfx_row_affine(const float* x, const float* a, const float* b, float* out, i
 int rfx_span_mask(float* x, int32_t R, int32_t F, int32_t T, const int32_t* f0, const int32_t* f1, const int32_t* t0,
                   const int32_t* t1, void* stream);
 
+/* Overlapping-frame layout of the Hybrid Demucs BLSTM (torchaudio `_BLSTM`: sequences longer than 200 steps run as
+ * frames of `width` 200 at `stride` 100, the central parts are stitched back; reached from models.py:319).
+ * x: (B, C, T) contiguous; h: (C, width * Bn) with Bn = B * nfr, position t * Bn + b * nfr + k = step t of frame k of row b
+ * (the channel-major layout of rfx_lstm_fwd).  mode 0: h = frames of x (zero beyond T);  1: x = adjoint of mode 0 applied to h;
+ * 2: x = stitched central parts of h (+ skip[b][c][tau] when skip != NULL);  3: h = adjoint of mode 2 applied to x. */
+int rfx_blstm_frames(const float* src, const float* skip, float* dst, int32_t B, int32_t C, int32_t T, int32_t nfr,
+                     int32_t width, int32_t stride, int32_t mode, void* stream);
+
 /* sum |a-b| over n elements -> *out (+=, caller zeroes).  nn.L1Loss numerator, models.py:320 */
 int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream);
 

@@ -135,6 +135,7 @@ SIGNATURES = {
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_blstm_frames": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "rfx_span_mask": [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_row_moments": [_P, _I32, _I64, _P, _P, _P, _P],
     "rfx_row_affine": [_P, _P, _P, _P, _I32, _I64, _P],

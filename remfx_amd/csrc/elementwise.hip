@@ -330,6 +330,57 @@ extern "C" int rfx_span_mask(float* x, int32_t R, int32_t F, int32_t T, const in
   RFX_CHECK_LAUNCH();
   return 0;
 }
+// frame k of row b covers tau in [k*stride, k*stride + width); the stitched output takes tau from frame
+// k = clamp((tau - lim) / stride, 0, nfr - 1), lim = stride / 2 (first frame up to width - lim, last frame from lim on)
+__global__ void blstm_frames_kernel(const float* __restrict__ src, const float* __restrict__ skip, float* __restrict__ dst,
+                                    int B, int Cn, int T, int nfr, int width, int stride, int mode) {
+  const int Bn = B * nfr, lim = stride / 2;
+  const int64_t total = (mode == 0 || mode == 3) ? (int64_t)Cn * width * Bn : (int64_t)B * Cn * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (mode == 0 || mode == 3) {                      // destination h[c][t * Bn + b * nfr + k]
+      const int bk = (int)(i % Bn);
+      const int64_t r = i / Bn;
+      const int t = (int)(r % width), c = (int)(r / width);
+      const int b = bk / nfr, k = bk - b * nfr, tau = k * stride + t;
+      float v = 0.f;
+      if (tau < T) {
+        if (mode == 0) v = src[((int64_t)b * Cn + c) * T + tau];
+        else {
+          int ks = (tau - lim) / stride;
+          ks = tau < lim ? 0 : (ks > nfr - 1 ? nfr - 1 : ks);
+          if (ks == k) v = src[((int64_t)b * Cn + c) * T + tau];
+        }
+      }
+      dst[i] = v;
+    } else {                                           // destination x[b][c][tau]
+      const int tau = (int)(i % T);
+      const int64_t r = i / T;
+      const int c = (int)(r % Cn), b = (int)(r / Cn);
+      float v = 0.f;
+      if (mode == 2) {
+        int k = (tau - lim) / stride;
+        k = tau < lim ? 0 : (k > nfr - 1 ? nfr - 1 : k);
+        v = src[(int64_t)c * width * Bn + (int64_t)(tau - k * stride) * Bn + b * nfr + k];
+        if (skip) v += skip[i];
+      } else {
+        for (int k = 0; k < nfr; ++k) {
+          const int t = tau - k * stride;
+          if (t >= 0 && t < width) v += src[(int64_t)c * width * Bn + (int64_t)t * Bn + b * nfr + k];
+        }
+      }
+      dst[i] = v;
+    }
+  }
+}
+extern "C" int rfx_blstm_frames(const float* src, const float* skip, float* dst, int32_t B, int32_t Cn, int32_t T, int32_t nfr,
+                                int32_t width, int32_t stride, int32_t mode, void* stream) {
+  if (!src || !dst || B <= 0 || Cn <= 0 || T <= 0 || nfr <= 0 || width <= 0 || stride <= 0 || mode < 0 || mode > 3) return -1;
+  const int64_t total = (mode == 0 || mode == 3) ? (int64_t)Cn * width * B * nfr : (int64_t)B * Cn * T;
+  hipLaunchKernelGGL(blstm_frames_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, skip, dst, B, Cn, T,
+                     nfr, width, stride, mode);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv,
                                void* stream) {
   if (!x || !sums || !mean || !stdv || R <= 0 || L <= 1) return -1;

@@ -57,24 +57,16 @@ class _BLSTM(nn.Module):
 
     def forward(self, x):
         B, C, T = x.shape
-        y = x
-        framed = T > self.max_steps
-        if framed:
+        if T > self.max_steps:                       # overlapping frames of 200 steps at stride 100, central parts stitched
             width, stride = self.max_steps, self.max_steps // 2
             nfr = math.ceil(T / stride)
-            xp = F.pad(x, (0, (nfr - 1) * stride + width - T))
-            x = xp.unfold(-1, width, stride).permute(0, 2, 1, 3).reshape(-1, C, width)
-        Bn, _, W = x.shape
-        h = x.permute(1, 2, 0).reshape(1, C, W * Bn)                 # channel-major, position = t*Bn + b
-        h = lstm.blstm(self.lstm, h, W, Bn)
+        else:
+            width, stride, nfr = T, T, 1
+        Bn = B * nfr
+        h = nnops.blstm_frame(x, nfr, width, stride)                 # (1, C, width * Bn): position = t * Bn + b * nfr + k
+        h = lstm.blstm(self.lstm, h, width, Bn)
         h = ops.conv1d(h, self.linear.weight.unsqueeze(-1), self.linear.bias)
-        x = h.view(C, W, Bn).permute(2, 0, 1)
-        if framed:
-            fr = x.reshape(B, nfr, C, width)
-            lim = stride // 2
-            parts = [fr[:, 0, :, :-lim]] + [fr[:, k, :, lim:-lim] for k in range(1, nfr - 1)] + [fr[:, nfr - 1, :, lim:]]
-            x = torch.cat(parts, -1)[..., :T]
-        return x + y if self.skip else x
+        return nnops.blstm_unframe(h, x if self.skip else None, B, T, nfr, width, stride)
 
 
 class _LocalState(nn.Module):

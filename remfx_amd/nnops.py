@@ -319,6 +319,60 @@ def local_state_attention(q, k, content, query_decay, heads, ndecay):
     return _LocalStateFn.apply(q, k, content, query_decay, heads, ndecay)
 
 
+class _BlstmFrameFn(torch.autograd.Function):
+    """(B, C, T) -> channel-major overlapping frames (1, C, width * B * nfr); rfx_blstm_frames modes 0 / 1."""
+
+    @staticmethod
+    def forward(ctx, x, nfr, width, stride):
+        ops._req(x, "x")
+        x = x.contiguous()
+        B, Cc, T = x.shape
+        h = torch.empty((1, Cc, width * B * nfr), device=x.device, dtype=torch.float32)
+        check(_lib.lib().rfx_blstm_frames(_ptr(x), None, _ptr(h), B, Cc, T, nfr, width, stride, 0, _stream()), "rfx_blstm_frames")
+        ctx.cfg = (B, Cc, T, nfr, width, stride)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cc, T, nfr, width, stride = ctx.cfg
+        dx = torch.empty((B, Cc, T), device=g.device, dtype=torch.float32)
+        check(_lib.lib().rfx_blstm_frames(_ptr(g.contiguous()), None, _ptr(dx), B, Cc, T, nfr, width, stride, 1, _stream()),
+              "rfx_blstm_frames")
+        return dx, None, None, None
+
+
+class _BlstmUnframeFn(torch.autograd.Function):
+    """frames (1, C, width * B * nfr) -> stitched (B, C, T) [+ skip]; rfx_blstm_frames modes 2 / 3."""
+
+    @staticmethod
+    def forward(ctx, h, skip, B, T, nfr, width, stride):
+        ops._req(h, "h")
+        h = h.contiguous()
+        Cc = h.shape[1]
+        out = torch.empty((B, Cc, T), device=h.device, dtype=torch.float32)
+        sk = skip.contiguous() if skip is not None else None
+        check(_lib.lib().rfx_blstm_frames(_ptr(h), _ptr(sk), _ptr(out), B, Cc, T, nfr, width, stride, 2, _stream()),
+              "rfx_blstm_frames")
+        ctx.cfg = (B, Cc, T, nfr, width, stride, skip is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cc, T, nfr, width, stride, has_skip = ctx.cfg
+        g = g.contiguous()
+        dh = torch.empty((1, Cc, width * B * nfr), device=g.device, dtype=torch.float32)
+        check(_lib.lib().rfx_blstm_frames(_ptr(g), None, _ptr(dh), B, Cc, T, nfr, width, stride, 3, _stream()), "rfx_blstm_frames")
+        return dh, (g if has_skip else None), None, None, None, None, None
+
+
+def blstm_frame(x, nfr, width, stride):
+    return _BlstmFrameFn.apply(x, nfr, width, stride)
+
+
+def blstm_unframe(h, skip, B, T, nfr, width, stride):
+    return _BlstmUnframeFn.apply(h, skip, B, T, nfr, width, stride)
+
+
 def lstm(module, x):
     """module: nn.LSTM parameter container; x: (T, B, C)."""
     _interim("lstm")

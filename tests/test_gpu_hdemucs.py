@@ -103,3 +103,30 @@ def test_hdemucs_decoder_groupnorm_sees_cropped_border():
         assert zd.shape == z.shape
         assert _rms(wrong, z) > 3e-3, "test input does not separate the two orderings"
         check(_rms(zd.cpu(), z), 1e-5, max(1.0, float(z.abs().max())), what=(freq, _rms(zd.cpu(), z)))
+
+
+@pytest.mark.parametrize("T", [256, 130, 201])
+def test_blstm_overlapping_frames(T):
+    """torchaudio `_BLSTM`: sequences longer than 200 steps run as frames of 200 at stride 100 and the central parts are
+    stitched back.  Forward and all gradients against the oracle, at the frame count of the headline config (T = 256 -> 3
+    frames), the unframed case and the shortest framed one."""
+    from oracle import ref_hdemucs
+    from remfx_amd import hdemucs
+    torch.manual_seed(11)
+    ref = ref_hdemucs.BLSTM(32, layers=2, skip=True)
+    net = hdemucs._BLSTM(32, layers=2, skip=True)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(3, 32, T, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = ref(xr)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = net(xd)
+    yd.backward(gy.to(DEV))
+    check(_rms(yd.detach().cpu(), y.detach()), 1e-5, max(1.0, float(y.detach().abs().max())))
+    check(_rms(xd.grad.cpu(), xr.grad), 2e-5, max(1.0, float(xr.grad.abs().max())))
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        check(_rms(p.grad.cpu(), q.grad), 1e-4, max(1e-3, float(q.grad.abs().max())), what=n)
