@@ -269,6 +269,9 @@ def main():
                     choices=["demucs", "tcn", "dcunet", "umx", "chain", "demucs_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--union-ranks", type=int, default=0,
+                    help="single process only: train on the concatenation of the synthetic batches ranks 0..N-1 would "
+                         "get (N x --batch clips) -- the reference point of the data-parallel equivalence test")
     ap.add_argument("--gemm", default=os.environ.get("RFX_GEMM_PREC", "bf16"), choices=["bf16", "bf16x3", "f32"],
                     help="MFMA arithmetic of the gather-GEMMs.  bf16 (default): operands rounded to bf16, fp32 accumulation -- "
                          "trainer.precision=bf16-mixed, the precision BASELINE.json's headline config names; bf16x3: fp32 "
@@ -299,6 +302,9 @@ def main():
     ddp.broadcast_parameters(opt.flat.data)
     sync = ddp.GradSync(opt.flat)
     data = synthetic_batch(batch, rank, device)
+    if args.union_ranks > 1:
+        parts = [synthetic_batch(batch, r, device) for r in range(args.union_ranks)]
+        data = tuple(torch.cat([p[i] for p in parts], 0) for i in range(4))
     timer = KernelTimer()
     timer.install()
 
@@ -366,7 +372,11 @@ def main():
                                 "umx": "Open-Unmix (cfg/model/umx.yaml) train step, +exp=distortion model=umx"}[args.workload],
                    "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
                    "step": "fwd + MRSTFT+100*L1 loss + bwd + clip 10 + AdamW + per-step metrics",
-                   "parallelism": f"dp{world}", "final_loss": round(float(loss.detach()), 5)},
+                   "parallelism": f"dp{world}", "final_loss": round(float(loss.detach()), 5),
+                   # data-parallel bookkeeping: collective backend ("nccl" = RCCL over xGMI) and a checksum of the
+                   # parameters after the timed steps (equal across replicas; tests compare it with a 1-rank run)
+                   "dist_backend": torch.distributed.get_backend() if world > 1 else None, "ranks": world,
+                   "param_abs_sum": float(opt.flat.data.double().abs().sum())},
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_TFLOPS, 4),

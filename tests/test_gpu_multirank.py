@@ -1,0 +1,45 @@
+"""GPU: the data-parallel path with real kernels under it.  Two ranks run `bench.py --gpus 2` through torch.distributed.run
+-- over RCCL when two devices are visible, otherwise both ranks on device 0 with the gloo backend (RFX_FORCE_DEVICE test
+hook) -- so the flat-buffer bucketed all-reduce overlaps a backward pass that contains the wave-cluster LSTM kernels,
+whose inter-workgroup spins assume co-residency.  Checked: no spin time-out (bench.py raises on the flag), finite loss,
+and parameters after the steps equal to a 1-rank run on the union of the two ranks' clips (mean of per-rank mean losses =
+mean over the union; the reference has no multi-GPU path of its own, cfg/config.yaml:118)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.one_mode]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(out):
+    for line in reversed(out.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError(out[-3000:])
+
+
+def test_two_ranks_match_union_batch():
+    common = ["--steps", "2", "--warmup", "1", "--batch", "2", "--workload", "demucs", "--no-cpu-baseline", "--gemm", "bf16x3"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    two_dev = torch.cuda.device_count() >= 2
+    if not two_dev:
+        env.update(RFX_FORCE_DEVICE="0", RFX_DIST_BACKEND="gloo")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+                        + common, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    two = _json_line(r2.stdout)
+    assert two["n_gpus"] == 2 and two["config"]["ranks"] == 2
+    assert two["config"]["dist_backend"] == ("nccl" if two_dev else "gloo")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--union-ranks", "2"] + common,
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ))
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    one = _json_line(r1.stdout)
+    a, b = two["config"]["param_abs_sum"], one["config"]["param_abs_sum"]
+    assert a > 0 and abs(a - b) < 2e-6 * b, (a, b)          # AdamW steps of 1e-4 on ~8e7 parameters: a wrong average moves it by > 1e-5
+    assert torch.isfinite(torch.tensor(two["config"]["final_loss"]))
