@@ -110,3 +110,33 @@ def test_losses_basic():
     b = ref_losses.sisdr_loss(3.0 * x, y)
     assert a.item() == pytest.approx(b.item(), rel=1e-4)
     assert ref_losses.sisdr_loss(y, y).item() < -60
+
+
+def test_resample_oracle_properties():
+    """oracle/ref_resample.py (torchaudio's sinc_interp_hann, unpinned): a sinusoid well below both Nyquist rates comes
+    out as the same sinusoid sampled at the new rate (away from the zero-padded edges), equal rates are the identity and
+    the length is ceil(new * L / orig)."""
+    import math
+    from oracle import ref_resample
+    for orig, new in ((44100, 48000), (48000, 16000), (22050, 48000)):
+        L = 2000
+        t = torch.arange(L) / orig
+        x = torch.sin(2 * math.pi * 440.0 * t)[None]
+        y = ref_resample.resample(x, orig, new)
+        n = math.ceil(new // math.gcd(orig, new) * L / (orig // math.gcd(orig, new)))
+        assert y.shape == (1, n)
+        want = torch.sin(2 * math.pi * 440.0 * torch.arange(n) / new)[None]
+        mid = slice(n // 8, n - n // 8)
+        assert float((y[:, mid] - want[:, mid]).abs().max()) < 2e-3, (orig, new)
+    assert ref_resample.resample(x, 48000, 48000) is x
+
+
+def test_resample_table_matches_oracle_filter():
+    """The product's host-built filter bank (remfx_amd/resample.py, vectorised) against the oracle's per-phase loop."""
+    from oracle import ref_resample
+    from remfx_amd import resample
+    for orig, new in ((44100, 48000), (48000, 16000), (3, 2)):
+        kern, width, o, n = resample.sinc_kernel(orig, new)
+        ref, w = ref_resample._filter(o, n)
+        assert width == w and kern.shape == ref.shape
+        assert float((kern - ref).abs().max()) < 1e-7
