@@ -214,11 +214,13 @@ int rfx_lstm_ws_bytes(int32_t H);
 int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stream);
 /* xp [2][4H][P]; pack = both directions; out [2H][P] (forward dir rows 0..H-1, reverse H..2H-1);
  * gates [2][4H][P] and cstate [2][H][P] are saved for the backward sweep (both NULL for inference). */
+/* prec: RFX_PREC_BF16 = h and W_hh rounded to bf16 (one MFMA per product: bf16-mixed); any other value = the bf16x3
+ * split (fp32-grade products; also what the exact-fp32 GEMM mode uses for the recurrence). */
 int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_t Bn, int32_t H, float* out, float* gates,
-                 float* cstate, void* ws, void* stream);
+                 float* cstate, void* ws, int32_t prec, void* stream);
 /* gout [2H][P] -> dG [2][4H][P], the gradients of the gate pre-activations. */
 int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
-                 int32_t Bn, int32_t H, float* dG, void* ws, void* stream);
+                 int32_t Bn, int32_t H, float* dG, void* ws, int32_t prec, void* stream);
 
 /* ---- elementwise / reductions ------------------------------------------------ */
 /* y = act(x) elementwise over n contiguous floats; PReLU/bias not supported here. */

@@ -142,8 +142,8 @@ SIGNATURES = {
     "rfx_lstm_pack_bytes": [_I32],
     "rfx_lstm_pack": [_P, _I32, _P, _P],
     "rfx_lstm_ws_bytes": [_I32],
-    "rfx_lstm_fwd": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
-    "rfx_lstm_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P],
+    "rfx_lstm_fwd": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P],
+    "rfx_lstm_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _P],
     "rfx_channel_sum": [_P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _P, _P],
 }
 

@@ -153,7 +153,9 @@ __device__ __forceinline__ void lstm_fetch_lds(const uint64_t* src, int n, int l
 // (55 instead of 32 cycles per MFMA, in-kernel s_memtime stamps).  Fully unrolled, its wait counts are exact (24-32 loads
 // stay in flight) -- provided the fragment base pointer is made opaque once per time step (otherwise ~100 hoisted
 // addresses spill) and keeps its global address space (a laundered generic pointer turns every load into flat_load).
-template <int D, int NKS>
+// LO = true: bf16x3 split products (hi.hi + hi.lo + lo.hi); false: bf16 operands only (the bf16-mixed mode: a third of the
+// MFMA chain and half of the weight stream per step).
+template <int D, int NKS, bool LO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_kernel(const LstmArgs a) {
   int cluster, ub;
   if (!lstm_ids(a, cluster, ub)) return;
@@ -183,24 +185,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int g = 0; g < 4; ++g) {
       // wave-uniform base + zero-extended lane offset -> scalar-base addressing (no per-fragment 64-bit VGPR address)
       f.h[g] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Ahi + (g * nks + ks) * 64) + lane16));
-      f.l[g] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Alo + (g * nks + ks) * 64) + lane16));
+      if (LO) f.l[g] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Alo + (g * nks + ks) * 64) + lane16));
     }
   };
   auto loadB = [&](bf16x8& bh, bf16x8& bl, int ks) {
     bh = *reinterpret_cast<const bf16x8*>(lstm_smem + ks * 2048 + lane * 16);
-    bl = *reinterpret_cast<const bf16x8*>(lstm_smem + ks * 2048 + 1024 + lane * 16);
+    if (LO) bl = *reinterpret_cast<const bf16x8*>(lstm_smem + ks * 2048 + 1024 + lane * 16);
   };
   // the four gate accumulators are independent: issue them round-robin so no MFMA waits on its predecessor
   auto mma = [&](f32x16* acc, const LstmAFrag& f, const bf16x8 bh, const bf16x8 bl) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[g]), bh, acc[g], 0, 0, 0);
+    if (LO) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[g]), bl, acc[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[g]), bl, acc[g], 0, 0, 0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.l[g]), bh, acc[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.l[g]), bh, acc[g], 0, 0, 0);
+    }
   };
   float c[16];
 #pragma unroll
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // consumer's slice is H/32 x 4 KB, contiguous, fetched straight into LDS.
 // TPC = unit-block tiles per ring refill round: the weight ring holds 8*TPC k-step fragments (hi, lo); 16 in flight
 // cover the L2 round trip (3 MFMAs per fragment), so TPC = 2 whenever H/32 is even.
-template <int TPC, int NWC>        // NWC = H/32 at compile time (0 = runtime), as NKS in the forward kernel
+template <int TPC, int NWC, bool LO>        // NWC = H/32 at compile time (0 = runtime), as NKS in the forward kernel; LO as there
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(const LstmArgs a) {
   int cluster, ub;
   if (!lstm_ids(a, cluster, ub)) return;
@@ -440,19 +444,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
           for (int tp = 0; tp < TPC; ++tp)
             acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[tp * 8 + kk]), Bh, acc[tp], 0, 0, 0);
+          if (LO) {
 #pragma unroll
-          for (int tp = 0; tp < TPC; ++tp)
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[tp * 8 + kk]), Bl, acc[tp], 0, 0, 0);
+            for (int tp = 0; tp < TPC; ++tp)
+              acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[tp * 8 + kk]), Bl, acc[tp], 0, 0, 0);
 #pragma unroll
-          for (int tp = 0; tp < TPC; ++tp)
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl[tp * 8 + kk]), Bh, acc[tp], 0, 0, 0);
+            for (int tp = 0; tp < TPC; ++tp)
+              acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl[tp * 8 + kk]), Bh, acc[tp], 0, 0, 0);
+          }
 #pragma unroll
           for (int tp = 0; tp < TPC; ++tp) {
             const int i = tp * 8 + kk;
             int fn = f0 + i + RING;                                 // the slot's next occupant (wraps into the next step)
             fn = fn >= F ? fn - F : fn;
             wh[i] = __builtin_bit_cast(uint4, Ahi[frag_index(fn)]);
-            wl[i] = __builtin_bit_cast(uint4, Alo[frag_index(fn)]);
+            if (LO) wl[i] = __builtin_bit_cast(uint4, Alo[frag_index(fn)]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -505,8 +511,8 @@ static int lstm_max_clusters(int H) {
   int dev = 0, ncu = 0, occ_f = 0, occ_b = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_fwd_kernel<4, 0>, 64, lstm_smem_bytes(H)) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bwd_kernel<2, 0>, 64, lstm_smem_bytes(H)) != hipSuccess)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_fwd_kernel<4, 0, true>, 64, lstm_smem_bytes(H)) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bwd_kernel<2, 0, true>, 64, lstm_smem_bytes(H)) != hipSuccess)
     return 0;
   const int occ = occ_f < occ_b ? occ_f : occ_b;
   int waves = ncu * occ;
@@ -563,21 +569,28 @@ static int lstm_launch(K kernel, LstmArgs a, void* ws, void* stream) {
 }
 
 extern "C" int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_t Bn, int32_t H, float* out,
-                            float* gates, float* cstate, void* ws, void* stream) {
+                            float* gates, float* cstate, void* ws, int32_t prec, void* stream) {
   if (!xp || !pack || !out || !ws || T <= 0 || Bn <= 0 || lstm_bad_h(H)) return -1;
   if ((gates == nullptr) != (cstate == nullptr)) return -1;
   if ((int64_t)4 * H * T * Bn >= ((int64_t)1 << 31)) return -1;
   LstmArgs a{};
   a.xp = xp; a.packA = reinterpret_cast<const uint4*>(pack); a.out = out; a.gates = gates; a.cstate = cstate;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
-  if (H == 192) return lstm_launch(lstm_fwd_kernel<4, 12>, a, ws, stream);     // HDemucs DConv widths and Open-Unmix: unrolled k loop
-  if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16>, a, ws, stream);
-  if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24>, a, ws, stream);
-  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0>, a, ws, stream) : lstm_launch(lstm_fwd_kernel<2, 0>, a, ws, stream);
+  if (prec == RFX_PREC_BF16) {                 // bf16 operands (bf16-mixed): no lo fragments
+    if (H == 192) return lstm_launch(lstm_fwd_kernel<4, 12, false>, a, ws, stream);
+    if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16, false>, a, ws, stream);
+    if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24, false>, a, ws, stream);
+    return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0, false>, a, ws, stream)
+                       : lstm_launch(lstm_fwd_kernel<2, 0, false>, a, ws, stream);
+  }
+  if (H == 192) return lstm_launch(lstm_fwd_kernel<4, 12, true>, a, ws, stream);     // HDemucs DConv widths and Open-Unmix: unrolled k loop
+  if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16, true>, a, ws, stream);
+  if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24, true>, a, ws, stream);
+  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0, true>, a, ws, stream) : lstm_launch(lstm_fwd_kernel<2, 0, true>, a, ws, stream);
 }
 
 extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
-                            int32_t Bn, int32_t H, float* dG, void* ws, void* stream) {
+                            int32_t Bn, int32_t H, float* dG, void* ws, int32_t prec, void* stream) {
   if (!gout || !pack || !gates || !cstate || !dG || !ws || T <= 0 || Bn <= 0 || lstm_bad_h(H)) return -1;
   if ((int64_t)4 * H * T * Bn >= ((int64_t)1 << 31)) return -1;
   LstmArgs a{};
@@ -585,5 +598,8 @@ extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* ga
   a.cstate = const_cast<float*>(cstate); a.dG = dG;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
   // (the unrolled NWC forms of the backward kernel spill at 512 registers: only the runtime form is instantiated)
-  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1, 0>, a, ws, stream);
+  if (prec == RFX_PREC_BF16)
+    return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, false>, a, ws, stream)
+                             : lstm_launch(lstm_bwd_kernel<1, 0, false>, a, ws, stream);
+  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, true>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1, 0, true>, a, ws, stream);
 }

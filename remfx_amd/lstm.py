@@ -86,8 +86,9 @@ class _LSTMLayerFn(torch.autograd.Function):
         gates = torch.empty((2, 4 * H, P), device=x.device, dtype=torch.float32) if need else None
         cst = torch.empty((2, H, P), device=x.device, dtype=torch.float32) if need else None
         check(_lib.lib().rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), _ptr(gates), _ptr(cst),
-                                      _ptr(_workspace(x.device, H)), _stream()),
+                                      _ptr(_workspace(x.device, H)), ops.GEMM_PREC, _stream()),
               "rfx_lstm_fwd")
+        ctx.prec = ops.GEMM_PREC
         if need:
             ctx.save_for_backward(x, wcat, pack, gates, cst, out)
             ctx.dims = (T, Bn, H, Cin)
@@ -101,7 +102,7 @@ class _LSTMLayerFn(torch.autograd.Function):
         g = g.contiguous()
         dG = torch.empty((1, 8 * H, 1, P), device=g.device, dtype=torch.float32)
         check(_lib.lib().rfx_lstm_bwd(_ptr(g), _ptr(pack), _ptr(gates), _ptr(cst), T, Bn, H, _ptr(dG),
-                                      _ptr(_workspace(g.device, H)), _stream()),
+                                      _ptr(_workspace(g.device, H)), ctx.prec, _stream()),
               "rfx_lstm_bwd")
         x4 = x.unsqueeze(2)
         dx = None

@@ -23,10 +23,16 @@ def main(argv=None):
     model = rcfg.instantiate(cfg["model"])
     logger = rcfg.instantiate(cfg["logger"]) if "logger" in cfg else None
     trainer = rcfg.instantiate(cfg["trainer"], callbacks=[], logger=logger)
-    metrics = trainer.fit(model=model, datamodule=datamodule,
+    # `+ckpt_path=...` resumes (weights, AdamW moments, scheduler, counters); the reference's own ckpt_path branch
+    # (scripts/train.py:19-30) discards what it loads
+    metrics = trainer.fit(model=model, datamodule=datamodule, ckpt_path=cfg.get("ckpt_path"),
                           ckpt_dir=os.path.join(cfg.get("logs_dir", "./logs"), "ckpts"))
     if trainer.rank == 0:
         print({k: round(float(v), 5) for k, v in metrics.items()})
+    if cfg.get("test_after_fit", True):                     # scripts/train.py:55: trainer.test(..., ckpt_path="best")
+        out = trainer.test(model=model, datamodule=datamodule, ckpt_path="best")
+        if trainer.rank == 0:
+            print({k: round(float(v), 5) for k, v in out[0].items()})
     return metrics
 
 

@@ -16,11 +16,12 @@ def test_train_script_tcn_two_steps(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train.py"), "+exp=reverb",
                         "model.network.nblocks=3", "model.network.channel_width=16", "chunk_size=16384",
                         "datamodule.train_batch_size=2", "datamodule.train_dataset.total_chunks=4",
-                        "datamodule.val_dataset.total_chunks=2", "trainer.max_steps=2", f"logs_dir={tmp_path}"],
+                        "datamodule.val_dataset.total_chunks=2", "datamodule.test_dataset.total_chunks=2", "trainer.max_steps=2",
+                        f"logs_dir={tmp_path}"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert "train_loss" in r.stdout and "valid_loss" in r.stdout
-    ck = torch.load(os.path.join(tmp_path, "ckpts", "last.ckpt"), map_location="cpu")
+    assert "train_loss" in r.stdout and "valid_loss" in r.stdout and "test_loss" in r.stdout
+    ck = torch.load(os.path.join(tmp_path, "ckpts", "last.ckpt"), map_location="cpu", weights_only=False)
     assert "state_dict" in ck and "model.model.process_blocks.0.conv1.weight" in ck["state_dict"]
     assert os.path.exists(os.path.join(tmp_path, "csv", "metrics.csv"))
 
@@ -60,3 +61,42 @@ def test_chain_inference_script_small(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     for k in ("test_loss", "test_SISDR", "test_STFT", "Input_SISDR", "Input_STFT"):
         assert k in r.stdout, k
+
+
+@pytest.mark.one_mode
+def test_train_script_umx_config1(tmp_path):
+    """BASELINE config 1 (`+exp=distortion model=umx`, 4 clips, one train step) through scripts/train.py.  The reference
+    runs it on the CPU (`accelerator=null`); this build has no CPU compute path by design, so the same command line runs
+    with accelerator=gpu."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train.py"), "+exp=distortion", "model=umx",
+                        "accelerator=gpu", "chunk_size=32768", "datamodule.train_batch_size=4",
+                        "datamodule.train_dataset.total_chunks=4", "datamodule.val_dataset.total_chunks=2",
+                        "datamodule.test_dataset.total_chunks=2", "trainer.max_steps=1", f"logs_dir={tmp_path}"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "train_loss" in r.stdout and "valid_loss" in r.stdout
+    ck = torch.load(os.path.join(tmp_path, "ckpts", "last.ckpt"), map_location="cpu", weights_only=False)
+    assert ck["global_step"] == 1 and len(ck["optimizer_states"]) == 1 and len(ck["lr_schedulers"]) == 1
+    assert any(k.startswith("model.separator.") for k in ck["state_dict"])          # duplicate registration, as upstream
+
+
+@pytest.mark.one_mode
+def test_train_script_demucs_bf16_mixed_config3(tmp_path):
+    """BASELINE config 3's command line (`+exp=chorus_aug model=demucs trainer.precision=bf16-mixed`), reduced width and
+    clip length: the trainer switches the GEMMs to bf16 operands, trains two steps, resumes from its own checkpoint."""
+    base = [sys.executable, os.path.join(ROOT, "scripts", "train.py"), "+exp=chorus_aug", "model=demucs",
+            "trainer.precision=bf16-mixed", "model.network.channels=8", "chunk_size=32768", "datamodule.train_batch_size=2",
+            "datamodule.train_dataset.total_chunks=4", "datamodule.val_dataset.total_chunks=2",
+            "datamodule.test_dataset.total_chunks=2", f"logs_dir={tmp_path}"]
+    r = subprocess.run(base + ["trainer.max_steps=2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "train_loss" in r.stdout
+    ck = torch.load(os.path.join(tmp_path, "ckpts", "last.ckpt"), map_location="cpu", weights_only=False)
+    assert ck["global_step"] == 2
+    st = ck["optimizer_states"][0]["state"]
+    assert float(st[0]["step"]) == 2.0 and st[0]["exp_avg"].abs().sum() > 0
+    r = subprocess.run(base + ["trainer.max_steps=3", "+ckpt_path=" + os.path.join(tmp_path, "ckpts", "last.ckpt")],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    ck2 = torch.load(os.path.join(tmp_path, "ckpts", "last.ckpt"), map_location="cpu", weights_only=False)
+    assert ck2["global_step"] == 3 and float(ck2["optimizer_states"][0]["state"][0]["step"]) == 3.0      # one more step, not three
