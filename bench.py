@@ -61,11 +61,13 @@ def synthetic_batch(batch, rank, device, clip=CLIP):
 
 
 class KernelTimer:
-    """HIP-event timing of the dominant kernel family (gather-GEMM launches) on the stream
-    they are launched on; also accumulates their algorithmic FLOPs (2*M*K*positions*N)."""
+    """HIP-event timing of the dominant kernel family (forward-family gather-GEMM launches: conv forward, input
+    gradients, transposed convs, linear layers) on the stream they are launched on, with the algorithmic FLOPs
+    (2*M*K*positions*N) and bytes (every distinct input element / weight read once, every output written once) of each
+    launch, so that every launch can be priced against the roofline that binds IT (ridge = peak FLOP/s / peak B/s)."""
 
     def __init__(self):
-        self.events, self.flops, self.bytes, self.enabled = [], 0.0, 0.0, False
+        self.launches, self.enabled = [], False          # (start, end, flops, bytes)
 
     def install(self):
         from remfx_amd import ops
@@ -81,18 +83,23 @@ class KernelTimer:
             e.record()
             p = dp.p
             k = p.extra["n_weight_rows"] + (kw["dp2"].p.extra["n_weight_rows"] if kw.get("dp2") is not None else 0)
-            timer.flops += 2.0 * p.M * k * p.OA * p.OB * p.N
-            # algorithmic bytes: every distinct input element / weight read once, every output written once
-            timer.bytes += 4.0 * (x.numel() + out.numel() + p.M * k)
-            timer.events.append((s, e))
+            extra = sum(t.numel() for t in (kw.get("res"), kw.get("glu_out")) if t is not None)
+            timer.launches.append((s, e, 2.0 * p.M * k * p.OA * p.OB * p.N, 4.0 * (x.numel() + out.numel() + p.M * k + extra)))
             return r
         ops.gemm_fwd = timed
         import remfx_amd.tcn as tcn_mod
         tcn_mod.ops.gemm_fwd = timed
 
-    def result(self):
-        ms = sum(s.elapsed_time(e) for s, e in self.events)
-        return ms, len(self.events)
+    def result(self, peak_tflops, peak_gbs):
+        """Totals + the split of the family into MFMA-bound and HBM-bound launches (by each launch's own arithmetic
+        intensity against the ridge point of the mode's peaks)."""
+        ridge = peak_tflops * 1e12 / (peak_gbs * 1e9)
+        cls = {"mfma": [0.0, 0.0, 0.0, 0], "hbm": [0.0, 0.0, 0.0, 0]}        # ms, flops, bytes, launches
+        for s, e, fl, by in self.launches:
+            c = cls["mfma" if fl / by >= ridge else "hbm"]
+            c[0] += s.elapsed_time(e); c[1] += fl; c[2] += by; c[3] += 1
+        ms = cls["mfma"][0] + cls["hbm"][0]
+        return ms, len(self.launches), cls, ridge
 
 
 def _host_cpu():
@@ -342,24 +349,35 @@ def main():
     if rank != 0:
         return
     audio_s = world * batch * CLIP / SR * args.steps
-    kms, klaunches = timer.result()
-    achieved = timer.flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
     # algorithmic (fp32-equivalent) FLOP/s; in bf16x3 mode the matrix pipe executes 3x that in bf16
     peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[args.gemm]
     kname = {"f32": "gemm_fwd_kernel<R> (gather-GEMM, v_mfma_f32_32x32x2_f32)",
-             "bf16x3": "gemm_tap_kernel<R,1> (tap-major gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per 16-deep K step)",
-             "bf16": "gemm_tap_kernel<R,2> (tap-major gather-GEMM, 1 x v_mfma_f32_32x32x16_bf16 per 16-deep K step)"}[args.gemm]
-    # roofline.traffic: HBM bytes per launch of the dominant kernel family from the committed PMC passes
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command, scripts/collect_pmc.py)
+             "bf16x3": "gemm_tap_kernel<R,1> + gemm_tap_stream_kernel<1,..> (tap-major gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per K step)",
+             "bf16": "gemm_tap_kernel<R,2> + gemm_tap_stream_kernel<2,..> (tap-major gather-GEMM, 1 x v_mfma_f32_32x32x16_bf16 per K step)"}[args.gemm]
+    kms, klaunches, cls, ridge = timer.result(peak, PEAK_HBM_GBS)
+    tot_fl = cls["mfma"][1] + cls["hbm"][1]
+    tot_by = cls["mfma"][2] + cls["hbm"][2]
+    f_mfma = tot_fl / (kms * 1e-3) / 1e12 / peak if kms > 0 else 0.0
+    f_hbm = tot_by / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS if kms > 0 else 0.0
+    bound = "hbm" if f_hbm >= f_mfma else "mfma"
+
+    def _cls(name):
+        ms, fl, by, n = cls[name]
+        if not n:
+            return {"launches": 0}
+        return {"launches": n, "ms_per_step": round(ms / args.steps, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                "gbs": round(by / (ms * 1e-3) / 1e9, 1),
+                "frac": round((fl / (ms * 1e-3) / 1e12 / peak) if name == "mfma" else (by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS), 4)}
+    # roofline.traffic: HBM bytes per launch of the family from the committed PMC passes of this same command
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, scripts/collect_pmc.py)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", f"r02_demucs_b64_pmc_traffic_{args.gemm}.json")
     if args.workload == "demucs" and batch == 64 and os.path.exists(pmc):
         ks = json.load(open(pmc))["kernels"]
-        fam = [v for k, v in ks.items() if k.startswith(("gemm_fwd_kernel", "gemm_tap_kernel"))]
+        fam = [v for k, v in ks.items() if k.startswith(("gemm_fwd_kernel", "gemm_tap_kernel", "gemm_tap_stream_kernel"))]
         n = sum(v["launches_per_step"] for v in fam)
         if n:
             traffic = round(sum(v["bytes_per_step"] for v in fam) / n)
-    alg_bytes = timer.bytes / max(klaunches, 1)
     out = {
         "metric": "audio-seconds/sec fwd+bwd (whole job)", "value": round(audio_s / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -377,10 +395,17 @@ def main():
                    # parameters after the timed steps (equal across replicas; tests compare it with a 1-rank run)
                    "dist_backend": torch.distributed.get_backend() if world > 1 else None, "ranks": world,
                    "param_abs_sum": float(opt.flat.data.double().abs().sum())},
-        "roofline": {"bound": "mfma", "kernel": kname,
-                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_TFLOPS, 4),
-                     "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
+        # the dominant kernel FAMILY (all forward-type gather-GEMM launches of the step).  `bound` is the roofline the family
+        # as a whole sits closer to: with bf16 operands on fp32 storage almost every Demucs layer has an arithmetic intensity
+        # below the ridge (2500 TF/s / 8 TB/s = 312 flop/B) and is priced against HBM; `by_bound` prices the launches on
+        # either side of the ridge separately.
+        "roofline": {"bound": bound, "kernel": kname,
+                     "achieved": round(tot_by / (kms * 1e-3) / 1e9, 1) if bound == "hbm" else round(tot_fl / (kms * 1e-3) / 1e12, 2),
+                     "peak": PEAK_HBM_GBS if bound == "hbm" else round(peak, 1), "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                     "frac": round(max(f_hbm, f_mfma), 4), "frac_mfma": round(f_mfma, 4), "frac_hbm": round(f_hbm, 4),
+                     "ridge_flop_per_byte": round(ridge, 1), "by_bound": {"mfma": _cls("mfma"), "hbm": _cls("hbm")},
+                     "traffic": traffic, "algorithmic_bytes_per_launch": round(tot_by / max(klaunches, 1)),
+                     "algorithmic_flops_per_launch": round(tot_fl / max(klaunches, 1)),
                      "launches": klaunches, "avg_launch_ms": round(kms / max(klaunches, 1), 4),
                      "share_of_step": round(kms / (dt * 1e3), 3)},
     }

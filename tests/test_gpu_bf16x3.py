@@ -24,6 +24,11 @@ CASES = [
     (24, 33, (17, 23), (3, 3), (1, 1), (1, 1), (1, 1), 2),
     (8, 45, (40, 30), (7, 5), (2, 2), (3, 2), (1, 1), 2),
     (3, 20, (1, 500), (1, 7), (1, 1), (0, 0), (1, 4), 2),      # K = 21: padded K step
+    # unit stride along b with aligned 256-column rows (the Hybrid Demucs decoder geometry)
+    (48, 96, (6, 256), (3, 3), (1, 1), (1, 1), (1, 1), 2),     # decoder rewrite: one 256-column segment per row
+    (32, 40, (1, 1000), (1, 3), (1, 1), (0, 2), (1, 2), 3),    # dilated k3 over 4 segments, last one partial, halo 2
+    (24, 64, (5, 260), (3, 3), (1, 1), (1, 1), (1, 1), 1),     # 1.5 chunks of channels, a 4-column tail segment
+    (16, 192, (3, 512), (3, 1), (1, 1), (1, 0), (1, 1), 2),    # row taps only (no halo columns), M = 192
 ]
 
 
@@ -101,3 +106,4 @@ def test_hdemucs_small_grads_bf16x3():
             continue
         num += float(((p.grad.cpu() - r) ** 2).sum()); den += float((r ** 2).sum())
     check((num / den) ** 0.5, 3e-3, what=(num / den) ** 0.5)
+
