@@ -367,7 +367,7 @@ static int rfx_launch_wgrad_bf(const WgradArgs& w, int shape, dim3 grid, hipStre
   RFX_CHECK_LAUNCH();
   return 0;
 }
-// wide-load kernel, shape: 0 = 96 x 128 (waves 1 x 4), 1 = 32 x 256, 2 = 32 x 128, 3 = 128 x 128, 4 = 64 x 128
+// wide-load kernel, shape: 0 = 96 x 128 (waves 1 x 4), 1 = 32 x 256, 2 = 32 x 128, 3 = 128 x 128, 4 = 64 x 128, 5 = 96 x 256
 template <int MODE>
 static int rfx_launch_wgrad_wide(const WgradArgs& w, int shape, dim3 grid, hipStream_t s) {
   switch (shape) {
@@ -375,6 +375,7 @@ static int rfx_launch_wgrad_wide(const WgradArgs& w, int shape, dim3 grid, hipSt
     case 1: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 2, 1, MODE>), grid, dim3(256), 0, s, w); break;
     case 2: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 1, 1, MODE>), grid, dim3(256), 0, s, w); break;
     case 3: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<2, 2, 2, MODE>), grid, dim3(256), 0, s, w); break;
+    case 5: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<3, 2, 1, MODE>), grid, dim3(256), 0, s, w); break;
     default: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 2, 2, MODE>), grid, dim3(256), 0, s, w); break;
   }
   RFX_CHECK_LAUNCH();

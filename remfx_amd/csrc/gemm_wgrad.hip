@@ -223,8 +223,12 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
       d->out_cs >= 0 && d->out_as >= 0) {
     w.in_bytes = (uint32_t)d->in_extent; w.g_bytes = (uint32_t)g_span;
     const bool r96 = d->M > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;
-    const int shape = r96 ? 0 : d->M <= 32 ? (d->K > 128 ? 1 : 2) : d->M > 64 ? 3 : 4;
-    const int rm = shape == 0 ? 96 : shape <= 2 ? 32 : shape == 3 ? 128 : 64, rk = shape == 1 ? 256 : 128;
+    // 96 x 256 tiles (bf16 mode: the hi + lo images of the split mode would need 101 KB of LDS) when K has >= 2 of them:
+    // twice the MFMA work per staged element and half the re-reads of g
+    static const int wide256 = getenv("RFX_WGRAD_256") ? atoi(getenv("RFX_WGRAD_256")) : 1;
+    const int shape = r96 ? ((prec == 2 && wide256 && d->K > 256) ? 5 : 0) : d->M <= 32 ? (d->K > 128 ? 1 : 2) : d->M > 64 ? 3 : 4;
+    const int rm = (shape == 0 || shape == 5) ? 96 : shape <= 2 ? 32 : shape == 3 ? 128 : 64;
+    const int rk = (shape == 1 || shape == 5) ? 256 : 128;
     const int mt = (d->M + rm - 1) / rm, kt = (d->K + rk - 1) / rk;
     const int chunks = d->N * d->OA * ((d->OB + 63) / 64);          // 64-position chunks of one (n, a) row
     int splits = max(1, 2048 / (mt * kt));
