@@ -25,7 +25,7 @@ DECODERS = ((128, 90, (5, 3), (2, 1)), (180, 90, (5, 3), (2, 2)), (180, 90, (5, 
             (135, 90, (1, 7), (1, 1)), (135, 1, (7, 1), (1, 1)))
 
 
-def stft_filters(n_filters=1024, kernel_size=512, stride=256):
+def stft_filters(n_filters=1024, kernel_size=512, stride=256, form="slice"):
     """asteroid-filterbanks STFTFB: windowed, centred part of the DFT basis, (n_filters+2, 1, kernel)."""
     cutoff = n_filters // 2 + 1
     window = np.hanning(kernel_size + 1)[:-1] ** 0.5
@@ -36,7 +36,14 @@ def stft_filters(n_filters=1024, kernel_size=512, stride=256):
     filt = np.vstack([np.real(filt[:cutoff, idx]), np.imag(filt[:cutoff, idx])])
     filt[0, :] /= np.sqrt(2)
     filt[n_filters // 2, :] /= np.sqrt(2)
-    return torch.from_numpy(filt * window).unsqueeze(1).float()
+    filt = filt * window
+    if form == "zero_pad":       # window zero-padded to n_filters: (n_filters + 2, 1, n_filters) buffers, kernel = n_filters
+        full = np.zeros((filt.shape[0], n_filters))
+        full[:, lpad:lpad + kernel_size] = filt
+        filt = full
+    elif form != "slice":
+        raise ValueError(f"stft filter form {form!r}: 'slice' or 'zero_pad'")
+    return torch.from_numpy(filt).unsqueeze(1).float()
 
 
 class _FB(nn.Module):
@@ -153,10 +160,13 @@ class _Masker(nn.Module):
 
 class DCUNet(nn.Module):
     def __init__(self, architecture="Large-DCUNet-20", stft_n_filters=1024, stft_kernel_size=1024, stft_stride=256,
-                 sample_rate=16000.0, fix_length_mode=None):
+                 sample_rate=16000.0, fix_length_mode=None, stft_filter_form="slice"):
         super().__init__()
         assert architecture == "Large-DCUNet-20" and fix_length_mode == "pad"
-        filt = stft_filters(stft_n_filters, stft_kernel_size, stft_stride)
+        # stft_filter_form (not an upstream keyword): asteroid-filterbanks is absent here, so the buffer shape of its STFTFB
+        # cannot be pinned -- "slice" = the kernel_size centred columns of the DFT basis, (1026, 1, 512) at RemFX's setting
+        # (this restatement's reading of the published code); "zero_pad" = the window padded to n_filters, (1026, 1, 1024)
+        filt = stft_filters(stft_n_filters, stft_kernel_size, stft_stride, stft_filter_form)
         self.stride = stft_stride
         self.encoder, self.decoder = _Coder(filt), _Coder(filt.clone())
         self.masker = _Masker()

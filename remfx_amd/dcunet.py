@@ -18,6 +18,8 @@ MI355X design:
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -35,7 +37,7 @@ DECODERS = ((128, 90, (5, 3), (2, 1)), (180, 90, (5, 3), (2, 2)), (180, 90, (5, 
 LEAKY = 0.01
 
 
-def stft_filters(n_filters=1024, kernel_size=512, stride=256):
+def stft_filters(n_filters=1024, kernel_size=512, stride=256, form="slice"):
     """asteroid-filterbanks STFTFB buffer: (n_filters + 2, 1, kernel_size)."""
     cutoff = n_filters // 2 + 1
     window = np.hanning(kernel_size + 1)[:-1] ** 0.5
@@ -46,7 +48,14 @@ def stft_filters(n_filters=1024, kernel_size=512, stride=256):
     filt = np.vstack([np.real(filt[:cutoff, idx]), np.imag(filt[:cutoff, idx])])
     filt[0, :] /= np.sqrt(2)
     filt[n_filters // 2, :] /= np.sqrt(2)
-    return torch.from_numpy(filt * window).unsqueeze(1).float()
+    filt = filt * window
+    if form == "zero_pad":       # window zero-padded to n_filters: (n_filters + 2, 1, n_filters) buffers, kernel = n_filters
+        full = np.zeros((filt.shape[0], n_filters))
+        full[:, lpad:lpad + kernel_size] = filt
+        filt = full
+    elif form != "slice":
+        raise ValueError(f"stft filter form {form!r}: 'slice' or 'zero_pad'")
+    return torch.from_numpy(filt).unsqueeze(1).float()
 
 
 class _FB(nn.Module):
@@ -291,12 +300,17 @@ class _Masker(nn.Module):
 
 class DCUNet(nn.Module):
     def __init__(self, architecture="Large-DCUNet-20", stft_n_filters=1024, stft_kernel_size=1024, stft_stride=256,
-                 sample_rate=16000.0, fix_length_mode=None, **kwargs):
+                 sample_rate=16000.0, fix_length_mode=None, stft_filter_form=None, **kwargs):
         super().__init__()
         if architecture != "Large-DCUNet-20" or fix_length_mode != "pad":
             raise NotImplementedError("only the configuration RemFX uses (cfg/model/dcunet.yaml) is built")
-        filt = stft_filters(stft_n_filters, stft_kernel_size, stft_stride)
-        self.stride, self.kernel_size, self.n_filters = stft_stride, stft_kernel_size, stft_n_filters
+        # Shape of asteroid-filterbanks' STFTFB buffers (unpinned: the package is in neither tree): "slice" (default) keeps the
+        # kernel_size centred columns, (1026, 1, 512) at RemFX's setting; "zero_pad" pads the window to n_filters,
+        # (1026, 1, 1024).  A released checkpoint loads strictly with exactly one of them: RFX_DCUNET_FILTER_FORM or the
+        # keyword selects it (oracle/ref_dcunet.py takes the same keyword).
+        form = stft_filter_form or os.environ.get("RFX_DCUNET_FILTER_FORM", "slice")
+        filt = stft_filters(stft_n_filters, stft_kernel_size, stft_stride, form)
+        self.stride, self.kernel_size, self.n_filters = stft_stride, filt.shape[-1], stft_n_filters
         self.encoder, self.decoder = _Coder(filt), _Coder(filt.clone())
         self.masker = _Masker()
 

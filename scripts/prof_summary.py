@@ -1,28 +1,69 @@
-"""Print a per-kernel and per-family summary of a rocprofv3 --kernel-trace --stats kernel_stats.csv."""
+"""Per-family and per-kernel summary of a rocprofv3 --kernel-trace --stats kernel_stats.csv, as a markdown table; with the
+PMC traffic JSON of the same command (scripts/collect_pmc.py) every kernel also gets its measured HBM bytes per launch and
+the rate / fraction of the 8 TB/s peak they correspond to.  DESIGN.md section 6 is this script's output.
+
+    python scripts/prof_summary.py <kernel_stats.csv> [steps=4] [rows=25] [pmc_traffic.json]
+"""
 import csv
+import json
 import sys
 
-f, steps = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
-rows = list(csv.DictReader(open(f)))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-fam = {}
-for r in rows:
-    n = r["Name"].replace("void ", "")
-    key = ("gemm_fwd" if n.startswith("gemm_fwd") or n.startswith("gemm_thin") else
-           "gemm_wgrad" if n.startswith("gemm_wgrad") else
-           "lstm" if n.startswith("lstm") else
-           "miopen/rocblas" if ("Cijk" in n or "LSTM" in n or "miopen" in n.lower()) else
-           "gn/bn" if n.startswith(("gn_", "bn_")) else
-           "fft" if n.startswith(("fft", "stft", "istft")) else
-           "glu/act/add" if n.startswith(("glu", "act", "add_", "row_", "prelu")) else
-           "loss" if n.startswith(("l1", "stft_loss", "sisdr")) else
-           "pack" if n.startswith(("pack", "unpack")) else
-           "optim" if n.startswith(("adamw", "sumsq", "clip")) else
-           "aten" if "at::" in n else "other")
-    fam[key] = fam.get(key, 0.0) + float(r["TotalDurationNs"])
-for k, v in sorted(fam.items(), key=lambda kv: -kv[1]):
-    print(f"{k:16s} {v / steps / 1e6:8.2f} ms/step {100 * v / tot:5.1f} %")
-print(f"{'total':16s} {tot / steps / 1e6:8.2f} ms/step")
-for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 25]:
-    print(f"{r['Name'][:100]:100s} {int(r['Calls']):6d} {float(r['TotalDurationNs']) / steps / 1e6:8.2f} ms/step "
-          f"{float(r['AverageNs']) / 1e3:9.1f} us")
+PEAK_HBM = 8.0e12
+
+FAMILIES = [
+    ("gemm forward family", ("gemm_fwd", "gemm_tap", "gemm_thin_fwd")),
+    ("gemm weight gradient", ("gemm_wgrad", "gemm_thin_wgrad")),
+    ("GroupNorm / BatchNorm", ("gn_", "bn_")),
+    ("LSTM recurrence", ("lstm",)),
+    ("GLU / activations / adds", ("glu", "act", "add_", "row_", "prelu", "channel_sum", "blstm_frames", "span_mask")),
+    ("framed FFT", ("fft", "stft", "istft")),
+    ("losses", ("l1", "stft_loss", "sisdr")),
+    ("attention", ("localstate",)),
+    ("pack / unpack", ("pack", "unpack")),
+    ("optimiser", ("adamw", "sumsq", "clip")),
+]
+
+
+def family(name):
+    n = name.replace("void ", "")
+    for fam, prefixes in FAMILIES:
+        if n.startswith(prefixes):
+            return fam
+    if "Cijk" in n or "miopen" in n.lower() or "rocblas" in n.lower():
+        return "rocBLAS / MIOpen"
+    if "at::" in n or "rocclr" in n or "elementwise_kernel" in n:
+        return "ATen / runtime copies"
+    return "other"
+
+
+def main(path, steps=4.0, top=25, pmc=None):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    traffic = json.load(open(pmc))["kernels"] if pmc else {}
+    fam = {}
+    for r in rows:
+        f = family(r["Name"])
+        a = fam.setdefault(f, [0.0, 0])
+        a[0] += float(r["TotalDurationNs"]); a[1] += int(r["Calls"])
+    print(f"kernel time {tot / steps / 1e6:.2f} ms per step over {sum(int(r['Calls']) for r in rows) / steps:.0f} launches "
+          f"({path.split('/')[-1]}, {steps:g} steps profiled)\n")
+    print("| family | ms / step | share | launches / step |\n|---|---|---|---|")
+    for f, (ns, calls) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+        print(f"| {f} | {ns / steps / 1e6:.2f} | {100 * ns / tot:.1f} % | {calls / steps:.0f} |")
+    print("\n| kernel | launches / step | ms / step | avg us | HBM bytes / launch (PMC) | TB/s | of 8 TB/s |\n|---|---|---|---|---|---|---|")
+    for r in rows[:top]:
+        name = r["Name"].replace("void ", "")
+        key = name.split("(")[0]
+        avg = float(r["AverageNs"])
+        t = traffic.get(key)
+        if t:
+            b = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+            extra = f"{b / 1e6:.1f} MB | {b / avg / 1e3:.2f} | {b / avg * 1e9 / PEAK_HBM:.2f}"
+        else:
+            extra = " | | "
+        print(f"| `{key[:70]}` | {int(r['Calls']) / steps:.0f} | {float(r['TotalDurationNs']) / steps / 1e6:.2f} | {avg / 1e3:.1f} | {extra} |")
+
+
+if __name__ == "__main__":
+    a = sys.argv
+    main(a[1], float(a[2]) if len(a) > 2 else 4.0, int(a[3]) if len(a) > 3 else 25, a[4] if len(a) > 4 else None)

@@ -43,6 +43,32 @@ def test_dcunet_eval_forward():
         yd = net(x.to(DEV)).cpu()
     assert yd.shape == y.shape == (2, 1, 20000)
     check(_rms(yd, y), 1e-4, max(1.0, float(y.abs().max())), what=_rms(yd, y))
+    # BASELINE config 4's quality figure: SI-SDR (auraloss definition) of the device output against the CPU restatement
+    from oracle import ref_losses
+    sisdr = -float(ref_losses.sisdr_loss(yd, y))
+    print(f"DCUNet eval forward: SI-SDR(device output, CPU restatement) = {sisdr:.1f} dB [{mode()}]")
+    assert sisdr > tol(80.0, bf16x3=70.0, bf16=25.0), sisdr
+
+
+@pytest.mark.one_mode
+def test_dcunet_zero_padded_filterbank_form():
+    """The alternative reading of asteroid's STFTFB buffer shape (window zero-padded to n_filters): (1026, 1, 1024) buffers,
+    strict state_dict round trip between oracle and product, same output parity."""
+    from oracle import ref_dcunet
+    from remfx_amd.dcunet import DCUNet
+    torch.manual_seed(4)
+    ref = ref_dcunet.DCUNet(stft_kernel_size=512, fix_length_mode="pad", stft_filter_form="zero_pad").eval()
+    assert tuple(ref.state_dict()["encoder.filterbank._filters"].shape) == (1026, 1, 1024)
+    net = DCUNet(stft_kernel_size=512, fix_length_mode="pad", stft_filter_form="zero_pad")
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV).eval()
+    with pytest.raises(RuntimeError):                       # the two forms are not interchangeable under a strict load
+        DCUNet(stft_kernel_size=512, fix_length_mode="pad").load_state_dict(ref.state_dict(), strict=True)
+    x = torch.randn(1, 20000, generator=torch.Generator().manual_seed(5)) * 0.3
+    with torch.no_grad():
+        y = ref(x)
+        yd = net(x.to(DEV)).cpu()
+    check(_rms(yd, y), 1e-4, max(1.0, float(y.abs().max())))
 
 
 def test_dcunet_train_fwd_bwd():
