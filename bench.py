@@ -297,7 +297,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # BASELINE.json configs: Demucs 64 clips/GPU (headline), TCN 32, DCUNet 32 over 8 GPUs = 4/GPU, UMX 4
-    batch = args.batch or {"tcn": 32, "demucs": 64, "dcunet": 4, "umx": 4, "chain": 16}[args.workload]
+    batch = args.batch or {"tcn": 32, "demucs": 64, "dcunet": 4, "umx": 4, "chain": 16, "demucs_fwd": 64}[args.workload]
 
     if args.workload == "chain":
         return bench_chain(args, rank, world, device)

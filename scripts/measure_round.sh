@@ -2,7 +2,7 @@
 #   bash scripts/measure_round.sh r02 bf16
 # writes gpurun_out/<round>/: kernel-trace stats CSV of the headline bench, the two PMC passes (FETCH_SIZE / WRITE_SIZE in
 # SEPARATE runs, counters only + kernel trace: rocprofv3 must not combine --pmc with other trace domains on this pool)
-# turned into the per-kernel HBM traffic JSON, and the bench lines of every workload.  Copy the summaries you want judged
+# (the stats cover 2 warm-up + 4 timed steps = 6 steps) turned into the per-kernel HBM traffic JSON, and the bench lines of every workload.  Copy the summaries you want judged
 # into profiles/ afterwards (gpurun_out/ is scratch).
 R=${1:-r02}; MODE=${2:-bf16}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
@@ -18,7 +18,7 @@ done
 cd $ROOT
 python scripts/collect_pmc.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json 1
 rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv
-python scripts/prof_summary.py $OUT/${R}_demucs_b64_kernel_stats_$MODE.csv 4 40 $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json > $OUT/${R}_demucs_b64_summary_$MODE.md
+python scripts/prof_summary.py $OUT/${R}_demucs_b64_kernel_stats_$MODE.csv 6 40 $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json > $OUT/${R}_demucs_b64_summary_$MODE.md
 python bench.py --gemm $MODE > $OUT/bench_demucs_$MODE.json 2> $OUT/bench_demucs_$MODE.err
 python bench.py --workload demucs_fwd --gemm $MODE > $OUT/bench_demucs_fwd_$MODE.json 2>> $OUT/bench_demucs_$MODE.err
 for w in tcn dcunet umx chain; do
