@@ -16,7 +16,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_$c
 done
 cd $ROOT
-python scripts/collect_pmc.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json 1
+python scripts/collect_pmc.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json 2
 rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv
 python scripts/prof_summary.py $OUT/${R}_demucs_b64_kernel_stats_$MODE.csv 6 40 $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json > $OUT/${R}_demucs_b64_summary_$MODE.md
 python bench.py --gemm $MODE > $OUT/bench_demucs_$MODE.json 2> $OUT/bench_demucs_$MODE.err
