@@ -67,7 +67,7 @@ class KernelTimer:
     launch, so that every launch can be priced against the roofline that binds IT (ridge = peak FLOP/s / peak B/s)."""
 
     def __init__(self):
-        self.launches, self.enabled = [], False          # (start, end, flops, bytes)
+        self.launches, self.enabled, self.desc = [], False, []          # (start, end, flops, bytes); plan of each launch
 
     def install(self):
         from remfx_amd import ops
@@ -85,6 +85,8 @@ class KernelTimer:
             k = p.extra["n_weight_rows"] + (kw["dp2"].p.extra["n_weight_rows"] if kw.get("dp2") is not None else 0)
             extra = sum(t.numel() for t in (kw.get("res"), kw.get("glu_out")) if t is not None)
             timer.launches.append((s, e, 2.0 * p.M * k * p.OA * p.OB * p.N, 4.0 * (x.numel() + out.numel() + p.M * k + extra)))
+            timer.desc.append({"M": p.M, "K": k, "N": p.N, "OA": p.OA, "OB": p.OB, "R": p.R, "x": list(x.shape), "out": list(out.shape),
+                               "two_phase": kw.get("dp2") is not None, "extra_elems": extra})
             return r
         ops.gemm_fwd = timed
         import remfx_amd.tcn as tcn_mod
@@ -276,6 +278,7 @@ def main():
                     choices=["demucs", "tcn", "dcunet", "umx", "chain", "demucs_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-launches", default="", help="write the per-launch plan / algorithmic work / event time list of the timed steps (JSON)")
     ap.add_argument("--union-ranks", type=int, default=0,
                     help="single process only: train on the concatenation of the synthetic batches ranks 0..N-1 would "
                          "get (N x --batch clips) -- the reference point of the data-parallel equivalence test")
@@ -355,6 +358,9 @@ def main():
              "bf16x3": "gemm_tap_kernel<R,1> + gemm_tap_stream_kernel<1,..> (tap-major gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per K step)",
              "bf16": "gemm_tap_kernel<R,2> + gemm_tap_stream_kernel<2,..> (tap-major gather-GEMM, 1 x v_mfma_f32_32x32x16_bf16 per K step)"}[args.gemm]
     kms, klaunches, cls, ridge = timer.result(peak, PEAK_HBM_GBS)
+    if args.dump_launches:         # per-launch plan + algorithmic work + event time, in launch order (scripts/join_launch_pmc.py)
+        json.dump([dict(d, ms=s.elapsed_time(e), flops=fl, bytes=by) for d, (s, e, fl, by) in zip(timer.desc, timer.launches)],
+                  open(args.dump_launches, "w"))
     tot_fl = cls["mfma"][1] + cls["hbm"][1]
     tot_by = cls["mfma"][2] + cls["hbm"][2]
     f_mfma = tot_fl / (kms * 1e-3) / 1e12 / peak if kms > 0 else 0.0

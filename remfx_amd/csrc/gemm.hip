@@ -183,6 +183,7 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   if (apack2 && (Kpad2 % 16 != 0 || (prec == 0 && Kpad2 < K2))) return -1;
   if (prec < 0 || prec > 2 || (d->R == 0 && prec != 0)) return -1;
   FwdArgs g;
+  g.xcd_chunk = 0;
   g.d = *d;
   g.apack = apack; g.ktab = ktab; g.in = in; g.out = out;
   if (epi) g.e = *epi;
@@ -213,6 +214,11 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   const int64_t nblk = ((work + 7) / 8) * 8 * (d->Mpad / bm);
   if (nblk > 0x7fffffff) return -1;
   dim3 grid((unsigned)nblk);
+  // Position tiles are 128 flattened (a, b) positions.  When the taps reach over rows of the A axis (2-D kernels, the (8,1) / stride-4
+  // frequency convolutions and their transposes) neighbouring tiles read the same input rows: give each XCD a contiguous run of
+  // tiles so the overlap is served by ITS L2 instead of being fetched from HBM once per XCD.  RFX_FWD_XCD_CHUNK=0 restores round-robin.
+  static const int chunk_on = getenv("RFX_FWD_XCD_CHUNK") ? atoi(getenv("RFX_FWD_XCD_CHUNK")) : 1;
+  g.xcd_chunk = (chunk_on == 2 || (chunk_on == 1 && d->OA > 1)) ? (int)((work + 7) / 8) : 0;
   if (prec == 0) return rfx_launch_gemm_fwd_f32(g, r, grid, s);
   // bf16x3 / bf16: tap-major kernels (gemm_tap.h); the caller packed A and passes the tap tables in that order
   if (d->Kpad_t <= 0 || d->Kpad_t % 16 != 0 || d->gpt <= 0 || d->ntaps <= 0 || d->ntaps > 112 || d->in_extent <= 0 ||

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_kernel(const FwdArgs g) {
   // neighbouring position tiles are spread over the 8 XCDs.
   const int mtiles = d.Mpad / BM, ptiles = (P + 127) / 128;
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int ym = q % mtiles, pw = (q / mtiles) * 8 + xcd;      // pw: (n, position tile) work item
+  const int ym = q % mtiles;
+  const int pw = g.xcd_chunk > 0 ? xcd * g.xcd_chunk + q / mtiles : (q / mtiles) * 8 + xcd;   // (n, position tile) work item
   if (pw >= ptiles * d.N) return;
   const int n = pw / ptiles;
   const int m0 = ym * BM;

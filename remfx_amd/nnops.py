@@ -16,11 +16,10 @@ from ._lib import check
 from .ops import _ptr, _stream
 
 INTERIM = set()
-_STRICT = os.environ.get("RFX_STRICT_NATIVE", "0") == "1"
 
 
 def _interim(name):
-    if _STRICT:
+    if os.environ.get("RFX_STRICT_NATIVE", "0") == "1":
         raise RuntimeError(f"op '{name}' has no HIP kernel yet (RFX_STRICT_NATIVE=1)")
     INTERIM.add(name)
 
@@ -373,25 +372,9 @@ def blstm_unframe(h, skip, B, T, nfr, width, stride):
     return _BlstmUnframeFn.apply(h, skip, B, T, nfr, width, stride)
 
 
-def lstm(module, x):
-    """module: nn.LSTM parameter container; x: (T, B, C)."""
-    _interim("lstm")
-    return module(x)[0]
-
-
 def linear(x, weight, bias):
     """x: (..., Cin) -> (..., Cout) as a 1x1 gather-GEMM over the flattened rows."""
     shp = x.shape
     x2 = x.reshape(1, -1, shp[-1]).transpose(1, 2)              # (1, Cin, rows) strided view
     y = ops.conv1d(x2, weight.unsqueeze(-1), bias)              # (1, Cout, rows)
     return y.transpose(1, 2).reshape(*shp[:-1], weight.shape[0])
-
-
-def softmax(x, dim):
-    _interim("softmax")
-    return torch.softmax(x, dim=dim)
-
-
-def einsum(eq, *xs):
-    _interim("einsum:" + eq)
-    return torch.einsum(eq, *xs)

@@ -28,7 +28,11 @@ def _pair(channels, seed=0):
     return ref, net.to(DEV)
 
 
-def test_hdemucs_small_fwd_bwd():
+def test_hdemucs_small_fwd_bwd(monkeypatch):
+    # RFX_STRICT_NATIVE=1: an op without a HIP kernel (nnops.INTERIM) raises instead of running through torch-ROCm
+    from remfx_amd import nnops
+    monkeypatch.setenv("RFX_STRICT_NATIVE", "1")
+    nnops.INTERIM.clear()
     ref, net = _pair(8)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 1, 20000, generator=g) * 0.5
@@ -58,6 +62,7 @@ def test_hdemucs_small_fwd_bwd():
     rel = (num / den) ** 0.5
     print("global relative grad error", rel, "worst tensor", worst)
     check(rel, 2e-3, what=rel)
+    assert not nnops.INTERIM
 
 
 def test_hdemucs_full_config_forward():
