@@ -14,6 +14,8 @@ Prints ONE JSON line (rank 0).  metric = audio-seconds processed per second (who
 import argparse
 import json
 import os
+
+os.environ.setdefault("RFX_STRICT_NATIVE", "1")     # an op without a HIP kernel raises instead of running through torch-ROCm
 import sys
 import time
 

@@ -77,8 +77,10 @@ typedef struct rfx_gemm_desc {
    * by the bf16x3 / bf16 kernels: k runs over 8-channel groups g = t * gpt + c8 (tap t, channels 8*c8 .. 8*c8+7),
    * Kpad_t = 16 * ceil(ntaps * gpt / 2); the table passed as `ktab` then has ntaps + 16 rows (off = offset of channel 0
    * of the tap, da, db; 16 invalid tail rows) and In(n, k, a, b) adds channel * in_cs.  in_extent = bytes spanned by one
-   * sample of the operand: reads beyond it (padded channels of the last group) return 0. */
-  int32_t Kpad_t, gpt, ntaps, tap_reserved;
+   * sample of the operand: reads beyond it (padded channels of the last group) return 0.  The planner may cut the channels into
+   * blocks and present every (block, tap) as one table row (gpt = groups per block).  gpt2: groups per table row of the SECOND
+   * phase's table in two-phase launches (0 = same as gpt). */
+  int32_t Kpad_t, gpt, ntaps, gpt2;
   int64_t in_ns, in_as, in_bs;
   int64_t out_ns, out_cs, out_as, out_bs;
   int64_t in_cs, in_extent;

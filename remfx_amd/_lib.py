@@ -73,7 +73,7 @@ class KtabEntry(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "M", "K", "OA", "OB", "IA", "IB", "SA", "SB", "Mpad",
                                          "Kpad", "out_a0", "out_b0", "out_sa", "out_sb", "R", "mg_log", "mg_axis", "mg_len", "mg_off",
-                                         "Kpad_t", "gpt", "ntaps", "tap_reserved")] + \
+                                         "Kpad_t", "gpt", "ntaps", "gpt2")] + \
                [(n, C.c_int64) for n in ("in_ns", "in_as", "in_bs", "out_ns", "out_cs", "out_as", "out_bs", "in_cs", "in_extent")]
 
 

@@ -14,6 +14,8 @@ Covered (reference call sites):
 """
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 
 INVALID_DA = -(1 << 30)
@@ -117,6 +119,9 @@ class GemmPlan:
         return self
 
 
+TAP_BLOCK_GROUPS = int(os.environ.get("RFX_TAP_BLOCK", "2"))      # smallest channel block in 8-channel groups; 0 = no blocking
+
+
 def _tap_major(self, kt, woff):
     """Tap-major re-ordering of the reduction axis for the bf16 MFMA kernels (csrc/gemm_tap.h).
 
@@ -143,17 +148,37 @@ def _tap_major(self, kt, woff):
     if not (np.array_equal(kt[:, 0], exp_off) and np.array_equal(kt[:, 1:3], np.tile(taps[:, 1:3], (self.cin, 1)))
             and not kt[:, 3].any()):
         raise AssertionError("gather-GEMM plan rows are not (channel, tap) ordered")
-    gpt = -(-self.cin // 8)
-    G = nt * gpt
-    self.ntaps, self.gpt, self.Kpad_t = nt, gpt, 16 * (-(-G // 2))
-    tab = np.zeros((nt + 16, 4), dtype=np.int64)
-    tab[:nt] = taps
-    tab[nt:, 1] = INVALID_DA
+    gpt_all = -(-self.cin // 8)
+    # Channel blocking: with many channels AND several taps, "all channels of tap 0, then all channels of tap 1, ..." re-reads a
+    # position tile's input once per tap with a whole channel sweep (hundreds of KB per workgroup) in between: the r02 per-launch
+    # PMC join measured 5-7.5x the algorithmic bytes on the 3x3 layers (192 ch x 9 taps: 11.2 GB read for a 1.6 GB operand).
+    # The reduction is therefore cut into blocks of gb groups (8 gb channels); inside a block the taps are walked back to back,
+    # so the re-use distance is one block (16 channels x rows x 130 positions ~ 25 KB).  The kernels do not know: a block is
+    # presented as nt "virtual taps" whose table offset includes the block's channel offset, and gpt = gb.
+    gb, nb = gpt_all, 1
+    if nt > 1 and gpt_all >= 4 and TAP_BLOCK_GROUPS > 0:
+        fits = [c for c in range(TAP_BLOCK_GROUPS, gpt_all) if nt * -(-gpt_all // c) <= 112]
+        even = [c for c in fits if gpt_all % c == 0]
+        pick = (even or fits or [gpt_all])[0]
+        if even and fits and even[0] > 2 * fits[0]:         # a divisor far above the smallest fitting block: accept the padding
+            pick = fits[0]
+        gb, nb = pick, -(-gpt_all // pick)
+    ntv = nt * nb
+    G = ntv * gb
+    self.ntaps, self.gpt, self.Kpad_t = ntv, gb, 16 * (-(-G // 2))
+    tab = np.zeros((ntv + 16, 4), dtype=np.int64)
+    for cb in range(nb):
+        tab[cb * nt:(cb + 1) * nt] = taps
+        tab[cb * nt:(cb + 1) * nt, 0] += cb * gb * 8 * int(self.in_cs)
+    tab[ntv:, 1] = INVALID_DA
+    if np.abs(tab[:, 0]).max() > 0x3fffffff:
+        raise AssertionError("tap offset does not fit 32 bits")
     self.tap_tab = tab.astype(np.int32)
     wt = np.full(self.Kpad_t, -1, dtype=np.int64)
-    t, c = np.meshgrid(np.arange(nt), np.arange(gpt * 8), indexing="ij")
-    ok = c < self.cin
-    wt[((t * gpt * 8) + c)[ok]] = woff[(c * nt + t)[ok]]
+    cbi, t, c = np.meshgrid(np.arange(nb), np.arange(nt), np.arange(gb * 8), indexing="ij")
+    ch = cbi * gb * 8 + c
+    ok = ch < self.cin
+    wt[(((cbi * nt + t) * gb * 8) + c)[ok]] = woff[(ch * nt + t)[ok]]
     self.woff_t = wt.astype(np.int32)
 
 

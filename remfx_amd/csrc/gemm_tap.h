@@ -161,7 +161,7 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
 
 template <int R, int MODE>
 __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const float* __restrict__ apack,
-                                              const rfx_ktab_entry* __restrict__ tap_tab, int ntaps, int Kpad, int m0,
+                                              const rfx_ktab_entry* __restrict__ tap_tab, int ntaps, int gpt, int Kpad, int m0,
                                               TapLane c, uint4* as, int4* taps, f32x16 (&acc)[R]) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
   const int tid = threadIdx.x;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
   const uint4* apk = reinterpret_cast<const uint4*>(apack);
   const int64_t arr_stride = (int64_t)(Kpad / 8 + 8) * d.Mpad;
   const uint32_t cs4 = (uint32_t)(d.in_cs * 4);
-  const uint32_t gstep = 16u * cs4, gwrap = (uint32_t)d.gpt * 8u * cs4;
+  const uint32_t gstep = 16u * cs4, gwrap = (uint32_t)gpt * 8u * cs4;
   __syncthreads();            // a previous phase (two-phase launches) may still be reading the LDS buffers / tap table
   {
     const AStage s0 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 0, m0, tid);
@@ -181,8 +181,8 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
     tap_a_store<R, MODE>(as + CELLS, tid, s1);
   }
   __syncthreads();
-  c.t = h / d.gpt;            // group g = h of K step 0
-  c.goff = (uint32_t)(h - c.t * d.gpt) * 8u * cs4;
+  c.t = h / gpt;              // group g = h of K step 0
+  c.goff = (uint32_t)(h - c.t * gpt) * 8u * cs4;
   // the gathers run RFX_BDIST K steps ahead of the MFMAs: one K step is ~0.1-0.2 us of matrix work, a gather that misses
   // L2 takes ~1-2 us, and only two waves share a SIMD
   float b0[8], b1[8], b2[8], b3[8];
@@ -244,12 +244,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_kernel(const FwdArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  run_phase_tap<R, MODE>(d, g.apack, g.ktab, d.ntaps, d.Kpad_t, m0, c, as, taps, acc);
+  run_phase_tap<R, MODE>(d, g.apack, g.ktab, d.ntaps, d.gpt, d.Kpad_t, m0, c, as, taps, acc);
   fwd_epilogue_mid<R>(g, tc, acc);
   if (g.apack2 != nullptr) {
     if (g.in2) c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.in2 + (int64_t)n * d.in_ns), 0,
                                                         (int)d.in_extent, 0x00020000);
-    run_phase_tap<R, MODE>(d, g.apack2, g.ktab2, g.ntaps2, g.Kpad2, m0, c, as, taps, acc);
+    run_phase_tap<R, MODE>(d, g.apack2, g.ktab2, g.ntaps2, d.gpt2 > 0 ? d.gpt2 : d.gpt, g.Kpad2, m0, c, as, taps, acc);
   }
   fwd_epilogue_store<R>(g, tc, acc);
 }
@@ -296,7 +296,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g
   const int ptiles = (q.P + 127) / 128;                          // 128-position tiles per sample
   const int tiles = ptiles * d.N;                                // a block of NT consecutive tiles may span samples
   const int work = (tiles + NT - 1) / NT;
-  const int ym = blockIdx.x % mtiles, w0 = blockIdx.x / mtiles, stride = gridDim.x / mtiles;
+  // the mtiles channel tiles of one position walk are blocks b, b + 8, b + 16, ... = the SAME XCD, started together and doing
+  // equal work per tile: they read their (shared) input through one L2.  With `ym = b % mtiles` the channel tiles sat on
+  // different XCDs and every one of them fetched the input from HBM (r02 per-launch PMC: reads = mtiles x the operand).
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  const int ym = qq % mtiles, w0 = (qq / mtiles) * 8 + xcd, stride = gridDim.x / mtiles;
   q.m0 = ym * BM;
   q.nk = d.Kpad_t / 16;
   q.cs4 = (uint32_t)(d.in_cs * 4);
@@ -365,8 +369,8 @@ static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s
   if (!stream_off && g.d.Kpad_t <= 64 && g.apack2 == nullptr && work >= 4096 && r == 1 && g.e.act == RFX_ACT_NONE &&
       g.e.act2 == RFX_ACT_NONE && !g.e.bwd && g.d.mg_log == 0 && !g.e.res) {
     const int mtiles = g.d.Mpad / 32;
-    int nw = 512 / mtiles;                                       // persistent workgroups per channel tile (2 per CU in all)
-    nw = nw < 1 ? 1 : nw;
+    int nw = (512 / mtiles) & ~7;                                // persistent workgroups per channel tile (2 per CU in all),
+    nw = nw < 8 ? 8 : nw;                                        // a multiple of 8: one walk per XCD slot (kernel's block order)
     dim3 sg((unsigned)(nw * mtiles));
     if (g.d.Kpad_t <= 16) hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 4, 1>), sg, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 2, 4>), sg, dim3(256), 0, s, g);

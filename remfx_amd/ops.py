@@ -53,7 +53,7 @@ class DevPlan:
         self.woff = torch.from_numpy(np.ascontiguousarray(plan.woff)).to(device)
         d = GemmDesc()
         for f, _ in GemmDesc._fields_:
-            if f not in ("tap_reserved", "in_extent"):
+            if f not in ("gpt2", "in_extent"):
                 setattr(d, f, int(getattr(plan, f)))
         d.in_extent = int(plan.in_extent) * 4              # bytes
         self.desc = d
@@ -125,6 +125,7 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
     tab = dp.tap_tab if prec else dp.ktab
     if dp2 is not None and prec:
         a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.tap_tab), dp2.p.ntaps, dp2.p.Kpad_t
+        dp.desc.gpt2 = int(dp2.p.gpt)                      # the second table's own channel blocking
     elif dp2 is not None:
         a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.ktab), dp2.p.K, dp2.p.Kpad
     else:

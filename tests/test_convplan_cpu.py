@@ -23,6 +23,10 @@ CASES = [
     (16, 3, (20, 6), (8, 1), (4, 1), (2, 0), (1, 1)),     # strided freq conv
     (8, 10, (1, 70), (1, 7), (1, 1), (0, 0), (1, 3)),     # TCN dilated
     (24, 4, (1, 33), (1, 1), (1, 1), (0, 0), (1, 1)),     # 1x1, three groups, odd group count
+    # >= 32 input channels and several taps: channel-BLOCKED tap order (blocks of 16 channels presented as virtual taps)
+    (32, 5, (5, 9), (3, 3), (1, 1), (1, 1), (1, 1)),      # 2 blocks x 9 taps
+    (40, 3, (1, 30), (1, 3), (1, 1), (0, 2), (1, 2)),     # 5 groups -> 3 blocks, last one half padding
+    (48, 4, (9, 5), (8, 1), (4, 1), (2, 0), (1, 1)),      # strided freq conv, 3 blocks x 8 taps
 ]
 
 

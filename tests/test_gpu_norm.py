@@ -125,3 +125,19 @@ def test_activation_to_permuted_layout(shape):
     (z * gy.to(DEV)).sum().backward()
     assert _rms(z.detach().cpu(), zr.detach()) < 1e-6
     assert _rms(xd.grad.cpu(), xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 300), (2, 6, 1, 4099), (64, 4, 1, 1024), (1, 3, 40, 1000), (2, 3, 4, 5)])
+def test_channel_sum(shape):
+    """bias-gradient reduction over (N, A, B): vectorised contiguous-plane kernel (planes >= 1024 values, incl. a ragged tail and a
+    channel-sliced view) and the strided fallback, vs an fp64 sum."""
+    from remfx_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g).to(DEV)
+    ref = x.double().sum(dim=(0, 2, 3))
+    got = ops.channel_sum(x)
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * float(x.abs().double().sum() / shape[1] + 1.0)
+    if shape[1] > 2:
+        v = x[:, 1:-1]                                             # non-contiguous over (n, c), contiguous planes
+        got = ops.channel_sum(v)
+        assert float((got.double() - ref[1:-1]).abs().max()) <= 2e-6 * float(x.abs().double().sum() / shape[1] + 1.0)

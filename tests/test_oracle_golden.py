@@ -140,3 +140,24 @@ def test_resample_table_matches_oracle_filter():
         ref, w = ref_resample._filter(o, n)
         assert width == w and kern.shape == ref.shape
         assert float((kern - ref).abs().max()) < 1e-7
+
+
+def test_hdemucs_full_config_gradient_fixture_reproduces(golden_dir):
+    """The committed full-config HDemucs gradient fixture is what the oracle produces here (scripts/gen_hdemucs_grad_golden.py:
+    seeded weights + inputs, forward + backward of one 262144-sample clip, ~15 s on 8 cores)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("gen_hd", os.path.join(os.path.dirname(__file__), "..", "scripts",
+                                                                          "gen_hdemucs_grad_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gd = np.load(os.path.join(golden_dir, "hdemucs_full_grad.npz"))
+    ref = gen.build()
+    x, gy = gen.inputs()
+    y = ref(x)
+    y.backward(gy)
+    np.testing.assert_allclose(y.detach().reshape(-1)[::4099].numpy(), gd["y_slice"], rtol=1e-4, atol=1e-6)
+    names = dict(ref.named_parameters())
+    for i, n in enumerate(gd["names"].tolist()):
+        gr = names[n].grad.detach().reshape(-1)
+        assert abs(float(gr.double().norm()) - float(gd[f"g{i}_norm"])) <= 1e-3 * float(gd[f"g{i}_norm"]), n
