@@ -84,6 +84,12 @@ typedef struct rfx_gemm_desc {
   int64_t in_ns, in_as, in_bs;
   int64_t out_ns, out_cs, out_as, out_bs;
   int64_t in_cs, in_extent;
+  /* bf16 STORAGE of single operands (bf16 arithmetic mode only; strides stay in elements, in_extent in bytes):
+   * in_bf16: the gathered operand `in` (forward family) / the input operand x (rfx_gemm_wgrad) holds bf16 values -- tap-major
+   *          tiled kernels only;  out_bf16: `out` is written as bf16 (forward family, RNE; GroupNorm statistics of the epilogue
+   *          are those of the rounded values) / the gradient operand g of rfx_gemm_wgrad holds bf16 values.
+   * A tensor consumed only as a GEMM operand in bf16 mode loses nothing by being stored in 16 bits: the MFMA rounds it anyway. */
+  int32_t in_bf16, out_bf16;
 } rfx_gemm_desc;
 
 /* Epilogue: v = acc + bias[m]; v = act(v); [second GEMM phase accumulates into
@@ -253,6 +259,11 @@ int rfx_add_bcast(const float* x, const float* y, float* out, int64_t N, int32_t
 int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv, void* stream);
 int rfx_row_affine(const float* x, const float* a, const float* b, float* out, int32_t R, int64_t L, void* stream);
 
+/* Inverted dropout with a counter-based mask (keep(i) = u24(splitmix64(seed, i)) >= p; out = x / (1 - p) or 0); the backward pass
+ * is the same call on the gradient with the same seed.  Replaces F.dropout(train=True) in Cnn14 (classifier.py:211-284) and the
+ * inter-layer dropout of Open-Unmix's nn.LSTM (models.py:298; un-vendored open-unmix 1.2.1).  0 <= p < 1. */
+int rfx_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream);
+
 /* x[r][f][t] = 0 where f0[r] <= f < f1[r] or t0[r] <= t < t1[r], in place; x: (R, F, T) contiguous.
  * torchaudio FrequencyMasking / TimeMasking (iid masks) as Cnn14 applies them in training when specaugment is set:
  * classifier.py:185-187, 198-204.  Span bounds are R-length int32 device vectors drawn by the caller. */
@@ -281,6 +292,17 @@ int rfx_localstate_bwd(const float* q, const float* k, const float* cont, const 
                        const float* gout, int32_t B, int32_t heads, int32_t ch, int32_t T, int32_t nd, float* dq, float* dk,
                        float* dcont, float* dqd, void* stream);
 
+/* The same operator on the bf16 matrix pipe (bf16 arithmetic mode = torch autocast: both products on bf16 operands, fp32
+ * accumulation, fp32 softmax): flash-style, the (T, T) weights stay in registers and are recomputed in the backward pass, so
+ * there is no w tensor.  ch in {16, 32, 48, 64, 96}, T <= 256, nd <= 8; rfx_localstate_mfma_ok returns 1 for supported shapes
+ * (callers fall back to rfx_localstate_fwd / bwd otherwise). */
+int rfx_localstate_mfma_ok(int32_t B, int32_t heads, int32_t ch, int32_t T, int32_t nd);
+int rfx_localstate_mfma_fwd(const float* q, const float* k, const float* cont, const float* qd, int32_t B, int32_t heads,
+                            int32_t ch, int32_t T, int32_t nd, float* out, void* stream);
+int rfx_localstate_mfma_bwd(const float* q, const float* k, const float* cont, const float* qd, const float* gout, int32_t B,
+                            int32_t heads, int32_t ch, int32_t T, int32_t nd, float* dq, float* dk, float* dcont, float* dqd,
+                            float* stat /* workspace, B*heads*T*4 floats, 16-byte aligned */, void* stream);
+
 /* ---- GroupNorm (+ fused activation) --------------------------------------------
  * x: (N, C, S) contiguous, G groups.  mode: 0 y = gn(x); 1 y = gelu(gn(x));
  * 2 y = glu(gn(x)) -> (N, C/2, S); 3 y = res + scale[c] * glu(gn(x))  (DConv tail).
@@ -298,6 +320,15 @@ int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
                       const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S, int32_t G,
                       int32_t mode, const float* scale, float* work, float* dx, float* dgamma, float* dbeta,
                       float* dscale, void* stream);
+
+/* The same two calls with x -- and, in the backward pass, dx -- STORED as bf16 (a conv output of the bf16 arithmetic mode that
+ * only this norm and GEMM operands ever read); y, res, gy stay fp32.  S % 4 == 0. */
+int rfx_groupnorm_fwd_x16(const void* x, const float* gamma, const float* beta, int32_t N, int32_t C, int32_t S, int32_t G,
+                          float eps, int32_t mode, const float* res, const float* scale, double* sums, int32_t sums_given,
+                          float* mean, float* rstd, float* y, void* stream);
+int rfx_groupnorm_bwd_x16(const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                          const float* gy, int32_t N, int32_t C, int32_t S, int32_t G, int32_t mode, const float* scale,
+                          float* work, void* dx, float* dgamma, float* dbeta, float* dscale, void* stream);
 /* BatchNorm2d (+ReLU, mode 4) over (N, S) per channel -- classifier.py:271-272 (ConvBlock).
  * use_given_stats != 0: eval mode, mean = running_mean, rstd = 1/sqrt(running_var + eps) are inputs;
  * otherwise batch statistics are computed into mean / rstd (biased variance).  sums: C*2 fp64 workspace. */
@@ -316,6 +347,9 @@ int rfx_avgpool2d_bwd(const float* gy, float* gx, int64_t NC, int32_t H, int32_t
 /* GLU over the channel axis of (N, C, S): y = x[:, :C/2] * sigmoid(x[:, C/2:]) */
 int rfx_glu_fwd(const float* x, float* y, int64_t N, int64_t C, int64_t S, void* stream);
 int rfx_glu_bwd(const float* x, const float* gy, float* gx, int64_t N, int64_t C, int64_t S, void* stream);
+/* same with x (the conv output) and gx (its gradient) STORED as bf16 (bf16 arithmetic mode: both are only GEMM operands / GLU
+ * inputs); gy fp32; (C/2)*S a multiple of 4. */
+int rfx_glu_bwd_bf16(const void* x, const float* gy, void* gx, int64_t N, int64_t C, int64_t S, void* stream);
 
 /* ---- complex-valued pieces of DCUNet (asteroid DCUNet via models.py:347-367) -------
  * Complex tensors are real tensors (N, 2C, S): channels [0,C) real parts, [C,2C) imaginary parts; a complex

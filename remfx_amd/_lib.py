@@ -74,7 +74,8 @@ class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "M", "K", "OA", "OB", "IA", "IB", "SA", "SB", "Mpad",
                                          "Kpad", "out_a0", "out_b0", "out_sa", "out_sb", "R", "mg_log", "mg_axis", "mg_len", "mg_off",
                                          "Kpad_t", "gpt", "ntaps", "gpt2")] + \
-               [(n, C.c_int64) for n in ("in_ns", "in_as", "in_bs", "out_ns", "out_cs", "out_as", "out_bs", "in_cs", "in_extent")]
+               [(n, C.c_int64) for n in ("in_ns", "in_as", "in_bs", "out_ns", "out_cs", "out_as", "out_bs", "in_cs", "in_extent")] + \
+               [("in_bf16", C.c_int32), ("out_bf16", C.c_int32)]
 
 
 class Epilogue(C.Structure):
@@ -113,6 +114,8 @@ SIGNATURES = {
     "rfx_adamw_step": [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P, _P],
     "rfx_groupnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
     "rfx_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "rfx_groupnorm_fwd_x16": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
+    "rfx_groupnorm_bwd_x16": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rfx_batchnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, C.c_float, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_batchnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_avgpool2d_fwd": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P],
@@ -127,6 +130,7 @@ SIGNATURES = {
     "rfx_phase_mask_bwd": [_P, _P, _P, _I64, _P],
     "rfx_glu_fwd": [_P, _P, _I64, _I64, _I64, _P],
     "rfx_glu_bwd": [_P, _P, _P, _I64, _I64, _I64, _P],
+    "rfx_glu_bwd_bf16": [_P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_act_fwd": [_P, _P, _I64, _I32, _P],
     "rfx_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "rfx_act_rows": [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P],
@@ -135,8 +139,12 @@ SIGNATURES = {
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_localstate_mfma_ok": [_I32, _I32, _I32, _I32, _I32],
+    "rfx_localstate_mfma_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P],
+    "rfx_localstate_mfma_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P],
     "rfx_blstm_frames": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "rfx_span_mask": [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_dropout": [_P, _P, _I64, C.c_float, C.c_uint64, _P],
     "rfx_row_moments": [_P, _I32, _I64, _P, _P, _P, _P],
     "rfx_row_affine": [_P, _P, _P, _P, _I32, _I64, _P],
     "rfx_lstm_pack_bytes": [_I32],

@@ -141,11 +141,11 @@ class Cnn14(nn.Module):
         x = (x - x.mean(dim=(2, 3), keepdim=True)) / x.std(dim=(2, 3), keepdim=True)
         for i in range(1, 7):
             x = getattr(self, f"conv_block{i}")(x, pool_size=(2, 2) if i < 6 else (1, 1), pool_type="avg")
-            x = F.dropout(x, p=0.2, training=train)
+            x = nnops.dropout(x, 0.2, train)
         x = torch.mean(x, dim=3)
         (x1, _) = torch.max(x, dim=2)
         x = x1 + torch.mean(x, dim=2)
-        x = F.dropout(x, p=0.5, training=train)
+        x = nnops.dropout(x, 0.5, train)
         x = ops.activation(nnops.linear(x, self.fc1.weight, self.fc1.bias), "relu")
         w = torch.cat([h.weight for h in self.heads], 0)                         # (num_classes, 2048)
         b = torch.cat([h.bias for h in self.heads], 0)

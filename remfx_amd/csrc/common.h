@@ -8,6 +8,28 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// bf16 STORAGE of activations (bf16 arithmetic mode): 16 stored bits per value, RNE on store, exact widening on load
+struct rfx_bf16s { uint16_t v; };
+__device__ __forceinline__ uint32_t rfx_bf16_bits(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float rfx_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float rfx_ld1(const rfx_bf16s* p) { return __uint_as_float((uint32_t)p->v << 16); }
+__device__ __forceinline__ void rfx_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void rfx_st1(rfx_bf16s* p, float v) { p->v = (uint16_t)rfx_bf16_bits(v); }
+__device__ __forceinline__ f32x4 rfx_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 rfx_ld4(const rfx_bf16s* p) {          // 4 values = 8 bytes (8-byte aligned)
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+               __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void rfx_st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void rfx_st4(rfx_bf16s* p, const f32x4& v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(rfx_bf16_bits(v[0]) | (rfx_bf16_bits(v[1]) << 16),
+                                            rfx_bf16_bits(v[2]) | (rfx_bf16_bits(v[3]) << 16));
+}
+
 #define RFX_CHECK_LAUNCH()                                  \
   do {                                                      \
     hipError_t e_ = hipGetLastError();                      \

@@ -444,3 +444,29 @@ extern "C" int rfx_row_affine(const float* x, const float* a, const float* b, fl
   RFX_CHECK_LAUNCH();
   return 0;
 }
+
+// Inverted dropout, out[i] = keep(i) ? x[i] / (1 - p) : 0, with a COUNTER-BASED mask: keep(i) = u(seed, i) >= p where u is
+// the top 24 bits of splitmix64(seed + i).  No mask tensor: the backward pass is the same launch on the gradient with the
+// same seed.  (nn.LSTM inter-layer dropout of Open-Unmix, F.dropout in Cnn14 with train=True: classifier.py:211-284 /
+// the un-vendored open-unmix; the reference draws from torch's Philox stream -- same distribution, different draws.)
+__device__ __forceinline__ float dropout_u(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + 0x9e3779b97f4a7c15ull * (i + 1);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float p, float inv_keep,
+                               uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = dropout_u(seed, (uint64_t)i) >= p ? x[i] * inv_keep : 0.f;
+}
+extern "C" int rfx_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream) {
+  if (!x || !out || n < 0 || !(p >= 0.f) || !(p < 1.f)) return -1;
+  if (n == 0) return 0;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, out, n, p,
+                     1.0f / (1.0f - p), seed);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

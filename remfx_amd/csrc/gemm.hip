@@ -193,6 +193,10 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
                       d->mg_log)) return -1;
   if (d->mg_log && (d->R == 0 || g.e.bwd || g.e.res || g.e.act2 != RFX_ACT_NONE || g.e.stat_sums || apack2 ||
                     d->mg_log > 8 || d->mg_axis < 0 || d->mg_axis > 1)) return -1;
+  // bf16 storage of single operands: gathered input on the tap-major tiled kernels of the bf16 mode; output wherever the
+  // plain / GLU store runs (not the phase-merged, backward-epilogue or thin paths)
+  if (d->in_bf16 && (prec != 2 || d->R == 0)) return -1;
+  if (d->out_bf16 && (d->R == 0 || d->mg_log || g.e.bwd || g.e.res)) return -1;
   g.apack2 = apack2; g.ktab2 = ktab2; g.Kpad2 = apack2 ? Kpad2 : 0; g.in2 = in2;
   g.ntaps2 = apack2 ? K2 : 0;      // tap-major launches pass the second phase's tap count in K2
   const int P = d->OA * d->OB;

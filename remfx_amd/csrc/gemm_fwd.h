@@ -274,6 +274,7 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
   struct { bool jvalid; } c = {tc.jvalid};
   const int64_t opos = (int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
   float* outp = g.out + (int64_t)n * d.out_ns + opos;
+  uint16_t* outh = reinterpret_cast<uint16_t*>(g.out) + (int64_t)n * d.out_ns + opos;      // d.out_bf16: same element offsets
   const float* resp = nullptr;
   if (e.res)
     resp = e.res + (int64_t)n * e.res_ns + (int64_t)(a * d.out_sa + d.out_a0) * e.res_as +
@@ -349,9 +350,16 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
           const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (m < d.M) {
             const int ch = m >> 1;
-            const float a = acc[mt][r], b = acc[mt][r + 1];
-            outp[(int64_t)ch * d.out_cs] = a;
-            outp[(int64_t)(Ch + ch) * d.out_cs] = b;
+            float a = acc[mt][r], b = acc[mt][r + 1];
+            if (d.out_bf16) {      // conv output kept in 16 bits (wave-uniform); the GLU is taken of the STORED values, as the
+              const uint32_t ab = bf16_rne(a), bb = bf16_rne(b);     // backward pass will see them
+              outh[(int64_t)ch * d.out_cs] = (uint16_t)ab;
+              outh[(int64_t)(Ch + ch) * d.out_cs] = (uint16_t)bb;
+              a = __uint_as_float(ab << 16); b = __uint_as_float(bb << 16);
+            } else {
+              outp[(int64_t)ch * d.out_cs] = a;
+              outp[(int64_t)(Ch + ch) * d.out_cs] = b;
+            }
             gl[(int64_t)ch * d.out_cs] = a * rfx_sigmoid(b);
           }
         }
@@ -385,8 +393,14 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < d.M) {
-          const float v = acc[mt][r];
-          outp[(int64_t)m * d.out_cs] = v;
+          float v = acc[mt][r];
+          if (d.out_bf16) {        // wave-uniform; statistics are those of the stored (rounded) values
+            const uint32_t vb = bf16_rne(v);
+            outh[(int64_t)m * d.out_cs] = (uint16_t)vb;
+            v = __uint_as_float(vb << 16);
+          } else {
+            outp[(int64_t)m * d.out_cs] = v;
+          }
           s1 += v; s2 += v * v;
         }
       }

@@ -57,23 +57,36 @@ __device__ __forceinline__ bf16x8 round8(const float (&x)[8]) {
   return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
 }
 
+// eight zero-extended bf16 bit patterns (gather8_tap<true>) -> one B fragment
+__device__ __forceinline__ bf16x8 bf16_pack8(const float (&x)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = __float_as_uint(x[2 * q]) | (__float_as_uint(x[2 * q + 1]) << 16);
+  return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+}
+
 // The 8 gathers of one lane for one K step + advance of its (tap, group) position by two groups.
 // gstep = 16 channel strides (two groups), gwrap = gpt * 8 channel strides (one tap), both in bytes.
 // Branch-free on purpose: with a plain `ok ? offset : OOB` hipcc sank the offset arithmetic AND the table read into a
 // branch (s_and_saveexec + ds_read + lgkmcnt(0) per K step); the empty asm makes the offset opaque, so it is computed
 // unconditionally and the select stays a v_cndmask.  A masked lane must get EXACTLY 2^31: its raw offset may be
 // "negative" (taps left of the row start), and 0xfffffff0 + i * cs4 would wrap back into the sample.
+template <bool IN16 = false>
 __device__ __forceinline__ void gather8_tap(const rfx_gemm_desc& d, const int4* taps, uint32_t cs4, uint32_t gstep,
                                             uint32_t gwrap, TapLane& c, float (&b)[8]) {
   const int4 e = taps[c.t];          // (offset of channel 0, da, db, -): two distinct addresses per wave
   const bool ok = ((unsigned)(c.ia0 + e.y) < (unsigned)d.IA) & ((unsigned)(c.ib0 + e.z) < (unsigned)d.IB);
-  uint32_t off = c.voff + ((uint32_t)e.x << 2) + c.goff;
+  uint32_t off = c.voff + ((uint32_t)e.x << (IN16 ? 1 : 2)) + c.goff;     // cs4 / gstep / gwrap / voff are BYTE quantities of the operand's type
   asm volatile("" : "+v"(off));
   // bit 31 set = beyond num_records (one sample spans < 2 GiB) = the load returns 0 and touches nothing
   const uint32_t base = ok ? off : RFX_BUF_OOB;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, base + (uint32_t)i * cs4, 0, 0));
+  for (int i = 0; i < 8; ++i) {
+    if (IN16)      // bf16 operand: the 16 stored bits, zero-extended; bf16_pack8 pairs them up without any conversion
+      b[i] = __uint_as_float((uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(c.rs, base + (uint32_t)i * cs4, 0, 0));
+    else
+      b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, base + (uint32_t)i * cs4, 0, 0));
+  }
   c.goff += gstep;
   bool w = c.goff >= gwrap;          // gpt >= 1: at most two wraps
   c.goff -= w ? gwrap : 0u; c.t += w ? 1 : 0;
@@ -117,7 +130,7 @@ __device__ __forceinline__ void tap_a_store(uint4* as, int tid, const AStage& s)
 //   global -> registers: A tile of step ks+4 (into the register set that held A(ks+2)), gathers of step ks+3;
 //   MFMAs;  registers -> LDS: A(ks+2) into the OTHER buffer;  barrier if SUB.
 // Everything written in steps {2D, 2D+1} is first read in step 2D+2, i.e. behind the barrier that ends step 2D+1.
-template <int R, int MODE, int SUB>
+template <int R, int MODE, int SUB, bool IN16 = false>
 __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* __restrict__ apk, int64_t arr_stride,
                                            const int4* taps, uint32_t cs4, uint32_t gstep, uint32_t gwrap, int ks, int m0, TapLane& c,
                                            uint4* as, f32x16 (&acc)[R], const float (&bc)[8], float (&bn)[8],
@@ -137,7 +150,7 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
   // RFX_BDIST steps later, go last and stay in flight
   const AStage a_now = a_set;                                         // A(ks+2), fetched two steps ago
   a_set = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2 * (ks + 4), m0, tid);
-  gather8_tap(d, taps, cs4, gstep, gwrap, c, bn);
+  gather8_tap<IN16>(d, taps, cs4, gstep, gwrap, c, bn);
   if (MODE == 1) {
     bf16x8 bh, bl;
     split8(bc, bh, bl);
@@ -149,7 +162,7 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
       acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc[mt], 0, 0, 0);
     }
   } else {
-    const bf16x8 bh = round8(bc);
+    const bf16x8 bh = IN16 ? bf16_pack8(bc) : round8(bc);
 #pragma unroll
     for (int mt = 0; mt < R; ++mt)
       acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), bh, acc[mt], 0, 0, 0);
@@ -159,7 +172,7 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
   else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // keep the two steps apart in the compiler too
 }
 
-template <int R, int MODE>
+template <int R, int MODE, bool IN16 = false>
 __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const float* __restrict__ apack,
                                               const rfx_ktab_entry* __restrict__ tap_tab, int ntaps, int gpt, int Kpad, int m0,
                                               TapLane c, uint4* as, int4* taps, f32x16 (&acc)[R]) {
@@ -170,7 +183,7 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
   if (nk == 0) return;
   const uint4* apk = reinterpret_cast<const uint4*>(apack);
   const int64_t arr_stride = (int64_t)(Kpad / 8 + 8) * d.Mpad;
-  const uint32_t cs4 = (uint32_t)(d.in_cs * 4);
+  const uint32_t cs4 = (uint32_t)(d.in_cs * (IN16 ? 2 : 4));
   const uint32_t gstep = 16u * cs4, gwrap = (uint32_t)gpt * 8u * cs4;
   __syncthreads();            // a previous phase (two-phase launches) may still be reading the LDS buffers / tap table
   {
@@ -188,22 +201,22 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
   float b0[8], b1[8], b2[8], b3[8];
   AStage a0 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 4, m0, tid);          // A(2), A(3): even / odd register set
   AStage a1 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 6, m0, tid);
-  gather8_tap(d, taps, cs4, gstep, gwrap, c, b0);
-  gather8_tap(d, taps, cs4, gstep, gwrap, c, b1);
-  gather8_tap(d, taps, cs4, gstep, gwrap, c, b2);
+  gather8_tap<IN16>(d, taps, cs4, gstep, gwrap, c, b0);
+  gather8_tap<IN16>(d, taps, cs4, gstep, gwrap, c, b1);
+  gather8_tap<IN16>(d, taps, cs4, gstep, gwrap, c, b2);
   int ks = 0;
   for (; ks + 3 < nk; ks += 4) {
-    k_step_tap<R, MODE, 0>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, m0, c, as, acc, b0, b3, a0);
-    k_step_tap<R, MODE, 1>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, m0, c, as, acc, b1, b0, a1);
-    k_step_tap<R, MODE, 0>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
-    k_step_tap<R, MODE, 1>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 3, m0, c, as, acc, b3, b2, a1);
+    k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, m0, c, as, acc, b0, b3, a0);
+    k_step_tap<R, MODE, 1, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, m0, c, as, acc, b1, b0, a1);
+    k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
+    k_step_tap<R, MODE, 1, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 3, m0, c, as, acc, b3, b2, a1);
   }
-  if (ks < nk) k_step_tap<R, MODE, 0>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, m0, c, as, acc, b0, b3, a0);
-  if (ks + 1 < nk) k_step_tap<R, MODE, 1>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, m0, c, as, acc, b1, b0, a1);
-  if (ks + 2 < nk) k_step_tap<R, MODE, 0>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
+  if (ks < nk) k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, m0, c, as, acc, b0, b3, a0);
+  if (ks + 1 < nk) k_step_tap<R, MODE, 1, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, m0, c, as, acc, b1, b0, a1);
+  if (ks + 2 < nk) k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
 }
 
-template <int R, int MODE>
+template <int R, int MODE, bool IN16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tap_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
   __shared__ __attribute__((aligned(16))) uint4 smem[4 * CELLS + RFX_TAP_LDS];   // A: 2 buffers x 2 K steps; tap table
@@ -234,8 +247,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_kernel(const FwdArgs g) {
   const int ia0 = tc.a * d.SA, ib0 = tc.b * d.SB;
   c.ia0 = tc.jvalid ? ia0 : (1 << 30);
   c.ib0 = ib0;
-  c.voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * 4);
-  c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.in + (int64_t)n * d.in_ns), 0, (int)d.in_extent, 0x00020000);
+  constexpr int ESZ = IN16 ? 2 : 4;                               // bytes per element of the gathered operand
+  c.voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * ESZ);
+  c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.in) + (int64_t)n * d.in_ns * ESZ), 0,
+                                           (int)d.in_extent, 0x00020000);
   c.t = 0; c.goff = 0;
 
   f32x16 acc[R];
@@ -244,12 +259,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_kernel(const FwdArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  run_phase_tap<R, MODE>(d, g.apack, g.ktab, d.ntaps, d.gpt, d.Kpad_t, m0, c, as, taps, acc);
+  run_phase_tap<R, MODE, IN16>(d, g.apack, g.ktab, d.ntaps, d.gpt, d.Kpad_t, m0, c, as, taps, acc);
   fwd_epilogue_mid<R>(g, tc, acc);
   if (g.apack2 != nullptr) {
-    if (g.in2) c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.in2 + (int64_t)n * d.in_ns), 0,
+    if (g.in2) c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.in2) + (int64_t)n * d.in_ns * ESZ), 0,
                                                         (int)d.in_extent, 0x00020000);
-    run_phase_tap<R, MODE>(d, g.apack2, g.ktab2, g.ntaps2, d.gpt2 > 0 ? d.gpt2 : d.gpt, g.Kpad2, m0, c, as, taps, acc);
+    run_phase_tap<R, MODE, IN16>(d, g.apack2, g.ktab2, g.ntaps2, d.gpt2 > 0 ? d.gpt2 : d.gpt, g.Kpad2, m0, c, as, taps, acc);
   }
   fwd_epilogue_store<R>(g, tc, acc);
 }
@@ -366,7 +381,7 @@ static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s
   // short single-phase reductions with enough position tiles to keep persistent workgroups busy: streaming kernel
   static const int stream_off = getenv("RFX_GEMM_STREAM") ? !atoi(getenv("RFX_GEMM_STREAM")) : 0;   // RFX_GEMM_STREAM=0: A/B switch
   const int64_t work = (int64_t)((g.d.OA * g.d.OB + 127) / 128) * g.d.N;
-  if (!stream_off && g.d.Kpad_t <= 64 && g.apack2 == nullptr && work >= 4096 && r == 1 && g.e.act == RFX_ACT_NONE &&
+  if (!stream_off && !g.d.in_bf16 && g.d.Kpad_t <= 64 && g.apack2 == nullptr && work >= 4096 && r == 1 && g.e.act == RFX_ACT_NONE &&
       g.e.act2 == RFX_ACT_NONE && !g.e.bwd && g.d.mg_log == 0 && !g.e.res) {
     const int mtiles = g.d.Mpad / 32;
     int nw = (512 / mtiles) & ~7;                                // persistent workgroups per channel tile (2 per CU in all),
@@ -374,6 +389,17 @@ static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s
     dim3 sg((unsigned)(nw * mtiles));
     if (g.d.Kpad_t <= 16) hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 4, 1>), sg, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 2, 4>), sg, dim3(256), 0, s, g);
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
+  if (g.d.in_bf16) {                                             // bf16 STORAGE of the gathered operand (bf16 mode only)
+    if (MODE != 2) return -1;
+    switch (r) {
+      case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, true>), grid, dim3(256), 0, s, g); break;
+      case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, true>), grid, dim3(256), 0, s, g); break;
+      case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, true>), grid, dim3(256), 0, s, g); break;
+      default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, true>), grid, dim3(256), 0, s, g); break;
+    }
     RFX_CHECK_LAUNCH();
     return 0;
   }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
 // negative offset would fail the whole dwordx4 range check, scripts/probes/bufprobe.hip); elements right of the row
 // end / beyond OB are zeroed after the load; rows whose a-coordinate is out of range load nothing (offset 2^31).
 // ---------------------------------------------------------------------------------
-template <int TM, int TK, int WM, int MODE>
+template <int TM, int TK, int WM, int MODE, bool G16 = false>     // G16: the gradient operand g is stored as bf16 (bf16 mode only)
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_wide_kernel(const WgradArgs w) {
   constexpr int WK = 4 / WM;
   constexpr int RM = 32 * WM * TM, RK = 32 * WK * TK, LDW = 72, PC = 64;
@@ -243,18 +243,26 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_wide_kernel(const WgradArgs
     // beyond it (per-dword range check) instead of touching memory behind the allocation
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.in + (int64_t)n * d.in_ns), 0,
                                                                          (int)w.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.g + (int64_t)n * d.out_ns), 0,
-                                                                         (int)w.g_bytes, 0x00020000);
+    constexpr int GSZ = G16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(w.g) + (int64_t)n * d.out_ns * GSZ), 0, (int)w.g_bytes, 0x00020000);
     const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(ob + d.out_b0) +
-                                      (int64_t)(m0 + r0) * d.out_cs) * 4);
-    const uint32_t gstep = (uint32_t)(16 * d.out_cs * 4);
+                                      (int64_t)(m0 + r0) * d.out_cs) * GSZ);
+    const uint32_t gstep = (uint32_t)(16 * d.out_cs * GSZ);
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
       const bool ok = (lim > 0) & (m0 + r0 + 16 * i < d.M);
-      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
+      if (G16) {                                                   // 4 positions = 8 bytes, already bf16: no conversion at staging
+        uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
+        u.x = lim > 1 ? u.x : (u.x & 0xffffu);                     // a row end inside the quad
+        u.y = lim > 3 ? u.y : (lim > 2 ? (u.y & 0xffffu) : 0u);
+        st.gv[i] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
+      } else {
+        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
 #pragma unroll
-      for (int e = 1; e < 4; ++e) v[e] = e < lim ? v[e] : 0.f;     // a row end inside the quad (OA == 1, OB % 4 != 0)
-      st.gv[i] = v;
+        for (int e = 1; e < 4; ++e) v[e] = e < lim ? v[e] : 0.f;   // a row end inside the quad (OA == 1, OB % 4 != 0)
+        st.gv[i] = v;
+      }
     }
     const int ia0 = a * d.SA;
     const uint32_t voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ob) * 4);
@@ -296,7 +304,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_wide_kernel(const WgradArgs
   };
   auto stage = [&](const Stage& st) {
 #pragma unroll
-    for (int i = 0; i < NG; ++i) put4(gs_hi, gs_lo, r0 + 16 * i, st.gv[i]);
+    for (int i = 0; i < NG; ++i) {
+      if (G16) *reinterpret_cast<uint2*>(gs_hi + (r0 + 16 * i) * LDW + q4) = make_uint2(__float_as_uint(st.gv[i][0]), __float_as_uint(st.gv[i][1]));
+      else put4(gs_hi, gs_lo, r0 + 16 * i, st.gv[i]);
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) put4(xs_hi, xs_lo, r0 + 16 * i, st.xv[i]);
   };
@@ -370,6 +381,19 @@ static int rfx_launch_wgrad_bf(const WgradArgs& w, int shape, dim3 grid, hipStre
 // wide-load kernel, shape: 0 = 96 x 128 (waves 1 x 4), 1 = 32 x 256, 2 = 32 x 128, 3 = 128 x 128, 4 = 64 x 128, 5 = 96 x 256
 template <int MODE>
 static int rfx_launch_wgrad_wide(const WgradArgs& w, int shape, dim3 grid, hipStream_t s) {
+  if (w.d.out_bf16) {
+    if (MODE != 2) return -1;
+    switch (shape) {
+      case 0: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<3, 1, 1, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 1: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 2, 1, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 2: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 1, 1, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 3: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 5: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<3, 2, 1, 2, true>), grid, dim3(256), 0, s, w); break;
+      default: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 2, 2, 2, true>), grid, dim3(256), 0, s, w); break;
+    }
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   switch (shape) {
     case 0: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<3, 1, 1, MODE>), grid, dim3(256), 0, s, w); break;
     case 1: hipLaunchKernelGGL((gemm_wgrad_wide_kernel<1, 2, 1, MODE>), grid, dim3(256), 0, s, w); break;

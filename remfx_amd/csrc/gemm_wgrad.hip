@@ -196,6 +196,8 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
                               const float* gout, float* dapack, int32_t prec, void* stream) {
   if (!desc_ok(d) || !ktab || !in || !gout || !dapack) return -1;
   if (d->K == 0) return 0;
+  if (d->in_bf16) return -1;                          // bf16 storage is implemented for the gradient operand only (wide kernel)
+  if (d->out_bf16 && (prec != 2 || d->M <= 8 || ((d->out_b0 | d->out_cs | d->out_as | d->out_ns) & 1))) return -1;
   WgradArgs w;
   w.d = *d; w.ktab = ktab; w.in = in; w.g = gout; w.dapack = dapack;
   const int P = d->OA * d->OB;
@@ -217,7 +219,7 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   // wide-load kernel (gemm_wgrad.h): both operands contiguous and unit-stride along b, quads never straddle an output row
   static const int wide_off = getenv("RFX_WGRAD_WIDE") ? !atoi(getenv("RFX_WGRAD_WIDE")) : 0;     // RFX_WGRAD_WIDE=0: A/B switch
   const int64_t g_span = ((int64_t)(d->M - 1) * llabs(d->out_cs) + ((int64_t)(d->OA - 1) * d->out_sa + d->out_a0) * llabs(d->out_as) +
-                          (d->OB - 1 + d->out_b0) + 1) * 4;
+                          (d->OB - 1 + d->out_b0) + 1) * (d->out_bf16 ? 2 : 4);
   if (prec != 0 && !wide_off && d->SB == 1 && d->in_bs == 1 && d->out_bs == 1 && d->out_sb == 1 &&
       (d->OA == 1 || d->OB % 4 == 0) && d->in_extent > 0 && d->in_extent <= 0x7fffffffLL && g_span <= 0x7fffffffLL &&
       d->out_cs >= 0 && d->out_as >= 0) {
@@ -245,6 +247,7 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     dim3 grid = w.xcd_grouped ? dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1) : dim3(kt, mt, splits);
     return prec == 1 ? rfx_launch_wgrad_wide_bf3(w, shape, grid, s) : rfx_launch_wgrad_wide_bf16(w, shape, grid, s);
   }
+  if (d->out_bf16) return -1;                             // callers convert to fp32 for plans the wide kernel does not take
   const bool narrow = prec != 0 && d->M <= 32;            // 32 x (128 tk) tiles, waves 1 x 4 (see gemm_wgrad_bf3_kernel)
   // 96-row tiles (waves 1 x 4, three 32-row MFMA tiles each) when they pad M less than 128-row ones: M = 96, 192, 288
   const bool rows96 = prec != 0 && d->M > 64 && d->K > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;

@@ -28,7 +28,23 @@ struct GnArgs {
   int N, C, S, G, mode;
   float eps;
   int bn;
+  int x16;              // bf16 STORAGE of x (forward input) and, in the backward pass, of dx as well (bf16 arithmetic mode)
 };
+
+// element pointers with widening loads / rounding stores: x[i], dx[i] = v keep their syntax for both storage types
+template <typename XT> struct GnXPtr {
+  const XT* p;
+  __device__ __forceinline__ float operator[](int64_t i) const { return rfx_ld1(p + i); }
+  __device__ __forceinline__ GnXPtr operator+(int64_t o) const { return GnXPtr{p + o}; }
+};
+template <typename XT> struct GnDxPtr {
+  XT* p;
+  struct Ref { XT* q; __device__ __forceinline__ void operator=(float v) const { rfx_st1(q, v); } };
+  __device__ __forceinline__ Ref operator[](int64_t i) const { return Ref{p + i}; }
+  __device__ __forceinline__ GnDxPtr operator+(int64_t o) const { return GnDxPtr{p + o}; }
+};
+template <typename XT> __device__ __forceinline__ GnXPtr<XT> gn_xp(const GnArgs& a) { return GnXPtr<XT>{reinterpret_cast<const XT*>(a.x)}; }
+template <typename XT> __device__ __forceinline__ GnDxPtr<XT> gn_dxp(const GnArgs& a) { return GnDxPtr<XT>{reinterpret_cast<XT*>(a.y)}; }
 
 __device__ __forceinline__ int gn_sidx(const GnArgs& a, int n, int ch) {
   return a.bn ? ch : n * a.G + ch / (a.C / a.G);
@@ -40,6 +56,7 @@ __device__ __forceinline__ int gn_sidx(const GnArgs& a, int n, int ch) {
 // left the first case at 64 workgroups on 256 CUs (rocprof r1a: 30 % of the Demucs step).
 constexpr int GN_CHUNK = 4096;
 
+template <typename XT>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* __restrict__ sums, int nchunks) {
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,17 +65,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* _
   const int sc = (int)(item % nchunks);
   const int64_t r = item / nchunks;           // n*C + ch
   const int ch = (int)(r % a.C), n = (int)(r / a.C);
-  const float* xr = a.x + r * a.S;
+  const XT* xr = reinterpret_cast<const XT*>(a.x) + r * a.S;
   const int64_t s0 = (int64_t)sc * GN_CHUNK, s1 = min(s0 + GN_CHUNK, (int64_t)a.S);
   float p = 0.f, q = 0.f;
   if ((a.S & 3) == 0) {      // rows are 16-byte aligned: one dwordx4 per lane
     for (int64_t s = s0 + 4 * lane; s < s1; s += 256) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xr + s);
+      const f32x4 v = rfx_ld4(xr + s);
       p += (v[0] + v[1]) + (v[2] + v[3]);
       q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
   } else {
-    for (int64_t s = s0 + lane; s < s1; s += 64) { const float v = xr[s]; p += v; q += v * v; }
+    for (int64_t s = s0 + lane; s < s1; s += 64) { const float v = rfx_ld1(xr + s); p += v; q += v * v; }
   }
   const double dp = rfx_wave_sum_d((double)p), dq = rfx_wave_sum_d((double)q);
   if (lane == 0) {
@@ -154,11 +171,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
 // channels (group sums) and over samples (dgamma / dbeta / dscale): no hot atomics.
 struct GnDu { float du_a, xh_a, du_b, xh_b, gf; };
 
+template <typename XT = float>
 __device__ __forceinline__ GnDu gn_du_pair(const GnArgs& a, int n, int co, int64_t s) {
   GnDu r;
   const int Co = a.C / 2;
   const int ga = gn_sidx(a, n, co), gb = gn_sidx(a, n, co + Co);
-  const float xa = a.x[((int64_t)n * a.C + co) * a.S + s], xb = a.x[((int64_t)n * a.C + co + Co) * a.S + s];
+  const GnXPtr<XT> X = gn_xp<XT>(a);
+  const float xa = X[((int64_t)n * a.C + co) * a.S + s], xb = X[((int64_t)n * a.C + co + Co) * a.S + s];
   r.xh_a = (xa - a.mean[ga]) * a.rstd[ga];
   r.xh_b = (xb - a.mean[gb]) * a.rstd[gb];
   const float ua = r.xh_a * a.gamma[co] + a.beta[co], ub = r.xh_b * a.gamma[co + Co] + a.beta[co + Co];
@@ -171,10 +190,11 @@ __device__ __forceinline__ GnDu gn_du_pair(const GnArgs& a, int n, int co, int64
   return r;
 }
 
+template <typename XT = float>
 __device__ __forceinline__ float gn_du_single(const GnArgs& a, int n, int ch, int64_t s, float& xhat) {
   const int g = gn_sidx(a, n, ch);
   const int64_t i = ((int64_t)n * a.C + ch) * a.S + s;
-  xhat = (a.x[i] - a.mean[g]) * a.rstd[g];
+  xhat = (gn_xp<XT>(a)[i] - a.mean[g]) * a.rstd[g];
   const float g0 = a.gy[i];
   if (a.mode == GN_GELU) return g0 * rfx_gelu_grad(xhat * a.gamma[ch] + a.beta[ch]);
   if (a.mode == GN_RELU) return (xhat * a.gamma[ch] + a.beta[ch]) > 0.f ? g0 : 0.f;
@@ -182,6 +202,7 @@ __device__ __forceinline__ float gn_du_single(const GnArgs& a, int n, int ch, in
 }
 
 // part: (N, C, 2) = { sum du, sum du*xhat } per (n, channel);  psc: (N, C/2) = sum gy*f (mode 3)
+template <typename XT>
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const GnArgs a, float* __restrict__ part,
                                                              float* __restrict__ psc, int nchunks) {
   const int lane = threadIdx.x & 63;
@@ -197,13 +218,13 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const GnArgs a, flo
   float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (pair) {
     for (int64_t s = s0 + lane; s < s1; s += 64) {
-      const GnDu d = gn_du_pair(a, n, cw, s);
+      const GnDu d = gn_du_pair<XT>(a, n, cw, s);
       v[0] += d.du_a; v[1] += d.du_a * d.xh_a; v[2] += d.du_b; v[3] += d.du_b * d.xh_b; v[4] += d.gf;
     }
   } else {
     for (int64_t s = s0 + lane; s < s1; s += 64) {
       float xh;
-      const float du = gn_du_single(a, n, cw, s, xh);
+      const float du = gn_du_single<XT>(a, n, cw, s, xh);
       v[0] += du; v[1] += du * xh;
     }
   }
@@ -323,6 +344,7 @@ __device__ __forceinline__ GnRow gn_row_item(const GnArgs& a, int Cw, uint32_t n
 
 __device__ __forceinline__ f32x4 gn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+template <typename XT>
 __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const GnArgs a, uint32_t nitems, uint32_t ipr) {
   const bool glu = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
   const int Co = glu ? a.C / 2 : a.C;
@@ -331,15 +353,15 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const GnArgs a, uint
   const int n = it.n, c = it.c;
   const int ga = gn_sidx(a, n, c);
   const float ma = a.mean[ga], ra = a.rstd[ga] * a.gamma[c], ba = a.beta[c];
-  const float* xa = a.x + ((int64_t)n * a.C + c) * a.S + it.s;
+  const XT* xa = reinterpret_cast<const XT*>(a.x) + ((int64_t)n * a.C + c) * a.S + it.s;
   const int64_t oi = ((int64_t)n * Co + c) * a.S + it.s;
-  const f32x4 va = gn_ld4(xa);
+  const f32x4 va = rfx_ld4(xa);
   f32x4 vb = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
   float mb = 0.f, rb = 0.f, bb = 0.f, sc = 0.f;
   if (glu) {
     const int gb = gn_sidx(a, n, c + Co);
     mb = a.mean[gb]; rb = a.rstd[gb] * a.gamma[c + Co]; bb = a.beta[c + Co];
-    vb = gn_ld4(xa + (int64_t)Co * a.S);
+    vb = rfx_ld4(xa + (int64_t)Co * a.S);
     if (a.mode == GN_GLU_SCALE_RES) { sc = a.scale[c]; rs = gn_ld4(a.res + oi); }
   }
   f32x4 o;
@@ -357,6 +379,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const GnArgs a, uint
   *reinterpret_cast<f32x4*>(a.y + oi) = o;
 }
 
+template <typename XT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const GnArgs a, uint32_t nitems, uint32_t ipr) {
   const bool pair = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
   const int Cw = pair ? a.C / 2 : a.C, Cg = a.C / a.G;
@@ -366,9 +389,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const GnArgs a, 
   const float inv = a.bn ? 1.f / ((float)a.N * (float)a.S) : 1.f / ((float)Cg * (float)a.S);
   const int64_t xi = ((int64_t)n * a.C + cw) * a.S + it.s;
   const f32x4 g4 = gn_ld4(a.gy + ((int64_t)n * Cw + cw) * a.S + it.s);
-  const f32x4 xa = gn_ld4(a.x + xi);
+  const XT* X = reinterpret_cast<const XT*>(a.x);
+  XT* DX = reinterpret_cast<XT*>(a.y);
+  const f32x4 xa = rfx_ld4(X + xi);
   if (pair) {
-    const f32x4 xb = gn_ld4(a.x + xi + (int64_t)Cw * a.S);
+    const f32x4 xb = rfx_ld4(X + xi + (int64_t)Cw * a.S);
     const int ga = gn_sidx(a, n, cw), gb = gn_sidx(a, n, cw + Cw);
     const float mea = a.mean[ga], meb = a.mean[gb], ra = a.rstd[ga], rb = a.rstd[gb];
     const float m1a = a.gsum[2 * ga] * inv, m2a = a.gsum[2 * ga + 1] * inv;
@@ -386,8 +411,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const GnArgs a, 
       da[q] = ra * (dua * gma - m1a - xha * m2a);
       db[q] = rb * (dub * gmb - m1b - xhb * m2b);
     }
-    *reinterpret_cast<f32x4*>(a.y + xi) = da;
-    *reinterpret_cast<f32x4*>(a.y + xi + (int64_t)Cw * a.S) = db;
+    rfx_st4(DX + xi, da);
+    rfx_st4(DX + xi + (int64_t)Cw * a.S, db);
   } else {
     const int g = gn_sidx(a, n, cw);
     const float me = a.mean[g], rg = a.rstd[g], m1 = a.gsum[2 * g] * inv, m2 = a.gsum[2 * g + 1] * inv;
@@ -401,7 +426,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const GnArgs a, 
       else if (a.mode == GN_RELU) du = (xh * gm + bt) > 0.f ? du : 0.f;
       d[q] = rg * (du * gm - m1 - xh * m2);
     }
-    *reinterpret_cast<f32x4*>(a.y + xi) = d;
+    rfx_st4(DX + xi, d);
   }
 }
 
@@ -418,7 +443,7 @@ static int gn_grid(int64_t total) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-static int norm_fwd(int bn, int use_given_stats, int sums_given, const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
+static int norm_fwd(int x16, int bn, int use_given_stats, int sums_given, const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
                                  int32_t S, int32_t G, float eps, int32_t mode, const float* res,
                                  const float* scale, double* sums /* N*G*2 workspace */, float* mean,
                                  float* rstd, float* y, void* stream) {
@@ -428,7 +453,8 @@ static int norm_fwd(int bn, int use_given_stats, int sums_given, const float* x,
   if (mode == GN_GLU_SCALE_RES && (!res || !scale)) return -1;
   GnArgs a{};
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd; a.y = y; a.res = res; a.scale = scale;
-  a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode; a.eps = eps; a.bn = bn;
+  a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode; a.eps = eps; a.bn = bn; a.x16 = x16;
+  if (x16 && ((S & 3) || bn)) return -1;                   // bf16 storage: 8-byte vectors of 4 values, GroupNorm only
   const int nstat = bn ? C : N * G;
   hipStream_t s = (hipStream_t)stream;
   if (!use_given_stats) {
@@ -437,7 +463,8 @@ static int norm_fwd(int bn, int use_given_stats, int sums_given, const float* x,
     const int64_t nitems = (int64_t)N * C * nchunks;
     if (!sums_given) {
       if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * nstat, s) != hipSuccess) return -3;
-      hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, sums, nchunks);
+      if (x16) hipLaunchKernelGGL(gn_stats_kernel<rfx_bf16s>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, sums, nchunks);
+      else hipLaunchKernelGGL(gn_stats_kernel<float>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, sums, nchunks);
       RFX_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, sums, mean, rstd, nstat,
@@ -446,8 +473,10 @@ static int norm_fwd(int bn, int use_given_stats, int sums_given, const float* x,
   }
   const int64_t total = (int64_t)N * (glu ? C / 2 : C) * S;
   uint32_t nrow_items = 0, ipr = 0;
-  if (gn_row_items((int64_t)N * (glu ? C / 2 : C), S, &nrow_items, &ipr))
-    hipLaunchKernelGGL(gn_apply_rows_kernel, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+  if (gn_row_items((int64_t)N * (glu ? C / 2 : C), S, &nrow_items, &ipr)) {
+    if (x16) hipLaunchKernelGGL(gn_apply_rows_kernel<rfx_bf16s>, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+    else hipLaunchKernelGGL(gn_apply_rows_kernel<float>, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+  } else if (x16) return -1;
   else if ((S & 3) == 0) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(gn_grid(total / 4)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(gn_grid(total)), dim3(256), 0, s, a);
   RFX_CHECK_LAUNCH();
@@ -458,7 +487,15 @@ extern "C" int rfx_groupnorm_fwd(const float* x, const float* gamma, const float
                                  int32_t S, int32_t G, float eps, int32_t mode, const float* res,
                                  const float* scale, double* sums, int32_t sums_given, float* mean, float* rstd,
                                  float* y, void* stream) {
-  return norm_fwd(0, 0, sums_given, x, gamma, beta, N, C, S, G, eps, mode, res, scale, sums, mean, rstd, y, stream);
+  return norm_fwd(0, 0, 0, sums_given, x, gamma, beta, N, C, S, G, eps, mode, res, scale, sums, mean, rstd, y, stream);
+}
+// x stored as bf16 (a conv output of the bf16 arithmetic mode); y, res fp32.  S % 4 == 0.
+extern "C" int rfx_groupnorm_fwd_x16(const void* x, const float* gamma, const float* beta, int32_t N, int32_t C,
+                                     int32_t S, int32_t G, float eps, int32_t mode, const float* res,
+                                     const float* scale, double* sums, int32_t sums_given, float* mean, float* rstd,
+                                     float* y, void* stream) {
+  return norm_fwd(1, 0, 0, sums_given, static_cast<const float*>(x), gamma, beta, N, C, S, G, eps, mode, res, scale, sums, mean,
+                  rstd, y, stream);
 }
 // BatchNorm over (N, S) per channel.  use_given_stats: mean / rstd are inputs (eval mode:
 // running_mean, 1/sqrt(running_var + eps)); else batch statistics are computed and written.
@@ -466,7 +503,7 @@ extern "C" int rfx_batchnorm_fwd(const float* x, const float* gamma, const float
                                  int32_t S, float eps, int32_t mode, int32_t use_given_stats, double* sums,
                                  float* mean, float* rstd, float* y, void* stream) {
   if (mode != GN_NONE && mode != GN_RELU) return -1;
-  return norm_fwd(1, use_given_stats, 0, x, gamma, beta, N, C, S, C, eps, mode, nullptr, nullptr, sums, mean, rstd, y,
+  return norm_fwd(0, 1, use_given_stats, 0, x, gamma, beta, N, C, S, C, eps, mode, nullptr, nullptr, sums, mean, rstd, y,
                   stream);
 }
 
@@ -475,6 +512,7 @@ extern "C" int rfx_batchnorm_fwd(const float* x, const float* gamma, const float
 // then dx -- so the operands are re-read from L2 / Infinity Cache instead of HBM, there is no per-element index decoding
 // and the per-channel constants are loaded once per row.  The wave-per-(n, channel, chunk) kernels above spend most of
 // their time on row overhead at S = 256 (2.5 TB/s measured) and stay the path for large samples.
+template <typename XT>
 __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, float* __restrict__ part,
                                                             float* __restrict__ psc) {
   __shared__ float red[4][2];
@@ -482,9 +520,9 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, floa
   const bool pair = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
   const int Cw = pair ? a.C / 2 : a.C;
   const float mean = a.mean[n], rstd = a.rstd[n];
-  const float* xn = a.x + (int64_t)n * a.C * a.S;
+  const GnXPtr<XT> xn = gn_xp<XT>(a) + (int64_t)n * a.C * a.S;
   const float* gyn = a.gy + (int64_t)n * Cw * a.S;
-  float* dxn = a.y + (int64_t)n * a.C * a.S;
+  const GnDxPtr<XT> dxn = gn_dxp<XT>(a) + (int64_t)n * a.C * a.S;
   float gs1 = 0.f, gs2 = 0.f;
   // du of one element; pair modes return both halves (same formulas as gn_du_pair / gn_du_single)
   auto du_pair = [&](float xa, float xb, float g0, float ga, float ba, float gb, float bb, float sc, float& xha,
@@ -508,8 +546,8 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, floa
     if (pair) {
       const float ga = a.gamma[cw], ba = a.beta[cw], gb = a.gamma[cw + Cw], bb = a.beta[cw + Cw];
       const float sc = a.mode == GN_GLU_SCALE_RES ? a.scale[cw] : 1.f;
-      const float* xa = xn + (int64_t)cw * a.S;
-      const float* xb = xn + (int64_t)(cw + Cw) * a.S;
+      const GnXPtr<XT> xa = xn + (int64_t)cw * a.S;
+      const GnXPtr<XT> xb = xn + (int64_t)(cw + Cw) * a.S;
       const float* gr = gyn + (int64_t)cw * a.S;
       for (int s = lane; s < a.S; s += 64) {
         float xha, xhb, dua, dub, gf;
@@ -528,7 +566,7 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, floa
       }
     } else {
       const float gm = a.gamma[cw], bt = a.beta[cw];
-      const float* xr = xn + (int64_t)cw * a.S;
+      const GnXPtr<XT> xr = xn + (int64_t)cw * a.S;
       const float* gr = gyn + (int64_t)cw * a.S;
       for (int s = lane; s < a.S; s += 64) {
         float xh;
@@ -553,11 +591,11 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, floa
     if (pair) {
       const float ga = a.gamma[cw], ba = a.beta[cw], gb = a.gamma[cw + Cw], bb = a.beta[cw + Cw];
       const float sc = a.mode == GN_GLU_SCALE_RES ? a.scale[cw] : 1.f;
-      const float* xa = xn + (int64_t)cw * a.S;
-      const float* xb = xn + (int64_t)(cw + Cw) * a.S;
+      const GnXPtr<XT> xa = xn + (int64_t)cw * a.S;
+      const GnXPtr<XT> xb = xn + (int64_t)(cw + Cw) * a.S;
       const float* gr = gyn + (int64_t)cw * a.S;
-      float* da = dxn + (int64_t)cw * a.S;
-      float* db = dxn + (int64_t)(cw + Cw) * a.S;
+      const GnDxPtr<XT> da = dxn + (int64_t)cw * a.S;
+      const GnDxPtr<XT> db = dxn + (int64_t)(cw + Cw) * a.S;
       for (int s = lane; s < a.S; s += 64) {
         float xha, xhb, dua, dub, gf;
         du_pair(xa[s], xb[s], gr[s], ga, ba, gb, bb, sc, xha, xhb, dua, dub, gf);
@@ -566,9 +604,9 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, floa
       }
     } else {
       const float gm = a.gamma[cw], bt = a.beta[cw];
-      const float* xr = xn + (int64_t)cw * a.S;
+      const GnXPtr<XT> xr = xn + (int64_t)cw * a.S;
       const float* gr = gyn + (int64_t)cw * a.S;
-      float* dr = dxn + (int64_t)cw * a.S;
+      const GnDxPtr<XT> dr = dxn + (int64_t)cw * a.S;
       for (int s = lane; s < a.S; s += 64) {
         float xh;
         const float du = du_single(xr[s], gr[s], gm, bt, xh);
@@ -583,16 +621,16 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_kernel(const GnArgs a, floa
 // pass, so every operand is read exactly once (the 256-thread kernel re-reads them from L2 / Infinity Cache).
 // KEEPG = false (RW = 6: up to 96 channel pairs): gy is streamed in both passes (its second read comes from cache) and only
 // the two x rows stay in registers -- (x_a, x_b, gy) for six rows would spill at the 128 VGPRs a 1024-thread group has.
-template <int RW, int SV, bool KEEPG = true>
+template <int RW, int SV, bool KEEPG = true, typename XT = float>
 __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a, float* __restrict__ part,
                                                                  float* __restrict__ psc) {
   __shared__ float red[16][2];
   const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Cw = a.C / 2;
   const float mean = a.mean[n], rstd = a.rstd[n];
-  const float* xn = a.x + (int64_t)n * a.C * a.S;
+  const GnXPtr<XT> xn = gn_xp<XT>(a) + (int64_t)n * a.C * a.S;
   const float* gyn = a.gy + (int64_t)n * Cw * a.S;
-  float* dxn = a.y + (int64_t)n * a.C * a.S;
+  const GnDxPtr<XT> dxn = gn_dxp<XT>(a) + (int64_t)n * a.C * a.S;
   float xa[RW][SV], xb[RW][SV], gg[KEEPG ? RW : 1][SV];
 #pragma unroll
   for (int j = 0; j < RW; ++j) {
@@ -676,15 +714,15 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
 
 // Tiny samples in the single-channel modes (DConv bottleneck: 12 / 24 channels x 256 frames): one WAVE owns a sample
 // and holds it in registers -- wave reductions only, no workgroup barrier, operands read once.
-template <int CMAX, int SV>
+template <int CMAX, int SV, typename XT = float>
 __global__ __launch_bounds__(256) void gn_bwd_sample_wave_kernel(const GnArgs a, float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= a.N) return;
   const float mean = a.mean[n], rstd = a.rstd[n];
-  const float* xn = a.x + (int64_t)n * a.C * a.S;
+  const GnXPtr<XT> xn = gn_xp<XT>(a) + (int64_t)n * a.C * a.S;
   const float* gyn = a.gy + (int64_t)n * a.C * a.S;
-  float* dxn = a.y + (int64_t)n * a.C * a.S;
+  const GnDxPtr<XT> dxn = gn_dxp<XT>(a) + (int64_t)n * a.C * a.S;
   float xv[CMAX][SV], gv[CMAX][SV];
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) {
@@ -736,7 +774,7 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_wave_kernel(const GnArgs a,
   }
 }
 
-static int norm_bwd(int bn, const float* x, const float* gamma, const float* beta, const float* mean,
+static int norm_bwd(int x16, int bn, const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t G, int32_t mode, const float* scale,
                                  float* work /* N*C*2 + N*(C/2) + max(N*G, C)*2 floats */, float* dx, float* dgamma,
@@ -752,7 +790,8 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
   a.gy = gy; a.scale = scale; a.gsum = psc + (int64_t)N * (C / 2); a.y = dx; a.dgamma = dgamma; a.dbeta = dbeta;
   a.dscale = dscale;
-  a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode; a.bn = bn;
+  a.N = N; a.C = C; a.S = S; a.G = G; a.mode = mode; a.bn = bn; a.x16 = x16;
+  if (x16 && ((S & 3) || bn)) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
   const int Cw = glu ? C / 2 : C;
@@ -762,22 +801,27 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
   if (!bn && G == 1 && N >= 512 && (int64_t)C * S <= 65536) {
     // many small samples: one workgroup per sample, both passes fused (gn_bwd_sample_kernel); the GLU modes of the
     // HDemucs freq-branch shapes keep the sample in registers (gn_bwd_sample_reg_kernel)
+#define GN_LAUNCH_X(KERNEL_F, KERNEL_H, ...)                                  \
+  do {                                                                        \
+    if (x16) hipLaunchKernelGGL(KERNEL_H, __VA_ARGS__);                       \
+    else hipLaunchKernelGGL(KERNEL_F, __VA_ARGS__);                           \
+  } while (0)
     if (!glu && S <= 256 && C <= 12)
-      hipLaunchKernelGGL((gn_bwd_sample_wave_kernel<12, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, part);
+      GN_LAUNCH_X((gn_bwd_sample_wave_kernel<12, 4, float>), (gn_bwd_sample_wave_kernel<12, 4, rfx_bf16s>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, part);
     else if (!glu && S <= 256 && C <= 24)
-      hipLaunchKernelGGL((gn_bwd_sample_wave_kernel<24, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, part);
+      GN_LAUNCH_X((gn_bwd_sample_wave_kernel<24, 4, float>), (gn_bwd_sample_wave_kernel<24, 4, rfx_bf16s>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a, part);
     else if (glu && S <= 256 && C / 2 <= 48)
-      hipLaunchKernelGGL((gn_bwd_sample_reg_kernel<3, 4>), dim3((unsigned)N), dim3(1024), 0, s, a, part, psc);
+      GN_LAUNCH_X((gn_bwd_sample_reg_kernel<3, 4, true, float>), (gn_bwd_sample_reg_kernel<3, 4, true, rfx_bf16s>), dim3((unsigned)N), dim3(1024), 0, s, a, part, psc);
     else if (glu && S <= 256 && C / 2 <= 96)
-      hipLaunchKernelGGL((gn_bwd_sample_reg_kernel<6, 4, false>), dim3((unsigned)N), dim3(1024), 0, s, a, part, psc);
+      GN_LAUNCH_X((gn_bwd_sample_reg_kernel<6, 4, false, float>), (gn_bwd_sample_reg_kernel<6, 4, false, rfx_bf16s>), dim3((unsigned)N), dim3(1024), 0, s, a, part, psc);
     else
-      hipLaunchKernelGGL(gn_bwd_sample_kernel, dim3((unsigned)N), dim3(256), 0, s, a, part, psc);
+      GN_LAUNCH_X(gn_bwd_sample_kernel<float>, gn_bwd_sample_kernel<rfx_bf16s>, dim3((unsigned)N), dim3(256), 0, s, a, part, psc);
     RFX_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
     RFX_CHECK_LAUNCH();
     return 0;
   }
-  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, part, psc, nchunks);
+  GN_LAUNCH_X(gn_bwd_partial_kernel<float>, gn_bwd_partial_kernel<rfx_bf16s>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, part, psc, nchunks);
   RFX_CHECK_LAUNCH();
   if (!bn) {
     hipLaunchKernelGGL(gn_bwd_groupsum_kernel, dim3((N * G + 3) / 4), dim3(256), 0, s, a, part);
@@ -787,7 +831,8 @@ static int norm_bwd(int bn, const float* x, const float* gamma, const float* bet
   RFX_CHECK_LAUNCH();
   uint32_t nrow_items = 0, ipr = 0;
   if (gn_row_items((int64_t)N * Cw, S, &nrow_items, &ipr))
-    hipLaunchKernelGGL(gn_bwd_apply_rows_kernel, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+    GN_LAUNCH_X(gn_bwd_apply_rows_kernel<float>, gn_bwd_apply_rows_kernel<rfx_bf16s>, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+  else if (x16) return -1;
   else if ((S & 3) == 0) hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3(gn_grid((int64_t)N * Cw * S / 4)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(gn_grid((int64_t)N * Cw * S)), dim3(256), 0, s, a);
   RFX_CHECK_LAUNCH();
@@ -798,14 +843,22 @@ extern "C" int rfx_groupnorm_bwd(const float* x, const float* gamma, const float
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t G, int32_t mode, const float* scale, float* work, float* dx,
                                  float* dgamma, float* dbeta, float* dscale, void* stream) {
-  return norm_bwd(0, x, gamma, beta, mean, rstd, gy, N, C, S, G, mode, scale, work, dx, dgamma, dbeta, dscale, stream);
+  return norm_bwd(0, 0, x, gamma, beta, mean, rstd, gy, N, C, S, G, mode, scale, work, dx, dgamma, dbeta, dscale, stream);
+}
+// x and dx stored as bf16; gy fp32.  S % 4 == 0.
+extern "C" int rfx_groupnorm_bwd_x16(const void* x, const float* gamma, const float* beta, const float* mean,
+                                     const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
+                                     int32_t G, int32_t mode, const float* scale, float* work, void* dx,
+                                     float* dgamma, float* dbeta, float* dscale, void* stream) {
+  return norm_bwd(1, 0, static_cast<const float*>(x), gamma, beta, mean, rstd, gy, N, C, S, G, mode, scale, work,
+                  static_cast<float*>(dx), dgamma, dbeta, dscale, stream);
 }
 // train-mode BatchNorm backward (batch statistics); work: N*C*2 + N*(C/2) + C*2 floats
 extern "C" int rfx_batchnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t mode, float* work, float* dx, float* dgamma, float* dbeta, void* stream) {
   if (mode != GN_NONE && mode != GN_RELU) return -1;
-  return norm_bwd(1, x, gamma, beta, mean, rstd, gy, N, C, S, C, mode, nullptr, work, dx, dgamma, dbeta, nullptr, stream);
+  return norm_bwd(0, 1, x, gamma, beta, mean, rstd, gy, N, C, S, C, mode, nullptr, work, dx, dgamma, dbeta, nullptr, stream);
 }
 
 // ---- 2x2 average pooling (classifier.py:275) ---------------------------------------------
@@ -893,8 +946,9 @@ __global__ __launch_bounds__(256) void glu_fwd_rows_kernel(const float* __restri
   for (int q = 0; q < 4; ++q) r[q] = a[q] * rfx_sigmoid(b[q]);
   *reinterpret_cast<f32x4*>(y + (int64_t)n * L + o) = r;
 }
-__global__ __launch_bounds__(256) void glu_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                           float* __restrict__ gx, uint32_t nitems, uint32_t ipr,
+template <typename XT>      // XT: storage type of x (the conv output) and of gx (its gradient): float or rfx_bf16s
+__global__ __launch_bounds__(256) void glu_bwd_rows_kernel(const XT* __restrict__ x, const float* __restrict__ gy,
+                                                           XT* __restrict__ gx, uint32_t nitems, uint32_t ipr,
                                                            int64_t L) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t w = blockIdx.x * 4u + wave;
@@ -903,7 +957,7 @@ __global__ __launch_bounds__(256) void glu_bwd_rows_kernel(const float* __restri
   const int64_t o = (int64_t)ck * 256 + (threadIdx.x & 63) * 4;
   if (o >= L) return;
   const int64_t ia = (int64_t)n * 2 * L + o;
-  const f32x4 a = gn_ld4(x + ia), b = gn_ld4(x + ia + L), g = gn_ld4(gy + (int64_t)n * L + o);
+  const f32x4 a = rfx_ld4(x + ia), b = rfx_ld4(x + ia + L), g = gn_ld4(gy + (int64_t)n * L + o);
   f32x4 da, db;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -911,8 +965,8 @@ __global__ __launch_bounds__(256) void glu_bwd_rows_kernel(const float* __restri
     da[q] = g[q] * sg;
     db[q] = g[q] * a[q] * sg * (1.f - sg);
   }
-  *reinterpret_cast<f32x4*>(gx + ia) = da;
-  *reinterpret_cast<f32x4*>(gx + ia + L) = db;
+  rfx_st4(gx + ia, da);
+  rfx_st4(gx + ia + L, db);
 }
 static bool glu_row_items(int64_t N, int64_t L, uint32_t* nitems, uint32_t* ipr) {
   const int64_t per = (L + 255) / 256;
@@ -935,10 +989,21 @@ extern "C" int rfx_glu_bwd(const float* x, const float* gy, float* gx, int64_t N
   if (!x || !gy || !gx || N <= 0 || C <= 0 || (C & 1) || S <= 0) return -1;
   uint32_t nitems = 0, ipr = 0;
   if (glu_row_items(N, (C / 2) * S, &nitems, &ipr))
-    hipLaunchKernelGGL(glu_bwd_rows_kernel, dim3((nitems + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gy, gx, nitems,
+    hipLaunchKernelGGL(glu_bwd_rows_kernel<float>, dim3((nitems + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gy, gx, nitems,
                        ipr, (C / 2) * S);
   else
     hipLaunchKernelGGL(glu_bwd_kernel, dim3(gn_grid(N * (C / 2) * S)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, N, C / 2, S);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+// x (conv output) and gx (its gradient) stored as bf16 (bf16 mode: both are only ever GEMM operands / GLU inputs); gy fp32.
+// (C / 2) * S must be a multiple of 4.
+extern "C" int rfx_glu_bwd_bf16(const void* x, const float* gy, void* gx, int64_t N, int64_t C, int64_t S, void* stream) {
+  if (!x || !gy || !gx || N <= 0 || C <= 0 || (C & 1) || S <= 0) return -1;
+  uint32_t nitems = 0, ipr = 0;
+  if (!glu_row_items(N, (C / 2) * S, &nitems, &ipr)) return -1;
+  hipLaunchKernelGGL(glu_bwd_rows_kernel<rfx_bf16s>, dim3((nitems + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const rfx_bf16s*>(x), gy, static_cast<rfx_bf16s*>(gx), nitems, ipr, (C / 2) * S);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -121,7 +121,9 @@ class _DConv(nn.Module):
             if attn:
                 y = mods[i](y); i += 1
             st = torch.zeros((x.shape[0], _STAT_SLOTS, 2), device=x.device, dtype=torch.float64)
-            y = ops.conv1d(y, mods[i].weight, mods[i].bias, stat_sums=st)
+            # the 2C-channel tensor is read only by the GroupNorm + GLU kernel (and, in backward, its gradient only by GEMMs):
+            # 16-bit storage in the bf16 mode
+            y = ops.conv1d(y, mods[i].weight, mods[i].bias, stat_sums=st, out_bf16=True)
             x = nnops.group_norm(y, 1, mods[i + 1].weight, mods[i + 1].bias, mods[i + 1].eps,
                                  mode="glu_scale_res", res=x, scale=mods[i + 3].scale, sums=st)
         return x

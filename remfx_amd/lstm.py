@@ -137,6 +137,5 @@ def blstm(module, x, T, Bn):
         h = _LSTMLayerFn.apply(h, *p, T, Bn)
         if module.dropout > 0 and module.training and layer < module.num_layers - 1:
             from . import nnops
-            nnops._interim("dropout")
-            h = F.dropout(h, module.dropout, True)
+            h = nnops.dropout(h, module.dropout, True)
     return h

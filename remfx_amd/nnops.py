@@ -36,7 +36,9 @@ class _GroupNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps, mode, res, scale, sums=None):
-        ops._req(x, "x")
+        x16 = x.dtype == torch.bfloat16            # a conv output kept in 16 bits (bf16 mode, ops.bf16_storage)
+        if not x16:
+            ops._req(x, "x")
         x = x.contiguous()
         N, Cc = x.shape[0], x.shape[1]
         S = x.numel() // (N * Cc)
@@ -51,9 +53,9 @@ class _GroupNormFn(torch.autograd.Function):
             sums = torch.empty(N * groups * 2, device=x.device, dtype=torch.float64)
         if res is not None:
             res = res.contiguous()
-        check(_lib.lib().rfx_groupnorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), N, Cc, S, groups, eps, mode,
-                                           _ptr(res), _ptr(scale), _ptr(sums), given, _ptr(mean), _ptr(rstd), _ptr(y),
-                                           _stream()),
+        fwd = _lib.lib().rfx_groupnorm_fwd_x16 if x16 else _lib.lib().rfx_groupnorm_fwd
+        check(fwd(_ptr(x), _ptr(gamma), _ptr(beta), N, Cc, S, groups, eps, mode,
+                  _ptr(res), _ptr(scale), _ptr(sums), given, _ptr(mean), _ptr(rstd), _ptr(y), _stream()),
               "rfx_groupnorm_fwd")
         ctx.save_for_backward(x, gamma, beta, mean, rstd, scale)
         ctx.cfg = (N, Cc, S, groups, mode)
@@ -68,9 +70,10 @@ class _GroupNormFn(torch.autograd.Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         dscale = torch.empty_like(scale) if mode == 3 else None
         gsum = torch.empty(N * Cc * 2 + N * (Cc // 2) + N * groups * 2, device=x.device, dtype=torch.float32)
-        check(_lib.lib().rfx_groupnorm_bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gy),
-                                           N, Cc, S, groups, mode, _ptr(scale), _ptr(gsum), _ptr(dx),
-                                           _ptr(dgamma), _ptr(dbeta), _ptr(dscale), _stream()),
+        bwd = _lib.lib().rfx_groupnorm_bwd_x16 if x.dtype == torch.bfloat16 else _lib.lib().rfx_groupnorm_bwd
+        check(bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gy),
+                  N, Cc, S, groups, mode, _ptr(scale), _ptr(gsum), _ptr(dx),
+                  _ptr(dgamma), _ptr(dbeta), _ptr(dscale), _stream()),
               "rfx_groupnorm_bwd")
         return dx, dgamma, dbeta, None, None, None, (gy if mode == 3 else None), dscale, None
 
@@ -293,23 +296,39 @@ class _LocalStateFn(torch.autograd.Function):
         ch = Ctot // heads
         out = torch.empty_like(q)
         need_w = any(ctx.needs_input_grad[:4])
-        w = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32) if need_w else None
-        check(_lib.lib().rfx_localstate_fwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), B, heads, ch, T, ndecay, _ptr(w),
-                                            _ptr(out), _stream()), "rfx_localstate_fwd")
-        if need_w:
-            ctx.save_for_backward(q, k, cont, qd, w)
-        ctx.cfg = (B, heads, ch, T, ndecay)
+        L = _lib.lib()
+        # bf16 mode: MFMA kernels (attention_mfma.hip), weights recomputed in the backward pass instead of stored
+        mfma = ops.GEMM_PREC == 2 and bool(L.rfx_localstate_mfma_ok(B, heads, ch, T, ndecay))
+        if mfma:
+            check(L.rfx_localstate_mfma_fwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), B, heads, ch, T, ndecay, _ptr(out),
+                                            _stream()), "rfx_localstate_mfma_fwd")
+            if need_w:
+                ctx.save_for_backward(q, k, cont, qd)
+        else:
+            w = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32) if need_w else None
+            check(L.rfx_localstate_fwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), B, heads, ch, T, ndecay, _ptr(w),
+                                       _ptr(out), _stream()), "rfx_localstate_fwd")
+            if need_w:
+                ctx.save_for_backward(q, k, cont, qd, w)
+        ctx.cfg = (B, heads, ch, T, ndecay, mfma)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        q, k, cont, qd, w = ctx.saved_tensors
-        B, heads, ch, T, ndecay = ctx.cfg
+        B, heads, ch, T, ndecay, mfma = ctx.cfg
         g = g.contiguous()
+        q, k, cont, qd = ctx.saved_tensors[:4]
         dq, dk, dc, dqd = torch.empty_like(q), torch.empty_like(k), torch.empty_like(cont), torch.empty_like(qd)
-        check(_lib.lib().rfx_localstate_bwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), _ptr(w), _ptr(g), B, heads, ch, T,
-                                            ndecay, _ptr(dq), _ptr(dk), _ptr(dc), _ptr(dqd), _stream()),
-              "rfx_localstate_bwd")
+        if mfma:
+            stat = torch.empty((B * heads * T, 4), device=q.device, dtype=torch.float32)
+            check(_lib.lib().rfx_localstate_mfma_bwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), _ptr(g), B, heads, ch, T, ndecay,
+                                                     _ptr(dq), _ptr(dk), _ptr(dc), _ptr(dqd), _ptr(stat), _stream()),
+                  "rfx_localstate_mfma_bwd")
+        else:
+            w = ctx.saved_tensors[4]
+            check(_lib.lib().rfx_localstate_bwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), _ptr(w), _ptr(g), B, heads, ch, T,
+                                                ndecay, _ptr(dq), _ptr(dk), _ptr(dc), _ptr(dqd), _stream()),
+                  "rfx_localstate_bwd")
         return dq, dk, dc, dqd, None, None
 
 
@@ -370,6 +389,35 @@ def blstm_frame(x, nfr, width, stride):
 
 def blstm_unframe(h, skip, B, T, nfr, width, stride):
     return _BlstmUnframeFn.apply(h, skip, B, T, nfr, width, stride)
+
+
+class _DropoutFn(torch.autograd.Function):
+    """F.dropout(x, p, training=True) with a counter-based mask (rfx_dropout): no mask tensor, backward re-draws it."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ops._req(x, "x")
+        xc = x.contiguous()
+        out = torch.empty_like(xc)
+        check(_lib.lib().rfx_dropout(_ptr(xc), _ptr(out), xc.numel(), float(p), int(seed), _stream()), "rfx_dropout")
+        ctx.cfg = (float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed = ctx.cfg
+        gc = g.contiguous()
+        dx = torch.empty_like(gc)
+        check(_lib.lib().rfx_dropout(_ptr(gc), _ptr(dx), gc.numel(), p, seed, _stream()), "rfx_dropout")
+        return dx, None, None
+
+
+def dropout(x, p, training=True):
+    """The seed is drawn from torch's CPU generator (torch.manual_seed makes runs repeatable; no device sync)."""
+    if not training or p <= 0.0:
+        return x
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    return _DropoutFn.apply(x, float(p), seed)
 
 
 def linear(x, weight, bias):

@@ -19,6 +19,15 @@ PREC_NAMES = {"f32": 0, "bf16x3": 1, "bf16": 2}
 GEMM_PREC = PREC_NAMES[_os.environ.get("RFX_GEMM_PREC", "f32")]
 
 
+BF16_STORE = _os.environ.get("RFX_BF16_STORE", "1") != "0"      # RFX_BF16_STORE=0: fp32 storage everywhere (A/B switch)
+
+
+def bf16_storage():
+    """bf16 mode keeps selected activations (conv outputs that are read only by GLU / norm kernels and GEMM operands, and their
+    gradients) in 16 bits -- DESIGN.md section 3."""
+    return GEMM_PREC == 2 and BF16_STORE
+
+
 def set_gemm_precision(name):
     global GEMM_PREC
     GEMM_PREC = PREC_NAMES[name]
@@ -53,10 +62,11 @@ class DevPlan:
         self.woff = torch.from_numpy(np.ascontiguousarray(plan.woff)).to(device)
         d = GemmDesc()
         for f, _ in GemmDesc._fields_:
-            if f not in ("gpt2", "in_extent"):
+            if f not in ("gpt2", "in_extent", "in_bf16", "out_bf16"):
                 setattr(d, f, int(getattr(plan, f)))
         d.in_extent = int(plan.in_extent) * 4              # bytes
         self.desc = d
+        self._desc16 = {}
         self.tap = plan.cin >= 8 and plan.R > 0              # tap-major tables exist: bf16x3 / bf16 run the gemm_tap kernels
         if self.tap:
             self.tap_tab = torch.from_numpy(np.ascontiguousarray(plan.tap_tab)).to(device)
@@ -66,6 +76,23 @@ class DevPlan:
         """Arithmetic the forward-family launch of this plan runs in: the library mode for tap-major plans, exact fp32 on
         the channel-major kernel otherwise (fewer than 8 input channels / thin M <= 8 layers: HBM-bound either way)."""
         return GEMM_PREC if self.tap else 0
+
+    def desc_for(self, x, out):
+        """The descriptor with the storage types of this call's operands (bf16 STORAGE of the gathered / written tensor: a
+        copy of the plan's descriptor with the flag set and the operand's byte extent halved; fp32 + fp32 is the plan's own)."""
+        in16, out16 = x.dtype == torch.bfloat16, out.dtype == torch.bfloat16
+        if not (in16 or out16):
+            return self.desc
+        if (in16 and x.dtype != torch.bfloat16) or GEMM_PREC != 2:
+            raise ValueError("bf16 tensor storage needs the bf16 arithmetic mode")
+        key = (in16, out16)
+        v = self._desc16.get(key)
+        if v is None:
+            v = GemmDesc.from_buffer_copy(self.desc)
+            v.in_bf16, v.out_bf16 = int(in16), int(out16)
+            v.in_extent = int(self.p.in_extent) * (2 if in16 else 4)
+            self._desc16[key] = v
+        return v
 
     def set_io(self, x=None, out=None):
         """Refresh strides for a new tensor with the same geometry key (cheap)."""
@@ -130,13 +157,26 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
         a2, k2, K2, Kpad2 = _ptr(apack2), _ptr(dp2.ktab), dp2.p.K, dp2.p.Kpad
     else:
         a2, k2, K2, Kpad2 = None, None, 0, 0
-    check(_lib.lib().rfx_gemm_fwd(C.byref(dp.desc), _ptr(apack), _ptr(tab), _ptr(x), _ptr(out),
+    if x.dtype == torch.bfloat16 and not (prec == 2 and dp.p.R > 0):
+        x = x.float()                # thin / channel-major plans (fewer than 8 input channels, M <= 8) read fp32: widen once
+    desc = dp.desc_for(x, out)
+    if dp2 is not None and prec:
+        desc.gpt2 = int(dp2.p.gpt)
+    check(_lib.lib().rfx_gemm_fwd(C.byref(desc), _ptr(apack), _ptr(tab), _ptr(x), _ptr(out),
                                   C.byref(e), a2, k2, K2, Kpad2, _ptr(in2), prec, _stream()),
           "rfx_gemm_fwd")
     return out
 
 
 def gemm_wgrad(dp, x, g, dapack):
+    if x.dtype == torch.bfloat16:                            # bf16 storage is implemented for the gradient operand only
+        x = x.float()
+    if g.dtype == torch.bfloat16:
+        rc = _lib.lib().rfx_gemm_wgrad(C.byref(dp.desc_for(x, g)), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(dapack),
+                                       GEMM_PREC, _stream())
+        if rc == 0:
+            return
+        g = g.float()                                        # a plan the wide-load kernel does not take: widen once
     check(_lib.lib().rfx_gemm_wgrad(C.byref(dp.desc), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(dapack),
                                     GEMM_PREC, _stream()), "rfx_gemm_wgrad")
 
@@ -159,14 +199,18 @@ def _key(*a):
     return tuple(tuple(x) if isinstance(x, (list, tuple, torch.Size)) else x for x in a)
 
 
-def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=None, out=None, stat_sums=None):
+def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=None, out=None, stat_sums=None,
+                   out_bf16=False):
+    """out_bf16: the caller's only readers of the result are a GroupNorm kernel and GEMM operands -- in the bf16 arithmetic mode
+    it is then STORED in 16 bits (what torch autocast stores for a conv output); ignored in the other modes."""
     _req(x, "x"); _req(w, "weight")
     N, Cin, IA, IB = x.shape
     Cout, _, KA, KB = w.shape
     OA = convplan._out_len(IA, KA, stride[0], padding[0], dilation[0])
     OB = convplan._out_len(IB, KB, stride[1], padding[1], dilation[1])
     if out is None:
-        out = torch.empty((N, Cout, OA, OB), device=x.device, dtype=torch.float32)
+        use16 = out_bf16 and bf16_storage() and Cout > 8 and Cin >= 8 and (OA * OB) % 4 == 0 and act is None
+        out = torch.empty((N, Cout, OA, OB), device=x.device, dtype=torch.bfloat16 if use16 else torch.float32)
     key = _key("cf", x.shape, x.stride(), w.shape, stride, padding, dilation, out.stride())
     dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
         tuple(x.shape), x.stride(), tuple(w.shape), stride, padding, dilation, out.stride()))
@@ -245,10 +289,10 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d / nn.Conv1d (A == 1) forward + backward on the gather-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padding, dilation, stat_sums=None):
+    def forward(ctx, x, w, bias, stride, padding, dilation, stat_sums=None, out_bf16=False):
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, dilation, bias is not None)
-        return conv2d_forward(x, w, bias, stride, padding, dilation, stat_sums=stat_sums)
+        return conv2d_forward(x, w, bias, stride, padding, dilation, stat_sums=stat_sums, out_bf16=out_bf16)
 
     @staticmethod
     def backward(ctx, g):
@@ -260,7 +304,7 @@ class Conv2dFn(torch.autograd.Function):
             dx = conv2d_dgrad(g, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class ConvFork2dFn(torch.autograd.Function):
@@ -270,10 +314,10 @@ class ConvFork2dFn(torch.autograd.Function):
     read-read-write accumulation pass over the activation."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padding, dilation, stat_sums=None):
+    def forward(ctx, x, w, bias, stride, padding, dilation, stat_sums=None, out_bf16=False):
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, dilation, bias is not None)
-        return conv2d_forward(x, w, bias, stride, padding, dilation, stat_sums=stat_sums), x.view_as(x)
+        return conv2d_forward(x, w, bias, stride, padding, dilation, stat_sums=stat_sums, out_bf16=out_bf16), x.view_as(x)
 
     @staticmethod
     def backward(ctx, g, gres):
@@ -285,7 +329,7 @@ class ConvFork2dFn(torch.autograd.Function):
             dx = conv2d_dgrad(g, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation, res=gres)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class ConvGlu2dFn(torch.autograd.Function):
@@ -306,6 +350,10 @@ class ConvGlu2dFn(torch.autograd.Function):
         key = _key("cf", x.shape, x.stride(), w.shape, stride, padding, dilation, y2.stride())
         dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
             tuple(x.shape), x.stride(), tuple(w.shape), stride, padding, dilation, y2.stride()))
+        # bf16 mode: the conv output and its gradient never leave this node and are read only as GLU inputs / GEMM operands
+        # (which round to bf16 anyway): keep both in 16 bits -- what torch autocast stores for a conv output
+        if bf16_storage() and dp.tap and C2 >= 16 and Cin > 8 and (Ch * OA * OB) % 4 == 0:
+            y2 = torch.empty((N, C2, OA, OB), device=x.device, dtype=torch.bfloat16)
         wi = w.view(2, Ch, Cin, KA, KB).transpose(0, 1).reshape(C2, Cin, KA, KB)     # rows (c, half)
         gemm_fwd(dp, pack_a(dp, wi), x, y2, bias=bias, glu_out=out)
         ctx.save_for_backward(x, w, y2)
@@ -319,7 +367,10 @@ class ConvGlu2dFn(torch.autograd.Function):
         N, C2 = y2.shape[0], y2.shape[1]
         S = y2.numel() // (N * C2)
         g2 = torch.empty_like(y2)
-        check(_lib.lib().rfx_glu_bwd(_ptr(y2), _ptr(g.contiguous()), _ptr(g2), N, C2, S, _stream()), "rfx_glu_bwd")
+        if y2.dtype == torch.bfloat16:
+            check(_lib.lib().rfx_glu_bwd_bf16(_ptr(y2), _ptr(g.contiguous()), _ptr(g2), N, C2, S, _stream()), "rfx_glu_bwd_bf16")
+        else:
+            check(_lib.lib().rfx_glu_bwd(_ptr(y2), _ptr(g.contiguous()), _ptr(g2), N, C2, S, _stream()), "rfx_glu_bwd")
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(g2, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation)
@@ -340,25 +391,26 @@ def conv1d_glu(x, w, bias=None, stride=1, padding=0, dilation=1):
     return conv2d_glu(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation)).squeeze(2)
 
 
-def conv2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), stat_sums=None):
-    return Conv2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation), stat_sums)
+def conv2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), stat_sums=None, out_bf16=False):
+    return Conv2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation), stat_sums, out_bf16)
 
 
-def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None):
+def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None, out_bf16=False):
     """stat_sums: optional zeroed fp64 (N, 2) tensor; the GEMM epilogue adds {sum, sum^2} of every sample's
-    output into it (GroupNorm(1, C) statistics for free)."""
-    y = Conv2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation), stat_sums)
+    output into it (GroupNorm(1, C) statistics for free).  out_bf16: see conv2d_forward."""
+    y = Conv2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation), stat_sums, out_bf16)
     return y.squeeze(2)
 
 
-def conv2d_fork(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), stat_sums=None):
+def conv2d_fork(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), stat_sums=None, out_bf16=False):
     """(conv2d(x), alias of x) -- see ConvFork2dFn."""
-    return ConvFork2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation), stat_sums)
+    return ConvFork2dFn.apply(x, w, bias, tuple(stride), tuple(padding), tuple(dilation), stat_sums, out_bf16)
 
 
-def conv1d_fork(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None):
+def conv1d_fork(x, w, bias=None, stride=1, padding=0, dilation=1, stat_sums=None, out_bf16=False):
     """(conv1d(x), alias of x) -- see ConvFork2dFn; use the alias for the residual connection around the branch."""
-    y, xr = ConvFork2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation), stat_sums)
+    y, xr = ConvFork2dFn.apply(x.unsqueeze(2), w.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation), stat_sums,
+                               out_bf16)
     return y.squeeze(2), xr.squeeze(2)
 
 

@@ -165,3 +165,47 @@ def test_hdemucs_full_config_gradients_golden(golden_dir):
         # slice RMS error relative to the slice RMS; bias-like tensors are cancelling sums (see test_hdemucs_small_fwd_bwd)
         check(err, 2e-2, bf16x3=2e-2, bf16=0.25, what=(n, "slice", err))
         check(abs(float(gr.double().norm()) - ref_norm), 1e-2, ref_norm, bf16=0.1, what=(n, "norm"))
+
+
+@pytest.mark.one_mode
+@pytest.mark.parametrize("B,heads,ch,T,nd", [(3, 4, 48, 256, 4), (2, 4, 96, 200, 4), (2, 4, 96, 64, 4), (2, 2, 16, 37, 3),
+                                             (1, 2, 64, 130, 4), (2, 1, 32, 256, 1)])
+def test_localstate_mfma_vs_exact(B, heads, ch, T, nd):
+    """LocalState attention on the bf16 matrix pipe (attention_mfma.hip, flash-style: weights recomputed in the backward pass)
+    and the exact fp32 kernels (attention.hip; ch * T <= 12288) against autograd over the operator written out in torch
+    fp64, forward and all four gradients.  bf16 bound: operand rounding of q, k, content, P and dS (2^-9 relative each) --
+    2 % of the RMS of each tensor; exact kernels: 2e-5."""
+    from remfx_amd import nnops, ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    mk = lambda c: (torch.randn(B, heads * c, T, generator=g) * 0.8).to(DEV).requires_grad_(True)
+    q, k, cont, qd = mk(ch), mk(ch), mk(ch), mk(nd)
+    gy = torch.randn(B, heads * ch, T, generator=g).to(DEV)
+    qq, kk, cc, dd = (t.detach().double().cpu().requires_grad_(True) for t in (q, k, cont, qd))
+    qh, kh, chh = (t.view(B, heads, ch, T) for t in (qq, kk, cc))
+    dots = torch.einsum("bhct,bhcs->bhts", kh, qh) / ch ** 0.5
+    idx = torch.arange(T, dtype=torch.float64)
+    delta = (idx[:, None] - idx[None, :]).abs()
+    dec = torch.sigmoid(dd.view(B, heads, nd, T)) / 2
+    pen = -torch.arange(1, nd + 1, dtype=torch.float64).view(-1, 1, 1) * delta / nd ** 0.5
+    dots = dots + torch.einsum("fts,bhfs->bhts", pen, dec)
+    dots = dots.masked_fill(torch.eye(T, dtype=torch.bool), -100.0)
+    w = torch.softmax(dots, dim=2)
+    yr = torch.einsum("bhts,bhct->bhcs", w, chh).reshape(B, heads * ch, T)
+    yr.backward(gy.double().cpu())
+    ref = [yr.detach(), qq.grad, kk.grad, cc.grad, dd.grad]
+    prev = ops.gemm_precision()
+    try:
+        for m, bound in (("f32", 2e-5), ("bf16", 2e-2)):
+            if m == "f32" and ch * T > 12288:
+                continue
+            ops.set_gemm_precision(m)
+            for t in (q, k, cont, qd):
+                t.grad = None
+            y = nnops.local_state_attention(q, k, cont, qd, heads, nd)
+            y.backward(gy)
+            for name, a, b in zip(("out", "dq", "dk", "dcont", "dqd"), [y.detach()] + [t.grad for t in (q, k, cont, qd)], ref):
+                rms = float(b.pow(2).mean().sqrt())
+                err = float((a.double().cpu() - b).pow(2).mean().sqrt())
+                assert err <= bound * rms + 1e-9, (m, name, err, rms)
+    finally:
+        ops.set_gemm_precision(prev)

@@ -141,3 +141,26 @@ def test_channel_sum(shape):
         v = x[:, 1:-1]                                             # non-contiguous over (n, c), contiguous planes
         got = ops.channel_sum(v)
         assert float((got.double() - ref[1:-1]).abs().max()) <= 2e-6 * float(x.abs().double().sum() / shape[1] + 1.0)
+
+
+def test_dropout_native():
+    """rfx_dropout: keep rate, 1/(1-p) scaling, same mask in backward, repeatable under torch.manual_seed, identity in eval."""
+    from remfx_amd import nnops
+    x = torch.randn(1 << 20, device=DEV).abs() + 0.5
+    x.requires_grad_(True)
+    torch.manual_seed(11)
+    y = nnops.dropout(x, 0.4, True)
+    keep = (y != 0)
+    assert abs(float(keep.float().mean()) - 0.6) < 3e-3
+    torch.testing.assert_close(y[keep], (x.detach() / 0.6)[keep])
+    y.sum().backward()
+    torch.testing.assert_close(x.grad, keep.float() / 0.6)
+    torch.manual_seed(11)
+    y2 = nnops.dropout(x.detach(), 0.4, True)
+    assert torch.equal(y2, y.detach())
+    y3 = nnops.dropout(x.detach(), 0.4, True)          # next draw differs
+    assert not torch.equal(y3, y2)
+    assert nnops.dropout(x, 0.4, False) is x
+    # no visible structure along the index: keep rates of 1024-element blocks scatter binomially
+    blk = keep.float().view(-1, 1024).mean(1)
+    assert float(blk.std()) < 2.5 * (0.6 * 0.4 / 1024) ** 0.5
