@@ -113,7 +113,7 @@ class _DConv(nn.Module):
         for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
             mods = list(seq)
             st = torch.zeros((x.shape[0], _STAT_SLOTS, 2), device=x.device, dtype=torch.float64)   # GN(1, C) statistics
-            y, x = ops.conv1d_fork(x, mods[0].weight, mods[0].bias, 1, pad, dil, stat_sums=st)   # come out of the GEMM epilogue
+            y, x = ops.conv1d_fork(x, mods[0].weight, mods[0].bias, 1, pad, dil, stat_sums=st, out_bf16=True)   # statistics come out of the GEMM epilogue
             y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu", sums=st)
             i = 3
             if lstm:

@@ -121,3 +121,84 @@ def test_hdemucs_full_config_bf16_forward():
     e_hip, e_auto = _rms(yd, y), _rms(ya, y)
     print("full config forward rms error vs fp32 oracle: hip bf16", e_hip, "autocast oracle", e_auto, "max |y|", float(y.abs().max()))
     assert e_hip < 2.0 * e_auto, (e_hip, e_auto)
+
+
+@pytest.mark.one_mode
+def test_bf16_storage_is_exactly_rounding():
+    """bf16 STORAGE of a conv output / its gradient (ops.bf16_storage) changes nothing but the stored bits: the 16-bit paths of the
+    tap-major gather (dgrad), the wide weight-gradient kernel, the GEMM store, GroupNorm (+GLU) forward / backward and the GLU
+    backward are compared BIT-EXACTLY with the fp32-storage kernels fed the same (already bf16-representable) values."""
+    from remfx_amd import nnops, ops
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(5)
+        N, Cin, Cout, T = 5, 24, 96, 200
+        x = torch.randn(N, Cin, T, generator=g).to(DEV)
+        w = (torch.randn(Cout, Cin, 1, generator=g) * 0.2).to(DEV)
+        b = torch.randn(Cout, generator=g).to(DEV)
+        # forward store: 16-bit output == RNE(fp32 output); epilogue statistics are those of the rounded values
+        st32 = torch.zeros(N, 16, 2, device=DEV, dtype=torch.float64)
+        st16 = torch.zeros_like(st32)
+        y32 = ops.conv1d(x, w, b, stat_sums=st32)
+        y16 = ops.conv1d(x, w, b, stat_sums=st16, out_bf16=True)
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16())
+        ref = torch.stack([y16.float().double().sum((1, 2)), y16.float().double().pow(2).sum((1, 2))], 1)
+        torch.testing.assert_close(st16.sum(1), ref, rtol=1e-6, atol=1e-6)
+        # GroupNorm + GLU + LayerScale + residual on the 16-bit tensor == the fp32 kernel on the widened values
+        gam, bet = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+        sc = torch.rand(Cout // 2, generator=g).to(DEV)
+        res = torch.randn(N, Cout // 2, T, generator=g).to(DEV)
+        outs = []
+        for yy in (y16, y16.float()):
+            yy = yy.detach().requires_grad_(True)
+            o = nnops.group_norm(yy, 1, gam, bet, 1e-5, mode="glu_scale_res", res=res, scale=sc)
+            go = torch.randn(o.shape, generator=torch.Generator().manual_seed(9)).to(DEV)
+            o.backward(go)
+            outs.append((o.detach(), yy.grad))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert outs[0][1].dtype == torch.bfloat16 and torch.equal(outs[0][1], outs[1][1].bfloat16())
+        # many small samples (freq-branch DConv shapes): the register-resident per-sample backward kernels
+        for (Nn, Cc, Ss, md) in ((600, 96, 64, "glu_scale_res"), (520, 192, 128, "glu"), (530, 12, 256, "gelu"), (515, 40, 32, "none")):
+            xs = torch.randn(Nn, Cc, Ss, generator=g).to(DEV).bfloat16()
+            gm, bt = torch.randn(Cc, generator=g).to(DEV), torch.randn(Cc, generator=g).to(DEV)
+            kw = {}
+            if md == "glu_scale_res":
+                kw = dict(res=torch.randn(Nn, Cc // 2, Ss, generator=g).to(DEV), scale=torch.rand(Cc // 2, generator=g).to(DEV))
+            pair = []
+            for xx in (xs, xs.float()):
+                xx = xx.detach().requires_grad_(True)
+                o = nnops.group_norm(xx, 1, gm, bt, 1e-5, mode=md, **kw)
+                o.backward(torch.randn(o.shape, generator=torch.Generator().manual_seed(3)).to(DEV))
+                pair.append((o.detach(), xx.grad))
+            assert torch.equal(pair[0][0], pair[1][0]), md
+            assert torch.equal(pair[0][1], pair[1][1].bfloat16()), md
+        # the 16-bit gradient as GEMM operand: input gradient and weight gradient == the fp32-storage kernels on the same values
+        gz = outs[0][1]
+        for gg in (gz, gz.float()):
+            xx = x.detach().requires_grad_(True)
+            ww = w.detach().requires_grad_(True)
+            bb = b.detach().requires_grad_(True)
+            yy = ops.conv1d(xx, ww, bb, out_bf16=gg.dtype == torch.bfloat16)
+            yy.backward(gg)
+            outs.append((xx.grad, ww.grad, bb.grad))
+        for a16, a32 in zip(outs[2], outs[3]):
+            assert torch.equal(a16, a32)
+        # GLU in the GEMM store with the conv output kept in 16 bits (ConvGlu2dFn) vs RFX_BF16_STORE off
+        x2 = torch.randn(3, 16, 6, 40, generator=g).to(DEV)
+        w2 = (torch.randn(32, 16, 3, 3, generator=g) * 0.1).to(DEV)
+        b2 = torch.randn(32, generator=g).to(DEV)
+        got = []
+        for store in (True, False):
+            ops.BF16_STORE = store
+            xx, ww = x2.detach().requires_grad_(True), w2.detach().requires_grad_(True)
+            o = ops.conv2d_glu(xx, ww, b2, (1, 1), (1, 1))
+            o.backward(torch.ones_like(o))
+            got.append((o.detach(), xx.grad, ww.grad))
+        ops.BF16_STORE = True
+        # not bit-equal: the GLU is taken of the rounded conv output (as the backward pass sees it); bf16 rounding of its inputs
+        for a, c in zip(got[0], got[1]):
+            assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max())
+    finally:
+        ops.BF16_STORE = True
+        ops.set_gemm_precision(prev)
