@@ -69,7 +69,7 @@ class KernelTimer:
     launch, so that every launch can be priced against the roofline that binds IT (ridge = peak FLOP/s / peak B/s)."""
 
     def __init__(self):
-        self.launches, self.enabled, self.desc = [], False, []          # (start, end, flops, bytes); plan of each launch
+        self.launches, self.enabled, self.desc, self.wgrad = [], False, [], []          # (start, end, flops, bytes); plan of each launch
 
     def install(self):
         from remfx_amd import ops
@@ -93,6 +93,22 @@ class KernelTimer:
         ops.gemm_fwd = timed
         import remfx_amd.tcn as tcn_mod
         tcn_mod.ops.gemm_fwd = timed
+        orig_w = ops.gemm_wgrad
+
+        def timed_w(dp, x, g, dapack):                     # weight-gradient launches: only listed by --dump-launches
+            if not timer.enabled:
+                return orig_w(dp, x, g, dapack)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_w(dp, x, g, dapack)
+            e.record()
+            p = dp.p
+            timer.wgrad.append((s, e, {"M": p.M, "K": p.K, "N": p.N, "OA": p.OA, "OB": p.OB, "x": list(x.shape), "g": list(g.shape),
+                                       "x_dtype": str(x.dtype), "g_dtype": str(g.dtype),
+                                       "flops": 2.0 * p.M * p.K * p.OA * p.OB * p.N,
+                                       "bytes": float(x.numel() * x.element_size() + g.numel() * g.element_size())}))
+            return r
+        ops.gemm_wgrad = timed_w
 
     def result(self, peak_tflops, peak_gbs):
         """Totals + the split of the family into MFMA-bound and HBM-bound launches (by each launch's own arithmetic
@@ -363,6 +379,7 @@ def main():
     if args.dump_launches:         # per-launch plan + algorithmic work + event time, in launch order (scripts/join_launch_pmc.py)
         json.dump([dict(d, ms=s.elapsed_time(e), flops=fl, bytes=by) for d, (s, e, fl, by) in zip(timer.desc, timer.launches)],
                   open(args.dump_launches, "w"))
+        json.dump([dict(d, ms=s.elapsed_time(e)) for s, e, d in timer.wgrad], open(args.dump_launches + ".wgrad.json", "w"))
     tot_fl = cls["mfma"][1] + cls["hbm"][1]
     tot_by = cls["mfma"][2] + cls["hbm"][2]
     f_mfma = tot_fl / (kms * 1e-3) / 1e12 / peak if kms > 0 else 0.0

@@ -234,11 +234,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_wide_kernel(const WgradArgs
   const int q4 = (tid & 15) * 4, r0 = tid >> 4;                    // this thread's quad inside the chunk / first row
   const int chunks_per_row = (d.OB + PC - 1) / PC;
   struct Stage { f32x4 gv[NG], xv[NX]; };
-  auto load_chunk = [&](int t, Stage& st) {
+  auto load_chunk = [&](int t, Stage& st, bool valid) {            // !valid: every load gets the out-of-range offset -> zeros
     const int row = t / chunks_per_row;                            // (n, a), wave-uniform
     const int n = row / d.OA, a = row - n * d.OA;
     const int ob = (t - row * chunks_per_row) * PC + q4;           // first position of this thread's quad
-    const int lim = d.OB - ob;                                     // valid elements of the quad (<= 0: none)
+    const int lim = valid ? d.OB - ob : 0;                         // valid elements of the quad (<= 0: none)
     // num_records = the sample's exact span: a quad that runs past the last row of the tensor reads 0 for the dwords
     // beyond it (per-dword range check) instead of touching memory behind the allocation
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.in + (int64_t)n * d.in_ns), 0,
@@ -339,17 +339,45 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_wide_kernel(const WgradArgs
         }
     }
   };
-  // one register stage: the loads of chunk t+1 are issued right after chunk t went to LDS and stay in flight under
-  // chunk t's MFMAs (two workgroups per CU cover each other's barriers)
-  Stage st;
+  // Register stages.  With ONE stage the loads of chunk t+1 are in flight only under chunk t's MFMAs (~0.3 us) while an L2 / HBM
+  // round trip under load is 1-2 us: the r02b launch list showed the MFMA-heavy layers (3x3 rewrite convs, K = 9 Cin) at 270-360
+  // TF/s, i.e. waiting on loads.  Where two stages fit the register budget (everything but the 96 x 256 tile) the loop runs two
+  // chunks per iteration and each stage's loads fly under TWO chunks of staging + MFMAs.  An odd tail chunk is loaded with the
+  // out-of-range offset (zeros), so the loop body is branch-free.
+  constexpr int STAGE_REGS = 4 * NX + (G16 ? 2 : 4) * NG;
+  // MEASURED (r02b, Demucs step): weight-gradient launches 36.3 -> 39.5 ms with the two-stage loop, the 3x3 layers unchanged
+  // (2.56 -> 2.59 ms): they are bound by LDS / L1 bandwidth (48-64 KB into the CU per 512 clk of MFMA work), not by load latency,
+  // and the extra registers cost the small tiles occupancy.  Kept for the record, switched off.
+  constexpr bool DEEP = false && 2 * STAGE_REGS + 16 * TM * TK <= 200;
   const int t_last = t_end - 1;
-  if (t_begin < t_end) load_chunk(t_begin, st);
-  for (int t = t_begin; t < t_end; ++t) {
-    __syncthreads();                       // the previous chunk's fragment reads are done
-    stage(st);
-    __syncthreads();
-    load_chunk(min(t + 1, t_last), st);    // unconditional (branch-free): the last chunk is re-read
-    mma_chunk();
+  if (DEEP) {
+    Stage s0, s1;
+    if (t_begin < t_end) {
+      load_chunk(t_begin, s0, true);
+      load_chunk(min(t_begin + 1, t_last), s1, t_begin + 1 < t_end);
+    }
+    for (int t = t_begin; t < t_end; t += 2) {
+      __syncthreads();                       // the previous chunk's fragment reads are done
+      stage(s0);
+      __syncthreads();
+      load_chunk(min(t + 2, t_last), s0, t + 2 < t_end);
+      mma_chunk();
+      __syncthreads();
+      stage(s1);
+      __syncthreads();
+      load_chunk(min(t + 3, t_last), s1, t + 3 < t_end);
+      mma_chunk();
+    }
+  } else {
+    Stage st;
+    if (t_begin < t_end) load_chunk(t_begin, st, true);
+    for (int t = t_begin; t < t_end; ++t) {
+      __syncthreads();                       // the previous chunk's fragment reads are done
+      stage(st);
+      __syncthreads();
+      load_chunk(min(t + 1, t_last), st, true);    // unconditional (branch-free): the last chunk is re-read
+      mma_chunk();
+    }
   }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)

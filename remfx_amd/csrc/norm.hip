@@ -216,7 +216,31 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const GnArgs a, flo
   const int cw = (int)(r % Cw), n = (int)(r / Cw);
   const int64_t s0 = (int64_t)sc * GN_CHUNK, s1 = min(s0 + GN_CHUNK, (int64_t)a.S);
   float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  if (pair) {
+  if (pair && (a.S & 3) == 0) {
+    // 4 consecutive samples per lane, the (n, channel) constants loaded once per wave: the element-at-a-time loop below issues
+    // three scalar loads and ~10 constant fetches per element and ran at 0.33 of HBM on 16-bit x (r02b profile)
+    const int Co = a.C / 2;
+    const int ga = gn_sidx(a, n, cw), gb = gn_sidx(a, n, cw + Co);
+    const float mea = a.mean[ga], ra = a.rstd[ga], meb = a.mean[gb], rb = a.rstd[gb];
+    const float gma = a.gamma[cw], bta = a.beta[cw], gmb = a.gamma[cw + Co], btb = a.beta[cw + Co];
+    const float scl = a.mode == GN_GLU_SCALE_RES ? a.scale[cw] : 1.f;
+    const XT* xa = reinterpret_cast<const XT*>(a.x) + ((int64_t)n * a.C + cw) * a.S;
+    const XT* xb = xa + (int64_t)Co * a.S;
+    const float* gr = a.gy + ((int64_t)n * Co + cw) * a.S;
+    for (int64_t s = s0 + 4 * lane; s < s1; s += 256) {
+      const f32x4 va = rfx_ld4(xa + s), vb = rfx_ld4(xb + s), g4 = rfx_ld4(gr + s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xha = (va[q] - mea) * ra, xhb = (vb[q] - meb) * rb;
+        const float ua = xha * gma + bta, ub = xhb * gmb + btb;
+        const float sg = rfx_sigmoid(ub);
+        float g0 = g4[q];
+        if (a.mode == GN_GLU_SCALE_RES) { v[4] += g0 * ua * sg; g0 *= scl; }
+        const float dua = g0 * sg, dub = g0 * ua * sg * (1.f - sg);
+        v[0] += dua; v[1] += dua * xha; v[2] += dub; v[3] += dub * xhb;
+      }
+    }
+  } else if (pair) {
     for (int64_t s = s0 + lane; s < s1; s += 64) {
       const GnDu d = gn_du_pair<XT>(a, n, cw, s);
       v[0] += d.du_a; v[1] += d.du_a * d.xh_a; v[2] += d.du_b; v[3] += d.du_b * d.xh_b; v[4] += d.gf;
@@ -631,6 +655,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
   const GnXPtr<XT> xn = gn_xp<XT>(a) + (int64_t)n * a.C * a.S;
   const float* gyn = a.gy + (int64_t)n * Cw * a.S;
   const GnDxPtr<XT> dxn = gn_dxp<XT>(a) + (int64_t)n * a.C * a.S;
+  // 16-bit x: a lane owns PAIRS of adjacent samples (s = 2 lane + (q & 1) + 128 (q >> 1)) so that x and dx move as dwords (a 2-byte
+  // access per lane makes every load / store instruction carry half a cache line: 3.3 TB/s in the r02b profile); S is even there
+  constexpr bool PAIRED = sizeof(XT) == 2;
+  auto sof = [&](int q) { return PAIRED ? 2 * lane + (q & 1) + 128 * (q >> 1) : lane + 64 * q; };
   float xa[RW][SV], xb[RW][SV], gg[KEEPG ? RW : 1][SV];
 #pragma unroll
   for (int j = 0; j < RW; ++j) {
@@ -638,16 +666,26 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
     const int cc = cw < Cw ? cw : Cw - 1;                       // clamped: loads unconditional, results masked below
 #pragma unroll
     for (int q = 0; q < SV; ++q) {
-      const int s = lane + 64 * q;
+      const int s = sof(q);
       const int ss = s < a.S ? s : a.S - 1;
-      xa[j][q] = xn[(int64_t)cc * a.S + ss];
-      xb[j][q] = xn[(int64_t)(cc + Cw) * a.S + ss];
+      if (PAIRED) {
+        if ((q & 1) == 0) {                                      // one dword = samples (ss, ss + 1); ss is even, S is even
+          const int s2 = s < a.S ? s : a.S - 2;
+          const uint32_t ua = *reinterpret_cast<const uint32_t*>(xn.p + (int64_t)cc * a.S + s2);
+          const uint32_t ub = *reinterpret_cast<const uint32_t*>(xn.p + (int64_t)(cc + Cw) * a.S + s2);
+          xa[j][q] = __uint_as_float(ua << 16); xa[j][q + 1 < SV ? q + 1 : q] = __uint_as_float(ua & 0xffff0000u);
+          xb[j][q] = __uint_as_float(ub << 16); xb[j][q + 1 < SV ? q + 1 : q] = __uint_as_float(ub & 0xffff0000u);
+        }
+      } else {
+        xa[j][q] = xn[(int64_t)cc * a.S + ss];
+        xb[j][q] = xn[(int64_t)(cc + Cw) * a.S + ss];
+      }
       if (KEEPG) gg[j][q] = gyn[(int64_t)cc * a.S + ss];
     }
   }
   auto gval = [&](int j, int q, int cc) {
     if (KEEPG) return gg[j][q];
-    const int s = lane + 64 * q;
+    const int s = sof(q);
     return gyn[(int64_t)cc * a.S + (s < a.S ? s : a.S - 1)];
   };
   float gs1 = 0.f, gs2 = 0.f;
@@ -661,7 +699,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
     float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < SV; ++q) {
-      const float ok = (cok && lane + 64 * q < a.S) ? 1.f : 0.f;
+      const float ok = (cok && sof(q) < a.S) ? 1.f : 0.f;
       const float xha = (xa[j][q] - mean) * rstd, xhb = (xb[j][q] - mean) * rstd;
       const float ua = xha * ga + ba, ub = xhb * gb + bb;
       const float sg = rfx_sigmoid(ub);
@@ -695,18 +733,30 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
     if (cw >= Cw) continue;
     const float ga = a.gamma[cw], ba = a.beta[cw], gb = a.gamma[cw + Cw], bb = a.beta[cw + Cw];
     const float sc = a.mode == GN_GLU_SCALE_RES ? a.scale[cw] : 1.f;
+    float da[SV], db[SV];
 #pragma unroll
     for (int q = 0; q < SV; ++q) {
-      const int s = lane + 64 * q;
       const float xha = (xa[j][q] - mean) * rstd, xhb = (xb[j][q] - mean) * rstd;
       const float ua = xha * ga + ba, ub = xhb * gb + bb;
       const float sg = rfx_sigmoid(ub);
       const float gq = gval(j, q, cw);
       const float g0 = a.mode == GN_GLU_SCALE_RES ? gq * sc : gq;
       const float dua = g0 * sg, dub = g0 * ua * sg * (1.f - sg);
-      if (s < a.S) {
-        dxn[(int64_t)cw * a.S + s] = rstd * (dua * ga - m1 - xha * m2);
-        dxn[(int64_t)(cw + Cw) * a.S + s] = rstd * (dub * gb - m1 - xhb * m2);
+      da[q] = rstd * (dua * ga - m1 - xha * m2);
+      db[q] = rstd * (dub * gb - m1 - xhb * m2);
+    }
+#pragma unroll
+    for (int q = 0; q < SV; ++q) {
+      const int s = sof(q);
+      if (PAIRED) {
+        if ((q & 1) == 0 && s < a.S) {                           // (s, s + 1) as one dword
+          const int q1 = q + 1 < SV ? q + 1 : q;
+          *reinterpret_cast<uint32_t*>(dxn.p + (int64_t)cw * a.S + s) = rfx_bf16_bits(da[q]) | (rfx_bf16_bits(da[q1]) << 16);
+          *reinterpret_cast<uint32_t*>(dxn.p + (int64_t)(cw + Cw) * a.S + s) = rfx_bf16_bits(db[q]) | (rfx_bf16_bits(db[q1]) << 16);
+        }
+      } else if (s < a.S) {
+        dxn[(int64_t)cw * a.S + s] = da[q];
+        dxn[(int64_t)(cw + Cw) * a.S + s] = db[q];
       }
     }
   }
