@@ -396,8 +396,10 @@ def main():
     # roofline.traffic: HBM bytes per launch of the family from the committed PMC passes of this same command
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, scripts/collect_pmc.py)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", f"r02_demucs_b64_pmc_traffic_{args.gemm}.json")
-    if args.workload == "demucs" and batch == 64 and os.path.exists(pmc):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_demucs_b64_pmc_traffic_{args.gemm}.json")))   # latest round / pass last
+    pmc = cands[-1] if cands else ""
+    if args.workload == "demucs" and batch == 64 and pmc:
         ks = json.load(open(pmc))["kernels"]
         fam = [v for k, v in ks.items() if k.startswith(("gemm_fwd_kernel", "gemm_tap_kernel", "gemm_tap_stream_kernel"))]
         n = sum(v["launches_per_step"] for v in fam)

@@ -71,7 +71,7 @@ typedef struct rfx_gemm_desc {
    * gradient of a strided convolution) run as ONE GEMM with rows m = channel*G + phase, so the gathers are shared by G
    * times more MFMA work.  Row m, position index i on axis mg_axis (0 = A, 1 = B) is stored at channel m >> mg_log,
    * axis index i*G + (m & (G-1)) + mg_off if that lies in [0, mg_len); bias is indexed by the channel.  Epilogue
-   * options other than bias / act are not available in this mode, nor is the thin (M <= 8) path. */
+   * options other than bias / act / res are not available in this mode, nor is the thin (M <= 8) path. */
   int32_t mg_log, mg_axis, mg_len, mg_off;
   /* Tap-major form of the reduction axis (Kpad_t > 0; planner: every operand with >= 8 channels and <= 112 taps), used
    * by the bf16x3 / bf16 kernels: k runs over 8-channel groups g = t * gpt + c8 (tap t, channels 8*c8 .. 8*c8+7),

@@ -191,7 +191,7 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   if (g.e.bwd && !g.e.res) return -1;
   if (g.e.glu_out && (d->R == 0 || (d->M & 1) || g.e.bwd || g.e.res || g.e.act2 != RFX_ACT_NONE || g.e.stat_sums || apack2 ||
                       d->mg_log)) return -1;
-  if (d->mg_log && (d->R == 0 || g.e.bwd || g.e.res || g.e.act2 != RFX_ACT_NONE || g.e.stat_sums || apack2 ||
+  if (d->mg_log && (d->R == 0 || g.e.bwd || g.e.act2 != RFX_ACT_NONE || g.e.stat_sums || apack2 ||
                     d->mg_log > 8 || d->mg_axis < 0 || d->mg_axis > 1)) return -1;
   // bf16 storage of single operands: gathered input on the tap-major tiled kernels of the bf16 mode; output wherever the
   // plain / GLU store runs (not the phase-merged, backward-epilogue or thin paths)

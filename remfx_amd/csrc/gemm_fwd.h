@@ -327,6 +327,54 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
     const int64_t other = d.mg_axis ? (int64_t)(a * d.out_sa + d.out_a0) * d.out_as : (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
     const int64_t st = d.mg_axis ? d.out_bs : d.out_as;
     float* ob = g.out + (int64_t)n * d.out_ns + other;
+    // optional residual (a second gradient path into the same tensor: HDemucs skip connections), same coordinates as out
+    const int64_t rother = d.mg_axis ? (int64_t)(a * d.out_sa + d.out_a0) * e.res_as : (int64_t)(b * d.out_sb + d.out_b0) * e.res_bs;
+    const int64_t rst = d.mg_axis ? e.res_bs : e.res_as;
+    const float* rb = e.res ? e.res + (int64_t)n * e.res_ns + rother : nullptr;
+    if (d.mg_log == 2 && st == 1 && (!rb || rst == 1)) {
+      // G = 4, unit stride along the merged axis: a lane's rows r..r+3 are the 4 phases of one channel = 4 CONSECUTIVE output
+      // samples -> one 16-byte store (and one 16-byte residual load) per lane and channel when all four lie inside the row
+#pragma unroll
+      for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+          const int m = m0 + mt * 32 + 8 * (r >> 2) + 4 * h;          // phase 0 row of this quad (m0, 32 mt, 8 (r>>2), 4 h: all multiples of 4)
+          const int idx = (pos << 2) + d.mg_off;
+          if (!c.jvalid || m >= d.M) continue;
+          float* op = ob + (int64_t)(m >> 2) * d.out_cs + idx;
+          const float* rp = rb ? rb + (int64_t)(m >> 2) * e.res_cs + idx : nullptr;
+          if (idx >= 0 && idx + 3 < d.mg_len) {
+            f32x4 v = {acc[mt][r], acc[mt][r + 1], acc[mt][r + 2], acc[mt][r + 3]};
+            if (rp) {
+              f32x4 rv;
+              __builtin_memcpy(&rv, rp, 16);                         // 4-byte aligned 16-byte access (mg_off need not be a multiple of 4)
+              v += rv;
+            }
+            __builtin_memcpy(op, &v, 16);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if ((unsigned)(idx + q) < (unsigned)d.mg_len) op[q] = acc[mt][r + q] + (rp ? rp[q] : 0.f);
+          }
+        }
+      return;
+    }
+    if (rb) {          // wave-uniform.  All residual loads of a channel tile first (clamped addresses, unconditional), then the adds:
+                       // interleaved with the stores they would be serialised by the may-alias ordering
+#pragma unroll
+      for (int mt = 0; mt < R; ++mt) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int idx = (pos << d.mg_log) + (m & G1) + d.mg_off;
+          const bool ok = c.jvalid && m < d.M && (unsigned)idx < (unsigned)d.mg_len;
+          rv[r] = rb[ok ? (int64_t)(m >> d.mg_log) * e.res_cs + (int64_t)idx * rst : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] += rv[r];
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < R; ++mt)
 #pragma unroll

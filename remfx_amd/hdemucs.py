@@ -165,15 +165,31 @@ class _HEncLayer(nn.Module):
             self.norm2 = _norm(norm_groups, 2 * chout, norm)
             self.dconv = _DConv(chout, **(dconv_kw or {}))
 
-    def forward(self, x, inject=None):
+    def forward(self, x, inject=None, fork=False):
+        """fork=True (x is the previous layer's output, which is also a skip connection): returns (out, alias of x); the caller
+        keeps the ALIAS as the skip, so both gradients of x reach this layer's conv backward together and the skip gradient is
+        added in the input-gradient GEMM's store (ops.ConvFork2dFn) instead of a separate accumulation pass over the tensor."""
+        alias, want_pair = None, fork
         if not self.freq and x.dim() == 4:
             x = x.reshape(x.shape[0], -1, x.shape[-1])
+            fork = False
         if self.freq:
-            y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0))
+            if fork:
+                y, alias = ops.conv2d_fork(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0))
+            else:
+                y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0))
         else:
             if x.shape[-1] % self.stride:
                 x = F.pad(x, (0, self.stride - x.shape[-1] % self.stride))
-            y = ops.conv1d(x, self.conv.weight, self.conv.bias, self.stride, self.pad)
+                fork = False
+            if fork:
+                y, alias = ops.conv1d_fork(x, self.conv.weight, self.conv.bias, self.stride, self.pad)
+            else:
+                y = ops.conv1d(x, self.conv.weight, self.conv.bias, self.stride, self.pad)
+        out = self._rest(y, inject)
+        return (out, alias) if want_pair else out
+
+    def _rest(self, y, inject):
         if self.empty:
             return y
         if inject is not None:
@@ -347,12 +363,22 @@ class HDemucs(nn.Module):
             if idx < len(self.time_encoder):
                 lengths_t.append(xt.shape[-1])
                 tenc = self.time_encoder[idx]
-                xt = tenc(xt)
+                if saved_t and saved_t[-1] is xt:          # xt is the previous layer's output = a skip connection: see fork
+                    xt, alias = tenc(xt, fork=True)
+                    if alias is not None:
+                        saved_t[-1] = alias
+                else:
+                    xt = tenc(xt)
                 if not tenc.empty:
                     saved_t.append(xt)
                 else:
                     inject = xt
-            x = encode(x, inject)
+            if saved and saved[-1] is x:
+                x, alias = encode(x, inject, fork=True)
+                if alias is not None:
+                    saved[-1] = alias
+            else:
+                x = encode(x, inject)
             if idx == 0 and self.freq_emb is not None:
                 emb = self.freq_emb.table().t()[None, :, :, None]
                 x = nnops.add(x, emb, self.freq_emb_scale)

@@ -240,11 +240,11 @@ def _merged_weight(w_oik, ax, S):
     return (wm.unsqueeze(3) if ax == 0 else wm.unsqueeze(2)).contiguous(), J
 
 
-def _merged_launch(inp, wm, ax, S, J, off, out, bias=None):
+def _merged_launch(inp, wm, ax, S, J, off, out, bias=None, res=None):
     key = _key("mg", inp.shape, inp.stride(), wm.shape, ax, S, off, out.shape, out.stride())
     dp = _plans(key, inp.device, lambda: convplan.merged_phase_plan(
         tuple(inp.shape), inp.stride(), wm.shape[0], ax, S, J, off, out.shape[2 + ax], out.stride()))
-    gemm_fwd(dp, pack_a(dp, wm), inp, out, bias=bias)
+    gemm_fwd(dp, pack_a(dp, wm), inp, out, bias=bias, res=res)
     return out
 
 
@@ -257,10 +257,11 @@ def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None, res
     if ax is not None and w.shape[1] * stride[ax] >= 4:
         # dx[ci][o] = sum g[co][i] w[co][ci][kk], o = S*i + kk - P: all S phases of o as rows (ci, q) of one GEMM over g
         wm, J = _merged_weight(w.transpose(0, 1), ax, stride[ax])
-        out = _merged_launch(g, wm, ax, stride[ax], J, -padding[ax], dx)
-        # a residual operand in the merged-phase store was measured: the torch add it removes (-2.2 ms/step on the HDemucs
-        # skip connections) is paid back by the strided 4-byte residual loads in the GEMM (+1.5..2.5 ms): not kept
-        return out.add_(res) if res is not None else out
+        # the residual (skip-connection gradient) rides in the merged-phase store: stride 4 along a unit-stride axis makes a
+        # lane's four phases one 16-byte run, so the residual is ONE 16-byte load per lane and channel (round 1 measured the
+        # strided 4-byte form as a loss and kept the torch add instead)
+        # (time branch); along the frequency axis the four phases are four rows and the residual loads coalesce across lanes
+        return _merged_launch(g, wm, ax, stride[ax], J, -padding[ax], dx, res=res)
     if res is not None and tuple(stride) != (1, 1):       # per-phase plans: add afterwards
         return conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx).add_(res)
     key = _key("cd", xshape, xstrides, w.shape, stride, padding, dilation, g.shape, g.stride())

@@ -18,7 +18,7 @@ FAMILIES = [
     ("GLU / activations / adds", ("glu", "act", "add_", "row_", "prelu", "channel_sum", "blstm_frames", "span_mask")),
     ("framed FFT", ("fft", "stft", "istft")),
     ("losses", ("l1", "stft_loss", "sisdr")),
-    ("attention", ("localstate",)),
+    ("attention", ("localstate", "ls_mfma")),
     ("pack / unpack", ("pack", "unpack")),
     ("optimiser", ("adamw", "sumsq", "clip")),
 ]
