@@ -235,6 +235,8 @@ int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const 
 int rfx_act_fwd(const float* x, float* y, int64_t n, int32_t act, void* stream);
 /* gx = gy * act'(x) */
 int rfx_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int32_t act, void* stream);
+/* y = act(x) + res (same shapes, contiguous): decoder GELU + the next layer's skip-connection add (HDemucs, models.py:319) */
+int rfx_act_add_fwd(const float* x, const float* res, float* y, int64_t n, int32_t act, void* stream);
 /* The same between row layouts: x, gy (NULL: forward, out = act(x); else out = gy * act'(x)) and out are (D0, D1, D2)
  * grids of contiguous T-float rows with their own row strides (in floats).  Used where the reference permutes around
  * an activation -- torchaudio HDemucs _HEncLayer: `y = gelu(norm1(conv(x)))` then `y.permute(0, 2, 1, 3).reshape(-1, C, T)`

@@ -133,6 +133,7 @@ SIGNATURES = {
     "rfx_glu_bwd_bf16": [_P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_act_fwd": [_P, _P, _I64, _I32, _P],
     "rfx_act_bwd": [_P, _P, _P, _I64, _I32, _P],
+    "rfx_act_add_fwd": [_P, _P, _P, _I64, _I32, _P],
     "rfx_act_rows": [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P],
     "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_l1_sum": [_P, _P, _I64, _P, _P],

@@ -16,6 +16,22 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
     y[i] = rfx_act_apply(x[i], act, 0.f);
 }
 
+// y = act(x) + res: the decoder's GELU and the NEXT layer's skip-connection add in one pass (3 tensor passes instead of 5)
+__global__ void act_add_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y, int64_t n,
+                                   int act) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = rfx_act_apply(v[c], act, 0.f) + r[c];
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = rfx_act_apply(x[i], act, 0.f) + res[i];
+}
+
 __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                float* __restrict__ gx, int64_t n, int act) {
   const int64_t n4 = n >> 2;
@@ -230,6 +246,13 @@ extern "C" int rfx_act_bwd(const float* x, const float* gy, float* gx, int64_t n
   if (!x || !gy || !gx || n < 0) return -1;
   if (n == 0) return 0;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, n, act);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_act_add_fwd(const float* x, const float* res, float* y, int64_t n, int32_t act, void* stream) {
+  if (!x || !res || !y || n < 0) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_add_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, res, y, n, act);
   RFX_CHECK_LAUNCH();
   return 0;
 }

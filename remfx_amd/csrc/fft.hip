@@ -163,6 +163,14 @@ __device__ __forceinline__ float2 half_twiddle(const float2* tw, const float2* t
   return make_float2(c, -s);
 }
 
+// digit-reversed position of every natural index: one LDS read instead of ~12 integer instructions per use in the split / merge
+// steps (the r02c profile has these kernels VALU-issue-bound: ~6000 instructions per thread, two thirds of them index arithmetic)
+template <int LOGN>
+__device__ __forceinline__ void build_rev(uint16_t* rev) {
+  constexpr int NC = 1 << LOGN;
+  for (int t = threadIdx.x; t < NC; t += 256) rev[t] = (uint16_t)digit_pos<LOGN>(t);
+}
+
 template <int LOGN>
 __device__ __forceinline__ void build_twiddles(float2* tw) {
   constexpr int NC = 1 << LOGN;
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
   __shared__ float2 data[FB * FS];
   __shared__ float2 tw[NC];
   __shared__ float2 tw2[LOGN <= 10 ? NC / 2 : 1];     // e^{-i pi k / NC} for ODD k (even k is tw[k/2]); LDS budget: n_fft <= 2048
+  __shared__ uint16_t rev[NC];
   const rfx_stft_desc& d = a.d;
   int row, f_first;
   block_coords<LOGN>(a, row, f_first);
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
   const int tid = threadIdx.x;
   build_twiddles<LOGN>(tw);
   build_half_twiddles<LOGN>(tw2);
+  build_rev<LOGN>(rev);
   const int f_end = d.frame0 + d.frames_out;
   const float* xr = a.x + (int64_t)row * d.T;
   const int woff = (N - d.win) / 2;
@@ -193,6 +203,24 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
   // unconditional, validity is applied to the VALUE afterwards.  (With the loads inside `if (in window) if (in signal)`
   // hipcc emitted one load + s_waitcnt vmcnt(0) per sample: 64 dependent memory round trips per thread and workgroup,
   // which is where the r01 kernels spent their time: 0.87 ms for 3.4 GFLOP.)
+  // r02: the kernels are VALU-issue-bound, so (a) a thread's points have only NC / 256 distinct in-frame indices: their window
+  // values (x scale, 0 outside the window) are fetched once into registers; (b) a workgroup whose whole span lies inside the
+  // signal (all but the first / last few of a row) skips the reflect arithmetic of map_sample.
+  constexpr int NCB = NC / 256;                                   // distinct i per thread (1, 2, 4, 8)
+  float wv[NCB <= 4 ? NCB : 1][2];
+  if (NCB <= 4) {
+#pragma unroll
+    for (int c = 0; c < (NCB <= 4 ? NCB : 1); ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int wi = 2 * (tid + 256 * c) + u - woff;
+        const bool wok = (wi >= 0) & (wi < d.win);
+        wv[c][u] = wok ? a.window[wok ? wi : 0] * d.scale : 0.f;
+      }
+  }
+  const int shift = d.in_mode == 0 ? d.n_fft / 2 + d.extra_pad_l : d.in_offset;
+  const int64_t p_lo = (int64_t)f_first * d.hop, p_hi = (int64_t)(f_first + FB - 1) * d.hop + N - 1;
+  const bool interior = (f_first + FB <= f_end) & (p_lo - shift >= 0) & (p_hi - shift < (int64_t)d.T);      // workgroup-uniform
   for (int j0 = 0; j0 < (FB * NC) / 256; j0 += 4) {
     float xs[8], ws[8], ms[8];
     bool ok[8];
@@ -204,14 +232,23 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * i + u;
-        const int wi = t - woff;
         const int pp = f * d.hop + t;
-        const int sm = map_sample(d, pp);
-        const bool v = (f < f_end) & (wi >= 0) & (wi < d.win) & (sm >= 0);
-        ok[2 * e + u] = v;
-        xs[2 * e + u] = xr[v ? sm : 0];
-        ws[2 * e + u] = a.window[v ? wi : 0];
-        ms[2 * e + u] = a.mul ? a.mul[v ? pp : 0] : 1.f;       // a.mul: wave-uniform
+        if (NCB <= 4) {
+          const int sm = interior ? pp - shift : map_sample(d, pp);
+          const bool v = interior | ((f < f_end) & (sm >= 0));
+          ok[2 * e + u] = v;
+          xs[2 * e + u] = xr[v ? sm : 0];
+          ws[2 * e + u] = wv[e & (NCB <= 4 ? NCB - 1 : 0)][u];      // j0 is a multiple of 4: (j0 + e) mod NCB = e mod NCB
+          ms[2 * e + u] = a.mul ? a.mul[v ? pp : 0] : 1.f;       // a.mul: wave-uniform
+        } else {
+          const int wi = t - woff;
+          const int sm = map_sample(d, pp);
+          const bool v = (f < f_end) & (wi >= 0) & (wi < d.win) & (sm >= 0);
+          ok[2 * e + u] = v;
+          xs[2 * e + u] = xr[v ? sm : 0];
+          ws[2 * e + u] = a.window[v ? wi : 0] * d.scale;
+          ms[2 * e + u] = a.mul ? a.mul[v ? pp : 0] : 1.f;
+        }
       }
     }
 #pragma unroll
@@ -219,8 +256,8 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
       const int idx = tid + 256 * (j0 + e);
       const int fl = idx >> LOGN, i = idx & (NC - 1);
       float2 v;
-      v.x = ok[2 * e] ? xs[2 * e] * ws[2 * e] * d.scale * ms[2 * e] : 0.f;
-      v.y = ok[2 * e + 1] ? xs[2 * e + 1] * ws[2 * e + 1] * d.scale * ms[2 * e + 1] : 0.f;
+      v.x = ok[2 * e] ? xs[2 * e] * ws[2 * e] * ms[2 * e] : 0.f;
+      v.y = ok[2 * e + 1] ? xs[2 * e + 1] * ws[2 * e + 1] * ms[2 * e + 1] : 0.f;
       data[fl * FS + i] = v;
     }
   }
@@ -232,8 +269,8 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
     const int k = idx / FB, fl = idx - k * FB;
     const int f = f_first + fl;
     if (f >= f_end) continue;
-    const float2 A = data[fl * FS + digit_pos<LOGN>(k & (NC - 1))];
-    const float2 Bq = data[fl * FS + digit_pos<LOGN>((NC - k) & (NC - 1))];
+    const float2 A = data[fl * FS + rev[k & (NC - 1)]];
+    const float2 Bq = data[fl * FS + rev[(NC - k) & (NC - 1)]];
     const float2 Bc = make_float2(Bq.x, -Bq.y);
     const float2 E = make_float2(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
     const float2 D = make_float2(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
@@ -275,6 +312,7 @@ __global__ __launch_bounds__(256) void fft_synthesis_kernel(const FftArgs a) {
   __shared__ float2 data[FB * FS];
   __shared__ float2 tw[NC];
   __shared__ float2 tw2[LOGN <= 10 ? NC / 2 : 1];     // e^{-i pi k / NC} for ODD k (even k is tw[k/2]); LDS budget: n_fft <= 2048
+  __shared__ uint16_t rev[NC];
   const rfx_stft_desc& d = a.d;
   int row, f_first;
   block_coords<LOGN>(a, row, f_first);
@@ -282,6 +320,8 @@ __global__ __launch_bounds__(256) void fft_synthesis_kernel(const FftArgs a) {
   const int tid = threadIdx.x;
   build_twiddles<LOGN>(tw);
   build_half_twiddles<LOGN>(tw2);
+  build_rev<LOGN>(rev);
+  __syncthreads();                       // the merge step below reads the tables other threads built
   const int f_end = d.frame0 + d.frames_out;
   const int FO = d.frames_out;
   // merge step: Z[k] = (X[k] + conj X[NC-k]) + i e^{+i pi k/NC} (X[k] - conj X[NC-k]),  k in [0, NC)
@@ -326,7 +366,7 @@ __global__ __launch_bounds__(256) void fft_synthesis_kernel(const FftArgs a) {
         const float2 W = cmul(D, make_float2(hw.x, -hw.y));
         Z = make_float2(S.x - W.y, S.y + W.x);  // S + i*W
       }
-      data[fl * FS + digit_pos<LOGN>(k)] = Z;
+      data[fl * FS + rev[k]] = Z;
     }
   }
   __syncthreads();

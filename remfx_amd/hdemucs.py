@@ -238,11 +238,15 @@ class _HDecLayer(nn.Module):
             self.rewrite = klass(chin, 2 * chin, 1 + 2 * context, 1, context)
             self.norm1 = _norm(norm_groups, 2 * chin, norm)
 
-    def forward(self, x, skip, length):
+    def forward(self, x, skip, length, next_skip=None, skip_added=False):
+        """next_skip: the skip tensor the NEXT decoder layer will add to this layer's output; where this layer ends in a plain GELU
+        it is added in the same pass (ops.activation_add) and `self.fused_next_add` tells the caller to pass skip_added=True on."""
+        self.fused_next_add = False
         if self.freq and x.dim() == 3:
             x = x.view(x.shape[0], self.chin, -1, x.shape[-1])
         if not self.empty:
-            x = nnops.add(x, skip)
+            if not skip_added:
+                x = nnops.add(x, skip)
             c = self.context
             if not isinstance(self.norm1, nn.GroupNorm):              # GLU in the GEMM store
                 y = (ops.conv2d_glu(x, self.rewrite.weight, self.rewrite.bias, (1, 1), (c, c)) if self.freq else
@@ -275,6 +279,10 @@ class _HDecLayer(nn.Module):
                                      (self.pad, 0), (full - 2 * self.pad, y.shape[3]))
         else:              # crop [pad : pad + length]
             z = ops.conv_transpose1d(y, self.conv_tr.weight, self.conv_tr.bias, self.stride, 1, self.pad, length)
+        if (next_skip is not None and act == "gelu" and not isinstance(self.norm2, nn.GroupNorm) and z.is_contiguous()
+                and next_skip.shape == z.shape):
+            self.fused_next_add = True
+            return ops.activation_add(z, next_skip, "gelu"), y
         z = _norm_act(self.norm2, z, act)
         return z, y
 
@@ -386,15 +394,21 @@ class HDemucs(nn.Module):
         x = torch.zeros_like(x)
         xt = torch.zeros_like(x)
         offset = self.depth - len(self.time_decoder)
+        fadd = tadd = False                      # the previous layer already added this layer's skip (activation_add)
         for idx, decode in enumerate(self.freq_decoder):
-            x, pre = decode(x, saved.pop(-1), lengths.pop(-1))
+            skip = saved.pop(-1)
+            x, pre = decode(x, skip, lengths.pop(-1), next_skip=saved[-1] if saved else None, skip_added=fadd)
+            fadd = decode.fused_next_add
             if idx >= offset:
                 tdec = self.time_decoder[idx - offset]
                 length_t = lengths_t.pop(-1)
                 if tdec.empty:
                     xt, _ = tdec(pre[:, :, 0], None, length_t)
+                    tadd = False
                 else:
-                    xt, _ = tdec(xt, saved_t.pop(-1), length_t)
+                    skip_t = saved_t.pop(-1)
+                    xt, _ = tdec(xt, skip_t, length_t, next_skip=saved_t[-1] if saved_t else None, skip_added=tadd)
+                    tadd = tdec.fused_next_add
         S = len(self.sources)
         x = nnops.row_affine(x.reshape(B, -1), std, mean)          # S == 1 for RemFX: one (std, mean) per clip
         if S != 1:

@@ -524,6 +524,33 @@ def activation(x, act):
     return ActFn.apply(x, act)
 
 
+class ActAddFn(torch.autograd.Function):
+    """act(x) + res in one pass (rfx_act_add_fwd): the HDemucs decoder's GELU and the next layer's `x + skip`."""
+
+    @staticmethod
+    def forward(ctx, x, res, act):
+        _req(x); _req(res, "res")
+        x, res = x.contiguous(), res.contiguous()
+        y = torch.empty_like(x)
+        check(_lib.lib().rfx_act_add_fwd(_ptr(x), _ptr(res), _ptr(y), x.numel(), ACT[act], _stream()), "rfx_act_add_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        check(_lib.lib().rfx_act_bwd(_ptr(x), _ptr(gy), _ptr(gx), x.numel(), ACT[ctx.act], _stream()),
+              "rfx_act_bwd")
+        return gx, gy, None
+
+
+def activation_add(x, res, act):
+    return ActAddFn.apply(x, res, act)
+
+
 def _row_strides(t):
     """(D0, D1, D2, T) tensor whose last axis is contiguous -> its three row strides."""
     if t.dim() != 4 or t.stride(3) != 1:
