@@ -19,6 +19,17 @@
 //     (block b runs on XCD b % 8) so partial-line stores merge in one L2.
 #include "common.h"
 
+// complex points per workgroup: 8192 (64 KB of LDS, 2 workgroups per CU) -- or 4096 for n_fft <= 1024 (RFX_FFT_PTS_SMALL), which
+// doubles the resident waves of these barrier-separated LDS passes at the price of shorter store runs in the transposing epilogue
+#ifndef RFX_FFT_PTS_SMALL
+#define RFX_FFT_PTS_SMALL 2048
+#endif
+#ifndef RFX_FFT_PTS_LARGE
+#define RFX_FFT_PTS_LARGE 4096
+#endif
+#define RFX_FFT_PTS(LOGN) ((LOGN) <= 9 ? RFX_FFT_PTS_SMALL : RFX_FFT_PTS_LARGE)
+static int rfx_fft_pts(int nc) { return nc <= 512 ? RFX_FFT_PTS_SMALL : RFX_FFT_PTS_LARGE; }
+
 struct FftArgs {
   rfx_stft_desc d;
   const float* x;       // analysis: signal [R][T];   synthesis: spectrum
@@ -133,7 +144,7 @@ __device__ __forceinline__ int map_sample(const rfx_stft_desc& d, int p) {
 
 template <int LOGN>
 __device__ __forceinline__ void block_coords(const FftArgs& a, int& row, int& f_first) {
-  constexpr int FB = 8192 >> LOGN;
+  constexpr int FB = RFX_FFT_PTS(LOGN) >> LOGN;
   // same-row frame groups on the same XCD (block b -> XCD b % 8), adjacent in time
   const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
   const int slot = q / a.groups_per_row, grp = q - slot * a.groups_per_row;
@@ -183,7 +194,7 @@ __device__ __forceinline__ void build_twiddles(float2* tw) {
 
 template <int LOGN>
 __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
-  constexpr int NC = 1 << LOGN, FB = 8192 >> LOGN, FS = NC + 1, N = 2 * NC;
+  constexpr int NC = 1 << LOGN, FB = RFX_FFT_PTS(LOGN) >> LOGN, FS = NC + 1, N = 2 * NC;
   __shared__ float2 data[FB * FS];
   __shared__ float2 tw[NC];
   __shared__ float2 tw2[LOGN <= 10 ? NC / 2 : 1];     // e^{-i pi k / NC} for ODD k (even k is tw[k/2]); LDS budget: n_fft <= 2048
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
 
 template <int LOGN>
 __global__ __launch_bounds__(256) void fft_synthesis_kernel(const FftArgs a) {
-  constexpr int NC = 1 << LOGN, FB = 8192 >> LOGN, FS = NC + 1, N = 2 * NC;
+  constexpr int NC = 1 << LOGN, FB = RFX_FFT_PTS(LOGN) >> LOGN, FS = NC + 1, N = 2 * NC;
   __shared__ float2 data[FB * FS];
   __shared__ float2 tw[NC];
   __shared__ float2 tw2[LOGN <= 10 ? NC / 2 : 1];     // e^{-i pi k / NC} for ODD k (even k is tw[k/2]); LDS budget: n_fft <= 2048
@@ -417,7 +428,7 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
   FftArgs a;
   a.d = *d; a.x = x; a.window = window; a.mul = mul; a.out = out;
   const int nc = d->n_fft / 2;
-  const int fb = 8192 / nc;
+  const int fb = rfx_fft_pts(nc) / nc;
   a.groups_per_row = (d->frames_out + fb - 1) / fb;
   const int rows8 = (d->R + 7) / 8;
   const unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);

@@ -665,6 +665,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
   constexpr bool PAIRED = sizeof(XT) == 2;
   auto sof = [&](int q) { return PAIRED ? 2 * lane + (q & 1) + 128 * (q >> 1) : lane + 64 * q; };
   float xa[RW][SV], xb[RW][SV], gg[KEEPG ? RW : 1][SV];
+  // the sigmoid and the normalised first half are kept between the statistics pass and the dx pass where registers allow (RW = 3):
+  // the kernel is VALU-bound (two passes of ~50 instructions per pair), not HBM-bound
+  constexpr bool CACHE = RW <= 3;
+  float sgc[CACHE ? RW : 1][SV], uac[CACHE ? RW : 1][SV];
 #pragma unroll
   for (int j = 0; j < RW; ++j) {
     const int cw = wave + 16 * j;
@@ -708,6 +712,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
       const float xha = (xa[j][q] - mean) * rstd, xhb = (xb[j][q] - mean) * rstd;
       const float ua = xha * ga + ba, ub = xhb * gb + bb;
       const float sg = rfx_sigmoid(ub);
+      if (CACHE) { sgc[j][q] = sg; uac[j][q] = ua; }
       float g0 = gval(j, q, cc) * ok;
       float gf = 0.f;
       if (a.mode == GN_GLU_SCALE_RES) { gf = g0 * ua * sg; g0 *= sc; }
@@ -742,8 +747,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_sample_reg_kernel(const GnArgs a,
 #pragma unroll
     for (int q = 0; q < SV; ++q) {
       const float xha = (xa[j][q] - mean) * rstd, xhb = (xb[j][q] - mean) * rstd;
-      const float ua = xha * ga + ba, ub = xhb * gb + bb;
-      const float sg = rfx_sigmoid(ub);
+      const float ua = CACHE ? uac[j][q] : xha * ga + ba;
+      const float sg = CACHE ? sgc[j][q] : rfx_sigmoid(xhb * gb + bb);
       const float gq = gval(j, q, cw);
       const float g0 = a.mode == GN_GLU_SCALE_RES ? gq * sc : gq;
       const float dua = g0 * sg, dub = g0 * ua * sg * (1.f - sg);
