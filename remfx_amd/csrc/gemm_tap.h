@@ -216,8 +216,13 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
   if (ks + 2 < nk) k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
 }
 
+// R <= 2 (M <= 64 per tile: the bandwidth-bound layers) is compiled for three waves per SIMD (RFX_TAP_OCC): its accumulators are
+// small and more resident waves hide more gather latency; R >= 3 needs the registers
+#ifndef RFX_TAP_OCC
+#define RFX_TAP_OCC 3
+#endif
 template <int R, int MODE, bool IN16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_tap_kernel(const FwdArgs g) {
+__global__ __launch_bounds__(256, (R <= 2 && MODE == 2) ? RFX_TAP_OCC : 2) void gemm_tap_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
   __shared__ __attribute__((aligned(16))) uint4 smem[4 * CELLS + RFX_TAP_LDS];   // A: 2 buffers x 2 K steps; tap table
   uint4* as = smem;
@@ -297,7 +302,7 @@ __device__ __forceinline__ void stream_mma(const uint4* a_lds, int h, int l31, c
 }
 
 template <int MODE, int NT, int NKMAX>
-__global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g) {      // 3 waves / SIMD spills its tile ring: measured slower
   constexpr int R = 1, BM = 32, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
   __shared__ __attribute__((aligned(16))) uint4 smem[4 * CELLS + RFX_TAP_LDS];   // A of K steps 0..3; tap table
   uint4* as = smem;
