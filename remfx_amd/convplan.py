@@ -21,6 +21,9 @@ import numpy as np
 INVALID_DA = -(1 << 30)
 
 
+R_MAX = int(os.environ.get("RFX_R_MAX", "4"))
+
+
 def pick_r(M, K=1 << 30):
     """Mirror of rfx_gemm_pick_r (csrc/gemm.hip): channel tiles per wave."""
     if M <= 8:
@@ -29,6 +32,10 @@ def pick_r(M, K=1 << 30):
         return 1
     if K <= 64:
         return 1
+    if R_MAX < 4:                                     # experiment switch (RFX_R_MAX): cap the channel tiles per wave
+        cands = [r for r in (3, 2) if r <= R_MAX] or [1]
+        best = min(cands, key=lambda r: (-(-M // (32 * r)) * 32 * r, -r))
+        return best
     best, best_pad = 4, -(-M // 128) * 128
     for r in (3, 2):
         pad = -(-M // (32 * r)) * 32 * r
