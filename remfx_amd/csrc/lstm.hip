@@ -598,8 +598,13 @@ extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* ga
   a.cstate = const_cast<float*>(cstate); a.dG = dG;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
   // (the unrolled NWC forms of the backward kernel spill at 512 registers: only the runtime form is instantiated)
-  if (prec == RFX_PREC_BF16)
+  if (prec == RFX_PREC_BF16) {
+    // single-fragment products halve the weight ring: the unrolled forms (exact wait counts instead of a vmcnt(0) drain at the loop
+    // header) fit the register file here for H = 192 (H = 384 still spills 364 B; RFX_LSTM_BWD_UNROLL=0: runtime loop)
+    static const int unroll = getenv("RFX_LSTM_BWD_UNROLL") ? atoi(getenv("RFX_LSTM_BWD_UNROLL")) : 1;
+    if (unroll && H == 192) return lstm_launch(lstm_bwd_kernel<2, 6, false>, a, ws, stream);
     return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, false>, a, ws, stream)
                              : lstm_launch(lstm_bwd_kernel<1, 0, false>, a, ws, stream);
+  }
   return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, true>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1, 0, true>, a, ws, stream);
 }
