@@ -253,8 +253,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           const int k1 = ks + d + 1 == nks ? 0 : ks + d + 1;       // h fragments one k-step ahead (LDS latency)
           loadB(bh[(d + 1) & 1], bl[(d + 1) & 1], k1);
           mma(acc, f[d], bh[d & 1], bl[d & 1]);
-          const int kn = ks + d + D;                  // the slot's next occupant; wraps into the next step
-          loadA(f[d], kn >= nks ? kn - nks : kn);
+          if (!(NKS && D == NKS)) {                   // D == NKS: the whole W_hh slice of this wave stays in registers
+            const int kn = ks + d + D;                // the slot's next occupant; wraps into the next step
+            loadA(f[d], kn >= nks ? kn - nks : kn);
+          }
           __builtin_amdgcn_sched_barrier(0);          // keep the refill behind its MFMAs (scheduler would hoist all loads)
         }
       };
@@ -577,6 +579,10 @@ extern "C" int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_
   a.xp = xp; a.packA = reinterpret_cast<const uint4*>(pack); a.out = out; a.gates = gates; a.cstate = cstate;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
   if (prec == RFX_PREC_BF16) {                 // bf16 operands (bf16-mixed): no lo fragments
+    // H = 192: the wave's whole W_hh slice (48 fragments = 192 VGPRs) stays in registers instead of being re-streamed through L1
+    // every time step (RFX_LSTM_RESIDENT=0: 4-k-step ring)
+    static const int resident = getenv("RFX_LSTM_RESIDENT") ? atoi(getenv("RFX_LSTM_RESIDENT")) : 1;
+    if (H == 192 && resident) return lstm_launch(lstm_fwd_kernel<12, 12, false>, a, ws, stream);
     if (H == 192) return lstm_launch(lstm_fwd_kernel<4, 12, false>, a, ws, stream);
     if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16, false>, a, ws, stream);
     if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24, false>, a, ws, stream);

@@ -311,6 +311,40 @@ __global__ __launch_bounds__(256) void gn_bwd_chansum_kernel(const GnArgs a, con
   }
 }
 
+// Many samples (freq-branch DConvs: N = 32768): the kernel above gives one wave per channel a serial walk over all N with
+// channel-strided reads (90-100 us for 13 MB).  Split N over NS slices (partials [NS][C][3] in `scratch`), then add the slices up.
+__global__ __launch_bounds__(256) void gn_bwd_chansum_split_kernel(const GnArgs a, const float* __restrict__ part,
+                                                                   const float* __restrict__ psc, float* __restrict__ scratch,
+                                                                   int NS) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), sl = blockIdx.y;
+  if (ch >= a.C) return;
+  const int per = (a.N + NS - 1) / NS, n0 = sl * per, n1 = min(n0 + per, a.N);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const bool sc = a.mode == GN_GLU_SCALE_RES && ch < a.C / 2;
+  for (int n = n0 + lane; n < n1; n += 64) {
+    s0 += part[((int64_t)n * a.C + ch) * 2];
+    s1 += part[((int64_t)n * a.C + ch) * 2 + 1];
+    if (sc) s2 += psc[(int64_t)n * (a.C / 2) + ch];
+  }
+  s0 = rfx_wave_sum(s0); s1 = rfx_wave_sum(s1); s2 = rfx_wave_sum(s2);
+  if (lane == 0) {
+    float* o = scratch + ((int64_t)sl * a.C + ch) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+__global__ void gn_bwd_chansum_final_kernel(const GnArgs a, const float* __restrict__ scratch, int NS) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= a.C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int sl = 0; sl < NS; ++sl) {
+    const float* o = scratch + ((int64_t)sl * a.C + ch) * 3;
+    s0 += o[0]; s1 += o[1]; s2 += o[2];
+  }
+  a.dbeta[ch] = s0; a.dgamma[ch] = s1;
+  if (a.mode == GN_GLU_SCALE_RES && ch < a.C / 2) a.dscale[ch] = s2;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
   const bool pair = a.mode == GN_GLU || a.mode == GN_GLU_SCALE_RES;
@@ -877,7 +911,16 @@ static int norm_bwd(int x16, int bn, const float* x, const float* gamma, const f
     else
       GN_LAUNCH_X(gn_bwd_sample_kernel<float>, gn_bwd_sample_kernel<rfx_bf16s>, dim3((unsigned)N), dim3(256), 0, s, a, part, psc);
     RFX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
+    // the group-sum region of `work` (2 N floats) is unused on this path: scratch for the sliced channel sums
+    int NS = N >= 2048 ? 64 : 1;
+    while (NS > 1 && (int64_t)NS * C * 3 > (int64_t)2 * N) NS >>= 1;
+    if (NS > 1) {
+      hipLaunchKernelGGL(gn_bwd_chansum_split_kernel, dim3((C + 3) / 4, NS), dim3(256), 0, s, a, part, psc, a.gsum, NS);
+      RFX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(gn_bwd_chansum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, a, a.gsum, NS);
+    } else {
+      hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
+    }
     RFX_CHECK_LAUNCH();
     return 0;
   }
