@@ -1,5 +1,5 @@
 """Times every GroupNorm forward call of one Demucs training step (stats kernel + apply) with CUDA events, to find the launches
-behind gn_stats_kernel's 0.06-of-HBM figure in the r02c profile.   python scripts/probes/gn_stats_probe.py"""
+behind gn_stats_kernel's 0.06-of-HBM figure in the r02c (mid-round) profile.   python scripts/probes/gn_stats_probe.py"""
 import os
 import sys
 

@@ -15,7 +15,9 @@ def _rms(a, b):
                                           ((5, 96, 64), 4), ((2, 8, 3, 50), 1),
                                           ((600, 12, 150), 1),    # 600 small samples: fused per-sample backward
                                           ((520, 20, 70), 1),     # 13-24 channels: the wider wave-per-sample variant
-                                          ((513, 130, 40), 1)])   # 65 channel pairs: register kernel that streams gy twice
+                                          ((513, 130, 40), 1),    # 65 channel pairs: register kernel that streams gy twice
+                                          ((2100, 8, 16), 1),     # >= 2048 samples: sliced channel sums (gn_bwd_chansum_split)
+                                          ((3, 64, 24), 4)])      # short rows (S = 24): statistics walk contiguous groups
 @pytest.mark.parametrize("mode", ["none", "gelu", "glu", "glu_scale_res"])
 def test_groupnorm_modes(shape, groups, mode):
     from remfx_amd import nnops
