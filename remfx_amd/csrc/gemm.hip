@@ -184,6 +184,8 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   if (prec < 0 || prec > 2 || (d->R == 0 && prec != 0)) return -1;
   FwdArgs g;
   g.xcd_chunk = 0;
+  static const int pair_store = getenv("RFX_PAIR_STORE") ? atoi(getenv("RFX_PAIR_STORE")) : 1;
+  g.pair_store = pair_store;
   g.d = *d;
   g.apack = apack; g.ktab = ktab; g.in = in; g.out = out;
   if (epi) g.e = *epi;

@@ -34,6 +34,7 @@ struct FwdArgs {
   int32_t Kpad2;
   const float* in2;
   int32_t ntaps2;     // tap-major launches: taps of the second phase (ktab / ktab2 are tap tables there)
+  int32_t pair_store; // 16-bit outputs: two positions per store (bf16_pair_store); RFX_PAIR_STORE=0 switches it off
   int32_t xcd_chunk;  // > 0: XCD x walks the CONTIGUOUS work items [x * chunk, (x + 1) * chunk) (plans whose taps span rows of the
                       // A axis: neighbouring position tiles share input rows and should meet in one L2); 0: round-robin
 };
@@ -266,6 +267,18 @@ __device__ __forceinline__ void fwd_epilogue_mid(const FwdArgs& g, const TileCtx
 }
 
 // everything after the last K loop: residual / second activation / the store variants / statistics
+// 16-bit stores two positions at a time: lanes (j, j + 1), j even, swap one value (DPP quad_perm [1, 0, 3, 2]) so that the even lane
+// holds row r0 of both positions and the odd lane row r1 of both -- one dword store per lane and row pair instead of two 2-byte
+// stores (a 2-byte store per lane makes every store instruction carry 64 B; the bf16-output launches were store-issue-bound).
+__device__ __forceinline__ void bf16_pair_store(uint16_t* own_pos, bool odd, int64_t row0_off, int64_t row1_off, bool ok0, bool ok1,
+                                                uint32_t b0, uint32_t b1) {
+  const uint32_t send = odd ? b0 : b1;
+  const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);
+  const uint32_t word = odd ? (recv | (b1 << 16)) : (b0 | (recv << 16));
+  uint16_t* p = odd ? own_pos - 1 + row1_off : own_pos + row0_off;
+  if (odd ? ok1 : ok0) *reinterpret_cast<uint32_t*>(p) = word;
+}
+
 template <int R, bool FULL = true>
 __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileCtx& tc, f32x16 (&acc)[R]) {
   const rfx_gemm_desc& d = g.d;
@@ -275,6 +288,10 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
   const int64_t opos = (int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs;
   float* outp = g.out + (int64_t)n * d.out_ns + opos;
   uint16_t* outh = reinterpret_cast<uint16_t*>(g.out) + (int64_t)n * d.out_ns + opos;      // d.out_bf16: same element offsets
+  // positions j, j + 1 (j even) are adjacent 16-bit elements of one row and valid together (wave-uniform test)
+  const bool pair16 = g.pair_store && d.out_bf16 && d.out_bs == 1 && d.out_sb == 1 && !((d.OB | d.out_b0) & 1) &&
+                      !((d.out_ns | d.out_cs | d.out_as) & 1) && ((reinterpret_cast<uintptr_t>(g.out) & 3) == 0);
+  const bool odd = l31 & 1;
   const float* resp = nullptr;
   if (e.res)
     resp = e.res + (int64_t)n * e.res_ns + (int64_t)(a * d.out_sa + d.out_a0) * e.res_as +
@@ -390,6 +407,20 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
     // rows (r, r+1) of a lane are (a, b) of one GLU channel c = m >> 1: conv output in natural order + a * sigmoid(b)
     const int Ch = d.M >> 1;
     float* gl = e.glu_out + (int64_t)n * e.glu_ns + opos;
+    if (pair16) {                     // all lanes take part in the exchange; validity only gates the stores
+#pragma unroll
+      for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int ch = m >> 1;
+          const bool ok = c.jvalid && m < d.M;
+          const uint32_t ab = bf16_rne(acc[mt][r]), bb = bf16_rne(acc[mt][r + 1]);
+          bf16_pair_store(outh, odd, (int64_t)ch * d.out_cs, (int64_t)(Ch + ch) * d.out_cs, ok, ok, ab, bb);
+          if (ok) gl[(int64_t)ch * d.out_cs] = __uint_as_float(ab << 16) * rfx_sigmoid(__uint_as_float(bb << 16));
+        }
+      return;
+    }
     if (c.jvalid) {
 #pragma unroll
       for (int mt = 0; mt < R; ++mt)
@@ -434,7 +465,19 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][r] = rfx_act_apply(acc[mt][r], e.act2, 0.f);
   }
-  if (c.jvalid) {
+  if (pair16) {
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;         // rows m, m + 1
+        const bool ok0 = c.jvalid && m < d.M, ok1 = c.jvalid && m + 1 < d.M;
+        const uint32_t b0 = bf16_rne(acc[mt][r]), b1 = bf16_rne(acc[mt][r + 1]);
+        bf16_pair_store(outh, odd, (int64_t)m * d.out_cs, (int64_t)(m + 1) * d.out_cs, ok0, ok1, b0, b1);
+        const float v0 = ok0 ? __uint_as_float(b0 << 16) : 0.f, v1 = ok1 ? __uint_as_float(b1 << 16) : 0.f;
+        s1 += v0 + v1; s2 += v0 * v0 + v1 * v1;
+      }
+  } else if (c.jvalid) {
 #pragma unroll
     for (int mt = 0; mt < R; ++mt) {
 #pragma unroll
