@@ -71,7 +71,10 @@ __device__ __forceinline__ bf16x8 bf16_pack8(const float (&x)[8]) {
 // branch (s_and_saveexec + ds_read + lgkmcnt(0) per K step); the empty asm makes the offset opaque, so it is computed
 // unconditionally and the select stays a v_cndmask.  A masked lane must get EXACTLY 2^31: its raw offset may be
 // "negative" (taps left of the row start), and 0xfffffff0 + i * cs4 would wrap back into the sample.
-template <bool IN16 = false>
+// IN16: 0 = fp32 operand, 1 = bf16 operand (8 two-byte loads), 2 = bf16 operand of a 1x1 plan gathered in PAIRS of positions:
+// lanes (j, j + 1), j even, read the dword (x[c][j], x[c][j+1]) -- the even lane for channels 0..3 of the group, the odd lane for
+// channels 4..7 -- swap them (DPP quad_perm [1,0,3,2]) and pick their own halves: 4 loads of 128 B per wave instead of 8 of 64 B.
+template <int IN16 = 0>
 __device__ __forceinline__ void gather8_tap(const rfx_gemm_desc& d, const int4* taps, uint32_t cs4, uint32_t gstep,
                                             uint32_t gwrap, TapLane& c, float (&b)[8]) {
   const int4 e = taps[c.t];          // (offset of channel 0, da, db, -): two distinct addresses per wave
@@ -80,6 +83,23 @@ __device__ __forceinline__ void gather8_tap(const rfx_gemm_desc& d, const int4* 
   asm volatile("" : "+v"(off));
   // bit 31 set = beyond num_records (one sample spans < 2 GiB) = the load returns 0 and touches nothing
   const uint32_t base = ok ? off : RFX_BUF_OOB;
+  if (IN16 == 2) {
+    uint32_t D[4], Rv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) D[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(c.rs, base + (uint32_t)i * cs4, 0, 0);
+    const bool odd = threadIdx.x & 1;
+    const uint32_t sel = odd ? 0x07060302u : 0x05040100u;      // v_perm_b32 selector: high halves (position j+1) / low halves (position j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Rv[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)D[i], 0xB1, 0xF, 0xF, false);
+    // channels 0..3 come from the even lane's dwords, 4..7 from the odd lane's
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t lo0 = odd ? Rv[2 * q] : D[2 * q], lo1 = odd ? Rv[2 * q + 1] : D[2 * q + 1];
+      const uint32_t hi0 = odd ? D[2 * q] : Rv[2 * q], hi1 = odd ? D[2 * q + 1] : Rv[2 * q + 1];
+      b[q] = __uint_as_float(__builtin_amdgcn_perm(lo1, lo0, sel));          // (channel 2q, channel 2q+1) of this lane's position
+      b[2 + q] = __uint_as_float(__builtin_amdgcn_perm(hi1, hi0, sel));      // (channel 4+2q, 4+2q+1)
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (IN16)      // bf16 operand: the 16 stored bits, zero-extended; bf16_pack8 pairs them up without any conversion
@@ -130,7 +150,7 @@ __device__ __forceinline__ void tap_a_store(uint4* as, int tid, const AStage& s)
 //   global -> registers: A tile of step ks+4 (into the register set that held A(ks+2)), gathers of step ks+3;
 //   MFMAs;  registers -> LDS: A(ks+2) into the OTHER buffer;  barrier if SUB.
 // Everything written in steps {2D, 2D+1} is first read in step 2D+2, i.e. behind the barrier that ends step 2D+1.
-template <int R, int MODE, int SUB, bool IN16 = false>
+template <int R, int MODE, int SUB, int IN16 = 0>
 __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* __restrict__ apk, int64_t arr_stride,
                                            const int4* taps, uint32_t cs4, uint32_t gstep, uint32_t gwrap, int ks, int m0, TapLane& c,
                                            uint4* as, f32x16 (&acc)[R], const float (&bc)[8], float (&bn)[8],
@@ -162,7 +182,9 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
       acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc[mt], 0, 0, 0);
     }
   } else {
-    const bf16x8 bh = IN16 ? bf16_pack8(bc) : round8(bc);
+    const bf16x8 bh = IN16 == 2 ? __builtin_bit_cast(bf16x8, make_uint4(__float_as_uint(bc[0]), __float_as_uint(bc[1]), __float_as_uint(bc[2]),
+                                                                       __float_as_uint(bc[3])))
+                                : IN16 ? bf16_pack8(bc) : round8(bc);
 #pragma unroll
     for (int mt = 0; mt < R; ++mt)
       acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), bh, acc[mt], 0, 0, 0);
@@ -172,7 +194,7 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
   else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // keep the two steps apart in the compiler too
 }
 
-template <int R, int MODE, bool IN16 = false>
+template <int R, int MODE, int IN16 = 0>
 __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const float* __restrict__ apack,
                                               const rfx_ktab_entry* __restrict__ tap_tab, int ntaps, int gpt, int Kpad, int m0,
                                               TapLane c, uint4* as, int4* taps, f32x16 (&acc)[R]) {
@@ -221,7 +243,7 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
 #ifndef RFX_TAP_OCC
 #define RFX_TAP_OCC 3
 #endif
-template <int R, int MODE, bool IN16 = false>
+template <int R, int MODE, int IN16 = 0>
 __global__ __launch_bounds__(256, (R <= 2 && MODE == 2) ? RFX_TAP_OCC : 2) void gemm_tap_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
   __shared__ __attribute__((aligned(16))) uint4 smem[4 * CELLS + RFX_TAP_LDS];   // A: 2 buffers x 2 K steps; tap table
@@ -254,6 +276,7 @@ __global__ __launch_bounds__(256, (R <= 2 && MODE == 2) ? RFX_TAP_OCC : 2) void 
   c.ib0 = ib0;
   constexpr int ESZ = IN16 ? 2 : 4;                               // bytes per element of the gathered operand
   c.voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * ESZ);
+  if (IN16 == 2 && (lane & 1)) c.voff += (uint32_t)(4 * d.in_cs * ESZ) - (uint32_t)ESZ;      // odd lane: channels 4..7 of the pair's dword
   c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.in) + (int64_t)n * d.in_ns * ESZ), 0,
                                            (int)d.in_extent, 0x00020000);
   c.t = 0; c.goff = 0;
@@ -397,13 +420,24 @@ static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s
     RFX_CHECK_LAUNCH();
     return 0;
   }
+  if (g.d.in_bf16 == 2) {                                        // 1x1 plan, positions gathered in pairs (see gather8_tap)
+    if (MODE != 2) return -1;
+    switch (r) {
+      case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, 2>), grid, dim3(256), 0, s, g); break;
+      case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, 2>), grid, dim3(256), 0, s, g); break;
+      case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, 2>), grid, dim3(256), 0, s, g); break;
+      default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, 2>), grid, dim3(256), 0, s, g); break;
+    }
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   if (g.d.in_bf16) {                                             // bf16 STORAGE of the gathered operand (bf16 mode only)
     if (MODE != 2) return -1;
     switch (r) {
-      case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, true>), grid, dim3(256), 0, s, g); break;
-      case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, true>), grid, dim3(256), 0, s, g); break;
-      case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, true>), grid, dim3(256), 0, s, g); break;
-      default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, true>), grid, dim3(256), 0, s, g); break;
+      case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, 1>), grid, dim3(256), 0, s, g); break;
+      case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, 1>), grid, dim3(256), 0, s, g); break;
+      case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, 1>), grid, dim3(256), 0, s, g); break;
+      default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, 1>), grid, dim3(256), 0, s, g); break;
     }
     RFX_CHECK_LAUNCH();
     return 0;
