@@ -2,7 +2,7 @@
 parameters, cfg/model/demucs.yaml geometry) forward + backward ONCE on one seeded 262144-sample clip and stores, for a
 spread of parameters, the gradient's norm and a strided slice, plus output slices -> tests/golden/hdemucs_full_grad.npz.
 Weights come from the seeded initialiser (tests/test_gpu_hdemucs.py::_pair uses the same recipe), so the fixture holds
-inputs' seeds + expected outputs only.      python scripts/gen_hdemucs_grad_golden.py
+inputs' seeds + expected outputs only.      python oracle/gen_hdemucs_grad_golden.py
 """
 import os
 import sys

@@ -139,7 +139,7 @@ def test_blstm_overlapping_frames(T):
 
 def test_hdemucs_full_config_gradients_golden(golden_dir):
     """cfg/model/demucs.yaml geometry, one 262144-sample clip: backward of the HIP network against the committed gradient
-    fixture of the CPU oracle (scripts/gen_hdemucs_grad_golden.py: per-tensor gradient norms + strided slices of 13 parameters
+    fixture of the CPU oracle (oracle/gen_hdemucs_grad_golden.py: per-tensor gradient norms + strided slices of 13 parameters
     spread over encoders / decoders / DConv / BLSTM / attention / frequency embedding, global gradient norm, output slices)."""
     import os
     import numpy as np

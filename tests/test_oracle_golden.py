@@ -143,11 +143,11 @@ def test_resample_table_matches_oracle_filter():
 
 
 def test_hdemucs_full_config_gradient_fixture_reproduces(golden_dir):
-    """The committed full-config HDemucs gradient fixture is what the oracle produces here (scripts/gen_hdemucs_grad_golden.py:
+    """The committed full-config HDemucs gradient fixture is what the oracle produces here (oracle/gen_hdemucs_grad_golden.py:
     seeded weights + inputs, forward + backward of one 262144-sample clip, ~15 s on 8 cores)."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location("gen_hd", os.path.join(os.path.dirname(__file__), "..", "scripts",
+    spec = importlib.util.spec_from_file_location("gen_hd", os.path.join(os.path.dirname(__file__), "..", "oracle",
                                                                           "gen_hdemucs_grad_golden.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
