@@ -12,15 +12,16 @@
 //   * the NC-point FFT runs IN PLACE in LDS: radix-4 decimation-in-frequency passes
 //     (+ one radix-2 pass when log2 NC is odd), natural-order input -> digit-reversed
 //     output; the inverse runs the mirrored decimation-in-time passes;
-//   * FB * NC = 8192 complex points (64 KiB) + an NC-entry twiddle table per
+//   * FB * NC = RFX_FFT_PTS complex points (2048 / 4096, see below) + an NC-entry twiddle table per
 //     workgroup; frames are padded by one element so that the transposing epilogue
 //     (lanes along frames -> coalesced [bin][frame] stores) is bank-conflict free;
 //   * workgroups that write the same (row, bin) lines are placed on the same XCD
 //     (block b runs on XCD b % 8) so partial-line stores merge in one L2.
 #include "common.h"
 
-// complex points per workgroup: 8192 (64 KB of LDS, 2 workgroups per CU) -- or 4096 for n_fft <= 1024 (RFX_FFT_PTS_SMALL), which
-// doubles the resident waves of these barrier-separated LDS passes at the price of shorter store runs in the transposing epilogue
+// complex points per workgroup: 2048 for n_fft <= 1024, 4096 above (16-32 KB of LDS).  Round 1 used 8192 (64 KB: two workgroups =
+// 8 waves per CU between workgroup barriers) and the kernels were OCCUPANCY-bound: analysis 0.55 -> 0.32 ms, synthesis 1.1 -> 0.5 ms
+// per launch with the smaller groups, at the price of shorter store runs in the transposing epilogue.
 #ifndef RFX_FFT_PTS_SMALL
 #define RFX_FFT_PTS_SMALL 2048
 #endif
