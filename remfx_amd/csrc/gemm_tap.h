@@ -83,7 +83,11 @@ __device__ __forceinline__ void gather8_tap(const rfx_gemm_desc& d, const int4* 
   asm volatile("" : "+v"(off));
   // bit 31 set = beyond num_records (one sample spans < 2 GiB) = the load returns 0 and touches nothing
   const uint32_t base = ok ? off : RFX_BUF_OOB;
-  if (IN16 == 2) {
+  if (IN16 == 3) {
+    // channels-last bf16 operand (channel stride 1): the 8 channels of the group are 16 contiguous bytes -- ONE load per K step
+    const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(c.rs, base, 0, 0));
+    b[0] = __uint_as_float(v.x); b[1] = __uint_as_float(v.y); b[2] = __uint_as_float(v.z); b[3] = __uint_as_float(v.w);
+  } else if (IN16 == 2) {
     uint32_t D[4], Rv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) D[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(c.rs, base + (uint32_t)i * cs4, 0, 0);
@@ -182,7 +186,7 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
       acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, acc[mt], 0, 0, 0);
     }
   } else {
-    const bf16x8 bh = IN16 == 2 ? __builtin_bit_cast(bf16x8, make_uint4(__float_as_uint(bc[0]), __float_as_uint(bc[1]), __float_as_uint(bc[2]),
+    const bf16x8 bh = IN16 >= 2 ? __builtin_bit_cast(bf16x8, make_uint4(__float_as_uint(bc[0]), __float_as_uint(bc[1]), __float_as_uint(bc[2]),
                                                                        __float_as_uint(bc[3])))
                                 : IN16 ? bf16_pack8(bc) : round8(bc);
 #pragma unroll
@@ -417,6 +421,17 @@ static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s
     dim3 sg((unsigned)(nw * mtiles));
     if (g.d.Kpad_t <= 16) hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 4, 1>), sg, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 2, 4>), sg, dim3(256), 0, s, g);
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
+  if (g.d.in_bf16 == 3) {                                        // channels-last bf16 operand (probe of the next layout)
+    if (MODE != 2) return -1;
+    switch (r) {
+      case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, 3>), grid, dim3(256), 0, s, g); break;
+      case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, 3>), grid, dim3(256), 0, s, g); break;
+      case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, 3>), grid, dim3(256), 0, s, g); break;
+      default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, 3>), grid, dim3(256), 0, s, g); break;
+    }
     RFX_CHECK_LAUNCH();
     return 0;
   }
