@@ -86,8 +86,7 @@ typedef struct rfx_gemm_desc {
   int64_t in_cs, in_extent;
   /* bf16 STORAGE of single operands (bf16 arithmetic mode only; strides stay in elements, in_extent in bytes):
    * in_bf16: the gathered operand `in` (forward family) / the input operand x (rfx_gemm_wgrad) holds bf16 values -- tap-major
-   *          tiled kernels only; 2 = additionally every tap is the position itself (1x1 plan), unit position stride, even
-   *          extents: positions are then gathered in pairs (one dword per lane and channel pair); 3 = channels-last bf16 operand (in_cs == 1,
+   *          tiled kernels only; 3 = channels-last bf16 operand (in_cs == 1,
    *          position strides multiples of 8): one 16-byte load per lane and K step -- probe of the next layout,
    *          not used by the product path;  out_bf16: `out` is written as bf16 (forward family, RNE; GroupNorm statistics of the epilogue
    *          are those of the rounded values) / the gradient operand g of rfx_gemm_wgrad holds bf16 values.

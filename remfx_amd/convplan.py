@@ -150,7 +150,6 @@ def _tap_major(self, kt, woff):
         self.cin = 0
         return
     taps = kt[:nt].copy()
-    self.extra["one_by_one"] = bool(nt == 1 and not taps[0, 1:3].any() and taps[0, 0] == 0)      # every gather is the position itself
     ci = np.arange(self.cin)[:, None]
     exp_off = (taps[None, :, 0] + ci * self.in_cs).reshape(-1)
     if not (np.array_equal(kt[:, 0], exp_off) and np.array_equal(kt[:, 1:3], np.tile(taps[:, 1:3], (self.cin, 1)))

@@ -198,10 +198,7 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   // bf16 storage of single operands: gathered input on the tap-major tiled kernels of the bf16 mode; output wherever the
   // plain / GLU store runs (not the phase-merged, backward-epilogue or thin paths)
   if (d->in_bf16 && (prec != 2 || d->R == 0)) return -1;
-  // in_bf16 == 2: every tap is the position itself (1x1 plan; the planner's claim), positions j, j + 1 adjacent and 4-byte aligned
-  if (d->in_bf16 == 3 && (d->in_cs != 1 || ((d->in_ns | d->in_as | d->in_bs) & 7) || (reinterpret_cast<uintptr_t>(in) & 15) || apack2)) return -1;
-  if (d->in_bf16 == 2 && (d->in_bs != 1 || d->SB != 1 || d->SA != 1 || ((d->in_ns | d->in_cs | d->in_as | d->OB | d->IB) & 1) || apack2 ||
-                          (reinterpret_cast<uintptr_t>(in) & 3))) return -1;
+  if (d->in_bf16 == 2) return -1;                      // (was: paired gather of 1x1 plans, removed)
   if (d->out_bf16 && (d->R == 0 || d->mg_log || g.e.bwd || g.e.res)) return -1;
   g.apack2 = apack2; g.ktab2 = ktab2; g.Kpad2 = apack2 ? Kpad2 : 0; g.in2 = in2;
   g.ntaps2 = apack2 ? K2 : 0;      // tap-major launches pass the second phase's tap count in K2

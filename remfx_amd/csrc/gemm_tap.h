@@ -71,9 +71,8 @@ __device__ __forceinline__ bf16x8 bf16_pack8(const float (&x)[8]) {
 // branch (s_and_saveexec + ds_read + lgkmcnt(0) per K step); the empty asm makes the offset opaque, so it is computed
 // unconditionally and the select stays a v_cndmask.  A masked lane must get EXACTLY 2^31: its raw offset may be
 // "negative" (taps left of the row start), and 0xfffffff0 + i * cs4 would wrap back into the sample.
-// IN16: 0 = fp32 operand, 1 = bf16 operand (8 two-byte loads), 2 = bf16 operand of a 1x1 plan gathered in PAIRS of positions:
-// lanes (j, j + 1), j even, read the dword (x[c][j], x[c][j+1]) -- the even lane for channels 0..3 of the group, the odd lane for
-// channels 4..7 -- swap them (DPP quad_perm [1,0,3,2]) and pick their own halves: 4 loads of 128 B per wave instead of 8 of 64 B.
+// IN16: 0 = fp32 operand, 1 = bf16 operand (8 two-byte loads), 3 = channels-last bf16 operand (probe).  (2 was a paired
+// gather for 1x1 plans -- 4 dword loads + a DPP exchange: bit-exact, 0.9 ms slower on the step, removed)
 template <int IN16 = 0>
 __device__ __forceinline__ void gather8_tap(const rfx_gemm_desc& d, const int4* taps, uint32_t cs4, uint32_t gstep,
                                             uint32_t gwrap, TapLane& c, float (&b)[8]) {
@@ -87,22 +86,6 @@ __device__ __forceinline__ void gather8_tap(const rfx_gemm_desc& d, const int4* 
     // channels-last bf16 operand (channel stride 1): the 8 channels of the group are 16 contiguous bytes -- ONE load per K step
     const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(c.rs, base, 0, 0));
     b[0] = __uint_as_float(v.x); b[1] = __uint_as_float(v.y); b[2] = __uint_as_float(v.z); b[3] = __uint_as_float(v.w);
-  } else if (IN16 == 2) {
-    uint32_t D[4], Rv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) D[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(c.rs, base + (uint32_t)i * cs4, 0, 0);
-    const bool odd = threadIdx.x & 1;
-    const uint32_t sel = odd ? 0x07060302u : 0x05040100u;      // v_perm_b32 selector: high halves (position j+1) / low halves (position j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) Rv[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)D[i], 0xB1, 0xF, 0xF, false);
-    // channels 0..3 come from the even lane's dwords, 4..7 from the odd lane's
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const uint32_t lo0 = odd ? Rv[2 * q] : D[2 * q], lo1 = odd ? Rv[2 * q + 1] : D[2 * q + 1];
-      const uint32_t hi0 = odd ? D[2 * q] : Rv[2 * q], hi1 = odd ? D[2 * q + 1] : Rv[2 * q + 1];
-      b[q] = __uint_as_float(__builtin_amdgcn_perm(lo1, lo0, sel));          // (channel 2q, channel 2q+1) of this lane's position
-      b[2 + q] = __uint_as_float(__builtin_amdgcn_perm(hi1, hi0, sel));      // (channel 4+2q, 4+2q+1)
-    }
   } else
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -280,7 +263,6 @@ __global__ __launch_bounds__(256, (R <= 2 && MODE == 2) ? RFX_TAP_OCC : 2) void 
   c.ib0 = ib0;
   constexpr int ESZ = IN16 ? 2 : 4;                               // bytes per element of the gathered operand
   c.voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * ESZ);
-  if (IN16 == 2 && (lane & 1)) c.voff += (uint32_t)(4 * d.in_cs * ESZ) - (uint32_t)ESZ;      // odd lane: channels 4..7 of the pair's dword
   c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.in) + (int64_t)n * d.in_ns * ESZ), 0,
                                            (int)d.in_extent, 0x00020000);
   c.t = 0; c.goff = 0;
@@ -408,12 +390,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g
   }
 }
 
+// one translation unit per operand-storage variant (the tiled kernel is the slowest thing to compile in the library)
+template <int IN16>
+static int rfx_launch_gemm_tap_variant(const FwdArgs& g, int r, dim3 grid, hipStream_t s) {
+  switch (r) {
+    case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, IN16>), grid, dim3(256), 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, IN16>), grid, dim3(256), 0, s, g); break;
+    case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, IN16>), grid, dim3(256), 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, IN16>), grid, dim3(256), 0, s, g); break;
+  }
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+int rfx_launch_gemm_tap_in16(const FwdArgs& g, int r, dim3 grid, hipStream_t s);   // bf16 operand storage: gemm_fwd_bf16_in16.hip
+int rfx_launch_gemm_tap_cl(const FwdArgs& g, int r, dim3 grid, hipStream_t s);     // channels-last bf16 probe: gemm_fwd_bf16_cl.hip
+
 template <int MODE>
 static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s) {
+  if (g.d.in_bf16 == 3) return MODE == 2 ? rfx_launch_gemm_tap_cl(g, r, grid, s) : -1;
+  if (g.d.in_bf16) return (MODE == 2 && g.d.in_bf16 == 1) ? rfx_launch_gemm_tap_in16(g, r, grid, s) : -1;
   // short single-phase reductions with enough position tiles to keep persistent workgroups busy: streaming kernel
   static const int stream_off = getenv("RFX_GEMM_STREAM") ? !atoi(getenv("RFX_GEMM_STREAM")) : 0;   // RFX_GEMM_STREAM=0: A/B switch
   const int64_t work = (int64_t)((g.d.OA * g.d.OB + 127) / 128) * g.d.N;
-  if (!stream_off && !g.d.in_bf16 && g.d.Kpad_t <= 64 && g.apack2 == nullptr && work >= 4096 && r == 1 && g.e.act == RFX_ACT_NONE &&
+  if (!stream_off && g.d.Kpad_t <= 64 && g.apack2 == nullptr && work >= 4096 && r == 1 && g.e.act == RFX_ACT_NONE &&
       g.e.act2 == RFX_ACT_NONE && !g.e.bwd && g.d.mg_log == 0 && !g.e.res) {
     const int mtiles = g.d.Mpad / 32;
     int nw = (512 / mtiles) & ~7;                                // persistent workgroups per channel tile (2 per CU in all),
@@ -421,39 +420,6 @@ static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s
     dim3 sg((unsigned)(nw * mtiles));
     if (g.d.Kpad_t <= 16) hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 4, 1>), sg, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_tap_stream_kernel<MODE, 2, 4>), sg, dim3(256), 0, s, g);
-    RFX_CHECK_LAUNCH();
-    return 0;
-  }
-  if (g.d.in_bf16 == 3) {                                        // channels-last bf16 operand (probe of the next layout)
-    if (MODE != 2) return -1;
-    switch (r) {
-      case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, 3>), grid, dim3(256), 0, s, g); break;
-      case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, 3>), grid, dim3(256), 0, s, g); break;
-      case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, 3>), grid, dim3(256), 0, s, g); break;
-      default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, 3>), grid, dim3(256), 0, s, g); break;
-    }
-    RFX_CHECK_LAUNCH();
-    return 0;
-  }
-  if (g.d.in_bf16 == 2) {                                        // 1x1 plan, positions gathered in pairs (see gather8_tap)
-    if (MODE != 2) return -1;
-    switch (r) {
-      case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, 2>), grid, dim3(256), 0, s, g); break;
-      case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, 2>), grid, dim3(256), 0, s, g); break;
-      case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, 2>), grid, dim3(256), 0, s, g); break;
-      default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, 2>), grid, dim3(256), 0, s, g); break;
-    }
-    RFX_CHECK_LAUNCH();
-    return 0;
-  }
-  if (g.d.in_bf16) {                                             // bf16 STORAGE of the gathered operand (bf16 mode only)
-    if (MODE != 2) return -1;
-    switch (r) {
-      case 1: hipLaunchKernelGGL((gemm_tap_kernel<1, 2, 1>), grid, dim3(256), 0, s, g); break;
-      case 2: hipLaunchKernelGGL((gemm_tap_kernel<2, 2, 1>), grid, dim3(256), 0, s, g); break;
-      case 3: hipLaunchKernelGGL((gemm_tap_kernel<3, 2, 1>), grid, dim3(256), 0, s, g); break;
-      default: hipLaunchKernelGGL((gemm_tap_kernel<4, 2, 1>), grid, dim3(256), 0, s, g); break;
-    }
     RFX_CHECK_LAUNCH();
     return 0;
   }

@@ -19,10 +19,6 @@ PREC_NAMES = {"f32": 0, "bf16x3": 1, "bf16": 2}
 GEMM_PREC = PREC_NAMES[_os.environ.get("RFX_GEMM_PREC", "f32")]
 
 
-# 1x1 plans on 16-bit operands can gather positions in pairs (4 dword loads + a DPP exchange instead of 8 two-byte loads):
-# measured 0.9 ms SLOWER on the Demucs step (same box, 167.9 vs 168.7): the extra 16 VALU per K step cost more than the loads
-# saved -- the gathers are not issue-bound.  Off unless RFX_PAIR_GATHER=1.
-PAIR_GATHER = _os.environ.get("RFX_PAIR_GATHER", "0") == "1"
 BF16_STORE = _os.environ.get("RFX_BF16_STORE", "1") != "0"      # RFX_BF16_STORE=0: fp32 storage everywhere (A/B switch)
 
 
@@ -93,10 +89,7 @@ class DevPlan:
         v = self._desc16.get(key)
         if v is None:
             v = GemmDesc.from_buffer_copy(self.desc)
-            p = self.p
-            pair = (in16 and PAIR_GATHER and p.extra.get("one_by_one", False) and p.in_bs == 1 and p.SA == 1 and p.SB == 1 and
-                    not ((p.in_ns | p.in_cs | p.in_as | p.OB | p.IB) & 1))
-            v.in_bf16, v.out_bf16 = (2 if pair else int(in16)), int(out16)
+            v.in_bf16, v.out_bf16 = int(in16), int(out16)
             v.in_extent = int(self.p.in_extent) * (2 if in16 else 4)
             self._desc16[key] = v
         return v
