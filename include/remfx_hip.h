@@ -306,6 +306,15 @@ int rfx_localstate_mfma_fwd(const float* q, const float* k, const float* cont, c
 int rfx_localstate_mfma_bwd(const float* q, const float* k, const float* cont, const float* qd, const float* gout, int32_t B,
                             int32_t heads, int32_t ch, int32_t T, int32_t nd, float* dq, float* dk, float* dcont, float* dqd,
                             float* stat /* workspace, B*heads*T*4 floats, 16-byte aligned */, void* stream);
+/* Any-T path (whole files: more than 256 frames per clip; same operator, torchaudio HDemucs `_LocalState` reached from
+ * remfx/models.py:319 / scripts/remfx_detect.py:44-61): keys streamed through LDS, O(T) memory, exact fp32.  stat: B*heads*T*4
+ * floats {max, sum, <out, gout>, -}; the forward writes the first two, the backward reads them (and `out`) and fills the third.
+ * ch <= 104, nd <= 64.  Returns -1 for unsupported shapes. */
+int rfx_localstate_gen_fwd(const float* q, const float* k, const float* cont, const float* qd, int32_t B, int32_t heads,
+                           int32_t ch, int32_t T, int32_t nd, float* stat, float* out, void* stream);
+int rfx_localstate_gen_bwd(const float* q, const float* k, const float* cont, const float* qd, float* stat, const float* out,
+                           const float* gout, int32_t B, int32_t heads, int32_t ch, int32_t T, int32_t nd, float* dq, float* dk,
+                           float* dcont, float* dqd, void* stream);
 
 /* ---- GroupNorm (+ fused activation) --------------------------------------------
  * x: (N, C, S) contiguous, G groups.  mode: 0 y = gn(x); 1 y = gelu(gn(x));

@@ -153,6 +153,42 @@ def gen_tcn():
     print("tcn_full rf", net.receptive_field, sum(p.numel() for p in net.parameters()))
 
 
+def gen_tcn_full():
+    """The FULL cfg/model/tcn.yaml network (20 blocks x 256 channels, k = 7; 9 974 017 parameters) of the imported
+    reference (remfx/tcn.py:62-138) on one 32768-sample clip: forward output (all 20491 samples), and the gradient of
+    sum(y * r) for strided slices of eight parameters spread over the depth -- pins BASELINE config 2 at full width
+    against the reference itself (forward AND autograd backward).  Weights: oracle's seeded generator (40 MB, not stored)."""
+    import yaml
+    from remfx.tcn import TCN
+    full = yaml.safe_load(open(os.path.join(REF, "cfg/model/tcn.yaml")))["model"]["network"]
+    for k in ("_target_", "sample_rate", "num_bins"):
+        full.pop(k)
+    net = TCN(**full).eval()
+    sd = ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7, seed=31)
+    for i, k in enumerate([k for k in sd if k.endswith("relu.weight")]):   # non-trivial PReLU slopes, different per block
+        sd[k] = torch.linspace(0.05, 0.45, sd[k].numel()).roll(7 * i)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(131)
+    T = 32768
+    x = torch.randn(1, 1, T, generator=g) * 0.5
+    y = net(x)
+    r = torch.randn(y.shape, generator=g)
+    (y * r).sum().backward()
+    params = dict(net.named_parameters())
+    names = ["process_blocks.0.conv1.weight", "process_blocks.0.res.weight", "process_blocks.3.conv1.weight",
+             "process_blocks.9.conv1.bias", "process_blocks.10.relu.weight", "process_blocks.12.res.weight",
+             "process_blocks.19.conv1.weight", "output.weight"]
+    rec = {}
+    for n in names:
+        gr = params[n].grad.reshape(-1)
+        rec["gnorm_" + n] = np.float64(gr.double().norm())
+        rec["gslice_" + n] = gr[:: max(1, gr.numel() // 512)][:512].numpy().copy()
+    gtot = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in net.parameters()))
+    np.savez_compressed(os.path.join(OUT, "tcn_full_fwd_bwd.npz"), seed=np.int64(31), x_seed=np.int64(131), T=np.int64(T),
+                        y=y.detach().numpy(), grad_names=np.array(names), grad_total_norm=np.float64(gtot), **rec)
+    print("tcn_full_fwd_bwd", tuple(y.shape), "y rms", float(y.pow(2).mean().sqrt()), "gnorm", float(gtot))
+
+
 def gen_cnn14():
     from remfx.classifier import Cnn14
     net = Cnn14(num_classes=5, sample_rate=48000, model_sample_rate=48000, n_fft=2048,
@@ -252,7 +288,8 @@ def gen_flow():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
-    gen_utils()
-    gen_tcn()
-    gen_cnn14()
-    gen_flow()
+    only = sys.argv[1:]                      # e.g. `python oracle/gen_golden.py tcn_full` regenerates one fixture
+    for name, fn in (("utils", gen_utils), ("tcn", gen_tcn), ("tcn_full", gen_tcn_full), ("cnn14", gen_cnn14),
+                     ("flow", gen_flow)):
+        if not only or name in only:
+            fn()

@@ -140,6 +140,8 @@ SIGNATURES = {
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_localstate_gen_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "rfx_localstate_gen_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_localstate_mfma_ok": [_I32, _I32, _I32, _I32, _I32],
     "rfx_localstate_mfma_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "rfx_localstate_mfma_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P],

@@ -131,6 +131,14 @@ class Cnn14(nn.Module):
         init_layer(self.fc1)
 
     def forward(self, x: torch.Tensor, train: bool = False):
+        """train=False (detection / validation / test, reference models.py:60-64, 520-560): the network runs at fp32 parity
+        even under trainer.precision=bf16-mixed, so the thresholded labels are those of the fp32 reference."""
+        if train:
+            return self._forward(x, True)
+        with ops.at_least_fp32_parity():
+            return self._forward(x, False)
+
+    def _forward(self, x: torch.Tensor, train: bool):
         if self.sample_rate != self.model_sample_rate:
             from .resample import resample
             x = resample(x, self.sample_rate, self.model_sample_rate)

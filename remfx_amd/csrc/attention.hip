@@ -285,3 +285,197 @@ extern "C" int rfx_localstate_bwd(const float* q, const float* k, const float* c
   RFX_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- any-T path (streams the keys; no T x T block anywhere) --------------------------------------------------------
+// The two kernels above hold k / content of a whole (sample, head) in LDS and therefore stop at T = 256 frames, i.e. one
+// 262144-sample clip of the reference's configs.  Whole files (InferenceDataset, scripts/remfx_detect.py) are longer:
+// this path handles any T with O(T) memory.  One wave per 64 query columns (forward, query-major backward) or 64 key rows
+// (key-major backward); keys / queries stream through LDS in chunks of 64, lane-private vectors (q, accumulators) live in
+// LDS columns [c][lane] (bank = lane: conflict-free).  Two passes over the keys in the forward (max + sum, then the
+// weighted content sum) instead of a running rescale.  Exact fp32 on the vector ALU; this is the robustness path, not
+// the fast one (T <= 256 keeps the kernels above / attention_mfma.hip).
+// stat: (B*heads*T, 4) = {max, sum, delta = <out, gout> (written by the query-major backward), unused}
+struct LsGenArgs {
+  const float *q, *k, *cont, *qd, *out, *gout;
+  float *stat, *o, *dq, *dk, *dcont, *dqd;
+  int heads, ch, T, nd;
+};
+
+__device__ __forceinline__ float lsg_score(const float* rowv, const float* colv, int ch, float inv, float pen, int t, int s) {
+  // rowv[c * 64] broadcast operand, colv[c * 64] lane operand
+  float acc = 0.f;
+  for (int c = 0; c < ch; ++c) acc = fmaf(rowv[c * 64], colv[c * 64], acc);
+  const float v = acc * inv - fabsf((float)(t - s)) * pen;
+  return t == s ? -100.0f : v;
+}
+
+// mode 0: forward (stat{max,sum}, out); mode 1: query-major backward (dq, dqd, stat.delta)
+template <int MODE>
+__global__ __launch_bounds__(64) void localstate_gen_q_kernel(const LsGenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int T = a.T, ch = a.ch, nd = a.nd, lane = threadIdx.x;
+  float* qs = lds;                     // [ch][64] my queries
+  float* ks = qs + ch * 64;            // [ch][64] key chunk
+  float* cs = ks + ch * 64;            // [ch][64] content chunk
+  float* acc = cs + ch * 64;           // [ch][64] out (fwd) / dq (bwd) accumulators
+  float* gs = acc + ch * 64;           // [ch][64] gout tile (bwd only)
+  const int bh = blockIdx.x, s = blockIdx.y * 64 + lane;
+  const bool sv = s < T;
+  const int64_t base = (int64_t)bh * ch * T, dbase = (int64_t)bh * nd * T;
+  const float inv = 1.0f / sqrtf((float)ch), invd = 1.0f / sqrtf((float)nd);
+  float pen = 0.f;                     // sum_f (f + 1) / sqrt(nd) * sigmoid(qd[f, s]) / 2
+  for (int f = 0; f < nd; ++f) pen += sv ? (float)(f + 1) * invd * 0.5f * ls_sigmoid(a.qd[dbase + (int64_t)f * T + s]) : 0.f;
+  for (int c = 0; c < ch; ++c) {
+    qs[c * 64 + lane] = sv ? a.q[base + (int64_t)c * T + s] : 0.f;
+    acc[c * 64 + lane] = 0.f;
+    if (MODE == 1) gs[c * 64 + lane] = sv ? a.gout[base + (int64_t)c * T + s] : 0.f;
+  }
+  float m = -3.0e38f, l = 0.f, delta = 0.f, A = 0.f;
+  if (MODE == 1) {
+    if (sv) { m = a.stat[((int64_t)bh * T + s) * 4]; l = a.stat[((int64_t)bh * T + s) * 4 + 1]; }
+    for (int c = 0; c < ch; ++c) delta = fmaf(sv ? a.out[base + (int64_t)c * T + s] : 0.f, gs[c * 64 + lane], delta);
+    if (sv) a.stat[((int64_t)bh * T + s) * 4 + 2] = delta;
+  }
+  const int npass = MODE == 0 ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool second = MODE == 1 || pass == 1;
+    const float rl = second ? 1.0f / l : 0.f;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      __syncthreads();
+      const bool tv = t0 + lane < T;
+      for (int c = 0; c < ch; ++c) {
+        ks[c * 64 + lane] = tv ? a.k[base + (int64_t)c * T + t0 + lane] : 0.f;
+        if (second) cs[c * 64 + lane] = tv ? a.cont[base + (int64_t)c * T + t0 + lane] : 0.f;
+      }
+      __syncthreads();
+      const int nj = min(64, T - t0);
+      for (int j = 0; j < nj; ++j) {
+        const int t = t0 + j;
+        const float v = lsg_score(ks + j, qs + lane, ch, inv, pen, t, s);
+        if (!second) {
+          const float mn = fmaxf(m, v);
+          l = l * expf(m - mn) + expf(v - mn);
+          m = mn;
+        } else {
+          const float p = expf(v - m) * rl;
+          if (MODE == 0) {
+            for (int c = 0; c < ch; ++c) acc[c * 64 + lane] = fmaf(p, cs[c * 64 + j], acc[c * 64 + lane]);
+          } else {
+            float dw = 0.f;
+            for (int c = 0; c < ch; ++c) dw = fmaf(cs[c * 64 + j], gs[c * 64 + lane], dw);
+            const float dv = t == s ? 0.f : p * (dw - delta);          // the masked diagonal is a constant
+            A = fmaf(dv, fabsf((float)(t - s)), A);
+            const float dvi = dv * inv;
+            for (int c = 0; c < ch; ++c) acc[c * 64 + lane] = fmaf(dvi, ks[c * 64 + j], acc[c * 64 + lane]);
+          }
+        }
+      }
+    }
+  }
+  if (!sv) return;
+  if (MODE == 0) {
+    a.stat[((int64_t)bh * T + s) * 4] = m;
+    a.stat[((int64_t)bh * T + s) * 4 + 1] = l;
+    for (int c = 0; c < ch; ++c) a.o[base + (int64_t)c * T + s] = acc[c * 64 + lane];
+  } else {
+    for (int c = 0; c < ch; ++c) a.dq[base + (int64_t)c * T + s] = acc[c * 64 + lane];
+    for (int f = 0; f < nd; ++f) {
+      const float sg = ls_sigmoid(a.qd[dbase + (int64_t)f * T + s]);
+      a.dqd[dbase + (int64_t)f * T + s] = -(float)(f + 1) * invd * A * 0.5f * sg * (1.0f - sg);
+    }
+  }
+}
+
+// key-major backward: lane = key row t; dk[c][t], dcont[c][t]
+__global__ __launch_bounds__(64) void localstate_gen_k_kernel(const LsGenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int T = a.T, ch = a.ch, nd = a.nd, lane = threadIdx.x;
+  float* km = lds;                     // [ch][64] my keys
+  float* cm = km + ch * 64;            // [ch][64] my content rows
+  float* dka = cm + ch * 64;           // [ch][64]
+  float* dca = dka + ch * 64;          // [ch][64]
+  float* qc = dca + ch * 64;           // [ch][64] query chunk
+  float* gc = qc + ch * 64;            // [ch][64] gout chunk
+  float* sc = gc + ch * 64;            // [4][64] per query of the chunk: max, 1 / sum, delta, pen
+  const int bh = blockIdx.x, t = blockIdx.y * 64 + lane;
+  const bool tv = t < T;
+  const int64_t base = (int64_t)bh * ch * T, dbase = (int64_t)bh * nd * T;
+  const float inv = 1.0f / sqrtf((float)ch), invd = 1.0f / sqrtf((float)nd);
+  for (int c = 0; c < ch; ++c) {
+    km[c * 64 + lane] = tv ? a.k[base + (int64_t)c * T + t] : 0.f;
+    cm[c * 64 + lane] = tv ? a.cont[base + (int64_t)c * T + t] : 0.f;
+    dka[c * 64 + lane] = 0.f;
+    dca[c * 64 + lane] = 0.f;
+  }
+  for (int s0 = 0; s0 < T; s0 += 64) {
+    __syncthreads();
+    const int s = s0 + lane;
+    const bool sv = s < T;
+    for (int c = 0; c < ch; ++c) {
+      qc[c * 64 + lane] = sv ? a.q[base + (int64_t)c * T + s] : 0.f;
+      gc[c * 64 + lane] = sv ? a.gout[base + (int64_t)c * T + s] : 0.f;
+    }
+    float pen = 0.f;
+    for (int f = 0; f < nd; ++f) pen += sv ? (float)(f + 1) * invd * 0.5f * ls_sigmoid(a.qd[dbase + (int64_t)f * T + s]) : 0.f;
+    sc[lane] = sv ? a.stat[((int64_t)bh * T + s) * 4] : 0.f;
+    sc[64 + lane] = sv ? 1.0f / a.stat[((int64_t)bh * T + s) * 4 + 1] : 0.f;
+    sc[128 + lane] = sv ? a.stat[((int64_t)bh * T + s) * 4 + 2] : 0.f;
+    sc[192 + lane] = pen;
+    __syncthreads();
+    const int nj = min(64, T - s0);
+    for (int j = 0; j < nj; ++j) {
+      const int sj = s0 + j;
+      const float v = lsg_score(qc + j, km + lane, ch, inv, sc[192 + j], t, sj);
+      const float p = expf(v - sc[j]) * sc[64 + j];
+      float dw = 0.f;
+      for (int c = 0; c < ch; ++c) dw = fmaf(cm[c * 64 + lane], gc[c * 64 + j], dw);
+      const float dvi = (t == sj ? 0.f : p * (dw - sc[128 + j])) * inv;
+      for (int c = 0; c < ch; ++c) {
+        dca[c * 64 + lane] = fmaf(p, gc[c * 64 + j], dca[c * 64 + lane]);
+        dka[c * 64 + lane] = fmaf(dvi, qc[c * 64 + j], dka[c * 64 + lane]);
+      }
+    }
+  }
+  if (!tv) return;
+  for (int c = 0; c < ch; ++c) {
+    a.dk[base + (int64_t)c * T + t] = dka[c * 64 + lane];
+    a.dcont[base + (int64_t)c * T + t] = dca[c * 64 + lane];
+  }
+}
+
+static bool lsg_ok(int B, int heads, int ch, int T, int nd) {
+  return B > 0 && heads > 0 && ch > 0 && ch <= 104 && T > 0 && nd > 0 && nd <= 64 &&
+         (int64_t)B * heads <= 0x7fffffff && (T + 63) / 64 <= 65535;
+}
+
+template <typename K>
+static int lsg_launch(K kern, const LsGenArgs& a, int B, size_t lds, void* stream) {
+  if (lds > 160 * 1024) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return -3;
+  hipLaunchKernelGGL(kern, dim3(B * a.heads, (a.T + 63) / 64), dim3(64), lds, (hipStream_t)stream, a);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rfx_localstate_gen_fwd(const float* q, const float* k, const float* cont, const float* qd, int32_t B,
+                                      int32_t heads, int32_t ch, int32_t T, int32_t nd, float* stat, float* out, void* stream) {
+  if (!q || !k || !cont || !qd || !stat || !out || !lsg_ok(B, heads, ch, T, nd)) return -1;
+  LsGenArgs a{};
+  a.q = q; a.k = k; a.cont = cont; a.qd = qd; a.stat = stat; a.o = out;
+  a.heads = heads; a.ch = ch; a.T = T; a.nd = nd;
+  return lsg_launch(localstate_gen_q_kernel<0>, a, B, sizeof(float) * 5 * ch * 64, stream);
+}
+
+extern "C" int rfx_localstate_gen_bwd(const float* q, const float* k, const float* cont, const float* qd, float* stat,
+                                      const float* out, const float* gout, int32_t B, int32_t heads, int32_t ch, int32_t T,
+                                      int32_t nd, float* dq, float* dk, float* dcont, float* dqd, void* stream) {
+  if (!q || !k || !cont || !qd || !stat || !out || !gout || !dq || !dk || !dcont || !dqd || !lsg_ok(B, heads, ch, T, nd)) return -1;
+  LsGenArgs a{};
+  a.q = q; a.k = k; a.cont = cont; a.qd = qd; a.stat = stat; a.out = out; a.gout = gout;
+  a.dq = dq; a.dk = dk; a.dcont = dcont; a.dqd = dqd;
+  a.heads = heads; a.ch = ch; a.T = T; a.nd = nd;
+  int rc = lsg_launch(localstate_gen_q_kernel<1>, a, B, sizeof(float) * 5 * ch * 64, stream);     // writes stat.delta first
+  if (rc) return rc;
+  return lsg_launch(localstate_gen_k_kernel, a, B, sizeof(float) * (6 * ch * 64 + 256), stream);
+}

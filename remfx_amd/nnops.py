@@ -299,23 +299,34 @@ class _LocalStateFn(torch.autograd.Function):
         L = _lib.lib()
         # bf16 mode: MFMA kernels (attention_mfma.hip), weights recomputed in the backward pass instead of stored
         mfma = ops.GEMM_PREC == 2 and bool(L.rfx_localstate_mfma_ok(B, heads, ch, T, ndecay))
+        # more than 256 frames (whole files) or ch * T beyond the LDS-resident kernel: the streaming any-T kernels
+        gen = not mfma and (T > 256 or ch * T > 12288 or ndecay > 8)
         if mfma:
             check(L.rfx_localstate_mfma_fwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), B, heads, ch, T, ndecay, _ptr(out),
                                             _stream()), "rfx_localstate_mfma_fwd")
             if need_w:
                 ctx.save_for_backward(q, k, cont, qd)
+        elif gen:
+            if ch > 104 or ndecay > 64:
+                raise ValueError(f"LocalState attention: {ch} channels per head / {ndecay} decay terms exceed the HIP kernels' "
+                                 "limits (ch <= 104, ndecay <= 64)")
+            stat = torch.empty((B * heads * T, 4), device=q.device, dtype=torch.float32)
+            check(L.rfx_localstate_gen_fwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), B, heads, ch, T, ndecay, _ptr(stat),
+                                           _ptr(out), _stream()), "rfx_localstate_gen_fwd")
+            if need_w:
+                ctx.save_for_backward(q, k, cont, qd, stat, out)
         else:
             w = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32) if need_w else None
             check(L.rfx_localstate_fwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), B, heads, ch, T, ndecay, _ptr(w),
                                        _ptr(out), _stream()), "rfx_localstate_fwd")
             if need_w:
                 ctx.save_for_backward(q, k, cont, qd, w)
-        ctx.cfg = (B, heads, ch, T, ndecay, mfma)
+        ctx.cfg = (B, heads, ch, T, ndecay, mfma, gen)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, heads, ch, T, ndecay, mfma = ctx.cfg
+        B, heads, ch, T, ndecay, mfma, gen = ctx.cfg
         g = g.contiguous()
         q, k, cont, qd = ctx.saved_tensors[:4]
         dq, dk, dc, dqd = torch.empty_like(q), torch.empty_like(k), torch.empty_like(cont), torch.empty_like(qd)
@@ -324,6 +335,11 @@ class _LocalStateFn(torch.autograd.Function):
             check(_lib.lib().rfx_localstate_mfma_bwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), _ptr(g), B, heads, ch, T, ndecay,
                                                      _ptr(dq), _ptr(dk), _ptr(dc), _ptr(dqd), _ptr(stat), _stream()),
                   "rfx_localstate_mfma_bwd")
+        elif gen:
+            stat, out = ctx.saved_tensors[4:6]
+            check(_lib.lib().rfx_localstate_gen_bwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), _ptr(stat), _ptr(out), _ptr(g), B,
+                                                    heads, ch, T, ndecay, _ptr(dq), _ptr(dk), _ptr(dc), _ptr(dqd), _stream()),
+                  "rfx_localstate_gen_bwd")
         else:
             w = ctx.saved_tensors[4]
             check(_lib.lib().rfx_localstate_bwd(_ptr(q), _ptr(k), _ptr(cont), _ptr(qd), _ptr(w), _ptr(g), B, heads, ch, T,

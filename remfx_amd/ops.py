@@ -37,6 +37,24 @@ def gemm_precision():
     return {v: k for k, v in PREC_NAMES.items()}[GEMM_PREC]
 
 
+class at_least_fp32_parity:
+    """Scope in which the gather-GEMMs run at fp32 parity whatever the session's mode: `bf16` is lifted to `bf16x3`
+    (f32 / bf16x3 stay).  Used by the effect detector: its thresholded labels must equal the fp32 reference's bit for bit
+    (north_star; reference remfx/models.py:60-64), and 41 GFLOP per clip do not need the single-bf16 pipe."""
+
+    def __enter__(self):
+        global GEMM_PREC
+        self.prev = GEMM_PREC
+        if GEMM_PREC == 2:
+            GEMM_PREC = 1
+        return self
+
+    def __exit__(self, *exc):
+        global GEMM_PREC
+        GEMM_PREC = self.prev
+        return False
+
+
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "tanh": 3, "prelu": 4, "leaky": 5, "sigmoid": 6}
 
 

@@ -48,14 +48,78 @@ def test_cnn14_golden(golden_dir):
         outb = torch.hstack(net(x, train=False)).cpu().numpy()
     rel = np.sqrt(((mel - g["mel"]) ** 2).mean()) / np.abs(g["mel"]).max()
     check(rel, 1e-6, what=rel)
-    np.testing.assert_allclose(out, g["out_eval"], rtol=tol(2e-4, bf16=5e-2), atol=tol(2e-5, bf16=2e-2))
-    np.testing.assert_allclose(outb, g["out_bnbatch"], rtol=tol(5e-3, bf16=5e-2), atol=tol(5e-4, bf16=2e-2))
-    # bit-exact detected-effect labels (models.py:61-64) in the fp32-parity modes; with bf16 operands every probability
-    # further than the mode's output bound from the 0.5 threshold must still land on the reference's side
-    sure = (lambda ref: np.abs(ref - 0.5) > 2e-2) if mode() == "bf16" else (lambda ref: np.ones_like(ref, dtype=bool))
-    assert np.array_equal((out > 0.5)[sure(g["out_eval"])], (g["out_eval"] > 0.5)[sure(g["out_eval"])])
-    assert np.array_equal((outb > 0.5)[sure(g["out_bnbatch"])], (g["out_bnbatch"] > 0.5)[sure(g["out_bnbatch"])])
+    # the detector runs at fp32 parity in EVERY session mode (Cnn14.forward, train=False -> ops.at_least_fp32_parity): the
+    # bf16 session has the bf16x3 bounds
+    np.testing.assert_allclose(out, g["out_eval"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(outb, g["out_bnbatch"], rtol=5e-3, atol=5e-4)
+    # bit-exact detected-effect labels (models.py:61-64), all modes, no mask around the threshold
+    assert np.array_equal(out > 0.5, g["out_eval"] > 0.5)
+    assert np.array_equal(outb > 0.5, g["out_bnbatch"] > 0.5)
 
+
+_FULL = {}
+
+
+def _full_length_case():
+    """16 full-length (262144-sample) clips of different character + the CPU oracle's probabilities (computed once per session)."""
+    if not _FULL:
+        from oracle import ref_cnn14
+        g = torch.Generator().manual_seed(41)
+        t = torch.arange(262144) / 48000.0
+        clips = []
+        for i in range(16):
+            kind = i % 4
+            if kind == 0:
+                c = torch.randn(262144, generator=g) * (0.02 + 0.05 * i)
+            elif kind == 1:
+                c = 0.3 * torch.sin(2 * torch.pi * (100.0 + 300.0 * i + 500.0 * i * t) * t)
+            elif kind == 2:
+                c = torch.randn(262144, generator=g).cumsum(0)
+                c = 0.2 * c / c.abs().max()
+            else:
+                env = torch.exp(-((t * (3 + i)) % 1.0) * 8.0)
+                c = env * torch.sin(2 * torch.pi * 220.0 * (1 + i / 4) * t) * 0.4 + 0.01 * torch.randn(262144, generator=g)
+            clips.append(c)
+        x = torch.stack(clips)[:, None, :]
+        sd = _cnn14_sd()
+        torch.set_num_threads(min(32, os.cpu_count() or 8))
+        with torch.no_grad():
+            p0 = torch.hstack(ref_cnn14.cnn14_forward(x, sd, bn_train=False)).double()
+            # a randomly initialised Cnn14 in eval mode barely depends on its input (logit spread ~1e-2 across clips):
+            # re-centre and stretch each head (an affine map of its weight / bias) so that the 16 clips fall on BOTH sides
+            # of the threshold with logits spread over about +-2 -- the fp32 rounding noise is stretched with them, which
+            # makes this a far harsher label test than the raw heads would be
+            z = torch.log(p0 / (1 - p0))
+            for k in range(5):
+                a = float(2.0 / z[:, k].std())
+                zs = z[:, k].sort().values                     # threshold in the widest gap among the central clips
+                j = int((zs[5:12] - zs[4:11]).argmax()) + 4
+                c = float((zs[j] + zs[j + 1]) / 2)
+                sd[f"heads.{k}.bias"] = (sd[f"heads.{k}.bias"].double() - c) * a
+                sd[f"heads.{k}.weight"] = sd[f"heads.{k}.weight"].double() * a
+                sd[f"heads.{k}.bias"], sd[f"heads.{k}.weight"] = sd[f"heads.{k}.bias"].float(), sd[f"heads.{k}.weight"].float()
+            ref = torch.hstack(ref_cnn14.cnn14_forward(x, sd, bn_train=False)).numpy()
+        _FULL["x"], _FULL["ref"], _FULL["sd"] = x, ref, sd
+    return _FULL["x"], _FULL["ref"], _FULL["sd"]
+
+
+def test_detector_labels_full_length_bit_exact():
+    """BASELINE config 5's detector on 16 FULL-LENGTH clips (262144 samples, 48 kHz, n_fft 2048 / hop 512 / 128 mels =
+    cfg/model/cls_panns_48k*.yaml): thresholded labels (reference models.py:60-64) equal the CPU oracle's bit for bit in
+    every session mode, through FXClassifier.forward as RemFXChainInference calls it."""
+    from remfx_amd.classifier import Cnn14
+    from remfx_amd.models import FXClassifier
+    x, ref, sd = _full_length_case()
+    net = Cnn14(num_classes=5, sample_rate=48000, model_sample_rate=48000, n_fft=2048, hop_length=512, n_mels=128)
+    net.load_state_dict(sd, strict=False)
+    cls = FXClassifier(3e-4, 1e-3, 48000, net).to(DEV).eval()
+    with torch.no_grad():
+        out = torch.hstack(cls(x.to(DEV))).cpu().numpy()
+    margin = np.abs(ref - 0.5).min()
+    assert (ref > 0.5).any() and (ref <= 0.5).any(), "degenerate case: all labels equal"
+    # probabilities: the stretched heads amplify the fp32 feature noise by ~2 / (logit spread) ~ 100-400x
+    assert np.abs(out - ref).max() < 5e-3, np.abs(out - ref).max()
+    assert np.array_equal(out > 0.5, ref > 0.5), (margin, np.abs(out - ref).max())
 
 def test_cnn14_train_step_vs_oracle():
     """FXClassifier loss + a few gradients (train-mode BN) vs autograd over the CPU oracle."""

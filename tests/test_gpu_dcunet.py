@@ -71,29 +71,63 @@ def test_dcunet_zero_padded_filterbank_form():
     check(_rms(yd, y), 1e-4, max(1.0, float(y.abs().max())))
 
 
+_F64 = {}
+
+
+def _train_case():
+    """Train-mode (batch-statistic complex BatchNorm) forward + backward of the CPU oracle in fp32 AND fp64 on the same
+    weights / input (computed once per session; the fp64 pass is the ground truth both fp32 paths are measured against)."""
+    if not _F64:
+        import copy
+        ref, net = _pair(train=True)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2, 50000, generator=g) * 0.3
+        ref64 = copy.deepcopy(ref).double()
+        y = ref(x)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        y64 = ref64(x.double())
+        y64.backward(gy.double())
+        _F64.update(ref=ref, sd={k: v.clone() for k, v in net.state_dict().items()}, x=x, gy=gy, y=y.detach(), y64=y64.detach(),
+                    g32={n: p.grad for n, p in ref.named_parameters()}, g64={n: p.grad for n, p in ref64.named_parameters()})
+    return _F64
+
+
+def _global_rel(got, truth):
+    num = sum(float((got[n].double().cpu() - truth[n]).pow(2).sum()) for n in truth)
+    den = sum(float(truth[n].pow(2).sum()) for n in truth)
+    return (num / den) ** 0.5
+
+
 def test_dcunet_train_fwd_bwd():
-    ref, net = _pair(train=True)
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 50000, generator=g) * 0.3
-    y = ref(x)
-    gy = torch.randn(y.shape, generator=g)
-    y.backward(gy)
+    """Train-mode gradients.  The batch-statistic 2x2 whitening of 3 x W maps is ill-conditioned, so fp32 itself is noisy
+    here: the CPU oracle in fp32 sits 4.3e-3 (global relative) from its own fp64 run.  The parity statement is therefore
+    made against the fp64 ground truth: the exact-fp32 HIP path must be no further from it than 2 x the CPU fp32 path is."""
+    from remfx_amd.dcunet import DCUNet
+    c = _train_case()
+    ref, x, gy, y = c["ref"], c["x"], c["gy"], c["y"]
+    net = DCUNet(stft_kernel_size=512, fix_length_mode="pad")
+    net.load_state_dict(c["sd"], strict=True)
+    net = net.to(DEV).train()
     yd = net(x.to(DEV))
-    check(_rms(yd.detach().cpu(), y.detach()), 1e-4, max(1.0, float(y.detach().abs().max())))
+    check(_rms(yd.detach().cpu(), y), 1e-4, max(1.0, float(y.abs().max())))
+    check(_rms(yd.detach().cpu().double(), c["y64"]), 1e-4, max(1.0, float(y.abs().max())), what="fwd vs fp64")
     yd.backward(gy.to(DEV))
-    refg = dict(ref.named_parameters())
-    num = den = 0.0
-    errs = []
+    got = {n: p.grad for n, p in net.named_parameters()}
     for n, p in net.named_parameters():
-        r = refg[n].grad
-        d = p.grad.cpu() - r
-        num += float((d ** 2).sum()); den += float((r ** 2).sum())
-        errs.append((float((d ** 2).sum()) / max(float((r ** 2).sum()), 1e-30), n))
-        check(_rms(p.grad.cpu(), r), 5e-2, max(1e-6, float(r.abs().max())), what=n)
-    print("global rel", (num / den) ** 0.5, sorted(errs)[-4:])
-    # batch-statistic whitening of 3 x W maps is ill-conditioned: fp32 ordering noise is amplified
-    # measured: 4.3e-3 in exact fp32 (ordering noise only), 1.2e-2 with bf16x3 products, 0.22 with bf16 operands
-    check((num / den) ** 0.5, 5e-3, bf16x3=2e-2, bf16=0.4, what=(num / den) ** 0.5)
+        r = c["g64"][n]
+        check(_rms(p.grad.cpu().double(), r), 5e-2, max(1e-6, float(r.abs().max())), what=n)
+    e_cpu = _global_rel(c["g32"], c["g64"])                 # CPU oracle fp32 vs fp64: the conditioning of the problem
+    e_hip = _global_rel(got, c["g64"])
+    e_pair = _global_rel(got, {n: v.double() for n, v in c["g32"].items()})
+    print(f"DCUNet train-mode gradient, global relative error vs the fp64 oracle: CPU fp32 oracle {e_cpu:.2e}, HIP [{mode()}] "
+          f"{e_hip:.2e}; HIP vs CPU fp32 oracle {e_pair:.2e}")
+    assert 1e-4 < e_cpu < 2e-2, e_cpu                     # the premise: fp32 is this noisy on the CPU too
+    if mode() == "f32":
+        assert e_hip < 2.0 * e_cpu, (e_hip, e_cpu)
+    else:
+        # bf16x3: 2^-17 product rounding through the same conditioning (measured 1.2e-2); bf16: 2^-9 operands (0.22)
+        check(e_hip, 5e-3, bf16x3=2e-2, bf16=0.4, what=e_hip)
     # running statistics updated identically (momentum 0.1 lerp)
     rb = dict(ref.named_buffers())
     for n, b in net.named_buffers():

@@ -175,3 +175,68 @@ def _directional_derivative(models):
     # bf16: the two forward evaluations carry independent operand-rounding noise of ~1e-3 of the loss each, against a
     # first-order change of 2e-3 per side
     assert abs(fd - gnorm) < tol(0.05, bf16=0.5) * gnorm, (fd, gnorm, vals, float(loss))
+
+
+def test_hdemucs_batching_invariance_headline():
+    """Headline network (cfg/model/demucs.yaml, 83.6 M parameters, 262144-sample clips): the forward of a batch of 8 equals
+    the same 8 clips run one at a time.  Exercises what only B > 1 reaches: position tiles of the persistent short-K kernel
+    that span samples, the per-sample GroupNorm statistic slots, multi-cluster LSTM launches and the (B*Fr)-sample DConv
+    views.  Per-element arithmetic does not depend on the batch (same K order, same operand rounding); only the order of the
+    statistic atomics does, hence the tight bound in every mode."""
+    from remfx_amd.hdemucs import HDemucs
+    torch.manual_seed(11)
+    net = HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48).to(DEV).eval()
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith(".scale"):
+                p.fill_(0.3)                                  # make the DConv branches numerically visible
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(8, 1, CLIP, generator=g) * 0.1).to(DEV)
+    with torch.no_grad():
+        yb = net(x)
+        ys = torch.cat([net(x[i:i + 1]) for i in range(8)], 0)
+    scale = float(ys.pow(2).mean().sqrt())
+    err = float((yb - ys).pow(2).mean().sqrt())
+    check(err, 1e-5, scale, bf16x3=1e-5, bf16=2e-3, what=("batch-of-8 vs singles", err, scale))
+    emax = float((yb - ys).abs().max())
+    check(emax, 2e-4, max(scale, float(ys.abs().max())), bf16x3=2e-4, bf16=5e-2, what=("max", emax))
+
+
+def test_demucs_b64_step_equals_mean_of_single_clip_steps():
+    """One bench.py-shaped step (DemucsModel, 64 x 262144 white-noise clips, MRSTFT + 100 L1): the batch loss equals the mean
+    of the 64 single-clip losses and the batch gradient equals the mean of the 64 single-clip gradients (per-example
+    spectral convergence, auraloss >= 0.4; reference remfx/models.py:307-324).  This is the B = 64 configuration BENCH
+    reports, compared with the B = 1 configuration the oracle tests pin."""
+    from remfx_amd import models
+    torch.manual_seed(21)
+    net = models.DemucsModel(sample_rate=48000, sources=["mixture"], audio_channels=1, nfft=4096, channels=48).to(DEV)
+    B = 64
+    g = torch.Generator().manual_seed(12345)
+    x = (torch.randn(B, 1, CLIP, generator=g) * 0.1).to(DEV)
+    y = (torch.randn(B, 1, CLIP, generator=g) * 0.1).to(DEV)
+    params = [p for p in net.parameters() if p.requires_grad]
+    loss_b, out_b = net((x, y))
+    loss_b.backward()
+    params = [p for p in params if p.grad is not None]
+    gb = [p.grad.detach().clone() for p in params]
+    for p in params:
+        p.grad = None
+    losses = []
+    outs = []
+    for i in range(B):
+        li, oi = net((x[i:i + 1], y[i:i + 1]))
+        (li / B).backward()                                   # accumulates the mean gradient in p.grad
+        losses.append(float(li))
+        outs.append(oi.detach()[..., ::64])
+    mean_loss = sum(losses) / B
+    check(abs(float(loss_b) - mean_loss), 2e-6, mean_loss, bf16x3=2e-6, bf16=1e-4, what=("loss", float(loss_b), mean_loss))
+    oerr = float((out_b.detach()[..., ::64] - torch.cat(outs, 0)).pow(2).mean().sqrt())
+    check(oerr, 1e-5, float(out_b.detach().pow(2).mean().sqrt()), bf16x3=1e-5, bf16=2e-3, what=("out", oerr))
+    num = sum(float((a - p.grad).double().pow(2).sum()) for a, p in zip(gb, params))
+    den = sum(float(p.grad.double().pow(2).sum()) for p in params)
+    rel = (num / den) ** 0.5
+    # gradients: the weight-gradient GEMMs split the position range of the WHOLE batch over workgroups and combine fp32
+    # partial sums; 64 separately rounded single-clip gradients summed in fp32 differ at the 1e-6..1e-5 level.  bf16: the
+    # 16-bit stored gradient tensors (dz) round per element identically in both runs, the per-clip 1/B scaling does not
+    # commute with that rounding exactly
+    check(rel, 1e-4, 1.0, bf16x3=1e-4, bf16=5e-3, what=("grad batch vs mean of singles", rel))

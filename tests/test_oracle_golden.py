@@ -49,6 +49,34 @@ def test_tcn_full_known_answers(golden_dir):
     assert sorted(sd.keys()) == sorted(g["keys"].tolist())
 
 
+def _tcn_full_state(seed):
+    sd = ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7, seed=seed)
+    for i, k in enumerate([k for k in sd if k.endswith("relu.weight")]):
+        sd[k] = torch.linspace(0.05, 0.45, sd[k].numel()).roll(7 * i)
+    return sd
+
+
+def test_tcn_full_width_fwd_bwd_matches_reference(golden_dir):
+    """The oracle at the FULL cfg/model/tcn.yaml width (20 x 256, k 7) vs the imported reference's forward output and autograd
+    gradients on one 32768-sample clip (oracle/gen_golden.py::gen_tcn_full)."""
+    g = _load(golden_dir, "tcn_full_fwd_bwd.npz")
+    sd = {k: v.requires_grad_(True) for k, v in _tcn_full_state(int(g["seed"])).items()}
+    gen = torch.Generator().manual_seed(int(g["x_seed"]))
+    x = torch.randn(1, 1, int(g["T"]), generator=gen) * 0.5
+    y = ref_tcn.tcn_forward(x, sd, 20)
+    assert y.shape == g["y"].shape
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=2e-6)
+    r = torch.randn(y.shape, generator=gen)
+    (y * r).sum().backward()
+    gtot = float(torch.sqrt(sum(v.grad.double().pow(2).sum() for v in sd.values())))
+    assert abs(gtot - float(g["grad_total_norm"])) < 1e-4 * float(g["grad_total_norm"])
+    for n in g["grad_names"].tolist():
+        gr = sd[n].grad.reshape(-1)
+        sl = gr[:: max(1, gr.numel() // 512)][:512].numpy()
+        ref = g["gslice_" + n]
+        assert np.sqrt(((sl - ref) ** 2).mean()) < 1e-4 * max(1e-6, np.abs(ref).max()), n
+
+
 def test_cnn14_matches_reference(golden_dir):
     g = _load(golden_dir, "cnn14_full.npz")
     sd = ref_cnn14.cnn14_init_state_dict(seed=7)
