@@ -62,33 +62,58 @@ def synthetic_batch(batch, rank, device, clip=CLIP):
     return tuple(t.to(device) for t in (x, y, lab, lab.clone()))
 
 
-class KernelTimer:
-    """HIP-event timing of the dominant kernel family (forward-family gather-GEMM launches: conv forward, input
-    gradients, transposed convs, linear layers) on the stream they are launched on, with the algorithmic FLOPs
-    (2*M*K*positions*N) and bytes (every distinct input element / weight read once, every output written once) of each
-    launch, so that every launch can be priced against the roofline that binds IT (ridge = peak FLOP/s / peak B/s)."""
+def variant_name(code, prec):
+    """Kernel instantiation behind an rfx_gemm_fwd_variant() code (csrc/gemm.hip), spelled as rocprofv3 prints it."""
+    kind, r = code >> 4, code & 15
+    mode = {0: 0, 1: 1, 2: 2}[prec]
+    return {0: "gemm_thin_fwd_kernel<M>", 1: f"gemm_fwd_kernel<{r}>", 2: f"gemm_tap_kernel<{r}, {mode}, 0>",
+            3: f"gemm_tap_kernel<{r}, 2, 1>", 4: f"gemm_tap_stream_kernel<{mode}, 4, 1>",
+            5: f"gemm_tap_stream_kernel<{mode}, 2, 4>"}.get(kind, f"variant{code}")
 
-    def __init__(self):
-        self.launches, self.enabled, self.desc, self.wgrad = [], False, [], []          # (start, end, flops, bytes); plan of each launch
+
+def _pmc_key(name):
+    """Normalised key of a kernel name from a rocprofv3 CSV / the PMC traffic JSON: template booleans and integers compare
+    equal (`<4, 2, false>` == `<4, 2, 0>`)."""
+    return name.replace(" ", "").replace("false", "0").replace("true", "1").replace(",0>", ">") if name else name
+
+
+class KernelTimer:
+    """HIP-event timing of every forward-family gather-GEMM launch (conv forward, input gradients, transposed convs, linear
+    layers) on the stream it is launched on, with its algorithmic FLOPs (2*M*K*positions*N) and algorithmic BYTES priced by
+    the STORED type of each tensor (every distinct gathered input element once, every written output element once, the packed
+    weights once in the arithmetic mode's operand width, residual / GLU side tensors once), and the kernel instantiation the
+    launcher picked (rfx_gemm_fwd_variant).  Launches are grouped per instantiation; each group is priced against both roofs."""
+
+    def __init__(self, prec):
+        self.launches, self.enabled, self.desc, self.wgrad = [], False, [], []   # (start, end, flops, bytes, variant); plan of each launch
+        self.prec = prec
 
     def install(self):
         from remfx_amd import ops
         orig = ops.gemm_fwd
         timer = self
+        wbytes = {0: 4.0, 1: 4.0, 2: 2.0}        # packed weight bytes per element: fp32 / bf16 hi + lo / bf16
 
         def timed(dp, apack, x, out, *a, **kw):
             if not timer.enabled:
                 return orig(dp, apack, x, out, *a, **kw)
+            ops.TRACE_VARIANT = []
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = orig(dp, apack, x, out, *a, **kw)
             e.record()
+            code = ops.TRACE_VARIANT[-1] if ops.TRACE_VARIANT else -1
+            ops.TRACE_VARIANT = None
             p = dp.p
+            prec = dp.fwd_prec()
             k = p.extra["n_weight_rows"] + (kw["dp2"].p.extra["n_weight_rows"] if kw.get("dp2") is not None else 0)
-            extra = sum(t.numel() for t in (kw.get("res"), kw.get("glu_out")) if t is not None)
-            timer.launches.append((s, e, 2.0 * p.M * k * p.OA * p.OB * p.N, 4.0 * (x.numel() + out.numel() + p.M * k + extra)))
+            extra = sum(t.numel() * t.element_size() for t in (kw.get("res"), kw.get("glu_out"), kw.get("in2")) if t is not None)
+            written = p.N * p.M * p.OA * p.OB                       # output elements this launch stores
+            nbytes = float(x.numel() * x.element_size() + written * out.element_size() + p.M * k * wbytes[prec] + extra)
+            timer.launches.append((s, e, 2.0 * p.M * k * p.OA * p.OB * p.N, nbytes, variant_name(code, prec)))
             timer.desc.append({"M": p.M, "K": k, "N": p.N, "OA": p.OA, "OB": p.OB, "R": p.R, "x": list(x.shape), "out": list(out.shape),
-                               "two_phase": kw.get("dp2") is not None, "extra_elems": extra})
+                               "x_dtype": str(x.dtype), "out_dtype": str(out.dtype), "kernel": variant_name(code, prec),
+                               "two_phase": kw.get("dp2") is not None, "extra_bytes": extra})
             return r
         ops.gemm_fwd = timed
         import remfx_amd.tcn as tcn_mod
@@ -112,14 +137,18 @@ class KernelTimer:
 
     def result(self, peak_tflops, peak_gbs):
         """Totals + the split of the family into MFMA-bound and HBM-bound launches (by each launch's own arithmetic
-        intensity against the ridge point of the mode's peaks)."""
+        intensity against the ridge point of the mode's peaks) + per-instantiation groups."""
         ridge = peak_tflops * 1e12 / (peak_gbs * 1e9)
         cls = {"mfma": [0.0, 0.0, 0.0, 0], "hbm": [0.0, 0.0, 0.0, 0]}        # ms, flops, bytes, launches
-        for s, e, fl, by in self.launches:
+        kern = {}
+        for s, e, fl, by, name in self.launches:
+            ms = s.elapsed_time(e)
             c = cls["mfma" if fl / by >= ridge else "hbm"]
-            c[0] += s.elapsed_time(e); c[1] += fl; c[2] += by; c[3] += 1
+            c[0] += ms; c[1] += fl; c[2] += by; c[3] += 1
+            k = kern.setdefault(name, [0.0, 0.0, 0.0, 0])
+            k[0] += ms; k[1] += fl; k[2] += by; k[3] += 1
         ms = cls["mfma"][0] + cls["hbm"][0]
-        return ms, len(self.launches), cls, ridge
+        return ms, len(self.launches), cls, ridge, kern
 
 
 def _host_cpu():
@@ -241,37 +270,83 @@ def bench_chain(args, rank, world, device):
                                         "removal_model_applications_per_step": napplied, "parallelism": f"dp{world}"}}))
 
 
-def bench_demucs_fwd(args, rank, world, device):
-    """The north_star's own sub-metric: STFT + Hybrid Demucs FORWARD (model.sample: _spec, both U-Net branches, _ispec) on
-    64 x 262144-sample clips, no loss / backward.  Algorithmic work: 117.2 GFLOP and 396 MB of fp32
-    layer-boundary traffic per clip + 334 MB of weights per pass -> both roofline fractions are reported."""
-    batch = args.batch or 64
-    model = build_model("demucs", device).eval()
-    x = synthetic_batch(batch, rank, device)[0]
+def measure_demucs_fwd(model, x, steps, warmup, gemm, world=1):
+    """STFT + Hybrid Demucs FORWARD (DemucsModel.sample: _spec, both U-Net branches, _ispec) on the clips `x`, no loss /
+    backward: seconds per pass (max over ranks), output rms, and HIP-event times of the two HBM-bound end stages."""
+    from remfx_amd import stft as stft_mod
+    ev = {"stft": [], "istft": []}
+    orig = {"stft": stft_mod.stft, "istft": stft_mod.istft}
+    state = {"on": False}
+
+    def wrap(name):
+        def f(*a, **kw):
+            if not state["on"]:
+                return orig[name](*a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig[name](*a, **kw)
+            e.record()
+            ev[name].append((s, e))
+            return r
+        return f
+    stft_mod.stft, stft_mod.istft = wrap("stft"), wrap("istft")
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            model.model.sample(x)
-        fence()
-        t0 = time.time()
-        for _ in range(args.steps):
-            out = model.model.sample(x)
-        fence()
-    dt = time.time() - t0
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            for _ in range(warmup):
+                model.model.sample(x)
+            fence()
+            state["on"] = True
+            t0 = time.time()
+            for _ in range(steps):
+                out = model.model.sample(x)
+            fence()
+            dt = time.time() - t0
+            state["on"] = False
+    finally:
+        stft_mod.stft, stft_mod.istft = orig["stft"], orig["istft"]
+        model.train(was_training)
+    t = torch.tensor([dt], device=x.device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t) / steps
+    batch = x.shape[0]
+    flops = batch * (117.2e9 + 0.13e9)                              # SURVEY 8d
+    nbytes = batch * 396e6 + 334e6                                  # fp32 layer-boundary bytes + weights once
+    mfma_peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[gemm]
+    f_hbm, f_mfma = nbytes / dt / 1e9 / PEAK_HBM_GBS, flops / dt / 1e12 / mfma_peak
+    # the HBM-bound end stages (SURVEY 8d "STFT-only sub-metric"): _spec reads B*T*4 and writes (B, 2, nfft/2, T/hop) fp32;
+    # _ispec the reverse
+    end_bytes = batch * CLIP * 4 + batch * 2 * 2048 * 256 * 4
+    stages = {}
+    for name in ("stft", "istft"):
+        ms = sum(s.elapsed_time(e) for s, e in ev[name]) / max(len(ev[name]), 1)
+        stages[name] = {"ms": round(ms, 4), "algorithmic_bytes": end_bytes,
+                        "frac_hbm": round(end_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if ms > 0 else None}
+    unet_ms = dt * 1e3 - stages["stft"]["ms"] - stages["istft"]["ms"]
+    stages["unet"] = {"ms": round(unet_ms, 3), "frac_hbm": round((nbytes - 2 * end_bytes) / (unet_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                      "frac_mfma": round(batch * 117.2e9 / (unet_ms * 1e-3) / 1e12 / mfma_peak, 4)}
+    return {"seconds": dt, "flops": flops, "bytes": nbytes, "frac_hbm": f_hbm, "frac_mfma": f_mfma, "mfma_peak": mfma_peak,
+            "stages": stages, "output_rms": float(out.float().pow(2).mean().sqrt())}
+
+
+def bench_demucs_fwd(args, rank, world, device):
+    """The north_star's own sub-metric: STFT + Hybrid Demucs FORWARD on 64 x 262144-sample clips.  Algorithmic work
+    (SURVEY 8d): 117.2 GFLOP and 396 MB of fp32 layer-boundary traffic per clip + 334 MB of weights per pass -> both roofline
+    fractions are reported, plus the HBM fraction of each stage."""
+    batch = args.batch or 64
+    model = build_model("demucs", device).eval()
+    x = synthetic_batch(batch, rank, device)[0]
+    m = measure_demucs_fwd(model, x, args.steps, args.warmup, args.gemm, world)
     if rank != 0:
         return
-    dt = float(t) / args.steps
-    flops = batch * (117.2e9 + 0.13e9)
-    nbytes = batch * 396e6 + 334e6
-    mfma_peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[args.gemm]
-    f_hbm, f_mfma = nbytes / dt / 1e9 / PEAK_HBM_GBS, flops / dt / 1e12 / mfma_peak
+    dt, f_hbm, f_mfma = m["seconds"], m["frac_hbm"], m["frac_mfma"]
     bound = "hbm" if f_hbm >= f_mfma else "mfma"
     print(json.dumps({
         "metric": "audio-seconds/sec STFT + Demucs forward (whole job)", "value": round(world * batch * CLIP / SR / dt, 3),
@@ -280,11 +355,46 @@ def bench_demucs_fwd(args, rank, world, device):
         "dtype": DTYPES[args.gemm], "data": "synthetic",
         "config": {"workload": "Hybrid Demucs (cfg/model/demucs.yaml) forward only: STFT -> U-Net -> iSTFT, DemucsModel.sample",
                    "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR, "parallelism": f"dp{world}",
-                   "output_rms": round(float(out.float().pow(2).mean().sqrt()), 6)},
-        "roofline": {"bound": bound, "achieved": round(nbytes / dt / 1e9, 1) if bound == "hbm" else round(flops / dt / 1e12, 2),
-                     "peak": PEAK_HBM_GBS if bound == "hbm" else mfma_peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                   "output_rms": round(m["output_rms"], 6)},
+        "roofline": {"bound": bound, "achieved": round(m["bytes"] / dt / 1e9, 1) if bound == "hbm" else round(m["flops"] / dt / 1e12, 2),
+                     "peak": PEAK_HBM_GBS if bound == "hbm" else m["mfma_peak"], "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                      "frac": round(max(f_hbm, f_mfma), 4), "frac_hbm": round(f_hbm, 4), "frac_mfma": round(f_mfma, 4),
-                     "algorithmic_bytes_per_pass": nbytes, "algorithmic_flops_per_pass": flops, "traffic": None}}))
+                     "algorithmic_bytes_per_pass": m["bytes"], "algorithmic_flops_per_pass": m["flops"], "traffic": None,
+                     "stages": m["stages"]}}))
+
+
+def also_block(args, model, opt, sched, sync, data, device, step):
+    """Measured in the SAME process as the headline line (N = 1 only): (a) the training step in the fp32-parity arithmetic
+    (bf16x3: the mode whose forward is within 1e-4 RMS of the fp32 oracle, tests/), so the driver-run record carries the
+    1e-4-parity number next to the bf16 one; (b) the north_star's own sub-metric, STFT + Demucs forward, with per-stage HBM
+    fractions."""
+    from remfx_amd import ops
+    res = {}
+    if args.gemm != "bf16x3":
+        prev = ops.gemm_precision()
+        ops.set_gemm_precision("bf16x3")
+        try:
+            for i in range(2):
+                step(10_000 + i)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            n = max(3, min(args.steps, 10))
+            for i in range(n):
+                step(10_002 + i)
+            torch.cuda.synchronize()
+            dtx = (time.time() - t0) / n
+        finally:
+            ops.set_gemm_precision(prev)
+        res["train_step_bf16x3"] = {"ms_per_step": round(dtx * 1e3, 3), "audio_seconds_per_sec": round(data[0].shape[0] * CLIP / SR / dtx, 3),
+                                    "dtype": DTYPES["bf16x3"], "steps": n,
+                                    "parity": "forward within 1e-4 RMS of the fp32 oracle (tests/test_gpu_hdemucs.py)"}
+    m = measure_demucs_fwd(model, data[0], max(3, min(args.steps, 10)), 2, args.gemm)
+    res["demucs_fwd"] = {"metric": "audio-seconds/sec STFT + Demucs forward", "ms_per_pass": round(m["seconds"] * 1e3, 3),
+                         "audio_seconds_per_sec": round(data[0].shape[0] * CLIP / SR / m["seconds"], 3), "dtype": DTYPES[args.gemm],
+                         "frac_hbm": round(m["frac_hbm"], 4), "frac_mfma": round(m["frac_mfma"], 4),
+                         "algorithmic_bytes_per_pass": m["bytes"], "algorithmic_flops_per_pass": m["flops"], "stages": m["stages"],
+                         "target": "north_star: >= 0.5 of the HBM roofline on STFT + Demucs forward at 64 x 262144"}
+    return res
 
 
 def main():
@@ -296,16 +406,20 @@ def main():
                     choices=["demucs", "tcn", "dcunet", "umx", "chain", "demucs_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` block (bf16x3 step + Demucs forward sub-metric)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch plan / algorithmic work / event time list of the timed steps (JSON)")
     ap.add_argument("--union-ranks", type=int, default=0,
                     help="single process only: train on the concatenation of the synthetic batches ranks 0..N-1 would "
                          "get (N x --batch clips) -- the reference point of the data-parallel equivalence test")
-    ap.add_argument("--gemm", default=os.environ.get("RFX_GEMM_PREC", "bf16"), choices=["bf16", "bf16x3", "f32"],
-                    help="MFMA arithmetic of the gather-GEMMs.  bf16 (default): operands rounded to bf16, fp32 accumulation -- "
-                         "trainer.precision=bf16-mixed, the precision BASELINE.json's headline config names; bf16x3: fp32 "
-                         "operands split hi + lo, 3 MFMAs per product (HDemucs forward within 4e-6 RMS of the fp32 oracle); "
+    ap.add_argument("--gemm", default=os.environ.get("RFX_GEMM_PREC"), choices=["bf16", "bf16x3", "f32"],
+                    help="MFMA arithmetic of the gather-GEMMs.  Default = what the BASELINE config of the workload names: bf16 "
+                         "(operands rounded to bf16, fp32 accumulation = trainer.precision=bf16-mixed) for the Demucs headline "
+                         "(config 3); bf16x3 (fp32 operands split hi + lo, 3 MFMAs per product: fp32 parity, forward within 1e-4 RMS "
+                         "of the fp32 oracle) for the fp32 configs (TCN config 2, DCUNet config 4, Open-Unmix, chain inference); "
                          "f32: exact fp32 MFMA")
     args = ap.parse_args()
+    if args.gemm is None:
+        args.gemm = "bf16" if args.workload in ("demucs", "demucs_fwd") else "bf16x3"
     if args.workload == "tcn" and args.warmup < 2:
         # 32 x 262144 TCN activations fill ~190 of the 288 GB: the caching allocator settles only after its one
         # "free everything and retry" event at the start of step 2 (a 5.5 s host stall that is not part of a step)
@@ -333,7 +447,7 @@ def main():
     if args.union_ranks > 1:
         parts = [synthetic_batch(batch, r, device) for r in range(args.union_ranks)]
         data = tuple(torch.cat([p[i] for p in parts], 0) for i in range(4))
-    timer = KernelTimer()
+    timer = KernelTimer(ops.PREC_NAMES[args.gemm])
     timer.install()
 
     def step(i):
@@ -372,39 +486,55 @@ def main():
     audio_s = world * batch * CLIP / SR * args.steps
     # algorithmic (fp32-equivalent) FLOP/s; in bf16x3 mode the matrix pipe executes 3x that in bf16
     peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[args.gemm]
-    kname = {"f32": "gemm_fwd_kernel<R> (gather-GEMM, v_mfma_f32_32x32x2_f32)",
-             "bf16x3": "gemm_tap_kernel<R,1> + gemm_tap_stream_kernel<1,..> (tap-major gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per K step)",
-             "bf16": "gemm_tap_kernel<R,2> + gemm_tap_stream_kernel<2,..> (tap-major gather-GEMM, 1 x v_mfma_f32_32x32x16_bf16 per K step)"}[args.gemm]
-    kms, klaunches, cls, ridge = timer.result(peak, PEAK_HBM_GBS)
+    fam_name = {"f32": "gemm_fwd_kernel<R> (gather-GEMM, v_mfma_f32_32x32x2_f32)",
+                "bf16x3": "gemm_tap_kernel<R,1> + gemm_tap_stream_kernel<1,..> (tap-major gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per K step)",
+                "bf16": "gemm_tap_kernel<R,2[,IN16]> + gemm_tap_stream_kernel<2,..> (tap-major gather-GEMM, 1 x v_mfma_f32_32x32x16_bf16 per K step)"}[args.gemm]
+    kms, klaunches, cls, ridge, kern = timer.result(peak, PEAK_HBM_GBS)
     if args.dump_launches:         # per-launch plan + algorithmic work + event time, in launch order (scripts/join_launch_pmc.py)
-        json.dump([dict(d, ms=s.elapsed_time(e), flops=fl, bytes=by) for d, (s, e, fl, by) in zip(timer.desc, timer.launches)],
+        json.dump([dict(d, ms=s.elapsed_time(e), flops=fl, bytes=by) for d, (s, e, fl, by, _) in zip(timer.desc, timer.launches)],
                   open(args.dump_launches, "w"))
         json.dump([dict(d, ms=s.elapsed_time(e)) for s, e, d in timer.wgrad], open(args.dump_launches + ".wgrad.json", "w"))
     tot_fl = cls["mfma"][1] + cls["hbm"][1]
     tot_by = cls["mfma"][2] + cls["hbm"][2]
-    f_mfma = tot_fl / (kms * 1e-3) / 1e12 / peak if kms > 0 else 0.0
-    f_hbm = tot_by / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS if kms > 0 else 0.0
-    bound = "hbm" if f_hbm >= f_mfma else "mfma"
 
-    def _cls(name):
-        ms, fl, by, n = cls[name]
-        if not n:
+    def _price(ms, fl, by, n):
+        """One group of launches against both roofs."""
+        if not n or ms <= 0:
             return {"launches": 0}
-        return {"launches": n, "ms_per_step": round(ms / args.steps, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
-                "gbs": round(by / (ms * 1e-3) / 1e9, 1),
-                "frac": round((fl / (ms * 1e-3) / 1e12 / peak) if name == "mfma" else (by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS), 4)}
-    # roofline.traffic: HBM bytes per launch of the family from the committed PMC passes of this same command
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, scripts/collect_pmc.py)
-    traffic = None
+        tf, gb = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        fm, fh = tf / peak, gb / PEAK_HBM_GBS
+        return {"launches_per_step": round(n / args.steps, 2), "ms_per_step": round(ms / args.steps, 3), "avg_launch_us": round(ms / n * 1e3, 2),
+                "algorithmic_flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(by / n),
+                "tflops": round(tf, 2), "gbs": round(gb, 1), "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+                "bound": "hbm" if fh >= fm else "mfma", "frac": round(max(fh, fm), 4)}
+    # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate counter-only runs, scripts/collect_pmc.py + measure_round.sh), joined per kernel instantiation
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_demucs_b64_pmc_traffic_{args.gemm}.json")))   # latest round / pass last
-    pmc = cands[-1] if cands else ""
-    if args.workload == "demucs" and batch == 64 and pmc:
-        ks = json.load(open(pmc))["kernels"]
-        fam = [v for k, v in ks.items() if k.startswith(("gemm_fwd_kernel", "gemm_tap_kernel", "gemm_tap_stream_kernel"))]
-        n = sum(v["launches_per_step"] for v in fam)
+    pmc = {}
+    pmc_file = None
+    if args.workload == "demucs" and batch == 64 and cands:
+        pmc_file = os.path.basename(cands[-1])
+        pmc = {_pmc_key(k): v for k, v in json.load(open(cands[-1]))["kernels"].items()}
+    by_kernel = []
+    for name, (ms, fl, by, n) in sorted(kern.items(), key=lambda kv: -kv[1][0]):
+        row = dict(kernel=name, **_price(ms, fl, by, n))
+        t = pmc.get(_pmc_key(name))
+        if t:
+            row["traffic"] = round(t["bytes_per_step"] / max(t["launches_per_step"], 1))
+            row["traffic_launches_per_step"] = t["launches_per_step"]
+            # a lower bound cannot exceed what was moved: flag it instead of hiding it (tolerance: PMC sampling + launches
+            # whose tensors sit in the 256 MB Infinity Cache)
+            row["traffic_ge_algorithmic"] = bool(row["traffic"] >= 0.9 * row["algorithmic_bytes_per_launch"])
+        by_kernel.append(row)
+    dom = by_kernel[0] if by_kernel else {"kernel": None, "bound": "hbm", "frac": 0.0}
+    fam = _price(kms, tot_fl, tot_by, klaunches)
+    fam_traffic = None
+    if pmc:
+        rows = [v for k, v in pmc.items() if k.startswith(("gemm_fwd_kernel", "gemm_tap_kernel", "gemm_tap_stream_kernel"))]
+        n = sum(v["launches_per_step"] for v in rows)
         if n:
-            traffic = round(sum(v["bytes_per_step"] for v in fam) / n)
+            fam_traffic = round(sum(v["bytes_per_step"] for v in rows) / n)
     out = {
         "metric": "audio-seconds/sec fwd+bwd (whole job)", "value": round(audio_s / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -418,24 +548,33 @@ def main():
                    "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
                    "step": "fwd + MRSTFT+100*L1 loss + bwd + clip 10 + AdamW + per-step metrics",
                    "parallelism": f"dp{world}", "final_loss": round(float(loss.detach()), 5),
-                   # data-parallel bookkeeping: collective backend ("nccl" = RCCL over xGMI) and a checksum of the
-                   # parameters after the timed steps (equal across replicas; tests compare it with a 1-rank run)
+                   # data-parallel bookkeeping: collective backend ("nccl" = RCCL over xGMI), the all-reduce time the step
+                   # could NOT hide behind backward (GradSync.finish wait, ms per step), and a checksum of the parameters
+                   # after the timed steps (equal across replicas; tests compare it with a 1-rank run)
                    "dist_backend": torch.distributed.get_backend() if world > 1 else None, "ranks": world,
+                   "rccl_ranks": world if (world > 1 and torch.distributed.get_backend() == "nccl") else 0,
+                   "exposed_allreduce_ms": round(sync.exposed_ms() / max(args.steps + args.warmup, 1), 3) if hasattr(sync, "exposed_ms") else None,
                    "param_abs_sum": float(opt.flat.data.double().abs().sum())},
-        # the dominant kernel FAMILY (all forward-type gather-GEMM launches of the step).  `bound` is the roofline the family
-        # as a whole sits closer to: with bf16 operands on fp32 storage almost every Demucs layer has an arithmetic intensity
-        # below the ridge (2500 TF/s / 8 TB/s = 312 flop/B) and is priced against HBM; `by_bound` prices the launches on
-        # either side of the ridge separately.
-        "roofline": {"bound": bound, "kernel": kname,
-                     "achieved": round(tot_by / (kms * 1e-3) / 1e9, 1) if bound == "hbm" else round(tot_fl / (kms * 1e-3) / 1e12, 2),
-                     "peak": PEAK_HBM_GBS if bound == "hbm" else round(peak, 1), "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-                     "frac": round(max(f_hbm, f_mfma), 4), "frac_mfma": round(f_mfma, 4), "frac_hbm": round(f_hbm, 4),
-                     "ridge_flop_per_byte": round(ridge, 1), "by_bound": {"mfma": _cls("mfma"), "hbm": _cls("hbm")},
-                     "traffic": traffic, "algorithmic_bytes_per_launch": round(tot_by / max(klaunches, 1)),
-                     "algorithmic_flops_per_launch": round(tot_fl / max(klaunches, 1)),
-                     "launches": klaunches, "avg_launch_ms": round(kms / max(klaunches, 1), 4),
-                     "share_of_step": round(kms / (dt * 1e3), 3)},
+        # roofline: the SINGLE dominant kernel instantiation of the step's dominant family (most event-timed ms): achieved =
+        # its algorithmic bytes (or flops) per launch / its average launch duration; `bound` = the roof it sits closer to.
+        # `by_kernel` lists every instantiation of the family the same way, `family` the whole family, `by_bound` the
+        # family split at the ridge (peak FLOP/s / peak B/s) by each launch's own arithmetic intensity.
+        "roofline": {"bound": dom["bound"], "kernel": dom["kernel"],
+                     "achieved": (dom.get("gbs") if dom["bound"] == "hbm" else dom.get("tflops")),
+                     "peak": PEAK_HBM_GBS if dom["bound"] == "hbm" else round(peak, 1),
+                     "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s", "frac": dom["frac"],
+                     "frac_mfma": dom.get("frac_mfma"), "frac_hbm": dom.get("frac_hbm"),
+                     "traffic": dom.get("traffic"), "traffic_source": pmc_file,
+                     "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_launch"),
+                     "algorithmic_flops_per_launch": dom.get("algorithmic_flops_per_launch"),
+                     "launches_per_step": dom.get("launches_per_step"), "avg_launch_us": dom.get("avg_launch_us"),
+                     "ms_per_step": dom.get("ms_per_step"), "share_of_step": round(dom.get("ms_per_step", 0.0) / (dt / args.steps * 1e3), 3),
+                     "ridge_flop_per_byte": round(ridge, 1), "by_kernel": by_kernel,
+                     "family": dict(fam, kernel=fam_name, traffic=fam_traffic, share_of_step=round(kms / (dt * 1e3), 3)),
+                     "by_bound": {"mfma": _price(*cls["mfma"]), "hbm": _price(*cls["hbm"])}},
     }
+    if args.workload == "demucs" and world == 1 and not args.no_also:
+        out["also"] = also_block(args, model, opt, sched, sync, data, device, step)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     print(json.dumps(out))

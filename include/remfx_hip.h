@@ -316,6 +316,9 @@ int rfx_localstate_gen_bwd(const float* q, const float* k, const float* cont, co
                            const float* gout, int32_t B, int32_t heads, int32_t ch, int32_t T, int32_t nd, float* dq, float* dk,
                            float* dcont, float* dqd, void* stream);
 
+/* Label of the kernel instantiation rfx_gemm_fwd would launch (measurement only; see csrc/gemm.hip). */
+int rfx_gemm_fwd_variant(const rfx_gemm_desc* d, const rfx_epilogue* epi, int32_t two_phase, int32_t prec);
+
 /* ---- GroupNorm (+ fused activation) --------------------------------------------
  * x: (N, C, S) contiguous, G groups.  mode: 0 y = gn(x); 1 y = gelu(gn(x));
  * 2 y = glu(gn(x)) -> (N, C/2, S); 3 y = res + scale[c] * glu(gn(x))  (DConv tail).

@@ -184,8 +184,7 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   if (prec < 0 || prec > 2 || (d->R == 0 && prec != 0)) return -1;
   FwdArgs g;
   g.xcd_chunk = 0;
-  static const int pair_store = getenv("RFX_PAIR_STORE") ? atoi(getenv("RFX_PAIR_STORE")) : 1;
-  g.pair_store = pair_store;
+  g.pair_store = 1;
   g.d = *d;
   g.apack = apack; g.ktab = ktab; g.in = in; g.out = out;
   if (epi) g.e = *epi;
@@ -223,9 +222,8 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   dim3 grid((unsigned)nblk);
   // Position tiles are 128 flattened (a, b) positions.  When the taps reach over rows of the A axis (2-D kernels, the (8,1) / stride-4
   // frequency convolutions and their transposes) neighbouring tiles read the same input rows: give each XCD a contiguous run of
-  // tiles so the overlap is served by ITS L2 instead of being fetched from HBM once per XCD.  RFX_FWD_XCD_CHUNK=0 restores round-robin.
-  static const int chunk_on = getenv("RFX_FWD_XCD_CHUNK") ? atoi(getenv("RFX_FWD_XCD_CHUNK")) : 1;
-  g.xcd_chunk = (chunk_on == 2 || (chunk_on == 1 && d->OA > 1)) ? (int)((work + 7) / 8) : 0;
+  // tiles so the overlap is served by ITS L2 instead of being fetched from HBM once per XCD.
+  g.xcd_chunk = d->OA > 1 ? (int)((work + 7) / 8) : 0;
   if (prec == 0) return rfx_launch_gemm_fwd_f32(g, r, grid, s);
   // bf16x3 / bf16: tap-major kernels (gemm_tap.h); the caller packed A and passes the tap tables in that order
   if (d->Kpad_t <= 0 || d->Kpad_t % 16 != 0 || d->gpt <= 0 || d->ntaps <= 0 || d->ntaps > 112 || d->in_extent <= 0 ||
@@ -234,4 +232,18 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   return prec == 1 ? rfx_launch_gemm_fwd_bf3(g, r, grid, s) : rfx_launch_gemm_fwd_bf16(g, r, grid, s);
 }
 
+// Which kernel instantiation rfx_gemm_fwd launches for (desc, epilogue, prec): measurement tools label launches with it
+// (bench.py's per-kernel roofline).  kind * 16 + R; kind: 0 gemm_thin_fwd_kernel<M>, 1 gemm_fwd_kernel<R> (exact fp32, channel-major),
+// 2 gemm_tap_kernel<R, prec>, 3 gemm_tap_kernel<R, 2, IN16> (16-bit gathered operand), 4 gemm_tap_stream_kernel<prec, 4, 1>,
+// 5 gemm_tap_stream_kernel<prec, 2, 4>.  Pure function of its arguments.
+extern "C" int rfx_gemm_fwd_variant(const rfx_gemm_desc* d, const rfx_epilogue* epi, int32_t two_phase, int32_t prec) {
+  if (!d || prec < 0 || prec > 2) return -1;
+  rfx_epilogue e = epi ? *epi : rfx_epilogue{};
+  const int r = d->R;
+  if (r == 0) return 0;
+  if (prec == 0) return 16 + r;
+  if (d->in_bf16) return 48 + r;
+  if (rfx_tap_use_stream(*d, e, two_phase != 0, r)) return (d->Kpad_t <= 16 ? 64 : 80) + r;
+  return 32 + r;
+}
 

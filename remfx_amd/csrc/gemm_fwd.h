@@ -565,5 +565,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
 // launchers of the tiled forward kernels: channel-major table, exact fp32 (gemm_fwd_f32.hip); tap-major, split bf16x3
 // (gemm_fwd_bf3.hip) and plain bf16 operands (gemm_fwd_bf16.hip) -- see gemm_tap.h
 int rfx_launch_gemm_fwd_f32(const FwdArgs& g, int r, dim3 grid, hipStream_t s);
+// short single-phase reductions with enough position tiles to keep persistent workgroups busy run the streaming kernel
+// (gemm_tap_stream_kernel); shared by the launcher and rfx_gemm_fwd_variant
+static inline bool rfx_tap_use_stream(const rfx_gemm_desc& d, const rfx_epilogue& e, bool two_phase, int r) {
+  const int64_t work = (int64_t)((d.OA * d.OB + 127) / 128) * d.N;
+  return d.in_bf16 == 0 && d.Kpad_t <= 64 && !two_phase && work >= 4096 && r == 1 && e.act == RFX_ACT_NONE &&
+         e.act2 == RFX_ACT_NONE && !e.bwd && d.mg_log == 0 && !e.res;
+}
 int rfx_launch_gemm_fwd_bf3(const FwdArgs& g, int r, dim3 grid, hipStream_t s);
 int rfx_launch_gemm_fwd_bf16(const FwdArgs& g, int r, dim3 grid, hipStream_t s);

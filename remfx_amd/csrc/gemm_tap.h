@@ -403,17 +403,13 @@ static int rfx_launch_gemm_tap_variant(const FwdArgs& g, int r, dim3 grid, hipSt
   return 0;
 }
 int rfx_launch_gemm_tap_in16(const FwdArgs& g, int r, dim3 grid, hipStream_t s);   // bf16 operand storage: gemm_fwd_bf16_in16.hip
-int rfx_launch_gemm_tap_cl(const FwdArgs& g, int r, dim3 grid, hipStream_t s);     // channels-last bf16 probe: gemm_fwd_bf16_cl.hip
 
 template <int MODE>
 static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s) {
-  if (g.d.in_bf16 == 3) return MODE == 2 ? rfx_launch_gemm_tap_cl(g, r, grid, s) : -1;
+  if (g.d.in_bf16 == 3) return -1;      // channels-last operand: template branch kept for the layout probe, not instantiated
   if (g.d.in_bf16) return (MODE == 2 && g.d.in_bf16 == 1) ? rfx_launch_gemm_tap_in16(g, r, grid, s) : -1;
   // short single-phase reductions with enough position tiles to keep persistent workgroups busy: streaming kernel
-  static const int stream_off = getenv("RFX_GEMM_STREAM") ? !atoi(getenv("RFX_GEMM_STREAM")) : 0;   // RFX_GEMM_STREAM=0: A/B switch
-  const int64_t work = (int64_t)((g.d.OA * g.d.OB + 127) / 128) * g.d.N;
-  if (!stream_off && g.d.Kpad_t <= 64 && g.apack2 == nullptr && work >= 4096 && r == 1 && g.e.act == RFX_ACT_NONE &&
-      g.e.act2 == RFX_ACT_NONE && !g.e.bwd && g.d.mg_log == 0 && !g.e.res) {
+  if (rfx_tap_use_stream(g.d, g.e, g.apack2 != nullptr, r)) {
     const int mtiles = g.d.Mpad / 32;
     int nw = (512 / mtiles) & ~7;                                // persistent workgroups per channel tile (2 per CU in all),
     nw = nw < 8 ? 8 : nw;                                        // a multiple of 8: one walk per XCD slot (kernel's block order)

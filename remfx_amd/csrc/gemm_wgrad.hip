@@ -217,18 +217,16 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     return 0;
   }
   // wide-load kernel (gemm_wgrad.h): both operands contiguous and unit-stride along b, quads never straddle an output row
-  static const int wide_off = getenv("RFX_WGRAD_WIDE") ? !atoi(getenv("RFX_WGRAD_WIDE")) : 0;     // RFX_WGRAD_WIDE=0: A/B switch
   const int64_t g_span = ((int64_t)(d->M - 1) * llabs(d->out_cs) + ((int64_t)(d->OA - 1) * d->out_sa + d->out_a0) * llabs(d->out_as) +
                           (d->OB - 1 + d->out_b0) + 1) * (d->out_bf16 ? 2 : 4);
-  if (prec != 0 && !wide_off && d->SB == 1 && d->in_bs == 1 && d->out_bs == 1 && d->out_sb == 1 &&
+  if (prec != 0 && d->SB == 1 && d->in_bs == 1 && d->out_bs == 1 && d->out_sb == 1 &&
       (d->OA == 1 || d->OB % 4 == 0) && d->in_extent > 0 && d->in_extent <= 0x7fffffffLL && g_span <= 0x7fffffffLL &&
       d->out_cs >= 0 && d->out_as >= 0) {
     w.in_bytes = (uint32_t)d->in_extent; w.g_bytes = (uint32_t)g_span;
     const bool r96 = d->M > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;
     // 96 x 256 tiles (bf16 mode: the hi + lo images of the split mode would need 101 KB of LDS) when K has >= 2 of them:
     // twice the MFMA work per staged element and half the re-reads of g
-    static const int wide256 = getenv("RFX_WGRAD_256") ? atoi(getenv("RFX_WGRAD_256")) : 1;
-    const int shape = r96 ? ((prec == 2 && wide256 && d->K > 256) ? 5 : 0) : d->M <= 32 ? (d->K > 128 ? 1 : 2) : d->M > 64 ? 3 : 4;
+    const int shape = r96 ? ((prec == 2 && d->K > 256) ? 5 : 0) : d->M <= 32 ? (d->K > 128 ? 1 : 2) : d->M > 64 ? 3 : 4;
     const int rm = (shape == 0 || shape == 5) ? 96 : shape <= 2 ? 32 : shape == 3 ? 128 : 64;
     const int rk = (shape == 1 || shape == 5) ? 256 : 128;
     const int mt = (d->M + rm - 1) / rm, kt = (d->K + rk - 1) / rk;
@@ -241,9 +239,8 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     splits = (chunks + w.tiles_per_block - 1) / w.tiles_per_block;
     w.kt = kt; w.mt = mt; w.splits = splits;
     // every (k, m) tile of a position split re-reads the same g rows / input rows: group them behind one L2
-    // (measured on the Demucs B=64 step, bf16: 44.3 -> 40.2 ms of weight-gradient launches; RFX_WGRAD_XCD=0 turns it off)
-    static const int xcd_wide = getenv("RFX_WGRAD_XCD") ? atoi(getenv("RFX_WGRAD_XCD")) : 8;
-    w.xcd_grouped = xcd_wide > 0 && splits >= xcd_wide;
+    // (measured on the Demucs B=64 step, bf16: 44.3 -> 40.2 ms of weight-gradient launches)
+    w.xcd_grouped = splits >= 8;
     dim3 grid = w.xcd_grouped ? dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1) : dim3(kt, mt, splits);
     return prec == 1 ? rfx_launch_wgrad_wide_bf3(w, shape, grid, s) : rfx_launch_wgrad_wide_bf16(w, shape, grid, s);
   }
@@ -267,11 +264,7 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   dim3 grid(kt, mt, splits);
   w.xcd_grouped = 0;
   if (prec != 0) {
-    static const int xcd_mode = getenv("RFX_WGRAD_XCD") ? atoi(getenv("RFX_WGRAD_XCD")) : 0;   // measured on Demucs B=64: 408.0 ms off, 411.8 ms on
-    if (xcd_mode > 0 && splits >= xcd_mode) {
-      w.xcd_grouped = 1;
-      grid = dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1);
-    }
+    // (XCD-grouped block order measured slower for this staging: Demucs B=64 408.0 ms off, 411.8 ms on -- not used here)
     const int shape = rows96 ? 0 : (narrow && tk == 2) ? 1 : narrow ? 2 : (tm == 2 && tk == 2) ? 3 : tm == 2 ? 4 : tk == 2 ? 5 : 6;
     return prec == 1 ? rfx_launch_wgrad_bf3(w, shape, grid, s) : rfx_launch_wgrad_bf16(w, shape, grid, s);
   }

@@ -580,10 +580,8 @@ extern "C" int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
   if (prec == RFX_PREC_BF16) {                 // bf16 operands (bf16-mixed): no lo fragments
     // H = 192: the wave's whole W_hh slice (48 fragments = 192 VGPRs) stays in registers instead of being re-streamed through L1
-    // every time step (RFX_LSTM_RESIDENT=0: 4-k-step ring)
-    static const int resident = getenv("RFX_LSTM_RESIDENT") ? atoi(getenv("RFX_LSTM_RESIDENT")) : 1;
-    if (H == 192 && resident) return lstm_launch(lstm_fwd_kernel<12, 12, false>, a, ws, stream);
-    if (H == 192) return lstm_launch(lstm_fwd_kernel<4, 12, false>, a, ws, stream);
+    // every time step
+    if (H == 192) return lstm_launch(lstm_fwd_kernel<12, 12, false>, a, ws, stream);
     if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16, false>, a, ws, stream);
     if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24, false>, a, ws, stream);
     return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0, false>, a, ws, stream)
@@ -606,9 +604,8 @@ extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* ga
   // (the unrolled NWC forms of the backward kernel spill at 512 registers: only the runtime form is instantiated)
   if (prec == RFX_PREC_BF16) {
     // single-fragment products halve the weight ring: the unrolled forms (exact wait counts instead of a vmcnt(0) drain at the loop
-    // header) fit the register file here for H = 192 (H = 384 still spills 364 B; RFX_LSTM_BWD_UNROLL=0: runtime loop)
-    static const int unroll = getenv("RFX_LSTM_BWD_UNROLL") ? atoi(getenv("RFX_LSTM_BWD_UNROLL")) : 1;
-    if (unroll && H == 192) return lstm_launch(lstm_bwd_kernel<2, 6, false>, a, ws, stream);
+    // header) fit the register file here for H = 192 (H = 384 still spills 364 B: runtime loop)
+    if (H == 192) return lstm_launch(lstm_bwd_kernel<2, 6, false>, a, ws, stream);
     return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, false>, a, ws, stream)
                              : lstm_launch(lstm_bwd_kernel<1, 0, false>, a, ws, stream);
   }

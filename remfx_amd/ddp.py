@@ -55,6 +55,7 @@ class GradSync:
         self.flat = flat
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.handles = []
+        self._stall = []                # (event before the waits, event after) per step on the compute stream
         self.overlap = overlap and self.world > 1
         # buckets over the flat buffer in REVERSE parameter order (backward produces the last
         # layers' gradients first); boundaries fall on parameter boundaries
@@ -93,12 +94,27 @@ class GradSync:
         for b in self.buckets:
             if not self.overlap or b["ready"] != b["n"]:
                 self._launch(b)       # parameters without a gradient this step never fire their hook
+        timed = self.flat.grad.is_cuda
+        if timed:                     # GPU time the compute stream spends stalled on the collectives = what backward did not hide
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self.handles:
             h.wait()
+        if timed:
+            e1.record()
+            self._stall.append((e0, e1))
         self.handles = []
         for b in self.buckets:
             b["ready"] = 0
         return 1.0 / self.world       # fold the mean into the optimiser's gradient scale
+
+
+    def exposed_ms(self):
+        """Total ms the compute stream waited on gradient all-reduces so far (synchronises; measurement only)."""
+        if not self._stall:
+            return 0.0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self._stall))
 
 
 def all_reduce_mean_scalar(t):

@@ -19,7 +19,7 @@ PREC_NAMES = {"f32": 0, "bf16x3": 1, "bf16": 2}
 GEMM_PREC = PREC_NAMES[_os.environ.get("RFX_GEMM_PREC", "f32")]
 
 
-BF16_STORE = _os.environ.get("RFX_BF16_STORE", "1") != "0"      # RFX_BF16_STORE=0: fp32 storage everywhere (A/B switch)
+BF16_STORE = True      # tests flip it to compare 16-bit storage with fp32 storage bit for bit
 
 
 def bf16_storage():
@@ -53,6 +53,9 @@ class at_least_fp32_parity:
         global GEMM_PREC
         GEMM_PREC = self.prev
         return False
+
+
+TRACE_VARIANT = None          # bench.py sets this to a list: gemm_fwd appends rfx_gemm_fwd_variant() of every launch
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "tanh": 3, "prelu": 4, "leaky": 5, "sigmoid": 6}
@@ -180,6 +183,8 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
     desc = dp.desc_for(x, out)
     if dp2 is not None and prec:
         desc.gpt2 = int(dp2.p.gpt)
+    if TRACE_VARIANT is not None:               # measurement hook (bench.py): which kernel instantiation this launch is
+        TRACE_VARIANT.append(_lib.lib().rfx_gemm_fwd_variant(C.byref(desc), C.byref(e), int(dp2 is not None), prec))
     check(_lib.lib().rfx_gemm_fwd(C.byref(desc), _ptr(apack), _ptr(tab), _ptr(x), _ptr(out),
                                   C.byref(e), a2, k2, K2, Kpad2, _ptr(in2), prec, _stream()),
           "rfx_gemm_fwd")

@@ -118,7 +118,8 @@ def test_detector_labels_full_length_bit_exact():
     margin = np.abs(ref - 0.5).min()
     assert (ref > 0.5).any() and (ref <= 0.5).any(), "degenerate case: all labels equal"
     # probabilities: the stretched heads amplify the fp32 feature noise by ~2 / (logit spread) ~ 100-400x
-    assert np.abs(out - ref).max() < 5e-3, np.abs(out - ref).max()
+    # (measured: 6e-3 with the 2^-17 products of bf16x3, which is what a bf16 session's detector runs in)
+    assert np.abs(out - ref).max() < tol(5e-3, bf16x3=3e-2, bf16=3e-2), np.abs(out - ref).max()
     assert np.array_equal(out > 0.5, ref > 0.5), (margin, np.abs(out - ref).max())
 
 def test_cnn14_train_step_vs_oracle():
