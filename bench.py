@@ -406,6 +406,8 @@ def main():
                     choices=["demucs", "tcn", "dcunet", "umx", "chain", "demucs_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sink", default="side", choices=["side", "main", "off"],
+                    help="parameter-gradient sink (ops.GradSink) A/B: side stream (default) / compute stream / autograd accumulation")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (bf16x3 step + Demucs forward sub-metric)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch plan / algorithmic work / event time list of the timed steps (JSON)")
     ap.add_argument("--union-ranks", type=int, default=0,
@@ -427,6 +429,7 @@ def main():
 
     from remfx_amd import ddp, ops
     ops.set_gemm_precision(args.gemm)
+    ops.GradSink.MODE = args.sink
     rank, local, world = ddp.init_from_env()
     assert world == args.gpus or world == 1, (world, args.gpus)
     torch.cuda.set_device(local)

@@ -72,9 +72,18 @@ class GradSync:
                 for i in cur_params:
                     self.bucket_of[i] = b
                 hi, cur_params = cur_lo, []
+        # gradients reach the flat buffer two ways: autograd's accumulation (post-accumulate hook, once per parameter and
+        # step) and the gradient sink (ops.GradSink: kernels accumulate in place, once per USE of the parameter).  The first
+        # step only counts the sink's writes per parameter (no early launches); from then on a bucket is complete when every
+        # parameter has been written as often as in that calibration step.
+        self.sink = getattr(flat, "sink", None)
+        self.expected = None                        # sink writes per parameter in one step, learned in step 1
+        self._seen = [0] * len(flat.params)
         if self.overlap:
             for idx, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(idx))
+            if self.sink is not None:
+                self.sink.on_write = self._sink_write
 
     def _make_hook(self, idx):
         def hook(_p):
@@ -84,16 +93,34 @@ class GradSync:
                 self._launch(b)
         return hook
 
+    def _sink_write(self, idx):
+        self._seen[idx] += 1
+        if self.expected is None:
+            return                                   # calibration step: finish() launches everything
+        if self._seen[idx] == self.expected[idx]:
+            self._make_hook(idx)(None)
+
     def _launch(self, b):
-        self.handles.append(dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, async_op=True))
+        if b.get("launched"):
+            return
+        b["launched"] = True
+        sl = self.flat.grad[b["lo"]:b["hi"]]
+        side = self.sink.side if (self.sink is not None and sl.is_cuda) else None
+        if side is not None:
+            # the bucket's gradients come from the compute stream AND the sink's side stream: order the collective after both
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+            self.sink.used_side = True
+        else:
+            self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """Call after backward: launch whatever has not been reduced yet, wait, reset."""
         if self.world == 1:
             return 1.0
         for b in self.buckets:
-            if not self.overlap or b["ready"] != b["n"]:
-                self._launch(b)       # parameters without a gradient this step never fire their hook
+            self._launch(b)           # whatever the hooks have not launched (parameters without a gradient never fire theirs)
         timed = self.flat.grad.is_cuda
         if timed:                     # GPU time the compute stream spends stalled on the collectives = what backward did not hide
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -104,8 +131,16 @@ class GradSync:
             e1.record()
             self._stall.append((e0, e1))
         self.handles = []
+        self.flat.join() if hasattr(self.flat, "join") else None
         for b in self.buckets:
             b["ready"] = 0
+            b["launched"] = False
+        if self.sink is not None:
+            if self.expected is None:
+                self.expected = list(self._seen)
+            elif self._seen != self.expected:        # the graph changed: re-calibrate (one step without early launches)
+                self.expected = None
+            self._seen = [0] * len(self.flat.params)
         return 1.0 / self.world       # fold the mean into the optimiser's gradient scale
 
 

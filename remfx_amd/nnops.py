@@ -67,14 +67,31 @@ class _GroupNormFn(torch.autograd.Function):
         N, Cc, S, groups, mode = ctx.cfg
         gy = gy.contiguous()
         dx = torch.empty_like(x)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
-        dscale = torch.empty_like(scale) if mode == 3 else None
+        # parameter gradients: straight into the flat gradient buffer when a GradSink is armed and this is the parameter's first
+        # gradient of the step (the kernel SETS its outputs); otherwise fresh tensors for autograd's accumulation
+        sink = ops.SINK
+        tg = tb = ts = None
+        if sink is not None:
+            tg, tb = sink.lookup(gamma), sink.lookup(beta)
+            ts = sink.lookup(scale) if mode == 3 else None
+            ok = (tg is not None and tb is not None and (mode != 3 or ts is not None) and
+                  all(sink.writes[t[0]] == 0 for t in (tg, tb, ts) if t is not None))
+            if not ok:
+                tg = tb = ts = None
+        dgamma = tg[1] if tg else torch.empty_like(gamma)
+        dbeta = tb[1] if tb else torch.empty_like(beta)
+        dscale = (ts[1] if ts else torch.empty_like(scale)) if mode == 3 else None
         gsum = torch.empty(N * Cc * 2 + N * (Cc // 2) + N * groups * 2, device=x.device, dtype=torch.float32)
         bwd = _lib.lib().rfx_groupnorm_bwd_x16 if x.dtype == torch.bfloat16 else _lib.lib().rfx_groupnorm_bwd
         check(bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gy),
                   N, Cc, S, groups, mode, _ptr(scale), _ptr(gsum), _ptr(dx),
                   _ptr(dgamma), _ptr(dbeta), _ptr(dscale), _stream()),
               "rfx_groupnorm_bwd")
+        if tg:
+            for t in (tg, tb, ts):
+                if t is not None:
+                    sink.wrote(t[0])
+            return dx, None, None, None, None, None, (gy if mode == 3 else None), None, None
         return dx, dgamma, dbeta, None, None, None, (gy if mode == 3 else None), dscale, None
 
 

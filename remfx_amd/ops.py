@@ -55,6 +55,70 @@ class at_least_fp32_parity:
         return False
 
 
+class GradSink:
+    """Where the backward kernels put PARAMETER gradients when the parameters live in an optim.FlatParams buffer: straight
+    into the parameter's slice of the flat gradient buffer (accumulating: the buffer is zeroed once per step), instead of
+    returning a fresh tensor that autograd then adds into `.grad` with one small launch per parameter (322 launches per Demucs
+    step).  Weight-gradient GEMMs additionally run on a SIDE stream: nothing in the backward chain depends on them, so they
+    fill the machine under the latency-bound kernels of the main stream (LSTM recurrence, FFT, small layers); the optimiser
+    (FlatAdamW.step) and the gradient exchange (ddp.GradSync) join the side stream before they read the buffer.
+
+    Armed by FlatParams.zero_grad(), joined / disarmed by FlatParams.join().  A weight is recognised by its storage address:
+    the tensor a backward node saved must start where a parameter's view of the flat buffer starts, be contiguous and have the
+    parameter's size (`w.unsqueeze(2)` of a Conv1d weight qualifies, a transposed or concatenated weight does not and takes the
+    ordinary autograd route)."""
+
+    MODE = "side"      # "side": weight gradients on a side stream; "main": in place on the compute stream; "off": autograd accumulation
+
+    def __init__(self, flat, side_stream=True):
+        self.flat = flat
+        self.base = flat.data.data_ptr()
+        self.index = {self.base + 4 * o: i for i, o in enumerate(flat.offsets)}
+        dev = flat.data.device
+        self.side = torch.cuda.Stream(device=dev) if (side_stream and dev.type == "cuda") else None
+        self.used_side = False
+        self.writes = [0] * len(flat.params)         # sink writes per parameter in the current step
+        self.on_write = None                           # ddp.GradSync: called with the parameter index after each write
+
+    def lookup(self, w):
+        """(index, 1-D gradient view) of the parameter `w` is, or None."""
+        if w is None or not w.is_cuda:
+            return None
+        i = self.index.get(w.data_ptr())
+        if i is None:
+            return None
+        p = self.flat.params[i]
+        if w.numel() != p.numel() or not w.is_contiguous() or w.dtype != torch.float32:
+            return None
+        o = self.flat.offsets[i]
+        return i, self.flat.grad[o:o + p.numel()]
+
+    def wrote(self, i):
+        self.writes[i] += 1
+        if self.on_write is not None:
+            self.on_write(i)
+
+    def stream_for_wgrad(self, *operands):
+        """The stream weight-gradient work goes to (ordered after everything already on the current stream).  The operands were
+        allocated on the current stream: tell the caching allocator the side stream uses them too."""
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            return main
+        self.side.wait_stream(main)
+        for t in operands:
+            if t is not None:
+                t.record_stream(self.side)
+        self.used_side = True
+        return self.side
+
+    def join(self):
+        """Current stream waits for every queued weight gradient."""
+        if self.side is not None and self.used_side:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.used_side = False
+
+
+SINK = None                   # the armed GradSink (optim.FlatParams.zero_grad arms, .join disarms)
 TRACE_VARIANT = None          # bench.py sets this to a list: gemm_fwd appends rfx_gemm_fwd_variant() of every launch
 
 
@@ -296,11 +360,28 @@ def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None, res
     return dx
 
 
-def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias):
+def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias, w=None, b=None):
+    """w, b: the weight / bias tensors of the forward call (as the backward node saved them).  With a GradSink armed and both
+    recognised as flat-buffer parameters the gradients are accumulated in place on the sink's side stream and (None, None) is
+    returned; otherwise (dw, db) as fresh tensors for autograd."""
     key = _key("cw", x.shape, x.stride(), wshape, stride, padding, dilation, g.stride(), need_bias)
     dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
         tuple(x.shape), x.stride(), tuple(wshape), stride, padding, dilation, g.stride(), bias_row=need_bias))
     p = dp.p
+    sink = SINK
+    tw = sink.lookup(w) if (sink is not None and w is not None) else None
+    tb = sink.lookup(b) if (tw is not None and need_bias) else None
+    if tw is not None and (tb is not None or not need_bias):
+        with torch.cuda.stream(sink.stream_for_wgrad(x, g)):
+            dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
+            gemm_wgrad(dp, x, g, dapack)
+            unpack_add(dp, dapack, tw[1])                      # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
+            if need_bias:
+                tb[1].add_(dapack[:, p.K - 1])
+        sink.wrote(tw[0])
+        if need_bias:
+            sink.wrote(tb[0])
+        return None, None
     dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
     gemm_wgrad(dp, x, g, dapack)
     dw = torch.empty(wshape, device=x.device, dtype=torch.float32)
@@ -315,6 +396,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, dilation, stat_sums=None, out_bf16=False):
         ctx.save_for_backward(x, w)
+        ctx.bias = bias                                   # identity only (GradSink lookup); never read
         ctx.cfg = (stride, padding, dilation, bias is not None)
         return conv2d_forward(x, w, bias, stride, padding, dilation, stat_sums=stat_sums, out_bf16=out_bf16)
 
@@ -327,7 +409,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(g, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
+            dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias, w, ctx.bias)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -340,6 +422,7 @@ class ConvFork2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, dilation, stat_sums=None, out_bf16=False):
         ctx.save_for_backward(x, w)
+        ctx.bias = bias
         ctx.cfg = (stride, padding, dilation, bias is not None)
         return conv2d_forward(x, w, bias, stride, padding, dilation, stat_sums=stat_sums, out_bf16=out_bf16), x.view_as(x)
 
@@ -352,7 +435,7 @@ class ConvFork2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(g, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation, res=gres)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias)
+            dw, db = conv2d_wgrad(x, g, tuple(w.shape), stride, padding, dilation, has_bias, w, ctx.bias)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -381,6 +464,7 @@ class ConvGlu2dFn(torch.autograd.Function):
         wi = w.view(2, Ch, Cin, KA, KB).transpose(0, 1).reshape(C2, Cin, KA, KB)     # rows (c, half)
         gemm_fwd(dp, pack_a(dp, wi), x, y2, bias=bias, glu_out=out)
         ctx.save_for_backward(x, w, y2)
+        ctx.bias = bias
         ctx.cfg = (stride, padding, dilation, bias is not None)
         return out
 
@@ -399,7 +483,7 @@ class ConvGlu2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv2d_dgrad(g2, w, tuple(x.shape), tuple(x.stride()), stride, padding, dilation)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv2d_wgrad(x, g2, tuple(w.shape), stride, padding, dilation, has_bias)
+            dw, db = conv2d_wgrad(x, g2, tuple(w.shape), stride, padding, dilation, has_bias, w, ctx.bias)
         return dx, dw, db, None, None, None
 
 

@@ -36,12 +36,32 @@ class FlatParams:
             v.copy_(p.data)
             p.data = v
             p.grad = self.grad[o:o + p.numel()].view_as(p)
+        from . import ops
+        self.sink = None                                                   # see ops.GradSink
+        if dev.type == "cuda" and ops.GradSink.MODE != "off":
+            self.sink = ops.GradSink(self, side_stream=ops.GradSink.MODE == "side")
 
     def zero_grad(self):
+        """One fill of the flat gradient buffer; arms the gradient sink: until join() the backward kernels accumulate
+        parameter gradients straight into this buffer (weight-gradient GEMMs on the sink's side stream)."""
+        self.join()
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):      # re-seat in case something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+        if self.sink is not None:
+            from . import ops
+            self.sink.writes = [0] * len(self.params)
+            ops.SINK = self.sink
+
+    def join(self):
+        """Make the current stream wait for every gradient the sink still has in flight and disarm it.  Called by the
+        optimiser step and the gradient exchange; call it before reading `.grad` by hand after a backward pass."""
+        if self.sink is not None:
+            from . import ops
+            self.sink.join()
+            if ops.SINK is self.sink:
+                ops.SINK = None
 
 
 class FlatAdamW:
@@ -62,6 +82,7 @@ class FlatAdamW:
         """One update.  clip_norm: global L2 norm clip (Lightning gradient_clip_val);
         grad_prescale: factor already owed to the gradients (1/world_size after a SUM all-reduce)."""
         L, f = _lib.lib(), self.flat
+        f.join()                                         # side-stream weight gradients land before the buffer is read
         self.step_count += 1
         gscale = None
         if clip_norm or grad_prescale != 1.0:

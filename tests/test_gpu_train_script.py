@@ -100,3 +100,42 @@ def test_train_script_demucs_bf16_mixed_config3(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     ck2 = torch.load(os.path.join(tmp_path, "ckpts", "last.ckpt"), map_location="cpu", weights_only=False)
     assert ck2["global_step"] == 3 and float(ck2["optimizer_states"][0]["state"][0]["step"]) == 3.0      # one more step, not three
+
+
+def test_gradient_sink_matches_autograd_accumulation():
+    """Parameter gradients written straight into the flat gradient buffer (ops.GradSink: conv weight / bias gradients on
+    the side stream, GroupNorm / LayerScale gradients by their kernels) equal the gradients autograd's accumulation
+    produces for the same network, input and upstream gradient -- on a small Hybrid Demucs, whose backward reaches every
+    kind of sink (conv, fork-conv, GLU-conv, DConv GroupNorms, LSTM / attention projections)."""
+    from remfx_amd import ops
+    from remfx_amd.hdemucs import HDemucs
+    from remfx_amd.optim import FlatParams
+    torch.manual_seed(5)
+    net = HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=8).to(DEV)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith(".scale"):
+                p.fill_(0.3)
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(2, 1, 20000, generator=g) * 0.5).to(DEV)
+    gy = torch.randn(2, 1, 1, 20000, generator=g).to(DEV)
+    net(x).backward(gy)                                           # plain autograd accumulation
+    ref = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    flat = FlatParams(list(net.parameters()))
+    assert flat.sink is not None
+    for rep in range(2):                                          # twice: the buffer is re-zeroed, the sink re-armed
+        flat.zero_grad()
+        assert ops.SINK is flat.sink
+        net(x).backward(gy)
+        nsunk = sum(1 for w in flat.sink.writes if w)
+        flat.join()
+        assert ops.SINK is None
+        torch.cuda.synchronize()
+        assert nsunk > 100, nsunk                                 # most of the 397 tensors go through the sink
+        num = den = 0.0
+        for n, p in net.named_parameters():
+            if n in ref:
+                d = float((p.grad - ref[n]).double().pow(2).sum())
+                num += d; den += float(ref[n].double().pow(2).sum())
+                assert d ** 0.5 <= 1e-4 * max(1e-6, float(ref[n].abs().max())) * ref[n].numel() ** 0.5, n
+        assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5       # fp32 atomics order noise only
