@@ -316,6 +316,30 @@ int rfx_localstate_gen_bwd(const float* q, const float* k, const float* cont, co
                            const float* gout, int32_t B, int32_t heads, int32_t ch, int32_t T, int32_t nd, float* dq, float* dk,
                            float* dcont, float* dqd, void* stream);
 
+/* ---- audio-effect rendering on the device ---------------------------------------------------------------
+ * The reference renders its training effects on the CPU with pedalboard (JUCE DSP) and normalises loudness with pyloudnorm
+ * after every effect: remfx/effects.py:297-616 (RandomPedalboard{Distortion, Delay, Chorus, Compressor, Reverb}.forward),
+ * :619-629 (LoudnessNormalize), called from remfx/datasets.py:109-202 (parallel_process_effects) and :205-330
+ * (DynamicEffectDataset.process_effects).  x, y: (B, T) fp32 contiguous mono clips; every parameter is a B-vector on the device
+ * (each clip draws its own).  y may alias x except for rfx_fx_delay.  Algorithms: csrc/fx.hip; oracle/ref_effects.py. */
+int rfx_fx_distortion(const float* x, float* y, int32_t B, int64_t T, const float* gain /* 10^(drive_db / 20) */, void* stream);
+int rfx_fx_delay(const float* x, float* y, int32_t B, int64_t T, const int32_t* delay_samples, const float* feedback,
+                 const float* mix, void* stream);
+int rfx_fx_chorus(const float* x, float* y, int32_t B, int64_t T, float sample_rate, const float* rate_hz, const float* depth,
+                  const float* centre_delay_ms, const float* feedback, const float* mix, void* stream);
+int rfx_fx_compressor(const float* x, float* y, float* env_ws /* (B, T) workspace */, int32_t B, int64_t T,
+                      const float* threshold_lin, const float* ratio, const float* c_attack, const float* c_release, void* stream);
+int rfx_fx_reverb(const float* x, float* y, int32_t B, int64_t T, int32_t sample_rate, const float* damp, const float* feedback,
+                  const float* wet1, const float* dry, void* stream);
+/* BS.1770 integrated loudness (pyloudnorm.Meter.integrated_loudness, K-weighting, 400 ms blocks at 75 % overlap, absolute and
+ * relative gates) and the LoudnessNormalize gain 10^(clamp(target - L, -120, 40) / 20) per clip.  coef: 28 HOST doubles = the two
+ * normalised biquads b1[3] a1[3] b2[3] a2[3] and the 4 x 4 zero-input state transition of `chunk` samples (row-major);
+ * chunk * 64 >= T; hop_len = samples per 100 ms; nblk gating blocks over nhop >= nblk + 3 hops; inv_block = 1 / (0.4 * rate);
+ * hop_ws: B * nhop doubles.  Outputs lufs[B], gain[B]; apply the gain with rfx_fx_scale. */
+int rfx_fx_loudness(const float* x, int32_t B, int64_t T, int32_t chunk, int32_t hop_len, int32_t nhop, int32_t nblk,
+                    double inv_block, const double* coef, float target_lufs, double* hop_ws, float* lufs, float* gain, void* stream);
+int rfx_fx_scale(const float* x, float* y, int32_t B, int64_t T, const float* gain, void* stream);
+
 /* Label of the kernel instantiation rfx_gemm_fwd would launch (measurement only; see csrc/gemm.hip). */
 int rfx_gemm_fwd_variant(const rfx_gemm_desc* d, const rfx_epilogue* epi, int32_t two_phase, int32_t prec);
 

@@ -141,6 +141,13 @@ SIGNATURES = {
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_fx_distortion": [_P, _P, _I32, _I64, _P, _P],
+    "rfx_fx_delay": [_P, _P, _I32, _I64, _P, _P, _P, _P],
+    "rfx_fx_chorus": [_P, _P, _I32, _I64, C.c_float, _P, _P, _P, _P, _P, _P],
+    "rfx_fx_compressor": [_P, _P, _P, _I32, _I64, _P, _P, _P, _P, _P],
+    "rfx_fx_reverb": [_P, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P],
+    "rfx_fx_loudness": [_P, _I32, _I64, _I32, _I32, _I32, _I32, C.c_double, _P, C.c_float, _P, _P, _P, _P],
+    "rfx_fx_scale": [_P, _P, _I32, _I64, _P, _P],
     "rfx_localstate_gen_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_gen_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_localstate_mfma_ok": [_I32, _I32, _I32, _I32, _I32],

@@ -83,6 +83,92 @@ def spec_augment(x, freq_mask_param, time_mask_param):
     return y
 
 
+class _HearClassifier(nn.Module):
+    """The HEAR-embedding classifiers of reference remfx/classifier.py:16-128 (PANNs, Wav2CLIP, VGGish, wav2vec2): a FROZEN
+    pretrained scene-embedding model behind the HEAR API (`load_model`, `get_scene_embeddings(audio (B, T) at the model's rate)
+    -> (B, D)`), fed the clip resampled to the model's rate, and a trainable three-layer MLP head `proj` that emits the
+    (B, num_classes) logits FXClassifier trains with cross-entropy (models.py:457-476).
+
+    What runs where: the resampling is the device-side polyphase kernel and the head is three gather-GEMM launches with fused
+    ReLU; the embedding model is third-party pretrained code (hearbaseline / wav2clip_hear / panns_hear, weights downloaded by
+    those packages) and runs as the package provides it, under no_grad, exactly as upstream.  None of the packages ships in
+    this image, so the constructor raises ImportError unless an `embedder` is passed: any object with
+    `get_scene_embeddings(audio) -> (B, embed_dim)` (or a plain callable) -- the hook tests use and the place to plug a
+    locally available model.  Same constructor arguments and `proj.{0,2,4}.{weight,bias}` state_dict keys as upstream."""
+
+    embed_dim, model_rate, package = 0, 16000, ""
+
+    def __init__(self, num_classes: int, sample_rate: float, hidden_dim: int = 256, embedder=None) -> None:
+        super().__init__()
+        self.num_classes = num_classes
+        self._from_package = embedder is None
+        self.model = embedder if embedder is not None else self._load_model()
+        if isinstance(self.model, nn.Module):               # frozen upstream by the no_grad around it: say so to the optimiser
+            for p in self.model.parameters():               # (torch's AdamW skips parameters without a gradient; the flat
+                p.requires_grad_(False)                     # optimiser takes every trainable one)
+        from .resample import Resample
+        self.resample = Resample(orig_freq=sample_rate, new_freq=self.model_rate)
+        self.proj = nn.Sequential(nn.Linear(self.embed_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, hidden_dim), nn.ReLU(),
+                                  nn.Linear(hidden_dim, num_classes))
+
+    def _load_model(self):
+        raise NotImplementedError
+
+    def _package(self):
+        import importlib
+        try:
+            return importlib.import_module(self.package)
+        except ImportError as e:
+            raise ImportError(f"{type(self).__name__} needs the pretrained HEAR embedding package `{self.package}` (reference "
+                              "remfx/classifier.py:4-9), which is not installed; install it or pass embedder=<object with "
+                              "get_scene_embeddings(audio)>") from e
+
+    def _embed(self, audio):
+        if self._from_package:                              # <package>.get_scene_embeddings(audio, model), as upstream
+            return self._package().get_scene_embeddings(audio, self.model)
+        m = self.model
+        return m.get_scene_embeddings(audio) if hasattr(m, "get_scene_embeddings") else m(audio)
+
+    def forward(self, x: torch.Tensor, **kwargs):
+        with torch.no_grad():
+            x = self.resample(x)
+            embed = self._embed(x.reshape(x.shape[0], -1))
+        if embed.shape[-1] != self.embed_dim:
+            raise ValueError(f"{type(self).__name__}: embedding width {embed.shape[-1]} != {self.embed_dim}")
+        h = embed.float()
+        for i in (0, 2):
+            h = ops.activation(nnops.linear(h, self.proj[i].weight, self.proj[i].bias), "relu")
+        return nnops.linear(h, self.proj[4].weight, self.proj[4].bias)
+
+
+class PANNs(_HearClassifier):                           # classifier.py:16-40
+    embed_dim, model_rate, package = 2048, 32000, "panns_hear"
+
+    def _load_model(self):
+        return self._package().load_model("hear2021-panns_hear.pth")
+
+
+class Wav2CLIP(_HearClassifier):                        # classifier.py:43-69
+    embed_dim, model_rate, package = 512, 16000, "wav2clip_hear"
+
+    def _load_model(self):
+        return self._package().load_model("")
+
+
+class VGGish(_HearClassifier):                          # classifier.py:72-96
+    embed_dim, model_rate, package = 128, 16000, "hearbaseline.vggish"
+
+    def _load_model(self):
+        return self._package().load_model()
+
+
+class wav2vec2(_HearClassifier):                        # classifier.py:99-124
+    embed_dim, model_rate, package = 1024, 16000, "hearbaseline.wav2vec2"
+
+    def _load_model(self):
+        return self._package().load_model()
+
+
 class ConvBlock(nn.Module):
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -122,7 +208,11 @@ class Cnn14(nn.Module):
         self.fc1 = nn.Linear(2048, 2048, bias=True)
         self.heads = nn.ModuleList([nn.Linear(2048, 1, bias=True) for _ in range(num_classes)])
         self.init_weight()
-        # sample_rate != model_sample_rate: polyphase resampling on the device (classifier.py:180-183);
+        # sample_rate != model_sample_rate: polyphase resampling on the device (classifier.py:180-183); the transform's
+        # filter bank is a persistent buffer upstream (state_dict key `resample.kernel`), so it is one here
+        if sample_rate != model_sample_rate:
+            from .resample import Resample
+            self.resample = Resample(orig_freq=sample_rate, new_freq=model_sample_rate)
         # specaugment: iid frequency / time span masks in training only (classifier.py:185-187, 198-204)
         self.freq_mask_param, self.time_mask_param = 64, 128
 
@@ -140,8 +230,7 @@ class Cnn14(nn.Module):
 
     def _forward(self, x: torch.Tensor, train: bool):
         if self.sample_rate != self.model_sample_rate:
-            from .resample import resample
-            x = resample(x, self.sample_rate, self.model_sample_rate)
+            x = self.resample(x)
         x = self.melspec(x)                                                     # (B, 1, n_mels, frames)
         if self.specaugment and train:
             x = spec_augment(x, self.freq_mask_param, self.time_mask_param)

@@ -4,8 +4,10 @@
   * or seeded white noise when no corpus / rendered set is reachable (BASELINE.json's configs).
 
 What the hot path consumes is the batch tuple  (x_wet, y_dry, dry_labels, wet_labels)  with shapes
-(B,1,T), (B,1,T), (B,5), (B,5) (datasets.py:461-468).  RENDERING clips (pedalboard / sox / pyloudnorm on the
-CPU, datasets.py:399-452) is SURVEY 8(f) rank 3 and is not done here: a dataset that would have to render says so.
+(B,1,T), (B,1,T), (B,5), (B,5) (datasets.py:461-468).  RENDERING clips (pedalboard / pyloudnorm on the CPU in the
+reference, datasets.py:109-202, 267-318, 399-452) runs ON THE DEVICE here: `process_effects` applies the randomly chosen
+kept / removed effects and the in-between loudness normalisation through remfx_amd.effects (csrc/fx.hip), for
+`EffectDataset(render_files=True)` (writes the reference's layout) and `DynamicEffectDataset` (on-the-fly augmentation).
 
 The classes take the reference's constructor arguments, so ``cfg/config.yaml``'s datamodule node instantiates
 unchanged.  Multi-GPU: the loaders shard by rank with a DistributedSampler (what Lightning injects for the
@@ -50,6 +52,107 @@ def _usable_dir(p):
     return p is not None and "<unset env" not in str(p) and os.path.isdir(str(p))
 
 
+# split tables of the four corpora (datasets.py:20-50)
+vocalset_splits = {"train": ["male1", "male2", "male3", "male4", "male5", "male6", "male7", "male8", "male9", "female1",
+                             "female2", "female3", "female4", "female5", "female6", "female7"],
+                   "val": ["male10", "female8"], "test": ["male11", "female9"]}
+guitarset_splits = {"train": ["00", "01", "02", "03"], "val": ["04"], "test": ["05"]}
+dsd_100_splits = {"train": ["train"], "val": ["val"], "test": ["test"]}
+idmt_drums_splits = {"train": ["WaveDrum02", "TechnoDrum01"], "val": ["RealDrum01"], "test": ["TechnoDrum02", "WaveDrum01"]}
+
+
+def locate_files(root, mode):
+    """datasets.py:53-106: one sorted file list per corpus found under `root` (VocalSet1-2, audio_mono-mic = GuitarSet,
+    DSD100/DSD100, IDMT-SMT-DRUMS-V2), restricted to the split of `mode`."""
+    import glob
+    root, file_list = str(root), []
+    d = os.path.join(root, "VocalSet1-2")
+    if os.path.isdir(d):
+        files = []
+        for sd in glob.glob(os.path.join(d, "data_by_singer", "*")):
+            if os.path.basename(sd) in vocalset_splits[mode]:
+                files += glob.glob(os.path.join(sd, "**", "**", "*.wav"))
+        print(f"Found {len(files)} files in VocalSet {mode}.")
+        file_list.append(sorted(files))
+    d = os.path.join(root, "audio_mono-mic")
+    if os.path.isdir(d):
+        files = [f for f in glob.glob(os.path.join(d, "*.wav")) if os.path.basename(f).split("_")[0] in guitarset_splits[mode]]
+        print(f"Found {len(files)} files in GuitarSet {mode}.")
+        file_list.append(sorted(files))
+    d = os.path.join(root, "DSD100/DSD100")
+    if os.path.isdir(d):
+        files = glob.glob(os.path.join(d, mode, "**", "*.wav"), recursive=True)
+        file_list.append(sorted(files))
+        print(f"Found {len(files)} files in DSD100 {mode}.")
+    d = os.path.join(root, "IDMT-SMT-DRUMS-V2")
+    if os.path.isdir(d):
+        files = [f for f in glob.glob(os.path.join(d, "audio", "*.wav")) if os.path.basename(f).split("_")[0] in idmt_drums_splits[mode]]
+        file_list.append(sorted(files))
+        print(f"Found {len(files)} files in IDMT-SMT-Drums {mode}.")
+    return file_list
+
+
+def select_random_chunk(audio_file, chunk_size, sample_rate, device=None):
+    """utils.py:120-135: a random chunk of `chunk_size` samples AT `sample_rate` from a file (None when the file is too
+    short or the chunk is nearly silent); the resampling runs on the device (remfx_amd.resample)."""
+    audio, sr = load_wav(audio_file)
+    new_chunk_size = int(chunk_size * (sr / sample_rate))
+    if new_chunk_size >= audio.shape[-1]:
+        return None
+    max_len = audio.shape[-1] - new_chunk_size
+    random_start = torch.randint(0, max_len, (1,)).item()
+    chunk = audio[:, random_start:random_start + new_chunk_size]
+    if torch.mean(torch.abs(chunk)) < 1e-4:                     # skip if energy too low
+        return None
+    if device is not None:
+        chunk = chunk.to(device)
+    if sr != sample_rate:
+        from .resample import resample
+        chunk = resample(chunk, sr, sample_rate)
+    return chunk
+
+
+def process_effects(dry, effects, effects_to_keep, effects_to_remove, num_kept_effects, num_removed_effects,
+                    shuffle_kept_effects, shuffle_removed_effects, normalize):
+    """datasets.py:267-318 (= 139-191 of parallel_process_effects): random subset of the effects to keep applied to the dry
+    clip, random subset of the effects to remove applied on top for the wet clip, loudness normalisation after every effect
+    and at the end; the same random calls in the same order as the reference.  dry: (1, T) on the device.
+    Returns (normalized_dry, normalized_wet, dry_labels (5,), wet_labels (5,))."""
+    from .effects import Pedalboard_Effects as ALL_EFFECTS
+    idx = torch.randperm(len(effects_to_keep)) if shuffle_kept_effects else torch.arange(len(effects_to_keep))
+    r1, r2 = num_kept_effects[0], num_kept_effects[1]
+    n = torch.round((r1 - r2) * torch.rand(1) + r2).int()
+    dry_labels = []
+    for effect in [effects[effects_to_keep[i]] for i in idx[:n]]:
+        dry = normalize(effect(dry))                              # normalise in-between effects
+        dry_labels.append(ALL_EFFECTS.index(type(effect)))
+    idx = torch.randperm(len(effects_to_remove)) if shuffle_removed_effects else torch.arange(len(effects_to_remove))
+    wet = torch.clone(dry)
+    r1, r2 = num_removed_effects[0], num_removed_effects[1]
+    n = torch.round((r1 - r2) * torch.rand(1) + r2).int()
+    wet_labels = []
+    for effect in [effects[effects_to_remove[i]] for i in idx[:n]]:
+        wet = normalize(effect(wet))
+        wet_labels.append(ALL_EFFECTS.index(type(effect)))
+    wet_labels_tensor, dry_labels_tensor = torch.zeros(len(ALL_EFFECTS)), torch.zeros(len(ALL_EFFECTS))
+    for i in wet_labels:
+        wet_labels_tensor[i] = 1.0
+    for i in dry_labels:
+        dry_labels_tensor[i] = 1.0
+    return normalize(dry), normalize(wet), dry_labels_tensor, wet_labels_tensor
+
+
+def _random_chunk(files, chunk_size, sample_rate, device):
+    import random
+    chunk = None
+    corpus = random.choice(files)
+    while chunk is None:
+        chunk = select_random_chunk(random.choice(corpus), chunk_size, sample_rate, device)
+    if chunk.shape[0] > 1:                                       # sum to mono
+        chunk = chunk.sum(0, keepdim=True)
+    return chunk
+
+
 class SyntheticEffectDataset(Dataset):
     """Seeded white noise at the level the dataset normalises to (about -20 dB), random wet labels."""
 
@@ -73,14 +176,16 @@ class EffectDataset(Dataset):
     * rendered chunks under ``proc_root`` -> served from disk exactly like the reference's __getitem__;
     * no corpus (``root`` unset or missing: ``${oc.env:DATASET_ROOT}`` without the variable) -> the synthetic
       white-noise items of BASELINE.json's configs, ``total_chunks`` of them, with a one-time warning;
-    * a corpus that would have to be RENDERED -> NotImplementedError."""
+    * a corpus + ``render_files=True`` -> the chunks are RENDERED on the device (datasets.py:399-452: random chunk of a
+      random file, mono, `process_effects`, written as input.wav / target.wav / dry_effects.pt / wet_effects.pt); an
+      existing rendered set is wiped first, as upstream (which asks on stdin)."""
 
     _SEEDS = {"train": 12345, "val": 22345, "test": 32345}
 
     def __init__(self, root=None, sample_rate=48000, chunk_size=262144, total_chunks=1000, effect_modules=None,
                  effects_to_keep=None, effects_to_remove=None, num_kept_effects=(1, 5), num_removed_effects=(1, 5),
                  shuffle_kept_effects=True, shuffle_removed_effects=False, render_files=True, render_root=None,
-                 mode="train", parallel=False):
+                 mode="train", parallel=False, device=None):
         super().__init__()
         self.root, self.sample_rate, self.chunk_size, self.total_chunks = root, sample_rate, chunk_size, total_chunks
         self.mode, self.effects = mode, effect_modules or {}
@@ -96,18 +201,46 @@ class EffectDataset(Dataset):
                           if render_root is not None and "<unset env" not in str(render_root) else None)
         rendered = self._rendered_chunks()
         self.synthetic = None
-        if rendered:
+        self.device = device
+        if _usable_dir(root) and render_files and self.proc_root is not None:
+            self._render(rendered)
+        elif rendered:
+            if render_files and rendered != total_chunks:
+                warnings.warn(f"EffectDataset(mode={mode!r}): render_files=True but no corpus to render from; serving the "
+                              f"{rendered} chunks already under {self.proc_root} (asked for {total_chunks})", stacklevel=2)
             self.total_chunks = rendered                       # datasets.py:451 (render_files=False branch)
-        elif _usable_dir(root) and render_files:
-            raise NotImplementedError(
-                f"EffectDataset(mode={mode!r}): rendering {total_chunks} chunks from {root} needs the reference's "
-                "pedalboard / pyloudnorm pipeline (datasets.py:399-452; SURVEY 8(f) rank 3).  Render once with the "
-                "reference's scripts/generate_dataset.py, then point render_root at the result with render_files=False.")
         else:
             warnings.warn("EffectDataset: no corpus (DATASET_ROOT) and no rendered chunks: serving seeded white-noise "
                           "clips (BASELINE.json synthetic inputs)", stacklevel=2)
             self.synthetic = SyntheticEffectDataset(total_chunks=total_chunks, chunk_size=chunk_size,
                                                     seed=self._SEEDS.get(mode, 42345))
+
+    def _render(self, rendered):
+        """datasets.py:381-452 on the device: wipe an existing set (upstream asks first), render total_chunks chunks."""
+        import shutil
+        from .effects import LoudnessNormalize
+        if not torch.cuda.is_available():
+            raise RuntimeError("EffectDataset(render_files=True) renders on the GPU (remfx_amd.effects has no CPU path)")
+        dev = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        files = locate_files(self.root, self.mode)
+        if not files or not any(files):
+            raise ValueError(f"EffectDataset: no audio files of the known corpora under {self.root} for mode {self.mode!r}")
+        if rendered:
+            warnings.warn(f"EffectDataset: re-rendering {self.proc_root} (render_files=True); set render_files=False to keep it")
+            shutil.rmtree(self.proc_root)
+        self.proc_root.mkdir(parents=True, exist_ok=True)
+        normalize = LoudnessNormalize(self.sample_rate, target_lufs_db=-20)
+        for num_chunk in range(self.total_chunks):
+            chunk = _random_chunk(files, self.chunk_size, self.sample_rate, dev)
+            dry, wet, dry_effects, wet_effects = process_effects(
+                chunk, self.effects, self.effects_to_keep, self.effects_to_remove, self.num_kept_effects,
+                self.num_removed_effects, self.shuffle_kept_effects, self.shuffle_removed_effects, normalize)
+            d = self.proc_root / str(num_chunk)
+            d.mkdir(exist_ok=True)
+            save_wav(d / "input.wav", wet, self.sample_rate)
+            save_wav(d / "target.wav", dry, self.sample_rate)
+            torch.save(dry_effects, d / "dry_effects.pt")
+            torch.save(wet_effects, d / "wet_effects.pt")
 
     def _rendered_chunks(self):
         if self.proc_root is None or not self.proc_root.is_dir():
@@ -140,6 +273,52 @@ class EffectDataset(Dataset):
         inp, _ = load_wav(d / "input.wav")
         tgt, _ = load_wav(d / "target.wav")
         return inp, tgt, dry_effect_names, wet_effect_names
+
+
+class DynamicEffectDataset(Dataset):
+    """remfx.datasets.DynamicEffectDataset (datasets.py:205-330; cfg/exp/5-5_full_cls_dynamic.yaml): every item is a fresh
+    random chunk with freshly drawn effects -- rendered on the device (`device`, default the current GPU), so use
+    ``num_workers=0``.  Without a corpus (``root`` unset / missing) the source chunks are seeded white noise at about
+    -20 dB and the effects are still drawn and rendered: on-the-fly augmentation stays exercisable offline."""
+
+    def __init__(self, root=None, sample_rate=48000, chunk_size=262144, total_chunks=1000, effect_modules=None,
+                 effects_to_keep=None, effects_to_remove=None, num_kept_effects=(1, 5), num_removed_effects=(1, 5),
+                 shuffle_kept_effects=True, shuffle_removed_effects=False, render_files=True, render_root=None,
+                 mode="train", parallel=False, device=None):
+        super().__init__()
+        from .effects import LoudnessNormalize
+        self.root, self.sample_rate, self.chunk_size, self.total_chunks = root, sample_rate, chunk_size, total_chunks
+        self.mode, self.effects = mode, effect_modules or {}
+        self.effects_to_keep = [] if effects_to_keep is None else list(effects_to_keep)
+        self.effects_to_remove = [] if effects_to_remove is None else list(effects_to_remove)
+        self.num_kept_effects, self.num_removed_effects = list(num_kept_effects), list(num_removed_effects)
+        self.shuffle_kept_effects, self.shuffle_removed_effects = shuffle_kept_effects, shuffle_removed_effects
+        self.normalize = LoudnessNormalize(sample_rate, target_lufs_db=-20)
+        self.device, self.renders_on_device = device, True
+        self.files = locate_files(root, mode) if _usable_dir(root) else []
+        if not any(self.files):
+            warnings.warn("DynamicEffectDataset: no corpus (DATASET_ROOT): effects are rendered over seeded white-noise chunks",
+                          stacklevel=2)
+            self.files = []
+        self._noise = torch.Generator().manual_seed(EffectDataset._SEEDS.get(mode, 42345))
+
+    def process_effects(self, dry):
+        return process_effects(dry, self.effects, self.effects_to_keep, self.effects_to_remove, self.num_kept_effects,
+                               self.num_removed_effects, self.shuffle_kept_effects, self.shuffle_removed_effects, self.normalize)
+
+    def __len__(self):
+        return self.total_chunks
+
+    def __getitem__(self, _):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DynamicEffectDataset renders on the GPU (remfx_amd.effects has no CPU path)")
+        dev = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.files:
+            chunk = _random_chunk(self.files, self.chunk_size, self.sample_rate, dev)
+        else:
+            chunk = (torch.randn(1, self.chunk_size, generator=self._noise) * 0.1).to(dev)
+        dry, wet, dry_effects, wet_effects = self.process_effects(chunk)
+        return wet, dry, dry_effects, wet_effects
 
 
 class InferenceDataset(Dataset):
@@ -185,7 +364,9 @@ class EffectDatamodule:
 
     def __init__(self, train_dataset=None, val_dataset=None, test_dataset=None, *, train_batch_size=16,
                  test_batch_size=1, num_workers=0, pin_memory=False, **kwargs):
-        mk = lambda d, seed: d if isinstance(d, Dataset) else SyntheticEffectDataset(seed=seed, **(d or {}))
+        # eval.sh passes `datamodule.train_dataset=None` (the string): a split that is not used stays empty
+        mk = lambda d, seed: (d if isinstance(d, Dataset) else None if isinstance(d, str) else
+                              SyntheticEffectDataset(seed=seed, **(d or {})))
         self.train_dataset, self.val_dataset, self.test_dataset = (mk(train_dataset, 12345), mk(val_dataset, 22345),
                                                                    mk(test_dataset, 32345))
         self.train_batch_size, self.test_batch_size = train_batch_size, test_batch_size
@@ -205,7 +386,8 @@ class EffectDatamodule:
             sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=shuffle)
             sampler.set_epoch(self.epoch)
             shuffle = False
-        on_device = getattr(ds, "device", None) is not None        # device-side data prep: main process only
+        # device-side data prep (resampling / effect rendering): main process only
+        on_device = getattr(ds, "device", None) is not None or getattr(ds, "renders_on_device", False)
         return DataLoader(ds, batch_size=bs, shuffle=shuffle, sampler=sampler,
                           num_workers=0 if on_device else self.num_workers,
                           pin_memory=self.pin_memory and not on_device)

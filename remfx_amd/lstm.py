@@ -92,6 +92,7 @@ class _LSTMLayerFn(torch.autograd.Function):
         if need:
             ctx.save_for_backward(x, wcat, pack, gates, cst, out)
             ctx.dims = (T, Bn, H, Cin)
+            ctx.params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)    # identities for the GradSink lookup
         return out
 
     @staticmethod
@@ -108,19 +109,34 @@ class _LSTMLayerFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_dgrad(dG, wcat, tuple(x4.shape), x4.stride(), (1, 1), (0, 0), (1, 1)).squeeze(2)
-        dwcat, dbcat = ops.conv2d_wgrad(x4, dG, tuple(wcat.shape), (1, 1), (0, 0), (1, 1), True)
-        dwcat = dwcat.view(8 * H, Cin)
-        out4 = out.unsqueeze(2)
-        dwhh = []
-        for d in range(2):
-            dp, xs, gs = _whh_plan(out4, dG, H, d, Bn)
-            dap = torch.zeros((dp.p.M, dp.p.Kpad), device=g.device, dtype=torch.float32)
-            ops.gemm_wgrad(dp, xs, gs, dap)
-            dw = torch.zeros((4 * H, H), device=g.device, dtype=torch.float32)
-            ops.unpack_add(dp, dap, dw)
-            dwhh.append(dw)
-        db0, db1 = dbcat[:4 * H], dbcat[4 * H:]
-        return (dx, dwcat[:4 * H], dwhh[0], db0, db0, dwcat[4 * H:], dwhh[1], db1, db1, None, None)
+        # the eight parameter gradients: with a GradSink armed (all eight recognised) they are computed on its side stream and
+        # accumulated in place; nothing downstream in the backward chain needs them
+        sink = ops.SINK
+        tg = [sink.lookup(p) for p in ctx.params] if sink is not None else [None]
+        sunk = all(t is not None for t in tg)
+        stream = sink.stream_for_wgrad(x, dG, out) if sunk else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            dwcat, dbcat = ops.conv2d_wgrad(x4, dG, tuple(wcat.shape), (1, 1), (0, 0), (1, 1), True)
+            dwcat = dwcat.view(8 * H, Cin)
+            out4 = out.unsqueeze(2)
+            dwhh = []
+            for d in range(2):
+                dp, xs, gs = _whh_plan(out4, dG, H, d, Bn)
+                dap = torch.zeros((dp.p.M, dp.p.Kpad), device=g.device, dtype=torch.float32)
+                ops.gemm_wgrad(dp, xs, gs, dap)
+                dw = torch.zeros((4 * H, H), device=g.device, dtype=torch.float32)
+                ops.unpack_add(dp, dap, dw)
+                dwhh.append(dw)
+            db0, db1 = dbcat[:4 * H], dbcat[4 * H:]
+            grads = (dwcat[:4 * H], dwhh[0], db0, db0, dwcat[4 * H:], dwhh[1], db1, db1)
+            if sunk:
+                for (i, view), gr in zip(tg, grads):
+                    view.add_(gr.reshape(-1))
+        if sunk:
+            for i, _ in tg:
+                sink.wrote(i)
+            return (dx,) + (None,) * 10
+        return (dx,) + grads + (None, None)
 
 
 def blstm(module, x, T, Bn):

@@ -203,17 +203,33 @@ def mixup(x: torch.Tensor, y: torch.Tensor, alpha: float = 1.0):
     return mixed_x, mixed_y, lam
 
 
+def _multilabel_f1(probs, target, threshold=0.5):
+    """torchmetrics MultilabelF1Score(num_labels, threshold, average="none", multidim_average="global") on one batch:
+    per-label 2 TP / (2 TP + FP + FN), 0 where the denominator is 0 (models.py:457-476 metrics)."""
+    pred = (probs > threshold).long()
+    tgt = target.long()
+    tp = (pred * tgt).sum(0).float()
+    fp = (pred * (1 - tgt)).sum(0).float()
+    fn = ((1 - pred) * tgt).sum(0).float()
+    den = 2 * tp + fp + fn
+    return torch.where(den > 0, 2 * tp / den.clamp_min(1.0), torch.zeros_like(den))
+
+
 class FXClassifier(_Base):
-    """models.py:423-592 (Cnn14 branch): sum over the 5 heads of BCELoss, per-effect accuracy."""
+    """models.py:423-592.  Cnn14 network: sum over the 5 heads of BCELoss, per-effect binary accuracy.  Any other network
+    (the HEAR-embedding classifiers, classifier.py:16-128: one (B, 5) logit tensor): CrossEntropyLoss(label_smoothing) against
+    the wet-label vector and per-effect / macro multilabel F1 of the sigmoid outputs (models.py:457-476, 503-506, 540-570)."""
 
     def __init__(self, lr: float, lr_weight_decay: float, sample_rate: float, network: nn.Module,
                  mixup: bool = False, label_smoothing: float = 0.0):
         super().__init__()
+        from .classifier import Cnn14
         self.lr, self.lr_weight_decay, self.sample_rate = lr, lr_weight_decay, sample_rate
         self.network = network
         self.effects = ["Reverb", "Chorus", "Delay", "Distortion", "Compressor"]
         self.mixup, self.label_smoothing = mixup, label_smoothing     # label_smoothing unused for Cnn14 (Q12)
-        self.loss_fn = torch.nn.BCELoss()
+        self.multihead = isinstance(network, Cnn14)
+        self.loss_fn = torch.nn.BCELoss() if self.multihead else torch.nn.CrossEntropyLoss(label_smoothing=label_smoothing)
 
     def forward(self, x: torch.Tensor, train: bool = False):
         return self.network(x, train=train)
@@ -222,22 +238,34 @@ class FXClassifier(_Base):
         train = mode == "train"
         x, y, dry_label, wet_label = batch
         labels = wet_label
-        if train and self.mixup:
+        mixed = train and self.mixup
+        if mixed:
             x, labels, _ = mixup(x, wet_label)
         outputs = self(x, train)
-        loss = 0
-        for idx, output in enumerate(outputs):
-            loss = loss + self.loss_fn(output.squeeze(-1), labels[..., idx])
+        if self.multihead or mixed:                 # models.py:496-500 iterates `outputs` in the mixup branch whatever the network
+            loss = 0
+            for idx, output in enumerate(outputs):
+                loss = loss + self.loss_fn(output.squeeze(-1), labels[..., idx])
+        else:
+            loss = self.loss_fn(outputs, labels)    # (B, 5) logits against the (B, 5) float label vector (class probabilities)
         self.log(f"{mode}_loss", loss, on_step=True, on_epoch=True, prog_bar=True, logger=True, sync_dist=True)
-        accs = []
         with torch.no_grad():
-            for idx, name in enumerate(self.effects[:len(outputs)]):
-                acc = ((outputs[idx].squeeze(-1) > 0.5).float() == wet_label[..., idx]).float().mean()
-                self.log(f"{mode}_{name}_acc", acc, on_step=True, on_epoch=True, prog_bar=True, logger=True,
-                         sync_dist=True)
-                accs.append(acc)
-            self.log(f"{mode}_avg_acc", torch.mean(torch.stack(accs)), on_step=True, on_epoch=True,
-                     prog_bar=True, logger=True, sync_dist=True)
+            if self.multihead:
+                accs = []
+                for idx, name in enumerate(self.effects[:len(outputs)]):
+                    acc = ((outputs[idx].squeeze(-1) > 0.5).float() == wet_label[..., idx]).float().mean()
+                    self.log(f"{mode}_{name}_acc", acc, on_step=True, on_epoch=True, prog_bar=True, logger=True,
+                             sync_dist=True)
+                    accs.append(acc)
+                self.log(f"{mode}_avg_acc", torch.mean(torch.stack(accs)), on_step=True, on_epoch=True,
+                         prog_bar=True, logger=True, sync_dist=True)
+            else:
+                f1 = _multilabel_f1(torch.sigmoid(outputs), wet_label)
+                for idx, name in enumerate(self.effects):
+                    self.log(f"{mode}_f1_{name}", f1[idx], on_step=True, on_epoch=True, prog_bar=True, logger=True,
+                             sync_dist=True)
+                self.log(f"{mode}_avg_acc", f1.mean(), on_step=True, on_epoch=True, prog_bar=True, logger=True,
+                         sync_dist=True)              # macro F1 under the reference's name
         return loss
 
     def training_step(self, batch, batch_idx):

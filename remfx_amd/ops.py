@@ -549,6 +549,7 @@ class ConvT2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, dilation, crop_lo, out_len):
         ctx.save_for_backward(x, w)
+        ctx.bias = bias                                   # identity only (GradSink lookup)
         ctx.cfg = (stride, dilation, crop_lo, out_len, bias is not None)
         return convT2d_forward(x, w, bias, stride, dilation, crop_lo, out_len)
 
@@ -568,6 +569,22 @@ class ConvT2dFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_strided(tuple(x.shape), xs, device=x.device, dtype=torch.float32)
                 gemm_fwd(dp, pack_a(dp, wc), g, dx)
+            sink = SINK
+            tw = sink.lookup(w) if (sink is not None and need_w) else None
+            tb = sink.lookup(ctx.bias) if (tw is not None and has_bias) else None
+            if tw is not None and (tb is not None or not has_bias):
+                # in place on the sink's side stream (see conv2d_wgrad)
+                with torch.cuda.stream(sink.stream_for_wgrad(x, g)):
+                    p = dp.p
+                    dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
+                    gemm_wgrad(dp, g, x, dapack)
+                    unpack_add(dp, dapack, tw[1])
+                    if has_bias:
+                        tb[1].add_(channel_sum(g))
+                sink.wrote(tw[0])
+                if has_bias:
+                    sink.wrote(tb[0])
+                return dx, None, None, None, None, None, None
             if need_w:
                 p = dp.p
                 dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)

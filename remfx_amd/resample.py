@@ -39,8 +39,9 @@ def sinc_kernel(orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99, dtype
 _TABLES = {}
 
 
-def resample(x, orig_freq, new_freq, table_dtype=torch.float64):
-    """x: (..., L) fp32 on the GPU -> (..., ceil(new * L / orig)).  Identity when the rates are equal."""
+def resample(x, orig_freq, new_freq, table_dtype=torch.float64, kernel=None):
+    """x: (..., L) fp32 on the GPU -> (..., ceil(new * L / orig)).  Identity when the rates are equal.
+    kernel: the (new, 1, K) filter bank to use instead of the cached one (the `Resample` module's buffer)."""
     if int(orig_freq) == int(new_freq):
         return x
     ops._req(x, "waveform")
@@ -49,6 +50,10 @@ def resample(x, orig_freq, new_freq, table_dtype=torch.float64):
         kern, width, orig, new = sinc_kernel(orig_freq, new_freq, dtype=table_dtype)
         _TABLES[key] = (kern.to(x.device).unsqueeze(1).contiguous(), width, orig, new)     # (new, 1, K)
     w, width, orig, new = _TABLES[key]
+    if kernel is not None:
+        if kernel.shape != w.shape:
+            raise ValueError(f"resample kernel {tuple(kernel.shape)} does not fit {orig_freq} -> {new_freq} Hz {tuple(w.shape)}")
+        w = kernel.to(x.device, torch.float32).contiguous()
     shape = x.shape
     L = shape[-1]
     rows = x.reshape(-1, 1, L)
@@ -60,3 +65,22 @@ def resample(x, orig_freq, new_freq, table_dtype=torch.float64):
     ops.conv2d_forward(xp.unsqueeze(2), w.unsqueeze(2), None, (1, orig), (0, 0), (1, 1), out=out)
     target = math.ceil(new * L / orig)
     return buf.reshape(rows.shape[0], frames * new)[:, :target].reshape(*shape[:-1], target)
+
+
+class Resample(torch.nn.Module):
+    """torchaudio.transforms.Resample(orig_freq, new_freq) (classifier.py:24-26, 50-52, 75-77, 101-103, 180-183): holds the
+    filter bank as the persistent buffer ``kernel`` of shape (new / gcd, 1, 2 * width + orig / gcd) when the rates differ, as
+    upstream, so checkpoints of resampling classifiers (``network.resample.kernel``) load strictly; forward resamples on
+    the device with THAT buffer."""
+
+    def __init__(self, orig_freq=16000, new_freq=16000):
+        super().__init__()
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        if self.orig_freq != self.new_freq:
+            kern, self.width, _, _ = sinc_kernel(self.orig_freq, self.new_freq, dtype=torch.float64)
+            self.register_buffer("kernel", kern.unsqueeze(1).contiguous())
+
+    def forward(self, x):
+        if self.orig_freq == self.new_freq:
+            return x
+        return resample(x, self.orig_freq, self.new_freq, kernel=self.kernel)

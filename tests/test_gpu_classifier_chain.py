@@ -195,3 +195,70 @@ def test_remfx_step_and_chain_flow(golden_dir):
     assert sorted(chain.logged) == g["chain_log_names"].tolist()
     for k, v in zip(g["chain_log_names"].tolist(), g["chain_log_vals"]):
         check(abs(float(chain.logged[k]) - float(v)), 2e-3, max(1.0, abs(float(v))), what=k)
+
+
+class _ToyEmbedder(nn.Module):
+    """Stand-in for a HEAR scene-embedding model (hearbaseline / wav2clip_hear / panns_hear are not in the image): frame
+    energies through a fixed random projection -> (B, dim)."""
+
+    def __init__(self, dim, frame=400):
+        super().__init__()
+        g = torch.Generator().manual_seed(dim)
+        self.frame = frame
+        self.w = nn.Parameter(torch.randn(64, dim, generator=g) / 8.0)
+
+    def get_scene_embeddings(self, audio):
+        B, T = audio.shape
+        n = T // self.frame
+        e = audio[:, :n * self.frame].reshape(B, n, self.frame).pow(2).mean(-1).add(1e-8).log()          # (B, n)
+        feats = torch.nn.functional.adaptive_avg_pool1d(e.unsqueeze(1), 64).squeeze(1)
+        return feats @ self.w
+
+
+@pytest.mark.parametrize("cls_name,dim,rate", [("PANNs", 2048, 32000), ("VGGish", 128, 16000), ("Wav2CLIP", 512, 16000),
+                                               ("wav2vec2", 1024, 16000)])
+def test_hear_embedding_classifiers(cls_name, dim, rate):
+    """classifier.py:16-128 + the non-Cnn14 branch of FXClassifier (models.py:457-476, 503-506, 540-570): device-side
+    resampling to the embedding model's rate, frozen embedder, MLP head on the HIP GEMMs, cross-entropy against the wet-label
+    vector, multilabel F1 -- against the same computation in plain torch; one optimiser step moves the head only."""
+    from remfx_amd import classifier, models
+    from remfx_amd.resample import resample
+    torch.manual_seed(3)
+    emb = _ToyEmbedder(dim)
+    net = getattr(classifier, cls_name)(num_classes=5, sample_rate=48000, embedder=emb)
+    assert sorted(k for k in net.state_dict() if k.startswith("proj")) == sorted(
+        f"proj.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias"))
+    assert "resample.kernel" in net.state_dict()                 # torchaudio.transforms.Resample keeps its filter bank as a buffer
+    model = models.FXClassifier(3e-4, 1e-3, 48000, net, label_smoothing=0.1).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(6, 1, 24000, generator=g) * torch.logspace(-2, 0, 6).view(6, 1, 1)).to(DEV)
+    lab = (torch.rand(6, 5, generator=g) > 0.5).float().to(DEV)
+    logits = model(x)
+    assert logits.shape == (6, 5)
+    with torch.no_grad():
+        e = emb.get_scene_embeddings(resample(x, 48000, rate).reshape(6, -1))
+        ref = net.proj(e)
+    check(float((logits - ref).abs().max()), 2e-4, max(1.0, float(ref.abs().max())), what=cls_name)
+    opt = model.configure_optimizers()
+    assert len(opt.flat.params) == 6                         # the head's three Linear layers; the embedder is frozen
+    opt.zero_grad()
+    loss = model.training_step((x, None, None, lab), 0)
+    lref = torch.nn.functional.cross_entropy(ref, lab, label_smoothing=0.1)
+    check(abs(float(loss) - float(lref)), 2e-4, max(1.0, float(lref)))
+    probs = torch.sigmoid(ref)
+    for k, name in enumerate(model.effects):
+        pred, t = (probs[:, k] > 0.5), lab[:, k] > 0.5
+        tp, fp, fn = float((pred & t).sum()), float((pred & ~t).sum()), float((~pred & t).sum())
+        f1 = 2 * tp / (2 * tp + fp + fn) if (2 * tp + fp + fn) else 0.0
+        assert abs(model.logged[f"train_f1_{name}"] - f1) < 1e-6
+    assert "train_avg_acc" in model.logged and "train_loss" in model.logged
+    w_emb, w_head = emb.w.detach().clone(), net.proj[4].weight.detach().clone()
+    loss.backward()
+    opt.step()
+    assert torch.equal(emb.w, w_emb) and not torch.equal(net.proj[4].weight, w_head)
+
+
+def test_hear_classifier_without_package_raises():
+    from remfx_amd import classifier
+    with pytest.raises(ImportError, match="panns_hear"):
+        classifier.PANNs(num_classes=5, sample_rate=48000)

@@ -139,3 +139,51 @@ def test_gradient_sink_matches_autograd_accumulation():
                 num += d; den += float(ref[n].double().pow(2).sum())
                 assert d ** 0.5 <= 1e-4 * max(1e-6, float(ref[n].abs().max())) * ref[n].numel() ** 0.5, n
         assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5       # fp32 atomics order noise only
+
+
+def test_test_script_loads_checkpoint_and_evaluates(tmp_path):
+    """scripts/test.py (reference scripts/test.py:10-47): strict load of the checkpoint scripts/train.py wrote, then the test
+    split -- same metrics as the post-fit test of the training run that produced the checkpoint (same weights, same data)."""
+    common = ["+exp=reverb", "model.network.nblocks=3", "model.network.channel_width=16", "chunk_size=16384",
+              "datamodule.train_batch_size=2", "datamodule.train_dataset.total_chunks=4", "datamodule.val_dataset.total_chunks=2",
+              "datamodule.test_dataset.total_chunks=2", f"logs_dir={tmp_path}"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train.py")] + common + ["trainer.max_steps=2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    fit_test = eval(r.stdout.strip().splitlines()[-1])
+    ck = os.path.join(tmp_path, "ckpts", "last.ckpt")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "test.py")] + common + [f"+ckpt_path={ck}", "datamodule.train_dataset=None", "datamodule.val_dataset=None"],
+                        capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    out = eval(r2.stdout.strip().splitlines()[-1])
+    for k in ("test_loss", "test_SISDR", "test_STFT", "Input_SISDR", "Input_STFT"):
+        assert abs(out[k] - fit_test[k]) <= 1e-4 * max(1.0, abs(fit_test[k])), (k, out[k], fit_test[k])
+    # a missing checkpoint is an error, as upstream (torch.load raises)
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "test.py")] + common + ["+ckpt_path=/nonexistent.ckpt"],
+                        capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r3.returncode != 0 and "not found" in r3.stderr
+
+
+@pytest.mark.one_mode
+def test_remfx_detect_script_whole_file(tmp_path):
+    """scripts/remfx_detect.py (reference scripts/remfx_detect.py:13-61) on a 44.1 kHz stereo file LONGER than one training clip
+    (7 s -> 336000 samples at 48 kHz: more than 256 attention frames): device-side resampling, mono mix, detector + the five
+    removal networks on the whole file, float32 WAV out at cfg.sample_rate with the input's resampled length."""
+    import numpy as np
+    from scipy.io import wavfile
+    sr_in, secs = 44100, 7.0
+    t = np.arange(int(sr_in * secs)) / sr_in
+    rng = np.random.default_rng(0)
+    a = np.stack([0.3 * np.sin(2 * np.pi * 220.0 * t) + 0.02 * rng.standard_normal(t.size),
+                  0.2 * np.sin(2 * np.pi * 331.0 * t)], 1)
+    src, dst = os.path.join(tmp_path, "in.wav"), os.path.join(tmp_path, "out.wav")
+    wavfile.write(src, sr_in, (a * 32767).astype(np.int16))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "remfx_detect.py"), "+exp=remfx_detect",
+                        f"+audio_input={src}", f"+output_path={dst}", "inference_use_all_effect_models=True"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, RFX_ALLOW_RANDOM_INIT="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "Loading models..." in r.stdout and "Saving output to" in r.stdout
+    sr_out, y = wavfile.read(dst)
+    assert sr_out == 48000 and y.ndim == 1 or y.shape[1] == 1
+    n = int(np.ceil(a.shape[0] * 48000 / sr_in))
+    assert abs(y.shape[0] - n) <= 1 and np.isfinite(y).all() and y.dtype == np.float32

@@ -223,6 +223,24 @@ def test_reference_configs_instantiate(name, recwarn):
         assert list(cfg["inference_effects_ordering"]) == [n for n in cfg["inference_effects_ordering"] if n in models.ALL_EFFECT_NAMES]
 
 
+def test_dynamic_effect_config_instantiates():
+    """cfg/exp/5-5_full_cls_dynamic.yaml (on-the-fly augmentation): the train split is a DynamicEffectDataset holding the
+    five effect objects and a -20 LUFS normaliser (datasets.py:205-262); val / test stay EffectDatasets."""
+    from remfx_amd import config, datasets, effects
+    cfg = _composed()["cls_dynamic"]["cfg"]
+    with pytest.warns(UserWarning):
+        dm = config.instantiate(cfg["datamodule"])
+    tr = dm.train_dataset
+    assert isinstance(tr, datasets.DynamicEffectDataset) and len(tr) == 8000 and tr.renders_on_device
+    assert isinstance(tr.normalize, effects.LoudnessNormalize) and tr.normalize.target_lufs_db == -20
+    assert tr.effects_to_remove == ["distortion", "compressor", "reverb", "chorus", "delay"] and tr.num_removed_effects == [0, 5]
+    assert all(type(e) in effects.Pedalboard_Effects for e in tr.effects.values()) and tr.shuffle_removed_effects is True
+    assert isinstance(dm.val_dataset, datasets.EffectDataset) and isinstance(dm.test_dataset, datasets.EffectDataset)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="renders on the GPU"):
+            tr[0]
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/cfg"), reason="reference tree only exists in the build container")
 def test_composer_reproduces_fixture_from_reference_tree():
     from remfx_amd import config
@@ -243,11 +261,17 @@ def test_effect_label_order_and_alias():
     assert [c.__name__ for c in effects.Pedalboard_Effects] == models.ALL_EFFECT_NAMES      # effects.py:699-707
     assert alias.RandomPedalboardChorus is effects.RandomPedalboardChorus
     fx = effects.RandomPedalboardDelay(48000, min_delay_seconds=0.1, max_delay_sconds=1.0)
-    p = fx.draw(torch.Generator().manual_seed(0))
-    assert 0.1 <= p["delay_seconds"] <= 1.0 and set(p) == {"delay_seconds", "feedback", "mix"}
+    torch.manual_seed(0)
+    p = fx.draw()
+    assert 0.1 <= p["delay_seconds"] <= 1.0 and list(p) == ["delay_seconds", "feedback", "mix"]       # the reference's draw order
+    torch.manual_seed(7)
+    u = [float(torch.rand(1)) for _ in range(4)]
+    torch.manual_seed(7)
+    q = effects.RandomPedalboardCompressor(48000).draw()          # effects.py:323-326: threshold, ratio, attack, release
+    assert abs(q["threshold_db"] - (u[0] * 36.0 - 42.0)) < 1e-4 and abs(q["release_ms"] - (u[3] * 240.0 + 10.0)) < 1e-3
     with pytest.raises(TypeError):
         effects.RandomPedalboardReverb(48000, min_nonsense=1.0)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="no CPU path"):          # rendering runs on the GPU only
         fx(torch.zeros(1, 8))
 
 
@@ -278,8 +302,9 @@ def test_effect_dataset_reads_rendered_layout(tmp_path):
         assert torch.equal(x, wet) and torch.equal(y, dry) and torch.equal(wl, lab) and float(dl.sum()) == 0.0
     with pytest.raises(ValueError):
         datasets.EffectDataset(**dict(kw, effects_to_remove=["chorus"]))
-    with pytest.raises(NotImplementedError):                # a corpus that would have to be rendered
-        datasets.EffectDataset(**dict(kw, root=str(tmp_path), render_files=True, mode="train"))
+    if not torch.cuda.is_available():                       # a corpus to render: device-side rendering needs the GPU
+        with pytest.raises(RuntimeError, match="renders on the GPU"):
+            datasets.EffectDataset(**dict(kw, root=str(tmp_path), render_files=True, mode="train"))
 
 
 def test_multistep_lr_and_optimizer_state_layout():
