@@ -340,6 +340,25 @@ int rfx_fx_loudness(const float* x, int32_t B, int64_t T, int32_t chunk, int32_t
                     double inv_block, const double* coef, float target_lufs, double* hop_ws, float* lufs, float* gain, void* stream);
 int rfx_fx_scale(const float* x, float* y, int32_t B, int64_t T, const float* gain, void* stream);
 
+/* ---- fused DConv depth-layer of the Hybrid Demucs frequency branch (bf16 arithmetic) ---------------------------------------
+ * torchaudio HDemucs `_DConv` layer (reached from remfx/models.py:319): x_out = x + scale * GLU(GN(conv1x1(GELU(GN(conv3_dil(x))))))
+ * for N samples of (C, T = 256), C in {48, 96}, hidden = C / 4, dilation 1 or 2, GroupNorm(1, .) with `eps`.  One pass over x per
+ * direction (csrc/dconv.hip).  Weights in PyTorch layout: w1 (C/4, C, 3), w2 (2C, C/4[, 1]).  rfx_dconv_layer_ok: shape test. */
+int rfx_dconv_layer_ok(int32_t C, int32_t T, int32_t dil);
+int rfx_dconv_layer_fwd(const float* x, float* out, int32_t N, int32_t C, int32_t T, int32_t dil, const float* w1, const float* b1,
+                        const float* gn1w, const float* gn1b, const float* w2, const float* b2, const float* gn2w,
+                        const float* gn2b, const float* scale, float eps, void* stream);
+/* Backward of the same layer from its INPUT x (the forward is recomputed) and the upstream gradient g: gx = dL/dx.  C = 48 only.
+ * For the two weight-gradient GEMMs (existing rfx_gemm_wgrad plans, which also yield the conv biases) it writes dz (N, 2C, T)
+ * bf16 = gradient of the 1x1 conv output, a_out (N, C/4, T) fp32 = its input, dh (N, C/4, T) bf16 = gradient of the dilated conv
+ * output.  partial: rfx_dconv_layer_bwd_rows(N) rows of 5C + 2(C/4) floats [dscale C | dgn2w 2C | dgn2b 2C | dgn1w C/4 | dgn1b C/4],
+ * one per workgroup: the caller adds the rows (fixed order: deterministic). */
+int rfx_dconv_layer_bwd_rows(int32_t N);
+int rfx_dconv_layer_bwd(const float* x, const float* g, float* gx, int32_t N, int32_t C, int32_t T, int32_t dil, const float* w1,
+                        const float* b1, const float* gn1w, const float* gn1b, const float* w2, const float* b2, const float* gn2w,
+                        const float* gn2b, const float* scale, float eps, void* dz_bf16, float* a_out, void* dh_bf16,
+                        float* partial, void* stream);
+
 /* Label of the kernel instantiation rfx_gemm_fwd would launch (measurement only; see csrc/gemm.hip). */
 int rfx_gemm_fwd_variant(const rfx_gemm_desc* d, const rfx_epilogue* epi, int32_t two_phase, int32_t prec);
 

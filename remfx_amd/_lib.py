@@ -141,6 +141,10 @@ SIGNATURES = {
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_dconv_layer_ok": [_I32, _I32, _I32],
+    "rfx_dconv_layer_fwd": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P],
+    "rfx_dconv_layer_bwd_rows": [_I32],
+    "rfx_dconv_layer_bwd": [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P],
     "rfx_fx_distortion": [_P, _P, _I32, _I64, _P, _P],
     "rfx_fx_delay": [_P, _P, _I32, _I64, _P, _P, _P, _P],
     "rfx_fx_chorus": [_P, _P, _I32, _I64, C.c_float, _P, _P, _P, _P, _P, _P],

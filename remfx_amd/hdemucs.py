@@ -112,6 +112,12 @@ class _DConv(nn.Module):
     def forward(self, x):
         for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
             mods = list(seq)
+            if (not lstm and not attn and mods[1].eps == mods[4].eps and mods[1].num_groups == 1 and
+                    nnops.dconv_layer_fused_ok(x, mods[0].out_channels, mods[0].kernel_size[0], dil,
+                                               torch.is_grad_enabled() and (x.requires_grad or mods[0].weight.requires_grad))):
+                # frequency-branch samples of (C, 256): the whole depth-layer in one launch per direction (csrc/dconv.hip)
+                x = nnops.dconv_layer(x, mods[0], mods[1], mods[3], mods[4], mods[6].scale, dil)
+                continue
             st = torch.zeros((x.shape[0], _STAT_SLOTS, 2), device=x.device, dtype=torch.float64)   # GN(1, C) statistics
             y, x = ops.conv1d_fork(x, mods[0].weight, mods[0].bias, 1, pad, dil, stat_sums=st, out_bf16=True)   # statistics come out of the GEMM epilogue
             y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu", sums=st)

@@ -257,6 +257,71 @@ def add(x, y, alpha=1.0):
     return _AddFn.apply(x, y, alpha)
 
 
+class _DConvLayerFn(torch.autograd.Function):
+    """One depth-layer of the Hybrid Demucs DConv branch as ONE launch per direction (csrc/dconv.hip):
+    x + scale * GLU(GN(conv1x1(GELU(GN(conv3_dilated(x)))))) on (N, C, 256) samples, bf16 arithmetic.  Only the layer INPUT is
+    saved; the backward launch recomputes the forward, returns dL/dx, the LayerScale / GroupNorm gradients (per-workgroup partial
+    rows summed here) and hands dz / a / dh to the two weight-gradient GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, dil, eps):
+        ops._req(x, "x")
+        N, Cc, T = x.shape
+        out = torch.empty_like(x)
+        check(_lib.lib().rfx_dconv_layer_fwd(_ptr(x), _ptr(out), N, Cc, T, dil, _ptr(w1), _ptr(b1), _ptr(g1w), _ptr(g1b),
+                                             _ptr(w2), _ptr(b2), _ptr(g2w), _ptr(g2b), _ptr(scale), float(eps), _stream()),
+              "rfx_dconv_layer_fwd")
+        ctx.save_for_backward(x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale)
+        ctx.cfg = (dil, float(eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale = ctx.saved_tensors
+        dil, eps = ctx.cfg
+        N, Cc, T = x.shape
+        H = Cc // 4
+        g = g.contiguous()
+        L = _lib.lib()
+        gx = torch.empty_like(x)
+        dz = torch.empty((N, 2 * Cc, T), device=x.device, dtype=torch.bfloat16)
+        a_out = torch.empty((N, H, T), device=x.device, dtype=torch.float32)
+        dh = torch.empty((N, H, T), device=x.device, dtype=torch.bfloat16)
+        partial = torch.empty((L.rfx_dconv_layer_bwd_rows(N), 5 * Cc + 2 * H), device=x.device, dtype=torch.float32)
+        check(L.rfx_dconv_layer_bwd(_ptr(x), _ptr(g), _ptr(gx), N, Cc, T, dil, _ptr(w1), _ptr(b1), _ptr(g1w), _ptr(g1b), _ptr(w2),
+                                    _ptr(b2), _ptr(g2w), _ptr(g2b), _ptr(scale), eps, _ptr(dz), _ptr(a_out), _ptr(dh), _ptr(partial),
+                                    _stream()), "rfx_dconv_layer_bwd")
+        ps = partial.sum(0)
+        dscale, dg2w, dg2b = ps[:Cc], ps[Cc:3 * Cc], ps[3 * Cc:5 * Cc]
+        dg1w, dg1b = ps[5 * Cc:5 * Cc + H], ps[5 * Cc + H:]
+        # weight / bias gradients of the two convolutions on the existing wgrad kernels (side stream + in place when a GradSink is armed)
+        dw2, db2 = ops.conv2d_wgrad(a_out.unsqueeze(2), dz.unsqueeze(2), (2 * Cc, H, 1, 1), (1, 1), (0, 0), (1, 1), True, w2, b2)
+        dw1, db1 = ops.conv2d_wgrad(x.unsqueeze(2), dh.unsqueeze(2), (H, Cc, 1, 3), (1, 1), (0, dil), (1, dil), True, w1, b1)
+        if dw2 is not None:
+            dw2, dw1 = dw2.view_as(w2), dw1.view_as(w1)
+        return gx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None
+
+
+DCONV_FUSED = True            # bench.py --no-fused-dconv flips it for A/B runs
+
+
+def dconv_layer_fused_ok(x, hidden, kernel_size, dil, need_grad):
+    """Shapes / mode the fused DConv layer kernels take (csrc/dconv.hip): bf16 arithmetic, contiguous fp32 (N, C, 256) with
+    C = 48 (C = 96 forward-only), hidden = C / 4, kernel 3, dilation 1 or 2."""
+    if not DCONV_FUSED or ops.GEMM_PREC != 2 or x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
+        return False
+    Cc, T = x.shape[1], x.shape[2]
+    if hidden * 4 != Cc or kernel_size != 3 or not _lib.lib().rfx_dconv_layer_ok(Cc, T, dil):
+        return False
+    return Cc == 48 or not need_grad
+
+
+def dconv_layer(x, conv1, gn1, conv2, gn2, scale, dil):
+    """conv1 / conv2: nn.Conv1d parameter containers, gn1 / gn2: nn.GroupNorm(1, .), scale: the LayerScale vector."""
+    return _DConvLayerFn.apply(x, conv1.weight, conv1.bias, gn1.weight, gn1.bias, conv2.weight, conv2.bias, gn2.weight, gn2.bias,
+                               scale, int(dil), float(gn1.eps))
+
+
 def row_standardize(x, eps):
     """(x - mean) / (eps + std) over all dims but the first, unbiased std (HDemucs forward); x carries no
     gradient (it is the input waveform / its STFT).  Returns y, mean (R,), std (R,)."""
