@@ -246,7 +246,12 @@ int rfx_act_add_fwd(const float* x, const float* res, float* y, int64_t n, int32
 int rfx_act_rows(const float* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0, int64_t gs1,
                  int64_t gs2, float* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0, int32_t D1, int32_t D2,
                  int32_t T, int32_t act, void* stream);
-/* PReLU with per-channel slope over [N][C][L] contiguous: gx, and gslope[C] (+=, atomics). */
+/* y = a * b elementwise (contiguous, n elements; 16-byte aligned): mask * representation and tanh * sigmoid gating of asteroid's
+ * DPTNet (reference remfx/models.py:327-344). */
+int rfx_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* nn.PReLU over [N][C][L] contiguous with a per-channel slope (C = 1: the single-parameter form of asteroid DPTNet's
+ * `first_out`, reference remfx/models.py:327-344; per-channel: remfx/tcn.py:46).  Forward; backward: gx, and gslope[C] (+=, atomics). */
+int rfx_prelu_fwd(const float* x, const float* slope, float* y, int64_t N, int64_t C, int64_t L, void* stream);
 int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx, float* gslope,
                   int64_t N, int64_t C, int64_t L, void* stream);
 
@@ -342,25 +347,27 @@ int rfx_fx_scale(const float* x, float* y, int32_t B, int64_t T, const float* ga
 
 /* ---- fused DConv depth-layer of the Hybrid Demucs frequency branch (bf16 arithmetic) ---------------------------------------
  * torchaudio HDemucs `_DConv` layer (reached from remfx/models.py:319): x_out = x + scale * GLU(GN(conv1x1(GELU(GN(conv3_dil(x))))))
- * for N samples of (C, T = 256), C in {48, 96}, hidden = C / 4, dilation 1 or 2, GroupNorm(1, .) with `eps`.  One pass over x per
- * direction (csrc/dconv.hip).  Weights in PyTorch layout: w1 (C/4, C, 3), w2 (2C, C/4[, 1]).  rfx_dconv_layer_ok: shape test. */
+ * for N samples of (C = 48, T = 256), hidden = C / 4 = 12, dilation 1 or 2, GroupNorm(1, .) with `eps`: ONE launch, one pass over x
+ * (csrc/dconv.hip).  Weights in PyTorch layout: w1 (12, 48, 3), w2 (96, 12[, 1]).  rfx_dconv_layer_ok: shape test.
+ * Training: pass all four of h16 (N, 12, T) bf16 = conv1 output, z16 (N, 96, T) bf16 = conv2 output, a_out (N, 12, T) fp32 =
+ * GELU(GN(h)), stats (4, N) fp32 = mean1, rstd1, mean2, rstd2 -- exactly what rfx_groupnorm_bwd_x16 / the gather-GEMM input- and
+ * weight-gradient kernels of the layer-by-layer path read; inference: all four NULL. */
 int rfx_dconv_layer_ok(int32_t C, int32_t T, int32_t dil);
 int rfx_dconv_layer_fwd(const float* x, float* out, int32_t N, int32_t C, int32_t T, int32_t dil, const float* w1, const float* b1,
                         const float* gn1w, const float* gn1b, const float* w2, const float* b2, const float* gn2w,
-                        const float* gn2b, const float* scale, float eps, void* stream);
-/* Backward of the same layer from its INPUT x (the forward is recomputed) and the upstream gradient g: gx = dL/dx.  C = 48 only.
- * For the two weight-gradient GEMMs (existing rfx_gemm_wgrad plans, which also yield the conv biases) it writes dz (N, 2C, T)
- * bf16 = gradient of the 1x1 conv output, a_out (N, C/4, T) fp32 = its input, dh (N, C/4, T) bf16 = gradient of the dilated conv
- * output.  partial: rfx_dconv_layer_bwd_rows(N) rows of 5C + 2(C/4) floats [dscale C | dgn2w 2C | dgn2b 2C | dgn1w C/4 | dgn1b C/4],
- * one per workgroup: the caller adds the rows (fixed order: deterministic). */
-int rfx_dconv_layer_bwd_rows(int32_t N);
-int rfx_dconv_layer_bwd(const float* x, const float* g, float* gx, int32_t N, int32_t C, int32_t T, int32_t dil, const float* w1,
-                        const float* b1, const float* gn1w, const float* gn1b, const float* w2, const float* b2, const float* gn2w,
-                        const float* gn2b, const float* scale, float eps, void* dz_bf16, float* a_out, void* dh_bf16,
-                        float* partial, void* stream);
+                        const float* gn2b, const float* scale, float eps, void* h16, void* z16, float* a_out, float* stats,
+                        void* stream);
 
 /* Label of the kernel instantiation rfx_gemm_fwd would launch (measurement only; see csrc/gemm.hip). */
 int rfx_gemm_fwd_variant(const rfx_gemm_desc* d, const rfx_epilogue* epi, int32_t two_phase, int32_t prec);
+
+/* Plain multi-head scaled-dot-product attention, out[c, s] = sum_t softmax_t(<k[:, t], q[:, s]> / sqrt(ch)) v[c, t], on the streaming
+ * any-T kernels above; q, k, v: (B, heads * ch, T) channel-major.  The nn.MultiheadAttention core of asteroid's DPTNet
+ * (`ImprovedTransformedLayer`; reference remfx/models.py:327-344, cfg/model/dptnet.yaml).  stat: B * heads * T * 4 floats. */
+int rfx_mha_fwd(const float* q, const float* k, const float* v, int32_t B, int32_t heads, int32_t ch, int32_t T, float* stat,
+                float* out, void* stream);
+int rfx_mha_bwd(const float* q, const float* k, const float* v, float* stat, const float* out, const float* gout, int32_t B,
+                int32_t heads, int32_t ch, int32_t T, float* dq, float* dk, float* dv, void* stream);
 
 /* ---- GroupNorm (+ fused activation) --------------------------------------------
  * x: (N, C, S) contiguous, G groups.  mode: 0 y = gn(x); 1 y = gelu(gn(x));

@@ -136,15 +136,15 @@ SIGNATURES = {
     "rfx_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "rfx_act_add_fwd": [_P, _P, _P, _I64, _I32, _P],
     "rfx_act_rows": [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P],
+    "rfx_mul": [_P, _P, _P, _I64, _P],
+    "rfx_prelu_fwd": [_P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_l1_sum": [_P, _P, _I64, _P, _P],
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_dconv_layer_ok": [_I32, _I32, _I32],
-    "rfx_dconv_layer_fwd": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P],
-    "rfx_dconv_layer_bwd_rows": [_I32],
-    "rfx_dconv_layer_bwd": [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P],
+    "rfx_dconv_layer_fwd": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P],
     "rfx_fx_distortion": [_P, _P, _I32, _I64, _P, _P],
     "rfx_fx_delay": [_P, _P, _I32, _I64, _P, _P, _P, _P],
     "rfx_fx_chorus": [_P, _P, _I32, _I64, C.c_float, _P, _P, _P, _P, _P, _P],
@@ -154,6 +154,8 @@ SIGNATURES = {
     "rfx_fx_scale": [_P, _P, _I32, _I64, _P, _P],
     "rfx_localstate_gen_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_gen_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "rfx_mha_fwd": [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "rfx_mha_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P],
     "rfx_localstate_mfma_ok": [_I32, _I32, _I32, _I32, _I32],
     "rfx_localstate_mfma_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "rfx_localstate_mfma_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P],

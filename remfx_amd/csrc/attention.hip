@@ -299,14 +299,15 @@ struct LsGenArgs {
   const float *q, *k, *cont, *qd, *out, *gout;
   float *stat, *o, *dq, *dk, *dcont, *dqd;
   int heads, ch, T, nd;
+  int diag;            // 1: LocalState (diagonal masked to -100, decay penalty); 0: plain scaled-dot-product attention (nd = 0)
 };
 
-__device__ __forceinline__ float lsg_score(const float* rowv, const float* colv, int ch, float inv, float pen, int t, int s) {
+__device__ __forceinline__ float lsg_score(const float* rowv, const float* colv, int ch, float inv, float pen, int t, int s, int diag) {
   // rowv[c * 64] broadcast operand, colv[c * 64] lane operand
   float acc = 0.f;
   for (int c = 0; c < ch; ++c) acc = fmaf(rowv[c * 64], colv[c * 64], acc);
   const float v = acc * inv - fabsf((float)(t - s)) * pen;
-  return t == s ? -100.0f : v;
+  return (diag && t == s) ? -100.0f : v;
 }
 
 // mode 0: forward (stat{max,sum}, out); mode 1: query-major backward (dq, dqd, stat.delta)
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(64) void localstate_gen_q_kernel(const LsGenArgs a)
       const int nj = min(64, T - t0);
       for (int j = 0; j < nj; ++j) {
         const int t = t0 + j;
-        const float v = lsg_score(ks + j, qs + lane, ch, inv, pen, t, s);
+        const float v = lsg_score(ks + j, qs + lane, ch, inv, pen, t, s, a.diag);
         if (!second) {
           const float mn = fmaxf(m, v);
           l = l * expf(m - mn) + expf(v - mn);
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(64) void localstate_gen_q_kernel(const LsGenArgs a)
           } else {
             float dw = 0.f;
             for (int c = 0; c < ch; ++c) dw = fmaf(cs[c * 64 + j], gs[c * 64 + lane], dw);
-            const float dv = t == s ? 0.f : p * (dw - delta);          // the masked diagonal is a constant
+            const float dv = (a.diag && t == s) ? 0.f : p * (dw - delta);          // the masked diagonal is a constant
             A = fmaf(dv, fabsf((float)(t - s)), A);
             const float dvi = dv * inv;
             for (int c = 0; c < ch; ++c) acc[c * 64 + lane] = fmaf(dvi, ks[c * 64 + j], acc[c * 64 + lane]);
@@ -425,11 +426,11 @@ __global__ __launch_bounds__(64) void localstate_gen_k_kernel(const LsGenArgs a)
     const int nj = min(64, T - s0);
     for (int j = 0; j < nj; ++j) {
       const int sj = s0 + j;
-      const float v = lsg_score(qc + j, km + lane, ch, inv, sc[192 + j], t, sj);
+      const float v = lsg_score(qc + j, km + lane, ch, inv, sc[192 + j], t, sj, a.diag);
       const float p = expf(v - sc[j]) * sc[64 + j];
       float dw = 0.f;
       for (int c = 0; c < ch; ++c) dw = fmaf(cm[c * 64 + lane], gc[c * 64 + j], dw);
-      const float dvi = (t == sj ? 0.f : p * (dw - sc[128 + j])) * inv;
+      const float dvi = ((a.diag && t == sj) ? 0.f : p * (dw - sc[128 + j])) * inv;
       for (int c = 0; c < ch; ++c) {
         dca[c * 64 + lane] = fmaf(p, gc[c * 64 + j], dca[c * 64 + lane]);
         dka[c * 64 + lane] = fmaf(dvi, qc[c * 64 + j], dka[c * 64 + lane]);
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(64) void localstate_gen_k_kernel(const LsGenArgs a)
 }
 
 static bool lsg_ok(int B, int heads, int ch, int T, int nd) {
-  return B > 0 && heads > 0 && ch > 0 && ch <= 104 && T > 0 && nd > 0 && nd <= 64 &&
+  return B > 0 && heads > 0 && ch > 0 && ch <= 104 && T > 0 && nd >= 0 && nd <= 64 &&
          (int64_t)B * heads <= 0x7fffffff && (T + 63) / 64 <= 65535;
 }
 
@@ -460,22 +461,45 @@ static int lsg_launch(K kern, const LsGenArgs& a, int B, size_t lds, void* strea
 
 extern "C" int rfx_localstate_gen_fwd(const float* q, const float* k, const float* cont, const float* qd, int32_t B,
                                       int32_t heads, int32_t ch, int32_t T, int32_t nd, float* stat, float* out, void* stream) {
-  if (!q || !k || !cont || !qd || !stat || !out || !lsg_ok(B, heads, ch, T, nd)) return -1;
+  if (!q || !k || !cont || !qd || !stat || !out || nd <= 0 || !lsg_ok(B, heads, ch, T, nd)) return -1;
   LsGenArgs a{};
   a.q = q; a.k = k; a.cont = cont; a.qd = qd; a.stat = stat; a.o = out;
-  a.heads = heads; a.ch = ch; a.T = T; a.nd = nd;
+  a.heads = heads; a.ch = ch; a.T = T; a.nd = nd; a.diag = 1;
   return lsg_launch(localstate_gen_q_kernel<0>, a, B, sizeof(float) * 5 * ch * 64, stream);
 }
 
 extern "C" int rfx_localstate_gen_bwd(const float* q, const float* k, const float* cont, const float* qd, float* stat,
                                       const float* out, const float* gout, int32_t B, int32_t heads, int32_t ch, int32_t T,
                                       int32_t nd, float* dq, float* dk, float* dcont, float* dqd, void* stream) {
-  if (!q || !k || !cont || !qd || !stat || !out || !gout || !dq || !dk || !dcont || !dqd || !lsg_ok(B, heads, ch, T, nd)) return -1;
+  if (!q || !k || !cont || !qd || !stat || !out || !gout || !dq || !dk || !dcont || !dqd || nd <= 0 || !lsg_ok(B, heads, ch, T, nd)) return -1;
   LsGenArgs a{};
   a.q = q; a.k = k; a.cont = cont; a.qd = qd; a.stat = stat; a.out = out; a.gout = gout;
   a.dq = dq; a.dk = dk; a.dcont = dcont; a.dqd = dqd;
-  a.heads = heads; a.ch = ch; a.T = T; a.nd = nd;
+  a.heads = heads; a.ch = ch; a.T = T; a.nd = nd; a.diag = 1;
   int rc = lsg_launch(localstate_gen_q_kernel<1>, a, B, sizeof(float) * 5 * ch * 64, stream);     // writes stat.delta first
+  if (rc) return rc;
+  return lsg_launch(localstate_gen_k_kernel, a, B, sizeof(float) * (6 * ch * 64 + 256), stream);
+}
+
+// Plain multi-head scaled-dot-product attention on the same streaming kernels (no decay penalty, no diagonal mask):
+//   out[c, s] = sum_t softmax_t(<k[:, t], q[:, s]> / sqrt(ch)) v[c, t]        q, k, v: (B, heads * ch, T) channel-major
+// nn.MultiheadAttention core of asteroid's DPTNet `ImprovedTransformedLayer` (reference remfx/models.py:327-344).
+extern "C" int rfx_mha_fwd(const float* q, const float* k, const float* v, int32_t B, int32_t heads, int32_t ch, int32_t T, float* stat,
+                           float* out, void* stream) {
+  if (!q || !k || !v || !stat || !out || !lsg_ok(B, heads, ch, T, 0)) return -1;
+  LsGenArgs a{};
+  a.q = q; a.k = k; a.cont = v; a.qd = nullptr; a.stat = stat; a.o = out;
+  a.heads = heads; a.ch = ch; a.T = T; a.nd = 0; a.diag = 0;
+  return lsg_launch(localstate_gen_q_kernel<0>, a, B, sizeof(float) * 5 * ch * 64, stream);
+}
+extern "C" int rfx_mha_bwd(const float* q, const float* k, const float* v, float* stat, const float* out, const float* gout, int32_t B,
+                           int32_t heads, int32_t ch, int32_t T, float* dq, float* dk, float* dv, void* stream) {
+  if (!q || !k || !v || !stat || !out || !gout || !dq || !dk || !dv || !lsg_ok(B, heads, ch, T, 0)) return -1;
+  LsGenArgs a{};
+  a.q = q; a.k = k; a.cont = v; a.qd = nullptr; a.stat = stat; a.out = out; a.gout = gout;
+  a.dq = dq; a.dk = dk; a.dcont = dv; a.dqd = nullptr;
+  a.heads = heads; a.ch = ch; a.T = T; a.nd = 0; a.diag = 0;
+  int rc = lsg_launch(localstate_gen_q_kernel<1>, a, B, sizeof(float) * 5 * ch * 64, stream);
   if (rc) return rc;
   return lsg_launch(localstate_gen_k_kernel, a, B, sizeof(float) * (6 * ch * 64 + 256), stream);
 }

@@ -256,6 +256,40 @@ extern "C" int rfx_act_add_fwd(const float* x, const float* res, float* y, int64
   RFX_CHECK_LAUNCH();
   return 0;
 }
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const f32x4 u = rfx_ld4(a + i), v = rfx_ld4(b + i);
+      rfx_st4(y + i, u * v);
+    } else {
+      for (int64_t k = i; k < n; ++k) y[k] = a[k] * b[k];
+    }
+  }
+}
+extern "C" int rfx_mul(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  if (!a || !b || !y || n < 0) return -1;
+  if (n == 0) return 0;
+  int64_t g = (n + 1023) / 1024;
+  hipLaunchKernelGGL(mul_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope, float* __restrict__ y, int64_t C, int64_t L) {
+  const int64_t row = blockIdx.x;
+  const float s = slope[row % C];
+  const float* xr = x + row * L;
+  float* yr = y + row * L;
+  for (int64_t i = threadIdx.x; i < L; i += blockDim.x) {
+    const float v = xr[i];
+    yr[i] = v >= 0.f ? v : s * v;
+  }
+}
+extern "C" int rfx_prelu_fwd(const float* x, const float* slope, float* y, int64_t N, int64_t C, int64_t L, void* stream) {
+  if (!x || !slope || !y || N <= 0 || C <= 0 || L <= 0 || N * C > 0x7fffffffLL) return -1;
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3((unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, x, slope, y, C, L);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx,
                              float* gslope, int64_t N, int64_t C, int64_t L, void* stream) {
   if (!x || !gy || !slope || !gx || !gslope || N <= 0 || C <= 0 || L <= 0) return -1;

@@ -184,6 +184,27 @@ class DCUNetModel(_RemovalWrapper):
         return self.model(x.squeeze(1))
 
 
+class DPTNetModel(_RemovalWrapper):
+    """models.py:327-344: asteroid DPTNet (cfg/model/dptnet.yaml) + MRSTFT + 100 L1; no target crop (the network pads / crops
+    its output to the input length)."""
+
+    def __init__(self, sample_rate, num_bins, **kwargs):
+        super().__init__()
+        from .dptnet import DPTNet
+        self.model = DPTNet(**kwargs)
+        self.num_bins = num_bins
+        self.mrstftloss = MultiResolutionSTFTLoss(n_bins=num_bins, sample_rate=sample_rate)
+        self.l1loss = L1Loss()
+
+    def forward(self, batch):
+        x, target = batch
+        output = self.model(x.squeeze(1))                      # (B, 1, T)
+        return self._loss(output, target), output
+
+    def sample(self, x: Tensor) -> Tensor:
+        return self.model(x.squeeze(1))
+
+
 def mixup(x: torch.Tensor, y: torch.Tensor, alpha: float = 1.0):
     """models.py:393-420: per-item lambda ~ U(0.25, 0.75), applied with probability 0.5; labels are
     the logical OR of the two clips (not a lambda blend)."""

@@ -258,68 +258,111 @@ def add(x, y, alpha=1.0):
 
 
 class _DConvLayerFn(torch.autograd.Function):
-    """One depth-layer of the Hybrid Demucs DConv branch as ONE launch per direction (csrc/dconv.hip):
-    x + scale * GLU(GN(conv1x1(GELU(GN(conv3_dilated(x)))))) on (N, C, 256) samples, bf16 arithmetic.  Only the layer INPUT is
-    saved; the backward launch recomputes the forward, returns dL/dx, the LayerScale / GroupNorm gradients (per-workgroup partial
-    rows summed here) and hands dz / a / dh to the two weight-gradient GEMMs."""
+    """One depth-layer of the Hybrid Demucs DConv branch, forward in ONE launch (csrc/dconv.hip):
+    x + scale * GLU(GN(conv1x1(GELU(GN(conv3_dilated(x)))))) on (N, 48, 256) samples, bf16 arithmetic.  In training the kernel
+    also stores h / z (bf16), a and the GroupNorm statistics; the backward is the layer-by-layer one on the existing kernels
+    (GroupNorm backward x2, input-gradient GEMM x2, weight-gradient GEMM x2), in the order autograd would run them."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, dil, eps):
         ops._req(x, "x")
         N, Cc, T = x.shape
+        H = Cc // 4
         out = torch.empty_like(x)
+        need = any(ctx.needs_input_grad)
+        h16 = z16 = a_out = stats = None
+        if need:
+            h16 = torch.empty((N, H, T), device=x.device, dtype=torch.bfloat16)
+            z16 = torch.empty((N, 2 * Cc, T), device=x.device, dtype=torch.bfloat16)
+            a_out = torch.empty((N, H, T), device=x.device, dtype=torch.float32)
+            stats = torch.empty((4, N), device=x.device, dtype=torch.float32)
         check(_lib.lib().rfx_dconv_layer_fwd(_ptr(x), _ptr(out), N, Cc, T, dil, _ptr(w1), _ptr(b1), _ptr(g1w), _ptr(g1b),
-                                             _ptr(w2), _ptr(b2), _ptr(g2w), _ptr(g2b), _ptr(scale), float(eps), _stream()),
-              "rfx_dconv_layer_fwd")
-        ctx.save_for_backward(x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale)
-        ctx.cfg = (dil, float(eps))
+                                             _ptr(w2), _ptr(b2), _ptr(g2w), _ptr(g2b), _ptr(scale), float(eps), _ptr(h16),
+                                             _ptr(z16), _ptr(a_out), _ptr(stats), _stream()), "rfx_dconv_layer_fwd")
+        if need:
+            ctx.save_for_backward(x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, h16, z16, a_out, stats)
+            ctx.cfg = (dil,)
         return out
 
     @staticmethod
-    def backward(ctx, g):
-        x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale = ctx.saved_tensors
-        dil, eps = ctx.cfg
+    def backward(ctx, gy):
+        x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, h16, z16, a_out, stats = ctx.saved_tensors
+        (dil,) = ctx.cfg
         N, Cc, T = x.shape
         H = Cc // 4
-        g = g.contiguous()
         L = _lib.lib()
-        gx = torch.empty_like(x)
-        dz = torch.empty((N, 2 * Cc, T), device=x.device, dtype=torch.bfloat16)
-        a_out = torch.empty((N, H, T), device=x.device, dtype=torch.float32)
-        dh = torch.empty((N, H, T), device=x.device, dtype=torch.bfloat16)
-        partial = torch.empty((L.rfx_dconv_layer_bwd_rows(N), 5 * Cc + 2 * H), device=x.device, dtype=torch.float32)
-        check(L.rfx_dconv_layer_bwd(_ptr(x), _ptr(g), _ptr(gx), N, Cc, T, dil, _ptr(w1), _ptr(b1), _ptr(g1w), _ptr(g1b), _ptr(w2),
-                                    _ptr(b2), _ptr(g2w), _ptr(g2b), _ptr(scale), eps, _ptr(dz), _ptr(a_out), _ptr(dh), _ptr(partial),
-                                    _stream()), "rfx_dconv_layer_bwd")
-        ps = partial.sum(0)
-        dscale, dg2w, dg2b = ps[:Cc], ps[Cc:3 * Cc], ps[3 * Cc:5 * Cc]
-        dg1w, dg1b = ps[5 * Cc:5 * Cc + H], ps[5 * Cc + H:]
-        # weight / bias gradients of the two convolutions on the existing wgrad kernels (side stream + in place when a GradSink is armed)
-        dw2, db2 = ops.conv2d_wgrad(a_out.unsqueeze(2), dz.unsqueeze(2), (2 * Cc, H, 1, 1), (1, 1), (0, 0), (1, 1), True, w2, b2)
-        dw1, db1 = ops.conv2d_wgrad(x.unsqueeze(2), dh.unsqueeze(2), (H, Cc, 1, 3), (1, 1), (0, dil), (1, dil), True, w1, b1)
+        gy = gy.contiguous()
+        # GroupNorm(1, 2C) + GLU + LayerScale backward (mode 3): dz (bf16), dgamma2 / dbeta2 / dscale; the residual passes gy on
+        dz = torch.empty_like(z16)
+        dg2w, dg2b, dscale = torch.empty_like(g2w), torch.empty_like(g2b), torch.empty_like(scale)
+        work = torch.empty(N * 2 * Cc * 2 + N * Cc + N * 2, device=x.device, dtype=torch.float32)
+        check(L.rfx_groupnorm_bwd_x16(_ptr(z16), _ptr(g2w), _ptr(g2b), _ptr(stats[2]), _ptr(stats[3]), _ptr(gy), N, 2 * Cc, T, 1, 3,
+                                      _ptr(scale), _ptr(work), _ptr(dz), _ptr(dg2w), _ptr(dg2b), _ptr(dscale), _stream()),
+              "rfx_groupnorm_bwd")
+        # 1x1 convolution: da = W2^T dz;  dW2, db2
+        w24 = w2.reshape(2 * Cc, H, 1, 1)
+        a4, dz4 = a_out.unsqueeze(2), dz.unsqueeze(2)
+        da = ops.conv2d_dgrad(dz4, w24, tuple(a4.shape), tuple(a4.stride()), (1, 1), (0, 0), (1, 1)).squeeze(2)
+        dw2, db2 = ops.conv2d_wgrad(a4, dz4, (2 * Cc, H, 1, 1), (1, 1), (0, 0), (1, 1), True, w2, b2)
+        # GroupNorm(1, H) + GELU backward (mode 1): dh (bf16), dgamma1 / dbeta1
+        dh = torch.empty_like(h16)
+        dg1w, dg1b = torch.empty_like(g1w), torch.empty_like(g1b)
+        work1 = torch.empty(N * H * 2 + N * (H // 2) + N * 2, device=x.device, dtype=torch.float32)
+        check(L.rfx_groupnorm_bwd_x16(_ptr(h16), _ptr(g1w), _ptr(g1b), _ptr(stats[0]), _ptr(stats[1]), _ptr(da), N, H, T, 1, 1,
+                                      None, _ptr(work1), _ptr(dh), _ptr(dg1w), _ptr(dg1b), None, _stream()), "rfx_groupnorm_bwd")
+        # dilated convolution: dx = W1^T * dh + gy (the residual rides in the GEMM's store);  dW1, db1
+        w14 = w1.reshape(H, Cc, 1, 3)
+        x4, dh4 = x.unsqueeze(2), dh.unsqueeze(2)
+        dx = ops.conv2d_dgrad(dh4, w14, tuple(x4.shape), tuple(x4.stride()), (1, 1), (0, dil), (1, dil), res=gy.unsqueeze(2)).squeeze(2)
+        dw1, db1 = ops.conv2d_wgrad(x4, dh4, (H, Cc, 1, 3), (1, 1), (0, dil), (1, dil), True, w1, b1)
         if dw2 is not None:
             dw2, dw1 = dw2.view_as(w2), dw1.view_as(w1)
-        return gx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None
+        return dx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None
 
 
 DCONV_FUSED = True            # bench.py --no-fused-dconv flips it for A/B runs
 
 
 def dconv_layer_fused_ok(x, hidden, kernel_size, dil, need_grad):
-    """Shapes / mode the fused DConv layer kernels take (csrc/dconv.hip): bf16 arithmetic, contiguous fp32 (N, C, 256) with
-    C = 48 (C = 96 forward-only), hidden = C / 4, kernel 3, dilation 1 or 2."""
+    """Shapes / mode the fused DConv layer kernel takes (csrc/dconv.hip): bf16 arithmetic, contiguous fp32 (N, 48, 256),
+    hidden = 12, kernel 3, dilation 1 or 2."""
     if not DCONV_FUSED or ops.GEMM_PREC != 2 or x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
         return False
     Cc, T = x.shape[1], x.shape[2]
-    if hidden * 4 != Cc or kernel_size != 3 or not _lib.lib().rfx_dconv_layer_ok(Cc, T, dil):
-        return False
-    return Cc == 48 or not need_grad
+    return hidden * 4 == Cc and kernel_size == 3 and bool(_lib.lib().rfx_dconv_layer_ok(Cc, T, dil))
 
 
 def dconv_layer(x, conv1, gn1, conv2, gn2, scale, dil):
     """conv1 / conv2: nn.Conv1d parameter containers, gn1 / gn2: nn.GroupNorm(1, .), scale: the LayerScale vector."""
     return _DConvLayerFn.apply(x, conv1.weight, conv1.bias, gn1.weight, gn1.bias, conv2.weight, conv2.bias, gn2.weight, gn2.bias,
                                scale, int(dil), float(gn1.eps))
+
+
+class _MulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ops._req(a, "a"); ops._req(b, "b")
+        a, b = a.contiguous(), b.contiguous()
+        if a.shape != b.shape:
+            raise ValueError("mul: equal shapes")
+        y = torch.empty_like(a)
+        check(_lib.lib().rfx_mul(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()), "rfx_mul")
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        check(_lib.lib().rfx_mul(_ptr(g), _ptr(b), _ptr(ga), a.numel(), _stream()), "rfx_mul")
+        check(_lib.lib().rfx_mul(_ptr(g), _ptr(a), _ptr(gb), a.numel(), _stream()), "rfx_mul")
+        return ga, gb
+
+
+def mul(a, b):
+    """a * b elementwise (equal shapes) with gradients to both."""
+    return _MulFn.apply(a, b)
 
 
 def row_standardize(x, eps):

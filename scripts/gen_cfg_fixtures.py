@@ -26,6 +26,8 @@ COMMANDS = {
     "config5_remfx_detect": ["+exp=remfx_detect"],
     "cls_5-5_full_cls": ["+exp=5-5_full_cls"],
     "cls_mixup": ["+exp=5-5_full_cls", "model=cls_panns_48k_mixup"],
+    "dptnet": ["+exp=distortion", "model=dptnet"],                            # asteroid DPTNet removal network
+    "cls_vggish": ["+exp=5-5_full_cls", "model=cls_vggish"],                  # HEAR-embedding classifier head
     "cls_dynamic": ["+exp=5-5_full_cls_dynamic", "model=cls_panns_48k"],      # DynamicEffectDataset: on-the-fly effect rendering
     "cls_16k": ["+exp=5-5_full_cls", "model=cls_panns_16k"],
     "remfx_all": ["+exp=remfx_all"],

@@ -245,7 +245,7 @@ def test_hear_embedding_classifiers(cls_name, dim, rate):
     loss = model.training_step((x, None, None, lab), 0)
     lref = torch.nn.functional.cross_entropy(ref, lab, label_smoothing=0.1)
     check(abs(float(loss) - float(lref)), 2e-4, max(1.0, float(lref)))
-    probs = torch.sigmoid(ref)
+    probs = torch.sigmoid(logits.detach())               # the metric is defined on the model's own outputs (a bf16 session may flip a borderline one)
     for k, name in enumerate(model.effects):
         pred, t = (probs[:, k] > 0.5), lab[:, k] > 0.5
         tp, fp, fn = float((pred & t).sum()), float((pred & ~t).sum()), float((~pred & t).sum())

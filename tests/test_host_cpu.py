@@ -223,6 +223,25 @@ def test_reference_configs_instantiate(name, recwarn):
         assert list(cfg["inference_effects_ordering"]) == [n for n in cfg["inference_effects_ordering"] if n in models.ALL_EFFECT_NAMES]
 
 
+def test_dptnet_and_hear_configs_instantiate():
+    """cfg/model/dptnet.yaml builds the DPTNet removal wrapper with asteroid's state_dict names (83 tensors, 2 851 393 parameters
+    -- the oracle restatement's count); cfg/model/cls_vggish.yaml needs the pretrained HEAR package, absent here: ImportError,
+    as upstream's module import would fail."""
+    from oracle import ref_dptnet
+    from remfx_amd import config, models
+    cfg = _composed()["dptnet"]["cfg"]
+    model = config.instantiate(cfg["model"])
+    assert isinstance(model.model, models.DPTNetModel)
+    net = model.model.model
+    kw = {k: v for k, v in cfg["model"]["network"].items() if k not in ("_target_", "num_bins")}
+    ref = ref_dptnet.DPTNet(**{**kw, "sample_rate": 48000})
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys()) and len(ref.state_dict()) == 83
+    assert sum(p.numel() for p in net.parameters()) == sum(p.numel() for p in ref.parameters()) == 2851393
+    net.load_state_dict(ref.state_dict(), strict=True)
+    with pytest.raises(ImportError, match="hearbaseline"):
+        config.instantiate(_composed()["cls_vggish"]["cfg"]["model"])
+
+
 def test_dynamic_effect_config_instantiates():
     """cfg/exp/5-5_full_cls_dynamic.yaml (on-the-fly augmentation): the train split is a DynamicEffectDataset holding the
     five effect objects and a -20 LUFS normaliser (datasets.py:205-262); val / test stay EffectDatasets."""
