@@ -63,6 +63,8 @@ class MelSpectrogram(nn.Module):
 
 def _iid_span(n, size, mask_param, device):
     """torchaudio mask_along_axis_iid bookkeeping: per row, length ~ U[0, mask_param), start ~ U[0, size - length)."""
+    if mask_param > size:                       # torchaudio.functional.mask_along_axis_iid raises here too
+        raise ValueError(f"mask_param ({mask_param}) must not be longer than the axis ({size})")
     value = torch.rand(n, device=device) * mask_param
     start = (torch.rand(n, device=device) * (size - value)).long()
     return start.int(), (start + value.long()).int()

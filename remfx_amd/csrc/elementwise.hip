@@ -418,7 +418,8 @@ __global__ void span_mask_kernel(float* __restrict__ x, int F, int T, const int3
                                  const int32_t* __restrict__ t1) {
   const int r = blockIdx.y, f = blockIdx.x;
   const bool frow = f >= f0[r] && f < f1[r];
-  const int ta = frow ? 0 : t0[r], tb = frow ? T : t1[r];
+  int ta = frow ? 0 : t0[r], tb = frow ? T : t1[r];
+  ta = ta < 0 ? 0 : ta; tb = tb > T ? T : tb;             // spans are clamped to the row
   float* row = x + ((int64_t)r * F + f) * T;
   for (int t = ta + threadIdx.x; t < tb; t += blockDim.x) row[t] = 0.f;
 }

@@ -263,6 +263,8 @@ def gemm_wgrad(dp, x, g, dapack):
                                        GEMM_PREC, _stream())
         if rc == 0:
             return
+        if rc != -1:                                         # -1 = "plan not supported by the 16-bit path"; anything else is a real failure
+            check(rc, "rfx_gemm_wgrad")
         g = g.float()                                        # a plan the wide-load kernel does not take: widen once
     check(_lib.lib().rfx_gemm_wgrad(C.byref(dp.desc), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(dapack),
                                     GEMM_PREC, _stream()), "rfx_gemm_wgrad")

@@ -119,15 +119,24 @@ class FlatAdamW:
             self.step_count = int(sd["step"]); self.param_groups[0]["lr"] = float(sd["lr"])
             return
         f = self.flat
-        if len(sd["state"]) not in (0, len(f.params)):
-            raise ValueError(f"optimizer state has {len(sd['state'])} parameters, the model {len(f.params)}")
-        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
-            st = sd["state"].get(i)
-            if st is None:
-                continue
+        # torch / Lightning key the state by the parameter's position in the optimiser's param list, which may hold parameters this
+        # flat buffer does not (frozen ones: no state entry).  Entries are matched to the trainable parameters IN ORDER and by
+        # SHAPE; anything that does not line up is an error, never a silent skip.
+        ids = list(sd["param_groups"][0].get("params", range(len(f.params))))
+        entries = [(i, sd["state"][i]) for i in ids if i in sd["state"]]
+        if entries and len(entries) != len(f.params):
+            raise ValueError(f"optimizer state holds {len(entries)} parameters with moments, the model has {len(f.params)} trainable ones")
+        steps = set()
+        for (i, st), (p, o) in zip(entries, zip(f.params, f.offsets)):
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state entry {i}: moment shape {tuple(st['exp_avg'].shape)} != parameter shape {tuple(p.shape)}")
             self.m[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
             self.v[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
-            self.step_count = int(float(st["step"]))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"optimizer state entries disagree on the step count: {sorted(steps)}")
+        if steps:
+            self.step_count = steps.pop()
         g = sd["param_groups"][0]
         self.param_groups[0]["lr"] = float(g["lr"])
         self.betas, self.eps, self.weight_decay = tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])

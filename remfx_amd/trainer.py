@@ -37,8 +37,17 @@ PRECISIONS = {"32": "f32", "32-true": "f32", "bf16-mixed": "bf16", "bf16": "bf16
 
 
 def _check_lstm(where):
+    """Raise on EVERY rank when any rank's recurrence kernel timed out (a rank raising alone would leave the others hung in
+    the next collective): the flag is max-reduced over the process group first."""
     from . import lstm as _lstm
-    if _lstm.error_flag():
+    bad = _lstm.error_flag()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([1.0 if bad else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad = bool(t.item() > 0)
+    if bad:
         raise RuntimeError(f"LSTM recurrence kernel reported a spin time-out ({where}): the step's outputs are invalid")
 
 
@@ -74,10 +83,17 @@ class Trainer:
         self.device = torch.device("cuda", self.local_rank) if accelerator in ("gpu", "cuda") or (
             accelerator is None and torch.cuda.is_available()) else torch.device("cpu")
 
+    _MODE_BEFORE_BF16 = None        # the library mode a bf16-mixed trainer replaced (restored by the next precision=32 trainer)
+
     def _apply_precision(self):
+        from . import ops
         if self.gemm_mode is not None:
-            from . import ops
+            if ops.gemm_precision() != self.gemm_mode and Trainer._MODE_BEFORE_BF16 is None:
+                Trainer._MODE_BEFORE_BF16 = ops.gemm_precision()
             ops.set_gemm_precision(self.gemm_mode)
+        elif Trainer._MODE_BEFORE_BF16 is not None:      # precision=32 after a bf16-mixed trainer in the same process
+            ops.set_gemm_precision(Trainer._MODE_BEFORE_BF16)
+            Trainer._MODE_BEFORE_BF16 = None
 
     def _to(self, batch):
         return tuple(t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
@@ -132,6 +148,8 @@ class Trainer:
         sync = ddp.GradSync(opt.flat)
         last = {}
         last_path = os.path.join(ckpt_dir, "last.ckpt") if ckpt_dir else None
+        # ModelCheckpoint(monitor="valid_loss", mode="min") of the reference's cfg/config.yaml callbacks: best.ckpt next to last.ckpt
+        self.best_path, self.best_score, self._best_state = (os.path.join(ckpt_dir, "best.ckpt") if ckpt_dir else None), None, None
         while self.global_step < self.max_steps and (self.max_epochs < 0 or self.current_epoch < self.max_epochs):
             model.train()
             if hasattr(datamodule, "set_epoch"):
@@ -161,6 +179,13 @@ class Trainer:
                         model.validation_step(self._to(batch), i)
                 _check_lstm("validation")
                 last.update(self._log(model))
+                score = last.get("valid_loss")
+                if score is not None and (self.best_score is None or float(score) < self.best_score):
+                    self.best_score = float(score)
+                    if self.best_path:
+                        self.save_checkpoint(self.best_path, model, opt, sched)
+                    else:                                        # no checkpoint directory: keep the weights in memory
+                        self._best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
             if last_path:
                 self.save_checkpoint(last_path, model, opt, sched)
         if last_path:
@@ -174,7 +199,14 @@ class Trainer:
         self._apply_precision()
         model.trainer = self
         model.to(self.device)
-        if ckpt_path and ckpt_path != "best":                    # "best": the in-memory weights of the fit that just ended
+        if ckpt_path == "best":           # the best-by-validation-loss weights of the fit that just ended (Lightning's ckpt_path="best")
+            best = getattr(self, "best_path", None)
+            if best and os.path.exists(best):
+                model.load_state_dict(load_checkpoint_file(best, map_location=self.device)["state_dict"])
+            elif getattr(self, "_best_state", None) is not None:
+                model.load_state_dict(self._best_state)
+            # no validation ran: the last-step weights, as Lightning falls back to
+        elif ckpt_path:
             ck = load_checkpoint_file(ckpt_path, map_location=self.device)
             if ck is not None:
                 model.load_state_dict(ck["state_dict"])
