@@ -550,7 +550,29 @@ extern "C" int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stre
 
 template <typename K>
 static int lstm_launch(K kernel, LstmArgs a, void* ws, void* stream) {
-  const int H = a.H, nwc = H / 32, ntiles = (a.Bn + 31) / 32, mc = lstm_max_clusters(H);
+  const int H = a.H, nwc = H / 32, ntiles = (a.Bn + 31) / 32;
+  int mc = lstm_max_clusters(H);
+  // the waves of a launch wait for each other: the bound must hold for THIS instantiation (the register-resident forms use more
+  // VGPRs than the generic kernels lstm_max_clusters asks about); a launch that cannot be co-resident is refused, not attempted
+  {
+    static thread_local const void* seen[16];
+    static thread_local int seen_mc[16], seen_h[16];
+    static thread_local int nseen = 0;
+    int i = 0;
+    for (; i < nseen; ++i) if (seen[i] == reinterpret_cast<const void*>(kernel) && seen_h[i] == H) break;
+    if (i == nseen && nseen < 16) {
+      int dev = 0, ncu = 0, occ = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 64, lstm_smem_bytes(H)) != hipSuccess) return -3;
+      int waves = ncu * occ;
+      if (waves > RFX_LSTM_MAX_WAVES) waves = RFX_LSTM_MAX_WAVES;
+      seen[nseen] = reinterpret_cast<const void*>(kernel);
+      seen_h[nseen] = H;
+      seen_mc[nseen] = (waves / nwc) & ~7;
+      ++nseen;
+    }
+    if (i < nseen && seen_mc[i] < mc) mc = seen_mc[i];
+  }
   if (mc < 8) return -4;
   const size_t smem = lstm_smem_bytes(H);
   unsigned char* w = reinterpret_cast<unsigned char*>(ws);
