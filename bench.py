@@ -497,6 +497,26 @@ def main():
                 "bf16x3": "gemm_tap_kernel<R,1> + gemm_tap_stream_kernel<1,..> (tap-major gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per K step)",
                 "bf16": "gemm_tap_kernel<R,2[,IN16]> + gemm_tap_stream_kernel<2,..> (tap-major gather-GEMM, 1 x v_mfma_f32_32x32x16_bf16 per K step)"}[args.gemm]
     kms, klaunches, cls, ridge, kern = timer.result(peak, PEAK_HBM_GBS)
+    # The timed region runs weight-gradient GEMMs on a second stream (ops.GradSink), so a forward-family launch shares the machine
+    # with them and its event-timed duration is a CONCURRENT one.  For the kernel's own efficiency, time a few extra steps with
+    # everything on the compute stream (not part of `value`): roofline.exclusive.
+    excl = None
+    sink = getattr(opt.flat, "sink", None)
+    if rank == 0 and world == 1 and sink is not None and sink.side is not None and not args.no_also:
+        timer2 = KernelTimer(ops.PREC_NAMES[args.gemm])
+        timer2.install()
+        side, sink.side = sink.side, None
+        try:
+            step(20_000)
+            torch.cuda.synchronize()
+            timer2.enabled = True
+            for i in range(3):
+                step(20_001 + i)
+            torch.cuda.synchronize()
+            timer2.enabled = False
+        finally:
+            sink.side = side
+        excl = timer2.result(peak, PEAK_HBM_GBS)[4]
     if args.dump_launches:         # per-launch plan + algorithmic work + event time, in launch order (scripts/join_launch_pmc.py)
         json.dump([dict(d, ms=s.elapsed_time(e), flops=fl, bytes=by) for d, (s, e, fl, by, _) in zip(timer.desc, timer.launches)],
                   open(args.dump_launches, "w"))
@@ -535,6 +555,14 @@ def main():
             row["traffic_ge_algorithmic"] = bool(row["traffic"] >= 0.9 * row["algorithmic_bytes_per_launch"])
         by_kernel.append(row)
     dom = by_kernel[0] if by_kernel else {"kernel": None, "bound": "hbm", "frac": 0.0}
+    exclusive = None
+    if excl and dom.get("kernel") in excl:
+        ms_, fl_, by_, n_ = excl[dom["kernel"]]
+        tf, gb = fl_ / (ms_ * 1e-3) / 1e12, by_ / (ms_ * 1e-3) / 1e9
+        exclusive = {"note": "same kernel, 3 extra steps with the weight-gradient GEMMs on the compute stream (no concurrent stream)",
+                     "avg_launch_us": round(ms_ / n_ * 1e3, 2), "tflops": round(tf, 2), "gbs": round(gb, 1),
+                     "frac_mfma": round(tf / peak, 4), "frac_hbm": round(gb / PEAK_HBM_GBS, 4),
+                     "frac": round(max(tf / peak, gb / PEAK_HBM_GBS), 4)}
     fam = _price(kms, tot_fl, tot_by, klaunches)
     fam_traffic = None
     if pmc:
@@ -576,6 +604,7 @@ def main():
                      "algorithmic_flops_per_launch": dom.get("algorithmic_flops_per_launch"),
                      "launches_per_step": dom.get("launches_per_step"), "avg_launch_us": dom.get("avg_launch_us"),
                      "ms_per_step": dom.get("ms_per_step"), "share_of_step": round(dom.get("ms_per_step", 0.0) / (dt / args.steps * 1e3), 3),
+                     "concurrent_streams": 2 if (sink is not None and sink.side is not None) else 1, "exclusive": exclusive,
                      "ridge_flop_per_byte": round(ridge, 1), "by_kernel": by_kernel,
                      "family": dict(fam, kernel=fam_name, traffic=fam_traffic, share_of_step=round(kms / (dt * 1e3), 3)),
                      "by_bound": {"mfma": _price(*cls["mfma"]), "hbm": _price(*cls["hbm"])}},

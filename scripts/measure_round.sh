@@ -4,14 +4,14 @@
 # SEPARATE runs, counters only + kernel trace: rocprofv3 must not combine --pmc with other trace domains on this pool)
 # (the stats cover 2 warm-up + 4 timed steps = 6 steps) turned into the per-kernel HBM traffic JSON, and the bench lines of every workload.  Copy the summaries you want judged
 # into profiles/ afterwards (gpurun_out/ is scratch).
-R=${1:-r02}; MODE=${2:-bf16}
+R=${1:-r03}; MODE=${2:-bf16}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$MODE -o kt -- python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --gemm $MODE > $OUT/kt_$MODE.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$MODE -o kt -- python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-also --gemm $MODE > $OUT/kt_$MODE.log 2>&1
 find $OUT/kt_$MODE -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_demucs_b64_kernel_stats_$MODE.csv \;
 rm -rf $OUT/kt_$MODE
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o r -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --gemm $MODE > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o r -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-also --gemm $MODE > $OUT/pmc_$c.log 2>&1
   find $OUT/pmc_$c -name "*counter_collection.csv" -exec cp {} $OUT/pmc_$c.csv \;
   rm -rf $OUT/pmc_$c
 done
@@ -19,9 +19,12 @@ cd $ROOT
 python scripts/collect_pmc.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json 2
 rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv
 python scripts/prof_summary.py $OUT/${R}_demucs_b64_kernel_stats_$MODE.csv 6 40 $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json > $OUT/${R}_demucs_b64_summary_$MODE.md
-python bench.py --gemm $MODE > $OUT/bench_demucs_$MODE.json 2> $OUT/bench_demucs_$MODE.err
+cp $OUT/${R}_demucs_b64_pmc_traffic_$MODE.json profiles/ 2>/dev/null    # bench.py joins its per-kernel table with the newest PMC pass
+python bench.py --steps 20 --warmup 5 --gemm $MODE > $OUT/bench_demucs_$MODE.json 2> $OUT/bench_demucs_$MODE.err
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also --sink main --gemm $MODE 2>> $OUT/bench_demucs_$MODE.err | tail -1 > $OUT/bench_demucs_${MODE}_sinkmain.json
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also --sink off --no-fused-dconv --gemm $MODE 2>> $OUT/bench_demucs_$MODE.err | tail -1 > $OUT/bench_demucs_${MODE}_r02path.json
 python bench.py --workload demucs_fwd --gemm $MODE > $OUT/bench_demucs_fwd_$MODE.json 2>> $OUT/bench_demucs_$MODE.err
-for w in tcn dcunet umx chain; do
-  python bench.py --workload $w --no-cpu-baseline --gemm $MODE 2>> $OUT/bench_demucs_$MODE.err | tail -1 > $OUT/bench_${w}_$MODE.json
+for w in tcn dcunet umx chain; do     # their BASELINE configs are fp32: default arithmetic = fp32 parity (bf16x3)
+  python bench.py --workload $w --no-cpu-baseline 2>> $OUT/bench_demucs_$MODE.err | tail -1 > $OUT/bench_${w}_bf16x3.json
 done
 grep -ho '"ms_per_step": [0-9.]*' $OUT/bench_*_$MODE.json | tr '\n' ' '
