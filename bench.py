@@ -406,6 +406,9 @@ def main():
                     choices=["demucs", "tcn", "dcunet", "umx", "chain", "demucs_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat", type=int, default=3,
+                    help="extra UNTIMED steps before the W warm-up steps: the first process on a fresh box runs its first ~1-2 s of "
+                         "steps up to 10 %% slower (measured: 175 / 167 ms with W = 3 / 4 against 158 ms steady state)")
     ap.add_argument("--sink", default="side", choices=["side", "main", "off"],
                     help="parameter-gradient sink (ops.GradSink) A/B: side stream (default) / compute stream / autograd accumulation")
     ap.add_argument("--no-fused-dconv", action="store_true", help="A/B: layer-by-layer DConv instead of the fused kernels (csrc/dconv.hip)")
@@ -427,6 +430,8 @@ def main():
         # 32 x 262144 TCN activations fill ~190 of the 288 GB: the caching allocator settles only after its one
         # "free everything and retry" event at the start of step 2 (a 5.5 s host stall that is not part of a step)
         args.warmup = 2
+    if args.workload == "tcn":
+        args.preheat = 0                        # 2.5 s per step: the warm-up steps are warm-up enough
 
     from remfx_amd import ddp, ops
     ops.set_gemm_precision(args.gemm)
@@ -471,6 +476,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    for i in range(args.preheat):
+        step(i)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -575,7 +582,7 @@ def main():
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPES[args.gemm],
-        "data": "synthetic",
+        "data": "synthetic", "preheat_steps": args.preheat,
         "config": {"workload": {"tcn": "TCN (cfg/model/tcn.yaml) train step, +exp=reverb model=tcn",
                                 "demucs": "Hybrid Demucs (cfg/model/demucs.yaml) train step, +exp=chorus_aug model=demucs",
                                 "dcunet": "DCUNet Large-DCUNet-20 (cfg/model/dcunet.yaml) train step, +exp=5-5_full model=dcunet",
