@@ -279,6 +279,114 @@ __device__ __forceinline__ void bf16_pair_store(uint16_t* own_pos, bool odd, int
   if (odd ? ok1 : ok0) *reinterpret_cast<uint32_t*>(p) = word;
 }
 
+// ---- lean stores of a FULL tile ------------------------------------------------------------------------------------
+// r03 PMC on the streaming kernel (12 -> 96 channels, 1x1, bf16 output): 392 VALU instructions per 32x32 tile, SQ_ACTIVE_INST_VALU =
+// 57 % of the kernel's time, 2.3 TB/s -- the "bandwidth-class" launches were VALU-bound in the generic epilogue below (per-row 64-bit
+// address arithmetic, per-row validity branches, a 4-instruction software bf16 rounding per value).  When every position of the wave's
+// tile is valid and all 32 R rows are < M (a wave-uniform test) the per-row part of each address is a SCALAR (the soffset operand of a
+// raw buffer store: (row constant) * channel stride), the per-lane part is computed once per tile, and the rounding is
+// v_cvt_pk_bf16_f32 (round-to-nearest-even, bit-equal to bf16_rne on finite values).
+typedef __bf16 rfx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rfx_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rfx_cvt_pk_bf16(float lo, float hi) {
+  const rfx_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rfx_bf16x2));
+}
+// Launch-uniform part of the test (also evaluated on the host: the streaming kernel only takes launches whose EVERY tile qualifies).
+// *records = the buffer's num_records: rows >= M of a partial channel tile are dropped by the hardware range check when every position
+// offset is < the channel stride (a plain NCHW tensor) -- offset = m * cs + position >= M * cs  <=>  m >= M
+static inline __host__ __device__ bool rfx_fast_store_geo(const rfx_gemm_desc& d, int esz, uint32_t* records, bool* partial_ok) {
+  const int64_t posmax = (int64_t)((d.OA - 1) * d.out_sa + d.out_a0) * d.out_as + (int64_t)((d.OB - 1) * d.out_sb + d.out_b0) * d.out_bs;
+  const int64_t maxoff = (int64_t)(d.M - 1) * d.out_cs + posmax;
+  *partial_ok = posmax < d.out_cs && !(d.M & 1);
+  *records = *partial_ok ? (uint32_t)((int64_t)d.M * d.out_cs * esz) : 0x7fffffffu;
+  return d.out_cs > 0 && d.out_as >= 0 && d.out_bs >= 0 && (maxoff + 2) * esz < 0x7fffffffll;
+}
+// 16-bit output: positions j, j + 1 (j even) are adjacent elements of one row, 4-byte aligned, and valid together
+static inline __host__ __device__ bool rfx_pair16_geo(const rfx_gemm_desc& d, const void* out) {
+  return d.out_bf16 && d.out_bs == 1 && d.out_sb == 1 && !((d.OB | d.out_b0) & 1) && !((d.out_ns | d.out_cs | d.out_as) & 1) &&
+         ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
+}
+// does the wave's whole tile qualify?  (wave-uniform)
+__device__ __forceinline__ bool fwd_tile_full(const rfx_gemm_desc& d, const TileCtx& tc, int rows, int esz, uint32_t* records = nullptr) {
+  uint32_t rec; bool partial_ok;
+  const bool geo = rfx_fast_store_geo(d, esz, &rec, &partial_ok);
+  const bool rows_ok = tc.m0 + rows <= d.M || (records && partial_ok);
+  if (records) *records = rec;
+  return geo && rows_ok && __builtin_amdgcn_ballot_w64(!tc.jvalid) == 0;
+}
+
+// plain store of a full tile (+ the moments s1, s2 of the stored values).  pair16: 16-bit output, two positions per store -- even
+// lanes write row r of positions (j, j + 1), odd lanes row r + 1 of positions (j - 1, j); otherwise fp32.  records: see fwd_tile_full.
+template <int R>
+__device__ __forceinline__ void fwd_store_fast_plain(const FwdArgs& g, const TileCtx& tc, const f32x16 (&acc)[R], int64_t opos, bool pair16,
+                                                     uint32_t records, float& s1, float& s2) {
+  const rfx_gemm_desc& d = g.d;
+  const int m0 = tc.m0, h = tc.h;
+  const bool partial = m0 + 32 * R > d.M;               // wave-uniform: rows >= M are dropped by the range check, masked out of the sums
+  char* base = reinterpret_cast<char*>(g.out) + (int64_t)tc.n * d.out_ns * (d.out_bf16 ? 2 : 4);
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)records, 0x00020000);
+  if (pair16) {
+    const bool odd = tc.l31 & 1;
+    const uint32_t csb = (uint32_t)d.out_cs * 2u;
+    const uint32_t vo = (uint32_t)(opos * 2) + (uint32_t)(4 * h) * csb + (odd ? csb - 2u : 0u);
+    const uint32_t sel = odd ? 0x03020706u : 0x05040100u;
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t mc = (uint32_t)__builtin_amdgcn_readfirstlane(m0 + mt * 32 + (r & 3) + 8 * (r >> 2));
+        const uint32_t w = rfx_cvt_pk_bf16(acc[mt][r], acc[mt][r + 1]);
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, false);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(recv, w, sel), rso, vo, mc * csb, 0);
+        float v0 = __uint_as_float(w << 16), v1 = __uint_as_float(w & 0xffff0000u);
+        if (partial && (int)mc + 4 * h >= d.M) { v0 = 0.f; v1 = 0.f; }
+        s1 += v0 + v1; s2 += v0 * v0 + v1 * v1;
+      }
+  } else {
+    const uint32_t csb = (uint32_t)d.out_cs * 4u;
+    const uint32_t vo = (uint32_t)(opos * 4) + (uint32_t)(4 * h) * csb;
+#pragma unroll
+    for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t mc = (uint32_t)__builtin_amdgcn_readfirstlane(m0 + mt * 32 + (r & 3) + 8 * (r >> 2));
+        float v = acc[mt][r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, vo, mc * csb, 0);
+        if (partial && (int)mc + 4 * h >= d.M) v = 0.f;
+        s1 += v; s2 += v * v;
+      }
+  }
+}
+// fused-GLU store of a full tile with a 16-bit conv output: rows (r, r + 1) of a lane are (a, b) of GLU channel ch = m >> 1.  Even lanes
+// store the a row (channel ch) of positions (j, j + 1), odd lanes the b row (channel Ch + ch) of positions (j - 1, j); every lane stores
+// a * sigmoid(b) of its own position (fp32), taken of the STORED (rounded) values as the backward pass will see them.
+template <int R>
+__device__ __forceinline__ void fwd_store_fast_glu(const FwdArgs& g, const TileCtx& tc, const f32x16 (&acc)[R], int64_t opos) {
+  const rfx_gemm_desc& d = g.d;
+  const int m0 = tc.m0, h = tc.h, Ch = d.M >> 1;
+  const bool odd = tc.l31 & 1;
+  const uint32_t csb = (uint32_t)d.out_cs * 2u;
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(g.out) + (int64_t)tc.n * d.out_ns * 2, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(g.e.glu_out) + (int64_t)tc.n * g.e.glu_ns * 4, 0, 0x7fffffff, 0x00020000);
+  const uint32_t vo = (uint32_t)(opos * 2) + (uint32_t)(2 * h) * csb + (odd ? (uint32_t)Ch * csb - 2u : 0u);
+  const uint32_t vg = (uint32_t)(opos * 4) + (uint32_t)(2 * h) * csb * 2u;
+  const uint32_t sel = odd ? 0x03020706u : 0x05040100u;
+#pragma unroll
+  for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const uint32_t chc = (uint32_t)__builtin_amdgcn_readfirstlane((m0 + mt * 32) / 2 + ((r & 3) >> 1) + 4 * (r >> 2));
+      const uint32_t w = rfx_cvt_pk_bf16(acc[mt][r], acc[mt][r + 1]);
+      const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, false);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(recv, w, sel), rso, vo, chc * csb, 0);
+      const float av = __uint_as_float(w << 16), bv = __uint_as_float(w & 0xffff0000u);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av * rfx_sigmoid(bv)), rsg, vg, chc * csb * 2u, 0);
+    }
+}
+
 template <int R, bool FULL = true>
 __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileCtx& tc, f32x16 (&acc)[R]) {
   const rfx_gemm_desc& d = g.d;
@@ -289,8 +397,7 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
   float* outp = g.out + (int64_t)n * d.out_ns + opos;
   uint16_t* outh = reinterpret_cast<uint16_t*>(g.out) + (int64_t)n * d.out_ns + opos;      // d.out_bf16: same element offsets
   // positions j, j + 1 (j even) are adjacent 16-bit elements of one row and valid together (wave-uniform test)
-  const bool pair16 = g.pair_store && d.out_bf16 && d.out_bs == 1 && d.out_sb == 1 && !((d.OB | d.out_b0) & 1) &&
-                      !((d.out_ns | d.out_cs | d.out_as) & 1) && ((reinterpret_cast<uintptr_t>(g.out) & 3) == 0);
+  const bool pair16 = g.pair_store && rfx_pair16_geo(d, g.out);
   const bool odd = l31 & 1;
   const float* resp = nullptr;
   if (e.res)
@@ -407,6 +514,10 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
     // rows (r, r+1) of a lane are (a, b) of one GLU channel c = m >> 1: conv output in natural order + a * sigmoid(b)
     const int Ch = d.M >> 1;
     float* gl = e.glu_out + (int64_t)n * e.glu_ns + opos;
+    if (pair16 && fwd_tile_full(d, tc, 32 * R, 4)) {
+      fwd_store_fast_glu<R>(g, tc, acc, opos);
+      return;
+    }
     if (pair16) {                     // all lanes take part in the exchange; validity only gates the stores
 #pragma unroll
       for (int mt = 0; mt < R; ++mt)
@@ -465,6 +576,10 @@ __device__ __forceinline__ void fwd_epilogue_store(const FwdArgs& g, const TileC
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][r] = rfx_act_apply(acc[mt][r], e.act2, 0.f);
   }
+  uint32_t frec = 0;
+  if ((pair16 || !d.out_bf16) && fwd_tile_full(d, tc, 32 * R, d.out_bf16 ? 2 : 4, &frec)) {
+    fwd_store_fast_plain<R>(g, tc, acc, opos, pair16, frec, s1, s2);
+  } else
   if (pair16) {
 #pragma unroll
     for (int mt = 0; mt < R; ++mt)
@@ -567,10 +682,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_kernel(const FwdArgs g) {
 int rfx_launch_gemm_fwd_f32(const FwdArgs& g, int r, dim3 grid, hipStream_t s);
 // short single-phase reductions with enough position tiles to keep persistent workgroups busy run the streaming kernel
 // (gemm_tap_stream_kernel); shared by the launcher and rfx_gemm_fwd_variant
+// ... and whose every wave tile takes the lean store (stream_store): 32 | positions per sample, rows full or dropped by the range check,
+// 16-bit outputs pairable.  (The output pointer's 4-byte alignment is checked by the launcher; every torch allocation has it.)
 static inline bool rfx_tap_use_stream(const rfx_gemm_desc& d, const rfx_epilogue& e, bool two_phase, int r) {
   const int64_t work = (int64_t)((d.OA * d.OB + 127) / 128) * d.N;
+  uint32_t rec; bool partial_ok;
+  const bool geo = rfx_fast_store_geo(d, (d.out_bf16 && !e.glu_out) ? 2 : 4, &rec, &partial_ok);
+  const bool rows_ok = d.M % 32 == 0 || (partial_ok && !e.glu_out);
+  const bool store_ok = geo && rows_ok && (d.OA * d.OB) % 32 == 0 && (d.out_bf16 ? rfx_pair16_geo(d, nullptr) : !e.glu_out);
   return d.in_bf16 == 0 && d.Kpad_t <= 64 && !two_phase && work >= 4096 && r == 1 && e.act == RFX_ACT_NONE &&
-         e.act2 == RFX_ACT_NONE && !e.bwd && d.mg_log == 0 && !e.res;
+         e.act2 == RFX_ACT_NONE && !e.bwd && d.mg_log == 0 && !e.res && store_ok;
 }
 int rfx_launch_gemm_fwd_bf3(const FwdArgs& g, int r, dim3 grid, hipStream_t s);
 int rfx_launch_gemm_fwd_bf16(const FwdArgs& g, int r, dim3 grid, hipStream_t s);

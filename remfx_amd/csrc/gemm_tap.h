@@ -310,6 +310,13 @@ __device__ __forceinline__ void stream_mma(const uint4* a_lds, int h, int l31, c
   }
 }
 
+__device__ __forceinline__ void stream_stat_flush(const FwdArgs& g, int n, int pw, int lane, float s1, float s2) {
+  const double d1 = rfx_wave_sum_d((double)s1), d2 = rfx_wave_sum_d((double)s2);
+  const int slots = g.e.stat_slots > 1 ? g.e.stat_slots : 1;
+  double* dst = g.e.stat_sums + 2 * ((int64_t)n * slots + (pw & (slots - 1)));
+  if (lane == 0) { atomicAdd(dst, d1); atomicAdd(dst + 1, d2); }
+}
+
 template <int MODE, int NT, int NKMAX>
 __global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g) {      // 3 waves / SIMD spills its tile ring: measured slower
   constexpr int R = 1, BM = 32, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
@@ -348,6 +355,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g
   float bias[1][16];
   if (g.e.bias) fwd_load_bias<1>(g, q.m0, q.h, bias);
 
+  const bool pair16 = d.out_bf16 != 0;                           // the launcher checked rfx_pair16_geo
+  uint32_t frec; bool partial_ok;
+  rfx_fast_store_geo(d, d.out_bf16 ? 2 : 4, &frec, &partial_ok);
+  if (d.M % 32 == 0) frec = 0x7fffffffu;
+  int stat_n = -1, stat_pw = 0;
+  float st1 = 0.f, st2 = 0.f;
   for (int pw = w0; pw < work; pw += stride) {                   // wave-uniform trip count
     TileCtx tc[NT];
     float b[NT][NKMAX][8];
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g
       tc[nt].l31 = q.l31; tc[nt].h = q.h;
       tc[nt].jvalid = tv & (j < q.P);
       const int jj = tc[nt].jvalid ? j : 0;
-      tc[nt].a = jj / d.OB;
+      tc[nt].a = d.OA == 1 ? 0 : jj / d.OB;                     // wave-uniform select: the 1-D layers skip the division
       tc[nt].b = jj - tc[nt].a * d.OB;
       TapLane c;
       const int ia0 = tc[nt].a * d.SA, ib0 = tc[nt].b * d.SB;
@@ -384,9 +397,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g
 #pragma unroll
       for (int ks = 0; ks < NKMAX; ++ks)
         if (ks == 0 || ks < q.nk) stream_mma<MODE>(as + ks * CELLS, q.h, q.l31, b[nt][ks], acc[0]);
-      fwd_epilogue_mid<1, false>(g, tc[nt], acc, bias);
-      fwd_epilogue_store<1, false>(g, tc[nt], acc);
+      if (g.e.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += bias[0][r];
+      }
+      // lean stores only: the launcher (rfx_tap_use_stream) sends every launch with a tile that could not take them to the tiled kernel.
+      // 32 | P: a wave's 32 positions are valid or invalid together
+      const bool tvalid = __builtin_amdgcn_ballot_w64(tc[nt].jvalid) != 0;
+      float s1 = 0.f, s2 = 0.f;
+      if (tvalid) {
+        const int64_t opos = (int64_t)(tc[nt].a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(tc[nt].b * d.out_sb + d.out_b0) * d.out_bs;
+        if (g.e.glu_out) fwd_store_fast_glu<1>(g, tc[nt], acc, opos);
+        else fwd_store_fast_plain<1>(g, tc[nt], acc, opos, pair16, frec, s1, s2);
+      }
+      if (g.e.stat_sums) {
+        // GroupNorm(1, C) moments: summed per lane over the consecutive tiles of one sample, one wave reduction + fp64 atomic pair per run
+        if (tvalid && tc[nt].n != stat_n) {
+          if (stat_n >= 0) stream_stat_flush(g, stat_n, stat_pw, q.lane, st1, st2);
+          stat_n = tc[nt].n; st1 = 0.f; st2 = 0.f;
+        }
+        if (tvalid) { st1 += s1; st2 += s2; stat_pw = tc[nt].pw; }
+      }
     }
+    if (g.e.stat_sums && stat_n >= 0) { stream_stat_flush(g, stat_n, stat_pw, q.lane, st1, st2); stat_n = -1; }
   }
 }
 
@@ -409,7 +442,7 @@ static int rfx_launch_gemm_tap(const FwdArgs& g, int r, dim3 grid, hipStream_t s
   if (g.d.in_bf16 == 3) return -1;      // channels-last operand: template branch kept for the layout probe, not instantiated
   if (g.d.in_bf16) return (MODE == 2 && g.d.in_bf16 == 1) ? rfx_launch_gemm_tap_in16(g, r, grid, s) : -1;
   // short single-phase reductions with enough position tiles to keep persistent workgroups busy: streaming kernel
-  if (rfx_tap_use_stream(g.d, g.e, g.apack2 != nullptr, r)) {
+  if (rfx_tap_use_stream(g.d, g.e, g.apack2 != nullptr, r) && (!g.d.out_bf16 || (reinterpret_cast<uintptr_t>(g.out) & 3) == 0)) {
     const int mtiles = g.d.Mpad / 32;
     int nw = (512 / mtiles) & ~7;                                // persistent workgroups per channel tile (2 per CU in all),
     nw = nw < 8 ? 8 : nw;                                        // a multiple of 8: one walk per XCD slot (kernel's block order)
