@@ -10,10 +10,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // bf16 STORAGE of activations (bf16 arithmetic mode): 16 stored bits per value, RNE on store, exact widening on load
 struct rfx_bf16s { uint16_t v; };
-__device__ __forceinline__ uint32_t rfx_bf16_bits(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+// v_cvt_pk_bf16_f32 (gfx950): two round-to-nearest-even conversions per instruction.  (The software form, add 0x7fff + lsb and
+// shift, cost 4 VALU instructions per VALUE; the 16-bit-storage kernels were VALU-bound on it -- r03 SQ counters)
+typedef __bf16 rfx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rfx_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rfx_cvt_pk_bf16(float lo, float hi) {
+  const rfx_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rfx_bf16x2));
 }
+__device__ __forceinline__ uint32_t rfx_bf16_bits(float f) { return rfx_cvt_pk_bf16(f, 0.f); }
 __device__ __forceinline__ float rfx_ld1(const float* p) { return *p; }
 __device__ __forceinline__ float rfx_ld1(const rfx_bf16s* p) { return __uint_as_float((uint32_t)p->v << 16); }
 __device__ __forceinline__ void rfx_st1(float* p, float v) { *p = v; }
@@ -26,8 +31,7 @@ __device__ __forceinline__ f32x4 rfx_ld4(const rfx_bf16s* p) {          // 4 val
 }
 __device__ __forceinline__ void rfx_st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void rfx_st4(rfx_bf16s* p, const f32x4& v) {
-  *reinterpret_cast<uint2*>(p) = make_uint2(rfx_bf16_bits(v[0]) | (rfx_bf16_bits(v[1]) << 16),
-                                            rfx_bf16_bits(v[2]) | (rfx_bf16_bits(v[3]) << 16));
+  *reinterpret_cast<uint2*>(p) = make_uint2(rfx_cvt_pk_bf16(v[0], v[1]), rfx_cvt_pk_bf16(v[2], v[3]));
 }
 
 #define RFX_CHECK_LAUNCH()                                  \
@@ -36,15 +40,25 @@ __device__ __forceinline__ void rfx_st4(rfx_bf16s* p, const f32x4& v) {
     if (e_ != hipSuccess) return -2 - (int)e_;              \
   } while (0)
 
-__device__ __forceinline__ float rfx_gelu(float v) {
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+// GELU by Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7 -- one fp32 ulp of the cdf; branch-free, one v_exp + one v_rcp); GELU and GELU'
+// share the exponential, exp(-(x / sqrt2)^2) = exp(-x^2 / 2).  The library erff is ~40 instructions with branches and the
+// normalise-and-activate passes were VALU-bound on it (r03 SQ counters).
+__device__ __forceinline__ void rfx_gelu_parts(float x, float& cdf, float& ex) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  ex = __expf(-0.5f * x * x);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * ex;                     // erf(|x| / sqrt2)
+  cdf = 0.5f * (1.0f + copysignf(e, x));
 }
-__device__ __forceinline__ float rfx_gelu_grad(float v) {
-  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
-  return cdf + v * pdf;
-}
-__device__ __forceinline__ float rfx_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float rfx_gelu(float v) { float c, e; rfx_gelu_parts(v, c, e); return v * c; }
+__device__ __forceinline__ float rfx_gelu_grad(float v) { float c, e; rfx_gelu_parts(v, c, e); return fmaf(v * 0.39894228040143267794f, e, c); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): the correctly rounded fp32 division is a ~10-instruction sequence and this runs per element of
+// every GLU / GLU-backward pass
+__device__ __forceinline__ float rfx_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ float rfx_act_apply(float v, int act, float slope) {
   switch (act) {

@@ -47,21 +47,10 @@ struct DcCfg {
   static constexpr int H = C / 4, G8 = C / 8, NK1 = 3 * G8 / 2, MT = C / 16, NK2 = (H + 15) / 16, CP = C + 8;
 };
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, branch-free, one v_exp + one v_rcp): GELU and GELU' share the exponential,
-// exp(-(x / sqrt2)^2) = exp(-x^2 / 2).  The library erff costs ~40 instructions with branches; this kernel is VALU-bound.
-__device__ __forceinline__ void dc_gelu_parts(float x, float& cdf, float& ex) {
-  const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  ex = __expf(-0.5f * x * x);
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * ex;                     // erf(|x| / sqrt2)
-  cdf = 0.5f * (1.0f + copysignf(e, x));
-}
-__device__ __forceinline__ float dc_gelu(float x) { float c, e; dc_gelu_parts(x, c, e); return x * c; }
-__device__ __forceinline__ float dc_gelu_grad(float x) { float c, e; dc_gelu_parts(x, c, e); return fmaf(x * 0.39894228040143267794f, e, c); }
+// GELU / GELU' / sigmoid: the branch-free forms of common.h (Abramowitz-Stegun erf, v_exp + v_rcp)
+__device__ __forceinline__ void dc_gelu_parts(float x, float& cdf, float& ex) { rfx_gelu_parts(x, cdf, ex); }
+__device__ __forceinline__ float dc_gelu(float x) { return rfx_gelu(x); }
+__device__ __forceinline__ float dc_gelu_grad(float x) { return rfx_gelu_grad(x); }
 __device__ __forceinline__ float dc_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // one sample of a (rows, T) tensor as a buffer: per-lane byte offset (row of lane half, column) + a compile-time row offset in

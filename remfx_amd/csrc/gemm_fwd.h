@@ -42,10 +42,7 @@ struct FwdArgs {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ uint32_t bf16_rne(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
+__device__ __forceinline__ uint32_t bf16_rne(float f) { return rfx_bf16_bits(f); }
 
 static inline bool desc_ok(const rfx_gemm_desc* d) {
   return d && d->N > 0 && d->M > 0 && d->K >= 0 && d->OA > 0 && d->OB > 0 && d->Mpad % 4 == 0 &&
@@ -286,12 +283,6 @@ __device__ __forceinline__ void bf16_pair_store(uint16_t* own_pos, bool odd, int
 // tile is valid and all 32 R rows are < M (a wave-uniform test) the per-row part of each address is a SCALAR (the soffset operand of a
 // raw buffer store: (row constant) * channel stride), the per-lane part is computed once per tile, and the rounding is
 // v_cvt_pk_bf16_f32 (round-to-nearest-even, bit-equal to bf16_rne on finite values).
-typedef __bf16 rfx_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float rfx_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t rfx_cvt_pk_bf16(float lo, float hi) {
-  const rfx_f32x2 v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rfx_bf16x2));
-}
 // Launch-uniform part of the test (also evaluated on the host: the streaming kernel only takes launches whose EVERY tile qualifies).
 // *records = the buffer's num_records: rows >= M of a partial channel tile are dropped by the hardware range check when every position
 // offset is < the channel stride (a plain NCHW tensor) -- offset = m * cs + position >= M * cs  <=>  m >= M
