@@ -245,6 +245,26 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const GnArgs a, flo
       const GnDu d = gn_du_pair<XT>(a, n, cw, s);
       v[0] += d.du_a; v[1] += d.du_a * d.xh_a; v[2] += d.du_b; v[3] += d.du_b * d.xh_b; v[4] += d.gf;
     }
+  } else if ((a.S & 3) == 0) {
+    // single-channel modes (GroupNorm + GELU / ReLU / none), 4 consecutive samples per lane, the (n, channel) constants loaded once
+    // per wave: the element-at-a-time loop below was VALU-bound (r03 SQ counters: ~44 VALU instructions per element, 0.72 VALU-busy)
+    const int gi = gn_sidx(a, n, cw);
+    const float me = a.mean[gi], rs = a.rstd[gi], gm = a.gamma[cw], bt = a.beta[cw];
+    const int64_t base = ((int64_t)n * a.C + cw) * a.S;
+    const XT* xr = reinterpret_cast<const XT*>(a.x) + base;
+    const float* gr = a.gy + base;
+    for (int64_t s = s0 + 4 * lane; s < s1; s += 256) {
+      const f32x4 vx = rfx_ld4(xr + s), g4 = rfx_ld4(gr + s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (vx[q] - me) * rs;
+        const float u = xh * gm + bt;
+        float du = g4[q];
+        if (a.mode == GN_GELU) du *= rfx_gelu_grad(u);
+        else if (a.mode == GN_RELU) du = u > 0.f ? du : 0.f;
+        v[0] += du; v[1] += du * xh;
+      }
+    }
   } else {
     for (int64_t s = s0 + lane; s < s1; s += 64) {
       float xh;
@@ -388,16 +408,25 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
 // 16-byte vectors.  Same arithmetic, same results.
 struct GnRow { int n, c; int64_t s; bool ok; };
 
+// Work decode WITHOUT integer divisions (two runtime u32 divisions per thread were a third of the instructions of these 4-element
+// threads): grid = (chunk groups, channel groups, samples).  ipr >= 3 chunks of 256 samples per row: a workgroup's 4 waves take 4
+// consecutive chunks of one (n, channel) row; ipr = 1 or 2: they take 4 / ipr consecutive channels of one sample.
 __device__ __forceinline__ GnRow gn_row_item(const GnArgs& a, int Cw, uint32_t nitems, uint32_t ipr) {
   GnRow r;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t w = blockIdx.x * 4u + wave;
-  const uint32_t row = w / ipr, ck = w - row * ipr;
-  r.n = (int)(row / (uint32_t)Cw);
-  r.c = (int)(row - (uint32_t)r.n * (uint32_t)Cw);
+  uint32_t ck;
+  if (ipr >= 3) { r.c = (int)blockIdx.y; ck = blockIdx.x * 4u + wave; }
+  else if (ipr == 2) { r.c = (int)(blockIdx.y * 2u + (wave >> 1)); ck = wave & 1u; }
+  else { r.c = (int)(blockIdx.y * 4u + wave); ck = 0; }
+  r.n = (int)blockIdx.z;
   r.s = (int64_t)ck * 256 + (threadIdx.x & 63) * 4;
-  r.ok = w < nitems && r.s < a.S;
+  r.ok = r.c < Cw && ck < ipr && r.s < a.S;
   return r;
+}
+static dim3 gn_row_grid(int N, int Cw, uint32_t ipr) {
+  const unsigned nz = (unsigned)(N < 65535 ? N : 65535);
+  if (ipr >= 3) return dim3((ipr + 3) / 4, (unsigned)Cw, nz);
+  return dim3(1, (unsigned)((Cw * ipr + 3) / 4), nz);
 }
 
 __device__ __forceinline__ f32x4 gn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -408,7 +437,8 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const GnArgs a, uint
   const int Co = glu ? a.C / 2 : a.C;
   const GnRow it = gn_row_item(a, Co, nitems, ipr);
   if (!it.ok) return;
-  const int n = it.n, c = it.c;
+  const int c = it.c;
+  for (int n = it.n; n < a.N; n += (int)gridDim.z) {       // gridDim.z = min(N, 65535)
   const int ga = gn_sidx(a, n, c);
   const float ma = a.mean[ga], ra = a.rstd[ga] * a.gamma[c], ba = a.beta[c];
   const XT* xa = reinterpret_cast<const XT*>(a.x) + ((int64_t)n * a.C + c) * a.S + it.s;
@@ -435,6 +465,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const GnArgs a, uint
     o[q] = v;
   }
   *reinterpret_cast<f32x4*>(a.y + oi) = o;
+  }
 }
 
 template <typename XT>
@@ -443,8 +474,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const GnArgs a, 
   const int Cw = pair ? a.C / 2 : a.C, Cg = a.C / a.G;
   const GnRow it = gn_row_item(a, Cw, nitems, ipr);
   if (!it.ok) return;
-  const int n = it.n, cw = it.c;
+  const int cw = it.c;
   const float inv = a.bn ? 1.f / ((float)a.N * (float)a.S) : 1.f / ((float)Cg * (float)a.S);
+  for (int n = it.n; n < a.N; n += (int)gridDim.z) {       // gridDim.z = min(N, 65535)
   const int64_t xi = ((int64_t)n * a.C + cw) * a.S + it.s;
   const f32x4 g4 = gn_ld4(a.gy + ((int64_t)n * Cw + cw) * a.S + it.s);
   const XT* X = reinterpret_cast<const XT*>(a.x);
@@ -485,6 +517,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const GnArgs a, 
       d[q] = rg * (du * gm - m1 - xh * m2);
     }
     rfx_st4(DX + xi, d);
+  }
   }
 }
 
@@ -536,9 +569,10 @@ static int norm_fwd(int x16, int bn, int use_given_stats, int sums_given, const 
   }
   const int64_t total = (int64_t)N * (glu ? C / 2 : C) * S;
   uint32_t nrow_items = 0, ipr = 0;
-  if (gn_row_items((int64_t)N * (glu ? C / 2 : C), S, &nrow_items, &ipr)) {
-    if (x16) hipLaunchKernelGGL(gn_apply_rows_kernel<rfx_bf16s>, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
-    else hipLaunchKernelGGL(gn_apply_rows_kernel<float>, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+  if (C <= 65535 && gn_row_items((int64_t)N * (glu ? C / 2 : C), S, &nrow_items, &ipr)) {
+    const dim3 rg = gn_row_grid(N, glu ? C / 2 : C, ipr);
+    if (x16) hipLaunchKernelGGL(gn_apply_rows_kernel<rfx_bf16s>, rg, dim3(256), 0, s, a, nrow_items, ipr);
+    else hipLaunchKernelGGL(gn_apply_rows_kernel<float>, rg, dim3(256), 0, s, a, nrow_items, ipr);
   } else if (x16) return -1;
   else if ((S & 3) == 0) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(gn_grid(total / 4)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(gn_grid(total)), dim3(256), 0, s, a);
@@ -933,8 +967,8 @@ static int norm_bwd(int x16, int bn, const float* x, const float* gamma, const f
   hipLaunchKernelGGL(gn_bwd_chansum_kernel, dim3((C + 3) / 4), dim3(256), 0, s, a, part, psc);
   RFX_CHECK_LAUNCH();
   uint32_t nrow_items = 0, ipr = 0;
-  if (gn_row_items((int64_t)N * Cw, S, &nrow_items, &ipr))
-    GN_LAUNCH_X(gn_bwd_apply_rows_kernel<float>, gn_bwd_apply_rows_kernel<rfx_bf16s>, dim3((nrow_items + 3) / 4), dim3(256), 0, s, a, nrow_items, ipr);
+  if (C <= 65535 && gn_row_items((int64_t)N * Cw, S, &nrow_items, &ipr))
+    GN_LAUNCH_X(gn_bwd_apply_rows_kernel<float>, gn_bwd_apply_rows_kernel<rfx_bf16s>, gn_row_grid(N, Cw, ipr), dim3(256), 0, s, a, nrow_items, ipr);
   else if (x16) return -1;
   else if ((S & 3) == 0) hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3(gn_grid((int64_t)N * Cw * S / 4)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(gn_grid((int64_t)N * Cw * S)), dim3(256), 0, s, a);
