@@ -231,13 +231,62 @@ __global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4) ? 3 : 2) void gemm
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int t_begin = zsplit * w.tiles_per_block;
   const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
+  // wave-uniform facts about this k tile's table rows: the b-shift range of its taps and whether it holds the bias ("ones") row.  A
+  // chunk whose every quad stays inside its row for every tap takes the lean load path below.
+  int dbmin = 0, dbmax = 0, any_ones = 0;
+  for (int i = lane; i < RK; i += 64) {
+    const rfx_ktab_entry e = kts[i];
+    if (e.flags & 1) any_ones = 1;
+    else if (e.da > -(1 << 29)) { dbmin = min(dbmin, e.db); dbmax = max(dbmax, e.db); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dbmin = min(dbmin, __shfl_xor(dbmin, o, 64)); dbmax = max(dbmax, __shfl_xor(dbmax, o, 64));
+    any_ones |= __shfl_xor(any_ones, o, 64);
+  }
+  dbmin = __builtin_amdgcn_readfirstlane(dbmin); dbmax = __builtin_amdgcn_readfirstlane(dbmax);
+  any_ones = __builtin_amdgcn_readfirstlane(any_ones);
   const int q4 = (tid & 15) * 4, r0 = tid >> 4;                    // this thread's quad inside the chunk / first row
   const int chunks_per_row = (d.OB + PC - 1) / PC;
   struct Stage { f32x4 gv[NG], xv[NX]; };
   auto load_chunk = [&](int t, Stage& st, bool valid) {            // !valid: every load gets the out-of-range offset -> zeros
     const int row = t / chunks_per_row;                            // (n, a), wave-uniform
     const int n = row / d.OA, a = row - n * d.OA;
-    const int ob = (t - row * chunks_per_row) * PC + q4;           // first position of this thread's quad
+    const int c0 = (t - row * chunks_per_row) * PC;
+    const int ob = c0 + q4;                                        // first position of this thread's quad
+    if (valid && c0 + PC <= d.OB && c0 + dbmin >= 0 && c0 + PC + dbmax <= d.IB) {
+      // INTERIOR chunk (wave-uniform test): every quad of every tap lies inside its row -- no edge selects, no straddle loads.  The
+      // general path below spends ~330 VALU instructions per chunk on them against 16 MFMAs (r03 ISA count): the kernel was VALU-bound.
+      const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.in + (int64_t)n * d.in_ns), 0,
+                                                                           (int)w.in_bytes, 0x00020000);
+      constexpr int GSZ = G16 ? 2 : 4;
+      const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(w.g) + (int64_t)n * d.out_ns * GSZ), 0, (int)w.g_bytes, 0x00020000);
+      const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(ob + d.out_b0) +
+                                        (int64_t)(m0 + r0) * d.out_cs) * GSZ);
+      const uint32_t gstep = (uint32_t)(16 * d.out_cs * GSZ);
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const uint32_t off = (m0 + r0 + 16 * i < d.M) ? goff + i * gstep : RFX_BUF_OOB;
+        if (G16) {
+          const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(grs, off, 0, 0));
+          st.gv[i] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
+        } else {
+          st.gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 0));
+        }
+      }
+      const int ia0 = a * d.SA;
+      const uint32_t voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ob) * 4);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const rfx_ktab_entry e = kts[r0 + 16 * i];
+        const bool rowok = !(e.flags & 1) & ((unsigned)(ia0 + e.da) < (unsigned)d.IA);
+        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, rowok ? voff + ((uint32_t)e.off << 2) : RFX_BUF_OOB, 0, 0));
+        if (any_ones && (e.flags & 1)) v = f32x4{1.f, 1.f, 1.f, 1.f};          // bias-gradient column (any_ones: wave-uniform)
+        st.xv[i] = v;
+      }
+      return;
+    }
     const int lim = valid ? d.OB - ob : 0;                         // valid elements of the quad (<= 0: none)
     // num_records = the sample's exact span: a quad that runs past the last row of the tensor reads 0 for the dwords
     // beyond it (per-dword range check) instead of touching memory behind the allocation
