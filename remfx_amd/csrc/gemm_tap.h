@@ -225,13 +225,13 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
   if (ks + 2 < nk) k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
 }
 
-// R <= 2 (M <= 64 per tile: the bandwidth-bound layers) is compiled for three waves per SIMD (RFX_TAP_OCC): its accumulators are
-// small and more resident waves hide more gather latency; R >= 3 needs the registers
-#ifndef RFX_TAP_OCC
-#define RFX_TAP_OCC 3
-#endif
+// Occupancy of the bf16 mode: four waves per SIMD for R <= 2 (128 VGPRs), three for R = 3, 4 (168 VGPRs).  The K loop fits those
+// budgets without scratch (checked in the ISA: accumulators 16 R + gather ring 32 + A fragments 4 R + staging); what spills is the
+// general epilogue, once per tile -- and the full tiles take the lean store anyway.  More resident waves hide more gather latency:
+// same-box A/B of the Demucs step (r03): R = 3 at three waves -1.5 ms, R = 4 at three waves -1.2 ms, R <= 2 at four waves -0.7 ms.
+// (The split-bf16x3 mode holds hi + lo fragments and stays at two waves.)
 template <int R, int MODE, int IN16 = 0>
-__global__ __launch_bounds__(256, (R <= 2 && MODE == 2) ? RFX_TAP_OCC : 2) void gemm_tap_kernel(const FwdArgs g) {
+__global__ __launch_bounds__(256, MODE == 2 ? (R <= 2 ? 4 : 3) : 2) void gemm_tap_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
   __shared__ __attribute__((aligned(16))) uint4 smem[4 * CELLS + RFX_TAP_LDS];   // A: 2 buffers x 2 K steps; tap table
   uint4* as = smem;
