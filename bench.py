@@ -507,6 +507,7 @@ def main():
     # The timed region runs weight-gradient GEMMs on a second stream (ops.GradSink), so a forward-family launch shares the machine
     # with them and its event-timed duration is a CONCURRENT one.  For the kernel's own efficiency, time a few extra steps with
     # everything on the compute stream (not part of `value`): roofline.exclusive.
+    param_abs_sum = float(opt.flat.data.double().abs().sum())     # state after exactly W + K (+ preheat) steps: the 2-rank test compares it
     excl = None
     sink = getattr(opt.flat, "sink", None)
     if rank == 0 and world == 1 and sink is not None and sink.side is not None and not args.no_also:
@@ -596,7 +597,7 @@ def main():
                    "dist_backend": torch.distributed.get_backend() if world > 1 else None, "ranks": world,
                    "rccl_ranks": world if (world > 1 and torch.distributed.get_backend() == "nccl") else 0,
                    "exposed_allreduce_ms": round(sync.exposed_ms() / max(args.steps + args.warmup, 1), 3) if hasattr(sync, "exposed_ms") else None,
-                   "param_abs_sum": float(opt.flat.data.double().abs().sum())},
+                   "param_abs_sum": param_abs_sum},
         # roofline: the SINGLE dominant kernel instantiation of the step's dominant family (most event-timed ms): achieved =
         # its algorithmic bytes (or flops) per launch / its average launch duration; `bound` = the roof it sits closer to.
         # `by_kernel` lists every instantiation of the family the same way, `family` the whole family, `by_bound` the

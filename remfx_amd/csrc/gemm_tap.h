@@ -310,8 +310,8 @@ __device__ __forceinline__ void stream_mma(const uint4* a_lds, int h, int l31, c
   }
 }
 
-__device__ __forceinline__ void stream_stat_flush(const FwdArgs& g, int n, int pw, int lane, float s1, float s2) {
-  const double d1 = rfx_wave_sum_d((double)s1), d2 = rfx_wave_sum_d((double)s2);
+__device__ __forceinline__ void stream_stat_flush(const FwdArgs& g, int n, int pw, int lane, double s1, double s2) {
+  const double d1 = rfx_wave_sum_d(s1), d2 = rfx_wave_sum_d(s2);
   const int slots = g.e.stat_slots > 1 ? g.e.stat_slots : 1;
   double* dst = g.e.stat_sums + 2 * ((int64_t)n * slots + (pw & (slots - 1)));
   if (lane == 0) { atomicAdd(dst, d1); atomicAdd(dst + 1, d2); }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g
   rfx_fast_store_geo(d, d.out_bf16 ? 2 : 4, &frec, &partial_ok);
   if (d.M % 32 == 0) frec = 0x7fffffffu;
   int stat_n = -1, stat_pw = 0;
-  float st1 = 0.f, st2 = 0.f;
+  double st1 = 0., st2 = 0.;             // fp64 across tiles: how a sample's tiles group into iterations depends on the batch size, the sums must not
   for (int pw = w0; pw < work; pw += stride) {                   // wave-uniform trip count
     TileCtx tc[NT];
     float b[NT][NKMAX][8];
@@ -414,9 +414,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tap_stream_kernel(const FwdArgs g
         // GroupNorm(1, C) moments: summed per lane over the consecutive tiles of one sample, one wave reduction + fp64 atomic pair per run
         if (tvalid && tc[nt].n != stat_n) {
           if (stat_n >= 0) stream_stat_flush(g, stat_n, stat_pw, q.lane, st1, st2);
-          stat_n = tc[nt].n; st1 = 0.f; st2 = 0.f;
+          stat_n = tc[nt].n; st1 = 0.; st2 = 0.;
         }
-        if (tvalid) { st1 += s1; st2 += s2; stat_pw = tc[nt].pw; }
+        if (tvalid) { st1 += (double)s1; st2 += (double)s2; stat_pw = tc[nt].pw; }
       }
     }
     if (g.e.stat_sums && stat_n >= 0) { stream_stat_flush(g, stat_n, stat_pw, q.lane, st1, st2); stat_n = -1; }

@@ -261,3 +261,28 @@ def test_conv_fork_residual_gradient(case):
     check(_rms(y.detach().cpu(), yr.detach()), 1e-5)
     for got, ref in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
         check(_rms(got.cpu(), ref), 2e-5, max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("case", [(3, 16, 12, 256, 1, False), (3, 16, 12, 256, 3, False), (3, 48, 12, 256, 3, True),
+                                  (2, 16, 40, 512, 1, False), (2, 16, 44, 512, 1, True), (2, 24, 96, 65536, 1, True)])
+def test_partial_channel_tile_stays_inside_the_tensor(case):
+    """The lean full-tile store (csrc/gemm_fwd.h fwd_store_fast_plain) lets the HARDWARE drop the rows >= M of a partial channel
+    tile: per-row offsets ride in the scalar offset of a raw buffer store whose num_records = M * channel stride.  If the range
+    check ignored the scalar offset those rows would land in the next sample / behind the tensor: guard regions either side of the
+    output must stay untouched and every sample must match torch."""
+    from remfx_amd import ops
+    N, Cin, Cout, T, k, out16 = case
+    torch.manual_seed(0)
+    x = torch.randn(N, Cin, 1, T, device="cuda")
+    w = torch.randn(Cout, Cin, 1, k, device="cuda") * 0.1
+    b = torch.randn(Cout, device="cuda")
+    dt = torch.bfloat16 if (out16 and mode() == "bf16") else torch.float32
+    n_out, guard = N * Cout * T, 4096
+    buf = torch.full((n_out + 2 * guard,), 7.0, device="cuda", dtype=dt)
+    out = buf[guard:guard + n_out].view(N, Cout, 1, T)
+    y = ops.conv2d_forward(x, w, b, (1, 1), (0, k // 2), (1, 1), out=out)
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 7.0).all()) and bool((buf[guard + n_out:] == 7.0).all()), "store outside the output tensor"
+    ref = F.conv2d(x, w, b, padding=(0, k // 2))
+    err = float((y.float() - ref).abs().max())
+    check(err, 2e-5, 1.0, bf16x3=2e-4, bf16=6e-2, what=("partial channel tile vs torch", case))

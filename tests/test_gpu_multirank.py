@@ -24,7 +24,7 @@ def _json_line(out):
 
 
 def test_two_ranks_match_union_batch():
-    common = ["--steps", "2", "--warmup", "1", "--batch", "2", "--workload", "demucs", "--no-cpu-baseline", "--gemm", "bf16x3"]
+    common = ["--steps", "2", "--warmup", "1", "--preheat", "0", "--batch", "2", "--workload", "demucs", "--no-cpu-baseline", "--gemm", "bf16x3"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     two_dev = torch.cuda.device_count() >= 2
     if not two_dev:
