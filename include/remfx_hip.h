@@ -246,6 +246,12 @@ int rfx_act_add_fwd(const float* x, const float* res, float* y, int64_t n, int32
 int rfx_act_rows(const float* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0, int64_t gs1,
                  int64_t gs2, float* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0, int32_t D1, int32_t D2,
                  int32_t T, int32_t act, void* stream);
+/* The same with x STORED as bf16 (a conv output of the bf16 arithmetic mode): gy == NULL: out (fp32) = act(x); otherwise out is the
+ * bf16 gradient of that bf16 tensor (strides of x / of the backward output in bf16 elements).  Replaces the same call sites as
+ * rfx_act_rows when trainer.precision = bf16-mixed keeps the encoder conv outputs in 16 bits (what torch autocast stores). */
+int rfx_act_rows16(const void* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0, int64_t gs1,
+                   int64_t gs2, void* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0, int32_t D1, int32_t D2,
+                   int32_t T, int32_t act, void* stream);
 /* y = a * b elementwise (contiguous, n elements; 16-byte aligned): mask * representation and tanh * sigmoid gating of asteroid's
  * DPTNet (reference remfx/models.py:327-344). */
 int rfx_mul(const float* a, const float* b, float* y, int64_t n, void* stream);

@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIBDIR = os.path.join(_HERE, "_C")
-LIBPATH = os.path.join(LIBDIR, "libremfx_hip.so")
+LIBPATH = os.environ.get("RFX_LIBPATH_DEV") or os.path.join(LIBDIR, "libremfx_hip.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
                "-I" + INCLUDE, "-I" + CSRC]
@@ -136,6 +136,7 @@ SIGNATURES = {
     "rfx_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "rfx_act_add_fwd": [_P, _P, _P, _I64, _I32, _P],
     "rfx_act_rows": [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P],
+    "rfx_act_rows16": [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P],
     "rfx_mul": [_P, _P, _P, _I64, _P],
     "rfx_prelu_fwd": [_P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],

@@ -2,6 +2,7 @@
 // Replaces F.gelu / F.relu / torch.tanh / nn.PReLU backward / nn.L1Loss call
 // sites of the hot path (tcn.py:51,129; models.py:320; HDemucs enc/dec).
 #include "common.h"
+#include <type_traits>
 
 __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
   const int64_t n4 = n >> 2;
@@ -190,57 +191,84 @@ struct ActRowsArgs {
   int D1, D2, T, act;
   uint32_t nitems, ipr;
 };
-template <bool VEC>
+// X16: x is STORED as bf16 (a conv output of the bf16 arithmetic mode, ops.bf16_storage) -- and so is the gradient this kernel
+// returns for it (autograd hands a 16-bit tensor a 16-bit gradient; its readers are GEMM operands, which round to bf16 anyway).
+// The forward result stays fp32.  Strides of x / the backward output are in ELEMENTS of their storage type.
+template <bool VEC, bool X16>
 __global__ __launch_bounds__(256) void act_rows_kernel(const ActRowsArgs a) {
+  typedef typename std::conditional<X16, rfx_bf16s, float>::type XT;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t w = blockIdx.x * 4u + wave;
   if (w >= a.nitems) return;
   const uint32_t row = w / a.ipr, ck = w - row * a.ipr;
   const uint32_t r1 = row / (uint32_t)a.D2, i2 = row - r1 * (uint32_t)a.D2;
   const uint32_t i0 = r1 / (uint32_t)a.D1, i1 = r1 - i0 * (uint32_t)a.D1;
-  const float* xr = a.x + (int64_t)i0 * a.xs[0] + (int64_t)i1 * a.xs[1] + (int64_t)i2 * a.xs[2];
+  const XT* xr = reinterpret_cast<const XT*>(a.x) + (int64_t)i0 * a.xs[0] + (int64_t)i1 * a.xs[1] + (int64_t)i2 * a.xs[2];
   const float* gr = a.gy ? a.gy + (int64_t)i0 * a.gs[0] + (int64_t)i1 * a.gs[1] + (int64_t)i2 * a.gs[2] : nullptr;
-  float* orow = a.out + (int64_t)i0 * a.os[0] + (int64_t)i1 * a.os[1] + (int64_t)i2 * a.os[2];
+  const int64_t ooff = (int64_t)i0 * a.os[0] + (int64_t)i1 * a.os[1] + (int64_t)i2 * a.os[2];
+  float* orow = a.out + ooff;                                        // forward (and fp32 backward) output
+  XT* orow_x = reinterpret_cast<XT*>(a.out) + ooff;                  // backward output in x's storage type
   const int lane = threadIdx.x & 63;
   if (VEC) {
     const int t = (int)ck * 256 + lane * 4;
     if (t >= a.T) return;
-    f32x4 v = *reinterpret_cast<const f32x4*>(xr + t);
+    f32x4 v = rfx_ld4(xr + t);
     if (gr) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gr + t);
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = g[c] * rfx_act_grad(v[c], a.act, 0.f);
+      rfx_st4(orow_x + t, v);
     } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = rfx_act_apply(v[c], a.act, 0.f);
+      *reinterpret_cast<f32x4*>(orow + t) = v;
     }
-    *reinterpret_cast<f32x4*>(orow + t) = v;
   } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int t = (int)ck * 256 + q * 64 + lane;
-      if (t < a.T) orow[t] = gr ? gr[t] * rfx_act_grad(xr[t], a.act, 0.f) : rfx_act_apply(xr[t], a.act, 0.f);
+      if (t < a.T) {
+        if (gr) rfx_st1(orow_x + t, gr[t] * rfx_act_grad(rfx_ld1(xr + t), a.act, 0.f));
+        else orow[t] = rfx_act_apply(rfx_ld1(xr + t), a.act, 0.f);
+      }
     }
   }
 }
-extern "C" int rfx_act_rows(const float* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0,
-                            int64_t gs1, int64_t gs2, float* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0,
-                            int32_t D1, int32_t D2, int32_t T, int32_t act, void* stream) {
+static int act_rows_launch(bool x16, const void* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0,
+                           int64_t gs1, int64_t gs2, void* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0,
+                           int32_t D1, int32_t D2, int32_t T, int32_t act, void* stream) {
   if (!x || !out || D0 <= 0 || D1 <= 0 || D2 <= 0 || T <= 0) return -1;
   const int64_t rows = (int64_t)D0 * D1 * D2, per = ((int64_t)T + 255) / 256;
   if (rows * per > 0x7fffffffLL) return -1;
   ActRowsArgs a;
-  a.x = x; a.gy = gy; a.out = out;
+  a.x = static_cast<const float*>(x); a.gy = gy; a.out = static_cast<float*>(out);
   a.xs[0] = xs0; a.xs[1] = xs1; a.xs[2] = xs2; a.gs[0] = gs0; a.gs[1] = gs1; a.gs[2] = gs2;
   a.os[0] = os0; a.os[1] = os1; a.os[2] = os2;
   a.D1 = D1; a.D2 = D2; a.T = T; a.act = act; a.nitems = (uint32_t)(rows * per); a.ipr = (uint32_t)per;
+  const int xal = x16 ? 7 : 15, oal = (x16 && gy) ? 7 : 15;        // 4 elements of the storage type
   const bool vec = !(T & 3) && !((xs0 | xs1 | xs2 | os0 | os1 | os2 | (gy ? (gs0 | gs1 | gs2) : 0)) & 3) &&
-                   !((uintptr_t)x & 15) && !((uintptr_t)out & 15) && !((uintptr_t)gy & 15);
+                   !((uintptr_t)x & xal) && !((uintptr_t)out & oal) && !((uintptr_t)gy & 15);
   const dim3 grid((a.nitems + 3) / 4);
-  if (vec) hipLaunchKernelGGL(act_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(act_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (x16) {
+    if (vec) hipLaunchKernelGGL((act_rows_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((act_rows_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((act_rows_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((act_rows_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   RFX_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int rfx_act_rows(const float* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0,
+                            int64_t gs1, int64_t gs2, float* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0,
+                            int32_t D1, int32_t D2, int32_t T, int32_t act, void* stream) {
+  return act_rows_launch(false, x, xs0, xs1, xs2, gy, gs0, gs1, gs2, out, os0, os1, os2, D0, D1, D2, T, act, stream);
+}
+// x stored as bf16; gy == NULL: out (fp32) = act(x); otherwise out (bf16, strides in bf16 elements) = gy * act'(x)
+extern "C" int rfx_act_rows16(const void* x, int64_t xs0, int64_t xs1, int64_t xs2, const float* gy, int64_t gs0,
+                              int64_t gs1, int64_t gs2, void* out, int64_t os0, int64_t os1, int64_t os2, int32_t D0,
+                              int32_t D1, int32_t D2, int32_t T, int32_t act, void* stream) {
+  return act_rows_launch(true, x, xs0, xs1, xs2, gy, gs0, gs1, gs2, out, os0, os1, os2, D0, D1, D2, T, act, stream);
 }
 extern "C" int rfx_act_bwd(const float* x, const float* gy, float* gx, int64_t n, int32_t act, void* stream) {
   if (!x || !gy || !gx || n < 0) return -1;

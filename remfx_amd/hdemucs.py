@@ -150,6 +150,9 @@ def _norm_act(m, x, act):
     return x
 
 
+ENC_Z16 = True      # bf16 mode: encoder conv outputs of the norm-free layers stored in 16 bits (bench.py --no-enc-z16 is the A/B)
+
+
 class _HEncLayer(nn.Module):
     def __init__(self, chin, chout, kernel_size=8, stride=4, norm_groups=4, empty=False, freq=True,
                  norm_type="group_norm", context=0, dconv_kw=None, pad=True):
@@ -180,10 +183,15 @@ class _HEncLayer(nn.Module):
             x = x.reshape(x.shape[0], -1, x.shape[-1])
             fork = False
         if self.freq:
+            # bf16 mode, layers without a norm: the conv output is read only by the GELU pass (and its backward), its gradient only
+            # by the input- / weight-gradient GEMMs, which round to bf16 anyway -- both are STORED in 16 bits (what torch autocast
+            # stores for a conv output).  Frequency branch only: the time branch's stride runs along the contiguous axis, and the
+            # weight-gradient kernel for those plans reads an fp32 gradient.
+            z16 = ENC_Z16 and (not self.empty) and inject is None and not isinstance(self.norm1, nn.GroupNorm)
             if fork:
-                y, alias = ops.conv2d_fork(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0))
+                y, alias = ops.conv2d_fork(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0), out_bf16=z16)
             else:
-                y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0))
+                y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0), out_bf16=z16)
         else:
             if x.shape[-1] % self.stride:
                 x = F.pad(x, (0, self.stride - x.shape[-1] % self.stride))

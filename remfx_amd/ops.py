@@ -298,7 +298,7 @@ def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=No
     OA = convplan._out_len(IA, KA, stride[0], padding[0], dilation[0])
     OB = convplan._out_len(IB, KB, stride[1], padding[1], dilation[1])
     if out is None:
-        use16 = out_bf16 and bf16_storage() and Cout > 8 and Cin >= 8 and (OA * OB) % 4 == 0 and act is None
+        use16 = out_bf16 and bf16_storage() and Cout > 8 and (OA * OB) % 4 == 0 and act is None
         out = torch.empty((N, Cout, OA, OB), device=x.device, dtype=torch.bfloat16 if use16 else torch.float32)
     key = _key("cf", x.shape, x.stride(), w.shape, stride, padding, dilation, out.stride())
     dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
@@ -625,13 +625,26 @@ def channel_sum(g):
     return out
 
 
+def _rows16(x, gy, out, act):
+    """rfx_act_rows16 on a contiguous tensor whose storage is bf16 (ops.bf16_storage): (rows, T) view, T = last axis."""
+    T = x.shape[-1]
+    R = x.numel() // T
+    check(_lib.lib().rfx_act_rows16(_ptr(x), 0, 0, T, _ptr(gy) if gy is not None else None, 0, 0, T, _ptr(out), 0, 0, T,
+                                    1, 1, R, T, ACT[act], _stream()), "rfx_act_rows16")
+
+
 class ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act):
-        _req(x)
-        x = x.contiguous()
-        y = torch.empty_like(x)
-        check(_lib.lib().rfx_act_fwd(_ptr(x), _ptr(y), x.numel(), ACT[act], _stream()), "rfx_act_fwd")
+        if x.dtype == torch.bfloat16:           # a conv output stored in 16 bits (bf16 mode): fp32 result, 16-bit gradient
+            x = x.contiguous()
+            y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+            _rows16(x, None, y, act)
+        else:
+            _req(x)
+            x = x.contiguous()
+            y = torch.empty_like(x)
+            check(_lib.lib().rfx_act_fwd(_ptr(x), _ptr(y), x.numel(), ACT[act], _stream()), "rfx_act_fwd")
         ctx.save_for_backward(x)
         ctx.act = act
         return y
@@ -641,6 +654,9 @@ class ActFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         gy = gy.contiguous()
         gx = torch.empty_like(x)
+        if x.dtype == torch.bfloat16:
+            _rows16(x, gy, gx, ctx.act)
+            return gx, None
         check(_lib.lib().rfx_act_bwd(_ptr(x), _ptr(gy), _ptr(gx), x.numel(), ACT[ctx.act], _stream()),
               "rfx_act_bwd")
         return gx, None
@@ -691,15 +707,18 @@ class ActToFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, act, perm):
-        _req(x)
+        x16 = x.dtype == torch.bfloat16         # a conv output stored in 16 bits (bf16 mode): fp32 result, 16-bit gradient
+        if not x16:
+            _req(x)
+        rows = _lib.lib().rfx_act_rows16 if x16 else _lib.lib().rfx_act_rows
         xs = _row_strides(x)
         D = x.shape
         y = torch.empty([D[p] for p in perm] + [D[3]], device=x.device, dtype=torch.float32)
         inv = [perm.index(i) for i in range(3)]
         y = y.permute(*inv, 3)                                  # x-shaped view of the permuted buffer
         ys = _row_strides(y)
-        check(_lib.lib().rfx_act_rows(_ptr(x), xs[0], xs[1], xs[2], None, 0, 0, 0, _ptr(y), ys[0], ys[1], ys[2],
-                                      D[0], D[1], D[2], D[3], ACT[act], _stream()), "rfx_act_rows")
+        check(rows(_ptr(x), xs[0], xs[1], xs[2], None, 0, 0, 0, _ptr(y), ys[0], ys[1], ys[2],
+                   D[0], D[1], D[2], D[3], ACT[act], _stream()), "rfx_act_rows")
         ctx.save_for_backward(x)
         ctx.act = act
         return y
@@ -710,9 +729,10 @@ class ActToFn(torch.autograd.Function):
         if gy.stride(3) != 1:
             gy = gy.contiguous()
         xs, gs, D = _row_strides(x), _row_strides(gy), x.shape
-        gx = torch.empty_strided(x.shape, x.stride(), device=x.device, dtype=torch.float32)
-        check(_lib.lib().rfx_act_rows(_ptr(x), xs[0], xs[1], xs[2], _ptr(gy), gs[0], gs[1], gs[2], _ptr(gx), xs[0], xs[1],
-                                      xs[2], D[0], D[1], D[2], D[3], ACT[ctx.act], _stream()), "rfx_act_rows")
+        gx = torch.empty_strided(x.shape, x.stride(), device=x.device, dtype=x.dtype)
+        rows = _lib.lib().rfx_act_rows16 if x.dtype == torch.bfloat16 else _lib.lib().rfx_act_rows
+        check(rows(_ptr(x), xs[0], xs[1], xs[2], _ptr(gy), gs[0], gs[1], gs[2], _ptr(gx), xs[0], xs[1],
+                   xs[2], D[0], D[1], D[2], D[3], ACT[ctx.act], _stream()), "rfx_act_rows")
         return gx, None, None
 
 
