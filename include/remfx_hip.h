@@ -186,7 +186,10 @@ enum rfx_stft_out {
   RFX_STFT_CAC = 1,     /* [R][2][bins][frames_out]: real plane, imag plane (HDemucs _magnitude) */
   RFX_STFT_MAG = 2,     /* [R][bins][frames_out] = sqrt(max(re^2+im^2, eps)) (auraloss) */
   RFX_STFT_POW = 3,     /* re^2+im^2 (MelSpectrogram power=2) */
-  RFX_STFT_MAGPOW = 4   /* (sqrt(re^2+im^2) + eps) ^ alpha (utils.py:159) */
+  RFX_STFT_MAGPOW = 4,  /* (sqrt(re^2+im^2) + eps) ^ alpha (utils.py:159) */
+  RFX_STFT_COMPLEX_FM = 5 /* [R][frames_out][bins][2]: frame-major complex, for consumers that are layout-free (the MR-STFT loss
+                             kernels, models.py:320): every frame's bins are one contiguous run, so the FFT kernels store / load
+                             full lines instead of 8-64 byte pieces of a [bin][frame] transpose */
 };
 typedef struct rfx_stft_desc {
   int32_t R, T;           /* rows (batch*channels), samples per row of the time signal */

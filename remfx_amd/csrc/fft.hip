@@ -6,30 +6,30 @@
 // HDemucs _spec/_ispec (models.py:319), auraloss STFTLoss (models.py:320 ...),
 // Open-Unmix Separator (models.py:298), MelSpectrogram (classifier.py:200).
 //
-// Structure (one workgroup = 256 threads = FB consecutive frames of one row):
-//   * a real n_fft-point transform is done as an NC = n_fft/2 point complex FFT of
-//     z[n] = x[2n] + i x[2n+1] plus the standard split/merge step;
-//   * the NC-point FFT runs IN PLACE in LDS: radix-4 decimation-in-frequency passes
-//     (+ one radix-2 pass when log2 NC is odd), natural-order input -> digit-reversed
-//     output; the inverse runs the mirrored decimation-in-time passes;
-//   * FB * NC = RFX_FFT_PTS complex points (2048 / 4096, see below) + an NC-entry twiddle table per
-//     workgroup; frames are padded by one element so that the transposing epilogue
-//     (lanes along frames -> coalesced [bin][frame] stores) is bank-conflict free;
-//   * workgroups that write the same (row, bin) lines are placed on the same XCD
-//     (block b runs on XCD b % 8) so partial-line stores merge in one L2.
+// Structure (round 3: register passes; rounds 1-2 ran six radix-4 passes in place in LDS and were VALU-issue-bound on their index
+// arithmetic, ~200 instructions per complex point):
+//   * a real n_fft-point transform is an NC = n_fft/2 point complex FFT of z[n] = x[2n] + i x[2n+1] plus the split / merge step;
+//   * one workgroup = 256 threads = FB = 4096 / NC frames at a time, T = NC / 16 threads per frame, every thread owns 16 complex
+//     points of its frame in REGISTERS in each pass.  NC = RA * 16 * 16: pass A (radix RA = NC / 256 = 2, 4, 8, stride 256; absent for
+//     NC = 256) takes its input straight from global memory, passes B and C are radix-16 butterflies (two radix-4 stages), three
+//     LDS exchanges in all (A->B, B->C, C->split) instead of seven read-modify-write passes.  Complex values are 2-vectors, so the
+//     butterflies compile to packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32: a complex add is one instruction, a complex
+//     multiply two);
+//   * every exchange has its own LDS layout (E1, E2, E3 below), chosen so that the writing pass and the reading pass are both
+//     lane-contiguous / at most 2-way bank-conflicted, and every LDS access is base + immediate offset (scripts/probes/fft_model.py
+//     is the index model of this file, checked against numpy.fft);
+//   * twiddles: W_256^(j m) of pass B and the 16 window pairs of a thread are frame-independent and stay in registers while the
+//     workgroup walks `nbatch` consecutive frame batches; pass A chains its RA - 1 twiddles from one table value per butterfly.
+//     The tables (host-computed in double precision, one set per n_fft and device) are read from global memory once per workgroup;
+//   * the inverse transform is the same forward code on conjugated data (the merge step writes conj Z, the overlap-add reads conj z);
+//   * the transposing epilogue (lanes along frames -> [bin][frame] stores) works on PAIRS of bins (k, NC - k), which share their
+//     two LDS reads; workgroups that write the same (row, bin) lines are placed on the same XCD (block b runs on XCD b % 8) so
+//     partial-line stores merge in one L2.
 #include "common.h"
+#include <math.h>
+#include <mutex>
 
-// complex points per workgroup: 2048 for n_fft <= 1024, 4096 above (16-32 KB of LDS).  Round 1 used 8192 (64 KB: two workgroups =
-// 8 waves per CU between workgroup barriers) and the kernels were OCCUPANCY-bound: analysis 0.55 -> 0.32 ms, synthesis 1.1 -> 0.5 ms
-// per launch with the smaller groups, at the price of shorter store runs in the transposing epilogue.
-#ifndef RFX_FFT_PTS_SMALL
-#define RFX_FFT_PTS_SMALL 2048
-#endif
-#ifndef RFX_FFT_PTS_LARGE
-#define RFX_FFT_PTS_LARGE 4096
-#endif
-#define RFX_FFT_PTS(LOGN) ((LOGN) <= 9 ? RFX_FFT_PTS_SMALL : RFX_FFT_PTS_LARGE)
-static int rfx_fft_pts(int nc) { return nc <= 512 ? RFX_FFT_PTS_SMALL : RFX_FFT_PTS_LARGE; }
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct FftArgs {
   rfx_stft_desc d;
@@ -37,93 +37,70 @@ struct FftArgs {
   const float* window;  // [win]
   const float* mul;     // optional per padded-sample multiplier (iSTFT 1/envelope)
   float* out;           // analysis: spectrum;       synthesis: signal [R][T] (atomic accumulate)
-  int groups_per_row;
+  const v2f* tables;    // [256] W_256^t | [256] W_NC^t | [NC/2 + 1] e^{-i pi k / NC}
+  int groups_per_row;   // workgroups per row
+  int nbatch;           // frame batches (FB frames each) a workgroup walks
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
-  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-
 template <int LOGN>
-__device__ __forceinline__ int digit_pos(int k) {
-  int pos = 0, L = 1 << LOGN, kk = k;
-#pragma unroll
-  for (int s = 0; s < LOGN / 2; ++s) {
-    pos += (kk & 3) * (L >> 2);
-    kk >>= 2;
-    L >>= 2;
-  }
-  if (LOGN & 1) pos += (kk & 1);
-  return pos;
-}
+struct FftCfg {
+  static constexpr int NC = 1 << LOGN, T = NC / 16, FB = 256 / T, RA = NC / 256, NB = RA > 1 ? 16 / RA : 1;
+  static constexpr int FS = NC + (RA > 1 ? 256 : 32) + 2;        // frame stride (elements); = 2 mod 32: frames interleave in the epilogue
+  static constexpr int RS1 = T + 16, RS2 = T + 1, RS3 = 256 + (RA > 1 ? 32 / RA : 0);
+  static constexpr int NH = NC / 2 + 1;
+};
 
-// In-place FFT of FB frames of NC complex points each (frame stride FS).
-template <int LOGN, bool INV>
-__device__ __forceinline__ void fft_passes(float2* data, const float2* tw, int nframes_elems /*FB*NC*/) {
-  constexpr int NC = 1 << LOGN, FS = NC + 1;
-  const int tid = threadIdx.x;
-  if (!INV) {
-    for (int L = NC; L >= 4; L >>= 2) {
-      const int q = L >> 2, tstep = NC / L;
-      for (int idx = tid; idx < nframes_elems / 4; idx += 256) {
-        const int fr = idx / (NC / 4), r = idx - fr * (NC / 4);
-        const int gI = r / q, j = r - gI * q;
-        float2* p = data + fr * FS + gI * L + j;
-        const float2 x0 = p[0], x1 = p[q], x2 = p[2 * q], x3 = p[3 * q];
-        const float2 t0 = make_float2(x0.x + x2.x, x0.y + x2.y), t1 = make_float2(x0.x - x2.x, x0.y - x2.y);
-        const float2 t2 = make_float2(x1.x + x3.x, x1.y + x3.y);
-        const float2 t3 = make_float2(x1.y - x3.y, -(x1.x - x3.x));  // (x1-x3) * (-i)
-        p[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
-        p[q] = cmul(make_float2(t1.x + t3.x, t1.y + t3.y), tw[j * tstep]);
-        p[2 * q] = cmul(make_float2(t0.x - t2.x, t0.y - t2.y), tw[2 * j * tstep]);
-        p[3 * q] = cmul(make_float2(t1.x - t3.x, t1.y - t3.y), tw[3 * j * tstep]);
-      }
-      __syncthreads();
-    }
-    if (LOGN & 1) {
-      for (int idx = tid; idx < nframes_elems / 2; idx += 256) {
-        const int fr = idx / (NC / 2), r = idx - fr * (NC / 2);
-        float2* p = data + fr * FS + 2 * r;
-        const float2 a = p[0], b = p[1];
-        p[0] = make_float2(a.x + b.x, a.y + b.y);
-        p[1] = make_float2(a.x - b.x, a.y - b.y);
-      }
-      __syncthreads();
-    }
-  } else {
-    if (LOGN & 1) {
-      for (int idx = tid; idx < nframes_elems / 2; idx += 256) {
-        const int fr = idx / (NC / 2), r = idx - fr * (NC / 2);
-        float2* p = data + fr * FS + 2 * r;
-        const float2 a = p[0], b = p[1];
-        p[0] = make_float2(a.x + b.x, a.y + b.y);
-        p[1] = make_float2(a.x - b.x, a.y - b.y);
-      }
-      __syncthreads();
-    }
-    for (int L = (LOGN & 1) ? 8 : 4; L <= NC; L <<= 2) {
-      const int q = L >> 2, tstep = NC / L;
-      for (int idx = tid; idx < nframes_elems / 4; idx += 256) {
-        const int fr = idx / (NC / 4), r = idx - fr * (NC / 4);
-        const int gI = r / q, j = r - gI * q;
-        float2* p = data + fr * FS + gI * L + j;
-        const float2 u0 = p[0];
-        const float2 u1 = cmulc(p[q], tw[j * tstep]);
-        const float2 u2 = cmulc(p[2 * q], tw[2 * j * tstep]);
-        const float2 u3 = cmulc(p[3 * q], tw[3 * j * tstep]);
-        const float2 t0 = make_float2(u0.x + u2.x, u0.y + u2.y), t1 = make_float2(u0.x - u2.x, u0.y - u2.y);
-        const float2 t2 = make_float2(u1.x + u3.x, u1.y + u3.y);
-        const float2 t3 = make_float2(-(u1.y - u3.y), u1.x - u3.x);  // (u1-u3) * (+i)
-        p[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
-        p[q] = make_float2(t1.x + t3.x, t1.y + t3.y);
-        p[2 * q] = make_float2(t0.x - t2.x, t0.y - t2.y);
-        p[3 * q] = make_float2(t1.x - t3.x, t1.y - t3.y);
-      }
-      __syncthreads();
-    }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access (vmcnt(0)): the
+// stores of a batch's epilogue and the prefetched loads of the next batch would be drained at each of the ~7 barriers of a batch.
+// Every barrier in this file separates LDS writes from LDS reads; global data is never exchanged between threads.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) { return a.xx * b + a.yy * v2f{-b.y, b.x}; }
+__device__ __forceinline__ v2f mul_negi(v2f a) { return v2f{a.y, -a.x}; }
+__device__ __forceinline__ v2f cconj(v2f a) { return v2f{a.x, -a.y}; }
+
+// forward DFTs over x[0], x[S], ..., x[(R-1) S] in place; output Y[m] lands at x[fft_slot<R>(m) * S]
+template <int R> __device__ __forceinline__ constexpr int fft_slot(int m) {
+  return R == 16 ? (m & 3) * 4 + (m >> 2) : R == 8 ? (m & 3) * 2 + (m >> 2) : m;
+}
+template <int S> __device__ __forceinline__ void dft2(v2f* x) {
+  const v2f t = x[0] - x[S];
+  x[0] = x[0] + x[S];
+  x[S] = t;
+}
+template <int S> __device__ __forceinline__ void dft4(v2f* x) {
+  const v2f t0 = x[0] + x[2 * S], t1 = x[0] - x[2 * S], t2 = x[S] + x[3 * S], t3 = mul_negi(x[S] - x[3 * S]);
+  x[0] = t0 + t2;
+  x[S] = t1 + t3;
+  x[2 * S] = t0 - t2;
+  x[3 * S] = t1 - t3;
+}
+template <int R, int S> __device__ __forceinline__ void dftR(v2f* x) {
+  constexpr float H = 0.70710678118654752440f, C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+  if (R == 2) dft2<S>(x);
+  else if (R == 4) dft4<S>(x);
+  else if (R == 8) {                       // q = q1 + 2 q2:  radix-4 over q2, W8^(q1 m2), radix-2 over q1
+    dft4<2 * S>(x);
+    dft4<2 * S>(x + S);
+    x[3 * S] = cmul(x[3 * S], v2f{H, -H});
+    x[5 * S] = mul_negi(x[5 * S]);
+    x[7 * S] = cmul(x[7 * S], v2f{-H, -H});
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) dft2<S>(x + 2 * m2 * S);
+  } else {                                 // q = q1 + 4 q2:  radix-4 over q2, W16^(q1 m2), radix-4 over q1
+#pragma unroll
+    for (int q1 = 0; q1 < 4; ++q1) dft4<4 * S>(x + q1 * S);
+    x[5 * S] = cmul(x[5 * S], v2f{C1, -S1});
+    x[9 * S] = cmul(x[9 * S], v2f{H, -H});
+    x[13 * S] = cmul(x[13 * S], v2f{S1, -C1});
+    x[6 * S] = cmul(x[6 * S], v2f{H, -H});
+    x[10 * S] = mul_negi(x[10 * S]);
+    x[14 * S] = cmul(x[14 * S], v2f{-H, -H});
+    x[7 * S] = cmul(x[7 * S], v2f{S1, -C1});
+    x[11 * S] = cmul(x[11 * S], v2f{-H, -H});
+    x[15 * S] = cmul(x[15 * S], v2f{-C1, S1});
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) dft4<S>(x + 4 * m2 * S);
   }
 }
 
@@ -145,272 +122,354 @@ __device__ __forceinline__ int map_sample(const rfx_stft_desc& d, int p) {
 
 template <int LOGN>
 __device__ __forceinline__ void block_coords(const FftArgs& a, int& row, int& f_first) {
-  constexpr int FB = RFX_FFT_PTS(LOGN) >> LOGN;
+  typedef FftCfg<LOGN> K;
   // same-row frame groups on the same XCD (block b -> XCD b % 8), adjacent in time
   const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
   const int slot = q / a.groups_per_row, grp = q - slot * a.groups_per_row;
   row = slot * 8 + xcd;
-  f_first = a.d.frame0 + grp * FB;
+  f_first = a.d.frame0 + grp * (K::FB * a.nbatch);
 }
 
-// e^{-i pi k / NC} for the split (analysis) / merge (synthesis) step: a table instead of one sincospif per output
-// element (n_fft <= 2048; the 4096-point kernels keep sincospif, their LDS is full)
+// Twiddles of the passes.  Pass B: W_256^(j2 m) from an LDS table stored [m][j2], so that a thread's 15 reads are base + immediate
+// offset (registers would cost 30 VGPRs per thread: the kernel is register-bound at three waves per SIMD).  Pass A: the base
+// W_NC^(j1) of each butterfly, from LDS for RA >= 4 (2 / 4 butterflies); for RA = 2 (LDS is full at NC = 512) W_512^u times a constant.
 template <int LOGN>
-__device__ __forceinline__ void build_half_twiddles(float2* tw2) {
-  constexpr int NC = 1 << LOGN;
-  if (LOGN > 10) return;
-  for (int t = threadIdx.x; t < NC / 2; t += 256) {
-    float s, c;
-    sincospif(-(float)(2 * t + 1) / (float)NC, &s, &c);
-    tw2[t] = make_float2(c, s);
+struct FftState {
+  const v2f* twB;                                        // LDS, + (u & 15)
+  const v2f* twAs;                                       // LDS, + u (RA >= 4)
+  v2f twA0;                                              // RA = 2: W_512^u; butterfly h uses W_512^(u + 32 h) = twA0 W_16^h
+};
+template <int LOGN>
+struct FftTables {
+  v2f twH[FftCfg<LOGN>::NH];
+  v2f tw256t[256];
+  v2f twAs[FftCfg<LOGN>::RA >= 4 ? 256 : 1];
+};
+template <int LOGN>
+__device__ __forceinline__ void fft_setup(const FftArgs& a, FftTables<LOGN>& tb, FftState<LOGN>& st) {
+  typedef FftCfg<LOGN> K;
+  const int tid = threadIdx.x, u = tid & (K::T - 1);
+  {                                                        // all loads first: a load -> wait -> LDS write loop costs a round trip each
+    constexpr int NI = (K::NH + 255) / 256;
+    v2f tmp[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) tmp[i] = a.tables[512 + min(tid + 256 * i, K::NH - 1)];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) if (tid + 256 * i < K::NH) tb.twH[tid + 256 * i] = tmp[i];
+  }
+  tb.tw256t[tid] = a.tables[(tid & 15) * (tid >> 4)];    // [m][j2]
+  if (K::RA >= 4) tb.twAs[tid] = a.tables[256 + tid];
+  st.twB = tb.tw256t + (u & 15);
+  st.twAs = tb.twAs + u;
+  st.twA0 = a.tables[256 + (K::RA == 2 ? u : 0)];
+}
+
+// The three passes on one batch: z = the thread's 16 points i = u + T n (n = 0..15) of frame fl.  Result: Z[k] in layout E3.
+// Callers put a barrier before the first LDS read of the NEXT use of `data`.
+template <int LOGN>
+__device__ __forceinline__ void fft_core(v2f (&z)[16], v2f* data, const FftState<LOGN>& st) {
+  typedef FftCfg<LOGN> K;
+  const int tid = threadIdx.x, u = tid & (K::T - 1), fl = tid / K::T;
+  v2f* fr = data + fl * K::FS;
+  if (K::RA > 1) {
+    // pass A: butterfly h works on z[h + NB q], j1 = u + h T;  E1: element (b1 = m, j1) at (j1 / 16) RS1 + 16 m + j1 % 16
+    v2f* wA = fr + (u >> 4) * K::RS1 + (u & 15);
+#pragma unroll
+    for (int h = 0; h < K::NB; ++h) {
+      dftR<K::RA, K::NB>(z + h);
+      v2f w[K::RA > 1 ? K::RA : 2];
+      if (K::RA == 2) {
+        constexpr float CS[8][2] = {{1.f, 0.f}, {0.92387953251128675613f, -0.38268343236508977173f},
+                                    {0.70710678118654752440f, -0.70710678118654752440f}, {0.38268343236508977173f, -0.92387953251128675613f},
+                                    {0.f, -1.f}, {-0.38268343236508977173f, -0.92387953251128675613f},
+                                    {-0.70710678118654752440f, -0.70710678118654752440f}, {-0.92387953251128675613f, -0.38268343236508977173f}};
+        v2f b = st.twA0;
+        asm volatile("" : "+v"(b));                      // keeps the eight products out of loop-invariant registers
+        w[1] = cmul(b, v2f{CS[h & 7][0], CS[h & 7][1]});
+      } else w[1] = st.twAs[h * K::T];
+#pragma unroll
+      for (int m = 2; m < K::RA; ++m) w[m] = (m & 1) ? cmul(w[m - 1], w[1]) : cmul(w[m / 2], w[m / 2]);
+      wA[h * (K::T / 16) * K::RS1] = z[h + K::NB * fft_slot<K::RA>(0)];
+#pragma unroll
+      for (int m = 1; m < K::RA; ++m)
+        wA[h * (K::T / 16) * K::RS1 + 16 * m] = cmul(z[h + K::NB * fft_slot<K::RA>(m)], w[m]);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) z[q] = fr[q * K::RS1 + u];
+    lds_barrier();
+  }
+  // pass B: radix 16 over stride 16 of a 256-point block b1 = u / 16, j2 = u % 16;  E2: element (v3 = 16 b1 + m, q = j2) at q RS2 + v3
+  dftR<16, 1>(z);
+  {
+    v2f* wB = fr + (u & 15) * K::RS2 + (u >> 4) * 16;
+    wB[0] = z[fft_slot<16>(0)];
+#pragma unroll
+    for (int m = 1; m < 16; ++m) wB[m] = cmul(z[fft_slot<16>(m)], st.twB[16 * m]);
+  }
+  lds_barrier();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) z[q] = fr[q * K::RS2 + u];
+  lds_barrier();
+  // pass C: radix 16, no twiddle;  output k = mA + RA (mB + 16 m), mA = u / 16, mB = u % 16;  E3: (k % RA) RS3 + k / RA
+  dftR<16, 1>(z);
+  {
+    v2f* wC = fr + (u >> 4) * K::RS3 + (u & 15);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wC[16 * m] = z[fft_slot<16>(m)];
   }
 }
-// k in [0, NC]: even k -> tw[k/2] = e^{-2 pi i (k/2) / NC}, odd k -> tw2[(k-1)/2]
-template <int LOGN>
-__device__ __forceinline__ float2 half_twiddle(const float2* tw, const float2* tw2, int k) {
-  constexpr int NC = 1 << LOGN;
-  if (LOGN <= 10) return ((k & 1) ? tw2 : tw)[k >> 1];
-  float s, c;
-  sincospif((float)k / (float)NC, &s, &c);
-  return make_float2(c, -s);
-}
-
-// digit-reversed position of every natural index: one LDS read instead of ~12 integer instructions per use in the split / merge
-// steps (the r02c profile has these kernels VALU-issue-bound: ~6000 instructions per thread, two thirds of them index arithmetic)
-template <int LOGN>
-__device__ __forceinline__ void build_rev(uint16_t* rev) {
-  constexpr int NC = 1 << LOGN;
-  for (int t = threadIdx.x; t < NC; t += 256) rev[t] = (uint16_t)digit_pos<LOGN>(t);
+template <int LOGN> __device__ __forceinline__ int fft_phys3(int k) {
+  typedef FftCfg<LOGN> K;
+  return K::RA > 1 ? (k & (K::RA - 1)) * K::RS3 + (k >> (LOGN - 8)) : k;
 }
 
 template <int LOGN>
-__device__ __forceinline__ void build_twiddles(float2* tw) {
-  constexpr int NC = 1 << LOGN;
-  for (int t = threadIdx.x; t < NC; t += 256) {
-    float s, c;
-    sincospif(-2.0f * (float)t / (float)NC, &s, &c);
-    tw[t] = make_float2(c, s);
-  }
-}
-
-template <int LOGN>
-__global__ __launch_bounds__(256) void fft_analysis_kernel(const FftArgs a) {
-  constexpr int NC = 1 << LOGN, FB = RFX_FFT_PTS(LOGN) >> LOGN, FS = NC + 1, N = 2 * NC;
-  __shared__ float2 data[FB * FS];
-  __shared__ float2 tw[NC];
-  __shared__ float2 tw2[LOGN <= 10 ? NC / 2 : 1];     // e^{-i pi k / NC} for ODD k (even k is tw[k/2]); LDS budget: n_fft <= 2048
-  __shared__ uint16_t rev[NC];
+__global__ __launch_bounds__(256, 3) void fft_analysis_kernel(const FftArgs a) {
+  typedef FftCfg<LOGN> K;
+  constexpr int NC = K::NC, T = K::T, FB = K::FB, N = 2 * NC;
+  __shared__ v2f data[FB * K::FS];
+  __shared__ FftTables<LOGN> tb;
   const rfx_stft_desc& d = a.d;
   int row, f_first;
   block_coords<LOGN>(a, row, f_first);
   if (row >= d.R) return;
-  const int tid = threadIdx.x;
-  build_twiddles<LOGN>(tw);
-  build_half_twiddles<LOGN>(tw2);
-  build_rev<LOGN>(rev);
+  const int tid = threadIdx.x, u = tid & (T - 1), fl = tid / T;
+  FftState<LOGN> st;
+  fft_setup<LOGN>(a, tb, st);
+  lds_barrier();                       // the passes read the tables other threads loaded
   const int f_end = d.frame0 + d.frames_out;
   const float* xr = a.x + (int64_t)row * d.T;
   const int woff = (N - d.win) / 2;
-  // Load phase, 4 complex points (8 samples) per thread and round: every index is clamped and every load is
-  // unconditional, validity is applied to the VALUE afterwards.  (With the loads inside `if (in window) if (in signal)`
-  // hipcc emitted one load + s_waitcnt vmcnt(0) per sample: 64 dependent memory round trips per thread and workgroup,
-  // which is where the r01 kernels spent their time: 0.87 ms for 3.4 GFLOP.)
-  // r02: the kernels are VALU-issue-bound, so (a) a thread's points have only NC / 256 distinct in-frame indices: their window
-  // values (x scale, 0 outside the window) are fetched once into registers; (b) a workgroup whose whole span lies inside the
-  // signal (all but the first / last few of a row) skips the reflect arithmetic of map_sample.
-  constexpr int NCB = NC / 256;                                   // distinct i per thread (1, 2, 4, 8)
-  float wv[NCB <= 4 ? NCB : 1][2];
-  if (NCB <= 4) {
+  // the thread's 16 window pairs (x scale; 0 outside the window): frame-independent
+  v2f wv[16];
+  {   // 32 independent loads at clamped indices, validity applied to the VALUE (a load inside `ok ? w[i] : 0` becomes a branch
+      // with its own s_waitcnt: 32 serialised round trips = ~10 us per workgroup, measured as an "empty" kernel of 100-150 us)
+    float wl[16][2];
 #pragma unroll
-    for (int c = 0; c < (NCB <= 4 ? NCB : 1); ++c)
+    for (int n = 0; n < 16; ++n)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int wi = 2 * (tid + 256 * c) + u - woff;
-        const bool wok = (wi >= 0) & (wi < d.win);
-        wv[c][u] = wok ? a.window[wok ? wi : 0] * d.scale : 0.f;
-      }
+      for (int c = 0; c < 2; ++c) wl[n][c] = a.window[min(max(2 * (u + T * n) + c - woff, 0), d.win - 1)];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      const int w0 = 2 * (u + T * n) - woff;
+      wv[n] = v2f{((w0 >= 0) & (w0 < d.win)) ? wl[n][0] * d.scale : 0.f, ((w0 + 1 >= 0) & (w0 + 1 < d.win)) ? wl[n][1] * d.scale : 0.f};
+    }
   }
   const int shift = d.in_mode == 0 ? d.n_fft / 2 + d.extra_pad_l : d.in_offset;
-  const int64_t p_lo = (int64_t)f_first * d.hop, p_hi = (int64_t)(f_first + FB - 1) * d.hop + N - 1;
-  const bool interior = (f_first + FB <= f_end) & (p_lo - shift >= 0) & (p_hi - shift < (int64_t)d.T);      // workgroup-uniform
-  for (int j0 = 0; j0 < (FB * NC) / 256; j0 += 4) {
-    float xs[8], ws[8], ms[8];
-    bool ok[8];
+  const int FO = d.frames_out;
+  // workgroup-uniform: every frame of a batch lies inside the signal (no reflection, no frame past the end) and its sample
+  // pairs are 8-byte aligned -> plain loads straight into the registers of pass A, ISSUED BEFORE the previous batch's epilogue
+  // (the barriers do not wait for them).  Otherwise (the first / last batches of a row, odd hops, the iSTFT-backward multiplier)
+  // the samples are mapped one by one in a rolled loop and staged through LDS.
+  auto batch_fast = [&](int fb0) -> bool {
+    const int64_t pb0 = (int64_t)fb0 * d.hop;
+    return (fb0 + FB <= f_end) & (pb0 - shift >= 0) & (pb0 + (int64_t)(FB - 1) * d.hop + N - 1 - shift < (int64_t)d.T) &
+           !(d.hop & 1) & ((((int64_t)row * d.T + pb0 - shift) & 1) == 0) & ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) & (a.mul == nullptr);
+  };
+  v2f z[16];
+  auto load_fast = [&](int fb0) {
+    const v2f* src = reinterpret_cast<const v2f*>(xr + ((int64_t)(fb0 + fl) * d.hop - shift)) + u;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + 256 * (j0 + e);
-      const int fl = idx >> LOGN, i = idx & (NC - 1);
-      const int f = f_first + fl;
+    for (int n = 0; n < 16; ++n) z[n] = src[T * n];
+  };
+  bool fast = f_first < f_end && batch_fast(f_first);
+  if (fast) load_fast(f_first);
+  for (int g = 0; g < a.nbatch; ++g) {
+    const int fb0 = f_first + g * FB;
+    if (fb0 >= f_end) break;                                   // workgroup-uniform
+    const int f = fb0 + fl;
+    const int64_t p0 = (int64_t)f * d.hop;
+    if (fast) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int t = 2 * i + u;
-        const int pp = f * d.hop + t;
-        if (NCB <= 4) {
-          const int sm = interior ? pp - shift : map_sample(d, pp);
-          const bool v = interior | ((f < f_end) & (sm >= 0));
-          ok[2 * e + u] = v;
-          xs[2 * e + u] = xr[v ? sm : 0];
-          ws[2 * e + u] = wv[e & (NCB <= 4 ? NCB - 1 : 0)][u];      // j0 is a multiple of 4: (j0 + e) mod NCB = e mod NCB
-          ms[2 * e + u] = a.mul ? a.mul[v ? pp : 0] : 1.f;       // a.mul: wave-uniform
-        } else {
-          const int wi = t - woff;
+      for (int n = 0; n < 16; ++n) z[n] = z[n] * wv[n];
+    } else {
+#pragma unroll 1
+      for (int n = 0; n < 16; ++n) {
+        float s[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int t = 2 * (u + T * n) + c, pp = (int)p0 + t, wi = t - woff;
           const int sm = map_sample(d, pp);
-          const bool v = (f < f_end) & (wi >= 0) & (wi < d.win) & (sm >= 0);
-          ok[2 * e + u] = v;
-          xs[2 * e + u] = xr[v ? sm : 0];
-          ws[2 * e + u] = a.window[v ? wi : 0] * d.scale;
-          ms[2 * e + u] = a.mul ? a.mul[v ? pp : 0] : 1.f;
+          const bool v = (f < f_end) & (sm >= 0) & (wi >= 0) & (wi < d.win);
+          const float xv = xr[v ? sm : 0] * a.window[v ? wi : 0] * d.scale;
+          const float mv = a.mul ? a.mul[v ? pp : 0] : 1.f;
+          s[c] = v ? xv * mv : 0.f;
+        }
+        data[fl * K::FS + u + T * n] = v2f{s[0], s[1]};
+      }
+      lds_barrier();
+#pragma unroll
+      for (int n = 0; n < 16; ++n) z[n] = data[fl * K::FS + u + T * n];
+      lds_barrier();
+    }
+    fft_core<LOGN>(z, data, st);
+    lds_barrier();
+    fast = (g + 1 < a.nbatch) && (fb0 + FB < f_end) && batch_fast(fb0 + FB);
+    if (fast) load_fast(fb0 + FB);                             // z is dead until the next batch: its loads fly over the epilogue
+    // split step on bin pairs (k, NC - k):
+    //   E = (A + conj B) / 2, P = (A - conj B) / 2 * e^{-i pi k / NC}:  X[k] = E - i P,  X[NC - k] = conj E - i conj P
+    // frame-major spectrum: lanes along bins, every frame's bins are one contiguous run (full-line stores)
+    if (d.mode == RFX_STFT_COMPLEX_FM) {
+      for (int idx = tid; idx < K::NH * FB; idx += 256) {
+        const int fl2 = idx / K::NH, k = idx - fl2 * K::NH;
+        const int f2 = fb0 + fl2;
+        if (f2 >= f_end) continue;
+        const v2f* fr = data + fl2 * K::FS;
+        const v2f A = fr[fft_phys3<LOGN>(k)];
+        const v2f B = cconj(fr[fft_phys3<LOGN>((NC - k) & (NC - 1))]);
+        const v2f E = (A + B) * 0.5f, D = (A - B) * 0.5f;
+        const v2f P = cmul(D, tb.twH[k]);
+        v2f X0 = v2f{E.x + P.y, E.y - P.x}, X1 = v2f{E.x - P.y, -E.y - P.x};
+        if (d.herm) {
+          if (k == 0) { X0.y = 0.f; X1.y = 0.f; }
+          else { X0 = X0 * 2.f; X1 = X1 * 2.f; }
+        }
+        v2f* o = reinterpret_cast<v2f*>(a.out) + ((int64_t)row * FO + (f2 - d.frame0)) * d.bins;
+        if (k < d.bins) o[k] = X0;
+        if (k != NC - k && NC - k < d.bins) o[NC - k] = X1;
+      }
+      lds_barrier();
+      continue;
+    }
+    // transposing epilogue, lanes along frames
+    for (int idx = tid; idx < K::NH * FB; idx += 256) {
+      const int k = idx / FB, fl2 = idx & (FB - 1);
+      const int f2 = fb0 + fl2;
+      if (f2 >= f_end) continue;
+      const v2f* fr = data + fl2 * K::FS;
+      const v2f A = fr[fft_phys3<LOGN>(k)];
+      const v2f B = cconj(fr[fft_phys3<LOGN>((NC - k) & (NC - 1))]);
+      const v2f E = (A + B) * 0.5f, D = (A - B) * 0.5f;
+      const v2f P = cmul(D, tb.twH[k]);
+      v2f X[2] = {v2f{E.x + P.y, E.y - P.x}, v2f{E.x - P.y, -E.y - P.x}};
+      const int kk[2] = {k, NC - k};
+      const int fo = f2 - d.frame0;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c == 1 && k == NC - k) break;
+        const int kc = kk[c];
+        if (kc >= d.bins) continue;
+        v2f Xc = X[c];
+        if (d.herm) {  // gradient of irfft: middle bins doubled, DC / Nyquist imaginary part dropped
+          if (kc == 0 || kc == NC) Xc.y = 0.f;
+          else Xc = Xc * 2.f;
+        }
+        const int64_t rb = (int64_t)row * d.bins + kc;
+        switch (d.mode) {
+          case RFX_STFT_COMPLEX:
+            reinterpret_cast<v2f*>(a.out)[rb * FO + fo] = Xc;
+            break;
+          case RFX_STFT_CAC:
+            a.out[((int64_t)row * 2 * d.bins + kc) * FO + fo] = Xc.x;
+            a.out[((int64_t)row * 2 * d.bins + d.bins + kc) * FO + fo] = Xc.y;
+            break;
+          case RFX_STFT_MAG:
+            a.out[rb * FO + fo] = sqrtf(fmaxf(Xc.x * Xc.x + Xc.y * Xc.y, d.eps));
+            break;
+          case RFX_STFT_POW:
+            a.out[rb * FO + fo] = Xc.x * Xc.x + Xc.y * Xc.y;
+            break;
+          default:  // RFX_STFT_MAGPOW
+            a.out[rb * FO + fo] = powf(sqrtf(Xc.x * Xc.x + Xc.y * Xc.y) + d.eps, d.alpha);
+            break;
         }
       }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + 256 * (j0 + e);
-      const int fl = idx >> LOGN, i = idx & (NC - 1);
-      float2 v;
-      v.x = ok[2 * e] ? xs[2 * e] * ws[2 * e] * ms[2 * e] : 0.f;
-      v.y = ok[2 * e + 1] ? xs[2 * e + 1] * ws[2 * e + 1] * ms[2 * e + 1] : 0.f;
-      data[fl * FS + i] = v;
-    }
-  }
-  __syncthreads();
-  fft_passes<LOGN, false>(data, tw, FB * NC);
-  // split step + transposing epilogue: lanes along frames
-  const int FO = d.frames_out;
-  for (int idx = tid; idx < d.bins * FB; idx += 256) {
-    const int k = idx / FB, fl = idx - k * FB;
-    const int f = f_first + fl;
-    if (f >= f_end) continue;
-    const float2 A = data[fl * FS + rev[k & (NC - 1)]];
-    const float2 Bq = data[fl * FS + rev[(NC - k) & (NC - 1)]];
-    const float2 Bc = make_float2(Bq.x, -Bq.y);
-    const float2 E = make_float2(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
-    const float2 D = make_float2(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
-    const float2 O = make_float2(D.y, -D.x);  // D * (-i)
-    const float2 hw = half_twiddle<LOGN>(tw, tw2, k);      // e^{-i pi k / NC}
-    float2 X = cmul(O, hw);
-    X.x += E.x;
-    X.y += E.y;
-    if (d.herm) {  // gradient of irfft: middle bins doubled, DC / Nyquist imaginary part dropped
-      if (k == 0 || k == NC) X.y = 0.f;
-      else { X.x *= 2.f; X.y *= 2.f; }
-    }
-    const int fo = f - d.frame0;
-    const int64_t rb = (int64_t)row * d.bins + k;
-    switch (d.mode) {
-      case RFX_STFT_COMPLEX:
-        reinterpret_cast<float2*>(a.out)[rb * FO + fo] = X;
-        break;
-      case RFX_STFT_CAC:
-        a.out[((int64_t)row * 2 * d.bins + k) * FO + fo] = X.x;
-        a.out[((int64_t)row * 2 * d.bins + d.bins + k) * FO + fo] = X.y;
-        break;
-      case RFX_STFT_MAG:
-        a.out[rb * FO + fo] = sqrtf(fmaxf(X.x * X.x + X.y * X.y, d.eps));
-        break;
-      case RFX_STFT_POW:
-        a.out[rb * FO + fo] = X.x * X.x + X.y * X.y;
-        break;
-      default:  // RFX_STFT_MAGPOW
-        a.out[rb * FO + fo] = powf(sqrtf(X.x * X.x + X.y * X.y) + d.eps, d.alpha);
-        break;
-    }
+    lds_barrier();      // the next batch's pass A / B writes E1 / E2 over this batch's E3
   }
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(256) void fft_synthesis_kernel(const FftArgs a) {
-  constexpr int NC = 1 << LOGN, FB = RFX_FFT_PTS(LOGN) >> LOGN, FS = NC + 1, N = 2 * NC;
-  __shared__ float2 data[FB * FS];
-  __shared__ float2 tw[NC];
-  __shared__ float2 tw2[LOGN <= 10 ? NC / 2 : 1];     // e^{-i pi k / NC} for ODD k (even k is tw[k/2]); LDS budget: n_fft <= 2048
-  __shared__ uint16_t rev[NC];
+__global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) {
+  typedef FftCfg<LOGN> K;
+  constexpr int NC = K::NC, T = K::T, FB = K::FB, N = 2 * NC;
+  __shared__ v2f data[FB * K::FS];
+  __shared__ FftTables<LOGN> tb;
   const rfx_stft_desc& d = a.d;
   int row, f_first;
   block_coords<LOGN>(a, row, f_first);
   if (row >= d.R) return;
-  const int tid = threadIdx.x;
-  build_twiddles<LOGN>(tw);
-  build_half_twiddles<LOGN>(tw2);
-  build_rev<LOGN>(rev);
-  __syncthreads();                       // the merge step below reads the tables other threads built
+  const int tid = threadIdx.x, u = tid & (T - 1), fl = tid / T;
+  FftState<LOGN> st;
+  fft_setup<LOGN>(a, tb, st);
+  lds_barrier();                       // the merge step below reads the table other threads loaded
   const int f_end = d.frame0 + d.frames_out;
   const int FO = d.frames_out;
-  // merge step: Z[k] = (X[k] + conj X[NC-k]) + i e^{+i pi k/NC} (X[k] - conj X[NC-k]),  k in [0, NC)
-  // batched, unconditional loads (see the analysis kernel): 2 points x (bin k, bin NC-k) x (re, im) per round
-  for (int j0 = 0; j0 < (NC * FB) / 256; j0 += 2) {
-    float2 xk[2], xm[2];
-    bool fv[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int idx = tid + 256 * (j0 + e);
-      const int k = idx / FB, fl = idx - k * FB;
-      const int f = f_first + fl;
-      fv[e] = f < f_end;
-      const int fo = fv[e] ? f - d.frame0 : 0;
-      auto fetch = [&](int kk) -> float2 {
-        const bool in = kk < d.bins;
-        const int kc = in ? kk : 0;
-        float2 v;
-        if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const float2*>(a.x)[((int64_t)row * d.bins + kc) * FO + fo];   // uniform
+  const int woff = (N - d.win) / 2;
+  float* outr = a.out + (int64_t)row * d.T;
+  for (int g = 0; g < a.nbatch; ++g) {
+    const int fb0 = f_first + g * FB;
+    if (fb0 >= f_end) break;
+    // merge step on bin pairs (k, NC - k), k in [0, NC / 2]: S = X[k] + conj X[NC-k], W = (X[k] - conj X[NC-k]) e^{+i pi k/NC}
+    //   Z[k] = S + i W,  Z[NC - k] = conj S + i conj W;  conj Z is written in natural order (the inverse = conj FFT conj)
+    const bool fm = d.mode == RFX_STFT_COMPLEX_FM;           // frame-major spectrum: lanes along bins
+    for (int idx = tid; idx < K::NH * FB; idx += 256) {
+      const int fl2 = fm ? idx / K::NH : idx & (FB - 1), k = fm ? idx - fl2 * K::NH : idx / FB;
+      const int f2 = fb0 + fl2;
+      const bool fv = f2 < f_end;
+      const int fo = fv ? f2 - d.frame0 : 0;
+      auto fetch = [&](int kq) -> v2f {
+        const bool in = kq < d.bins;
+        const int kc = in ? kq : 0;
+        v2f v;
+        if (fm) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * FO + fo) * d.bins + kc];
+        else if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * d.bins + kc) * FO + fo];   // uniform
         else {
           v.x = a.x[((int64_t)row * 2 * d.bins + kc) * FO + fo];
           v.y = a.x[((int64_t)row * 2 * d.bins + d.bins + kc) * FO + fo];
         }
-        if (!in) v = make_float2(0.f, 0.f);
-        if (kk == 0 || kk == NC) v.y = 0.f;           // real by construction / ignored by irfft
-        else if (!d.herm) { v.x *= 0.5f; v.y *= 0.5f; }  // adjoint of the one-sided rfft
+        if (!in) v = v2f{0.f, 0.f};
+        if (kq == 0 || kq == NC) v.y = 0.f;           // real by construction / ignored by irfft
+        else if (!d.herm) v = v * 0.5f;               // adjoint of the one-sided rfft
         return v;
       };
-      xk[e] = fetch(k);
-      xm[e] = fetch(NC - k);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int idx = tid + 256 * (j0 + e);
-      const int k = idx / FB, fl = idx - k * FB;
-      float2 Z = make_float2(0.f, 0.f);
-      if (fv[e]) {
-        const float2 Xc = make_float2(xm[e].x, -xm[e].y);
-        const float2 S = make_float2(xk[e].x + Xc.x, xk[e].y + Xc.y);
-        const float2 D = make_float2(xk[e].x - Xc.x, xk[e].y - Xc.y);
-        const float2 hw = half_twiddle<LOGN>(tw, tw2, k);     // e^{-i pi k/NC}; the merge needs its conjugate
-        const float2 W = cmul(D, make_float2(hw.x, -hw.y));
-        Z = make_float2(S.x - W.y, S.y + W.x);  // S + i*W
+      const v2f xk = fetch(k), xm = cconj(fetch(NC - k));
+      v2f Z0 = v2f{0.f, 0.f}, Z1 = v2f{0.f, 0.f};
+      if (fv) {
+        const v2f S = xk + xm, D = xk - xm;
+        const v2f W = cmul(D, cconj(tb.twH[k]));
+        Z0 = v2f{S.x - W.y, -(S.y + W.x)};            // conj Z[k]
+        Z1 = v2f{S.x + W.y, S.y - W.x};               // conj Z[NC - k]
       }
-      data[fl * FS + rev[k]] = Z;
+      v2f* fr = data + fl2 * K::FS;
+      fr[k] = Z0;
+      if (k != 0 && k != NC - k) fr[NC - k] = Z1;
     }
-  }
-  __syncthreads();
-  fft_passes<LOGN, true>(data, tw, FB * NC);
-  const int woff = (N - d.win) / 2;
-  float* outr = a.out + (int64_t)row * d.T;
-  // Overlap-add by GATHER inside the workgroup: its frames are consecutive, so every padded position p of their span
-  // sums the <= ceil(win / hop) frames that cover it out of LDS and issues ONE global atomic (the scatter form issued
-  // one per (frame, sample): 3.3-4.3x more, and the loss-gradient launches ran at the L2 atomic rate, 0.46 TB/s).
-  const int nf = min(FB, f_end - f_first);
-  if (nf <= 0) return;
-  const int span = (nf - 1) * d.hop + N;
-  const int64_t p0 = (int64_t)f_first * d.hop;
-  for (int q = tid; q < span; q += 256) {
-    const int qw = q - woff;                       // window index of frame 0 at this position
-    if (qw < 0) continue;
-    const int fl_hi = min(nf - 1, qw / d.hop);
-    const int lo_num = qw - d.win + 1;
-    const int fl_lo = lo_num > 0 ? (lo_num + d.hop - 1) / d.hop : 0;
-    if (fl_lo > fl_hi) continue;
-    float v = 0.f;
-    for (int fl = fl_lo; fl <= fl_hi; ++fl) {
-      const int t = q - fl * d.hop;
-      const float2 z = data[fl * FS + (t >> 1)];
-      v += ((t & 1) ? z.y : z.x) * a.window[t - woff];
+    lds_barrier();
+    v2f z[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) z[n] = data[fl * K::FS + u + T * n];
+    lds_barrier();
+    fft_core<LOGN>(z, data, st);
+    lds_barrier();
+    // Overlap-add by GATHER inside the workgroup: the batch's frames are consecutive, so every padded position p of their span
+    // sums the <= ceil(win / hop) frames that cover it out of LDS and issues ONE global atomic (the scatter form issued
+    // one per (frame, sample): 3.3-4.3x more, and the loss-gradient launches ran at the L2 atomic rate, 0.46 TB/s).
+    const int nf = min(FB, f_end - fb0);
+    const int span = (nf - 1) * d.hop + N;
+    const int64_t p0 = (int64_t)fb0 * d.hop;
+    for (int q = tid; q < span; q += 256) {
+      const int qw = q - woff;                       // window index of frame 0 at this position
+      if (qw < 0) continue;
+      const int fl_hi = min(nf - 1, qw / d.hop);
+      const int lo_num = qw - d.win + 1;
+      const int fl_lo = lo_num > 0 ? (lo_num + d.hop - 1) / d.hop : 0;
+      if (fl_lo > fl_hi) continue;
+      float v = 0.f;
+      for (int f2 = fl_lo; f2 <= fl_hi; ++f2) {
+        const int t = q - f2 * d.hop;
+        const v2f zz = data[f2 * K::FS + fft_phys3<LOGN>(t >> 1)];
+        v += ((t & 1) ? -zz.y : zz.x) * a.window[t - woff];
+      }
+      const int64_t p = p0 + q;
+      const int sidx = map_sample(d, (int)p);
+      if (sidx < 0) continue;
+      v *= d.scale;
+      if (a.mul) v *= a.mul[p];
+      atomicAdd(outr + sidx, v);
     }
-    const int64_t p = p0 + q;
-    const int sidx = map_sample(d, (int)p);
-    if (sidx < 0) continue;
-    v *= d.scale;
-    if (a.mul) v *= a.mul[p];
-    atomicAdd(outr + sidx, v);
+    lds_barrier();
   }
 }
 
@@ -422,6 +481,36 @@ static bool stft_desc_ok(const rfx_stft_desc* d) {
          d->bins > 0 && d->bins <= n / 2 + 1 && d->frame0 >= 0;
 }
 
+// twiddle tables of one n_fft on the current device: [256] W_256^t | [256] W_NC^t | [NC/2 + 1] e^{-i pi k / NC}
+static const v2f* fft_tables(int nc) {
+  static std::mutex mu;
+  static v2f* tab[16][4] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  const int slot = nc == 256 ? 0 : nc == 512 ? 1 : nc == 1024 ? 2 : 3;
+  std::lock_guard<std::mutex> lock(mu);
+  if (tab[dev][slot]) return tab[dev][slot];
+  const int n = 512 + nc / 2 + 1;
+  float* h = new float[2 * n];
+  const double pi = 3.14159265358979323846;
+  for (int t = 0; t < 256; ++t) {
+    h[2 * t] = (float)cos(-2.0 * pi * t / 256.0);
+    h[2 * t + 1] = (float)sin(-2.0 * pi * t / 256.0);
+    h[2 * (256 + t)] = (float)cos(-2.0 * pi * t / (double)nc);
+    h[2 * (256 + t) + 1] = (float)sin(-2.0 * pi * t / (double)nc);
+  }
+  for (int k = 0; k <= nc / 2; ++k) {
+    h[2 * (512 + k)] = (float)cos(-pi * k / (double)nc);
+    h[2 * (512 + k) + 1] = (float)sin(-pi * k / (double)nc);
+  }
+  v2f* p = nullptr;
+  if (hipMalloc(&p, sizeof(float) * 2 * n) == hipSuccess && hipMemcpy(p, h, sizeof(float) * 2 * n, hipMemcpyHostToDevice) == hipSuccess)
+    tab[dev][slot] = p;
+  else if (p) { (void)hipFree(p); p = nullptr; }
+  delete[] h;
+  return tab[dev][slot];
+}
+
 template <bool SYN>
 static int launch_fft(const rfx_stft_desc* d, const float* x, const float* window, const float* mul,
                       float* out, void* stream) {
@@ -429,9 +518,20 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
   FftArgs a;
   a.d = *d; a.x = x; a.window = window; a.mul = mul; a.out = out;
   const int nc = d->n_fft / 2;
-  const int fb = rfx_fft_pts(nc) / nc;
-  a.groups_per_row = (d->frames_out + fb - 1) / fb;
+  a.tables = fft_tables(nc);
+  if (!a.tables) return -3;
+  const int fb = 4096 / nc;
+  const int batches = (d->frames_out + fb - 1) / fb;
   const int rows8 = (d->R + 7) / 8;
+  // frame batches per workgroup: amortises the per-workgroup setup (tables, window registers) while the grid stays several times
+  // the 768 workgroups the chip holds at once.  Only for the frame-major layout: with a [bin][frame] spectrum the workgroups that
+  // share a 128-byte line must run at the same time for their partial-line stores to merge in L2 (_spec: 253 us at one batch per
+  // workgroup, 370 / 458 us at two / four -- measured).
+  int nb = 1;
+  if (d->mode == RFX_STFT_COMPLEX_FM)
+    while (nb < (SYN ? 2 : 4) && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
+  a.nbatch = nb;
+  a.groups_per_row = (batches + nb - 1) / nb;
   const unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);
   hipStream_t s = (hipStream_t)stream;
   switch (d->n_fft) {
@@ -462,6 +562,6 @@ extern "C" int rfx_fft_analysis(const rfx_stft_desc* d, const float* x, const fl
 }
 extern "C" int rfx_fft_synthesis(const rfx_stft_desc* d, const float* spec, const float* window,
                                  const float* mul, float* out, void* stream) {
-  if (d && d->mode != RFX_STFT_COMPLEX && d->mode != RFX_STFT_CAC) return -1;
+  if (d && d->mode != RFX_STFT_COMPLEX && d->mode != RFX_STFT_CAC && d->mode != RFX_STFT_COMPLEX_FM) return -1;
   return launch_fft<true>(d, spec, window, mul, out, stream);
 }

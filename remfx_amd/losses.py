@@ -46,13 +46,18 @@ class stft_memo:
         return False
 
 
+# The loss kernels are elementwise over (prediction, target) spectra plus row sums: layout-free.  Frame-major spectra
+# ([R][frames][bins][2]) let the FFT kernels store / load whole lines instead of pieces of a [bin][frame] transpose.
+_SPEC_MODE = stft.MODES["complex_fm"]
+
+
 def _spectrum(sig, n_fft, hop, win, w):
     if _MEMO is None:
-        return stft.stft_raw(sig, n_fft, hop, win, w, 0)
+        return stft.stft_raw(sig, n_fft, hop, win, w, _SPEC_MODE)
     key = (sig.data_ptr(), sig._version, tuple(sig.shape), tuple(sig.stride()), n_fft, hop, win)
     hit = _MEMO.get(key)
     if hit is None:
-        hit = (sig, stft.stft_raw(sig, n_fft, hop, win, w, 0))     # holding sig keeps its storage from being reused
+        hit = (sig, stft.stft_raw(sig, n_fft, hop, win, w, _SPEC_MODE))     # holding sig keeps its storage from being reused
         _MEMO[key] = hit
         _MEMO[("spec", hit[1].data_ptr())] = True
     return hit[1]
@@ -109,7 +114,7 @@ class _MRSTFTFn(torch.autograd.Function):
             check(_lib.lib().rfx_stft_loss_grad(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(G),
                                                 _stream()), "rfx_stft_loss_grad")
             w = stft.hann(win, g.device)
-            d = stft._desc(R, L, n_fft, hop, win, X.shape[1], 0, X.shape[2], 0, in_mode=0, herm=0, scale=1.0)
+            d = stft._desc(R, L, n_fft, hop, win, X.shape[2], 0, X.shape[1], _SPEC_MODE, in_mode=0, herm=0, scale=1.0)
             check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(G), _ptr(w), None, _ptr(gx), _stream()),
                   "rfx_fft_synthesis")
         ctx.saved = None

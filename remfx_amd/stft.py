@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import StftDesc, check
 from .ops import _ptr, _req, _stream
 
-MODES = {"complex": 0, "cac": 1, "mag": 2, "pow": 3, "magpow": 4}
+MODES = {"complex": 0, "cac": 1, "mag": 2, "pow": 3, "magpow": 4, "complex_fm": 5}
 _WINDOWS = {}
 
 
@@ -44,6 +44,8 @@ def _out_shape(R, bins, frames, mode):
         return (R, bins, frames, 2)
     if mode == 1:
         return (R, 2, bins, frames)
+    if mode == 5:                      # frame-major complex (layout-free consumers: the MR-STFT loss kernels)
+        return (R, frames, bins, 2)
     return (R, bins, frames)
 
 
@@ -82,7 +84,7 @@ class STFTFn(torch.autograd.Function):
         (window,) = ctx.saved_tensors
         (R, T), n_fft, hop, win, mode, normalized, bins, frame0, frames_out, extra_pad = ctx.cfg
         g = g.contiguous()
-        fo = g.shape[2] if mode == 0 else g.shape[3]
+        fo = g.shape[2] if mode == 0 else g.shape[1] if mode == 5 else g.shape[3]
         nb = g.shape[1] if mode == 0 else g.shape[2]
         gx = torch.zeros((R, T), device=g.device, dtype=torch.float32)
         d = _desc(R, T, n_fft, hop, win, nb, frame0, fo, mode, extra_pad, in_mode=0, herm=0,
@@ -99,7 +101,7 @@ def stft(x, n_fft, hop, win=None, window=None, mode="complex", normalized=False,
     win = n_fft if win is None else win
     window = hann(win, x.device) if window is None else window
     m = MODES[mode]
-    if m <= 1:
+    if m <= 1 or m == 5:
         return STFTFn.apply(x, window, n_fft, hop, win, m, normalized, bins, frame0, frames_out, extra_pad)
     return stft_raw(x.contiguous(), n_fft, hop, win, window, m, normalized, eps, alpha, bins, frame0,
                     frames_out, extra_pad)

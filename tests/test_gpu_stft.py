@@ -42,6 +42,24 @@ def test_stft_forward_modes(geom):
 
 
 @pytest.mark.parametrize("geom", GEOMS)
+def test_stft_frame_major(geom):
+    """complex_fm = the complex spectrum with (bins, frames) swapped, forward and adjoint (the MR-STFT loss's layout)."""
+    from remfx_amd import stft
+    n_fft, hop, win = geom
+    g = torch.Generator().manual_seed(n_fft + 3 * hop)
+    x = torch.randn(3, 30011, generator=g).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    a = stft.stft(xa, n_fft, hop, win, mode="complex")
+    b = stft.stft(xb, n_fft, hop, win, mode="complex_fm")
+    assert b.shape == (a.shape[0], a.shape[2], a.shape[1], 2)
+    assert torch.equal(a.permute(0, 2, 1, 3), b)
+    gy = torch.randn(a.shape, generator=g).to(DEV)
+    a.backward(gy)
+    b.backward(gy.permute(0, 2, 1, 3).contiguous())
+    assert _rms(xa.grad.cpu(), xb.grad.cpu()) < 1e-6 * float(xa.grad.abs().max())
+
+
+@pytest.mark.parametrize("geom", GEOMS)
 def test_stft_backward(geom):
     from remfx_amd import stft
     n_fft, hop, win = geom
