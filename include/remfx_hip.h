@@ -469,6 +469,9 @@ int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t L, int64_t
 /* ---- optimiser (flat fp32 buffers) ----------------------------------------------
  * Replaces torch.optim.AdamW.step + Lightning gradient_clip_val (models.py:185-191,
  * cfg/config.yaml:119).  *out += sum g^2 (fp64). */
+/* nbytes (multiple of 4) of zeros at p: optimizer.zero_grad() on the flat gradient buffer and the accumulation targets of the
+ * atomics-based kernels (torch.zeros call sites of the hot path; Lightning's zero_grad behind models.py:185-191) */
+int rfx_zero(void* p, int64_t nbytes, void* stream);
 int rfx_sumsq(const float* g, int64_t n, double* out, void* stream);
 /* *coef = min(1, max_norm / (sqrt(*sumsq) * pre + 1e-6)) * pre ; *norm_out = sqrt(*sumsq) * pre */
 int rfx_clip_coef(const double* sumsq, float max_norm, float pre, float* coef, float* norm_out, void* stream);

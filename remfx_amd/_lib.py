@@ -110,6 +110,7 @@ SIGNATURES = {
     "rfx_stft_loss_grad": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P],
     "rfx_l1_grad": [_P, _P, _I64, C.c_float, _P, _P],
     "rfx_sisdr_sums": [_P, _P, _I32, _I64, _I64, _I64, _P, _P],
+    "rfx_zero": [_P, _I64, _P],
     "rfx_sumsq": [_P, _I64, _P, _P],
     "rfx_clip_coef": [_P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_adamw_step": [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P, _P],

@@ -39,6 +39,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// Zero fill of nbytes (a multiple of 4, base 4-byte aligned): 16-byte stores, grid sized to the buffer.  (The framework's own fill ran
+// the 334 MB gradient buffer at 0.5 TB/s and the step issues ~200 fills: 3 ms of a 150 ms step.)
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, int64_t nwords) {
+  const int64_t head = min<int64_t>(((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2, nwords);
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if (gid < head) p[gid] = 0u;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  const int64_t n4 = (nwords - head) >> 2;
+  for (int64_t i = gid; i < n4; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+  const int64_t tail0 = head + (n4 << 2);
+  if (tail0 + gid < nwords) p[tail0 + gid] = 0u;
+}
+
 // coef = min(1, max_norm / (sqrt(sumsq * pre^2) + 1e-6)) * pre      (torch clip_grad_norm_ semantics;
 // pre = scale already owed to the gradients, e.g. 1/world_size after a summing all-reduce)
 __global__ void clip_coef_kernel(const double* __restrict__ sumsq, float max_norm, float pre, float* __restrict__ coef,
@@ -54,6 +67,16 @@ static int gridn(int64_t n) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
+extern "C" int rfx_zero(void* p, int64_t nbytes, void* stream) {
+  if (nbytes < 0 || (nbytes & 3) || (nbytes && !p) || (reinterpret_cast<uintptr_t>(p) & 3)) return -1;
+  if (nbytes == 0) return 0;
+  const int64_t nwords = nbytes >> 2;
+  const int64_t b = (nwords + 4095) / 4096;                       // four 16-byte stores per thread
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b))), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<uint32_t*>(p), nwords);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int rfx_sumsq(const float* g, int64_t n, double* out, void* stream) {
   if (!g || !out || n < 0) return -1;
   if (n == 0) return 0;

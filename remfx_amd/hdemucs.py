@@ -118,7 +118,7 @@ class _DConv(nn.Module):
                 # frequency-branch samples of (C, 256): the whole depth-layer in one launch per direction (csrc/dconv.hip)
                 x = nnops.dconv_layer(x, mods[0], mods[1], mods[3], mods[4], mods[6].scale, dil)
                 continue
-            st = torch.zeros((x.shape[0], _STAT_SLOTS, 2), device=x.device, dtype=torch.float64)   # GN(1, C) statistics
+            st = ops.zeros((x.shape[0], _STAT_SLOTS, 2), x.device, torch.float64)   # GN(1, C) statistics
             y, x = ops.conv1d_fork(x, mods[0].weight, mods[0].bias, 1, pad, dil, stat_sums=st, out_bf16=True)   # statistics come out of the GEMM epilogue
             y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu", sums=st)
             i = 3
@@ -126,7 +126,7 @@ class _DConv(nn.Module):
                 y = mods[i](y); i += 1
             if attn:
                 y = mods[i](y); i += 1
-            st = torch.zeros((x.shape[0], _STAT_SLOTS, 2), device=x.device, dtype=torch.float64)
+            st = ops.zeros((x.shape[0], _STAT_SLOTS, 2), x.device, torch.float64)
             # the 2C-channel tensor is read only by the GroupNorm + GLU kernel (and, in backward, its gradient only by GEMMs):
             # 16-bit storage in the bf16 mode
             y = ops.conv1d(y, mods[i].weight, mods[i].bias, stat_sums=st, out_bf16=True)
@@ -405,8 +405,8 @@ class HDemucs(nn.Module):
                 emb = self.freq_emb.table().t()[None, :, :, None]
                 x = nnops.add(x, emb, self.freq_emb_scale)
             saved.append(x)
-        x = torch.zeros_like(x)
-        xt = torch.zeros_like(x)
+        x = ops.zeros(x.shape, x.device)
+        xt = ops.zeros(x.shape, x.device)
         offset = self.depth - len(self.time_decoder)
         fadd = tadd = False                      # the previous layer already added this layer's skip (activation_add)
         for idx, decode in enumerate(self.freq_decoder):

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib, stft
 from ._lib import check
-from .ops import _ptr, _req, _stream
+from .ops import _ptr, _req, _stream, zeros
 
 FFT_SIZES = (1024, 2048, 512)
 HOP_SIZES = (120, 240, 50)
@@ -79,7 +79,7 @@ class _MRSTFTFn(torch.autograd.Function):
             skey = ("sums", X.data_ptr(), Y.data_ptr(), eps)
             sums = _MEMO.get(skey) if _MEMO is not None else None   # metric(output, target) repeats the loss's row sums
             if sums is None:
-                sums = torch.zeros((R, 3), device=x.device, dtype=torch.float32)
+                sums = zeros((R, 3), x.device)
                 check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), _stream()),
                       "rfx_stft_loss_reduce")
                 if _MEMO is not None and ("spec", X.data_ptr()) in _MEMO and ("spec", Y.data_ptr()) in _MEMO:
@@ -99,7 +99,7 @@ class _MRSTFTFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         shape, R, L, eps, per_example_sc, nres = ctx.meta
-        gx = torch.zeros((R, L), device=g.device, dtype=torch.float32)
+        gx = zeros((R, L), g.device)
         gval = float(g)          # scalar upstream gradient (one host sync per backward)
         for X, Y, sums, n, n_fft, hop, win in ctx.saved:
             if not per_example_sc:      # whole-batch Frobenius norm: same A, B for every row

@@ -122,9 +122,9 @@ class _LSTMLayerFn(torch.autograd.Function):
             dwhh = []
             for d in range(2):
                 dp, xs, gs = _whh_plan(out4, dG, H, d, Bn)
-                dap = torch.zeros((dp.p.M, dp.p.Kpad), device=g.device, dtype=torch.float32)
+                dap = ops.zeros((dp.p.M, dp.p.Kpad), g.device)
                 ops.gemm_wgrad(dp, xs, gs, dap)
-                dw = torch.zeros((4 * H, H), device=g.device, dtype=torch.float32)
+                dw = ops.zeros((4 * H, H), g.device)
                 ops.unpack_add(dp, dap, dw)
                 dwhh.append(dw)
             db0, db1 = dbcat[:4 * H], dbcat[4 * H:]

@@ -133,6 +133,21 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def zeros(shape, device, dtype=torch.float32):
+    """torch.zeros on the GPU through rfx_zero (one launch at HBM rate on the current stream)."""
+    t = torch.empty(shape, device=device, dtype=dtype)
+    if t.numel():
+        check(_lib.lib().rfx_zero(_ptr(t), t.numel() * t.element_size(), _stream()), "rfx_zero")
+    return t
+
+
+def zero_(t):
+    """t.zero_() for a contiguous GPU tensor of a 4- or 8-byte type."""
+    if t.numel():
+        check(_lib.lib().rfx_zero(_ptr(t), t.numel() * t.element_size(), _stream()), "rfx_zero")
+    return t
+
+
 def _req(t, name="tensor"):
     if not (t.is_cuda and t.dtype == torch.float32):
         raise ValueError(f"{name}: remfx_amd ops need fp32 tensors on the GPU (got {t.dtype}, {t.device}); "
@@ -375,7 +390,7 @@ def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias, w=None, b=N
     tb = sink.lookup(b) if (tw is not None and need_bias) else None
     if tw is not None and (tb is not None or not need_bias):
         with torch.cuda.stream(sink.stream_for_wgrad(x, g)):
-            dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
+            dapack = zeros((p.M, p.Kpad), x.device)
             gemm_wgrad(dp, x, g, dapack)
             unpack_add(dp, dapack, tw[1])                      # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
             if need_bias:
@@ -384,7 +399,7 @@ def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias, w=None, b=N
         if need_bias:
             sink.wrote(tb[0])
         return None, None
-    dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
+    dapack = zeros((p.M, p.Kpad), x.device)
     gemm_wgrad(dp, x, g, dapack)
     dw = torch.empty(wshape, device=x.device, dtype=torch.float32)
     unpack_set(dp, dapack, dw)                             # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
@@ -578,7 +593,7 @@ class ConvT2dFn(torch.autograd.Function):
                 # in place on the sink's side stream (see conv2d_wgrad)
                 with torch.cuda.stream(sink.stream_for_wgrad(x, g)):
                     p = dp.p
-                    dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
+                    dapack = zeros((p.M, p.Kpad), x.device)
                     gemm_wgrad(dp, g, x, dapack)
                     unpack_add(dp, dapack, tw[1])
                     if has_bias:
@@ -589,9 +604,9 @@ class ConvT2dFn(torch.autograd.Function):
                 return dx, None, None, None, None, None, None
             if need_w:
                 p = dp.p
-                dapack = torch.zeros((p.M, p.Kpad), device=x.device, dtype=torch.float32)
+                dapack = zeros((p.M, p.Kpad), x.device)
                 gemm_wgrad(dp, g, x, dapack)
-                dw = torch.zeros_like(wc)
+                dw = zeros(wc.shape, wc.device)
                 unpack_add(dp, dapack, dw)
         if has_bias and ctx.needs_input_grad[2]:
             db = channel_sum(g)
@@ -617,7 +632,7 @@ def conv_transpose1d(x, w, bias=None, stride=1, dilation=1, crop_lo=0, out_len=N
 def channel_sum(g):
     """sum over (N, A, B) of a (N, C, A, B) tensor -> (C,)"""
     g4 = g if g.dim() == 4 else g.unsqueeze(2)
-    out = torch.zeros(g4.shape[1], device=g.device, dtype=torch.float32)
+    out = zeros(g4.shape[1], g.device)
     N, Cc, A, B = g4.shape
     s = g4.stride()
     check(_lib.lib().rfx_channel_sum(_ptr(g4), N, Cc, A, B, s[0], s[1], s[2], s[3], _ptr(out), _stream()),

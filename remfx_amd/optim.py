@@ -11,7 +11,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check
 from .ops import _ptr, _stream
 
@@ -45,7 +45,11 @@ class FlatParams:
         """One fill of the flat gradient buffer; arms the gradient sink: until join() the backward kernels accumulate
         parameter gradients straight into this buffer (weight-gradient GEMMs on the sink's side stream)."""
         self.join()
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            from . import ops
+            ops.zero_(self.grad)
+        else:
+            self.grad.zero_()
         for p, o in zip(self.params, self.offsets):      # re-seat in case something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
@@ -86,7 +90,7 @@ class FlatAdamW:
         self.step_count += 1
         gscale = None
         if clip_norm or grad_prescale != 1.0:
-            self._sumsq.zero_()
+            ops.zero_(self._sumsq)
             check(L.rfx_sumsq(_ptr(f.grad), f.numel, _ptr(self._sumsq), _stream()), "rfx_sumsq")
             check(L.rfx_clip_coef(_ptr(self._sumsq), float(clip_norm or 0.0), float(grad_prescale),
                                   _ptr(self._coef), _ptr(self.last_grad_norm), _stream()), "rfx_clip_coef")

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import StftDesc, check
-from .ops import _ptr, _req, _stream
+from .ops import _ptr, _req, _stream, zeros
 
 MODES = {"complex": 0, "cac": 1, "mag": 2, "pow": 3, "magpow": 4, "complex_fm": 5}
 _WINDOWS = {}
@@ -86,7 +86,7 @@ class STFTFn(torch.autograd.Function):
         g = g.contiguous()
         fo = g.shape[2] if mode == 0 else g.shape[1] if mode == 5 else g.shape[3]
         nb = g.shape[1] if mode == 0 else g.shape[2]
-        gx = torch.zeros((R, T), device=g.device, dtype=torch.float32)
+        gx = zeros((R, T), g.device)
         d = _desc(R, T, n_fft, hop, win, nb, frame0, fo, mode, extra_pad, in_mode=0, herm=0,
                   scale=(1.0 / math.sqrt(n_fft)) if normalized else 1.0)
         check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(g), _ptr(window), None, _ptr(gx), _stream()),
@@ -141,7 +141,7 @@ class ISTFTFn(torch.autograd.Function):
         fi = spec.shape[2] if mode == 0 else spec.shape[3]
         inv_env = _inv_envelope(window, n_fft, hop, win, frames, spec.device)
         scale = (math.sqrt(n_fft) if normalized else 1.0) / n_fft
-        out = torch.zeros((R, length), device=spec.device, dtype=torch.float32)
+        out = zeros((R, length), spec.device)
         d = _desc(R, length, n_fft, hop, win, nb, frame0, fi, mode, in_mode=1, in_offset=n_fft // 2 + crop,
                   herm=1, scale=scale)
         check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(spec), _ptr(window), _ptr(inv_env), _ptr(out),
