@@ -460,6 +460,17 @@ int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R, int64_t n,
 /* gxc = w_sc * d[sqrt(A_r)/sqrt(B_r)]/dxc + w_lm * d[sum |log|X|-log|Y||]/dxc  (A_r, B_r from sums) */
 int rfx_stft_loss_grad(const float* xc, const float* yc, int32_t R, int64_t n, float eps,
                        const float* sums, float w_sc, float w_lm, float* gxc, void* stream);
+/* The forward of one STFTLoss resolution in ONE launch (replaces two rfx_fft_analysis + rfx_stft_loss_reduce; auraloss STFTLoss behind
+ * models.py:320): two frames of a signal come out of one complex FFT (w s_a + i w s_b), the prediction's clamped powers wait in
+ * registers for the target's and the three row sums are accumulated into sums [R][3] (zeroed by the caller) in the epilogue.  d: R, T, n_fft (512 / 1024 / 2048), hop, win, frames_out = 1 + T / hop,
+ * bins = n_fft / 2 + 1, frame0 = 0, in_mode 0.  xspec / ymag (both or neither): the prediction's spectrum, frame-major complex
+ * [R][frames][bins][2], and the clamped target magnitudes [R][frames][bins], for rfx_stft_loss_grad_m + rfx_fft_synthesis
+ * (RFX_STFT_COMPLEX_FM) in the backward. */
+int rfx_stft_pair_loss(const rfx_stft_desc* d, const float* x, const float* y, const float* window, float eps, float* sums,
+                       float* xspec, float* ymag, void* stream);
+/* rfx_stft_loss_grad with the target given by its clamped magnitudes (rfx_stft_pair_loss's ymag) instead of its spectrum */
+int rfx_stft_loss_grad_m(const float* xc, const float* ymag, int32_t R, int64_t n, float eps, const float* sums, float w_sc,
+                         float w_lm, float* gxc, void* stream);
 /* g[i] = w * sign(a[i] - b[i])   (nn.L1Loss backward) */
 int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, float* g, void* stream);
 /* per row: sums[r] += { sum x, sum t, sum x t, sum x^2, sum t^2 } in fp64 (auraloss SISDRLoss) */

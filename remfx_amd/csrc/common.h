@@ -84,6 +84,10 @@ __device__ __forceinline__ float rfx_act_grad(float x, int act, float slope) {
   }
 }
 
+// |re + i im|^2 with ONE fixed rounding sequence: the loss forward (csrc/fft.hip) and backward (csrc/losses.hip) must agree bit for bit
+// on the power of a stored spectrum value (loss(x, x) has an exactly zero gradient only if |X| == |Y| there too)
+__device__ __forceinline__ float rfx_pow2(float re, float im) { return __builtin_fmaf(im, im, re * re); }
+
 __device__ __forceinline__ float rfx_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

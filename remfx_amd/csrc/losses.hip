@@ -53,27 +53,42 @@ __global__ __launch_bounds__(256) void stft_loss_reduce_kernel(const float2* __r
 
 // gxc = d/dxc [ w_sc * sqrt(A_r)/sqrt(B_r) + w_lm * sum |log xm - log ym| ]
 //   w_sc, w_lm already contain the upstream gradient and the 1/R, 1/(R*n), 1/3 factors.
+// ymag != NULL: the clamped target magnitudes sqrt(max(|Y|^2, eps)) as stored by rfx_stft_pair_loss (yc unused)
 __global__ __launch_bounds__(256) void stft_loss_grad_kernel(const float2* __restrict__ xc,
-                                                             const float2* __restrict__ yc, int64_t n,
+                                                             const float2* __restrict__ yc, const float* __restrict__ ymag, int64_t n,
                                                              float eps, const float* __restrict__ sums,
                                                              float w_sc, float w_lm, float2* __restrict__ gxc) {
   const int r = blockIdx.y;
   const float A = sums[3 * r], B = sums[3 * r + 1];
   const float ksc = (A > 0.f && B > 0.f) ? w_sc / (sqrtf(A) * sqrtf(B)) : 0.f;   // d sqrt(A)/sqrt(B) / dA * 2
   const float2* xr = xc + (int64_t)r * n;
-  const float2* yr = yc + (int64_t)r * n;
+  const float2* yr = yc ? yc + (int64_t)r * n : nullptr;
+  const float* mr = ymag ? ymag + (int64_t)r * n : nullptr;
   float2* gr = gxc + (int64_t)r * n;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float2 x = xr[i], y = yr[i];
-    const float px = x.x * x.x + x.y * x.y;
+    const float2 x = xr[i];
     float2 g = make_float2(0.f, 0.f);
-    if (px > eps) {   // clamp(min=eps) passes no gradient below eps
-      const float xm = sqrtf(px);
-      const float ym = sqrtf(fmaxf(y.x * y.x + y.y * y.y, eps));
-      const float lg = logf(xm) - logf(ym);
-      const float dm = ksc * (xm - ym) + w_lm * (lg > 0.f ? 1.f : (lg < 0.f ? -1.f : 0.f)) / xm;
-      g.x = dm * x.x / xm;
-      g.y = dm * x.y / xm;
+    if (mr) {
+      // paired forward (rfx_stft_pair_loss): the same rounding sequence as its epilogue -- rfx_pow2, hardware sqrt -- and the sign of
+      // log xm - log ym taken from xm - ym, so identical signals (|X| == |Y| bit for bit) get an exactly zero gradient
+      const float px = rfx_pow2(x.x, x.y);
+      if (px > eps) {
+        const float xm = __builtin_amdgcn_sqrtf(px), ym = mr[i];
+        const float dm = ksc * (xm - ym) + w_lm * (xm > ym ? 1.f : (xm < ym ? -1.f : 0.f)) / xm;
+        g.x = dm * x.x / xm;
+        g.y = dm * x.y / xm;
+      }
+    } else {
+      const float px = x.x * x.x + x.y * x.y;
+      if (px > eps) {   // clamp(min=eps) passes no gradient below eps
+        const float xm = sqrtf(px);
+        const float2 y = yr[i];
+        const float ym = sqrtf(fmaxf(y.x * y.x + y.y * y.y, eps));
+        const float lg = logf(xm) - logf(ym);
+        const float dm = ksc * (xm - ym) + w_lm * (lg > 0.f ? 1.f : (lg < 0.f ? -1.f : 0.f)) / xm;
+        g.x = dm * x.x / xm;
+        g.y = dm * x.y / xm;
+      }
     }
     gr[i] = g;
   }
@@ -135,7 +150,15 @@ extern "C" int rfx_stft_loss_grad(const float* xc, const float* yc, int32_t R, i
                                   const float* sums, float w_sc, float w_lm, float* gxc, void* stream) {
   if (!xc || !yc || !sums || !gxc || R <= 0 || n <= 0) return -1;
   hipLaunchKernelGGL(stft_loss_grad_kernel, dim3(grid_x(n), R), dim3(256), 0, (hipStream_t)stream,
-                     (const float2*)xc, (const float2*)yc, n, eps, sums, w_sc, w_lm, (float2*)gxc);
+                     (const float2*)xc, (const float2*)yc, (const float*)nullptr, n, eps, sums, w_sc, w_lm, (float2*)gxc);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_stft_loss_grad_m(const float* xc, const float* ymag, int32_t R, int64_t n, float eps,
+                                    const float* sums, float w_sc, float w_lm, float* gxc, void* stream) {
+  if (!xc || !ymag || !sums || !gxc || R <= 0 || n <= 0) return -1;
+  hipLaunchKernelGGL(stft_loss_grad_kernel, dim3(grid_x(n), R), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)xc, (const float2*)nullptr, ymag, n, eps, sums, w_sc, w_lm, (float2*)gxc);
   RFX_CHECK_LAUNCH();
   return 0;
 }

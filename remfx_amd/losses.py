@@ -63,6 +63,32 @@ def _spectrum(sig, n_fft, hop, win, w):
     return hit[1]
 
 
+def _sig_key(sig):
+    return (sig.data_ptr(), sig._version, tuple(sig.shape), tuple(sig.stride()))
+
+
+def _pair_sums(x2, y2, n_fft, hop, win, w, eps, store):
+    """One resolution in one launch (rfx_stft_pair_loss): row sums [R, 3]; with store=True also the prediction's spectrum
+    (frame-major complex) and the clamped target magnitudes, which the backward reads.  Memoised like _spectrum."""
+    key = ("pair", _sig_key(x2), _sig_key(y2), n_fft, hop, win, eps)
+    hit = _MEMO.get(key) if _MEMO is not None else None
+    if hit is not None and (hit[1] is not None or not store):
+        return hit[0], hit[1], hit[2]
+    R, L = x2.shape
+    if n_fft // 2 >= L:
+        raise ValueError("reflect padding needs n_fft/2 < signal length")
+    frames, bins = 1 + L // hop, n_fft // 2 + 1
+    sums = zeros((R, 3), x2.device)
+    X = torch.empty((R, frames, bins, 2), device=x2.device, dtype=torch.float32) if store else None
+    ym = torch.empty((R, frames, bins), device=x2.device, dtype=torch.float32) if store else None
+    d = stft._desc(R, L, n_fft, hop, win, bins, 0, frames, _SPEC_MODE)
+    check(_lib.lib().rfx_stft_pair_loss(C.byref(d), _ptr(x2), _ptr(y2), _ptr(w), eps, _ptr(sums), _ptr(X), _ptr(ym), _stream()),
+          "rfx_stft_pair_loss")
+    if _MEMO is not None:
+        _MEMO[key] = (sums, X, ym, x2, y2)      # holding the signals keeps their storage from being reused under the key
+    return sums, X, ym
+
+
 class _MRSTFTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, fft_sizes, hops, wins, eps, per_example_sc):
@@ -73,17 +99,25 @@ class _MRSTFTFn(torch.autograd.Function):
         saved, total = [], None
         for n_fft, hop, win in zip(fft_sizes, hops, wins):
             w = stft.hann(win, x.device)
-            X = _spectrum(x2, n_fft, hop, win, w)
-            Y = _spectrum(y2, n_fft, hop, win, w)
-            n = X.shape[1] * X.shape[2]
-            skey = ("sums", X.data_ptr(), Y.data_ptr(), eps)
-            sums = _MEMO.get(skey) if _MEMO is not None else None   # metric(output, target) repeats the loss's row sums
-            if sums is None:
-                sums = zeros((R, 3), x.device)
-                check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), _stream()),
-                      "rfx_stft_loss_reduce")
-                if _MEMO is not None and ("spec", X.data_ptr()) in _MEMO and ("spec", Y.data_ptr()) in _MEMO:
-                    _MEMO[skey] = sums                               # both spectra are held by the memo: pointers stay valid
+            if n_fft in (512, 1024, 2048):
+                # both spectra of a frame from one complex FFT, sums in its epilogue: no spectrum is written unless the backward
+                # needs it, and then only the prediction's + the target's magnitudes
+                sums, X, Y = _pair_sums(x2, y2, n_fft, hop, win, w, eps, ctx.needs_input_grad[0])
+                n = (1 + L // hop) * (n_fft // 2 + 1)
+                paired = True
+            else:
+                X = _spectrum(x2, n_fft, hop, win, w)
+                Y = _spectrum(y2, n_fft, hop, win, w)
+                n = X.shape[1] * X.shape[2]
+                paired = False
+                skey = ("sums", X.data_ptr(), Y.data_ptr(), eps)
+                sums = _MEMO.get(skey) if _MEMO is not None else None   # metric(output, target) repeats the loss's row sums
+                if sums is None:
+                    sums = zeros((R, 3), x.device)
+                    check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), _stream()),
+                          "rfx_stft_loss_reduce")
+                    if _MEMO is not None and ("spec", X.data_ptr()) in _MEMO and ("spec", Y.data_ptr()) in _MEMO:
+                        _MEMO[skey] = sums                               # both spectra are held by the memo: pointers stay valid
             if per_example_sc:
                 sc = (sums[:, 0].sqrt() / sums[:, 1].sqrt()).mean()
             else:
@@ -91,7 +125,7 @@ class _MRSTFTFn(torch.autograd.Function):
             lm = sums[:, 2].sum() / (R * n)
             term = sc + lm
             total = term if total is None else total + term
-            saved.append((X, Y, sums, n, n_fft, hop, win))
+            saved.append((paired, X, Y, sums, n, n_fft, hop, win))
         ctx.saved = saved
         ctx.meta = (x.shape, R, L, eps, per_example_sc, len(fft_sizes))
         return total / len(fft_sizes)
@@ -101,7 +135,7 @@ class _MRSTFTFn(torch.autograd.Function):
         shape, R, L, eps, per_example_sc, nres = ctx.meta
         gx = zeros((R, L), g.device)
         gval = float(g)          # scalar upstream gradient (one host sync per backward)
-        for X, Y, sums, n, n_fft, hop, win in ctx.saved:
+        for paired, X, Y, sums, n, n_fft, hop, win in ctx.saved:
             if not per_example_sc:      # whole-batch Frobenius norm: same A, B for every row
                 sums = sums.clone()
                 sums[:, 0] = sums[:, 0].sum()
@@ -111,8 +145,12 @@ class _MRSTFTFn(torch.autograd.Function):
                 w_sc = gval / (nres * R)
             w_lm = gval / (nres * R * n)
             G = torch.empty_like(X)
-            check(_lib.lib().rfx_stft_loss_grad(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(G),
-                                                _stream()), "rfx_stft_loss_grad")
+            if paired:                  # Y = the clamped target magnitudes
+                check(_lib.lib().rfx_stft_loss_grad_m(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(G),
+                                                      _stream()), "rfx_stft_loss_grad_m")
+            else:
+                check(_lib.lib().rfx_stft_loss_grad(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(G),
+                                                    _stream()), "rfx_stft_loss_grad")
             w = stft.hann(win, g.device)
             d = stft._desc(R, L, n_fft, hop, win, X.shape[2], 0, X.shape[1], _SPEC_MODE, in_mode=0, herm=0, scale=1.0)
             check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(G), _ptr(w), None, _ptr(gx), _stream()),

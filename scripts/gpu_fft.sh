@@ -1,6 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out/fft
-timeout 900 python -m pytest tests/test_gpu_stft.py -x -q -m gpu > gpurun_out/fft/t.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_stft.py tests/test_gpu_fullsize_properties.py -x -q -m gpu > gpurun_out/fft/t.log 2>&1
 tail -15 gpurun_out/fft/t.log
-for nb in 1 2 4; do echo "== nb $nb"; RFX_FFT_NB=$nb timeout 300 python scripts/perf_fft.py 2>&1 | grep -v amdgpu.ids; done > gpurun_out/fft/perf.txt 2>&1
-cat gpurun_out/fft/perf.txt
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-also --no-cpu-baseline > gpurun_out/fft/b1.json 2> gpurun_out/fft/b1.err
+python - <<'P'
+import json
+d=json.loads(open("gpurun_out/fft/b1.json").read().strip().splitlines()[-1])
+print(d["ms_per_step"], d["value"], d["config"].get("final_loss"))
+P

@@ -152,6 +152,34 @@ def test_mrstft_l1_sisdr_vs_oracle():
     assert abs(float(s2) - float(ref_losses.sisdr_loss(x[..., 5:20000], y[..., 5:20000]))) < 1e-3
 
 
+@pytest.mark.parametrize("geom", [(1024, 120, 600), (2048, 240, 1200), (512, 50, 240), (512, 128, 512)])
+def test_pair_loss_kernel(geom):
+    """rfx_stft_pair_loss (both spectra of a frame from one complex FFT, sums in the epilogue) against the two-analysis + reduction
+    path: row sums, the stored prediction spectrum and the clamped target magnitudes, edge (reflected) frames included."""
+    import ctypes as C
+    from remfx_amd import _lib, losses, stft
+    from remfx_amd.ops import _ptr, _stream
+    n_fft, hop, win = geom
+    g = torch.Generator().manual_seed(n_fft + hop)
+    R, L = 5, 30011
+    x = (torch.randn(R, L, generator=g) * 0.3).to(DEV)
+    y = (x + 0.1 * torch.randn(R, L, generator=g).to(DEV)).contiguous()
+    w = stft.hann(win, DEV)
+    X = stft.stft_raw(x, n_fft, hop, win, w, 5)
+    Y = stft.stft_raw(y, n_fft, hop, win, w, 5)
+    n = X.shape[1] * X.shape[2]
+    ref = torch.zeros(R, 3, device=DEV)
+    _lib.check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, 1e-8, _ptr(ref), _stream()), "reduce")
+    sums, Xp, ym = losses._pair_sums(x, y, n_fft, hop, win, w, 1e-8, True)
+    assert Xp.shape == X.shape and ym.shape == X.shape[:3]
+    scale = float(X.abs().max())
+    assert _rms(Xp.cpu(), X.cpu()) < 2e-6 * scale
+    assert _rms(ym.cpu(), torch.sqrt(torch.clamp(Y[..., 0] ** 2 + Y[..., 1] ** 2, min=1e-8)).cpu()) < 2e-6 * scale
+    assert torch.allclose(sums.cpu(), ref.cpu(), rtol=2e-5, atol=0)
+    s2, X2, _ = losses._pair_sums(x, y, n_fft, hop, win, w, 1e-8, False)
+    assert X2 is None and torch.allclose(s2.cpu(), ref.cpu(), rtol=2e-5, atol=0)
+
+
 def test_stft_memo_scope():
     """Inside stft_memo() repeated MRSTFT evaluations are bit-identical to the unshared ones, an in-place change of a
     signal is seen (version bump), and nothing survives the scope."""
@@ -170,7 +198,7 @@ def test_stft_memo_scope():
         # metric(output, target) == loss term on shared spectra (row sums use float atomics: equal to rounding)
         assert abs(float(mr(xm.detach(), y)) - float(l)) < 1e-6 * plain and abs(float(l) - plain) < 1e-6 * plain
         n_entries = len(losses._MEMO)
-        assert sum(1 for k in losses._MEMO if len(k) == 7) == 6        # spectra: 2 signals x 3 resolutions, not 12
+        assert sum(1 for k in losses._MEMO if k[0] == "pair") == 3     # one (prediction, target) entry per resolution, not 6
         l.backward()
         # (the adjoint STFT overlap-adds with atomics: equal up to summation order)
         assert _rms(xm.grad.cpu(), xg.grad.cpu()) < 1e-5 * float(xg.grad.abs().max())
