@@ -581,7 +581,7 @@ struct PairArgs {
 };
 
 template <int LOGN>
-__global__ __launch_bounds__(256, 3) void fft_pair_loss_kernel(const PairArgs a) {
+__global__ __launch_bounds__(256, 2) void fft_pair_loss_kernel(const PairArgs a) {
   typedef FftCfg<LOGN> K;
   constexpr int NC = K::NC, T = K::T, FB = K::FB, N = NC;
   constexpr int NIT = (K::NH * FB + 255) / 256;                 // epilogue items per thread

@@ -47,3 +47,11 @@ for n_fft, hop, win in ((1024, 120, 600), (2048, 240, 1200), (512, 50, 240)):
     fs = lambda: torch.autograd.grad(Y, xs, g, retain_graph=True)
     us = timeit(fs)
     print(f"loss   synthesis {n_fft}/{hop}/{win:<5d}       {us:8.1f} {gb:6.3f} {gb / us * 1e3:6.2f} {gb / us * 1e3 / 8:6.3f}   (incl. zero fill)")
+
+from remfx_amd import losses
+y = torch.randn(R, L, device=dev)
+for n_fft, hop, win in ((1024, 120, 600), (2048, 240, 1200), (512, 50, 240)):
+    w = stft.hann(win, dev)
+    for store in (False, True):
+        us = timeit(lambda: losses._pair_sums(x, y, n_fft, hop, win, w, 1e-8, store))
+        print(f"pair loss {n_fft}/{hop}/{win:<5d} store={store!s:5s}   {us:8.1f} us")

@@ -21,6 +21,8 @@ FAMILIES = [
     ("attention", ("localstate", "ls_mfma")),
     ("pack / unpack", ("pack", "unpack")),
     ("optimiser", ("adamw", "sumsq", "clip")),
+    ("fused DConv layer", ("dconv_",)),
+    ("zero fills (rfx_zero)", ("zero_kernel",)),
 ]
 
 
