@@ -40,6 +40,7 @@ struct FftArgs {
   const v2f* tables;    // [256] W_256^t | [256] W_NC^t | [NC/2 + 1] e^{-i pi k / NC}
   int groups_per_row;   // workgroups per row
   int nbatch;           // frame batches (FB frames each) a workgroup walks
+  uint32_t hop_magic;   // ceil(2^32 / hop): q / hop = umulhi(q, hop_magic) for the q < 2^20 of one batch's span (hop <= 4096; else 0)
 };
 
 template <int LOGN>
@@ -260,12 +261,12 @@ __global__ __launch_bounds__(256, 3) void fft_analysis_kernel(const FftArgs a) {
   const int FO = d.frames_out;
   // workgroup-uniform: every frame of a batch lies inside the signal (no reflection, no frame past the end) and its sample
   // pairs are 8-byte aligned -> plain loads straight into the registers of pass A, ISSUED BEFORE the previous batch's epilogue
-  // (the barriers do not wait for them).  Otherwise (the first / last batches of a row, odd hops, the iSTFT-backward multiplier)
-  // the samples are mapped one by one in a rolled loop and staged through LDS.
+  // (the barriers do not wait for them).  Otherwise (the first / last batches of a row, odd hops) the samples are mapped one by one
+  // in a rolled loop and staged through LDS.
   auto batch_fast = [&](int fb0) -> bool {
     const int64_t pb0 = (int64_t)fb0 * d.hop;
     return (fb0 + FB <= f_end) & (pb0 - shift >= 0) & (pb0 + (int64_t)(FB - 1) * d.hop + N - 1 - shift < (int64_t)d.T) &
-           !(d.hop & 1) & ((((int64_t)row * d.T + pb0 - shift) & 1) == 0) & ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) & (a.mul == nullptr);
+           !(d.hop & 1) & ((((int64_t)row * d.T + pb0 - shift) & 1) == 0) & ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0);
   };
   v2f z[16];
   auto load_fast = [&](int fb0) {
@@ -281,6 +282,14 @@ __global__ __launch_bounds__(256, 3) void fft_analysis_kernel(const FftArgs a) {
     const int f = fb0 + fl;
     const int64_t p0 = (int64_t)f * d.hop;
     if (fast) {
+      if (a.mul) {                                             // iSTFT backward: 1 / envelope per padded sample (wave-uniform branch)
+        const float* mp = a.mul + p0 + 2 * u;
+        v2f mv[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) mv[n] = v2f{mp[2 * T * n], mp[2 * T * n + 1]};
+#pragma unroll
+        for (int n = 0; n < 16; ++n) z[n] = z[n] * mv[n];
+      }
 #pragma unroll
       for (int n = 0; n < 16; ++n) z[n] = z[n] * wv[n];
     } else {
@@ -404,27 +413,50 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     // merge step on bin pairs (k, NC - k), k in [0, NC / 2]: S = X[k] + conj X[NC-k], W = (X[k] - conj X[NC-k]) e^{+i pi k/NC}
     //   Z[k] = S + i W,  Z[NC - k] = conj S + i conj W;  conj Z is written in natural order (the inverse = conj FFT conj)
     const bool fm = d.mode == RFX_STFT_COMPLEX_FM;           // frame-major spectrum: lanes along bins
-    for (int idx = tid; idx < K::NH * FB; idx += 256) {
-      const int fl2 = fm ? idx / K::NH : idx & (FB - 1), k = fm ? idx - fl2 * K::NH : idx / FB;
+    // all loads of the thread's NIT items first (clamped indices, validity applied to the values): a load -> use loop costs one
+    // memory round trip per item and batch
+    constexpr int NIT = (K::NH * FB + 255) / 256;
+    v2f xkv[NIT], xmv[NIT];
+    auto item = [&](int it, int& fl2, int& k) -> bool {
+      const int idx = tid + 256 * it;
+      const bool act = idx < K::NH * FB;
+      const int ii = act ? idx : 0;
+      fl2 = fm ? ii / K::NH : ii & (FB - 1);
+      k = fm ? ii - fl2 * K::NH : ii / FB;
+      return act;
+    };
+    auto fetch = [&](int kq, int fo) -> v2f {
+      const int kc = kq < d.bins ? kq : 0;
+      v2f v;
+      if (fm) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * FO + fo) * d.bins + kc];
+      else if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * d.bins + kc) * FO + fo];   // uniform
+      else {
+        v.x = a.x[((int64_t)row * 2 * d.bins + kc) * FO + fo];
+        v.y = a.x[((int64_t)row * 2 * d.bins + d.bins + kc) * FO + fo];
+      }
+      return v;
+    };
+    auto fix = [&](v2f v, int kq) -> v2f {
+      if (kq >= d.bins) v = v2f{0.f, 0.f};
+      if (kq == 0 || kq == NC) v.y = 0.f;             // real by construction / ignored by irfft
+      else if (!d.herm) v = v * 0.5f;                 // adjoint of the one-sided rfft
+      return v;
+    };
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int fl2, k;
+      item(it, fl2, k);
       const int f2 = fb0 + fl2;
-      const bool fv = f2 < f_end;
-      const int fo = fv ? f2 - d.frame0 : 0;
-      auto fetch = [&](int kq) -> v2f {
-        const bool in = kq < d.bins;
-        const int kc = in ? kq : 0;
-        v2f v;
-        if (fm) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * FO + fo) * d.bins + kc];
-        else if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * d.bins + kc) * FO + fo];   // uniform
-        else {
-          v.x = a.x[((int64_t)row * 2 * d.bins + kc) * FO + fo];
-          v.y = a.x[((int64_t)row * 2 * d.bins + d.bins + kc) * FO + fo];
-        }
-        if (!in) v = v2f{0.f, 0.f};
-        if (kq == 0 || kq == NC) v.y = 0.f;           // real by construction / ignored by irfft
-        else if (!d.herm) v = v * 0.5f;               // adjoint of the one-sided rfft
-        return v;
-      };
-      const v2f xk = fetch(k), xm = cconj(fetch(NC - k));
+      const int fo = f2 < f_end ? f2 - d.frame0 : 0;
+      xkv[it] = fetch(k, fo);
+      xmv[it] = fetch(NC - k, fo);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int fl2, k;
+      if (!item(it, fl2, k)) continue;
+      const bool fv = fb0 + fl2 < f_end;
+      const v2f xk = fix(xkv[it], k), xm = cconj(fix(xmv[it], NC - k));
       v2f Z0 = v2f{0.f, 0.f}, Z1 = v2f{0.f, 0.f};
       if (fv) {
         const v2f S = xk + xm, D = xk - xm;
@@ -452,9 +484,15 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     for (int q = tid; q < span; q += 256) {
       const int qw = q - woff;                       // window index of frame 0 at this position
       if (qw < 0) continue;
-      const int fl_hi = min(nf - 1, qw / d.hop);
       const int lo_num = qw - d.win + 1;
-      const int fl_lo = lo_num > 0 ? (lo_num + d.hop - 1) / d.hop : 0;
+      int fl_hi, fl_lo;
+      if (a.hop_magic) {                             // wave-uniform
+        fl_hi = min(nf - 1, (int)__umulhi((uint32_t)qw, a.hop_magic));
+        fl_lo = lo_num > 0 ? (int)__umulhi((uint32_t)(lo_num + d.hop - 1), a.hop_magic) : 0;
+      } else {
+        fl_hi = min(nf - 1, qw / d.hop);
+        fl_lo = lo_num > 0 ? (lo_num + d.hop - 1) / d.hop : 0;
+      }
       if (fl_lo > fl_hi) continue;
       float v = 0.f;
       for (int f2 = fl_lo; f2 <= fl_hi; ++f2) {
@@ -520,6 +558,7 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
   const int nc = d->n_fft / 2;
   a.tables = fft_tables(nc);
   if (!a.tables) return -3;
+  a.hop_magic = d->hop <= 4096 ? (uint32_t)((0x100000000ULL + (uint64_t)d->hop - 1) / (uint64_t)d->hop) : 0u;   // exact for q * hop < 2^32
   const int fb = 4096 / nc;
   const int batches = (d->frames_out + fb - 1) / fb;
   const int rows8 = (d->R + 7) / 8;
