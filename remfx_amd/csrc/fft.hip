@@ -168,7 +168,7 @@ __device__ __forceinline__ void fft_setup(const FftArgs& a, FftTables<LOGN>& tb,
 // The three passes on one batch: z = the thread's 16 points i = u + T n (n = 0..15) of frame fl.  Result: Z[k] in layout E3.
 // Callers put a barrier before the first LDS read of the NEXT use of `data`.
 template <int LOGN>
-__device__ __forceinline__ void fft_core(v2f (&z)[16], v2f* data, const FftState<LOGN>& st) {
+__device__ __forceinline__ void fft_core(v2f (&z)[16], v2f* data, const FftState<LOGN>& st, const v2f* wout = nullptr) {
   typedef FftCfg<LOGN> K;
   const int tid = threadIdx.x, u = tid & (K::T - 1), fl = tid / K::T;
   v2f* fr = data + fl * K::FS;
@@ -217,7 +217,7 @@ __device__ __forceinline__ void fft_core(v2f (&z)[16], v2f* data, const FftState
   {
     v2f* wC = fr + (u >> 4) * K::RS3 + (u & 15);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) wC[16 * m] = z[fft_slot<16>(m)];
+    for (int m = 0; m < 16; ++m) wC[16 * m] = wout ? z[fft_slot<16>(m)] * wout[m] : z[fft_slot<16>(m)];   // wout: a register array or null (inlined)
   }
 }
 template <int LOGN> __device__ __forceinline__ int fft_phys3(int k) {
@@ -403,9 +403,26 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
   FftState<LOGN> st;
   fft_setup<LOGN>(a, tb, st);
   lds_barrier();                       // the merge step below reads the table other threads loaded
+  // The synthesis window is applied where the inverse transform leaves the registers (pass C): output m of a thread is time index
+  // i = mA + RA (mB + 16 m) = samples (2 i, 2 i + 1); its 16 window pairs are frame-independent.  The overlap-add then only sums LDS
+  // values: with the window fetched per (position, covering frame) its inner loop was a chain of global-load latencies.
+  const int woff = (N - d.win) / 2;
+  v2f wout[16];
+  {
+    float wl[16][2];
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        wl[m][c] = a.window[min(max(2 * ((u >> 4) + K::RA * ((u & 15) + 16 * m)) + c - woff, 0), d.win - 1)];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int w0 = 2 * ((u >> 4) + K::RA * ((u & 15) + 16 * m)) - woff;
+      wout[m] = v2f{((w0 >= 0) & (w0 < d.win)) ? wl[m][0] : 0.f, ((w0 + 1 >= 0) & (w0 + 1 < d.win)) ? wl[m][1] : 0.f};
+    }
+  }
   const int f_end = d.frame0 + d.frames_out;
   const int FO = d.frames_out;
-  const int woff = (N - d.win) / 2;
   float* outr = a.out + (int64_t)row * d.T;
   for (int g = 0; g < a.nbatch; ++g) {
     const int fb0 = f_first + g * FB;
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
 #pragma unroll
     for (int n = 0; n < 16; ++n) z[n] = data[fl * K::FS + u + T * n];
     lds_barrier();
-    fft_core<LOGN>(z, data, st);
+    fft_core<LOGN>(z, data, st, wout);
     lds_barrier();
     // Overlap-add by GATHER inside the workgroup: the batch's frames are consecutive, so every padded position p of their span
     // sums the <= ceil(win / hop) frames that cover it out of LDS and issues ONE global atomic (the scatter form issued
@@ -498,7 +515,7 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
       for (int f2 = fl_lo; f2 <= fl_hi; ++f2) {
         const int t = q - f2 * d.hop;
         const v2f zz = data[f2 * K::FS + fft_phys3<LOGN>(t >> 1)];
-        v += ((t & 1) ? -zz.y : zz.x) * a.window[t - woff];
+        v += (t & 1) ? -zz.y : zz.x;               // already windowed (pass C)
       }
       const int64_t p = p0 + q;
       const int sidx = map_sample(d, (int)p);
