@@ -131,22 +131,24 @@ __device__ __forceinline__ void tap_a_store(uint4* as, int tid, const AStage& s)
   if (NV > 256) as[tid + 256 < NV ? tid + 256 : NV - 1] = s.v1;
 }
 
-// One 16-deep K step.  LDS holds the A tiles of TWO K steps per buffer, so the workgroup barrier comes only after every
-// odd step (SUB == 1).  Per step ks:
-//   LDS -> fragments of A(ks) from buffer (ks/2)&1, half SUB;
-//   global -> registers: A tile of step ks+4 (into the register set that held A(ks+2)), gathers of step ks+3;
-//   MFMAs;  registers -> LDS: A(ks+2) into the OTHER buffer;  barrier if SUB.
-// Everything written in steps {2D, 2D+1} is first read in step 2D+2, i.e. behind the barrier that ends step 2D+1.
+// One 16-deep K step.  LDS holds the A tiles of FOUR K steps (a 64-deep K block) per buffer, so the workgroup barrier comes only
+// after every fourth step (SUB == 3; rounds 2-3 had two steps per buffer: the K loop is latency-bound and every barrier pulls
+// the four waves back into lockstep).  Per step ks:
+//   LDS -> fragments of A(ks) from buffer (ks/4)&1, quarter SUB;
+//   global -> registers: A tile of step ks+6 (into the register set that held A(ks+4)), gathers of step ks+3;
+//   MFMAs;  registers -> LDS: A(ks+4) into the OTHER buffer, same quarter;  barrier if SUB == 3.
+// Everything written in steps 4D .. 4D+3 is first read in step 4D+4, i.e. behind the barrier that ends step 4D+3, and overwrites
+// what was last read in steps 4D-4 .. 4D-1, i.e. before the barrier that ended step 4D-1.
 template <int R, int MODE, int SUB, int IN16 = 0>
 __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* __restrict__ apk, int64_t arr_stride,
-                                           const int4* taps, uint32_t cs4, uint32_t gstep, uint32_t gwrap, int ks, int m0, TapLane& c,
+                                           const int4* taps, uint32_t cs4, uint32_t gstep, uint32_t gwrap, int ks, int kmax, int m0, TapLane& c,
                                            uint4* as, f32x16 (&acc)[R], const float (&bc)[8], float (&bn)[8],
                                            AStage& a_set) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
   const int tid = threadIdx.x;
   const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int buf = (ks >> 1) & 1;
-  const uint4* a_lds = as + buf * 2 * CELLS + SUB * CELLS;
+  const int buf = (ks >> 2) & 1;
+  const uint4* a_lds = as + buf * 4 * CELLS + SUB * CELLS;
   uint4 ah[R], al[R];
 #pragma unroll
   for (int mt = 0; mt < R; ++mt) {
@@ -155,8 +157,8 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
   }
   // issue order matters: vmcnt retires in order; the A tile is written to LDS two steps later, the gathers, consumed
   // RFX_BDIST steps later, go last and stay in flight
-  const AStage a_now = a_set;                                         // A(ks+2), fetched two steps ago
-  a_set = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2 * (ks + 4), m0, tid);
+  const AStage a_now = a_set;                                         // A(ks+4), fetched two steps ago
+  a_set = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2 * min(ks + 6, kmax), m0, tid);   // kmax: last K step of the padded pack
   gather8_tap<IN16>(d, taps, cs4, gstep, gwrap, c, bn);
   if (MODE == 1) {
     bf16x8 bh, bl;
@@ -176,8 +178,8 @@ __device__ __forceinline__ void k_step_tap(const rfx_gemm_desc& d, const uint4* 
     for (int mt = 0; mt < R; ++mt)
       acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), bh, acc[mt], 0, 0, 0);
   }
-  tap_a_store<R, MODE>(as + (buf ^ 1) * 2 * CELLS + SUB * CELLS, tid, a_now);
-  if (SUB) __syncthreads();
+  tap_a_store<R, MODE>(as + (buf ^ 1) * 4 * CELLS + SUB * CELLS, tid, a_now);
+  if (SUB == 3) __syncthreads();
   else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // keep the two steps apart in the compiler too
 }
 
@@ -195,12 +197,17 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
   const uint32_t cs4 = (uint32_t)(d.in_cs * (IN16 ? 2 : 4));
   const uint32_t gstep = 16u * cs4, gwrap = (uint32_t)gpt * 8u * cs4;
   __syncthreads();            // a previous phase (two-phase launches) may still be reading the LDS buffers / tap table
+  const int kmax = nk + 3;    // the pack carries 8 k8 rows (4 K steps) of padding behind Kpad
   {
     const AStage s0 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 0, m0, tid);
     const AStage s1 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2, m0, tid);
+    const AStage s2 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 4, m0, tid);
+    const AStage s3 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 6, m0, tid);
     if (tid < ntaps + 16) taps[tid] = reinterpret_cast<const int4*>(tap_tab)[tid];   // table carries 16 invalid tail rows
-    tap_a_store<R, MODE>(as, tid, s0);                       // A(0), A(1) -> buffer 0
+    tap_a_store<R, MODE>(as, tid, s0);                       // A(0) .. A(3) -> buffer 0
     tap_a_store<R, MODE>(as + CELLS, tid, s1);
+    tap_a_store<R, MODE>(as + 2 * CELLS, tid, s2);
+    tap_a_store<R, MODE>(as + 3 * CELLS, tid, s3);
   }
   __syncthreads();
   c.t = h / gpt;              // group g = h of K step 0
@@ -208,21 +215,21 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
   // the gathers run RFX_BDIST K steps ahead of the MFMAs: one K step is ~0.1-0.2 us of matrix work, a gather that misses
   // L2 takes ~1-2 us, and only two waves share a SIMD
   float b0[8], b1[8], b2[8], b3[8];
-  AStage a0 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 4, m0, tid);          // A(2), A(3): even / odd register set
-  AStage a1 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 6, m0, tid);
+  AStage a0 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2 * min(4, kmax), m0, tid);          // A(4), A(5): even / odd register set
+  AStage a1 = tap_a_load<R, MODE>(apk, arr_stride, d.Mpad, 2 * min(5, kmax), m0, tid);
   gather8_tap<IN16>(d, taps, cs4, gstep, gwrap, c, b0);
   gather8_tap<IN16>(d, taps, cs4, gstep, gwrap, c, b1);
   gather8_tap<IN16>(d, taps, cs4, gstep, gwrap, c, b2);
   int ks = 0;
   for (; ks + 3 < nk; ks += 4) {
-    k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, m0, c, as, acc, b0, b3, a0);
-    k_step_tap<R, MODE, 1, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, m0, c, as, acc, b1, b0, a1);
-    k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
-    k_step_tap<R, MODE, 1, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 3, m0, c, as, acc, b3, b2, a1);
+    k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, kmax, m0, c, as, acc, b0, b3, a0);
+    k_step_tap<R, MODE, 1, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, kmax, m0, c, as, acc, b1, b0, a1);
+    k_step_tap<R, MODE, 2, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, kmax, m0, c, as, acc, b2, b1, a0);
+    k_step_tap<R, MODE, 3, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 3, kmax, m0, c, as, acc, b3, b2, a1);
   }
-  if (ks < nk) k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, m0, c, as, acc, b0, b3, a0);
-  if (ks + 1 < nk) k_step_tap<R, MODE, 1, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, m0, c, as, acc, b1, b0, a1);
-  if (ks + 2 < nk) k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, m0, c, as, acc, b2, b1, a0);
+  if (ks < nk) k_step_tap<R, MODE, 0, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks, kmax, m0, c, as, acc, b0, b3, a0);
+  if (ks + 1 < nk) k_step_tap<R, MODE, 1, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 1, kmax, m0, c, as, acc, b1, b0, a1);
+  if (ks + 2 < nk) k_step_tap<R, MODE, 2, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, kmax, m0, c, as, acc, b2, b1, a0);
 }
 
 // Occupancy of the bf16 mode: four waves per SIMD for R <= 2 (128 VGPRs), three for R = 3, 4 (168 VGPRs).  The K loop fits those
@@ -233,9 +240,9 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
 template <int R, int MODE, int IN16 = 0>
 __global__ __launch_bounds__(256, MODE == 2 ? (R <= 2 ? 4 : 3) : 2) void gemm_tap_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
-  __shared__ __attribute__((aligned(16))) uint4 smem[4 * CELLS + RFX_TAP_LDS];   // A: 2 buffers x 2 K steps; tap table
+  __shared__ __attribute__((aligned(16))) uint4 smem[8 * CELLS + RFX_TAP_LDS];   // A: 2 buffers x 4 K steps; tap table
   uint4* as = smem;
-  int4* taps = reinterpret_cast<int4*>(smem + 4 * CELLS);
+  int4* taps = reinterpret_cast<int4*>(smem + 8 * CELLS);
   const rfx_gemm_desc& d = g.d;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
