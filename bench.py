@@ -412,6 +412,7 @@ def main():
     ap.add_argument("--sink", default="side", choices=["side", "main", "off"],
                     help="parameter-gradient sink (ops.GradSink) A/B: side stream (default) / compute stream / autograd accumulation")
     ap.add_argument("--no-fused-dconv", action="store_true", help="A/B: layer-by-layer DConv instead of the fused kernels (csrc/dconv.hip)")
+    ap.add_argument("--no-enc-z16-time", action="store_true", help="A/B: time-branch encoder conv outputs stored as fp32 (hdemucs.ENC_Z16_TIME)")
     ap.add_argument("--no-enc-z16", action="store_true", help="A/B: encoder conv outputs stored as fp32 (hdemucs.ENC_Z16)")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (bf16x3 step + Demucs forward sub-metric)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch plan / algorithmic work / event time list of the timed steps (JSON)")
@@ -440,6 +441,9 @@ def main():
     if args.no_fused_dconv:
         from remfx_amd import nnops
         nnops.DCONV_FUSED = False
+    if args.no_enc_z16_time:
+        from remfx_amd import hdemucs
+        hdemucs.ENC_Z16_TIME = False
     if args.no_enc_z16:
         from remfx_amd import hdemucs
         hdemucs.ENC_Z16 = False

@@ -23,7 +23,9 @@ struct WgradArgs {
 // bottleneck convs with 12 / 24 output channels) -> 1 x 4 over 32 x (128 TK), so the MFMA rows beyond M and the
 // re-loads of g by every k tile are halved.
 // MODE 1: split bf16x3 (hi + lo tiles, 3 MFMAs per product); MODE 2: operands rounded to bf16 (hi tile only, 1 MFMA).
-template <int TM, int TK, int WM, int MODE>
+// G16: the gradient operand g is stored as bf16 (bf16 mode; strided plans, i.e. the time branch's encoder convs): two-byte loads,
+// the stored bits go to LDS as they are.
+template <int TM, int TK, int WM, int MODE, bool G16 = false>
 __global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
   constexpr int WK = 4 / WM;
   constexpr int RM = 32 * WM * TM, RK = 32 * WK * TK, LDW = 40;   // bf16 elements per LDS row
@@ -81,16 +83,21 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
     const int a = jj / d.OB, b = jj - a * d.OB;
     const int ia0 = a * d.SA, ib0 = b * d.SB;
     const __amdgpu_buffer_rsrc_t irs = rfx_sample_rsrc(w.in + (int64_t)n * d.in_ns);
-    const __amdgpu_buffer_rsrc_t grs = rfx_sample_rsrc(w.g + (int64_t)n * d.out_ns);
+    constexpr int GSZ = G16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t grs = rfx_sample_rsrc(reinterpret_cast<const float*>(
+        reinterpret_cast<const char*>(w.g) + (int64_t)n * d.out_ns * GSZ));
     const uint32_t voff = (uint32_t)(((int64_t)ia0 * d.in_as + (int64_t)ib0 * d.in_bs) * 4);
     const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as +
-                                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs + (int64_t)(m0 + prow) * d.out_cs) * 4);
-    const uint32_t gstep = (uint32_t)(8 * d.out_cs * 4);
+                                      (int64_t)(b * d.out_sb + d.out_b0) * d.out_bs + (int64_t)(m0 + prow) * d.out_cs) * GSZ);
+    const uint32_t gstep = (uint32_t)(8 * d.out_cs * GSZ);
     st.jv = jvalid ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < RM / 8; ++i) {
       const bool ok = jvalid & (m0 + prow + 8 * i < d.M);
-      st.gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
+      if (G16)       // the 16 stored bits, zero-extended (staged without conversion)
+        st.gv[i] = __uint_as_float((uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
+      else
+        st.gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, ok ? goff + i * gstep : RFX_BUF_OOB, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < RK / 8; ++i) {
@@ -111,7 +118,10 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
   };
   auto stage = [&](const Stage& st) {
 #pragma unroll
-    for (int i = 0; i < RM / 8; ++i) put(gs_hi, gs_lo, prow + 8 * i, st.gv[i]);
+    for (int i = 0; i < RM / 8; ++i) {
+      if (G16) gs_hi[(prow + 8 * i) * LDW + pl] = (unsigned short)__float_as_uint(st.gv[i]);
+      else put(gs_hi, gs_lo, prow + 8 * i, st.gv[i]);
+    }
 #pragma unroll
     for (int i = 0; i < RK / 8; ++i) put(xs_hi, xs_lo, prow + 8 * i, st.xv[i] + onesf[i] * st.jv);
   };
@@ -191,8 +201,11 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
 // negative offset would fail the whole dwordx4 range check, scripts/probes/bufprobe.hip); elements right of the row
 // end / beyond OB are zeroed after the load; rows whose a-coordinate is out of range load nothing (offset 2^31).
 // ---------------------------------------------------------------------------------
+#ifndef RFX_WGRAD_DEEP
+#define RFX_WGRAD_DEEP 0      // dev probe: two register stages for the 128 x 128 tile of the bf16 mode (see DEEP below)
+#endif
 template <int TM, int TK, int WM, int MODE, bool G16 = false>     // G16: the gradient operand g is stored as bf16 (bf16 mode only)
-__global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4) ? 3 : 2) void gemm_wgrad_wide_kernel(const WgradArgs w) {
+__global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4 && !(RFX_WGRAD_DEEP && TM * TK == 4)) ? 3 : 2) void gemm_wgrad_wide_kernel(const WgradArgs w) {
   constexpr int WK = 4 / WM;
   constexpr int RM = 32 * WM * TM, RK = 32 * WK * TK, LDW = 72, PC = 64;
   constexpr int LO = MODE == 1 ? 1 : 0;
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4) ? 3 : 2) void gemm
   // MEASURED (r02b, Demucs step): weight-gradient launches 36.3 -> 39.5 ms with the two-stage loop, the 3x3 layers unchanged
   // (2.56 -> 2.59 ms): they are bound by LDS / L1 bandwidth (48-64 KB into the CU per 512 clk of MFMA work), not by load latency,
   // and the extra registers cost the small tiles occupancy.  Kept for the record, switched off.
-  constexpr bool DEEP = false && 2 * STAGE_REGS + 16 * TM * TK <= 200;
+  constexpr bool DEEP = RFX_WGRAD_DEEP && MODE == 2 && TM * TK == 4 && 2 * STAGE_REGS + 16 * TM * TK <= 200;
   const int t_last = t_end - 1;
   if (DEEP) {
     Stage s0, s1;
@@ -443,6 +456,20 @@ __global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4) ? 3 : 2) void gemm
 // shape: 0 = 96-row tiles (waves 1 x 4), 1 / 2 = 32-row tiles with 256 / 128 k rows, 3..6 = (64 TM) x (64 TK) tiles
 template <int MODE>
 static int rfx_launch_wgrad_bf(const WgradArgs& w, int shape, dim3 grid, hipStream_t s) {
+  if (w.d.out_bf16) {
+    if (MODE != 2) return -1;
+    switch (shape) {
+      case 0: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<3, 1, 1, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 1: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 2, 1, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 2: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 1, 1, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 3: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 4: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<2, 1, 2, 2, true>), grid, dim3(256), 0, s, w); break;
+      case 5: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 2, 2, 2, true>), grid, dim3(256), 0, s, w); break;
+      default: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 1, 2, 2, true>), grid, dim3(256), 0, s, w); break;
+    }
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   switch (shape) {
     case 0: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<3, 1, 1, MODE>), grid, dim3(256), 0, s, w); break;
     case 1: hipLaunchKernelGGL((gemm_wgrad_bf_kernel<1, 2, 1, MODE>), grid, dim3(256), 0, s, w); break;

@@ -244,7 +244,9 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     dim3 grid = w.xcd_grouped ? dim3(((splits + 7) / 8) * 8 * kt * mt, 1, 1) : dim3(kt, mt, splits);
     return prec == 1 ? rfx_launch_wgrad_wide_bf3(w, shape, grid, s) : rfx_launch_wgrad_wide_bf16(w, shape, grid, s);
   }
-  if (d->out_bf16) return -1;                             // callers convert to fp32 for plans the wide kernel does not take
+  // strided plans (the time branch's encoder convs): the 32-position kernel takes a bf16 gradient operand with two-byte loads.
+  // num_records of its sample descriptors is 2^31 - 1 bytes: the operand's span past a sample base must stay below that
+  if (d->out_bf16 && (prec != 2 || g_span > 0x7fffffffLL)) return -1;
   const bool narrow = prec != 0 && d->M <= 32;            // 32 x (128 tk) tiles, waves 1 x 4 (see gemm_wgrad_bf3_kernel)
   // 96-row tiles (waves 1 x 4, three 32-row MFMA tiles each) when they pad M less than 128-row ones: M = 96, 192, 288
   const bool rows96 = prec != 0 && d->M > 64 && d->K > 64 && ((d->M + 95) / 96) * 96 < ((d->M + 127) / 128) * 128;

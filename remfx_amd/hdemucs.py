@@ -151,6 +151,7 @@ def _norm_act(m, x, act):
 
 
 ENC_Z16 = True      # bf16 mode: encoder conv outputs of the norm-free layers stored in 16 bits (bench.py --no-enc-z16 is the A/B)
+ENC_Z16_TIME = True # ... of the time branch too (bench.py --no-enc-z16-time)
 
 
 class _HEncLayer(nn.Module):
@@ -185,8 +186,7 @@ class _HEncLayer(nn.Module):
         if self.freq:
             # bf16 mode, layers without a norm: the conv output is read only by the GELU pass (and its backward), its gradient only
             # by the input- / weight-gradient GEMMs, which round to bf16 anyway -- both are STORED in 16 bits (what torch autocast
-            # stores for a conv output).  Frequency branch only: the time branch's stride runs along the contiguous axis, and the
-            # weight-gradient kernel for those plans reads an fp32 gradient.
+            # stores for a conv output).
             z16 = ENC_Z16 and (not self.empty) and inject is None and not isinstance(self.norm1, nn.GroupNorm)
             if fork:
                 y, alias = ops.conv2d_fork(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0), out_bf16=z16)
@@ -196,10 +196,12 @@ class _HEncLayer(nn.Module):
             if x.shape[-1] % self.stride:
                 x = F.pad(x, (0, self.stride - x.shape[-1] % self.stride))
                 fork = False
+            # time branch, same rule: the strided plans' weight-gradient kernel (gemm_wgrad_bf_kernel<.., G16>) reads the 16-bit gradient
+            z16 = ENC_Z16 and ENC_Z16_TIME and (not self.empty) and not isinstance(self.norm1, nn.GroupNorm)
             if fork:
-                y, alias = ops.conv1d_fork(x, self.conv.weight, self.conv.bias, self.stride, self.pad)
+                y, alias = ops.conv1d_fork(x, self.conv.weight, self.conv.bias, self.stride, self.pad, out_bf16=z16)
             else:
-                y = ops.conv1d(x, self.conv.weight, self.conv.bias, self.stride, self.pad)
+                y = ops.conv1d(x, self.conv.weight, self.conv.bias, self.stride, self.pad, out_bf16=z16)
         out = self._rest(y, inject)
         return (out, alias) if want_pair else out
 

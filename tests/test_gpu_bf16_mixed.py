@@ -188,6 +188,23 @@ def test_bf16_storage_is_exactly_rounding():
             outs.append((xx.grad, ww.grad, bb.grad))
         for a16, a32 in zip(outs[2], outs[3]):
             assert torch.equal(a16, a32)
+        # strided plans (the time branch's encoder convs: kernel 8, stride 4 along the contiguous axis): 16-bit output and a 16-bit
+        # gradient through the 32-position weight-gradient kernel (gemm_wgrad_bf_kernel<.., G16>) and the merged-phase input gradient
+        for (Ci, Co, Tt) in ((24, 96, 400), (1, 48, 1008), (48, 20, 272)):
+            xs = torch.randn(3, Ci, Tt, generator=g).to(DEV)
+            ws = (torch.randn(Co, Ci, 8, generator=g) * 0.1).to(DEV)
+            bs = torch.randn(Co, generator=g).to(DEV)
+            pair = []
+            for store in (True, False):
+                xx, ww, bb = (t.detach().requires_grad_(True) for t in (xs, ws, bs))
+                yy = ops.conv1d(xx, ww, bb, 4, 2, out_bf16=store)
+                assert yy.dtype == (torch.bfloat16 if store else torch.float32), (Ci, Co, yy.dtype)
+                gs = torch.randn(yy.shape, generator=torch.Generator().manual_seed(11)).to(DEV).bfloat16()
+                yy.backward(gs if store else gs.float())
+                pair.append((yy.detach().float(), xx.grad, ww.grad, bb.grad))
+            assert torch.equal(pair[0][0], pair[1][0].bfloat16().float()), (Ci, Co)
+            for a16, a32 in zip(pair[0][1:], pair[1][1:]):
+                assert torch.equal(a16, a32), (Ci, Co)
         # GLU in the GEMM store with the conv output kept in 16 bits (ConvGlu2dFn) vs RFX_BF16_STORE off
         x2 = torch.randn(3, 16, 6, 40, generator=g).to(DEV)
         w2 = (torch.randn(32, 16, 3, 3, generator=g) * 0.1).to(DEV)
