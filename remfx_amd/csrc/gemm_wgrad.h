@@ -201,11 +201,8 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
 // negative offset would fail the whole dwordx4 range check, scripts/probes/bufprobe.hip); elements right of the row
 // end / beyond OB are zeroed after the load; rows whose a-coordinate is out of range load nothing (offset 2^31).
 // ---------------------------------------------------------------------------------
-#ifndef RFX_WGRAD_DEEP
-#define RFX_WGRAD_DEEP 0      // dev probe: two register stages for the 128 x 128 tile of the bf16 mode (see DEEP below)
-#endif
 template <int TM, int TK, int WM, int MODE, bool G16 = false>     // G16: the gradient operand g is stored as bf16 (bf16 mode only)
-__global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4 && !(RFX_WGRAD_DEEP && TM * TK == 4)) ? 3 : 2) void gemm_wgrad_wide_kernel(const WgradArgs w) {
+__global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4) ? 3 : 2) void gemm_wgrad_wide_kernel(const WgradArgs w) {
   constexpr int WK = 4 / WM;
   constexpr int RM = 32 * WM * TM, RK = 32 * WK * TK, LDW = 72, PC = 64;
   constexpr int LO = MODE == 1 ? 1 : 0;
@@ -409,8 +406,11 @@ __global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4 && !(RFX_WGRAD_DEEP
   constexpr int STAGE_REGS = 4 * NX + (G16 ? 2 : 4) * NG;
   // MEASURED (r02b, Demucs step): weight-gradient launches 36.3 -> 39.5 ms with the two-stage loop, the 3x3 layers unchanged
   // (2.56 -> 2.59 ms): they are bound by LDS / L1 bandwidth (48-64 KB into the CU per 512 clk of MFMA work), not by load latency,
-  // and the extra registers cost the small tiles occupancy.  Kept for the record, switched off.
-  constexpr bool DEEP = RFX_WGRAD_DEEP && MODE == 2 && TM * TK == 4 && 2 * STAGE_REGS + 16 * TM * TK <= 200;
+  // and the extra registers cost the small tiles occupancy.  Re-measured in r03 on the lean-load kernel (bf16 mode, two workgroups per
+  // CU instead of three to make room): 128 x 128 tiles with two stages 1.59 -> 1.85 ms (192 -> 384, 3x3) and 1.94 -> 2.43 ms
+  // (384 -> 768), step 145.4 -> 147.4 ms; the 96-row layers on 96 x 128 tiles with two stages instead of 96 x 256 with one 2.22 ->
+  // 2.66 ms, step +0.9 ms: the third resident workgroup hides more latency than the second register stage.  Kept for the record, off.
+  constexpr bool DEEP = false && 2 * STAGE_REGS + 16 * TM * TK <= 200;
   const int t_last = t_end - 1;
   if (DEEP) {
     Stage s0, s1;
