@@ -232,13 +232,15 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
   if (ks + 2 < nk) k_step_tap<R, MODE, 2, IN16>(d, apk, arr_stride, taps, cs4, gstep, gwrap, ks + 2, kmax, m0, c, as, acc, b2, b1, a0);
 }
 
-// Occupancy of the bf16 mode: four waves per SIMD for R <= 2 (128 VGPRs), three for R = 3, 4 (168 VGPRs).  The K loop fits those
-// budgets without scratch (checked in the ISA: accumulators 16 R + gather ring 32 + A fragments 4 R + staging); what spills is the
-// general epilogue, once per tile -- and the full tiles take the lean store anyway.  More resident waves hide more gather latency:
-// same-box A/B of the Demucs step (r03): R = 3 at three waves -1.5 ms, R = 4 at three waves -1.2 ms, R <= 2 at four waves -0.7 ms.
-// (The split-bf16x3 mode holds hi + lo fragments and stays at two waves.)
+// Occupancy of the bf16 mode: four waves per SIMD for R <= 3 (128 VGPRs), three for R = 4 (168 VGPRs).  For R <= 2 and R = 4 the K
+// loop fits those budgets without scratch (checked in the ISA: accumulators 16 R + gather ring 32 + A fragments 4 R + staging); what
+// spills is the general epilogue, once per tile -- and the full tiles take the lean store anyway.  More resident waves hide more
+// gather latency: same-box A/B of the Demucs step (r03): R = 3 at three waves -1.5 ms, R = 4 at three waves -1.2 ms, R <= 2 at four
+// waves -0.7 ms, R = 3 at four waves another -1.0 ms (540 B of scratch per lane, still a net gain).  One step further the spills land
+// in the K loop and the step collapses: R = 4 at four waves 147 -> 379 ms, R = 3 at five 336 ms, R <= 2 at five 156 ms (second builds
+// of the library, same box).  (The split-bf16x3 mode holds hi + lo fragments and stays at two waves.)
 template <int R, int MODE, int IN16 = 0>
-__global__ __launch_bounds__(256, MODE == 2 ? (R <= 2 ? 4 : 3) : 2) void gemm_tap_kernel(const FwdArgs g) {
+__global__ __launch_bounds__(256, MODE == 2 ? (R <= 3 ? 4 : 3) : 2) void gemm_tap_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
   __shared__ __attribute__((aligned(16))) uint4 smem[8 * CELLS + RFX_TAP_LDS];   // A: 2 buffers x 4 K steps; tap table
   uint4* as = smem;
