@@ -21,7 +21,8 @@ import numpy as np
 INVALID_DA = -(1 << 30)
 
 
-R_MAX = 4            # channel tiles per wave (capping it at 3 / 2 / 1 measured 168.8 / 175.4 / 198.8 vs 166.3 ms on the Demucs step)
+R_MAX = 4            # channel tiles per wave (capping it at 3 / 2 / 1 measured 168.8 / 175.4 / 198.8 vs 166.3 ms on the Demucs step;
+                     # r03, with R = 3 at four waves per SIMD: 96-row tiles for every M % 96 == 0 still lose, 146.9 vs 144.3 ms)
 
 
 def pick_r(M, K=1 << 30):
