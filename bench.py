@@ -407,8 +407,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat", type=int, default=3,
-                    help="extra UNTIMED steps before the W warm-up steps: the first process on a fresh box runs its first ~1-2 s of "
-                         "steps up to 10 %% slower (measured: 175 / 167 ms with W = 3 / 4 against 158 ms steady state)")
+                    help="minimum number of extra UNTIMED steps before the W warm-up steps (0 = no preheat at all): a freshly leased box "
+                         "runs its first seconds of load ~5 %% slower (see --preheat-seconds and the loop in main)")
+    ap.add_argument("--preheat-seconds", type=float, default=10.0, help="minimum wall time of the untimed preheat (see the loop in main)")
+    ap.add_argument("--preheat-max", type=int, default=400, help="upper bound of the untimed preheat in steps")
     ap.add_argument("--sink", default="side", choices=["side", "main", "off"],
                     help="parameter-gradient sink (ops.GradSink) A/B: side stream (default) / compute stream / autograd accumulation")
     ap.add_argument("--no-fused-dconv", action="store_true", help="A/B: layer-by-layer DConv instead of the fused kernels (csrc/dconv.hip)")
@@ -484,8 +486,28 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.preheat):
-        step(i)
+    # Untimed preheat.  A freshly leased box runs its first ~5-9 s of sustained load ~5 % slower, as a PLATEAU (three bench processes
+    # back to back on one fresh box: 151.7 / 144.1 / 143.7 ms; with 60 untimed steps in front, the first process reads 144.8 ms) --
+    # too long for W = 5 warm-up steps and invisible to a "step time has stopped falling" test.  So: at least `--preheat` steps AND
+    # `--preheat-seconds` of wall time, then until the last three synchronised steps are within 1.5 % of the fastest one seen (bounded
+    # by `--preheat-max` steps).  `--preheat 0` disables all of it.  The count is reported as `preheat_steps`; none of it is timed.
+    pre_t, n_pre, pre_t0 = [], 0, time.time()
+    n_max = args.preheat_max if args.preheat > 0 else 0
+    while True:
+        if n_pre >= args.preheat:
+            stable = len(pre_t) >= 4 and max(pre_t[-3:]) <= 1.015 * min(pre_t[1:])
+            more = torch.tensor([float(n_pre < n_max and (time.time() - pre_t0 < args.preheat_seconds or not stable))], device=device)
+            if world > 1:                            # every rank takes the same decision
+                torch.distributed.all_reduce(more, op=torch.distributed.ReduceOp.MAX)
+            if float(more) == 0.0:
+                break
+        torch.cuda.synchronize()
+        t0 = time.time()
+        step(n_pre)
+        torch.cuda.synchronize()
+        pre_t.append(time.time() - t0)
+        n_pre += 1
+    args.preheat = n_pre
     for i in range(args.warmup):
         step(i)
     fence()
