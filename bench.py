@@ -411,6 +411,7 @@ def main():
                          "runs its first seconds of load ~5 %% slower (see --preheat-seconds and the loop in main)")
     ap.add_argument("--preheat-seconds", type=float, default=10.0, help="minimum wall time of the untimed preheat (see the loop in main)")
     ap.add_argument("--preheat-max", type=int, default=400, help="upper bound of the untimed preheat in steps")
+    ap.add_argument("--no-priority-stream", action="store_true", help="A/B: run the step on the default stream (ops.enter_compute_stream off)")
     ap.add_argument("--sink", default="side", choices=["side", "main", "off"],
                     help="parameter-gradient sink (ops.GradSink) A/B: side stream (default) / compute stream / autograd accumulation")
     ap.add_argument("--no-fused-dconv", action="store_true", help="A/B: layer-by-layer DConv instead of the fused kernels (csrc/dconv.hip)")
@@ -469,6 +470,8 @@ def main():
     if args.union_ranks > 1:
         parts = [synthetic_batch(batch, r, device) for r in range(args.union_ranks)]
         data = tuple(torch.cat([p[i] for p in parts], 0) for i in range(4))
+    if not args.no_priority_stream:
+        ops.enter_compute_stream(device)             # compute stream high priority, weight-gradient side stream normal (as Trainer.fit)
     timer = KernelTimer(ops.PREC_NAMES[args.gemm])
     timer.install()
 

@@ -138,6 +138,8 @@ class Trainer:
         self._apply_precision()
         model.trainer = self
         model.to(self.device)
+        from . import ops
+        ops.enter_compute_stream(self.device)                    # high-priority compute stream; weight gradients ride a normal one
         cfg = model.configure_optimizers()
         opt = cfg["optimizer"] if isinstance(cfg, dict) else cfg
         sched = cfg["lr_scheduler"]["scheduler"] if isinstance(cfg, dict) and "lr_scheduler" in cfg else None
