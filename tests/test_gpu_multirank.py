@@ -43,3 +43,20 @@ def test_two_ranks_match_union_batch():
     a, b = two["config"]["param_abs_sum"], one["config"]["param_abs_sum"]
     assert a > 0 and abs(a - b) < 2e-6 * b, (a, b)          # AdamW steps of 1e-4 on ~8e7 parameters: a wrong average moves it by > 1e-5
     assert torch.isfinite(torch.tensor(two["config"]["final_loss"]))
+
+
+def test_two_ranks_timed_preheat():
+    """bench.py's untimed preheat takes its stop / continue decision collectively (an all-reduce per preheat step): two ranks with the
+    wall-time rule switched on must agree on the step count and finish (a rank that left the loop alone would hang the next collective)."""
+    args = ["--steps", "2", "--warmup", "1", "--preheat", "2", "--preheat-seconds", "1.0", "--preheat-max", "12", "--batch", "2",
+            "--workload", "demucs", "--no-cpu-baseline", "--no-also", "--gemm", "bf16"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    if torch.cuda.device_count() < 2:
+        env.update(RFX_FORCE_DEVICE="0", RFX_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and 2 <= line["preheat_steps"] <= 12, line["preheat_steps"]
+    assert torch.isfinite(torch.tensor(line["config"]["final_loss"]))
