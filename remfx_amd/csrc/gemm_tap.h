@@ -238,7 +238,8 @@ __device__ __forceinline__ void run_phase_tap(const rfx_gemm_desc& d, const floa
 // gather latency: same-box A/B of the Demucs step (r03): R = 3 at three waves -1.5 ms, R = 4 at three waves -1.2 ms, R <= 2 at four
 // waves -0.7 ms, R = 3 at four waves another -1.0 ms (540 B of scratch per lane, still a net gain).  One step further the spills land
 // in the K loop and the step collapses: R = 4 at four waves 147 -> 379 ms, R = 3 at five 336 ms, R <= 2 at five 156 ms (second builds
-// of the library, same box).  (The split-bf16x3 mode holds hi + lo fragments and stays at two waves.)
+// of the library, same box).  (The split-bf16x3 mode holds hi + lo fragments and stays at two waves: R <= 2 at three is neutral,
+// 206.3 vs 206.1 ms on the bf16x3 step, R = 3, 4 at three +7.7 ms.)
 template <int R, int MODE, int IN16 = 0>
 __global__ __launch_bounds__(256, MODE == 2 ? (R <= 3 ? 4 : 3) : 2) void gemm_tap_kernel(const FwdArgs g) {
   constexpr int BM = 32 * R, NARR = MODE == 1 ? 2 : 1, CELLS = 2 * NARR * BM;
