@@ -68,7 +68,8 @@ def variant_name(code, prec):
     mode = {0: 0, 1: 1, 2: 2}[prec]
     return {0: "gemm_thin_fwd_kernel<M>", 1: f"gemm_fwd_kernel<{r}>", 2: f"gemm_tap_kernel<{r}, {mode}, 0>",
             3: f"gemm_tap_kernel<{r}, 2, 1>", 4: f"gemm_tap_stream_kernel<{mode}, 4, 1>",
-            5: f"gemm_tap_stream_kernel<{mode}, 2, 4>"}.get(kind, f"variant{code}")
+            5: f"gemm_tap_stream_kernel<{mode}, 2, 4>", 6: f"gemm_halo_kernel<{r}, 9, 0>", 7: f"gemm_halo_kernel<{r}, 9, 1>",
+            8: f"gemm_halo_kernel<{r}, 3, 0>", 9: f"gemm_halo_kernel<{r}, 3, 1>"}.get(kind, f"variant{code}")
 
 
 def _pmc_key(name):
@@ -414,6 +415,7 @@ def main():
     ap.add_argument("--no-priority-stream", action="store_true", help="A/B: run the step on the default stream (ops.enter_compute_stream off)")
     ap.add_argument("--sink", default="side", choices=["side", "main", "off"],
                     help="parameter-gradient sink (ops.GradSink) A/B: side stream (default) / compute stream / autograd accumulation")
+    ap.add_argument("--no-halo", action="store_true", help="A/B: stride-1 multi-tap convolutions on the tap-major kernels instead of gemm_halo_kernel (convplan.HALO)")
     ap.add_argument("--no-fused-dconv", action="store_true", help="A/B: layer-by-layer DConv instead of the fused kernels (csrc/dconv.hip)")
     ap.add_argument("--no-enc-z16-time", action="store_true", help="A/B: time-branch encoder conv outputs stored as fp32 (hdemucs.ENC_Z16_TIME)")
     ap.add_argument("--no-enc-z16", action="store_true", help="A/B: encoder conv outputs stored as fp32 (hdemucs.ENC_Z16)")
@@ -441,6 +443,9 @@ def main():
     from remfx_amd import ddp, ops
     ops.set_gemm_precision(args.gemm)
     ops.GradSink.MODE = args.sink
+    if args.no_halo:
+        from remfx_amd import convplan
+        convplan.HALO = False
     if args.no_fused_dconv:
         from remfx_amd import nnops
         nnops.DCONV_FUSED = False

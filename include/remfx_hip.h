@@ -92,6 +92,12 @@ typedef struct rfx_gemm_desc {
    *          are those of the rounded values) / the gradient operand g of rfx_gemm_wgrad holds bf16 values.
    * A tensor consumed only as a GEMM operand in bf16 mode loses nothing by being stored in 16 bits: the MFMA rounds it anyway. */
   int32_t in_bf16, out_bf16;
+  /* Halo-tile form (halo_nt > 0; bf16 arithmetic mode, single-phase, unit input strides, OB % 128 == 0; planner:
+   * convplan.halo_geometry): the table's first halo_nt rows are the REAL taps (3 or 9; the remaining rows repeat them per
+   * channel block), whose displacements span rows [halo_da0, halo_da0 + halo_rows) and columns [halo_db0, halo_db0 + halo_w - 128]
+   * around an output position.  gemm_halo_kernel (csrc/gemm_halo.h) stages that input tile once per 16-channel chunk in LDS and
+   * serves every tap from it; same packed A, same results up to the order of the fp32 accumulation.  0 = tap-major kernels. */
+  int32_t halo_nt, halo_rows, halo_w, halo_da0, halo_db0, halo_pad;
 } rfx_gemm_desc;
 
 /* Epilogue: v = acc + bias[m]; v = act(v); [second GEMM phase accumulates into

@@ -75,7 +75,8 @@ class GemmDesc(C.Structure):
                                          "Kpad", "out_a0", "out_b0", "out_sa", "out_sb", "R", "mg_log", "mg_axis", "mg_len", "mg_off",
                                          "Kpad_t", "gpt", "ntaps", "gpt2")] + \
                [(n, C.c_int64) for n in ("in_ns", "in_as", "in_bs", "out_ns", "out_cs", "out_as", "out_bs", "in_cs", "in_extent")] + \
-               [("in_bf16", C.c_int32), ("out_bf16", C.c_int32)]
+               [("in_bf16", C.c_int32), ("out_bf16", C.c_int32)] + \
+               [(n, C.c_int32) for n in ("halo_nt", "halo_rows", "halo_w", "halo_da0", "halo_db0", "halo_pad")]
 
 
 class Epilogue(C.Structure):

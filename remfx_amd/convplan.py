@@ -92,6 +92,13 @@ class GemmPlan:
     in_extent: int = 0           # elements spanned by one sample of the operand (buffer range check)
     tap_tab: np.ndarray = None   # [ntaps + 16, 4] int32 (off of channel 0, da, db, 0); tail rows invalid
     woff_t: np.ndarray = None    # [Kpad_t] int32 weight gather offsets in tap-major order, -1 = zero row
+    # halo-tile form (csrc/gemm_halo.h; set by _halo_geometry when the plan qualifies, all 0 otherwise)
+    halo_nt: int = 0             # real taps (3 or 9)
+    halo_rows: int = 0           # input rows the taps of one output row touch
+    halo_w: int = 0              # input columns the taps of a 256-position tile touch
+    halo_da0: int = 0            # first row / column displacement
+    halo_db0: int = 0
+    halo_pad: int = 0
     extra: dict = field(default_factory=dict)
 
     def finalize(self, bias_row=False):
@@ -188,6 +195,33 @@ def _tap_major(self, kt, woff):
     ok = ch < self.cin
     wt[(((cbi * nt + t) * gb * 8) + c)[ok]] = woff[(ch * nt + t)[ok]]
     self.woff_t = wt.astype(np.int32)
+    self._halo_geometry(taps, nt, gb)
+
+
+HALO = True               # bench.py --no-halo / tests switch the halo-tile kernel off (plans built while it is False carry halo_nt = 0)
+HALO_TW = 128             # output positions per workgroup of gemm_halo_kernel (csrc/gemm_halo.h: RFX_HALO_TW)
+
+
+def _halo_geometry(self, taps, nt, gb):
+    """Does gemm_halo_kernel take this plan?  Stride-1 convolution with 3 or 9 real taps over a unit-stride position axis whose
+    length is a multiple of the 128-position tile, channel blocks of an even number of 8-channel groups (a K step never straddles two
+    taps), and a halo tile that the kernel's staging slots cover: rows <= 3, rows x columns <= 256 (3 taps) / 512 (9 taps).
+    The first nt table rows are the real taps; the kernel derives each tap's position shift inside the tile from (da, db)."""
+    self.halo_nt = self.halo_rows = self.halo_w = self.halo_da0 = self.halo_db0 = 0
+    if not HALO or nt not in (3, 9) or gb < 2 or gb % 2 or self.SA != 1 or self.SB != 1 or int(self.in_bs) != 1:
+        return
+    if self.OB % HALO_TW or self.Kpad_t != 8 * self.ntaps * self.gpt:
+        return
+    da, db = taps[:, 1], taps[:, 2]
+    if not np.array_equal(taps[:, 0], da * int(self.in_as) + db * int(self.in_bs)):
+        return
+    rows, w = int(da.max() - da.min()) + 1, HALO_TW + int(db.max() - db.min())
+    if rows > 3 or rows * w > 256 * (2 if nt == 9 else 1):
+        return
+    self.halo_nt, self.halo_rows, self.halo_w, self.halo_da0, self.halo_db0 = nt, rows, w, int(da.min()), int(db.min())
+
+
+GemmPlan._halo_geometry = _halo_geometry
 
 
 GemmPlan._build_tap_major = _tap_major
@@ -351,6 +385,7 @@ def merged_phase_plan(inshape, instrides, rows, axis, G, J, off, out_len, ostrid
     else:
         p.OB = npos
     p.mg_log, p.mg_axis, p.mg_len, p.mg_off = int(G).bit_length() - 1, axis, out_len, off
+    p.halo_nt = 0                # the merged store is not a halo-kernel epilogue (and OA / OB were just changed)
     if p.R == 0:                 # few output rows (last decoders: 1-2 channels x 4 phases): the thin kernel has no merged store;
         p.R, p.Mpad = 1, 32      # one MFMA launch that reads the operand once beats G thin launches that each re-read it
     p.extra["out_shape"] = None

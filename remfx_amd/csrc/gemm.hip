@@ -214,6 +214,9 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
     RFX_CHECK_LAUNCH();
     return 0;
   }
+  // stride-1 multi-tap plans in the bf16 mode: halo-tile kernel (gemm_halo.h) -- the input tile of a 256-position row segment is
+  // staged once per 16-channel chunk in LDS and serves every tap
+  if (prec == 2 && !apack2 && d->in_bf16 != 3 && rfx_halo_takes(*d)) return rfx_launch_gemm_halo(g, s);
   const int bm = 32 * r;
   if (d->Mpad % bm != 0) return -1;
   const int64_t work = (int64_t)((P + 127) / 128) * d->N;          // (sample, position tile) items
@@ -235,13 +238,16 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
 // Which kernel instantiation rfx_gemm_fwd launches for (desc, epilogue, prec): measurement tools label launches with it
 // (bench.py's per-kernel roofline).  kind * 16 + R; kind: 0 gemm_thin_fwd_kernel<M>, 1 gemm_fwd_kernel<R> (exact fp32, channel-major),
 // 2 gemm_tap_kernel<R, prec>, 3 gemm_tap_kernel<R, 2, IN16> (16-bit gathered operand), 4 gemm_tap_stream_kernel<prec, 4, 1>,
-// 5 gemm_tap_stream_kernel<prec, 2, 4>.  Pure function of its arguments.
+// 5 gemm_tap_stream_kernel<prec, 2, 4>, 6 / 7 gemm_halo_kernel<R, 9, 0 / 1> (fp32 / 16-bit operand), 8 / 9 gemm_halo_kernel<R, 3, 0 / 1>.
+// Pure function of its arguments.
 extern "C" int rfx_gemm_fwd_variant(const rfx_gemm_desc* d, const rfx_epilogue* epi, int32_t two_phase, int32_t prec) {
   if (!d || prec < 0 || prec > 2) return -1;
   rfx_epilogue e = epi ? *epi : rfx_epilogue{};
   const int r = d->R;
   if (r == 0) return 0;
   if (prec == 0) return 16 + r;
+  if (prec == 2 && !two_phase && d->in_bf16 != 3 && rfx_halo_takes(*d))
+    return 16 * (6 + (d->in_bf16 ? 1 : 0) + (d->halo_nt == 3 ? 2 : 0)) + rfx_halo_pick_r(*d);
   if (d->in_bf16) return 48 + r;
   if (rfx_tap_use_stream(*d, e, two_phase != 0, r)) return (d->Kpad_t <= 16 ? 64 : 80) + r;
   return 32 + r;

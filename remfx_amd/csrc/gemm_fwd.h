@@ -685,4 +685,20 @@ static inline bool rfx_tap_use_stream(const rfx_gemm_desc& d, const rfx_epilogue
          e.act2 == RFX_ACT_NONE && !e.bwd && d.mg_log == 0 && !e.res && store_ok;
 }
 int rfx_launch_gemm_fwd_bf3(const FwdArgs& g, int r, dim3 grid, hipStream_t s);
+// halo-tile kernel (gemm_halo.h, gemm_fwd_halo.hip): launch-uniform eligibility, shared by the launcher and rfx_gemm_fwd_variant
+#define RFX_HALO_TW 128
+static inline __host__ __device__ bool rfx_halo_geo_ok(const rfx_gemm_desc& d) {
+  if (d.halo_nt != 3 && d.halo_nt != 9) return false;
+  const int slots = d.halo_nt == 9 ? 2 : 1;
+  return d.SA == 1 && d.SB == 1 && d.in_bs == 1 && d.mg_log == 0 && d.OB % RFX_HALO_TW == 0 && d.halo_rows >= 1 &&
+         d.halo_rows <= 3 && d.halo_w >= RFX_HALO_TW && d.halo_rows * d.halo_w <= 256 * slots && d.gpt >= 2 && (d.gpt & 1) == 0 &&
+         d.ntaps % d.halo_nt == 0 && d.Kpad_t == 8 * d.ntaps * d.gpt;
+}
+static inline int rfx_halo_pick_r(const rfx_gemm_desc& d) {
+  if (d.Mpad % 96 == 0) return 3;
+  if (d.Mpad % 64 == 0) return 2;
+  return d.Mpad % 32 == 0 ? 1 : 0;
+}
+static inline bool rfx_halo_takes(const rfx_gemm_desc& d) { return d.R > 0 && rfx_halo_geo_ok(d) && rfx_halo_pick_r(d) > 0; }
+int rfx_launch_gemm_halo(const FwdArgs& g, hipStream_t s);
 int rfx_launch_gemm_fwd_bf16(const FwdArgs& g, int r, dim3 grid, hipStream_t s);

@@ -14,6 +14,7 @@ unchanged.  Multi-GPU: the loaders shard by rank with a DistributedSampler (what
 reference), see ``EffectDatamodule._dl``.
 """
 import os
+import sys
 import warnings
 from pathlib import Path
 
@@ -177,8 +178,9 @@ class EffectDataset(Dataset):
     * no corpus (``root`` unset or missing: ``${oc.env:DATASET_ROOT}`` without the variable) -> the synthetic
       white-noise items of BASELINE.json's configs, ``total_chunks`` of them, with a one-time warning;
     * a corpus + ``render_files=True`` -> the chunks are RENDERED on the device (datasets.py:399-452: random chunk of a
-      random file, mono, `process_effects`, written as input.wav / target.wav / dry_effects.pt / wet_effects.pt); an
-      existing rendered set is wiped first, as upstream (which asks on stdin)."""
+      random file, mono, `process_effects`, written as input.wav / target.wav / dry_effects.pt / wet_effects.pt) by RANK 0
+      only (the other ranks wait at a barrier); an existing rendered set is replaced only after upstream's y/n question on a
+      terminal or with REMFX_OVERWRITE_RENDERED=1, and kept (with a warning) otherwise."""
 
     _SEEDS = {"train": 12345, "val": 22345, "test": 32345}
 
@@ -216,17 +218,43 @@ class EffectDataset(Dataset):
                                                     seed=self._SEEDS.get(mode, 42345))
 
     def _render(self, rendered):
-        """datasets.py:381-452 on the device: wipe an existing set (upstream asks first), render total_chunks chunks."""
+        """datasets.py:381-452 on the device.  Rank 0 renders, the other ranks wait at a barrier and then list the same
+        `proc_root` (every rank constructs the dataset under DDP; concurrent renders into one directory would tear the
+        input / target / label files of a chunk apart).  An existing non-empty rendered set is never deleted implicitly:
+        upstream asks y/n on stdin (datasets.py:385-395) -- so does this on a terminal; without one it takes
+        REMFX_OVERWRITE_RENDERED=1 as the "y" and otherwise KEEPS the set with a warning."""
         import shutil
         from .effects import LoudnessNormalize
         if not torch.cuda.is_available():
             raise RuntimeError("EffectDataset(render_files=True) renders on the GPU (remfx_amd.effects has no CPU path)")
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        rank = torch.distributed.get_rank() if dist_on else 0
+        try:
+            if rank == 0:
+                self._render_rank0(rendered, shutil, LoudnessNormalize)
+        finally:
+            if dist_on:
+                torch.distributed.barrier()                  # the other ranks list proc_root only after rank 0 is done
+        self.total_chunks = self._rendered_chunks() or self.total_chunks
+
+    def _render_rank0(self, rendered, shutil, LoudnessNormalize):
         dev = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         files = locate_files(self.root, self.mode)
         if not files or not any(files):
             raise ValueError(f"EffectDataset: no audio files of the known corpora under {self.root} for mode {self.mode!r}")
         if rendered:
-            warnings.warn(f"EffectDataset: re-rendering {self.proc_root} (render_files=True); set render_files=False to keep it")
+            if os.environ.get("REMFX_OVERWRITE_RENDERED", "") == "1":
+                answer = "y"
+            elif sys.stdin is not None and sys.stdin.isatty():
+                answer = input("WARNING: By default, will re-render files.\nSet render_files=False to skip re-rendering.\n"
+                               "Are you sure you want to re-render? (y/n): ")
+            else:
+                answer = "n"
+            if answer != "y":
+                warnings.warn(f"EffectDataset: keeping the {rendered} chunks already under {self.proc_root} "
+                              "(render_files=True, but an existing set is only replaced after a 'y' on the terminal or with "
+                              "REMFX_OVERWRITE_RENDERED=1)", stacklevel=3)
+                return
             shutil.rmtree(self.proc_root)
         self.proc_root.mkdir(parents=True, exist_ok=True)
         normalize = LoudnessNormalize(self.sample_rate, target_lufs_db=-20)
