@@ -264,7 +264,7 @@ def bench_chain(args, rank, world, device):
     print(json.dumps({
         "metric": "audio-seconds/sec chain inference (whole job)", "value": round(world * batch * CLIP / SR * args.steps / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": DTYPES[args.gemm],
         "data": "synthetic", "config": {"workload": "RemFX-detect chain inference (+exp=remfx_detect), inference only",
                                         "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
@@ -406,6 +406,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("RFX_WORKLOAD", "demucs"),
                     choices=["demucs", "tcn", "dcunet", "umx", "chain", "demucs_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the BASELINE config's batch)")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="strong: the BASELINE config's GLOBAL batch split over the ranks (SURVEY 8(e): config 3 = 64 clips -> 64 / N per GPU; "
+                         "the default for the training workloads); weak: that batch on EVERY rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat", type=int, default=3,
                     help="minimum number of extra UNTIMED steps before the W warm-up steps (0 = no preheat at all): a freshly leased box "
@@ -461,6 +464,15 @@ def main():
     device = torch.device("cuda", local)
     # BASELINE.json configs: Demucs 64 clips/GPU (headline), TCN 32, DCUNet 32 over 8 GPUs = 4/GPU, UMX 4
     batch = args.batch or {"tcn": 32, "demucs": 64, "dcunet": 4, "umx": 4, "chain": 16, "demucs_fwd": 64}[args.workload]
+    # Strong scaling (SURVEY 8(e) "Partitioning": batch B split evenly, B / N clips per GPU): the Demucs / TCN configs name a global
+    # batch (64 / 32 clips), so `--gpus N` splits it; DCUNet / Open-Unmix / chain are quoted per GPU already (32 over 8 GPUs = 4, 128 over
+    # 8 = 16) and stay weak.  `--batch` fixes the per-GPU count and implies weak.
+    if args.scaling is None:
+        args.scaling = "strong" if (args.workload in ("demucs", "tcn") and not args.batch) else "weak"
+    if args.scaling == "strong" and world > 1:
+        if batch % world:
+            raise SystemExit(f"--scaling strong: the global batch {batch} does not split over {world} ranks")
+        batch //= world
 
     if args.workload == "chain":
         return bench_chain(args, rank, world, device)
@@ -619,14 +631,14 @@ def main():
     out = {
         "metric": "audio-seconds/sec fwd+bwd (whole job)", "value": round(audio_s / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": DTYPES[args.gemm],
         "data": "synthetic", "preheat_steps": args.preheat,
         "config": {"workload": {"tcn": "TCN (cfg/model/tcn.yaml) train step, +exp=reverb model=tcn",
                                 "demucs": "Hybrid Demucs (cfg/model/demucs.yaml) train step, +exp=chorus_aug model=demucs",
                                 "dcunet": "DCUNet Large-DCUNet-20 (cfg/model/dcunet.yaml) train step, +exp=5-5_full model=dcunet",
                                 "umx": "Open-Unmix (cfg/model/umx.yaml) train step, +exp=distortion model=umx"}[args.workload],
-                   "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
+                   "clips_per_gpu": batch, "global_batch": batch * world, "clip_samples": CLIP, "sample_rate": SR,
                    "step": "fwd + MRSTFT+100*L1 loss + bwd + clip 10 + AdamW + per-step metrics",
                    "parallelism": f"dp{world}", "final_loss": round(float(loss.detach()), 5),
                    # data-parallel bookkeeping: collective backend ("nccl" = RCCL over xGMI), the all-reduce time the step

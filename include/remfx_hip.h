@@ -463,9 +463,11 @@ int rfx_phase_mask_bwd(const float* xc, const float* gout, float* gmag, int64_t 
  * Replaces auraloss.freq.STFTLoss.forward (models.py:299,320,362,385,107; metrics 237-255). */
 int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R, int64_t n, float eps, float* sums,
                          void* stream);
-/* gxc = w_sc * d[sqrt(A_r)/sqrt(B_r)]/dxc + w_lm * d[sum |log|X|-log|Y||]/dxc  (A_r, B_r from sums) */
+/* gxc = w_sc * d[sqrt(A_r)/sqrt(B_r)]/dxc + w_lm * d[sum |log|X|-log|Y||]/dxc  (A_r, B_r from sums).  gup (may be NULL): one
+ * device float that multiplies both weights -- the upstream gradient of the scalar loss, read on the device so that the backward
+ * pass needs no host synchronisation (and a training step can be captured into a hipGraph). */
 int rfx_stft_loss_grad(const float* xc, const float* yc, int32_t R, int64_t n, float eps,
-                       const float* sums, float w_sc, float w_lm, float* gxc, void* stream);
+                       const float* sums, float w_sc, float w_lm, const float* gup, float* gxc, void* stream);
 /* The forward of one STFTLoss resolution in ONE launch (replaces two rfx_fft_analysis + rfx_stft_loss_reduce; auraloss STFTLoss behind
  * models.py:320): two frames of a signal come out of one complex FFT (w s_a + i w s_b), the prediction's clamped powers wait in
  * registers for the target's and the three row sums are accumulated into sums [R][3] (zeroed by the caller) in the epilogue.  d: R, T, n_fft (512 / 1024 / 2048), hop, win, frames_out = 1 + T / hop,
@@ -476,9 +478,9 @@ int rfx_stft_pair_loss(const rfx_stft_desc* d, const float* x, const float* y, c
                        float* xspec, float* ymag, void* stream);
 /* rfx_stft_loss_grad with the target given by its clamped magnitudes (rfx_stft_pair_loss's ymag) instead of its spectrum */
 int rfx_stft_loss_grad_m(const float* xc, const float* ymag, int32_t R, int64_t n, float eps, const float* sums, float w_sc,
-                         float w_lm, float* gxc, void* stream);
-/* g[i] = w * sign(a[i] - b[i])   (nn.L1Loss backward) */
-int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, float* g, void* stream);
+                         float w_lm, const float* gup, float* gxc, void* stream);
+/* g[i] = w * gup[0] * sign(a[i] - b[i])   (nn.L1Loss backward; gup as above, NULL = 1) */
+int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, const float* gup, float* g, void* stream);
 /* per row: sums[r] += { sum x, sum t, sum x t, sum x^2, sum t^2 } in fp64 (auraloss SISDRLoss) */
 int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t L, int64_t x_rs, int64_t t_rs,
                    double* sums, void* stream);

@@ -108,10 +108,10 @@ SIGNATURES = {
     "rfx_fft_analysis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
     "rfx_fft_synthesis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
     "rfx_stft_loss_reduce": [_P, _P, _I32, _I64, C.c_float, _P, _P],
-    "rfx_stft_loss_grad": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P],
-    "rfx_stft_loss_grad_m": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P],
+    "rfx_stft_loss_grad": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P, _P],
+    "rfx_stft_loss_grad_m": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_stft_pair_loss": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P],
-    "rfx_l1_grad": [_P, _P, _I64, C.c_float, _P, _P],
+    "rfx_l1_grad": [_P, _P, _I64, C.c_float, _P, _P, _P],
     "rfx_sisdr_sums": [_P, _P, _I32, _I64, _I64, _I64, _P, _P],
     "rfx_zero": [_P, _I64, _P],
     "rfx_sumsq": [_P, _I64, _P, _P],

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(256) void stft_loss_reduce_kernel(const float2* __r
 __global__ __launch_bounds__(256) void stft_loss_grad_kernel(const float2* __restrict__ xc,
                                                              const float2* __restrict__ yc, const float* __restrict__ ymag, int64_t n,
                                                              float eps, const float* __restrict__ sums,
-                                                             float w_sc, float w_lm, float2* __restrict__ gxc) {
+                                                             float w_sc, float w_lm, const float* __restrict__ gup, float2* __restrict__ gxc) {
   const int r = blockIdx.y;
+  if (gup) { const float u = gup[0]; w_sc *= u; w_lm *= u; }      // upstream scalar gradient read on the device (no host sync)
   const float A = sums[3 * r], B = sums[3 * r + 1];
   const float ksc = (A > 0.f && B > 0.f) ? w_sc / (sqrtf(A) * sqrtf(B)) : 0.f;   // d sqrt(A)/sqrt(B) / dA * 2
   const float2* xr = xc + (int64_t)r * n;
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void stft_loss_grad_kernel(const float2* __res
 
 // g[i] = w * sign(a[i]-b[i])
 __global__ void l1_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float w,
-                               float* __restrict__ g) {
+                               const float* __restrict__ gup, float* __restrict__ g) {
+  if (gup) w *= gup[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float d = a[i] - b[i];
     g[i] = d > 0.f ? w : (d < 0.f ? -w : 0.f);
@@ -147,24 +149,24 @@ extern "C" int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R,
   return 0;
 }
 extern "C" int rfx_stft_loss_grad(const float* xc, const float* yc, int32_t R, int64_t n, float eps,
-                                  const float* sums, float w_sc, float w_lm, float* gxc, void* stream) {
+                                  const float* sums, float w_sc, float w_lm, const float* gup, float* gxc, void* stream) {
   if (!xc || !yc || !sums || !gxc || R <= 0 || n <= 0) return -1;
   hipLaunchKernelGGL(stft_loss_grad_kernel, dim3(grid_x(n), R), dim3(256), 0, (hipStream_t)stream,
-                     (const float2*)xc, (const float2*)yc, (const float*)nullptr, n, eps, sums, w_sc, w_lm, (float2*)gxc);
+                     (const float2*)xc, (const float2*)yc, (const float*)nullptr, n, eps, sums, w_sc, w_lm, gup, (float2*)gxc);
   RFX_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int rfx_stft_loss_grad_m(const float* xc, const float* ymag, int32_t R, int64_t n, float eps,
-                                    const float* sums, float w_sc, float w_lm, float* gxc, void* stream) {
+                                    const float* sums, float w_sc, float w_lm, const float* gup, float* gxc, void* stream) {
   if (!xc || !ymag || !sums || !gxc || R <= 0 || n <= 0) return -1;
   hipLaunchKernelGGL(stft_loss_grad_kernel, dim3(grid_x(n), R), dim3(256), 0, (hipStream_t)stream,
-                     (const float2*)xc, (const float2*)nullptr, ymag, n, eps, sums, w_sc, w_lm, (float2*)gxc);
+                     (const float2*)xc, (const float2*)nullptr, ymag, n, eps, sums, w_sc, w_lm, gup, (float2*)gxc);
   RFX_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, float* g, void* stream) {
+extern "C" int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, const float* gup, float* g, void* stream) {
   if (!a || !b || !g || n <= 0) return -1;
-  hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_x(n) * 4), dim3(256), 0, (hipStream_t)stream, a, b, n, w, g);
+  hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_x(n) * 4), dim3(256), 0, (hipStream_t)stream, a, b, n, w, gup, g);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -134,7 +134,8 @@ class _MRSTFTFn(torch.autograd.Function):
     def backward(ctx, g):
         shape, R, L, eps, per_example_sc, nres = ctx.meta
         gx = zeros((R, L), g.device)
-        gval = float(g)          # scalar upstream gradient (one host sync per backward)
+        gval = 1.0               # the scalar upstream gradient stays on the device: the kernels multiply their weights by *gup
+        gup = g.detach().reshape(1).float().contiguous()
         for paired, X, Y, sums, n, n_fft, hop, win in ctx.saved:
             if not per_example_sc:      # whole-batch Frobenius norm: same A, B for every row
                 sums = sums.clone()
@@ -146,10 +147,10 @@ class _MRSTFTFn(torch.autograd.Function):
             w_lm = gval / (nres * R * n)
             G = torch.empty_like(X)
             if paired:                  # Y = the clamped target magnitudes
-                check(_lib.lib().rfx_stft_loss_grad_m(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(G),
+                check(_lib.lib().rfx_stft_loss_grad_m(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(gup), _ptr(G),
                                                       _stream()), "rfx_stft_loss_grad_m")
             else:
-                check(_lib.lib().rfx_stft_loss_grad(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(G),
+                check(_lib.lib().rfx_stft_loss_grad(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(gup), _ptr(G),
                                                     _stream()), "rfx_stft_loss_grad")
             w = stft.hann(win, g.device)
             d = stft._desc(R, L, n_fft, hop, win, X.shape[2], 0, X.shape[1], _SPEC_MODE, in_mode=0, herm=0, scale=1.0)
@@ -185,7 +186,8 @@ class _L1Fn(torch.autograd.Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         ga = torch.empty_like(a)
-        check(_lib.lib().rfx_l1_grad(_ptr(a), _ptr(b), a.numel(), float(g) / a.numel(), _ptr(ga), _stream()),
+        gup = g.detach().reshape(1).float().contiguous()          # upstream scalar gradient, multiplied in on the device (no host sync)
+        check(_lib.lib().rfx_l1_grad(_ptr(a), _ptr(b), a.numel(), 1.0 / a.numel(), _ptr(gup), _ptr(ga), _stream()),
               "rfx_l1_grad")
         return ga, None
 

@@ -146,3 +146,47 @@ def test_dcunet_model_wrapper_full_length():
     assert out.shape == (1, 1, 262144) and torch.isfinite(loss)
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_dcunet_full_length_golden(golden_dir):
+    """BASELINE config 4 at its real length: one 262144-sample clip = 1023 STFT frames through Large-DCUNet-20, eval forward and
+    train-mode forward + backward against tests/golden/dcunet_full.npz (oracle/gen_full_length_golden.py).  The train-mode
+    expectations come from an fp64 run of the oracle; `cpu_fp32_vs_fp64_global_rel` is how far its own fp32 run sits from it."""
+    import os
+    import numpy as np
+    gd = np.load(os.path.join(golden_dir, "dcunet_full.npz"))
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 262144, generator=g) * 0.3
+    sl = lambda t, n=2048: t.detach().reshape(-1)[::max(1, t.numel() // n)][:n].numpy()
+    _, net = _pair(train=False)
+    with torch.no_grad():
+        yd = net(x.to(DEV)).cpu()
+    assert yd.shape == (1, 1, 262144)
+    e = float(np.sqrt(((sl(yd) - gd["eval_y_slice"]) ** 2).mean()))
+    check(e, 1e-4, max(1.0, float(gd["eval_y_absmax"])), what=("eval", e))
+    check(abs(float(yd.double().norm()) - float(gd["eval_y_norm"])), 1e-4, float(gd["eval_y_norm"]), bf16=2e-2, what="eval norm")
+    _, net = _pair(train=True)
+    gy = torch.randn(yd.shape, generator=g)
+    yt = net(x.to(DEV))
+    e = float(np.sqrt(((sl(yt.cpu()) - gd["train_y_slice"]) ** 2).mean()))
+    check(e, 1e-4, max(1.0, float(gd["train_y_absmax"])), what=("train", e))
+    yt.backward(gy.to(DEV))
+    params = dict(net.named_parameters())
+    tot = sum(float(p.grad.double().pow(2).sum()) for p in params.values()) ** 0.5
+    e_cpu = float(gd["cpu_fp32_vs_fp64_global_rel"])
+    check(abs(tot - float(gd["grad_global_norm"])), max(2e-3, 2 * e_cpu), float(gd["grad_global_norm"]), bf16x3=2e-2, bf16=0.4,
+          what="global grad norm")
+    num = den = 0.0
+    for i, n in enumerate(gd["names"].tolist()):
+        got, ref = sl(params[n].grad.cpu(), 512), gd[f"g{i}_slice"]
+        num += float(((got - ref) ** 2).sum()); den += float((ref ** 2).sum())
+    rel = (num / den) ** 0.5
+    print(f"DCUNet full-length train-mode gradients vs the fp64 oracle: slice-wise global relative error {rel:.2e} [{mode()}]; "
+          f"the CPU fp32 oracle itself: {e_cpu:.2e}")
+    if mode() == "f32":
+        assert rel < max(2.0 * e_cpu, 5e-3), (rel, e_cpu)
+    else:
+        check(rel, 5e-3, bf16x3=max(2e-2, 4 * e_cpu), bf16=0.4, what=("grad slices", rel))
+    rb = dict(net.named_buffers())
+    for k, n in enumerate(gd["rm_names"].tolist()):
+        check(_rms(rb[n].cpu(), torch.from_numpy(gd[f"rm{k}"])), 1e-5, max(1.0, float(np.abs(gd[f"rm{k}"]).max())), bf16x3=1e-4, what=n)

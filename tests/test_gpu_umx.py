@@ -86,3 +86,46 @@ def test_openunmix_model_wrapper():
     assert int(m.model.bn1.num_batches_tracked) == before + 2          # Q3: BN stats updated twice per step
     loss.backward()
     assert m.model.fc1.weight.grad is not None and torch.isfinite(m.model.fc1.weight.grad).all()
+
+
+def test_umx_full_length_golden(golden_dir):
+    """BASELINE config 1 at its real length: 262144-sample clips = 513 STFT frames = the 513-step 3-layer BiLSTM, eval forward and
+    train-mode forward + backward against tests/golden/umx_full.npz (oracle/gen_full_length_golden.py: the CPU oracle run once on
+    the seeded weights of `_pair` and a seeded pair of clips)."""
+    import os
+    import numpy as np
+    from remfx_amd.umx import Separator
+    gd = np.load(os.path.join(golden_dir, "umx_full.npz"))
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 1, 262144, generator=g) * 0.3
+    _, net = _pair()
+    net.eval()
+    sep = Separator(target_models={"other": net}, nb_channels=1, sample_rate=48000, n_fft=2048, n_hop=512).to(DEV)
+    with torch.no_grad():
+        yd = sep(x.to(DEV)).cpu()
+    assert yd.shape == (2, 1, 1, 262144)
+    sl = lambda t, n=2048: t.detach().reshape(-1)[::max(1, t.numel() // n)][:n].numpy()
+    e = float(np.sqrt(((sl(yd) - gd["eval_y_slice"]) ** 2).mean()))
+    check(e, 1e-4, max(1.0, float(gd["eval_y_absmax"])), what=("eval", e))
+    check(abs(float(yd.double().norm()) - float(gd["eval_y_norm"])), 1e-4, float(gd["eval_y_norm"]), what="eval norm")
+    _, net = _pair()
+    net.train()
+    net.lstm.dropout = 0.0
+    sep = Separator(target_models={"other": net}, nb_channels=1, sample_rate=48000, n_fft=2048, n_hop=512).to(DEV)
+    gy = torch.randn(yd.shape, generator=g)
+    yt = sep(x.to(DEV))
+    e = float(np.sqrt(((sl(yt.cpu()) - gd["train_y_slice"]) ** 2).mean()))
+    check(e, 1e-4, max(1.0, float(gd["train_y_absmax"])), what=("train", e))
+    yt.backward(gy.to(DEV))
+    params = dict(net.named_parameters())
+    tot = sum(float(params[n].grad.double().pow(2).sum()) for n in gd["names"].tolist()) ** 0.5
+    check(abs(tot - float(gd["grad_global_norm"])), 2e-3, float(gd["grad_global_norm"]), bf16=5e-2, what="global grad norm")
+    num = den = 0.0
+    for i, n in enumerate(gd["names"].tolist()):
+        got, ref = sl(params[n].grad.cpu(), 512), gd[f"g{i}_slice"]
+        num += float(((got - ref) ** 2).sum()); den += float((ref ** 2).sum())
+        check(abs(float(params[n].grad.double().norm()) - float(gd[f"g{i}_norm"])), 1e-2, max(float(gd[f"g{i}_norm"]), 1e-3 * tot),
+              bf16=0.1, what=(n, "norm"))
+    rel = (num / den) ** 0.5
+    print(f"Open-Unmix full-length gradients (513 recurrence steps): slice-wise global relative error {rel:.2e} [{mode()}]")
+    check(rel, 2e-3, what=("grad slices", rel))

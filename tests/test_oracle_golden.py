@@ -189,3 +189,42 @@ def test_hdemucs_full_config_gradient_fixture_reproduces(golden_dir):
     for i, n in enumerate(gd["names"].tolist()):
         gr = names[n].grad.detach().reshape(-1)
         assert abs(float(gr.double().norm()) - float(gd[f"g{i}_norm"])) <= 1e-3 * float(gd[f"g{i}_norm"]), n
+
+
+def test_full_length_umx_fixture_reproduces(golden_dir):
+    """tests/golden/umx_full.npz is what the Open-Unmix oracle produces here on the generator's seeded weights and clips
+    (oracle/gen_full_length_golden.py; eval forward of two 262144-sample clips = 513 BiLSTM steps, ~10 s on 8 cores)."""
+    import importlib.util
+    import os
+    import torch
+    from oracle import ref_umx
+    spec = importlib.util.spec_from_file_location("gen_full", os.path.join(os.path.dirname(__file__), "..", "oracle",
+                                                                            "gen_full_length_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gd = np.load(os.path.join(golden_dir, "umx_full.npz"))
+    x = torch.randn(2, 1, gen.T, generator=torch.Generator().manual_seed(22)) * 0.3
+    ref = gen.umx_pair_oracle().eval()
+    with torch.no_grad():
+        y = ref_umx.separator(ref, x)
+    np.testing.assert_allclose(gen._slice(y, 2048).numpy(), gd["eval_y_slice"], rtol=1e-4, atol=1e-5)
+    assert abs(float(y.double().norm()) - float(gd["eval_y_norm"])) <= 1e-4 * float(gd["eval_y_norm"])
+
+
+def test_full_length_dcunet_fixture_reproduces(golden_dir):
+    """tests/golden/dcunet_full.npz: eval forward of the DCUNet oracle on the generator's clip (1023 frames, ~15 s on 8 cores)."""
+    import importlib.util
+    import os
+    import torch
+    spec = importlib.util.spec_from_file_location("gen_full", os.path.join(os.path.dirname(__file__), "..", "oracle",
+                                                                            "gen_full_length_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gd = np.load(os.path.join(golden_dir, "dcunet_full.npz"))
+    x, _ = gen.full_inputs(21)
+    ref = gen.dcunet_pair_oracle(False)
+    with torch.no_grad():
+        y = ref(x)
+    np.testing.assert_allclose(gen._slice(y, 2048).numpy(), gd["eval_y_slice"], rtol=1e-4, atol=1e-5)
+    assert abs(float(y.double().norm()) - float(gd["eval_y_norm"])) <= 1e-4 * float(gd["eval_y_norm"])
+    assert 0 < float(gd["cpu_fp32_vs_fp64_global_rel"]) < 5e-2 and len(gd["names"]) == 10
