@@ -483,6 +483,7 @@ def main():
     opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
     ddp.broadcast_parameters(opt.flat.data)
     sync = ddp.GradSync(opt.flat)
+    sync.measure_stall = True                     # exposed_allreduce_ms below (two timing events per step; off in Trainer.fit)
     data = synthetic_batch(batch, rank, device)
     if args.union_ranks > 1:
         parts = [synthetic_batch(batch, r, device) for r in range(args.union_ranks)]

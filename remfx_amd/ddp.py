@@ -79,6 +79,9 @@ class GradSync:
         self.sink = getattr(flat, "sink", None)
         self.expected = None                        # sink writes per parameter in one step, learned in step 1
         self._seen = [0] * len(flat.params)
+        self._counted = [False] * len(flat.params)  # a parameter enters its bucket's `ready` count once per step, whichever route fired
+        self._late = False                          # a gradient write arrived after its bucket's all-reduce was queued
+        self.measure_stall = False                  # bench.py: time the compute stream's stall on the collectives (exposed_ms)
         if self.overlap:
             for idx, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(idx))
@@ -88,6 +91,14 @@ class GradSync:
     def _make_hook(self, idx):
         def hook(_p):
             b = self.buckets[self.bucket_of[idx]]
+            if b.get("launched"):                    # autograd accumulated into a slice that is already being reduced
+                self._late = True
+                return
+            if self._counted[idx] or b.get("hold"):
+                return
+            if self.expected is not None and self.expected[idx] > self._seen[idx]:
+                return                               # the sink still owes this parameter writes: its last write counts it
+            self._counted[idx] = True
             b["ready"] += 1
             if b["ready"] == b["n"]:
                 self._launch(b)
@@ -97,7 +108,13 @@ class GradSync:
         self._seen[idx] += 1
         if self.expected is None:
             return                                   # calibration step: finish() launches everything
-        if self._seen[idx] == self.expected[idx]:
+        b = self.buckets[self.bucket_of[idx]]
+        if b.get("launched"):
+            # the write lands behind the queued all-reduce and would stay a rank-local addition to the reduced slice
+            self._late = True
+        elif self._seen[idx] > self.expected[idx]:
+            b["hold"] = True                         # more writes than the calibration step saw: this bucket waits for finish()
+        elif self._seen[idx] == self.expected[idx]:
             self._make_hook(idx)(None)
 
     def _launch(self, b):
@@ -121,7 +138,7 @@ class GradSync:
             return 1.0
         for b in self.buckets:
             self._launch(b)           # whatever the hooks have not launched (parameters without a gradient never fire theirs)
-        timed = self.flat.grad.is_cuda
+        timed = self.flat.grad.is_cuda and self.measure_stall
         if timed:                     # GPU time the compute stream spends stalled on the collectives = what backward did not hide
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -135,12 +152,22 @@ class GradSync:
         for b in self.buckets:
             b["ready"] = 0
             b["launched"] = False
-        if self.sink is not None:
+            b["hold"] = False
+        self._counted = [False] * len(self.flat.params)
+        late, self._late = self._late, False
+        if self.sink is not None or self.expected is not None:
             if self.expected is None:
                 self.expected = list(self._seen)
             elif self._seen != self.expected:        # the graph changed: re-calibrate (one step without early launches)
                 self.expected = None
             self._seen = [0] * len(self.flat.params)
+        if late:
+            # A gradient was written into a slice AFTER its all-reduce had been queued (a data-dependent branch used a parameter more
+            # often than the calibration step did): that contribution is rank-local, the replicas would silently diverge.  No rank can
+            # repair it alone, so the step must not be applied: stop here (the other ranks stop at their next collective).
+            raise RuntimeError("GradSync: a parameter gradient was written after its bucket's all-reduce was launched; the reduced "
+                               "gradients of this step are inconsistent across ranks (construct GradSync(overlap=False) for models "
+                               "whose parameter use varies from step to step)")
         return 1.0 / self.world       # fold the mean into the optimiser's gradient scale
 
 
@@ -150,6 +177,12 @@ class GradSync:
             return 0.0
         torch.cuda.synchronize()
         return float(sum(a.elapsed_time(b) for a, b in self._stall))
+
+
+def barrier():
+    """dist.barrier() when a process group is up (no-op in single-process runs)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
 
 
 def all_reduce_mean_scalar(t):

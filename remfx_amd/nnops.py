@@ -264,12 +264,13 @@ class _DConvLayerFn(torch.autograd.Function):
     (GroupNorm backward x2, input-gradient GEMM x2, weight-gradient GEMM x2), in the order autograd would run them."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, dil, eps):
+    def forward(ctx, x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, dil, eps, grad_on=True):
         ops._req(x, "x")
         N, Cc, T = x.shape
         H = Cc // 4
         out = torch.empty_like(x)
-        need = any(ctx.needs_input_grad)
+        # grad_on: the CALLER's grad mode (inside Function.forward it is always off, and needs_input_grad ignores no_grad)
+        need = grad_on and any(ctx.needs_input_grad)
         h16 = z16 = a_out = stats = None
         if need:
             h16 = torch.empty((N, H, T), device=x.device, dtype=torch.bfloat16)
@@ -315,9 +316,9 @@ class _DConvLayerFn(torch.autograd.Function):
         x4, dh4 = x.unsqueeze(2), dh.unsqueeze(2)
         dx = ops.conv2d_dgrad(dh4, w14, tuple(x4.shape), tuple(x4.stride()), (1, 1), (0, dil), (1, dil), res=gy.unsqueeze(2)).squeeze(2)
         dw1, db1 = ops.conv2d_wgrad(x4, dh4, (H, Cc, 1, 3), (1, 1), (0, dil), (1, dil), True, w1, b1)
-        if dw2 is not None:
-            dw2, dw1 = dw2.view_as(w2), dw1.view_as(w1)
-        return dx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None
+        dw2 = dw2.view_as(w2) if dw2 is not None else None           # each convolution takes the sink route (None) or not on its own
+        dw1 = dw1.view_as(w1) if dw1 is not None else None
+        return dx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None, None
 
 
 DCONV_FUSED = True            # bench.py --no-fused-dconv flips it for A/B runs
@@ -335,7 +336,7 @@ def dconv_layer_fused_ok(x, hidden, kernel_size, dil, need_grad):
 def dconv_layer(x, conv1, gn1, conv2, gn2, scale, dil):
     """conv1 / conv2: nn.Conv1d parameter containers, gn1 / gn2: nn.GroupNorm(1, .), scale: the LayerScale vector."""
     return _DConvLayerFn.apply(x, conv1.weight, conv1.bias, gn1.weight, gn1.bias, conv2.weight, conv2.bias, gn2.weight, gn2.bias,
-                               scale, int(dil), float(gn1.eps))
+                               scale, int(dil), float(gn1.eps), torch.is_grad_enabled())
 
 
 class _MulFn(torch.autograd.Function):

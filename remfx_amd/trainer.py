@@ -107,8 +107,13 @@ class Trainer:
 
     # ---- checkpoints (Lightning's dict layout) ----------------------------------------------------
     def checkpoint_dict(self, model, opt=None, sched=None):
+        # callbacks: Lightning keeps ModelCheckpoint's state (best_model_score, best_model_path) here; restored by _resume so that
+        # the first validation after a resume does not overwrite a better earlier best.ckpt
+        best = getattr(self, "best_score", None)
         ck = {"epoch": self.current_epoch, "global_step": self.global_step, "pytorch-lightning_version": "2.0.0",
-              "state_dict": model.state_dict(), "loops": {}, "callbacks": {},
+              "state_dict": model.state_dict(), "loops": {},
+              "callbacks": {"ModelCheckpoint": {"monitor": "valid_loss", "mode": "min", "best_model_score": best,
+                                                "best_model_path": getattr(self, "best_path", None) if best is not None else ""}},
               "optimizer_states": [opt.state_dict()] if opt is not None else [],
               "lr_schedulers": [sched.state_dict()] if sched is not None else []}
         return ck
@@ -131,6 +136,9 @@ class Trainer:
         if sched is not None and ck.get("lr_schedulers"):
             sched.load_state_dict(ck["lr_schedulers"][0])
         self.global_step, self.current_epoch = int(ck.get("global_step", 0)), int(ck.get("epoch", 0))
+        cb = (ck.get("callbacks") or {}).get("ModelCheckpoint") or {}
+        if cb.get("best_model_score") is not None:
+            self._resumed_best = float(cb["best_model_score"])
 
     def fit(self, model, datamodule=None, ckpt_dir=None, ckpt_path=None):
         """ckpt_dir: where last.ckpt is written (every ckpt_every_n_steps steps when set, every epoch, and at the end);
@@ -151,7 +159,11 @@ class Trainer:
         last = {}
         last_path = os.path.join(ckpt_dir, "last.ckpt") if ckpt_dir else None
         # ModelCheckpoint(monitor="valid_loss", mode="min") of the reference's cfg/config.yaml callbacks: best.ckpt next to last.ckpt
-        self.best_path, self.best_score, self._best_state = (os.path.join(ckpt_dir, "best.ckpt") if ckpt_dir else None), None, None
+        # best_score: restored from the checkpoint this fit resumed from (Lightning's ModelCheckpoint state); _best_written: whether
+        # THIS fit wrote best.ckpt -- test(ckpt_path="best") never picks up a stale file an earlier run left in ckpt_dir
+        self.best_path, self._best_state = (os.path.join(ckpt_dir, "best.ckpt") if ckpt_dir else None), None
+        self.best_score, self._best_written = getattr(self, "_resumed_best", None), False
+        self._resumed_best = None
         while self.global_step < self.max_steps and (self.max_epochs < 0 or self.current_epoch < self.max_epochs):
             model.train()
             if hasattr(datamodule, "set_epoch"):
@@ -183,15 +195,17 @@ class Trainer:
                 last.update(self._log(model))
                 score = last.get("valid_loss")
                 if score is not None and (self.best_score is None or float(score) < self.best_score):
-                    self.best_score = float(score)
+                    self.best_score = float(score)               # `score` is the all-reduced mean: every rank takes the same branch
                     if self.best_path:
                         self.save_checkpoint(self.best_path, model, opt, sched)
+                        self._best_written = True
                     else:                                        # no checkpoint directory: keep the weights in memory
                         self._best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
             if last_path:
                 self.save_checkpoint(last_path, model, opt, sched)
         if last_path:
             self.save_checkpoint(last_path, model, opt, sched)
+        ddp.barrier()                                            # rank 0's files are complete before any rank reads them (test(ckpt_path="best"))
         if self.logger is not None and self.rank == 0:
             self.logger.save()
         self.logged_metrics = last
@@ -203,7 +217,8 @@ class Trainer:
         model.to(self.device)
         if ckpt_path == "best":           # the best-by-validation-loss weights of the fit that just ended (Lightning's ckpt_path="best")
             best = getattr(self, "best_path", None)
-            if best and os.path.exists(best):
+            ddp.barrier()                                        # only rank 0 writes checkpoints
+            if best and getattr(self, "_best_written", False) and os.path.exists(best):
                 model.load_state_dict(load_checkpoint_file(best, map_location=self.device)["state_dict"])
             elif getattr(self, "_best_state", None) is not None:
                 model.load_state_dict(self._best_state)

@@ -160,6 +160,31 @@ got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]) * pre
 assert torch.allclose(got, want, atol=1e-6), (got - want).abs().max()
 m = ddp.all_reduce_mean_scalar(torch.tensor(float(rank)))
 assert abs(float(m) - 0.5) < 1e-6
+if sync.overlap:
+    # the gradient-sink route (GPU: kernels write parameter gradients in place, once per USE of the parameter), driven by hand:
+    # a step that writes a parameter MORE often than the calibration step did.  Before its bucket launched -> the bucket is held
+    # back until finish() (correct result); after -> finish() must refuse the step (the extra write is rank-local).
+    n = len(flat.params)
+    flat.zero_grad()
+    sync.expected, sync._seen = [1] * n, [0] * n
+    last = sync.bucket_of[n - 1]
+    first_in_last = min(i for i in range(n) if sync.bucket_of[i] == last)
+    sync._sink_write(first_in_last); sync._sink_write(first_in_last)        # one write too many, bucket not yet complete
+    for i in range(n - 1, -1, -1):
+        if i != first_in_last:
+            sync._sink_write(i)
+    assert sync.buckets[last].get("hold") and not sync.buckets[last].get("launched")
+    assert sync.finish() == 0.5 and sync.expected is None                   # reduced at finish(), counts re-learned next step
+    sync.expected, sync._seen = [1] * n, [0] * n
+    for i in range(n - 1, -1, -1):
+        sync._sink_write(i)
+    assert all(b.get("launched") for b in sync.buckets)
+    sync._sink_write(0)                                                     # lands behind the queued all-reduce
+    try:
+        sync.finish()
+        raise SystemExit("late write was not refused")
+    except RuntimeError as e:
+        assert "after its bucket" in str(e)
 dist.barrier()
 print("rank", rank, "ok")
 """
