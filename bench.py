@@ -553,7 +553,7 @@ def main():
     peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[args.gemm]
     fam_name = {"f32": "gemm_fwd_kernel<R> (gather-GEMM, v_mfma_f32_32x32x2_f32)",
                 "bf16x3": "gemm_tap_kernel<R,1> + gemm_tap_stream_kernel<1,..> (tap-major gather-GEMM, 3 x v_mfma_f32_32x32x16_bf16 per K step)",
-                "bf16": "gemm_tap_kernel<R,2[,IN16]> + gemm_tap_stream_kernel<2,..> (tap-major gather-GEMM, 1 x v_mfma_f32_32x32x16_bf16 per K step)"}[args.gemm]
+                "bf16": "gemm_tap_kernel<R,2[,IN16]> + gemm_tap_stream_kernel<2,..> + gemm_halo_kernel<R,taps,IN16> (tap-major gather-GEMM / halo-tile implicit GEMM, 1 x v_mfma_f32_32x32x16_bf16 per K step)"}[args.gemm]
     kms, klaunches, cls, ridge, kern = timer.result(peak, PEAK_HBM_GBS)
     # The timed region runs weight-gradient GEMMs on a second stream (ops.GradSink), so a forward-family launch shares the machine
     # with them and its event-timed duration is a CONCURRENT one.  For the kernel's own efficiency, time a few extra steps with
@@ -625,7 +625,7 @@ def main():
     fam = _price(kms, tot_fl, tot_by, klaunches)
     fam_traffic = None
     if pmc:
-        rows = [v for k, v in pmc.items() if k.startswith(("gemm_fwd_kernel", "gemm_tap_kernel", "gemm_tap_stream_kernel"))]
+        rows = [v for k, v in pmc.items() if k.startswith(("gemm_fwd_kernel", "gemm_tap_kernel", "gemm_tap_stream_kernel", "gemm_halo_kernel"))]
         n = sum(v["launches_per_step"] for v in rows)
         if n:
             fam_traffic = round(sum(v["bytes_per_step"] for v in rows) / n)

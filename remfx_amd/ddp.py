@@ -72,15 +72,21 @@ class GradSync:
                 for i in cur_params:
                     self.bucket_of[i] = b
                 hi, cur_params = cur_lo, []
-        # gradients reach the flat buffer two ways: autograd's accumulation (post-accumulate hook, once per parameter and
-        # step) and the gradient sink (ops.GradSink: kernels accumulate in place, once per USE of the parameter).  The first
-        # step only counts the sink's writes per parameter (no early launches); from then on a bucket is complete when every
-        # parameter has been written as often as in that calibration step.
+        # Gradients reach the flat buffer two ways: autograd's accumulation and the gradient sink (ops.GradSink: kernels accumulate in
+        # place, once per USE of the parameter; the backward node then returns None).  The post-accumulate hook of a parameter runs
+        # after ALL of its uses have been back-propagated -- on this torch also when every gradient handed to it was None (sink-only
+        # parameters), which earlier versions did not promise.  So neither signal is trusted alone: the FIRST step only records, per
+        # parameter, how many sink writes it received and whether its hook ran (no early launches, finish() reduces everything); from
+        # then on a parameter is complete when it has been written that often AND (if its hook ran in the calibration step) the hook
+        # has run, and a bucket is reduced as soon as all its parameters are complete.
         self.sink = getattr(flat, "sink", None)
         self.expected = None                        # sink writes per parameter in one step, learned in step 1
+        self.hooked = None                          # did the parameter's post-accumulate hook run in step 1
         self._seen = [0] * len(flat.params)
-        self._counted = [False] * len(flat.params)  # a parameter enters its bucket's `ready` count once per step, whichever route fired
+        self._hook_seen = [False] * len(flat.params)
+        self._counted = [False] * len(flat.params)  # a parameter enters its bucket's `ready` count once per step
         self._late = False                          # a gradient write arrived after its bucket's all-reduce was queued
+        self._late_info = []                        # (route, parameter index, expected sink writes, seen) of those writes, for the error text
         self.measure_stall = False                  # bench.py: time the compute stream's stall on the collectives (exposed_ms)
         if self.overlap:
             for idx, p in enumerate(flat.params):
@@ -88,34 +94,55 @@ class GradSync:
             if self.sink is not None:
                 self.sink.on_write = self._sink_write
 
+    def _precount(self):
+        """Parameters the calibration step never touched (no sink write, no hook: unused in this model's forward) send no signal:
+        they count as complete from the start of the step."""
+        if self.expected is None:
+            return
+        for idx in range(len(self.flat.params)):
+            if self.expected[idx] == 0 and not self.hooked[idx]:
+                self._counted[idx] = True
+                self.buckets[self.bucket_of[idx]]["ready"] += 1
+
+    def _maybe_complete(self, idx):
+        if self.expected is None or self._counted[idx]:
+            return
+        b = self.buckets[self.bucket_of[idx]]
+        if b.get("hold") or self._seen[idx] < self.expected[idx] or (self.hooked[idx] and not self._hook_seen[idx]):
+            return
+        self._counted[idx] = True
+        b["ready"] += 1
+        if b["ready"] == b["n"]:
+            self._launch(b)
+
     def _make_hook(self, idx):
         def hook(_p):
+            self._hook_seen[idx] = True
+            if self.expected is None:
+                return                               # calibration step: finish() launches everything
             b = self.buckets[self.bucket_of[idx]]
-            if b.get("launched"):                    # autograd accumulated into a slice that is already being reduced
+            if b.get("launched"):
+                # a hook that did not run in the calibration step runs behind the queued all-reduce: autograd may have just
+                # accumulated into the slice being reduced
                 self._late = True
+                self._late_info.append(("hook", idx, self.expected[idx], self._seen[idx]))
                 return
-            if self._counted[idx] or b.get("hold"):
-                return
-            if self.expected is not None and self.expected[idx] > self._seen[idx]:
-                return                               # the sink still owes this parameter writes: its last write counts it
-            self._counted[idx] = True
-            b["ready"] += 1
-            if b["ready"] == b["n"]:
-                self._launch(b)
+            self._maybe_complete(idx)
         return hook
 
     def _sink_write(self, idx):
         self._seen[idx] += 1
         if self.expected is None:
-            return                                   # calibration step: finish() launches everything
+            return                                   # calibration step
         b = self.buckets[self.bucket_of[idx]]
         if b.get("launched"):
             # the write lands behind the queued all-reduce and would stay a rank-local addition to the reduced slice
             self._late = True
+            self._late_info.append(("sink", idx, self.expected[idx], self._seen[idx]))
         elif self._seen[idx] > self.expected[idx]:
             b["hold"] = True                         # more writes than the calibration step saw: this bucket waits for finish()
-        elif self._seen[idx] == self.expected[idx]:
-            self._make_hook(idx)(None)
+        else:
+            self._maybe_complete(idx)
 
     def _launch(self, b):
         if b.get("launched"):
@@ -155,19 +182,22 @@ class GradSync:
             b["hold"] = False
         self._counted = [False] * len(self.flat.params)
         late, self._late = self._late, False
-        if self.sink is not None or self.expected is not None:
+        if self.overlap:
             if self.expected is None:
-                self.expected = list(self._seen)
-            elif self._seen != self.expected:        # the graph changed: re-calibrate (one step without early launches)
-                self.expected = None
-            self._seen = [0] * len(self.flat.params)
+                self.expected, self.hooked = list(self._seen), list(self._hook_seen)
+            elif self._seen != self.expected or any(h and not s for h, s in zip(self.hooked, self._hook_seen)):
+                self.expected = self.hooked = None   # the graph changed: re-calibrate (one step without early launches)
+        self._seen = [0] * len(self.flat.params)
+        self._hook_seen = [False] * len(self.flat.params)
+        self._precount()
         if late:
             # A gradient was written into a slice AFTER its all-reduce had been queued (a data-dependent branch used a parameter more
             # often than the calibration step did): that contribution is rank-local, the replicas would silently diverge.  No rank can
             # repair it alone, so the step must not be applied: stop here (the other ranks stop at their next collective).
+            info, self._late_info = self._late_info[:8], []
             raise RuntimeError("GradSync: a parameter gradient was written after its bucket's all-reduce was launched; the reduced "
                                "gradients of this step are inconsistent across ranks (construct GradSync(overlap=False) for models "
-                               "whose parameter use varies from step to step)")
+                               f"whose parameter use varies from step to step).  (route, parameter, expected, seen): {info}")
         return 1.0 / self.world       # fold the mean into the optimiser's gradient scale
 
 

@@ -11,7 +11,7 @@ import sys
 PEAK_HBM = 8.0e12
 
 FAMILIES = [
-    ("gemm forward family", ("gemm_fwd", "gemm_tap", "gemm_thin_fwd")),
+    ("gemm forward family", ("gemm_fwd", "gemm_tap", "gemm_thin_fwd", "gemm_halo")),
     ("gemm weight gradient", ("gemm_wgrad", "gemm_thin_wgrad")),
     ("GroupNorm / BatchNorm", ("gn_", "bn_")),
     ("LSTM recurrence", ("lstm",)),

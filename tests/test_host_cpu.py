@@ -166,7 +166,7 @@ if sync.overlap:
     # back until finish() (correct result); after -> finish() must refuse the step (the extra write is rank-local).
     n = len(flat.params)
     flat.zero_grad()
-    sync.expected, sync._seen = [1] * n, [0] * n
+    sync.expected, sync.hooked, sync._seen = [1] * n, [False] * n, [0] * n
     last = sync.bucket_of[n - 1]
     first_in_last = min(i for i in range(n) if sync.bucket_of[i] == last)
     sync._sink_write(first_in_last); sync._sink_write(first_in_last)        # one write too many, bucket not yet complete
@@ -175,7 +175,7 @@ if sync.overlap:
             sync._sink_write(i)
     assert sync.buckets[last].get("hold") and not sync.buckets[last].get("launched")
     assert sync.finish() == 0.5 and sync.expected is None                   # reduced at finish(), counts re-learned next step
-    sync.expected, sync._seen = [1] * n, [0] * n
+    sync.expected, sync.hooked, sync._seen = [1] * n, [False] * n, [0] * n
     for i in range(n - 1, -1, -1):
         sync._sink_write(i)
     assert all(b.get("launched") for b in sync.buckets)
