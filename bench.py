@@ -220,6 +220,41 @@ def cpu_baseline(workload):
                       f"timed steps ({times[0]:.1f} / {times[1]:.1f} / {times[2]:.1f} s), {cores} torch threads"}
 
 
+def cpu_baseline_chain(labels, order):
+    """CPU oracle timing of the chain (BASELINE config 5), bounded: the detector (oracle Cnn14 on one full clip) and ONE inference
+    forward each of the two removal architectures (oracle Hybrid Demucs / DCUNet, one full clip), combined with the number of removal
+    applications per clip the GPU run's detected labels selected -- the chain's cost on the CPU is that linear combination."""
+    from oracle import ref_cnn14, ref_dcunet, ref_hdemucs
+    phys, cpu_model = _host_cpu()
+    cores = min(phys, 32)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    x = torch.randn(1, 1, CLIP, generator=torch.Generator().manual_seed(0)) * 0.1
+    hd = ref_hdemucs.HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48).eval()
+    du = ref_dcunet.DCUNet(stft_kernel_size=512, fix_length_mode="pad").eval()
+    sd = ref_cnn14.cnn14_init_state_dict()
+
+    def t_of(fn):
+        fn()
+        ts = []
+        for _ in range(2):
+            t0 = time.time(); fn(); ts.append(time.time() - t0)
+        return min(ts)
+    with torch.no_grad():
+        t_d = t_of(lambda: hd(x))
+        t_u = t_of(lambda: du(x.squeeze(1)))
+        t_c = t_of(lambda: ref_cnn14.cnn14_forward(x, sd, SR, 2048, 512, 128))
+    B = labels.shape[0]
+    n_d = float(labels[:, :2].sum()) / B             # distortion, compressor -> Demucs;  reverb, chorus, delay -> DCUNet (cfg/exp/remfx_detect.yaml)
+    n_u = float(labels[:, 2:].sum()) / B
+    per_clip = t_c + n_d * t_d + n_u * t_u
+    return {"value": round(CLIP / SR / per_clip, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "physical_cores": phys,
+            "sample": f"oracle inference forwards on one {CLIP}-sample clip, best of 2 after a warm-up: detector {t_c:.2f} s, Hybrid Demucs "
+                      f"{t_d:.2f} s, DCUNet {t_u:.2f} s; combined with the {n_d:.2f} Demucs + {n_u:.2f} DCUNet applications per clip the GPU "
+                      f"run's labels selected; {cores} torch threads"}
+
+
 def bench_chain(args, rank, world, device):
     """BASELINE config 5: RemFX-detect chain inference (Cnn14 detector + Demucs x2 + DCUNet x3 removal
     networks, cfg/exp/remfx_detect.yaml), inference only, 16 clips per GPU; random-init weights under the
@@ -240,6 +275,9 @@ def bench_chain(args, rank, world, device):
              "RandomPedalboardChorus", "RandomPedalboardDelay"]
     chain = models.RemFXChainInference(nets, SR, 1025, order, classifier=cls).to(device).eval()
     data = synthetic_batch(batch, rank, device)
+    from remfx_amd import ops
+    timer = KernelTimer(ops.PREC_NAMES[args.gemm])
+    timer.install()
 
     def fence():
         if world > 1:
@@ -249,11 +287,13 @@ def bench_chain(args, rank, world, device):
         for i in range(args.warmup):
             chain.test_step(data, i)
         fence()
+        timer.enabled = True
         t0 = time.time()
         for i in range(args.steps):
             chain.test_step(data, i)
         fence()
     dt = time.time() - t0
+    timer.enabled = False
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -261,7 +301,31 @@ def bench_chain(args, rank, world, device):
         return
     dt = float(t)
     napplied = float(chain.last_labels.sum())
-    print(json.dumps({
+    # roofline of the dominant gather-GEMM instantiation of the chain (detector at fp32 parity = bf16x3 inside at_least_fp32_parity,
+    # removal networks in the session mode): algorithmic flops / bytes per launch over its event-timed duration
+    import glob
+    peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[args.gemm]
+    kern = timer.result(peak, PEAK_HBM_GBS)[4]
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_chain_b{batch}_pmc_traffic_{args.gemm}.json")))
+    pmc = {_pmc_key(k): v for k, v in json.load(open(cands[-1]))["kernels"].items()} if cands else {}
+    roof = None
+    if kern:
+        name, (ms, fl, by, n) = max(kern.items(), key=lambda kv: kv[1][0])
+        tf, gb = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        bound = "hbm" if gb / PEAK_HBM_GBS >= tf / peak else "mfma"
+        t_ = pmc.get(_pmc_key(name))
+        roof = {"bound": bound, "kernel": name, "achieved": round(gb if bound == "hbm" else tf, 2),
+                "peak": PEAK_HBM_GBS if bound == "hbm" else round(peak, 1), "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                "frac": round(max(gb / PEAK_HBM_GBS, tf / peak), 4), "frac_mfma": round(tf / peak, 4), "frac_hbm": round(gb / PEAK_HBM_GBS, 4),
+                "traffic": round(t_["bytes_per_step"] / max(t_["launches_per_step"], 1)) if t_ else None,
+                "traffic_source": os.path.basename(cands[-1]) if cands else None,
+                "algorithmic_flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(by / n),
+                "launches_per_step": round(n / args.steps, 2), "avg_launch_us": round(ms / n * 1e3, 2),
+                "ms_per_step": round(ms / args.steps, 3), "share_of_step": round(ms / args.steps / (dt / args.steps * 1e3), 3)}
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline_chain(chain.last_labels.detach().cpu(), order)
+    print(json.dumps({"roofline": roof, "cpu_baseline": cpu,
         "metric": "audio-seconds/sec chain inference (whole job)", "value": round(world * batch * CLIP / SR * args.steps / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
@@ -419,6 +483,7 @@ def main():
     ap.add_argument("--sink", default="side", choices=["side", "main", "off"],
                     help="parameter-gradient sink (ops.GradSink) A/B: side stream (default) / compute stream / autograd accumulation")
     ap.add_argument("--no-halo", action="store_true", help="A/B: stride-1 multi-tap convolutions on the tap-major kernels instead of gemm_halo_kernel (convplan.HALO)")
+    ap.add_argument("--fused-dconv-bwd", action="store_true", help="A/B: the one-launch DConv backward (nnops.DCONV_FUSED_BWD; correct but slower, see nnops.py)")
     ap.add_argument("--no-fused-dconv", action="store_true", help="A/B: layer-by-layer DConv instead of the fused kernels (csrc/dconv.hip)")
     ap.add_argument("--no-enc-z16-time", action="store_true", help="A/B: time-branch encoder conv outputs stored as fp32 (hdemucs.ENC_Z16_TIME)")
     ap.add_argument("--no-enc-z16", action="store_true", help="A/B: encoder conv outputs stored as fp32 (hdemucs.ENC_Z16)")
@@ -449,6 +514,9 @@ def main():
     if args.no_halo:
         from remfx_amd import convplan
         convplan.HALO = False
+    if args.fused_dconv_bwd:
+        from remfx_amd import nnops
+        nnops.DCONV_FUSED_BWD = True
     if args.no_fused_dconv:
         from remfx_amd import nnops
         nnops.DCONV_FUSED = False
@@ -596,10 +664,10 @@ def main():
     # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate counter-only runs, scripts/collect_pmc.py + measure_round.sh), joined per kernel instantiation
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_demucs_b64_pmc_traffic_{args.gemm}.json")))   # latest round / pass last
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_b{batch}_pmc_traffic_{args.gemm}.json")))   # latest round / pass last
     pmc = {}
     pmc_file = None
-    if args.workload == "demucs" and batch == 64 and cands:
+    if cands:
         pmc_file = os.path.basename(cands[-1])
         pmc = {_pmc_key(k): v for k, v in json.load(open(cands[-1]))["kernels"].items()}
     by_kernel = []

@@ -372,6 +372,17 @@ int rfx_dconv_layer_fwd(const float* x, float* out, int32_t N, int32_t C, int32_
                         const float* gn1w, const float* gn1b, const float* w2, const float* b2, const float* gn2w,
                         const float* gn2b, const float* scale, float eps, void* h16, void* z16, float* a_out, float* stats,
                         void* stream);
+/* Backward of the same layer in ONE launch (round 4): recomputes the forward from x, returns gx = dL/dx, the operands of the two
+ * weight-gradient GEMMs -- dz (N, 2C, T) bf16 = gradient of the 1x1 convolution's output, a_out (N, H, T) fp32 = its input,
+ * dh (N, H, T) bf16 = gradient of the 3-tap convolution's output (rfx_gemm_wgrad: dW2 = dz a^T, dW1 = dh * x) -- and `partial`:
+ * rfx_dconv_layer_bwd_rows(N) rows of 5C + 2H floats [dscale C | dgn2w 2C | dgn2b 2C | dgn1w H | dgn1b H] whose column sums are the
+ * LayerScale / GroupNorm gradients (one row per workgroup; the caller adds them up).  Replaces the autograd backward of torchaudio
+ * `_DConv` reached from remfx/models.py:319. */
+int rfx_dconv_layer_bwd_rows(int32_t N);
+int rfx_dconv_layer_bwd(const float* x, const float* g, float* gx, int32_t N, int32_t C, int32_t T, int32_t dil, const float* w1,
+                        const float* b1, const float* gn1w, const float* gn1b, const float* w2, const float* b2, const float* gn2w,
+                        const float* gn2b, const float* scale, float eps, void* dz_bf16, float* a_out, void* dh_bf16, float* partial,
+                        void* stream);
 
 /* Label of the kernel instantiation rfx_gemm_fwd would launch (measurement only; see csrc/gemm.hip). */
 int rfx_gemm_fwd_variant(const rfx_gemm_desc* d, const rfx_epilogue* epi, int32_t two_phase, int32_t prec);

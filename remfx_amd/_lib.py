@@ -149,6 +149,8 @@ SIGNATURES = {
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_dconv_layer_ok": [_I32, _I32, _I32],
+    "rfx_dconv_layer_bwd_rows": [_I32],
+    "rfx_dconv_layer_bwd": [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P],
     "rfx_dconv_layer_fwd": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P],
     "rfx_fx_distortion": [_P, _P, _I32, _I64, _P, _P],
     "rfx_fx_delay": [_P, _P, _I32, _I64, _P, _P, _P, _P],

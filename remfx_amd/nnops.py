@@ -258,10 +258,12 @@ def add(x, y, alpha=1.0):
 
 
 class _DConvLayerFn(torch.autograd.Function):
-    """One depth-layer of the Hybrid Demucs DConv branch, forward in ONE launch (csrc/dconv.hip):
-    x + scale * GLU(GN(conv1x1(GELU(GN(conv3_dilated(x)))))) on (N, 48, 256) samples, bf16 arithmetic.  In training the kernel
-    also stores h / z (bf16), a and the GroupNorm statistics; the backward is the layer-by-layer one on the existing kernels
-    (GroupNorm backward x2, input-gradient GEMM x2, weight-gradient GEMM x2), in the order autograd would run them."""
+    """One depth-layer of the Hybrid Demucs DConv branch, ONE launch per direction (csrc/dconv.hip):
+    x + scale * GLU(GN(conv1x1(GELU(GN(conv3_dilated(x)))))) on (N, 48, 256) samples, bf16 arithmetic.
+    DCONV_FUSED_BWD (round 4): only the layer INPUT is saved; the backward launch recomputes the forward, returns dL/dx and the
+    LayerScale / GroupNorm gradients (per-workgroup partial rows, summed here) and hands dz / a / dh to the two weight-gradient GEMMs.
+    Otherwise (round 3 path, bench.py --no-fused-dconv-bwd): the forward also stores h / z (bf16), a and the GroupNorm statistics and
+    the backward runs layer by layer on the existing kernels (GroupNorm backward x2, input-gradient GEMM x2, weight-gradient GEMM x2)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, dil, eps, grad_on=True):
@@ -271,8 +273,9 @@ class _DConvLayerFn(torch.autograd.Function):
         out = torch.empty_like(x)
         # grad_on: the CALLER's grad mode (inside Function.forward it is always off, and needs_input_grad ignores no_grad)
         need = grad_on and any(ctx.needs_input_grad)
+        fused_bwd = need and DCONV_FUSED_BWD
         h16 = z16 = a_out = stats = None
-        if need:
+        if need and not fused_bwd:
             h16 = torch.empty((N, H, T), device=x.device, dtype=torch.bfloat16)
             z16 = torch.empty((N, 2 * Cc, T), device=x.device, dtype=torch.bfloat16)
             a_out = torch.empty((N, H, T), device=x.device, dtype=torch.float32)
@@ -280,15 +283,20 @@ class _DConvLayerFn(torch.autograd.Function):
         check(_lib.lib().rfx_dconv_layer_fwd(_ptr(x), _ptr(out), N, Cc, T, dil, _ptr(w1), _ptr(b1), _ptr(g1w), _ptr(g1b),
                                              _ptr(w2), _ptr(b2), _ptr(g2w), _ptr(g2b), _ptr(scale), float(eps), _ptr(h16),
                                              _ptr(z16), _ptr(a_out), _ptr(stats), _stream()), "rfx_dconv_layer_fwd")
-        if need:
+        if fused_bwd:
+            ctx.save_for_backward(x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale)
+            ctx.cfg = (dil, float(eps), True)
+        elif need:
             ctx.save_for_backward(x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, h16, z16, a_out, stats)
-            ctx.cfg = (dil,)
+            ctx.cfg = (dil, float(eps), False)
         return out
 
     @staticmethod
     def backward(ctx, gy):
+        dil, eps, fused_bwd = ctx.cfg
+        if fused_bwd:
+            return _DConvLayerFn._backward_fused(ctx, gy, dil, eps)
         x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, h16, z16, a_out, stats = ctx.saved_tensors
-        (dil,) = ctx.cfg
         N, Cc, T = x.shape
         H = Cc // 4
         L = _lib.lib()
@@ -320,7 +328,37 @@ class _DConvLayerFn(torch.autograd.Function):
         dw1 = dw1.view_as(w1) if dw1 is not None else None
         return dx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None, None
 
+    @staticmethod
+    def _backward_fused(ctx, gy, dil, eps):
+        x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale = ctx.saved_tensors
+        N, Cc, T = x.shape
+        H = Cc // 4
+        L = _lib.lib()
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        dz = torch.empty((N, 2 * Cc, T), device=x.device, dtype=torch.bfloat16)
+        a_out = torch.empty((N, H, T), device=x.device, dtype=torch.float32)
+        dh = torch.empty((N, H, T), device=x.device, dtype=torch.bfloat16)
+        partial = torch.empty((L.rfx_dconv_layer_bwd_rows(N), 5 * Cc + 2 * H), device=x.device, dtype=torch.float32)
+        check(L.rfx_dconv_layer_bwd(_ptr(x), _ptr(gy), _ptr(dx), N, Cc, T, dil, _ptr(w1), _ptr(b1), _ptr(g1w), _ptr(g1b), _ptr(w2),
+                                    _ptr(b2), _ptr(g2w), _ptr(g2b), _ptr(scale), eps, _ptr(dz), _ptr(a_out), _ptr(dh), _ptr(partial),
+                                    _stream()), "rfx_dconv_layer_bwd")
+        ps = partial.sum(0)
+        dscale, dg2w, dg2b = ps[:Cc], ps[Cc:3 * Cc], ps[3 * Cc:5 * Cc]
+        dg1w, dg1b = ps[5 * Cc:5 * Cc + H], ps[5 * Cc + H:]
+        # weight / bias gradients of the two convolutions on the existing wgrad kernels (side stream + in place when a GradSink is armed)
+        dw2, db2 = ops.conv2d_wgrad(a_out.unsqueeze(2), dz.unsqueeze(2), (2 * Cc, H, 1, 1), (1, 1), (0, 0), (1, 1), True, w2, b2)
+        dw1, db1 = ops.conv2d_wgrad(x.unsqueeze(2), dh.unsqueeze(2), (H, Cc, 1, 3), (1, 1), (0, dil), (1, dil), True, w1, b1)
+        dw2 = dw2.view_as(w2) if dw2 is not None else None
+        dw1 = dw1.view_as(w1) if dw1 is not None else None
+        return dx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None, None
 
+
+# Round 4 measurement (N = 32768 x (48, 256), two depth layers, scripts/perf_dconv.py): fused forward without the h / z / a stores 2.5 ms
+# (3.9 with them), but the fused backward launch takes 13.7 ms against 3.0 ms for the four kernels it replaces -- 7 ms of that in the
+# LDS float atomics of the parameter-gradient row sums (~100 clocks per ds_add_f32 wave-instruction), the rest in a dependency-bound
+# 16-wave lockstep with 424 bytes of scratch per lane.  Correct (tests/test_gpu_dconv_fused.py runs both), not the default.
+DCONV_FUSED_BWD = False       # bench.py --fused-dconv-bwd switches the one-launch backward on
 DCONV_FUSED = True            # bench.py --no-fused-dconv flips it for A/B runs
 
 

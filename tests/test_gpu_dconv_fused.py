@@ -29,11 +29,16 @@ def _pair(C, seed):
     return ref, net.to(DEV)
 
 
-@pytest.mark.parametrize("N", [5, 300])
-def test_fused_dconv_layer_vs_oracle_and_unfused(N, monkeypatch):
+@pytest.mark.parametrize("fused_bwd", [True, False])
+@pytest.mark.parametrize("N", [5, 300, 1026])
+def test_fused_dconv_layer_vs_oracle_and_unfused(N, fused_bwd, monkeypatch):
+    """fused_bwd: the one-launch backward (dconv_bwd_kernel: forward recomputed, dx + dz / a / dh + parameter-gradient partial rows;
+    N = 5 ends in a half-empty sample pair, 1026 gives the 256 persistent workgroups more than one pair each) or round 3's
+    layer-by-layer backward behind the fused forward."""
     from remfx_amd import nnops, ops
     prev = ops.gemm_precision()
     ops.set_gemm_precision("bf16")
+    monkeypatch.setattr(nnops, "DCONV_FUSED_BWD", fused_bwd)
     try:
         ref, net = _pair(48, 1)
         g = torch.Generator().manual_seed(2)
