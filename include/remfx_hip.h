@@ -151,6 +151,10 @@ int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int
 /* w[m*w_ms + woff[k]] += dapack[m][k]  (dapack is the [M][Kpad] output of rfx_gemm_wgrad). */
 int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
                    int32_t Kpad, float* dw, void* stream);
+/* rfx_unpack_add + the bias gradient in the same launch: db[m] += dapack[m][bias_col] (the constant-one column rfx_gemm_wgrad
+ * appends for plans built with a bias row).  Replaces the separate strided add per biased convolution (128 launches per Demucs step). */
+int rfx_unpack_add_bias(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K, int32_t Kpad, float* dw,
+                        int32_t bias_col, float* db, void* stream);
 /* Same with `=` instead of `+=`: for a plan whose K rows cover every weight element exactly once (a dense
  * convolution's own plan) the caller need not zero-fill dw first. */
 int rfx_unpack_set(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "rfx_gemm_pick_r": [_I32, _I32],
     "rfx_pack_a": [_P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "rfx_unpack_add": [_P, _P, _I64, _I32, _I32, _I32, _P, _P],
+    "rfx_unpack_add_bias": [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P],
     "rfx_unpack_set": [_P, _P, _I64, _I32, _I32, _I32, _P, _P],
     "rfx_gemm_fwd": [C.POINTER(GemmDesc), _P, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _I32, _I32, _P, _I32, _P],
     "rfx_gemm_fwd_variant": [C.POINTER(GemmDesc), C.POINTER(Epilogue), _I32, _I32],

@@ -199,6 +199,7 @@ def _tap_major(self, kt, woff):
 
 
 HALO = True               # bench.py --no-halo / tests switch the halo-tile kernel off (plans built while it is False carry halo_nt = 0)
+HALO_MIN_POSITIONS = 1 << 19
 HALO_TW = 128             # output positions per workgroup of gemm_halo_kernel (csrc/gemm_halo.h: RFX_HALO_TW)
 
 
@@ -211,6 +212,10 @@ def _halo_geometry(self, taps, nt, gb):
     if not HALO or nt not in (3, 9) or gb < 2 or gb % 2 or self.SA != 1 or self.SB != 1 or int(self.in_bs) != 1:
         return
     if self.OB % HALO_TW or self.Kpad_t != 8 * self.ntaps * self.gpt:
+        return
+    # few positions, many output channels (the deep layers: 64 x 128 ... 64 x 4096 positions): every 128-position workgroup re-reads
+    # its whole A chunk and the tap-major kernel is as fast or faster (scripts/perf_halo.py: 0.43 vs 0.47 ms at 1536 -> 3072 x 128)
+    if self.N * self.OA * self.OB < HALO_MIN_POSITIONS:
         return
     da, db = taps[:, 1], taps[:, 2]
     if not np.array_equal(taps[:, 0], da * int(self.in_as) + db * int(self.in_bs)):

@@ -3,11 +3,13 @@
 
 template <bool ADD>
 __global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_t* __restrict__ woff,
-                                  int64_t w_ms, int M, int K, int Kpad, float* __restrict__ dw) {
+                                  int64_t w_ms, int M, int K, int Kpad, float* __restrict__ dw,
+                                  int bias_col = -1, float* __restrict__ db = nullptr) {
   const int64_t total = (int64_t)K * M;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / K), k = (int)(i % K);
+    if (db && k == 0) db[m] += dapack[(int64_t)m * Kpad + bias_col];      // the bias-gradient column of the same matrix, one thread per row
     // distinct (k, m) map to distinct weight elements within one descriptor, but
     // several descriptors (stride phases) may run back to back on the stream.
     if (ADD) dw[(int64_t)m * w_ms + woff[k]] += dapack[(int64_t)m * Kpad + k];
@@ -183,6 +185,16 @@ static int unpack_launch(bool add, const float* dapack, const int32_t* woff, int
 extern "C" int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
                               int32_t K, int32_t Kpad, float* dw, void* stream) {
   return unpack_launch(true, dapack, woff, w_ms, M, K, Kpad, dw, stream);
+}
+extern "C" int rfx_unpack_add_bias(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K, int32_t Kpad,
+                                   float* dw, int32_t bias_col, float* db, void* stream) {
+  if (!dapack || !woff || !dw || !db || M <= 0 || K <= 0 || Kpad < K || bias_col < 0 || bias_col >= Kpad) return -1;
+  const int64_t total = (int64_t)K * M;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(unpack_add_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff, w_ms, M, K, Kpad, dw,
+                     bias_col, db);
+  RFX_CHECK_LAUNCH();
+  return 0;
 }
 extern "C" int rfx_unpack_set(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
                               int32_t K, int32_t Kpad, float* dw, void* stream) {

@@ -144,6 +144,18 @@ __device__ __forceinline__ void lstm_fetch_lds(const uint64_t* src, int n, int l
                                      16 /* sc1: agent scope */);
 }
 
+// the hi halves only (LO = false kernels: the lo fragments are neither stored nor read): chunk 2 ks lands where loadB expects it
+__device__ __forceinline__ void lstm_fetch_lds_hi(const uint64_t* src, int nks, int lane) {
+  for (int ks = 0; ks < nks; ++ks)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (2 * ks * 64 + lane) * 2),
+                                     (__attribute__((address_space(3))) void*)(lstm_smem + ks * 2048), 16, 0,
+                                     16 /* sc1: agent scope */);
+}
+__device__ __forceinline__ void lstm_xch_store_hi(uint64_t* phi, float v0, float v1, float v2, float v3) {
+  const uint64_t hi = (uint64_t)rfx_cvt_pk_bf16(v0, v1) | ((uint64_t)rfx_cvt_pk_bf16(v2, v3) << 32);
+  __hip_atomic_store(phi, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Forward exchange (h_t as MFMA B fragments): u64 index ((ks*2 + part)*64 + L)*2 + half; L = (sequence, hhB) is the
 // lane that consumes k = 16ks + 8hhB + 4half + e (e = 0..3, 16 bits each).  The producing lane (sequence l31, hh)
 // holds units du = (r&3) + 8(r>>2) + 4hh, i.e. for r = 8*ksl + 4*hhB + e: k-step 2ub+ksl, lane l31+32hhB, half hh.
@@ -233,7 +245,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
     if (s > 0) {
       if (!lstm_wait(ctr, (uint32_t)(nwc * s))) { *a.err = 1; return; }
-      lstm_fetch_lds(xch + ((s - 1) & 1) * bufw, 2 * nks, lane);
+      if (LO) lstm_fetch_lds(xch + ((s - 1) & 1) * bufw, 2 * nks, lane);
+      else lstm_fetch_lds_hi(xch + ((s - 1) & 1) * bufw, nks, lane);          // half the exchange volume in the bf16 mode
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): visible to the compiler's wait-count bookkeeping, unlike inline asm
     }
     {
@@ -284,7 +297,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int hb2 = 0; hb2 < 2; ++hb2) {
           const int r0 = 8 * ksl + 4 * hb2;
           uint64_t* d = hw + (((2 * ub + ksl) * 2) * 64 + l31 + 32 * hb2) * 2 + hh;
-          lstm_xch_store(d, d + 128, hv[r0], hv[r0 + 1], hv[r0 + 2], hv[r0 + 3]);
+          if (LO) lstm_xch_store(d, d + 128, hv[r0], hv[r0 + 1], hv[r0 + 2], hv[r0 + 3]);
+          else lstm_xch_store_hi(d, hv[r0], hv[r0 + 1], hv[r0 + 2], hv[r0 + 3]);
         }
       lstm_arrive(ctr, lane);
     }

@@ -124,6 +124,10 @@ class _LSTMLayerFn(torch.autograd.Function):
                 dp, xs, gs = _whh_plan(out4, dG, H, d, Bn)
                 dap = ops.zeros((dp.p.M, dp.p.Kpad), g.device)
                 ops.gemm_wgrad(dp, xs, gs, dap)
+                if sunk:                     # straight into the parameter's slice of the flat gradient buffer (no temporary, no add)
+                    ops.unpack_add(dp, dap, tg[1 + 4 * d][1])
+                    dwhh.append(None)
+                    continue
                 dw = ops.zeros((4 * H, H), g.device)
                 ops.unpack_add(dp, dap, dw)
                 dwhh.append(dw)
@@ -131,7 +135,8 @@ class _LSTMLayerFn(torch.autograd.Function):
             grads = (dwcat[:4 * H], dwhh[0], db0, db0, dwcat[4 * H:], dwhh[1], db1, db1)
             if sunk:
                 for (i, view), gr in zip(tg, grads):
-                    view.add_(gr.reshape(-1))
+                    if gr is not None:
+                        view.add_(gr.reshape(-1))
         if sunk:
             for i, _ in tg:
                 sink.wrote(i)

@@ -415,9 +415,11 @@ def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias, w=None, b=N
         with torch.cuda.stream(sink.stream_for_wgrad(x, g)):
             dapack = zeros((p.M, p.Kpad), x.device)
             gemm_wgrad(dp, x, g, dapack)
-            unpack_add(dp, dapack, tw[1])                      # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
-            if need_bias:
-                tb[1].add_(dapack[:, p.K - 1])
+            if need_bias:       # weight + bias gradient out of the same matrix in one launch
+                check(_lib.lib().rfx_unpack_add_bias(_ptr(dapack), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"], p.Kpad,
+                                                     _ptr(tw[1]), p.K - 1, _ptr(tb[1]), _stream()), "rfx_unpack_add_bias")
+            else:
+                unpack_add(dp, dapack, tw[1])                  # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
         sink.wrote(tw[0])
         if need_bias:
             sink.wrote(tb[0])

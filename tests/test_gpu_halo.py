@@ -35,11 +35,12 @@ def _variant(dp, x, out, prec=2):
 @pytest.fixture
 def bf16_mode():
     from remfx_amd import convplan, ops
-    prev, prev_halo = ops.gemm_precision(), convplan.HALO
+    prev, prev_halo, prev_min = ops.gemm_precision(), convplan.HALO, convplan.HALO_MIN_POSITIONS
     ops.set_gemm_precision("bf16")
+    convplan.HALO_MIN_POSITIONS = 0                 # the test shapes are small: lift the planner's "large layers only" rule
     ops._PLANS.clear()
     yield
-    convplan.HALO = prev_halo
+    convplan.HALO, convplan.HALO_MIN_POSITIONS = prev_halo, prev_min
     ops._PLANS.clear()
     ops.set_gemm_precision(prev)
 
