@@ -39,7 +39,9 @@ __device__ __forceinline__ void split_hi_lo(float v, unsigned short& hi, unsigne
   lo = (unsigned short)((__float_as_uint(r) + 0x8000u) >> 16);
 }
 
-// fwdA[ub][g][ks][lane]: W_hh[g*H + 32ub + (lane&31)][16ks + 8(lane>>5) + q], q = 0..7   (hi array, then lo array)
+// fwdA[ub16][tl][ks][lane]: W_hh[(2tl + (m>>4))*H + 16ub16 + (m&15)][16ks + 8(lane>>5) + q], m = lane&31, q = 0..7 (hi array, then lo):
+//   a forward wave owns 16 hidden units; its two 32-row MFMA tiles are (i | f) and (g | o) of those units, so that the four gates
+//   of one (unit, sequence) meet in one lane (accumulator registers r and r + 8 of the two tiles)
 // bwdA[ub][ks][lane]   : W_hh[16ks + 8(lane>>5) + q][32ub + (lane&31)]
 __global__ void lstm_pack_kernel(const float* __restrict__ whh, int H, uint4* __restrict__ fwdA, uint4* __restrict__ bwdA) {
   const int nub = H / 32, nks = H / 16, nks4 = 4 * H / 16;
@@ -54,8 +56,8 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh, int H, uint4* __
     for (int q = 0; q < 8; ++q) {
       float v;
       if (f) {
-        const int ks = (int)(r % nks), g = (int)((r / nks) % 4), ub = (int)(r / (4 * nks));
-        v = whh[(int64_t)(g * H + 32 * ub + (lane & 31)) * H + 16 * ks + 8 * (lane >> 5) + q];
+        const int ks = (int)(r % nks), tl = (int)((r / nks) % 2), ub = (int)(r / (2 * nks)), m = lane & 31;
+        v = whh[(int64_t)((2 * tl + (m >> 4)) * H + 16 * ub + (m & 15)) * H + 16 * ks + 8 * (lane >> 5) + q];
       } else {
         const int ks = (int)(r % nks4), ub = (int)(r / nks4);
         v = whh[(int64_t)(16 * ks + 8 * (lane >> 5) + q) * H + 32 * ub + (lane & 31)];
@@ -122,8 +124,8 @@ __device__ __forceinline__ void lstm_xch_store(uint64_t* phi, uint64_t* plo, flo
 }
 
 // workgroup id -> (cluster, unit block): ids congruent mod 8 share an XCD under round-robin dispatch
-__device__ __forceinline__ bool lstm_ids(const LstmArgs& a, int& cluster, int& ub) {
-  const int nwc = a.H / 32, w = blockIdx.x, j = w >> 3;
+__device__ __forceinline__ bool lstm_ids(const LstmArgs& a, int nwc, int& cluster, int& ub) {
+  const int w = blockIdx.x, j = w >> 3;
   cluster = (j / nwc) * 8 + (w & 7);
   ub = j % nwc;
   return cluster < a.nclusters;
@@ -132,7 +134,7 @@ __device__ __forceinline__ bool lstm_ids(const LstmArgs& a, int& cluster, int& u
 typedef uint32_t lstm_u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) lstm_u32x4* lstm_gptr_t;     // explicit global address space
 
-struct LstmAFrag { uint4 h[4], l[4]; };
+struct LstmAFrag { uint4 h[2], l[2]; };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
 
@@ -157,30 +159,32 @@ __device__ __forceinline__ void lstm_xch_store_hi(uint64_t* phi, float v0, float
 }
 
 // Forward exchange (h_t as MFMA B fragments): u64 index ((ks*2 + part)*64 + L)*2 + half; L = (sequence, hhB) is the
-// lane that consumes k = 16ks + 8hhB + 4half + e (e = 0..3, 16 bits each).  The producing lane (sequence l31, hh)
-// holds units du = (r&3) + 8(r>>2) + 4hh, i.e. for r = 8*ksl + 4*hhB + e: k-step 2ub+ksl, lane l31+32hhB, half hh.
-// D = depth of the weight-fragment ring in k-steps (each k-step = 4 gates x (hi, lo) = 8 KB per wave): the L2 round trip
-// (~0.5 us) is covered only if ~4 k-steps (0.64 us of MFMA work) are in flight; D = 2 when H is not a multiple of 64.
+// lane that consumes k = 16ks + 8hhB + 4half + e (e = 0..3, 16 bits each).  A forward wave owns the 16 units of ONE k-step (ks = its
+// unit block ub): its lane (sequence l31, hh) holds units du = (r&3) + 8(r>>2) + 4hh for r = 0..7, i.e. for r = 4*hhB + e: lane
+// l31+32hhB, half hh.  (16 units per wave, not 32: the cell update -- 5 quarter-rate transcendentals per (unit, sequence) -- was
+// 1.9 us of a 5 us step on the one wave a SIMD runs; the machine has 1024 such slots and a layer fills < 100 of them.)
+// D = depth of the weight-fragment ring in k-steps (each k-step = 2 tiles x (hi, lo) = 4 KB per wave): the L2 round trip
+// (~0.5 us) is covered only if several k-steps are in flight; D == NKS: the wave's whole W_hh slice stays in registers.
 // NKS = H/16 at compile time (0 = runtime trip count).  With a runtime k loop hipcc drains vmcnt(0) at the loop header
-// (55 instead of 32 cycles per MFMA, in-kernel s_memtime stamps).  Fully unrolled, its wait counts are exact (24-32 loads
-// stay in flight) -- provided the fragment base pointer is made opaque once per time step (otherwise ~100 hoisted
+// (55 instead of 32 cycles per MFMA, in-kernel s_memtime stamps).  Fully unrolled, its wait counts are exact
+// -- provided the fragment base pointer is made opaque once per time step (otherwise ~100 hoisted
 // addresses spill) and keeps its global address space (a laundered generic pointer turns every load into flat_load).
 // LO = true: bf16x3 split products (hi.hi + hi.lo + lo.hi); false: bf16 operands only (the bf16-mixed mode: a third of the
 // MFMA chain and half of the weight stream per step).
 template <int D, int NKS, bool LO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_kernel(const LstmArgs a) {
   int cluster, ub;
-  if (!lstm_ids(a, cluster, ub)) return;
+  if (!lstm_ids(a, a.H / 16, cluster, ub)) return;
   const int H = a.H, Bn = a.Bn, T = a.T, P = a.P;
   const int dir = cluster & 1, row0 = (a.tile0 + (cluster >> 1)) * 32;
   const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
-  const int nks = NKS ? NKS : H / 16, nwc = nks / 2;
+  const int nks = NKS ? NKS : H / 16, nwc = nks;                       // waves per cluster = unit blocks of 16
   const int row = row0 + l31;
   const bool rvalid = row < Bn;
   const int rowc = rvalid ? row : 0;      // idle lanes read sequence 0 and never store: every load stays unconditional
   const float* __restrict__ xp = a.xp + (int64_t)dir * 4 * H * P;
-  const int nf = nwc * 4 * nks * 64;
-  uint64_t abase = (uint64_t)(a.packA + (int64_t)dir * a.pack_stride + ub * 4 * nks * 64);   // wave-uniform
+  const int nf = nwc * 2 * nks * 64;
+  uint64_t abase = (uint64_t)(a.packA + (int64_t)dir * a.pack_stride + ub * 2 * nks * 64);   // wave-uniform
   lstm_gptr_t Ahi = (lstm_gptr_t)abase;
   lstm_gptr_t Alo = Ahi + nf;
   float* outp = a.out + (int64_t)dir * H * P;
@@ -190,49 +194,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   uint64_t* xch = a.xch + (int64_t)cluster * 2 * bufw;
   uint32_t* ctr = a.ctr + cluster * 16;
   const uint32_t uP = (uint32_t)P, HP = (uint32_t)H * uP;
-  const uint32_t ubase = (uint32_t)(32 * ub + 4 * hh) * uP + (uint32_t)rowc;   // + ((r&3) + 8(r>>2)) * P + t*Bn
+  const uint32_t ubase = (uint32_t)(16 * ub + 4 * hh) * uP + (uint32_t)rowc;   // + ((r&3) + 8(r>>2)) * P + t*Bn, r < 8
   const uint32_t lane16 = (uint32_t)lane * 16u;
   auto loadA = [&](LstmAFrag& f, int ks) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int tl = 0; tl < 2; ++tl) {
       // wave-uniform base + zero-extended lane offset -> scalar-base addressing (no per-fragment 64-bit VGPR address)
-      f.h[g] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Ahi + (g * nks + ks) * 64) + lane16));
-      if (LO) f.l[g] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Alo + (g * nks + ks) * 64) + lane16));
+      f.h[tl] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Ahi + (tl * nks + ks) * 64) + lane16));
+      if (LO) f.l[tl] = __builtin_bit_cast(uint4, *(lstm_gptr_t)((uint64_t)(Alo + (tl * nks + ks) * 64) + lane16));
     }
   };
   auto loadB = [&](bf16x8& bh, bf16x8& bl, int ks) {
     bh = *reinterpret_cast<const bf16x8*>(lstm_smem + ks * 2048 + lane * 16);
     if (LO) bl = *reinterpret_cast<const bf16x8*>(lstm_smem + ks * 2048 + 1024 + lane * 16);
   };
-  // the four gate accumulators are independent: issue them round-robin so no MFMA waits on its predecessor
+  // the two tile accumulators are independent: alternate them so that no MFMA waits on its predecessor
   auto mma = [&](f32x16* acc, const LstmAFrag& f, const bf16x8 bh, const bf16x8 bl) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[g]), bh, acc[g], 0, 0, 0);
+    for (int tl = 0; tl < 2; ++tl)
+      acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[tl]), bh, acc[tl], 0, 0, 0);
     if (LO) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[g]), bl, acc[g], 0, 0, 0);
+      for (int tl = 0; tl < 2; ++tl)
+        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.h[tl]), bl, acc[tl], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.l[g]), bh, acc[g], 0, 0, 0);
+      for (int tl = 0; tl < 2; ++tl)
+        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.l[tl]), bh, acc[tl], 0, 0, 0);
     }
   };
-  float c[16];
+  float c[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) c[r] = 0.f;
-  f32x16 acc[4];
+  for (int r = 0; r < 8; ++r) c[r] = 0.f;
+  f32x16 acc[2];
   LstmAFrag f[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) loadA(f[d], d);
   // xpv = this step's input projections, fetched one step ahead so that HBM latency hides behind the MFMA chain
-  float xpv[4][16], xpn[4][16];
+  float xpv[4][8], xpn[4][8];
   {
     const uint32_t o0 = ubase + (uint32_t)((dir == 0 ? 0 : T - 1) * Bn);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xpv[g][r] = xp[o0 + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
+      for (int r = 0; r < 8; ++r) xpv[g][r] = xp[o0 + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
   }
   for (int s = 0; s < T; ++s) {
     if (NKS) { asm volatile("" : "+s"(abase)); Ahi = (lstm_gptr_t)abase; Alo = Ahi + nf; }   // opaque base, see above
@@ -240,9 +244,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int t = dir == 0 ? s : T - 1 - s;
     const uint32_t o0 = ubase + (uint32_t)(t * Bn);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
     if (s > 0) {
       if (!lstm_wait(ctr, (uint32_t)(nwc * s))) { *a.err = 1; return; }
       if (LO) lstm_fetch_lds(xch + ((s - 1) & 1) * bufw, 2 * nks, lane);
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xpn[g][r] = xp[on + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
+        for (int r = 0; r < 8; ++r) xpn[g][r] = xp[on + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
     }
     if (s > 0) {
       bf16x8 bh[2], bl[2];
@@ -281,34 +285,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
     }
     uint64_t* hw = xch + (s & 1) * bufw;
-    float hv[16];
+    float hv[8], gi[8], gf[8], gc[8], go[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float ig = lstm_sigmoid(acc[0][r] + xpv[0][r]), fg = lstm_sigmoid(acc[1][r] + xpv[1][r]);
-      const float gg = lstm_tanh(acc[2][r] + xpv[2][r]), og = lstm_sigmoid(acc[3][r] + xpv[3][r]);
+    for (int r = 0; r < 8; ++r) {
+      const float ig = lstm_sigmoid(acc[0][r] + xpv[0][r]), fg = lstm_sigmoid(acc[0][r + 8] + xpv[1][r]);
+      const float gg = lstm_tanh(acc[1][r] + xpv[2][r]), og = lstm_sigmoid(acc[1][r + 8] + xpv[3][r]);
       c[r] = fg * c[r] + ig * gg;
       hv[r] = og * lstm_tanh(c[r]);
-      acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og;
+      gi[r] = ig; gf[r] = fg; gc[r] = gg; go[r] = og;
     }
     if (s + 1 < T) {                  // publish h_t first: it is the cluster's critical path
 #pragma unroll
-      for (int ksl = 0; ksl < 2; ++ksl)
-#pragma unroll
-        for (int hb2 = 0; hb2 < 2; ++hb2) {
-          const int r0 = 8 * ksl + 4 * hb2;
-          uint64_t* d = hw + (((2 * ub + ksl) * 2) * 64 + l31 + 32 * hb2) * 2 + hh;
-          if (LO) lstm_xch_store(d, d + 128, hv[r0], hv[r0 + 1], hv[r0 + 2], hv[r0 + 3]);
-          else lstm_xch_store_hi(d, hv[r0], hv[r0 + 1], hv[r0 + 2], hv[r0 + 3]);
-        }
+      for (int hb2 = 0; hb2 < 2; ++hb2) {
+        const int r0 = 4 * hb2;
+        uint64_t* d = hw + ((ub * 2) * 64 + l31 + 32 * hb2) * 2 + hh;
+        if (LO) lstm_xch_store(d, d + 128, hv[r0], hv[r0 + 1], hv[r0 + 2], hv[r0 + 3]);
+        else lstm_xch_store_hi(d, hv[r0], hv[r0 + 1], hv[r0 + 2], hv[r0 + 3]);
+      }
       lstm_arrive(ctr, lane);
     }
     if (rvalid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         const uint32_t o = o0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
         outp[o] = hv[r];
         if (gsave) {
-          gsave[o] = acc[0][r]; gsave[o + HP] = acc[1][r]; gsave[o + 2 * HP] = acc[2][r]; gsave[o + 3 * HP] = acc[3][r];
+          gsave[o] = gi[r]; gsave[o + HP] = gf[r]; gsave[o + 2 * HP] = gc[r]; gsave[o + 3 * HP] = go[r];
           csave[o] = c[r];
         }
       }
@@ -316,58 +318,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xpv[g][r] = xpn[g][r];
+      for (int r = 0; r < 8; ++r) xpv[g][r] = xpn[g][r];
   }
 }
 
-// Backward through time.  A wave multiplies ITS gate-gradient slice (K = 4 x 32 rows of W_hh) into partial
-// dh_{t-1} for ALL hidden units and publishes the fp32 partial tiles; the owner of a unit block sums the H/32
-// partials.  Exchange (per ping-pong buffer): [consumer unit block][producer][quad j][lane][4 floats], i.e. the
-// consumer's slice is H/32 x 4 KB, contiguous, fetched straight into LDS.
-// TPC = unit-block tiles per ring refill round: the weight ring holds 8*TPC k-step fragments (hi, lo); 16 in flight
-// cover the L2 round trip (3 MFMAs per fragment), so TPC = 2 whenever H/32 is even.
-template <int TPC, int NWC, bool LO>        // NWC = H/32 at compile time (0 = runtime), as NKS in the forward kernel; LO as there
+// Backward through time.  A wave owns 16 hidden units (as in the forward sweep): it multiplies ITS gate-gradient slice
+// (K = 4 gates x 16 rows of W_hh) into partial dh_{t-1} for ALL hidden units and publishes the fp32 partial tiles; the owner of
+// a unit block sums the H/16 partials.  Exchange (per ping-pong buffer): [consumer unit block][producer][quad jj][lane][4 floats]
+// -- a 32-unit MFMA tile's accumulator quads j = 0, 1 are its first 16 units, j = 2, 3 the second 16 -- i.e. the consumer's
+// slice is H/16 x 2 KB, contiguous, fetched straight into LDS.
+// TPC = output tiles per round (independent accumulators); RES: the wave's whole W_hh^T slice (4 fragments per output tile) stays
+// in registers; otherwise a ring of 4*TPC fragments is refilled behind its MFMAs.
+template <int TPC, int NWC, bool LO, bool RES>   // NWC = H/32 at compile time (0 = runtime), as NKS in the forward kernel; LO as there
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(const LstmArgs a) {
+  static_assert(!RES || NWC > 0, "resident weights need the compile-time tile count");
   int cluster, ub;
-  if (!lstm_ids(a, cluster, ub)) return;
+  if (!lstm_ids(a, a.H / 16, cluster, ub)) return;
   const int H = a.H, Bn = a.Bn, T = a.T, P = a.P;
   const int dir = cluster & 1, row0 = (a.tile0 + (cluster >> 1)) * 32;
   const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
-  const int nwc = H / 32, nks = 2 * nwc, nks4 = 4 * nks;
+  const int nwc = NWC ? NWC : H / 32, nwv = 2 * nwc, nks = nwv, nks4 = 4 * nks;    // output tiles, waves per cluster, k-steps
   const int row = row0 + l31;
   const bool rvalid = row < Bn;
   const int rowc = rvalid ? row : 0;
   const int nf = nwc * 4 * nks * 64, nb = nwc * nks4 * 64;
-  // bwdA[ot][ks'][lane]: tile ot = output unit block, ks' = gate-row k-step; this wave's rows: g*nks + 2ub + {0,1}
-  uint64_t abase = (uint64_t)(a.packA + (int64_t)dir * a.pack_stride + 2 * nf + 2 * ub * 64);   // wave-uniform
+  // bwdA[ot][ks'][lane]: tile ot = output unit block of 32, ks' = gate-row k-step; this wave's rows: g*nks + ub
+  uint64_t abase = (uint64_t)(a.packA + (int64_t)dir * a.pack_stride + 2 * nf + ub * 64);   // wave-uniform
   lstm_gptr_t Ahi = (lstm_gptr_t)abase;
   lstm_gptr_t Alo = Ahi + nb;
   const float* __restrict__ gates = a.gates + (int64_t)dir * 4 * H * P;
   const float* __restrict__ cst = a.cstate + (int64_t)dir * H * P;
   float* __restrict__ dG = a.dG + (int64_t)dir * 4 * H * P;
   const float* __restrict__ goutp = a.gout + (int64_t)dir * H * P;
-  const int bufw = nwc * nwc * 512;                                  // u64 per ping-pong buffer
+  const int bufw = nwv * nwv * 256;                                  // u64 per ping-pong buffer
   uint64_t* xch = a.xch + (int64_t)cluster * 2 * bufw;
   uint32_t* ctr = a.ctr + cluster * 16;
   const uint32_t uP = (uint32_t)P, HP = (uint32_t)H * uP;
-  const uint32_t ubase = (uint32_t)(32 * ub + 4 * hh) * uP + (uint32_t)rowc;
-  constexpr int RING = 8 * TPC;
-  const int F = 8 * nwc;                                             // fragments per time step, F % RING == 0
-  auto frag_index = [&](int fi) { const int ot = fi >> 3, kk = fi & 7; return (ot * nks4 + (kk >> 1) * nks + (kk & 1)) * 64 + lane; };
-  uint4 wh[RING], wl[RING];
+  const uint32_t ubase = (uint32_t)(16 * ub + 4 * hh) * uP + (uint32_t)rowc;
+  constexpr int RING = RES ? 4 * NWC : 4 * TPC;
+  const int F = 4 * nwc;                                             // fragments per time step, F % RING == 0
+  auto frag_index = [&](int fi) { const int ot = fi >> 2, g = fi & 3; return (ot * nks4 + g * nks) * 64 + lane; };
+  uint4 wh[RING], wl[LO ? RING : 1];
 #pragma unroll
   for (int i = 0; i < RING; ++i) {
     wh[i] = __builtin_bit_cast(uint4, Ahi[frag_index(i)]);
-    wl[i] = __builtin_bit_cast(uint4, Alo[frag_index(i)]);
+    if (LO) wl[i] = __builtin_bit_cast(uint4, Alo[frag_index(i)]);
   }
-  float dcc[16], ct[16];
-  float sg[4][16], cp[16], gy[16];            // this step's saved gates / c_{prev} / incoming gradient
-  float ng[4][16], ncp[16], ngy[16];          // next step's, fetched one step ahead
+  float dcc[8], ct[8];
+  float sg[4][8], cp[8], gy[8];            // this step's saved gates / c_{prev} / incoming gradient
+  float ng[4][8], ncp[8], ngy[8];          // next step's, fetched one step ahead
   {
     const uint32_t o0 = ubase + (uint32_t)((dir == 0 ? T - 1 : 0) * Bn);
     const uint32_t op0 = ubase + (uint32_t)((T > 1 ? (dir == 0 ? T - 2 : 1) : (dir == 0 ? T - 1 : 0)) * Bn);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 8; ++r) {
       const uint32_t du = (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
       dcc[r] = 0.f;
       ct[r] = cst[o0 + du];
@@ -377,13 +381,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
   }
   for (int s = T - 1; s >= 0; --s) {            // reverse of the forward processing order
-    if (NWC) { asm volatile("" : "+s"(abase)); Ahi = (lstm_gptr_t)abase; Alo = Ahi + nb; }   // opaque base (see the forward kernel)
+    if (NWC && !RES) { asm volatile("" : "+s"(abase)); Ahi = (lstm_gptr_t)abase; Alo = Ahi + nb; }   // opaque base (see the forward kernel)
     const int step = T - 1 - s;                 // exchange generation
     const int t = dir == 0 ? s : T - 1 - s;
     const uint32_t o0 = ubase + (uint32_t)(t * Bn);
     if (step > 0) {
-      if (!lstm_wait(ctr, (uint32_t)(nwc * step))) { *a.err = 1; return; }
-      lstm_fetch_lds(xch + ((step - 1) & 1) * bufw + ub * nwc * 512, 4 * nwc, lane);
+      if (!lstm_wait(ctr, (uint32_t)(nwv * step))) { *a.err = 1; return; }
+      lstm_fetch_lds(xch + ((step - 1) & 1) * bufw + ub * nwv * 256, 2 * nwv, lane);
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): visible to the compiler's wait-count bookkeeping, unlike inline asm
     }
     {
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       const uint32_t on = ubase + (uint32_t)((dir == 0 ? s1 : T - 1 - s1) * Bn);
       const uint32_t opn = ubase + (uint32_t)((dir == 0 ? s2 : T - 1 - s2) * Bn);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         const uint32_t du = (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
         ng[0][r] = gates[on + du]; ng[1][r] = gates[on + du + HP]; ng[2][r] = gates[on + du + 2 * HP]; ng[3][r] = gates[on + du + 3 * HP];
         ncp[r] = cst[opn + du];
@@ -400,15 +404,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
     }
     if (step > 0) {
-      for (int p = 0; p < nwc; ++p)
+      for (int p = 0; p < nwv; ++p)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(lstm_smem + (p * 4 + j) * 1024 + lane * 16);
-          gy[4 * j] += v[0]; gy[4 * j + 1] += v[1]; gy[4 * j + 2] += v[2]; gy[4 * j + 3] += v[3];
+        for (int jj = 0; jj < 2; ++jj) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(lstm_smem + (p * 2 + jj) * 1024 + lane * 16);
+          gy[4 * jj] += v[0]; gy[4 * jj + 1] += v[1]; gy[4 * jj + 2] += v[2]; gy[4 * jj + 3] += v[3];
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 8; ++r) {
       const float ig = sg[0][r], fg = sg[1][r], gg = sg[2][r], og = sg[3][r];
       const float cprev = s > 0 ? cp[r] : 0.f;
       const float th = lstm_tanh(ct[r]);
@@ -421,32 +425,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       ct[r] = cp[r];
     }
     if (s > 0) {
-      // own gate gradients as MFMA B fragments: lane (seq, hhB) needs units 16ksl + 8hhB + q; q < 4 live in the
+      // own gate gradients as MFMA B fragments: lane (seq, hhB) needs units 8hhB + q; q < 4 live in the
       // hh = 0 lane, q >= 4 in the hh = 1 lane of the same sequence -> one cross-half exchange per packed pair
-      uint4 bh[8], bl[8];                                   // index kk = 2g + ksl
+      uint4 bh[4], bl[LO ? 4 : 1];                           // index g
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g) {
+        uint32_t x0h[2], x0l[2], x1h[2], x1l[2];             // packed bf16 pairs of X0 = r 0..3, X1 = r 4..7
 #pragma unroll
-        for (int ksl = 0; ksl < 2; ++ksl) {
-          uint32_t x0h[2], x0l[2], x1h[2], x1l[2];         // packed bf16 pairs of X0 = r 8ksl+0..3, X1 = r 8ksl+4..7
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < 2; ++e) {
+          if (LO) {
             unsigned short h0, l0, h1, l1;
-            split_hi_lo(sg[g][8 * ksl + 2 * e], h0, l0); split_hi_lo(sg[g][8 * ksl + 2 * e + 1], h1, l1);
+            split_hi_lo(sg[g][2 * e], h0, l0); split_hi_lo(sg[g][2 * e + 1], h1, l1);
             x0h[e] = (uint32_t)h0 | ((uint32_t)h1 << 16); x0l[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
-            split_hi_lo(sg[g][8 * ksl + 4 + 2 * e], h0, l0); split_hi_lo(sg[g][8 * ksl + 4 + 2 * e + 1], h1, l1);
+            split_hi_lo(sg[g][4 + 2 * e], h0, l0); split_hi_lo(sg[g][4 + 2 * e + 1], h1, l1);
             x1h[e] = (uint32_t)h0 | ((uint32_t)h1 << 16); x1l[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+          } else {
+            x0h[e] = rfx_cvt_pk_bf16(sg[g][2 * e], sg[g][2 * e + 1]);
+            x1h[e] = rfx_cvt_pk_bf16(sg[g][4 + 2 * e], sg[g][4 + 2 * e + 1]);
+            x0l[e] = x1l[e] = 0;
           }
-          uint32_t rh[2], rl[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            rh[e] = (uint32_t)__shfl_xor((int)(hh ? x0h[e] : x1h[e]), 32, 64);
-            rl[e] = (uint32_t)__shfl_xor((int)(hh ? x0l[e] : x1l[e]), 32, 64);
-          }
-          bh[2 * g + ksl] = hh ? make_uint4(rh[0], rh[1], x1h[0], x1h[1]) : make_uint4(x0h[0], x0h[1], rh[0], rh[1]);
-          bl[2 * g + ksl] = hh ? make_uint4(rl[0], rl[1], x1l[0], x1l[1]) : make_uint4(x0l[0], x0l[1], rl[0], rl[1]);
         }
-      uint64_t* gw = xch + (step & 1) * bufw + ub * 512;            // + ot * nwc * 512 (consumer ot, producer ub)
+        uint32_t rh[2], rl[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          rh[e] = (uint32_t)__shfl_xor((int)(hh ? x0h[e] : x1h[e]), 32, 64);
+          if (LO) rl[e] = (uint32_t)__shfl_xor((int)(hh ? x0l[e] : x1l[e]), 32, 64);
+        }
+        bh[g] = hh ? make_uint4(rh[0], rh[1], x1h[0], x1h[1]) : make_uint4(x0h[0], x0h[1], rh[0], rh[1]);
+        if (LO) bl[g] = hh ? make_uint4(rl[0], rl[1], x1l[0], x1l[1]) : make_uint4(x0l[0], x0l[1], rl[0], rl[1]);
+      }
+      uint64_t* gw = xch + (step & 1) * bufw;
       auto round = [&](int f0) {
         f32x16 acc[TPC];
 #pragma unroll
@@ -455,58 +463,62 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
         // the TPC tiles of a round are independent accumulators: interleave them term by term
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[kk]), Bl = __builtin_bit_cast(bf16x8, bl[kk]);
+        for (int g = 0; g < 4; ++g) {
+          const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[g]), Bl = __builtin_bit_cast(bf16x8, bl[LO ? g : 0]);
 #pragma unroll
           for (int tp = 0; tp < TPC; ++tp)
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[tp * 8 + kk]), Bh, acc[tp], 0, 0, 0);
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[(RES ? f0 : 0) + tp * 4 + g]), Bh, acc[tp], 0, 0, 0);
           if (LO) {
 #pragma unroll
             for (int tp = 0; tp < TPC; ++tp)
-              acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[tp * 8 + kk]), Bl, acc[tp], 0, 0, 0);
+              acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[(RES ? f0 : 0) + tp * 4 + g]), Bl, acc[tp], 0, 0, 0);
 #pragma unroll
             for (int tp = 0; tp < TPC; ++tp)
-              acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl[tp * 8 + kk]), Bh, acc[tp], 0, 0, 0);
+              acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl[LO ? (RES ? f0 : 0) + tp * 4 + g : 0]), Bh, acc[tp], 0, 0, 0);
           }
+          if (!RES) {
 #pragma unroll
-          for (int tp = 0; tp < TPC; ++tp) {
-            const int i = tp * 8 + kk;
-            int fn = f0 + i + RING;                                 // the slot's next occupant (wraps into the next step)
-            fn = fn >= F ? fn - F : fn;
-            wh[i] = __builtin_bit_cast(uint4, Ahi[frag_index(fn)]);
-            if (LO) wl[i] = __builtin_bit_cast(uint4, Alo[frag_index(fn)]);
+            for (int tp = 0; tp < TPC; ++tp) {
+              const int i = tp * 4 + g;
+              int fn = f0 + i + RING;                                 // the slot's next occupant (wraps into the next step)
+              fn = fn >= F ? fn - F : fn;
+              wh[i] = __builtin_bit_cast(uint4, Ahi[frag_index(fn)]);
+              if (LO) wl[LO ? i : 0] = __builtin_bit_cast(uint4, Alo[frag_index(fn)]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int tp = 0; tp < TPC; ++tp) {
-          uint64_t* d = gw + (int64_t)((f0 >> 3) + tp) * nwc * 512 + lane * 2;
+          const int ot = (f0 >> 2) + tp;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
+            // quads 0, 1 -> consumer 2 ot (its units 0..15 of the tile), quads 2, 3 -> consumer 2 ot + 1
+            uint64_t* d = gw + (int64_t)(((2 * ot + (j >> 1)) * nwv + ub) * 2 + (j & 1)) * 128 + lane * 2;
             const uint64_t v0 = (uint64_t)__float_as_uint(acc[tp][4 * j]) | ((uint64_t)__float_as_uint(acc[tp][4 * j + 1]) << 32);
             const uint64_t v1 = (uint64_t)__float_as_uint(acc[tp][4 * j + 2]) | ((uint64_t)__float_as_uint(acc[tp][4 * j + 3]) << 32);
-            __hip_atomic_store(d + j * 128, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(d + j * 128 + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       };
       if (NWC) {
 #pragma unroll
-        for (int f0 = 0; f0 < 8 * NWC; f0 += RING) round(f0);
+        for (int f0 = 0; f0 < 4 * NWC; f0 += 4 * TPC) round(f0);
       } else {
-        for (int f0 = 0; f0 < F; f0 += RING) round(f0);
+        for (int f0 = 0; f0 < F; f0 += 4 * TPC) round(f0);
       }
       lstm_arrive(ctr, lane);
     }
     if (rvalid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         const uint32_t o = o0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
         dG[o] = sg[0][r]; dG[o + HP] = sg[1][r]; dG[o + 2 * HP] = sg[2][r]; dG[o + 3 * HP] = sg[3][r];
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 8; ++r) {
       sg[0][r] = ng[0][r]; sg[1][r] = ng[1][r]; sg[2][r] = ng[2][r]; sg[3][r] = ng[3][r];
       cp[r] = ncp[r]; gy[r] = ngy[r];
     }
@@ -519,23 +531,6 @@ static int64_t lstm_pack_uint4_per_dir(int H) {
 }
 static bool lstm_bad_h(int H) { return H <= 0 || H % 32 || H > 512; }
 static size_t lstm_smem_bytes(int H) { return (size_t)(H / 32) * 4096; }   // fwd: 2*nks KB, bwd: 4*nwc KB (equal)
-// co-residency bound: every wave of a launch must be on the machine at once (they wait for each other)
-static int lstm_max_clusters(int H) {
-  static int cached[17] = {0};
-  const int nwc = H / 32;
-  if (cached[nwc]) return cached[nwc];
-  int dev = 0, ncu = 0, occ_f = 0, occ_b = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_fwd_kernel<4, 0, true>, 64, lstm_smem_bytes(H)) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bwd_kernel<2, 0, true>, 64, lstm_smem_bytes(H)) != hipSuccess)
-    return 0;
-  const int occ = occ_f < occ_b ? occ_f : occ_b;
-  int waves = ncu * occ;
-  if (waves > RFX_LSTM_MAX_WAVES) waves = RFX_LSTM_MAX_WAVES;
-  cached[nwc] = (waves / nwc) & ~7;
-  return cached[nwc];
-}
 // workspace: [0,256) error flag | counters (64 B per cluster) | exchange buffers sized for the backward sweep
 static int64_t lstm_ws_ctr_off() { return 256; }
 static int64_t lstm_ws_xch_off(int H) { return 256 + (int64_t)(RFX_LSTM_MAX_WAVES / (H / 32)) * 64; }
@@ -562,31 +557,35 @@ extern "C" int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stre
   return 0;
 }
 
+// co-residency bound: every wave of a launch must be on the machine at once (they wait for each other).  The bound is taken for
+// THE instantiation being launched (the register-resident forms use more VGPRs than the generic ones); a launch that cannot be
+// co-resident is refused, not attempted.  wpc = waves per cluster (forward: H/16, backward: H/32).
 template <typename K>
-static int lstm_launch(K kernel, LstmArgs a, void* ws, void* stream) {
-  const int H = a.H, nwc = H / 32, ntiles = (a.Bn + 31) / 32;
-  int mc = lstm_max_clusters(H);
-  // the waves of a launch wait for each other: the bound must hold for THIS instantiation (the register-resident forms use more
-  // VGPRs than the generic kernels lstm_max_clusters asks about); a launch that cannot be co-resident is refused, not attempted
+static int lstm_launch(K kernel, LstmArgs a, int wpc, void* ws, void* stream) {
+  const int H = a.H, ntiles = (a.Bn + 31) / 32;
+  int mc = 0;
   {
-    static thread_local const void* seen[16];
-    static thread_local int seen_mc[16], seen_h[16];
+    static thread_local const void* seen[24];
+    static thread_local int seen_mc[24], seen_h[24];
     static thread_local int nseen = 0;
     int i = 0;
     for (; i < nseen; ++i) if (seen[i] == reinterpret_cast<const void*>(kernel) && seen_h[i] == H) break;
-    if (i == nseen && nseen < 16) {
+    if (i == nseen) {
+      if (nseen == 24) nseen = 0;
       int dev = 0, ncu = 0, occ = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 64, lstm_smem_bytes(H)) != hipSuccess) return -3;
       int waves = ncu * occ;
       if (waves > RFX_LSTM_MAX_WAVES) waves = RFX_LSTM_MAX_WAVES;
-      seen[nseen] = reinterpret_cast<const void*>(kernel);
-      seen_h[nseen] = H;
-      seen_mc[nseen] = (waves / nwc) & ~7;
-      ++nseen;
+      i = nseen++;
+      seen[i] = reinterpret_cast<const void*>(kernel);
+      seen_h[i] = H;
+      seen_mc[i] = (waves / wpc) & ~7;
     }
-    if (i < nseen && seen_mc[i] < mc) mc = seen_mc[i];
+    mc = seen_mc[i];
   }
+  const int mc_ws = RFX_LSTM_MAX_WAVES / (H / 32);       // clusters the workspace (counters, exchange buffers) is laid out for
+  if (mc > mc_ws) mc = mc_ws & ~7;
   if (mc < 8) return -4;
   const size_t smem = lstm_smem_bytes(H);
   unsigned char* w = reinterpret_cast<unsigned char*>(ws);
@@ -599,7 +598,7 @@ static int lstm_launch(K kernel, LstmArgs a, void* ws, void* stream) {
     a.tile0 = t0;
     a.nclusters = 2 * nt;
     if (hipMemsetAsync(a.ctr, 0, (size_t)mc * 64, s) != hipSuccess) return -3;
-    const int blocks = ((a.nclusters + 7) / 8) * 8 * nwc;
+    const int blocks = ((a.nclusters + 7) / 8) * 8 * wpc;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), smem, s, a);
     RFX_CHECK_LAUNCH();
   }
@@ -614,19 +613,20 @@ extern "C" int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_
   LstmArgs a{};
   a.xp = xp; a.packA = reinterpret_cast<const uint4*>(pack); a.out = out; a.gates = gates; a.cstate = cstate;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
+  const int wf = H / 16;
   if (prec == RFX_PREC_BF16) {                 // bf16 operands (bf16-mixed): no lo fragments
-    // H = 192: the wave's whole W_hh slice (48 fragments = 192 VGPRs) stays in registers instead of being re-streamed through L1
-    // every time step
-    if (H == 192) return lstm_launch(lstm_fwd_kernel<12, 12, false>, a, ws, stream);
-    if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16, false>, a, ws, stream);
-    if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24, false>, a, ws, stream);
-    return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0, false>, a, ws, stream)
-                       : lstm_launch(lstm_fwd_kernel<2, 0, false>, a, ws, stream);
+    // the wave's whole W_hh slice (2 tiles x H/16 k-steps: 96 VGPRs at H = 192, 192 at H = 384) stays in registers instead of being
+    // re-streamed through L1 every time step
+    if (H == 192) return lstm_launch(lstm_fwd_kernel<12, 12, false>, a, wf, ws, stream);
+    if (H == 256) return lstm_launch(lstm_fwd_kernel<16, 16, false>, a, wf, ws, stream);
+    if (H == 384) return lstm_launch(lstm_fwd_kernel<24, 24, false>, a, wf, ws, stream);
+    return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0, false>, a, wf, ws, stream)
+                       : lstm_launch(lstm_fwd_kernel<2, 0, false>, a, wf, ws, stream);
   }
-  if (H == 192) return lstm_launch(lstm_fwd_kernel<4, 12, true>, a, ws, stream);     // HDemucs DConv widths and Open-Unmix: unrolled k loop
-  if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16, true>, a, ws, stream);
-  if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24, true>, a, ws, stream);
-  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0, true>, a, ws, stream) : lstm_launch(lstm_fwd_kernel<2, 0, true>, a, ws, stream);
+  if (H == 192) return lstm_launch(lstm_fwd_kernel<12, 12, true>, a, wf, ws, stream);    // hi + lo fragments: 192 VGPRs
+  if (H == 256) return lstm_launch(lstm_fwd_kernel<4, 16, true>, a, wf, ws, stream);     // HDemucs DConv widths and Open-Unmix: unrolled k loop
+  if (H == 384) return lstm_launch(lstm_fwd_kernel<4, 24, true>, a, wf, ws, stream);
+  return H % 64 == 0 ? lstm_launch(lstm_fwd_kernel<4, 0, true>, a, wf, ws, stream) : lstm_launch(lstm_fwd_kernel<2, 0, true>, a, wf, ws, stream);
 }
 
 extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
@@ -637,13 +637,16 @@ extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* ga
   a.gout = gout; a.packA = reinterpret_cast<const uint4*>(pack); a.gates = const_cast<float*>(gates);
   a.cstate = const_cast<float*>(cstate); a.dG = dG;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
-  // (the unrolled NWC forms of the backward kernel spill at 512 registers: only the runtime form is instantiated)
+  const int wb = H / 16;
   if (prec == RFX_PREC_BF16) {
-    // single-fragment products halve the weight ring: the unrolled forms (exact wait counts instead of a vmcnt(0) drain at the loop
-    // header) fit the register file here for H = 192 (H = 384 still spills 364 B: runtime loop)
-    if (H == 192) return lstm_launch(lstm_bwd_kernel<2, 6, false>, a, ws, stream);
-    return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, false>, a, ws, stream)
-                             : lstm_launch(lstm_bwd_kernel<1, 0, false>, a, ws, stream);
+    // single-fragment products: the wave's W_hh^T slice (4 fragments per output tile: 96 VGPRs at H = 192, 192 at H = 384) is resident
+    if (H == 192) return lstm_launch(lstm_bwd_kernel<3, 6, false, true>, a, wb, ws, stream);
+    if (H == 256) return lstm_launch(lstm_bwd_kernel<4, 8, false, true>, a, wb, ws, stream);
+    if (H == 384) return lstm_launch(lstm_bwd_kernel<4, 12, false, true>, a, wb, ws, stream);
+    return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, false, false>, a, wb, ws, stream)
+                             : lstm_launch(lstm_bwd_kernel<1, 0, false, false>, a, wb, ws, stream);
   }
-  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, true>, a, ws, stream) : lstm_launch(lstm_bwd_kernel<1, 0, true>, a, ws, stream);
+  if (H == 192) return lstm_launch(lstm_bwd_kernel<3, 6, true, true>, a, wb, ws, stream);      // hi + lo resident: 192 VGPRs
+  return (H / 32) % 2 == 0 ? lstm_launch(lstm_bwd_kernel<2, 0, true, false>, a, wb, ws, stream)
+                           : lstm_launch(lstm_bwd_kernel<1, 0, true, false>, a, wb, ws, stream);
 }
