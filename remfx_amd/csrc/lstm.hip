@@ -6,14 +6,14 @@
 // Everything around the recurrence is a plain gather-GEMM on channel-major tensors (1, C, T*Bn):
 // input projections xp = W_ih x + b, and after the backward sweep dX, dW_ih, dW_hh, db.
 // The sweep itself is a *wave cluster*:
-//   * a cluster = (tile of 32 sequences, direction); it has H/32 single-wave workgroups, each owning 32 hidden
-//     units (all four gates).  Every step a wave needs its slice of W_hh (4*32*H weights) and the whole h_{t-1};
-//     one CU's vector L1 fills at 64 B/clk, so spreading a cluster's weight stream over H/32 CUs is what makes
-//     a step cost ~ the MFMA chain instead of ~ |W_hh| / 64 B/clk (measured: 30 us -> see DESIGN.md);
+//   * a cluster = (tile of 32 sequences, direction); it has H/16 single-wave workgroups, each owning 16 hidden
+//     units (all four gates).  Every step a wave needs its slice of W_hh (4*16*H weights) and the whole h_{t-1};
+//     one CU's vector L1 fills at 64 B/clk, so spreading a cluster's weights over H/16 CUs (register-resident in the
+//     bf16 mode) is what makes a step cost ~ the exchange instead of ~ |W_hh| / 64 B/clk (measured: 30 us -> see DESIGN.md);
 //   * gates^T[4H x 32] = xp[t] + W_hh[4H x H] . h^T[H x 32] on v_mfma_f32_32x32x16_bf16 with the
 //     bf16x3 split (hi.hi + hi.lo + lo.hi, fp32 accumulate); MFMA rows = gate units, columns =
 //     sequences, so every global access is coalesced along the sequence axis of the channel-major
-//     tensors and a lane owns (16 units x 1 sequence) of all four gates -> the cell update is local;
+//     tensors and a lane owns (8 units x 1 sequence) of all four gates -> the cell update is local;
 //   * h_t (resp. the gate gradients in the backward sweep) is exchanged between the waves of a cluster through a
 //     ping-pong buffer in global memory that is already in MFMA B-fragment order (bf16 hi / lo), written and
 //     read with agent-scope atomic 8-byte accesses, plus one arrival counter per cluster;
@@ -229,8 +229,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   LstmAFrag f[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) loadA(f[d], d);
-  // xpv = this step's input projections, fetched one step ahead so that HBM latency hides behind the MFMA chain
-  float xpv[4][8], xpn[4][8];
+  // xpv = this step's input projections: fetched at the END of the previous step (after the publish), so that the loads and their
+  // address arithmetic run while h_t is in flight instead of between the fetch and the MFMA chain
+  float xpv[4][8];
   {
     const uint32_t o0 = ubase + (uint32_t)((dir == 0 ? 0 : T - 1) * Bn);
 #pragma unroll
@@ -252,14 +253,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       if (LO) lstm_fetch_lds(xch + ((s - 1) & 1) * bufw, 2 * nks, lane);
       else lstm_fetch_lds_hi(xch + ((s - 1) & 1) * bufw, nks, lane);          // half the exchange volume in the bf16 mode
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): visible to the compiler's wait-count bookkeeping, unlike inline asm
-    }
-    {
-      const int tn = s + 1 < T ? (dir == 0 ? s + 1 : T - 2 - s) : t;     // clamped on the last step (harmless re-read)
-      const uint32_t on = ubase + (uint32_t)(tn * Bn);
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) xpn[g][r] = xp[on + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
     }
     if (s > 0) {
       bf16x8 bh[2], bl[2];
@@ -315,10 +308,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
       }
     }
+    if (s + 1 < T) {
+      const uint32_t on = ubase + (uint32_t)((dir == 0 ? s + 1 : T - 2 - s) * Bn);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 8; ++r) xpv[g][r] = xpn[g][r];
+        for (int r = 0; r < 8; ++r) xpv[g][r] = xp[on + (uint32_t)g * HP + (uint32_t)((r & 3) + 8 * (r >> 2)) * uP];
+    }
   }
 }
 
@@ -365,8 +361,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (LO) wl[i] = __builtin_bit_cast(uint4, Alo[frag_index(i)]);
   }
   float dcc[8], ct[8];
-  float sg[4][8], cp[8], gy[8];            // this step's saved gates / c_{prev} / incoming gradient
-  float ng[4][8], ncp[8], ngy[8];          // next step's, fetched one step ahead
+  float sg[4][8], cp[8], gy[8];            // this step's saved gates / c_{prev} / incoming gradient: fetched at the end of the previous step
   {
     const uint32_t o0 = ubase + (uint32_t)((dir == 0 ? T - 1 : 0) * Bn);
     const uint32_t op0 = ubase + (uint32_t)((T > 1 ? (dir == 0 ? T - 2 : 1) : (dir == 0 ? T - 1 : 0)) * Bn);
@@ -389,19 +384,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       if (!lstm_wait(ctr, (uint32_t)(nwv * step))) { *a.err = 1; return; }
       lstm_fetch_lds(xch + ((step - 1) & 1) * bufw + ub * nwv * 256, 2 * nwv, lane);
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): visible to the compiler's wait-count bookkeeping, unlike inline asm
-    }
-    {
-      // next step (s-1): its time index and the one before it in forward order (clamped at the sequence start)
-      const int s1 = s > 0 ? s - 1 : 0, s2 = s1 > 0 ? s1 - 1 : 0;
-      const uint32_t on = ubase + (uint32_t)((dir == 0 ? s1 : T - 1 - s1) * Bn);
-      const uint32_t opn = ubase + (uint32_t)((dir == 0 ? s2 : T - 1 - s2) * Bn);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const uint32_t du = (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
-        ng[0][r] = gates[on + du]; ng[1][r] = gates[on + du + HP]; ng[2][r] = gates[on + du + 2 * HP]; ng[3][r] = gates[on + du + 3 * HP];
-        ncp[r] = cst[opn + du];
-        ngy[r] = goutp[on + du];
-      }
     }
     if (step > 0) {
       for (int p = 0; p < nwv; ++p)
@@ -517,10 +499,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         dG[o] = sg[0][r]; dG[o + HP] = sg[1][r]; dG[o + 2 * HP] = sg[2][r]; dG[o + 3 * HP] = sg[3][r];
       }
     }
+    if (s > 0) {
+      // next step (s-1): its time index and the one before it in forward order (clamped at the sequence start); issued behind the
+      // publish so that the loads and their address arithmetic run while the partial tiles are in flight
+      const int s1 = s - 1, s2 = s1 > 0 ? s1 - 1 : 0;
+      const uint32_t on = ubase + (uint32_t)((dir == 0 ? s1 : T - 1 - s1) * Bn);
+      const uint32_t opn = ubase + (uint32_t)((dir == 0 ? s2 : T - 1 - s2) * Bn);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      sg[0][r] = ng[0][r]; sg[1][r] = ng[1][r]; sg[2][r] = ng[2][r]; sg[3][r] = ng[3][r];
-      cp[r] = ncp[r]; gy[r] = ngy[r];
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t du = (uint32_t)((r & 3) + 8 * (r >> 2)) * uP;
+        sg[0][r] = gates[on + du]; sg[1][r] = gates[on + du + HP]; sg[2][r] = gates[on + du + 2 * HP]; sg[3][r] = gates[on + du + 3 * HP];
+        cp[r] = cst[opn + du];
+        gy[r] = goutp[on + du];
+      }
     }
   }
 }
