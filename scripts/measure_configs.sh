@@ -34,5 +34,6 @@ done
 python bench.py --workload tcn --steps 2 --warmup 2 2>> $OUT/cfg.err | tail -1 > $OUT/bench_tcn_bf16x3.json
 python bench.py --workload dcunet 2>> $OUT/cfg.err | tail -1 > $OUT/bench_dcunet_bf16x3.json
 python bench.py --workload chain 2>> $OUT/cfg.err | tail -1 > $OUT/bench_chain_bf16x3.json
+python bench.py --workload umx 2>> $OUT/cfg.err | tail -1 > $OUT/bench_umx_bf16x3.json
 python bench.py --workload demucs --batch 8 --steps 20 --warmup 5 --no-also 2>> $OUT/cfg.err | tail -1 > $OUT/bench_demucs_bf16_b8.json
 grep -ho '"ms_per_step": [0-9.]*' $OUT/bench_tcn_bf16x3.json $OUT/bench_dcunet_bf16x3.json $OUT/bench_chain_bf16x3.json $OUT/bench_demucs_bf16_b8.json | tr '\n' ' '

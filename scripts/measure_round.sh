@@ -24,7 +24,5 @@ python bench.py --steps 20 --warmup 5 --gemm $MODE > $OUT/bench_demucs_$MODE.jso
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also --sink main --gemm $MODE 2>> $OUT/bench_demucs_$MODE.err | tail -1 > $OUT/bench_demucs_${MODE}_sinkmain.json
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also --sink off --no-fused-dconv --gemm $MODE 2>> $OUT/bench_demucs_$MODE.err | tail -1 > $OUT/bench_demucs_${MODE}_r02path.json
 python bench.py --workload demucs_fwd --gemm $MODE > $OUT/bench_demucs_fwd_$MODE.json 2>> $OUT/bench_demucs_$MODE.err
-for w in tcn dcunet umx chain; do     # their BASELINE configs are fp32: default arithmetic = fp32 parity (bf16x3)
-  python bench.py --workload $w --no-cpu-baseline 2>> $OUT/bench_demucs_$MODE.err | tail -1 > $OUT/bench_${w}_bf16x3.json
-done
+# (TCN / DCUNet / Open-Unmix / chain / the 8-clip batch: scripts/measure_configs.sh, with their own kernel stats, PMC passes and cpu_baseline)
 grep -ho '"ms_per_step": [0-9.]*' $OUT/bench_*_$MODE.json | tr '\n' ' '
