@@ -37,6 +37,8 @@ def broadcast_parameters(flat_data, src=0):
     """Replicas start from rank 0's weights (and buffers passed in as extra tensors)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(flat_data, src)
+        from . import ops
+        ops.weights_changed()
 
 
 def broadcast_buffers(module, src=0):

@@ -250,6 +250,56 @@ def pack_a(dp, w):
     return apack
 
 
+# ---- packed weights, cached ----------------------------------------------------------
+# A layer's packed A matrix changes only when its weights do, yet it used to be rebuilt by every call (218 pack launches + the torch
+# reshapes of the merged / interleaved forms per Demucs step).  An entry is valid while (a) the tensor it was packed from is held
+# alive HERE (a strong reference: its storage cannot be freed and re-used under the same address), (b) torch's version counter of
+# that storage is unchanged (every in-place torch op, load_state_dict, optimiser of torch.optim bumps it) and (c) no NATIVE writer
+# has touched the weights since (FlatAdamW's kernel and the parameter broadcast write through raw pointers: they call
+# weights_changed()).  Entries are per plan, arithmetic mode and stream; the cache is bounded by bytes (oldest entries go first).
+PACK_CACHE = _os.environ.get("RFX_PACK_CACHE", "1") != "0"
+PACK_CACHE_BYTES = 6 << 30
+_PACKS = {}
+_PACKS_BYTES = [0]
+_WEIGHT_EPOCH = [0]
+
+
+def weights_changed():
+    """A native kernel wrote parameters in place (no torch version bump): every cached pack is stale."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def pack_cached(dp, src, derive=None, tag=0):
+    """Packed A of plan dp for the weight tensor src; derive(src) -> the tensor rfx_pack_a gathers from (default: src.contiguous())."""
+    if PACK_CACHE:
+        try:
+            ver = src._version
+        except RuntimeError:                       # inference tensors carry no version counter: no caching
+            ver = None
+        if ver is not None:
+            key = (id(dp), src.data_ptr(), tuple(src.stride()), tag, dp.fwd_prec(), torch.cuda.current_stream().cuda_stream)
+            e = _PACKS.get(key)
+            if e is not None and e[1] is dp and e[2] == ver and e[3] == _WEIGHT_EPOCH[0]:
+                return e[4]
+            apack = pack_a(dp, derive(src) if derive is not None else src.contiguous())
+            nbytes = apack.numel() * 4 + src.numel() * src.element_size()
+            if e is not None:
+                _PACKS_BYTES[0] -= e[5]
+                del _PACKS[key]                    # re-insert at the young end
+            _PACKS[key] = (src, dp, ver, _WEIGHT_EPOCH[0], apack, nbytes)
+            _PACKS_BYTES[0] += nbytes
+            while _PACKS_BYTES[0] > PACK_CACHE_BYTES and len(_PACKS) > 1:
+                k0 = next(iter(_PACKS))
+                _PACKS_BYTES[0] -= _PACKS.pop(k0)[5]
+            return apack
+    return pack_a(dp, derive(src) if derive is not None else src.contiguous())
+
+
+def clear_pack_cache():
+    _PACKS.clear()
+    _PACKS_BYTES[0] = 0
+
+
 def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, act2=None,
              dp2=None, apack2=None, in2=None, bwd=False, gparam=None, stat_sums=None, glu_out=None):
     e = Epilogue()
@@ -341,8 +391,7 @@ def conv2d_forward(x, w, bias, stride, padding, dilation, act=None, act_param=No
     key = _key("cf", x.shape, x.stride(), w.shape, stride, padding, dilation, out.stride())
     dp = _plans(key, x.device, lambda: convplan.conv_fwd_plan(
         tuple(x.shape), x.stride(), tuple(w.shape), stride, padding, dilation, out.stride()))
-    wc = w.contiguous()
-    gemm_fwd(dp, pack_a(dp, wc), x, out, bias=bias, act=act, act_param=act_param, stat_sums=stat_sums)
+    gemm_fwd(dp, pack_cached(dp, w), x, out, bias=bias, act=act, act_param=act_param, stat_sums=stat_sums)
     return out
 
 
@@ -367,11 +416,16 @@ def _merged_weight(w_oik, ax, S):
     return (wm.unsqueeze(3) if ax == 0 else wm.unsqueeze(2)).contiguous(), J
 
 
-def _merged_launch(inp, wm, ax, S, J, off, out, bias=None, res=None):
-    key = _key("mg", inp.shape, inp.stride(), wm.shape, ax, S, off, out.shape, out.stride())
+def _merged_launch(inp, w_oik, ax, S, off, out, bias=None, res=None, w_src=None, tag=0):
+    """w_oik: the (O, I, KA, KB) correlation weight (possibly a transposed view); w_src: the tensor the pack cache watches."""
+    O, I = w_oik.shape[:2]
+    J = w_oik.shape[2 + ax] // S
+    wm_shape = (O * S, I, J, 1) if ax == 0 else (O * S, I, 1, J)
+    key = _key("mg", inp.shape, inp.stride(), wm_shape, ax, S, off, out.shape, out.stride())
     dp = _plans(key, inp.device, lambda: convplan.merged_phase_plan(
-        tuple(inp.shape), inp.stride(), wm.shape[0], ax, S, J, off, out.shape[2 + ax], out.stride()))
-    gemm_fwd(dp, pack_a(dp, wm), inp, out, bias=bias, res=res)
+        tuple(inp.shape), inp.stride(), wm_shape[0], ax, S, J, off, out.shape[2 + ax], out.stride()))
+    apack = pack_cached(dp, w_src if w_src is not None else w_oik, derive=lambda _t: _merged_weight(w_oik, ax, S)[0], tag=tag)
+    gemm_fwd(dp, apack, inp, out, bias=bias, res=res)
     return out
 
 
@@ -383,20 +437,18 @@ def conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx=None, res
     ax = _merge_axis(w.shape[2:], stride, padding, dilation)
     if ax is not None and w.shape[1] * stride[ax] >= 4:
         # dx[ci][o] = sum g[co][i] w[co][ci][kk], o = S*i + kk - P: all S phases of o as rows (ci, q) of one GEMM over g
-        wm, J = _merged_weight(w.transpose(0, 1), ax, stride[ax])
         # the residual (skip-connection gradient) rides in the merged-phase store: stride 4 along a unit-stride axis makes a
         # lane's four phases one 16-byte run, so the residual is ONE 16-byte load per lane and channel (round 1 measured the
         # strided 4-byte form as a loss and kept the torch add instead)
         # (time branch); along the frequency axis the four phases are four rows and the residual loads coalesce across lanes
-        return _merged_launch(g, wm, ax, stride[ax], J, -padding[ax], dx, res=res)
+        return _merged_launch(g, w.transpose(0, 1), ax, stride[ax], -padding[ax], dx, res=res, w_src=w, tag=1)
     if res is not None and tuple(stride) != (1, 1):       # per-phase plans: add afterwards
         return conv2d_dgrad(g, w, xshape, xstrides, stride, padding, dilation, dx).add_(res)
     key = _key("cd", xshape, xstrides, w.shape, stride, padding, dilation, g.shape, g.stride())
     dps = _plans(key, g.device, lambda: convplan.conv_dgrad_plans(
         tuple(xshape), tuple(xstrides), tuple(w.shape), stride, padding, dilation, tuple(g.shape), g.stride()))
-    wc = w.contiguous()
     for dp in dps:
-        gemm_fwd(dp, pack_a(dp, wc), g, dx, res=res)
+        gemm_fwd(dp, pack_cached(dp, w), g, dx, res=res)
     return dx
 
 
@@ -503,8 +555,9 @@ class ConvGlu2dFn(torch.autograd.Function):
         # (which round to bf16 anyway): keep both in 16 bits -- what torch autocast stores for a conv output
         if bf16_storage() and dp.tap and C2 >= 16 and Cin > 8 and (Ch * OA * OB) % 4 == 0:
             y2 = torch.empty((N, C2, OA, OB), device=x.device, dtype=torch.bfloat16)
-        wi = w.view(2, Ch, Cin, KA, KB).transpose(0, 1).reshape(C2, Cin, KA, KB)     # rows (c, half)
-        gemm_fwd(dp, pack_a(dp, wi), x, y2, bias=bias, glu_out=out)
+        apack = pack_cached(dp, w, tag=2,                                            # rows (c, half)
+                            derive=lambda t: t.reshape(2, Ch, Cin, KA, KB).transpose(0, 1).reshape(C2, Cin, KA, KB))
+        gemm_fwd(dp, apack, x, y2, bias=bias, glu_out=out)
         ctx.save_for_backward(x, w, y2)
         ctx.bias = bias
         ctx.cfg = (stride, padding, dilation, bias is not None)
@@ -574,14 +627,12 @@ def convT2d_forward(x, w, bias, stride, dilation, crop_lo, out_len, act=None):
     if (ax is not None and act is None and Cout * stride[ax] >= 4 and crop_lo[1 - ax] == 0
             and out_len[1 - ax] == x.shape[3 - ax]):
         # y[co][o] = sum x[ci][i] w[ci][co][kk], o = S*i + kk: the S phases of o as rows (co, q) of one GEMM over x
-        wm, J = _merged_weight(w.transpose(0, 1), ax, stride[ax])
-        return _merged_launch(x, wm, ax, stride[ax], J, -crop_lo[ax], out, bias=bias)
+        return _merged_launch(x, w.transpose(0, 1), ax, stride[ax], -crop_lo[ax], out, bias=bias, w_src=w, tag=3)
     key = _key("tf", x.shape, x.stride(), w.shape, stride, dilation, crop_lo, out_len, out.stride())
     dps = _plans(key, x.device, lambda: convplan.convT_fwd_plans(
         tuple(x.shape), x.stride(), tuple(w.shape), stride, dilation, crop_lo, out_len, out.stride()))
-    wc = w.contiguous()
     for dp in dps:
-        gemm_fwd(dp, pack_a(dp, wc), x, out, bias=bias, act=act)
+        gemm_fwd(dp, pack_cached(dp, w), x, out, bias=bias, act=act)
     return out
 
 
@@ -607,10 +658,9 @@ class ConvT2dFn(torch.autograd.Function):
             xs = tuple(x.stride())
             dp = _plans(key, x.device, lambda: convplan.convT_dgrad_plan(
                 tuple(x.shape), xs, tuple(w.shape), stride, dilation, crop_lo, tuple(g.shape), g.stride()))
-            wc = w.contiguous()
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_strided(tuple(x.shape), xs, device=x.device, dtype=torch.float32)
-                gemm_fwd(dp, pack_a(dp, wc), g, dx)
+                gemm_fwd(dp, pack_cached(dp, w), g, dx)
             sink = SINK
             tw = sink.lookup(w) if (sink is not None and need_w) else None
             tb = sink.lookup(ctx.bias) if (tw is not None and has_bias) else None
@@ -631,7 +681,7 @@ class ConvT2dFn(torch.autograd.Function):
                 p = dp.p
                 dapack = zeros((p.M, p.Kpad), x.device)
                 gemm_wgrad(dp, g, x, dapack)
-                dw = zeros(wc.shape, wc.device)
+                dw = zeros(tuple(w.shape), w.device)
                 unpack_add(dp, dapack, dw)
         if has_bias and ctx.needs_input_grad[2]:
             db = channel_sum(g)

@@ -99,6 +99,7 @@ class FlatAdamW:
         check(L.rfx_adamw_step(_ptr(f.data), _ptr(f.grad), _ptr(self.m), _ptr(self.v), f.numel, lr,
                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
                                _ptr(gscale), _stream()), "rfx_adamw_step")
+        ops.weights_changed()                            # the kernel wrote the parameters through a raw pointer: cached packs are stale
 
     def zero_grad(self):
         self.flat.zero_grad()

@@ -63,8 +63,8 @@ def tcn_block_forward(x, w1, b1, slope, wres, dilation, causal):
     Cout, Cin, ksize = w1.shape
     (dp1, dp2), Lout, _ = _block_plans(x4, Cout, ksize, dilation, causal)
     out = torch.empty((x.shape[0], Cout, Lout), device=x.device, dtype=torch.float32)
-    a1 = ops.pack_a(dp1, w1.contiguous())
-    a2 = ops.pack_a(dp2, wres.contiguous())
+    a1 = ops.pack_cached(dp1, w1)
+    a2 = ops.pack_cached(dp2, wres)
     ops.gemm_fwd(dp1, a1, x4, out, bias=b1, act="prelu", act_param=slope, dp2=dp2, apack2=a2)
     return out
 
@@ -88,7 +88,7 @@ class TCNBlockFn(torch.autograd.Function):
         # 1. re-materialise pre = conv1(x)+b; g1 = g * prelu'(pre); dslope = sum g * min(pre, 0)
         g1 = torch.empty_like(g)
         dslope = torch.zeros((64, slope.numel()), device=x.device, dtype=torch.float32)   # partial sums, see gemm_fwd.h
-        ops.gemm_fwd(dp1, ops.pack_a(dp1, w1.contiguous()), x4, g1, bias=b1, act="prelu", act_param=slope,
+        ops.gemm_fwd(dp1, ops.pack_cached(dp1, w1), x4, g1, bias=b1, act="prelu", act_param=slope,
                      res=g4, bwd=True, gparam=dslope)
         g14 = g1.unsqueeze(2)
         # 2. weight gradients: conv1 from (x, g1) with the bias row; residual 1x1 from (x shifted, g)
@@ -121,8 +121,8 @@ class TCNBlockFn(torch.autograd.Function):
                 pr.R, pr.Mpad = pd[0].R, pd[0].Mpad
                 return [pd[0], pr]
             dpd, dpr = ops._plans(key, x.device, build)
-            ops.gemm_fwd(dpd, ops.pack_a(dpd, w1.contiguous()), g14, dx4, dp2=dpr,
-                         apack2=ops.pack_a(dpr, wres.contiguous()), in2=g4)
+            ops.gemm_fwd(dpd, ops.pack_cached(dpd, w1), g14, dx4, dp2=dpr,
+                         apack2=ops.pack_cached(dpr, wres), in2=g4)
         return dx, dw1.view_as(w1), db1, dslope.sum(0).view_as(slope), dwres, None, None
 
 

@@ -11,6 +11,7 @@ import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
 L = _lib.lib()
+VARIANT = L.rfx_gemm_fwd_variant
 ops.set_gemm_precision(os.environ.get("RFX_GEMM_PREC", "bf16"))
 ops.GradSink.MODE = "main"
 rec = []
@@ -37,6 +38,11 @@ def wrap(name):
         if name in ("rfx_gemm_fwd", "rfx_gemm_wgrad"):
             d = args[0]._obj
             info = f"N={d.N} M={d.M} K={d.K} P={d.OA}x{d.OB} S=({d.SA},{d.SB}) in16={d.in_bf16} out16={d.out_bf16}"
+            if name == "rfx_gemm_fwd":
+                a2 = args[6]
+                pv = getattr(args[11], "value", args[11])
+                v = VARIANT(args[0], args[5], int(bool(getattr(a2, "value", a2))), pv)
+                info += f" v={v >> 4}/{v & 15}"
         elif name.startswith("rfx_groupnorm"):
             a = args[3:7] if name.endswith("fwd") or "fwd" in name else args[6:10]
             info = "N,C,S,G=" + ",".join(str(getattr(v, "value", v)) for v in a)

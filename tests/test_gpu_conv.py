@@ -286,3 +286,52 @@ def test_partial_channel_tile_stays_inside_the_tensor(case):
     ref = F.conv2d(x, w, b, padding=(0, k // 2))
     err = float((y.float() - ref).abs().max())
     check(err, 2e-5, 1.0, bf16x3=2e-4, bf16=6e-2, what=("partial channel tile vs torch", case))
+
+
+@pytest.mark.one_mode
+def test_pack_cache_follows_weight_updates():
+    """ops.pack_cached: a layer's packed weights are rebuilt after an in-place torch update (version counter), after a native
+    optimiser step (ops.weights_changed via FlatAdamW.step) and for a new tensor at a recycled address; otherwise re-used."""
+    from remfx_amd import ops
+    from remfx_amd.optim import FlatParams, FlatAdamW
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 16, 1, 256, generator=g).to(dev)
+    conv = torch.nn.Conv2d(16, 32, (1, 3), padding=(0, 1)).to(dev)
+    ct = torch.nn.ConvTranspose2d(16, 8, (1, 8), stride=(1, 4)).to(dev)
+
+    def run():
+        y = ops.conv2d(x, conv.weight, conv.bias, (1, 1), (0, 1), (1, 1))
+        z = ops.conv_transpose2d(x, ct.weight, ct.bias, (1, 4), (1, 1), (0, 0), (1, 1024))
+        return y.detach().clone(), z.detach().clone()
+
+    def ref():
+        prev = ops.PACK_CACHE
+        ops.PACK_CACHE = False
+        try:
+            return run()
+        finally:
+            ops.PACK_CACHE = prev
+
+    ops.clear_pack_cache()
+    a = run()
+    n0 = len(ops._PACKS)
+    assert n0 >= 2
+    b = run()
+    assert len(ops._PACKS) == n0 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with torch.no_grad():                                    # torch in-place update: version counter
+        conv.weight.mul_(1.5)
+        ct.weight.add_(0.25)
+    c, r = run(), ref()
+    assert torch.equal(c[0], r[0]) and torch.equal(c[1], r[1]) and not torch.equal(c[0], a[0]) and not torch.equal(c[1], a[1])
+    # native optimiser step (raw-pointer kernel): parameters move into the flat buffer, then change without a version bump
+    mods = torch.nn.ModuleList([conv, ct])
+    opt = FlatAdamW(FlatParams(list(mods.parameters())), lr=1e-2)
+    d = run()
+    opt.zero_grad()
+    ya = ops.conv2d(x, conv.weight, conv.bias, (1, 1), (0, 1), (1, 1)).square().mean() + \
+        ops.conv_transpose2d(x, ct.weight, ct.bias, (1, 4), (1, 1), (0, 0), (1, 1024)).square().mean()
+    ya.backward()
+    opt.step()
+    e, r = run(), ref()
+    assert torch.equal(e[0], r[0]) and torch.equal(e[1], r[1]) and not torch.equal(e[0], d[0]) and not torch.equal(e[1], d[1])
