@@ -522,15 +522,11 @@ __global__ __launch_bounds__(1024, 4) void dconv_bwd_kernel(const DconvArgs a) {
         const float g = live ? gr[mt][r] : 0.f;
         const float du = g * s.pz[6][o + r];
         const float dp = du * sg, dq = du * znp * sg * (1.0f - sg);
-#ifndef DC_DBG_NO_ATOMICS
         atomicAdd(accj + 32 * c, g * znp * sg);                                  // dscale[c]
         atomicAdd(accj + 32 * (C + c), dp * zhp);                                // dgn2w value / gate rows
         atomicAdd(accj + 32 * (2 * C + c), dq * zhq);
         atomicAdd(accj + 32 * (3 * C + c), dp);                                  // dgn2b
         atomicAdd(accj + 32 * (4 * C + c), dq);
-#else
-        asm volatile("" :: "v"(g * znp * sg), "v"(dp * zhp), "v"(dq * zhq));
-#endif
         const float ep = gp * dp, eq = gq * dq;
         S1 += ep + eq;
         S2 = fmaf(ep, zhp, fmaf(eq, zhq, S2));
@@ -584,12 +580,10 @@ __global__ __launch_bounds__(1024, 4) void dconv_bwd_kernel(const DconvArgs a) {
       const int m = dc_hrow(r, hh);
       const float hn_ = hacc[r];
       const float dhn = m < K::H ? da[r] * dc_gelu_grad(fmaf(hn_, s.g1[m], s.be1[m])) : 0.f;
-#ifndef DC_DBG_NO_ATOMICS
       if (m < K::H) {                                                // compile-time per (r) up to the lane half: rows beyond H have no slot
         atomicAdd(accj + 32 * (5 * C + m), dhn * hn_);                // dgn1w
         atomicAdd(accj + 32 * (5 * C + K::H + m), dhn);               // dgn1b
       }
-#endif
       const float e = s.g1[m] * dhn;
       Q1 += e; Q2 = fmaf(e, hn_, Q2);
       da[r] = e;

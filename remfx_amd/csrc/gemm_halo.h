@@ -93,24 +93,13 @@ __global__ __launch_bounds__(256, R <= 2 ? 4 : 3) void gemm_halo_kernel(const Fw
 
   float bpre[NSLOT][16];
   uint4 apre[NASLOT];
-#if defined(HALO_DBG_NO_ALOAD) || defined(HALO_DBG_NO_BLOAD)
-#pragma unroll
-  for (int s = 0; s < NASLOT; ++s) apre[s] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-#pragma unroll
-  for (int s = 0; s < NSLOT; ++s)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) bpre[s][i] = 1.0f;
-#endif
   auto issue = [&](int c) {                          // global loads of chunk c (clamped: the last iteration re-reads its own chunk)
     const int cc = __builtin_amdgcn_readfirstlane(c < nchunks ? c : nchunks - 1);
     const int blk = cc / g2, sub = cc - blk * g2;
     const uint32_t kb = (uint32_t)(2 * (blk * NT * g2 + sub) * d.Mpad * 16);
-#ifndef HALO_DBG_NO_ALOAD
 #pragma unroll
     for (int s = 0; s < NASLOT; ++s) apre[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff[s], kb, 0));
-#endif
     const uint32_t so = (uint32_t)(cc * 16) * csb;
-#ifndef HALO_DBG_NO_BLOAD
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s)
 #pragma unroll
@@ -120,7 +109,6 @@ __global__ __launch_bounds__(256, R <= 2 ? 4 : 3) void gemm_halo_kernel(const Fw
         else
           bpre[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[s], so + (uint32_t)i * csb, 0));
       }
-#endif
   };
   issue(0);
   const unsigned char* bbase = img + (wave * 32 + l31) * RFX_HALO_PS + h * 16;
@@ -153,19 +141,10 @@ __global__ __launch_bounds__(256, R <= 2 ? 4 : 3) void gemm_halo_kernel(const Fw
 #pragma unroll
       for (int mt = 0; mt < R; ++mt) {
         const bf16x8 af = __builtin_bit_cast(bf16x8, abase[t * 2 * BM + mt * 32]);
-#ifndef HALO_DBG_NO_MFMA
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[mt], 0, 0, 0);
-#else
-        asm volatile("" :: "v"(af), "v"(bf));
-#endif
       }
     }
   }
-#ifdef HALO_DBG_NO_EPI
-#pragma unroll
-  for (int mt = 0; mt < R; ++mt) asm volatile("" :: "v"(acc[mt]));
-  return;
-#endif
   TileCtx tc;
   tc.n = n; tc.pw = (int)(pw & 0x7fffffff); tc.m0 = m0; tc.wave = wave; tc.lane = lane; tc.l31 = l31; tc.h = h;
   tc.jvalid = true;
@@ -187,10 +166,8 @@ template <int IN16>
 static int rfx_launch_halo_variant(const FwdArgs& g, int r, dim3 grid, hipStream_t s) {
   const bool nine = g.d.halo_nt == 9;
   switch (r) {
-#ifndef RFX_HALO_ONLY_R3
     case 1: return nine ? rfx_launch_halo_one<1, 9, IN16>(g, grid, s) : rfx_launch_halo_one<1, 3, IN16>(g, grid, s);
     case 2: return nine ? rfx_launch_halo_one<2, 9, IN16>(g, grid, s) : rfx_launch_halo_one<2, 3, IN16>(g, grid, s);
-#endif
     case 3: return nine ? rfx_launch_halo_one<3, 9, IN16>(g, grid, s) : rfx_launch_halo_one<3, 3, IN16>(g, grid, s);
   }
   return -1;
