@@ -235,16 +235,16 @@ def _plans(key, device, builder):
     return v
 
 
-def pack_a(dp, w):
-    """Gather the weight tensor into the packed [Kpad][Mpad] A matrix of a plan."""
+def pack_a(dp, w, out=None):
+    """Gather the weight tensor into the packed [Kpad][Mpad] A matrix of a plan (out: an earlier result of the same plan to overwrite)."""
     p = dp.p
     prec = dp.fwd_prec()
     if prec == 0:
-        apack = torch.empty((p.Kpad + 64, p.Mpad), device=w.device, dtype=torch.float32)
+        apack = out if out is not None else torch.empty((p.Kpad + 64, p.Mpad), device=w.device, dtype=torch.float32)
         check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"], p.Mpad, p.Kpad, 0,
                                     _ptr(apack), _stream()), "rfx_pack_a")
     else:                                       # tap-major order, bf16 hi / lo cells: 2 x [Kpad_t / 8 + 8][Mpad] x 16 bytes
-        apack = torch.empty((p.Kpad_t + 64, p.Mpad), device=w.device, dtype=torch.float32)
+        apack = out if out is not None else torch.empty((p.Kpad_t + 64, p.Mpad), device=w.device, dtype=torch.float32)
         check(_lib.lib().rfx_pack_a(_ptr(w), _ptr(dp.woff_t), p.w_ms, p.M, p.Kpad_t, p.Mpad, p.Kpad_t, prec,
                                     _ptr(apack), _stream()), "rfx_pack_a")
     return apack
@@ -252,11 +252,16 @@ def pack_a(dp, w):
 
 # ---- packed weights, cached ----------------------------------------------------------
 # A layer's packed A matrix changes only when its weights do, yet it used to be rebuilt by every call (218 pack launches + the torch
-# reshapes of the merged / interleaved forms per Demucs step).  An entry is valid while (a) the tensor it was packed from is held
-# alive HERE (a strong reference: its storage cannot be freed and re-used under the same address), (b) torch's version counter of
-# that storage is unchanged (every in-place torch op, load_state_dict, optimiser of torch.optim bumps it) and (c) no NATIVE writer
-# has touched the weights since (FlatAdamW's kernel and the parameter broadcast write through raw pointers: they call
-# weights_changed()).  Entries are per plan, arithmetic mode and stream; the cache is bounded by bytes (oldest entries go first).
+# reshapes of the merged / interleaved forms per Demucs step, on the compute stream in front of the GEMM that needs them).  An entry
+# is valid while (a) the tensor it was packed from is held alive HERE (a strong reference: its storage cannot be freed and re-used
+# under the same address), (b) torch's version counter of that storage is unchanged (every in-place torch op, load_state_dict, the
+# optimisers of torch.optim bump it) and (c) no NATIVE writer has touched the weights since (FlatAdamW's kernel and the parameter
+# broadcast write through raw pointers: they call weights_changed()).  Entries are per plan, arithmetic mode and stream; the cache
+# is bounded by bytes (oldest entries go first).  NOT seen: writes through `p.data` (they bypass the version counter) -- call
+# ops.weights_changed() after such a write, or run with RFX_PACK_CACHE=0.
+# (Rebuilding all entries on a side stream right after the optimiser step, so that a training step finds them ready, was built and
+# measured SLOWER: 137.4 -> 141.8-146.9 ms at 64 clips, 39.5 -> 41.5-42.4 ms at 8 -- the cache therefore pays in inference and
+# wherever a weight is used more than once between updates; a training step still packs each weight once per use.)
 PACK_CACHE = _os.environ.get("RFX_PACK_CACHE", "1") != "0"
 PACK_CACHE_BYTES = 6 << 30
 _PACKS = {}
@@ -264,9 +269,17 @@ _PACKS_BYTES = [0]
 _WEIGHT_EPOCH = [0]
 
 
+class _PackEntry:
+    __slots__ = ("src", "dp", "ver", "epoch", "apack", "nbytes")
+
+
 def weights_changed():
     """A native kernel wrote parameters in place (no torch version bump): every cached pack is stale."""
     _WEIGHT_EPOCH[0] += 1
+
+
+def _derived(src, derive):
+    return derive(src) if derive is not None else src.contiguous()
 
 
 def pack_cached(dp, src, derive=None, tag=0):
@@ -277,22 +290,25 @@ def pack_cached(dp, src, derive=None, tag=0):
         except RuntimeError:                       # inference tensors carry no version counter: no caching
             ver = None
         if ver is not None:
-            key = (id(dp), src.data_ptr(), tuple(src.stride()), tag, dp.fwd_prec(), torch.cuda.current_stream().cuda_stream)
+            prec, cur = dp.fwd_prec(), torch.cuda.current_stream()
+            key = (id(dp), src.data_ptr(), tuple(src.stride()), tag, prec, cur.cuda_stream)
             e = _PACKS.get(key)
-            if e is not None and e[1] is dp and e[2] == ver and e[3] == _WEIGHT_EPOCH[0]:
-                return e[4]
-            apack = pack_a(dp, derive(src) if derive is not None else src.contiguous())
-            nbytes = apack.numel() * 4 + src.numel() * src.element_size()
+            if e is not None and e.dp is dp and e.ver == ver and e.epoch == _WEIGHT_EPOCH[0]:
+                return e.apack
+            apack = pack_a(dp, _derived(src, derive))
             if e is not None:
-                _PACKS_BYTES[0] -= e[5]
+                _PACKS_BYTES[0] -= e.nbytes
                 del _PACKS[key]                    # re-insert at the young end
-            _PACKS[key] = (src, dp, ver, _WEIGHT_EPOCH[0], apack, nbytes)
-            _PACKS_BYTES[0] += nbytes
+            e = _PackEntry()
+            e.src, e.dp, e.ver, e.epoch, e.apack = src, dp, ver, _WEIGHT_EPOCH[0], apack
+            e.nbytes = apack.numel() * 4 + src.numel() * src.element_size()
+            _PACKS[key] = e
+            _PACKS_BYTES[0] += e.nbytes
             while _PACKS_BYTES[0] > PACK_CACHE_BYTES and len(_PACKS) > 1:
                 k0 = next(iter(_PACKS))
-                _PACKS_BYTES[0] -= _PACKS.pop(k0)[5]
+                _PACKS_BYTES[0] -= _PACKS.pop(k0).nbytes
             return apack
-    return pack_a(dp, derive(src) if derive is not None else src.contiguous())
+    return pack_a(dp, _derived(src, derive))
 
 
 def clear_pack_cache():
