@@ -40,7 +40,7 @@ def _ptr(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _as_clips(x):

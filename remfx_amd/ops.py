@@ -148,8 +148,20 @@ TRACE_VARIANT = None          # bench.py sets this to a list: gemm_fwd appends r
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "tanh": 3, "prelu": 4, "leaky": 5, "sigmoid": 6}
 
 
+# torch.cuda.current_stream() builds a Stream object through four Python layers (~9 us); a training step asks ~1200 times (11 ms of
+# the 34 ms a step costs the host at 8 clips, where the host is what bounds the step: scripts/host_time.py).  The raw handle is one
+# C call.
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
+def raw_stream():
+    """hipStream_t of the current device's current stream, as an int."""
+    return _raw_stream(_cur_device())
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream(_cur_device()))
 
 
 def _ptr(t):
@@ -290,8 +302,8 @@ def pack_cached(dp, src, derive=None, tag=0):
         except RuntimeError:                       # inference tensors carry no version counter: no caching
             ver = None
         if ver is not None:
-            prec, cur = dp.fwd_prec(), torch.cuda.current_stream()
-            key = (id(dp), src.data_ptr(), tuple(src.stride()), tag, prec, cur.cuda_stream)
+            prec = dp.fwd_prec()
+            key = (id(dp), src.data_ptr(), tuple(src.stride()), tag, prec, raw_stream())
             e = _PACKS.get(key)
             if e is not None and e.dp is dp and e.ver == ver and e.epoch == _WEIGHT_EPOCH[0]:
                 return e.apack
