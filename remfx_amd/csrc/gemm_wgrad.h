@@ -244,27 +244,75 @@ __global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4) ? 3 : 2) void gemm
   const int t_end = min(t_begin + w.tiles_per_block, w.total_tiles);
   // wave-uniform facts about this k tile's table rows: the b-shift range of its taps and whether it holds the bias ("ones") row.  A
   // chunk whose every quad stays inside its row for every tap takes the lean load path below.
-  int dbmin = 0, dbmax = 0, any_ones = 0;
+  int dbmin = 0, dbmax = 0, damin = 0, damax = 0, any_ones = 0;
   for (int i = lane; i < RK; i += 64) {
     const rfx_ktab_entry e = kts[i];
     if (e.flags & 1) any_ones = 1;
-    else if (e.da > -(1 << 29)) { dbmin = min(dbmin, e.db); dbmax = max(dbmax, e.db); }
+    else if (e.da > -(1 << 29)) {
+      dbmin = min(dbmin, e.db); dbmax = max(dbmax, e.db);
+      damin = min(damin, e.da); damax = max(damax, e.da);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     dbmin = min(dbmin, __shfl_xor(dbmin, o, 64)); dbmax = max(dbmax, __shfl_xor(dbmax, o, 64));
+    damin = min(damin, __shfl_xor(damin, o, 64)); damax = max(damax, __shfl_xor(damax, o, 64));
     any_ones |= __shfl_xor(any_ones, o, 64);
   }
   dbmin = __builtin_amdgcn_readfirstlane(dbmin); dbmax = __builtin_amdgcn_readfirstlane(dbmax);
+  damin = __builtin_amdgcn_readfirstlane(damin); damax = __builtin_amdgcn_readfirstlane(damax);
   any_ones = __builtin_amdgcn_readfirstlane(any_ones);
   const int q4 = (tid & 15) * 4, r0 = tid >> 4;                    // this thread's quad inside the chunk / first row
   const int chunks_per_row = (d.OB + PC - 1) / PC;
+  // Per-thread byte offsets of this thread's NX table rows, taken from the table ONCE: rows that never load (bias row, channel
+  // padding) get 2^31, which pushes any sum with a sample-relative offset (< 2^31) beyond num_records -> 0.  The chunk loop of the
+  // r03 kernel re-read the table from LDS and re-derived offset, row test and select for every row of every chunk: ablation builds
+  //  showed the 3x3 layers taking the same 2.2 ms with the load instructions REMOVED -- the kernel was bound by that
+  // per-chunk address arithmetic, not by the loads.
+  uint32_t xoff[NX];
+  uint32_t onesmask = 0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const rfx_ktab_entry e = kts[r0 + 16 * i];
+    const bool ones = e.flags & 1;
+    xoff[i] = (ones || e.da <= -(1 << 29)) ? RFX_BUF_OOB : ((uint32_t)e.off << 2);
+    if (ones) onesmask |= 1u << i;
+  }
   struct Stage { f32x4 gv[NG], xv[NX]; };
-  auto load_chunk = [&](int t, Stage& st, bool valid) {            // !valid: every load gets the out-of-range offset -> zeros
-    const int row = t / chunks_per_row;                            // (n, a), wave-uniform
-    const int n = row / d.OA, a = row - n * d.OA;
-    const int c0 = (t - row * chunks_per_row) * PC;
+  auto load_chunk = [&](int n, int a, int c0, Stage& st, bool valid) {   // (n, a, c0) wave-uniform; !valid: every load gets the out-of-range offset -> zeros
     const int ob = c0 + q4;                                        // first position of this thread's quad
+    if (valid && c0 + PC <= d.OB && c0 + dbmin >= 0 && c0 + PC + dbmax <= d.IB && a * d.SA + damin >= 0 &&
+        a * d.SA + damax < d.IA) {
+      // FULLY interior chunk (wave-uniform test): every tap of every row is inside the input on both axes -> one add per load
+      const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.in + (int64_t)n * d.in_ns), 0,
+                                                                           (int)w.in_bytes, 0x00020000);
+      constexpr int GSZ = G16 ? 2 : 4;
+      const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(w.g) + (int64_t)n * d.out_ns * GSZ), 0, (int)w.g_bytes, 0x00020000);
+      const uint32_t goff = (uint32_t)(((int64_t)(a * d.out_sa + d.out_a0) * d.out_as + (int64_t)(ob + d.out_b0) +
+                                        (int64_t)(m0 + r0) * d.out_cs) * GSZ);
+      const uint32_t gstep = (uint32_t)(16 * d.out_cs * GSZ);
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const uint32_t off = (m0 + r0 + 16 * i < d.M) ? goff + i * gstep : RFX_BUF_OOB;
+        if (G16) {
+          const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(grs, off, 0, 0));
+          st.gv[i] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
+        } else {
+          st.gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 0));
+        }
+      }
+      const uint32_t voff = (uint32_t)(((int64_t)a * d.SA * d.in_as + (int64_t)ob) * 4);
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        st.xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff + xoff[i], 0, 0));
+      if (any_ones) {                                              // the tile that holds the bias-gradient column (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+          if (onesmask & (1u << i)) st.xv[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+      }
+      return;
+    }
     if (valid && c0 + PC <= d.OB && c0 + dbmin >= 0 && c0 + PC + dbmax <= d.IB) {
       // INTERIOR chunk (wave-uniform test): every quad of every tap lies inside its row -- no edge selects, no straddle loads.  The
       // general path below spends ~330 VALU instructions per chunk on them against 16 MFMAs (r03 ISA count): the kernel was VALU-bound.
@@ -404,43 +452,35 @@ __global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4) ? 3 : 2) void gemm
   // TF/s, i.e. waiting on loads.  Where two stages fit the register budget (everything but the 96 x 256 tile) the loop runs two
   // chunks per iteration and each stage's loads fly under TWO chunks of staging + MFMAs.  An odd tail chunk is loaded with the
   // out-of-range offset (zeros), so the loop body is branch-free.
-  constexpr int STAGE_REGS = 4 * NX + (G16 ? 2 : 4) * NG;
   // MEASURED (r02b, Demucs step): weight-gradient launches 36.3 -> 39.5 ms with the two-stage loop, the 3x3 layers unchanged
   // (2.56 -> 2.59 ms): they are bound by LDS / L1 bandwidth (48-64 KB into the CU per 512 clk of MFMA work), not by load latency,
   // and the extra registers cost the small tiles occupancy.  Re-measured in r03 on the lean-load kernel (bf16 mode, two workgroups per
   // CU instead of three to make room): 128 x 128 tiles with two stages 1.59 -> 1.85 ms (192 -> 384, 3x3) and 1.94 -> 2.43 ms
   // (384 -> 768), step 145.4 -> 147.4 ms; the 96-row layers on 96 x 128 tiles with two stages instead of 96 x 256 with one 2.22 ->
   // 2.66 ms, step +0.9 ms: the third resident workgroup hides more latency than the second register stage.  Kept for the record, off.
-  constexpr bool DEEP = false && 2 * STAGE_REGS + 16 * TM * TK <= 200;
   const int t_last = t_end - 1;
-  if (DEEP) {
-    Stage s0, s1;
-    if (t_begin < t_end) {
-      load_chunk(t_begin, s0, true);
-      load_chunk(min(t_begin + 1, t_last), s1, t_begin + 1 < t_end);
+  // position of the chunk being loaded, advanced incrementally (the r03 loop decoded t with two integer divisions per chunk)
+  int pn = 0, pa = 0, pc0 = 0;
+  if (t_begin < t_end) {
+    const int row = t_begin / chunks_per_row;
+    pn = row / d.OA; pa = row - pn * d.OA; pc0 = (t_begin - row * chunks_per_row) * PC;
+  }
+  pn = __builtin_amdgcn_readfirstlane(pn); pa = __builtin_amdgcn_readfirstlane(pa); pc0 = __builtin_amdgcn_readfirstlane(pc0);
+  Stage st;
+  if (t_begin < t_end) load_chunk(pn, pa, pc0, st, true);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();                       // the previous chunk's fragment reads are done
+    stage(st);
+    __syncthreads();
+    if (t < t_last) {                      // wave-uniform; on the last iteration the same chunk is re-read (branch-free loads)
+      pc0 += PC;
+      if (pc0 >= chunks_per_row * PC) {
+        pc0 = 0;
+        if (++pa == d.OA) { pa = 0; ++pn; }
+      }
     }
-    for (int t = t_begin; t < t_end; t += 2) {
-      __syncthreads();                       // the previous chunk's fragment reads are done
-      stage(s0);
-      __syncthreads();
-      load_chunk(min(t + 2, t_last), s0, t + 2 < t_end);
-      mma_chunk();
-      __syncthreads();
-      stage(s1);
-      __syncthreads();
-      load_chunk(min(t + 3, t_last), s1, t + 3 < t_end);
-      mma_chunk();
-    }
-  } else {
-    Stage st;
-    if (t_begin < t_end) load_chunk(t_begin, st, true);
-    for (int t = t_begin; t < t_end; ++t) {
-      __syncthreads();                       // the previous chunk's fragment reads are done
-      stage(st);
-      __syncthreads();
-      load_chunk(min(t + 1, t_last), st, true);    // unconditional (branch-free): the last chunk is re-read
-      mma_chunk();
-    }
+    load_chunk(pn, pa, pc0, st, true);
+    mma_chunk();
   }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
