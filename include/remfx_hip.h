@@ -452,6 +452,19 @@ int rfx_glu_bwd_bf16(const void* x, const float* gy, void* gx, int64_t N, int64_
  * convolution is then ONE rfx_gemm_fwd with the block weight [[Wr,-Wi],[Wi,Wr]].
  * sums (5, per channel c at c*5+q): sum xr, xi, xr^2, xr*xi, xi^2 in fp64 (ComplexBatchNorm statistics). */
 int rfx_cplx_moments(const float* x, int32_t N, int32_t C, int64_t S, double* sums, void* stream);
+/* ComplexBatchNorm coefficients (asteroid complex_nn BatchNorm inside DCUNet, models.py:356-367) in one launch: per channel
+ * coef (6, C) = Zrr, Zri, Zir, Zii, Br', Bi' with y = Z x + B', Z = W V^{-1/2} (2x2 inverse square root of the covariance + eps)
+ * and the mean folded into the bias.  Statistics come from `sums` (rfx_cplx_moments, inv_count = 1 / (N S); training) or from
+ * stats_in (5, C) = running Mr, Mi, Vrr, Vri, Vii (eval) -- exactly one of the two.  stats_out (5, C), optional: the batch
+ * statistics; RM* / RV*, optional (all five or none): running buffers updated in place, buf += momentum * (stat - buf).
+ * rfx_cplx_coef_bwd: gcoef (6, C) -> gw (5, C) = gradients of Wrr, Wri, Wii, Br, Bi and, with sums given, cm (5, C) = the
+ * gradient with respect to the five raw moments times inv_count (the `coef` operand of rfx_cplx_moments_bwd); cm may be NULL. */
+int rfx_cplx_coef_fwd(const double* sums, double inv_count, const float* stats_in, const float* Wrr, const float* Wri,
+                      const float* Wii, const float* Br, const float* Bi, float eps, int32_t C, float* coef, float* stats_out,
+                      float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, float momentum, void* stream);
+int rfx_cplx_coef_bwd(const double* sums, double inv_count, const float* stats_in, const float* Wrr, const float* Wri,
+                      const float* Wii, const float* Br, const float* Bi, float eps, int32_t C, const float* gcoef, float* gw,
+                      float* cm, void* stream);
 /* gx += d(sum_q coef[q][c] * moment_q)/dx, coef: (5, C) fp32 */
 int rfx_cplx_moments_bwd(const float* x, const float* coef, int32_t N, int32_t C, int64_t S, float* gx, void* stream);
 /* out = leaky_relu(Z x + b, slope) per complex channel; coef (6, C) = Zrr, Zri, Zir, Zii, Br, Bi.

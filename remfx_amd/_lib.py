@@ -128,6 +128,8 @@ SIGNATURES = {
     "rfx_avgpool2d_bwd": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "rfx_cplx_moments": [_P, _I32, _I32, _I64, _P, _P],
     "rfx_cplx_moments_bwd": [_P, _P, _I32, _I32, _I64, _P, _P],
+    "rfx_cplx_coef_fwd": [_P, C.c_double, _P, _P, _P, _P, _P, _P, C.c_float, _I32, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P],
+    "rfx_cplx_coef_bwd": [_P, C.c_double, _P, _P, _P, _P, _P, _P, C.c_float, _I32, _P, _P, _P, _P],
     "rfx_cplx_affine_act_fwd": [_P, _P, _I32, _I32, _I64, C.c_float, _P, _I64, _I64, _P],
     "rfx_cplx_affine_act_bwd": [_P, _P, _P, _I64, _I64, _I32, _I32, _I64, C.c_float, _P, _P, _P],
     "rfx_bound_mask_fwd": [_P, _P, _P, _I32, _I64, _I64, _I64, _I64, _P],

@@ -252,3 +252,131 @@ extern "C" int rfx_phase_mask_bwd(const float* xc, const float* gout, float* gma
   RFX_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------
+// ComplexBatchNorm coefficients and their backward (asteroid DCUNet's complex_nn.BatchNorm via remfx/models.py:356-367):
+// per channel, y = Z x + B' with Z = W . V^{-1/2} (2x2 inverse square root of the covariance) and the mean folded into B'.
+// One thread per channel; until round 4 this was ~45 (forward) + ~60 (autograd) torch launches on (C,) tensors per norm layer --
+// 4000 of the 4300 launches of a DCUNet step.
+// sums: [c][5] fp64 = sum xr, xi, xr^2, xr xi, xi^2 (rfx_cplx_moments), inv = 1 / (N S); or stats_in (5, C) fp32 = running
+// statistics (eval).  The variances are formed in fp64 (m2 - m^2 cancels), everything after in fp32 as the reference does.
+// ---------------------------------------------------------------------------------
+struct CxCoefW { const float *Wrr, *Wri, *Wii, *Br, *Bi; };
+struct CxCoefRun { float *RMr, *RMi, *RVrr, *RVri, *RVii; };
+
+__device__ __forceinline__ void cx_stats(const double* sums, double inv, const float* stats_in, int C, int c, float st[5]) {
+  if (sums) {
+    const double m0 = sums[c * 5 + 0] * inv, m1 = sums[c * 5 + 1] * inv;
+    st[0] = (float)m0; st[1] = (float)m1;
+    st[2] = (float)(sums[c * 5 + 2] * inv - m0 * m0);
+    st[3] = (float)(sums[c * 5 + 3] * inv - m0 * m1);
+    st[4] = (float)(sums[c * 5 + 4] * inv - m1 * m1);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) st[q] = stats_in[q * C + c];
+  }
+}
+
+__global__ void cplx_coef_fwd_kernel(const double* __restrict__ sums, double inv, const float* __restrict__ stats_in, CxCoefW w,
+                                     float eps, int C, float* __restrict__ coef, float* __restrict__ stats_out, CxCoefRun run,
+                                     float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float st[5];
+  cx_stats(sums, inv, stats_in, C, c, st);
+  if (stats_out) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) stats_out[q * C + c] = st[q];
+  }
+  if (run.RMr) {                         // running statistics: buf.lerp_(stat, momentum)
+    run.RMr[c] += momentum * (st[0] - run.RMr[c]);   run.RMi[c] += momentum * (st[1] - run.RMi[c]);
+    run.RVrr[c] += momentum * (st[2] - run.RVrr[c]); run.RVri[c] += momentum * (st[3] - run.RVri[c]);
+    run.RVii[c] += momentum * (st[4] - run.RVii[c]);
+  }
+  const float Mr = st[0], Mi = st[1], Vrr = st[2] + eps, Vri = st[3], Vii = st[4] + eps;
+  const float tau = Vrr + Vii, delta = Vrr * Vii - Vri * Vri;
+  const float s = sqrtf(delta), t = sqrtf(tau + 2.f * s), rst = 1.f / (s * t);
+  const float Urr = (s + Vii) * rst, Uii = (s + Vrr) * rst, Uri = -Vri * rst;
+  const float Wrr = w.Wrr[c], Wri = w.Wri[c], Wii = w.Wii[c];
+  const float Zrr = Wrr * Urr + Wri * Uri, Zri = Wrr * Uri + Wri * Uii;
+  const float Zir = Wri * Urr + Wii * Uri, Zii = Wri * Uri + Wii * Uii;
+  coef[0 * C + c] = Zrr; coef[1 * C + c] = Zri; coef[2 * C + c] = Zir; coef[3 * C + c] = Zii;
+  coef[4 * C + c] = w.Br[c] - (Zrr * Mr + Zri * Mi);
+  coef[5 * C + c] = w.Bi[c] - (Zir * Mr + Zii * Mi);
+}
+
+// gcoef (6, C) -> gw (5, C) = d/d(Wrr, Wri, Wii, Br, Bi) and, in training mode, cm (5, C) = d/d(raw moment q) * inv (what
+// rfx_cplx_moments_bwd takes).  Reverse-mode by hand of the forward above, in fp64.
+__global__ void cplx_coef_bwd_kernel(const double* __restrict__ sums, double inv, const float* __restrict__ stats_in, CxCoefW w,
+                                     float eps, int C, const float* __restrict__ gcoef, float* __restrict__ gw,
+                                     float* __restrict__ cm) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float st[5];
+  cx_stats(sums, inv, stats_in, C, c, st);
+  const double Mr = st[0], Mi = st[1], Vrr = (double)(st[2] + eps), Vri = st[3], Vii = (double)(st[4] + eps);
+  const double tau = Vrr + Vii, delta = Vrr * Vii - Vri * Vri;
+  const double s = sqrt(delta), t = sqrt(tau + 2.0 * s), rst = 1.0 / (s * t);
+  const double Urr = (s + Vii) * rst, Uii = (s + Vrr) * rst, Uri = -Vri * rst;
+  const double Wrr = w.Wrr[c], Wri = w.Wri[c], Wii = w.Wii[c];
+  const double Zrr = Wrr * Urr + Wri * Uri, Zri = Wrr * Uri + Wri * Uii;
+  const double Zir = Wri * Urr + Wii * Uri, Zii = Wri * Uri + Wii * Uii;
+  const double gB0 = gcoef[4 * C + c], gB1 = gcoef[5 * C + c];
+  const double gZrr = (double)gcoef[0 * C + c] - gB0 * Mr, gZri = (double)gcoef[1 * C + c] - gB0 * Mi;
+  const double gZir = (double)gcoef[2 * C + c] - gB1 * Mr, gZii = (double)gcoef[3 * C + c] - gB1 * Mi;
+  gw[0 * C + c] = (float)(gZrr * Urr + gZri * Uri);
+  gw[1 * C + c] = (float)(gZrr * Uri + gZri * Uii + gZir * Urr + gZii * Uri);
+  gw[2 * C + c] = (float)(gZir * Uri + gZii * Uii);
+  gw[3 * C + c] = (float)gB0;
+  gw[4 * C + c] = (float)gB1;
+  if (!cm) return;
+  const double gMr = -(gB0 * Zrr + gB1 * Zir), gMi = -(gB0 * Zri + gB1 * Zii);
+  const double gUrr = gZrr * Wrr + gZir * Wri;
+  const double gUri = gZrr * Wri + gZri * Wrr + gZir * Wii + gZii * Wri;
+  const double gUii = gZri * Wri + gZii * Wii;
+  double gs = (gUrr + gUii) * rst;
+  double gVii = gUrr * rst, gVrr = gUii * rst, gVri = -gUri * rst;
+  const double grst = gUrr * (s + Vii) + gUii * (s + Vrr) - gUri * Vri;
+  const double gst = -grst * rst * rst;                 // d / d(s t)
+  gs += gst * t;
+  const double gt = gst * s;
+  const double gtau = gt / (2.0 * t);                   // d / d(tau + 2 s)
+  gs += 2.0 * gtau;
+  const double gdelta = gs / (2.0 * s);
+  gVrr += gdelta * Vii + gtau;
+  gVii += gdelta * Vrr + gtau;
+  gVri += -2.0 * gdelta * Vri;
+  // central statistics -> raw moments: Vrr = m2 - Mr^2, Vri = m3 - Mr Mi, Vii = m4 - Mi^2
+  cm[0 * C + c] = (float)((gMr - 2.0 * Mr * gVrr - Mi * gVri) * inv);
+  cm[1 * C + c] = (float)((gMi - 2.0 * Mi * gVii - Mr * gVri) * inv);
+  cm[2 * C + c] = (float)(gVrr * inv);
+  cm[3 * C + c] = (float)(gVri * inv);
+  cm[4 * C + c] = (float)(gVii * inv);
+}
+
+extern "C" int rfx_cplx_coef_fwd(const double* sums, double inv_count, const float* stats_in, const float* Wrr, const float* Wri,
+                                 const float* Wii, const float* Br, const float* Bi, float eps, int32_t C, float* coef,
+                                 float* stats_out, float* RMr, float* RMi, float* RVrr, float* RVri, float* RVii, float momentum,
+                                 void* stream) {
+  if ((sums == nullptr) == (stats_in == nullptr) || !Wrr || !Wri || !Wii || !Br || !Bi || !coef || C <= 0) return -1;
+  if ((RMr != nullptr) != (RMi != nullptr) || (RMr != nullptr) != (RVrr != nullptr) || (RMr != nullptr) != (RVri != nullptr) ||
+      (RMr != nullptr) != (RVii != nullptr))
+    return -1;
+  CxCoefW w{Wrr, Wri, Wii, Br, Bi};
+  CxCoefRun r{RMr, RMi, RVrr, RVri, RVii};
+  hipLaunchKernelGGL(cplx_coef_fwd_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, inv_count, stats_in, w, eps,
+                     C, coef, stats_out, r, momentum);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rfx_cplx_coef_bwd(const double* sums, double inv_count, const float* stats_in, const float* Wrr, const float* Wri,
+                                 const float* Wii, const float* Br, const float* Bi, float eps, int32_t C, const float* gcoef,
+                                 float* gw, float* cm, void* stream) {
+  if ((sums == nullptr) == (stats_in == nullptr) || !Wrr || !Wri || !Wii || !Br || !Bi || !gcoef || !gw || C <= 0) return -1;
+  CxCoefW w{Wrr, Wri, Wii, Br, Bi};
+  hipLaunchKernelGGL(cplx_coef_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, inv_count, stats_in, w, eps,
+                     C, gcoef, gw, cm);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

@@ -150,37 +150,37 @@ class _CplxNormActFn(torch.autograd.Function):
         y = y.contiguous()
         N, C2, H, W = y.shape
         Cc, S = C2 // 2, H * W
+        # coefficients of y = Z x + B' in ONE launch (rfx_cplx_coef_fwd; running statistics updated by the same kernel) -- the torch
+        # form (`norm.coef`, kept as the readable statement of the math) cost ~45 launches on (C,) tensors per layer
+        pw = [p.detach() for p in params]
+        coefc = torch.empty((6, Cc), device=y.device, dtype=torch.float32)
         if norm.training:
             sums = torch.empty(Cc * 5, device=y.device, dtype=torch.float64)
             check(L.rfx_cplx_moments(_ptr(y), N, Cc, S, _ptr(sums), _stream()), "rfx_cplx_moments")
-            with torch.enable_grad():
-                mom = (sums.view(Cc, 5).t() / float(N * S)).detach().requires_grad_(True)     # (5, C) fp64
-                Mr, Mi = mom[0], mom[1]
-                Vrr, Vri, Vii = mom[2] - Mr * Mr, mom[3] - Mr * Mi, mom[4] - Mi * Mi
-                stats = [t.float() for t in (Mr, Mi, Vrr, Vri, Vii)]
-                coef = norm.coef(*stats)
+            inv = 1.0 / float(N * S)
+            check(L.rfx_cplx_coef_fwd(_ptr(sums), inv, None, *[_ptr(t) for t in pw], norm.eps, Cc, _ptr(coefc), None,
+                                      _ptr(norm.RMr), _ptr(norm.RMi), _ptr(norm.RVrr), _ptr(norm.RVri), _ptr(norm.RVii),
+                                      norm.momentum, _stream()), "rfx_cplx_coef_fwd")
             with torch.no_grad():
                 norm.num_batches_tracked += 1
-                for buf, v in zip((norm.RMr, norm.RMi, norm.RVrr, norm.RVri, norm.RVii), stats):
-                    buf.lerp_(v.detach(), norm.momentum)
-            ctx.graph = (mom, coef)
+            ctx.stat = (sums, inv, None)
         else:
-            with torch.enable_grad():
-                coef = norm.coef(norm.RMr, norm.RMi, norm.RVrr, norm.RVri, norm.RVii)
-            ctx.graph = (None, coef)
-        coefc = coef.detach().contiguous()
+            stats_in = torch.stack([norm.RMr, norm.RMi, norm.RVrr, norm.RVri, norm.RVii]).float().contiguous()
+            check(L.rfx_cplx_coef_fwd(None, 0.0, _ptr(stats_in), *[_ptr(t) for t in pw], norm.eps, Cc, _ptr(coefc), None,
+                                      None, None, None, None, None, 0.0, _stream()), "rfx_cplx_coef_fwd")
+            ctx.stat = (None, 0.0, stats_in)
         dst = dst.t if dst is not None else torch.empty_like(y)
         assert dst.shape == y.shape and dst.stride(1) == S and dst.stride(3) == 1
         check(L.rfx_cplx_affine_act_fwd(_ptr(y), _ptr(coefc), N, Cc, S, LEAKY, _ptr(dst), dst.stride(0), Cc, _stream()),
               "rfx_cplx_affine_act_fwd")
-        ctx.save_for_backward(y, coefc)
+        ctx.save_for_backward(y, coefc, *pw)
         ctx.norm = norm
         return dst
 
     @staticmethod
     def backward(ctx, g):
         L = _lib.lib()
-        y, coefc = ctx.saved_tensors
+        y, coefc, *pw = ctx.saved_tensors
         norm = ctx.norm
         N, C2, H, W = y.shape
         Cc, S = C2 // 2, H * W
@@ -190,15 +190,16 @@ class _CplxNormActFn(torch.autograd.Function):
         gcoef = torch.empty((6, Cc), device=y.device, dtype=torch.float32)
         check(L.rfx_cplx_affine_act_bwd(_ptr(y), _ptr(coefc), _ptr(g), g.stride(0), Cc, N, Cc, S, LEAKY, _ptr(gx),
                                         _ptr(gcoef), _stream()), "rfx_cplx_affine_act_bwd")
-        mom, coef = ctx.graph
-        params = [norm.Wrr, norm.Wri, norm.Wii, norm.Br, norm.Bi]
-        wrt = params + ([mom] if mom is not None else [])
-        grads = torch.autograd.grad(coef, wrt, gcoef, allow_unused=True)
-        if mom is not None:
-            cm = (grads[-1] / float(N * S)).float().contiguous()                   # (5, C)
+        sums, inv, stats_in = ctx.stat
+        gw = torch.empty((5, Cc), device=y.device, dtype=torch.float32)
+        cm = torch.empty((5, Cc), device=y.device, dtype=torch.float32) if sums is not None else None
+        check(L.rfx_cplx_coef_bwd(_ptr(sums) if sums is not None else None, inv, _ptr(stats_in) if stats_in is not None else None,
+                                  *[_ptr(t) for t in pw], norm.eps, Cc, _ptr(gcoef), _ptr(gw), _ptr(cm) if cm is not None else None,
+                                  _stream()), "rfx_cplx_coef_bwd")
+        if cm is not None:
             check(L.rfx_cplx_moments_bwd(_ptr(y), _ptr(cm), N, Cc, S, _ptr(gx), _stream()), "rfx_cplx_moments_bwd")
-        ctx.graph = None
-        return (gx, None, None) + tuple(grads[:5])
+        ctx.stat = None
+        return (gx, None, None, gw[0], gw[1], gw[2], gw[3], gw[4])
 
 
 def _norm_act(y, norm, dst=None):

@@ -1,5 +1,5 @@
-"""Dev tool: is a Demucs training step bound by the host?  Times (a) the Python thread enqueueing one step (return of opt.step(), no
-synchronisation inside) and (b) the same step to GPU completion, plus a cProfile of the enqueue path.   python scripts/host_time.py [B]"""
+"""Dev tool: is a training step bound by the host?  Times (a) the Python thread enqueueing one step (return of opt.step(), no
+synchronisation inside) and (b) the same step to GPU completion, plus a cProfile of the enqueue path.   python scripts/host_time.py [B] [demucs|dcunet|umx|tcn]"""
 import sys, os, time, cProfile, pstats, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,9 +7,10 @@ from remfx_amd import ops
 import bench
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+WORK = sys.argv[2] if len(sys.argv) > 2 else "demucs"
 dev = torch.device("cuda:0")
-ops.set_gemm_precision("bf16")
-model = bench.build_model("demucs", dev)
+ops.set_gemm_precision("bf16" if WORK == "demucs" else "bf16x3")
+model = bench.build_model(WORK, dev)
 opt = model.configure_optimizers()["optimizer"]
 data = bench.synthetic_batch(B, 0, dev)
 
