@@ -273,7 +273,10 @@ def pack_a(dp, w, out=None):
 # ops.weights_changed() after such a write, or run with RFX_PACK_CACHE=0.
 # (Rebuilding all entries on a side stream right after the optimiser step, so that a training step finds them ready, was built and
 # measured SLOWER: 137.4 -> 141.8-146.9 ms at 64 clips, 39.5 -> 41.5-42.4 ms at 8 -- the cache therefore pays in inference and
-# wherever a weight is used more than once between updates; a training step still packs each weight once per use.)
+# wherever a weight is used more than once between updates; a training step still packs each weight once per use.  Re-packing all
+# plain weights in ONE launch on the compute stream right after the optimiser step (device descriptor table, in place) was also
+# built: 136.3 -> 138.7 ms at 64 clips -- the pack kernels' cost is their gather (a lane per output row: 64 cache lines per wave
+# load), not their launches, so one big launch in front of the forward pass is slower than 218 small ones spread through the step.)
 PACK_CACHE = _os.environ.get("RFX_PACK_CACHE", "1") != "0"
 PACK_CACHE_BYTES = 6 << 30
 _PACKS = {}
