@@ -527,6 +527,58 @@ int rfx_clip_coef(const double* sumsq, float max_norm, float pre, float* coef, f
 int rfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                    float eps, float wd, int32_t step, const float* gscale, void* stream);
 
+/* ---- channels-last bf16 family (round 5; bf16 arithmetic mode = BASELINE config 3, trainer.precision=bf16-mixed) --------------
+ * The frequency branch of Hybrid Demucs (torchaudio HDemucs freq_encoder / freq_decoder reached from remfx/models.py:308,317)
+ * keeps its activations as [N][A][B][C] bf16 with the channels of one position contiguous: an MFMA B fragment is then one
+ * 16-byte group, so operands go global -> LDS by DMA (`buffer_load ... lds`) with no per-element work and results leave through
+ * an LDS transpose as full lines.  Every kernel of the family reads / writes such tensors; strides are in ELEMENTS. */
+typedef struct rfx_cl_tensor {
+  void* p;               /* bf16 [N][A][B][bs]; NULL = absent */
+  int64_t ns, as;        /* element strides of n and of a row (a); a position (b) is bs elements */
+  int32_t bs, c0;        /* channels stored per position; first channel this operand addresses */
+} rfx_cl_tensor;
+
+enum rfx_cl_epi {
+  RFX_CL_STORE = 0,      /* out0 = v                                   (v = acc + bias [+ res]) */
+  RFX_CL_GELU = 1,       /* out0 = v (may be absent), out1 = gelu(v) [+ aux0]   (encoder conv; decoder conv_tr + next skip) */
+  RFX_CL_GLU = 2,        /* rows interleaved (a_c, b_c): out0 = v in natural order [a | b] (may be absent), out1 = a * sigmoid(b) */
+  RFX_CL_DGELU = 3,      /* out0 = v (may be absent), out1 = v * gelu'(aux0)    (backward of GELU_ADD: skip gradient + pre-activation gradient) */
+  RFX_CL_DGLU = 4        /* aux0 = stored [a | b] of the forward GLU: out0 = [v * sigmoid(b) | v * a * sigmoid(b) (1 - sigmoid(b))] */
+};
+
+/* Implicit-GEMM convolution on channels-last operands (forward of Conv2d / ConvTranspose2d and their input gradients):
+ *   acc[m](n, oa, b) = sum over row taps r, chunks c, column taps t, channels k of the chunk
+ *                      W[m][r][c][t][k] * in[n][oa*SA + da[r]][b + db[t]][16 KS c + k]             (0 outside the tensor)
+ * A workgroup (8 waves) owns BM rows x 256 consecutive b of one (n, oa); the reduction is cut into UNITS (r, c) of NTC column taps x
+ * KS K steps of 16 channels whose B slab (256 [+ halo] positions x 16 KS channels) and packed A block arrive by LDS DMA through a
+ * 2- or 3-deep ring, one workgroup barrier per unit.  OB == IB, OB % 256 == 0; row taps whose input row falls outside [0, IA) are skipped.
+ * wrapb != 0: the B axis continues into the neighbouring row (1-D signals stored as [A][256]): halo columns come from linear memory
+ * and only the sample's ends read as zero.
+ * Merged phases (G > 1): GEMM row m = psi * Co + co is stored at output row oa * G + psi + g_off (dropped outside [0, OAo)),
+ * channel co -- ConvTranspose2d with stride G along A, and the input gradient of a stride-G Conv2d, as ONE GEMM over 2 row taps. */
+typedef struct rfx_cl_conv_desc {
+  rfx_cl_tensor in;
+  int32_t N, IA, IB, OA, OB, SA;
+  int32_t NTR, NCH, NTC, KS;   /* row taps, channel chunks of 16 KS channels (coff = 16 KS c), column taps, K steps per chunk and tap */
+  int32_t da0, da_step;   /* da[r] = da0 + r * da_step */
+  int32_t db0, db_step;   /* db[t] = db0 + t * db_step, |db| <= 8 */
+  int32_t wrapb;
+  const void* apack;      /* rfx_cl_pack output: [NTR * NCH][MG][NTC][KS][BM / 32] 1-KiB MFMA A fragments */
+  int32_t M, BM;          /* GEMM rows; rows per workgroup: 32, 64, 96 or 192 */
+  int32_t mode;           /* enum rfx_cl_epi */
+  int32_t G, g_off, OAo, Co;
+  const float* bias;      /* the layer's bias in ITS channel order (GLU: [a | b]; merged: [Co]), or NULL */
+  rfx_cl_tensor out0, out1, aux0, res;
+} rfx_cl_conv_desc;
+int rfx_cl_conv(const rfx_cl_conv_desc* d, void* stream);
+/* dst[i] = bf16(idx[i] < 0 ? 0 : src[idx[i]]): weights -> packed MFMA fragments (idx built once per layer by the host planner) */
+int rfx_cl_pack(const float* src, const int32_t* idx, int64_t n, void* dst, void* stream);
+/* channel-major fp32 / bf16 (N, C, A, B) [strides in elements, B contiguous] <-> channels-last bf16; B % 32 == 0, C % 8 == 0 */
+int rfx_cl_from_cm(const void* src, int32_t src_bf16, int64_t s_ns, int64_t s_cs, int64_t s_as, int32_t N, int32_t C, int32_t A,
+                   int32_t B, const rfx_cl_tensor* dst, void* stream);
+int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int32_t A, int32_t B, void* dst, int32_t dst_bf16, int64_t d_ns,
+                 int64_t d_cs, int64_t d_as, void* stream);
+
 int rfx_abi_version(void);
 /* channel tiles per wave the MFMA forward kernel should use for M output rows and reduction length K
  * (0 = thin path; short-K, output-bound problems get R = 1 for occupancy);

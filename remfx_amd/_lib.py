@@ -94,6 +94,20 @@ class StftDesc(C.Structure):
                [(n, C.c_float) for n in ("scale", "eps", "alpha")]
 
 
+class ClTensor(C.Structure):
+    """rfx_cl_tensor: a channels-last bf16 operand [N][A][B][bs] (include/remfx_hip.h)."""
+    _fields_ = [("p", C.c_void_p), ("ns", C.c_int64), ("as_", C.c_int64), ("bs", C.c_int32), ("c0", C.c_int32)]
+
+
+class ClConvDesc(C.Structure):
+    _fields_ = [("inp", ClTensor)] + \
+               [(n, C.c_int32) for n in ("N", "IA", "IB", "OA", "OB", "SA", "NTR", "NCH", "NTC", "KS", "da0", "da_step", "db0",
+                                         "db_step", "wrapb")] + \
+               [("apack", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("M", "BM", "mode", "G", "g_off", "OAo", "Co")] + \
+               [("bias", C.c_void_p), ("out0", ClTensor), ("out1", ClTensor), ("aux0", ClTensor), ("res", ClTensor)]
+
+
 _P, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
 # name -> argtypes; every symbol include/remfx_hip.h declares must be listed here
 SIGNATURES = {
@@ -180,6 +194,10 @@ SIGNATURES = {
     "rfx_lstm_fwd": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P],
     "rfx_lstm_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _P],
     "rfx_channel_sum": [_P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _P, _P],
+    "rfx_cl_conv": [C.POINTER(ClConvDesc), _P],
+    "rfx_cl_pack": [_P, _P, _I64, _P, _P],
+    "rfx_cl_from_cm": [_P, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, C.POINTER(ClTensor), _P],
+    "rfx_cl_to_cm": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _P, _I32, _I64, _I64, _I64, _P],
 }
 
 _lib = None

@@ -1,0 +1,208 @@
+"""Channels-last bf16 trunk of the frequency branch of Hybrid Demucs (bf16 arithmetic mode = BASELINE config 3,
+`trainer.precision=bf16-mixed`; torchaudio HDemucs `freq_encoder` / `freq_decoder` behind remfx/models.py:308,317).
+
+Tensors here are torch.bfloat16 of shape (N, A, B, C), contiguous, C % 8 == 0: the channels of one position are contiguous, so an
+MFMA operand fragment is one 16-byte group and the kernels (csrc/cl_conv.hip, cl_wgrad.hip, cl_elem.hip) move operands global ->
+LDS by DMA.  This module holds the host side: the packing index of every layer form (which weight element lands in which MFMA
+fragment cell), descriptors, and the autograd nodes of the encoder / decoder chains.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import ClConvDesc, ClTensor, check
+
+EPI = {"store": 0, "gelu": 1, "glu": 2, "dgelu": 3, "dglu": 4}
+
+
+def _stream():
+    return C.c_void_p(ops.raw_stream())
+
+
+def cl_tensor(t, c0=0):
+    """rfx_cl_tensor view of a (N, A, B, C) bf16 tensor whose last two axes are dense (stride(3) == 1, stride(2) == C_stored)."""
+    ct = ClTensor()
+    if t is None:
+        return ct
+    if t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(3) != 1 or not t.is_cuda:
+        raise ValueError(f"channels-last operand must be a 4-D bf16 GPU tensor with dense channels (got {t.dtype}, {tuple(t.shape)}, {t.stride()})")
+    ct.p = t.data_ptr()
+    ct.ns, ct.as_, ct.bs, ct.c0 = t.stride(0), t.stride(1), t.stride(2), c0
+    return ct
+
+
+def empty(N, A, B, Cc, device):
+    return torch.empty((N, A, B, Cc), device=device, dtype=torch.bfloat16)
+
+
+def from_cm(x, out=None):
+    """(N, C, A, B) fp32 / bf16 channel-major (B contiguous) -> (N, A, B, C) bf16 channels-last."""
+    N, Cc, A, B = x.shape
+    if x.stride(3) != 1:
+        x = x.contiguous()
+    if out is None:
+        out = empty(N, A, B, Cc, x.device)
+    ct = cl_tensor(out)
+    check(_lib.lib().rfx_cl_from_cm(C.c_void_p(x.data_ptr()), int(x.dtype == torch.bfloat16), x.stride(0), x.stride(1), x.stride(2),
+                                    N, Cc, A, B, C.byref(ct), _stream()), "rfx_cl_from_cm")
+    return out
+
+
+def to_cm(x, dtype=torch.float32, out=None):
+    """(N, A, B, C) bf16 channels-last -> (N, C, A, B) channel-major fp32 / bf16."""
+    N, A, B, Cc = x.shape
+    if out is None:
+        out = torch.empty((N, Cc, A, B), device=x.device, dtype=dtype)
+    ct = cl_tensor(x)
+    check(_lib.lib().rfx_cl_to_cm(C.byref(ct), N, Cc, A, B, C.c_void_p(out.data_ptr()), int(out.dtype == torch.bfloat16),
+                                  out.stride(0), out.stride(1), out.stride(2), _stream()), "rfx_cl_to_cm")
+    return out
+
+
+# ---- tile choice ----------------------------------------------------------------------------------------------------------------
+def pick_bm(M):
+    """Rows per workgroup: 192 (two wave rows of 96) for the wide layers, else the smallest of 32 / 64 / 96 that holds M in
+    the fewest tiles."""
+    if M > 96:
+        return 192 if (M % 192 == 0 or M > 288) else 96
+    if M > 64:
+        return 96
+    if M > 32:
+        return 64
+    return 32
+
+
+class ConvForm:
+    """One GEMM form of a layer: geometry of rfx_cl_conv + the gather index that packs its weight tensor.
+
+    widx(m, r, t, ch) -> flat element index into the weight tensor (numpy int64 arrays broadcast together), -1 where the GEMM cell is
+    structurally zero."""
+
+    def __init__(self, M, Cin, NTR, NTC, da0, da_step, db0, db_step, SA, widx, G=1, g_off=0, Co=0, KS=None):
+        self.M, self.Cin, self.NTR, self.NTC = M, Cin, NTR, NTC
+        self.da0, self.da_step, self.db0, self.db_step, self.SA = da0, da_step, db0, db_step, SA
+        self.G, self.g_off, self.Co = G, g_off, (Co or M)
+        self.BM = pick_bm(M)
+        self.MG = -(-M // self.BM)
+        if KS is None:
+            KS = 1 if NTC > 1 else (2 if Cin % 32 == 0 else 1)
+        self.KS = KS
+        if Cin % (16 * KS):
+            raise ValueError(f"channels-last GEMM: {Cin} input channels are not a multiple of {16 * KS}")
+        self.NCH = Cin // (16 * KS)
+        self.idx = self._build_index(widx)
+        self._dev = {}
+
+    def _build_index(self, widx):
+        MT = self.BM // 32
+        U = self.NTR * self.NCH
+        shape = (self.NTR, self.NCH, self.MG, self.NTC, self.KS, MT, 64, 8)
+        r, c, mg, t, ks, mt, lane, e = np.meshgrid(*[np.arange(s, dtype=np.int64) for s in shape], indexing="ij", sparse=True)
+        m = mg * self.BM + mt * 32 + (lane & 31)
+        ch = c * (16 * self.KS) + ks * 16 + 8 * (lane >> 5) + e
+        ok = (m < self.M) & (ch < self.Cin)
+        m_c = np.minimum(m, self.M - 1)
+        ch_c = np.minimum(ch, self.Cin - 1)
+        idx = np.broadcast_to(widx(m_c, r, t, ch_c), shape)
+        idx = np.where(np.broadcast_to(ok, shape), idx, -1)
+        assert idx.size == U * self.MG * self.NTC * self.KS * MT * 512
+        return np.ascontiguousarray(idx.reshape(-1).astype(np.int32))
+
+
+def _dev_index(form, device):
+    """The form's gather index on `device` (uploaded once; kept on the form object, whose lifetime it shares)."""
+    key = str(device)
+    v = form._dev.get(key)
+    if v is None:
+        v = torch.from_numpy(form.idx).to(device)
+        form._dev[key] = v
+    return v
+
+
+def pack(form, w):
+    """Packed MFMA A fragments (bf16) of weight tensor w for one GEMM form: one gather launch."""
+    idx = _dev_index(form, w.device)
+    wf = w if w.is_contiguous() else w.contiguous()
+    out = torch.empty(idx.numel(), device=w.device, dtype=torch.bfloat16)
+    check(_lib.lib().rfx_cl_pack(C.c_void_p(wf.data_ptr()), C.c_void_p(idx.data_ptr()), idx.numel(), C.c_void_p(out.data_ptr()),
+                                 _stream()), "rfx_cl_pack")
+    return out
+
+
+def conv(form, apack, x, N, IA, IB, OA, mode, bias=None, out0=None, out1=None, aux0=None, res=None, OAo=0, x_c0=0, wrapb=False):
+    """Launch rfx_cl_conv for `form` on the channels-last operand x; outputs / auxiliaries are channels-last tensors."""
+    d = ClConvDesc()
+    d.inp = cl_tensor(x, x_c0)
+    d.N, d.IA, d.IB, d.OA, d.OB, d.SA = N, IA, IB, OA, IB, form.SA
+    d.NTR, d.NCH, d.NTC, d.KS = form.NTR, form.NCH, form.NTC, form.KS
+    d.da0, d.da_step, d.db0, d.db_step = form.da0, form.da_step, form.db0, form.db_step
+    d.wrapb = int(wrapb)
+    d.apack = apack.data_ptr()
+    d.M, d.BM, d.mode = form.M, form.BM, EPI[mode]
+    d.G, d.g_off, d.OAo, d.Co = form.G, form.g_off, OAo, form.Co
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.out0, d.out1, d.aux0, d.res = cl_tensor(out0), cl_tensor(out1), cl_tensor(aux0), cl_tensor(res)
+    check(_lib.lib().rfx_cl_conv(C.byref(d), _stream()), "rfx_cl_conv")
+
+
+# ---- GEMM forms of the Hybrid Demucs layers ---------------------------------------------------------------------------------------
+def form_conv_glu(Cout2, Cin, KA, KB):
+    """Conv2d(Cin -> Cout2, (KA, KB), padding same) + GLU: GEMM rows interleaved (a_c, b_c); weight (Cout2, Cin, KA, KB)."""
+    Ch = Cout2 // 2
+
+    def widx(m, r, t, ch):
+        oc = (m & 1) * Ch + (m >> 1)
+        return ((oc * Cin + ch) * KA + r) * KB + t
+    return ConvForm(Cout2, Cin, KA, KB, -(KA // 2), 1, -(KB // 2), 1, 1, widx)
+
+
+def form_conv_dgrad(Cout, Cin, KA, KB):
+    """Input gradient of Conv2d(Cin -> Cout, (KA, KB), stride 1, padding same): rows = Cin, reduction over Cout; weight (Cout, Cin, KA, KB)."""
+    def widx(m, r, t, ch):
+        return ((ch * Cin + m) * KA + (KA - 1 - r)) * KB + (KB - 1 - t)
+    return ConvForm(Cin, Cout, KA, KB, -(KA // 2), 1, -(KB // 2), 1, 1, widx)
+
+
+def form_conv(Cout, Cin, KA, KB):
+    """Conv2d(Cin -> Cout, (KA, KB), stride 1, padding same), rows in natural order."""
+    def widx(m, r, t, ch):
+        return ((m * Cin + ch) * KA + r) * KB + t
+    return ConvForm(Cout, Cin, KA, KB, -(KA // 2), 1, -(KB // 2), 1, 1, widx)
+
+
+def form_convtr_s4(Cin, Cout):
+    """ConvTranspose2d(Cin -> Cout, (8, 1), stride (4, 1)) cropped by 2 rows on each side, as ONE GEMM over 2 row taps: super-row q
+    (0 .. IA) produces output rows 4 q + psi - 2, psi = 0..3, from input rows q - 1 (kernel tap psi + 4) and q (tap psi).
+    Weight (Cin, Cout, 8, 1).  Rows m = psi * Cout + co."""
+    def widx(m, r, t, ch):
+        psi, co = m // Cout, m % Cout
+        k = psi + 4 * (1 - r)                      # r = 0: input row q - 1; r = 1: input row q
+        return (ch * Cout + co) * 8 + k
+    return ConvForm(4 * Cout, Cin, 2, 1, -1, 1, 0, 0, 1, widx, G=4, g_off=-2, Co=Cout)
+
+
+def form_conv_s4(Cout, Cin):
+    """Conv2d(Cin -> Cout, (8, 1), stride (4, 1), padding (2, 0)): 8 row taps, input row 4 oa + k - 2.  Weight (Cout, Cin, 8, 1).
+    Also the input gradient of form_convtr_s4's layer when called with its weight transposed (see form_convtr_s4_dgrad)."""
+    def widx(m, r, t, ch):
+        return (m * Cin + ch) * 8 + r
+    return ConvForm(Cout, Cin, 8, 1, -2, 1, 0, 0, 4, widx)
+
+
+def form_convtr_s4_dgrad(Cin, Cout):
+    """Input gradient of the ConvTranspose2d above: dy[ia][ci] = sum_k sum_co w[ci][co][k] dz[4 ia + k - 2][co]."""
+    def widx(m, r, t, ch):
+        return (m * Cout + ch) * 8 + r
+    return ConvForm(Cin, Cout, 8, 1, -2, 1, 0, 0, 4, widx)
+
+
+def form_conv_s4_dgrad(Cout, Cin):
+    """Input gradient of Conv2d(Cin -> Cout, (8, 1), stride (4, 1), padding (2, 0)) as a merged 2-row-tap GEMM (the transposed
+    convolution): rows m = rho * Cin + ci, output row 4 q + rho - 2 from gradient rows q - 1 (tap rho + 4) and q (tap rho)."""
+    def widx(m, r, t, ch):
+        rho, ci = m // Cin, m % Cin
+        k = rho + 4 * (1 - r)
+        return (ch * Cin + ci) * 8 + k
+    return ConvForm(4 * Cin, Cout, 2, 1, -1, 1, 0, 0, 1, widx, G=4, g_off=-2, Co=Cin)
