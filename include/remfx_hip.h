@@ -579,6 +579,29 @@ int rfx_cl_from_cm(const void* src, int32_t src_bf16, int64_t s_ns, int64_t s_cs
 int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int32_t A, int32_t B, void* dst, int32_t dst_bf16, int64_t d_ns,
                  int64_t d_cs, int64_t d_as, void* stream);
 
+/* Weight gradients on channels-last operands, deterministic (no atomics):
+ *   D[m][(r, t, c)] = sum over (n, oa, b) of P[n][oa][b][m] * Q[n][oa*SA + da0 + r][b + db0 + t*db_step][c]     (Q = 0 outside)
+ * = dW of Conv2d / ConvTranspose2d with P, Q = (output gradient, input) or (input, output gradient).  rfx_cl_wgrad cuts the
+ * positions into S splits x D tiles (32 RW rows x the (tap, channel) columns of a CW-channel slice of Q); every workgroup leaves
+ * its fp32 accumulators in its own slot of `ws` (rfx_cl_wgrad_ws_floats floats).  rfx_cl_wgrad_reduce sums the slots in a fixed
+ * order and writes / accumulates through `map` (host-built: flat weight index per accumulator cell, wn + m = bias gradient m,
+ * -1 = none) -- replaces the fp32 atomicAdd weight gradients of csrc/gemm_wgrad.h for the layers on this layout.
+ * Call sites replaced: torch autograd of nn.Conv2d / nn.ConvTranspose2d weights inside torchaudio HDemucs (remfx/models.py:308,317). */
+typedef struct rfx_cl_wgrad_desc {
+  rfx_cl_tensor p, q;
+  int32_t N, OA, IA, B;          /* rows of P, rows of Q, positions per row (B % 64 == 0) */
+  int32_t SA, da0, NTR;          /* row taps: Q row oa*SA + da0 + r, r < NTR, SA <= NTR */
+  int32_t NTC, db0, db_step;     /* column taps, |db| <= 8 */
+  int32_t M, Cq, CW;             /* D rows (channels of P from p.c0); channels of Q (from q.c0); Q channels per D tile (% 16 == 0) */
+  int32_t RW, WK;                /* 32-row tiles per D tile (2 | 3); K split inside a workgroup (1 | 2 | 4) */
+  int32_t S, ahead, bias;        /* position splits (every split non-empty); prefetch distance in steps; 1 = also sum P over positions */
+  float* ws;
+} rfx_cl_wgrad_desc;
+int64_t rfx_cl_wgrad_ws_floats(const rfx_cl_wgrad_desc* d);
+int rfx_cl_wgrad(const rfx_cl_wgrad_desc* d, void* stream);
+int rfx_cl_wgrad_reduce(const float* ws, const int32_t* map, int64_t nmap, int32_t S, int32_t DT, int32_t RW, int32_t WK, float* dw,
+                        int64_t wn, float* db, int32_t accumulate, void* stream);
+
 int rfx_abi_version(void);
 /* channel tiles per wave the MFMA forward kernel should use for M output rows and reduction length K
  * (0 = thin path; short-K, output-bound problems get R = 1 for occupancy);

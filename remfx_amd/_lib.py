@@ -108,6 +108,13 @@ class ClConvDesc(C.Structure):
                [("bias", C.c_void_p), ("out0", ClTensor), ("out1", ClTensor), ("aux0", ClTensor), ("res", ClTensor)]
 
 
+class ClWgradDesc(C.Structure):
+    _fields_ = [("p", ClTensor), ("q", ClTensor)] + \
+               [(n, C.c_int32) for n in ("N", "OA", "IA", "B", "SA", "da0", "NTR", "NTC", "db0", "db_step", "M", "Cq", "CW", "RW", "WK",
+                                         "S", "ahead", "bias")] + \
+               [("ws", C.c_void_p)]
+
+
 _P, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
 # name -> argtypes; every symbol include/remfx_hip.h declares must be listed here
 SIGNATURES = {
@@ -196,10 +203,14 @@ SIGNATURES = {
     "rfx_channel_sum": [_P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _P, _P],
     "rfx_cl_conv": [C.POINTER(ClConvDesc), _P],
     "rfx_cl_pack": [_P, _P, _I64, _P, _P],
+    "rfx_cl_wgrad_ws_floats": [_P],
+    "rfx_cl_wgrad": [_P, _P],
+    "rfx_cl_wgrad_reduce": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _I32, _P],
     "rfx_cl_from_cm": [_P, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, C.POINTER(ClTensor), _P],
     "rfx_cl_to_cm": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _P, _I32, _I64, _I64, _I64, _P],
 }
 
+_RET64 = {"rfx_cl_wgrad_ws_floats"}
 _lib = None
 
 
@@ -221,7 +232,7 @@ def lib():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(L, name)          # AttributeError if the export is missing
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name in _RET64 else C.c_int
     if L.rfx_abi_version() != 1:
         raise RuntimeError("libremfx_hip ABI version mismatch")
     _lib = L

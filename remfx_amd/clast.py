@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import ClConvDesc, ClTensor, check
+from ._lib import ClConvDesc, ClTensor, ClWgradDesc, check
 
 EPI = {"store": 0, "gelu": 1, "glu": 2, "dgelu": 3, "dglu": 4}
 
@@ -206,3 +206,140 @@ def form_conv_s4_dgrad(Cout, Cin):
         k = rho + 4 * (1 - r)
         return (ch * Cin + ci) * 8 + k
     return ConvForm(4 * Cin, Cout, 2, 1, -1, 1, 0, 0, 1, widx, G=4, g_off=-2, Co=Cin)
+
+
+# ---- weight gradients -------------------------------------------------------------------------------------------------------------
+class WgradForm:
+    """One weight-gradient GEMM (csrc/cl_wgrad.hip): D[m][(r, t, c)] = sum_pos P[pos][m] * Q[pos shifted by tap (r, t)][c].
+
+    widx(m, r, t, c) -> flat index of that cell in the layer's weight tensor.  Chooses the tiling (rows per D tile, Q-channel slice,
+    wave arrangement, prefetch depth) and builds the index map the fixed-order reduction scatters through."""
+
+    LDS_MAX = 160 * 1024
+
+    def __init__(self, M, Cq, NTR, NTC, SA, da0, db0, db_step, widx, wn, bias=True):
+        self.M, self.Cq, self.NTR, self.NTC, self.SA, self.da0, self.db0, self.db_step = M, Cq, NTR, NTC, SA, da0, db0, db_step
+        self.wn, self.bias = wn, bias
+        self.RW = 3 if M > 64 else 2
+        T = NTR * NTC
+        nb = 1 if bias else 0
+        best = None
+        for CW in (96, 80, 64, 48, 32, 16):
+            if CW > -(-Cq // 16) * 16:
+                continue
+            tiles = -(-(T * CW // 16) // 2) + nb
+            if tiles > 16:
+                continue
+            ctn = -(-Cq // CW)
+            cost = (ctn, ctn * CW - Cq)
+            if best is None or cost < best[0]:
+                best = (cost, CW, tiles)
+        if best is None:
+            raise ValueError(f"channels-last weight gradient: no tiling for {T} taps x {Cq} channels")
+        _, self.CW, tiles = best
+        self.WK = 1 if tiles > 8 else (2 if tiles > 4 else 4)
+        self.WC = 8 // self.WK
+        self.MTn, self.CTn = -(-M // (32 * self.RW)), -(-Cq // self.CW)
+        self.DT = self.MTn * self.CTn
+        hb = max(abs(db0 + t * db_step) for t in range(NTC))
+        NP = 4 * self.RW
+        NQ = -(-((64 + 2 * hb) * self.CW * 2) // 1024)
+        PPW = -(-(NP + SA * NQ) // 8)
+        self.ahead = None
+        for ahead in (6, 5, 4, 3, 2, 1):
+            R = -(-(NTR + ahead * SA) // SA) * SA
+            if (ahead + 1) * NP * 1024 + R * NQ * 1024 <= self.LDS_MAX and (ahead - 1) * PPW <= 24:
+                self.ahead = ahead
+                break
+        if self.ahead is None:
+            raise ValueError("channels-last weight gradient: tile does not fit LDS")
+        self.map = self._build_map(widx)
+        self._dev = {}
+
+    def _build_map(self, widx):
+        RW, NT, WC = self.RW, 2, self.WC
+        NCG = self.CW // 16
+        HN = self.NTR * self.NTC * NCG
+        bias_tile = -(-HN // 2)
+        shape = (self.MTn, self.CTn, WC, RW, NT, 16, 64)
+        mt, ct, cw, i, t, r, lane = np.meshgrid(*[np.arange(s, dtype=np.int64) for s in shape], indexing="ij", sparse=True)
+        m = mt * 32 * RW + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        l31 = lane & 31
+        tile = cw * NT + t
+        hh = 2 * tile + (l31 >> 4)
+        cgl, tt = hh % NCG, hh // NCG
+        tc, tr = tt % self.NTC, tt // self.NTC
+        c = ct * self.CW + cgl * 16 + (l31 & 15)
+        ok = (hh < HN) & (m < self.M) & (c < self.Cq)
+        idx = widx(np.minimum(m, self.M - 1), np.minimum(tr, self.NTR - 1), tc, np.minimum(c, self.Cq - 1))
+        out = np.where(np.broadcast_to(ok, shape), np.broadcast_to(idx, shape), -1)
+        if self.bias:
+            isb = (tile == bias_tile) & (l31 == 0) & (ct == 0) & (m < self.M)
+            out = np.where(np.broadcast_to(isb, shape), np.broadcast_to(self.wn + m, shape), out)
+        flat = out.reshape(-1)
+        used = flat[flat >= 0]
+        assert used.size == np.unique(used).size, "weight-gradient map: a destination is written twice"
+        return np.ascontiguousarray(flat.astype(np.int32))
+
+    def splits(self, steps):
+        """Position splits: about two workgroups per CU in all, every split non-empty."""
+        S = max(1, min(steps, -(-512 // self.DT)))
+        sps = -(-steps // S)
+        return -(-steps // sps)
+
+
+def _dev_map(form, device):
+    key = str(device)
+    v = form._dev.get(key)
+    if v is None:
+        v = torch.from_numpy(form.map).to(device)
+        form._dev[key] = v
+    return v
+
+
+def wgrad(form, p, q, N, OA, IA, B, dw, db=None, accumulate=False, p_c0=0, q_c0=0):
+    """dw (flat fp32 view of the weight gradient, form.wn elements) and db (fp32, form.M) from the channels-last operands p
+    (N, OA, B, >= M channels) and q (N, IA, B, >= Cq channels).  Two launches: partial sums per position split, then the fixed-order
+    reduction (deterministic: no atomics)."""
+    if form.bias and db is None:
+        raise ValueError("this weight-gradient form carries the bias gradient: pass db")
+    d = ClWgradDesc()
+    d.p, d.q = cl_tensor(p, p_c0), cl_tensor(q, q_c0)
+    d.N, d.OA, d.IA, d.B = N, OA, IA, B
+    d.SA, d.da0, d.NTR, d.NTC, d.db0, d.db_step = form.SA, form.da0, form.NTR, form.NTC, form.db0, form.db_step
+    d.M, d.Cq, d.CW, d.RW, d.WK = form.M, form.Cq, form.CW, form.RW, form.WK
+    d.S = form.splits(N * (B // 64) * OA)
+    d.ahead, d.bias = form.ahead, int(form.bias)
+    L = _lib.lib()
+    nws = L.rfx_cl_wgrad_ws_floats(C.byref(d))
+    if nws <= 0:
+        raise RuntimeError("rfx_cl_wgrad: geometry rejected")
+    ws = torch.empty(nws, device=p.device, dtype=torch.float32)
+    d.ws = ws.data_ptr()
+    check(L.rfx_cl_wgrad(C.byref(d), _stream()), "rfx_cl_wgrad")
+    mp = _dev_map(form, p.device)
+    check(L.rfx_cl_wgrad_reduce(C.c_void_p(ws.data_ptr()), C.c_void_p(mp.data_ptr()), mp.numel(), d.S, form.DT, form.RW, form.WK,
+                                C.c_void_p(dw.data_ptr()), form.wn, C.c_void_p(db.data_ptr()) if db is not None else None,
+                                int(accumulate), _stream()), "rfx_cl_wgrad_reduce")
+
+
+def wform_conv(Cout, Cin, KA, KB):
+    """dW of Conv2d(Cin -> Cout, (KA, KB), stride 1, padding same): P = output gradient (Cout), Q = input (Cin); weight (Cout, Cin, KA, KB)."""
+    def widx(m, r, t, c):
+        return ((m * Cin + c) * KA + r) * KB + t
+    return WgradForm(Cout, Cin, KA, KB, 1, -(KA // 2), -(KB // 2), 1, widx, Cout * Cin * KA * KB)
+
+
+def wform_conv_s4(Cout, Cin):
+    """dW of Conv2d(Cin -> Cout, (8, 1), stride (4, 1), padding (2, 0)): P = output gradient, Q = input rows 4 oa + k - 2."""
+    def widx(m, r, t, c):
+        return (m * Cin + c) * 8 + r
+    return WgradForm(Cout, Cin, 8, 1, 4, -2, 0, 0, widx, Cout * Cin * 8)
+
+
+def wform_convtr_s4(Cin, Cout):
+    """dW of ConvTranspose2d(Cin -> Cout, (8, 1), stride (4, 1)) cropped by 2 rows: P = layer input (Cin), Q = output gradient rows
+    4 ia + k - 2 (Cout); weight (Cin, Cout, 8, 1).  The bias gradient (a sum of Q) is not this GEMM's: bias=False."""
+    def widx(m, r, t, c):
+        return (m * Cout + c) * 8 + r
+    return WgradForm(Cin, Cout, 8, 1, 4, -2, 0, 0, widx, Cin * Cout * 8, bias=False)

@@ -193,3 +193,72 @@ def test_conv_s4_forward_and_dgrad(Cin, Cout, OA, N):
     _close(_cm(dzrw), zq.grad, "skip add + glu backward", ulps=4.0,
            mag=torch.cat([torch.sigmoid(zq[:, Cin:]), (zq[:, :Cin] * torch.sigmoid(zq[:, Cin:]) * (1 - torch.sigmoid(zq[:, Cin:]))).abs()], 1).detach()
            * (_r(xv.grad).abs() + _r(gskip).abs()).repeat(1, 2, 1, 1))
+
+
+def _wclose(got, ref, what):
+    """fp32 weight gradients of bf16 operands: the products are exact, only the fp32 accumulation order differs."""
+    ref = ref.to(torch.float64)
+    got = got.detach().cpu().to(torch.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    rms = float(((got - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    print(f"{what}: max err / max {err:.3e}, rel rms {rms:.3e}")
+    assert err < 2e-4 and rms < 2e-5, what
+
+
+@pytest.mark.parametrize("Cin,Cout,KA,A,N", [(48, 96, 3, 5, 2), (96, 192, 3, 3, 1), (192, 384, 3, 2, 1), (48, 96, 1, 4, 2), (96, 192, 1, 2, 1),
+                                              (96, 48, 3, 3, 1), (32, 48, 3, 2, 1)])
+def test_wgrad_conv(Cin, Cout, KA, A, N):
+    """dW, db of a stride-1 convolution (3x3 / 1x1) from channels-last operands; deterministic (two runs bit-equal)."""
+    from remfx_amd import clast
+    g = torch.Generator().manual_seed(5)
+    B = 256
+    x = torch.randn(N, Cin, A, B, generator=g)
+    dz = torch.randn(N, Cout, A, B, generator=g)
+    form = clast.wform_conv(Cout, Cin, KA, KA)
+    dw = torch.full((Cout, Cin, KA, KA), 7.0, device=DEV)
+    db = torch.full((Cout,), 7.0, device=DEV)
+    xc, gc = _cl(x), _cl(dz)
+    clast.wgrad(form, gc, xc, N, A, A, B, dw, db)
+    torch.cuda.synchronize()
+    w = torch.zeros(Cout, Cin, KA, KA, dtype=torch.float64, requires_grad=True)
+    bb = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(_r(x), w, bb, padding=KA // 2).backward(_r(dz))
+    _wclose(dw, w.grad, "dW")
+    _wclose(db, bb.grad, "db")
+    dw2 = dw.clone()
+    db2 = db.clone()
+    clast.wgrad(form, gc, xc, N, A, A, B, dw2, db2, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, 2 * dw) and torch.equal(db2, 2 * db)
+
+
+@pytest.mark.parametrize("Cin,Cout,OA,N", [(48, 96, 3, 2), (96, 192, 5, 1), (192, 384, 2, 1)])
+def test_wgrad_conv_s4_and_convtr(Cin, Cout, OA, N):
+    """dW of the encoder's Conv2d((8, 1), stride (4, 1), padding (2, 0)) and of the decoder's cropped ConvTranspose2d((8, 1), stride (4, 1))."""
+    from remfx_amd import clast
+    g = torch.Generator().manual_seed(6)
+    B = 256
+    IA = 4 * OA
+    x = torch.randn(N, Cin, IA, B, generator=g)
+    dz = torch.randn(N, Cout, OA, B, generator=g)
+    form = clast.wform_conv_s4(Cout, Cin)
+    dw = torch.empty(Cout, Cin, 8, 1, device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    clast.wgrad(form, _cl(dz), _cl(x), N, OA, IA, B, dw, db)
+    torch.cuda.synchronize()
+    w = torch.zeros(Cout, Cin, 8, 1, dtype=torch.float64, requires_grad=True)
+    bb = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(_r(x), w, bb, stride=(4, 1), padding=(2, 0)).backward(_r(dz))
+    _wclose(dw, w.grad, "conv_s4 dW")
+    _wclose(db, bb.grad, "conv_s4 db")
+    # transposed convolution Cout -> Cin (coarse rows OA -> fine rows 4 OA): P = its input, Q = its output gradient
+    y = torch.randn(N, Cout, OA, B, generator=g)
+    dzt = torch.randn(N, Cin, IA, B, generator=g)
+    ft = clast.wform_convtr_s4(Cout, Cin)
+    dwt = torch.empty(Cout, Cin, 8, 1, device=DEV)
+    clast.wgrad(ft, _cl(y), _cl(dzt), N, OA, IA, B, dwt)
+    torch.cuda.synchronize()
+    wt = torch.zeros(Cout, Cin, 8, 1, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(_r(y), wt, None, stride=(4, 1))[:, :, 2:2 + IA].backward(_r(dzt))
+    _wclose(dwt, wt.grad, "conv_tr dW")
