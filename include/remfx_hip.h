@@ -543,7 +543,7 @@ enum rfx_cl_epi {
   RFX_CL_GELU = 1,       /* out0 = v (may be absent), out1 = gelu(v) [+ aux0]   (encoder conv; decoder conv_tr + next skip) */
   RFX_CL_GLU = 2,        /* rows interleaved (a_c, b_c): out0 = v in natural order [a | b] (may be absent), out1 = a * sigmoid(b) */
   RFX_CL_DGELU = 3,      /* out0 = v (may be absent), out1 = v * gelu'(aux0)    (backward of GELU_ADD: skip gradient + pre-activation gradient) */
-  RFX_CL_DGLU = 4        /* aux0 = stored [a | b] of the forward GLU: out0 = [v * sigmoid(b) | v * a * sigmoid(b) (1 - sigmoid(b))] */
+  RFX_CL_DGLU = 4        /* aux0 = stored [a | b] of the forward GLU: out0 = [v * sigmoid(b) | v * a * sigmoid(b) (1 - sigmoid(b))]; out1 = v (optional) */
 };
 
 /* Implicit-GEMM convolution on channels-last operands (forward of Conv2d / ConvTranspose2d and their input gradients):
@@ -568,14 +568,17 @@ typedef struct rfx_cl_conv_desc {
   int32_t mode;           /* enum rfx_cl_epi */
   int32_t G, g_off, OAo, Co;
   const float* bias;      /* the layer's bias in ITS channel order (GLU: [a | b]; merged: [Co]), or NULL */
+  const float* rowadd;    /* RFX_CL_GLU only: fp32 [OA][M / 2] added to out1 (a per-row vector: the frequency embedding), or NULL */
   rfx_cl_tensor out0, out1, aux0, res;
 } rfx_cl_conv_desc;
 int rfx_cl_conv(const rfx_cl_conv_desc* d, void* stream);
 /* dst[i] = bf16(idx[i] < 0 ? 0 : src[idx[i]]): weights -> packed MFMA fragments (idx built once per layer by the host planner) */
 int rfx_cl_pack(const float* src, const int32_t* idx, int64_t n, void* dst, void* stream);
-/* channel-major fp32 / bf16 (N, C, A, B) [strides in elements, B contiguous] <-> channels-last bf16; B % 32 == 0, C % 8 == 0 */
+/* channel-major fp32 / bf16 (N, C, A, B) [strides in elements, B contiguous] <-> channels-last bf16; B % 64 == 0, C % 8 == 0.
+ * rfx_cl_from_cm fuses what would follow the conversion: v = src (+ res); mode 0: dst = v; 1: dst = v * gelu'(aux);
+ * 2: GLU backward against aux = stored [a | b] (2 C channels), dst = [v * sigmoid(b) | v * a * sigmoid(b) (1 - sigmoid(b))]. */
 int rfx_cl_from_cm(const void* src, int32_t src_bf16, int64_t s_ns, int64_t s_cs, int64_t s_as, int32_t N, int32_t C, int32_t A,
-                   int32_t B, const rfx_cl_tensor* dst, void* stream);
+                   int32_t B, const rfx_cl_tensor* dst, const rfx_cl_tensor* res, const rfx_cl_tensor* aux, int32_t mode, void* stream);
 int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int32_t A, int32_t B, void* dst, int32_t dst_bf16, int64_t d_ns,
                  int64_t d_cs, int64_t d_as, void* stream);
 
@@ -601,6 +604,11 @@ int64_t rfx_cl_wgrad_ws_floats(const rfx_cl_wgrad_desc* d);
 int rfx_cl_wgrad(const rfx_cl_wgrad_desc* d, void* stream);
 int rfx_cl_wgrad_reduce(const float* ws, const int32_t* map, int64_t nmap, int32_t S, int32_t DT, int32_t RW, int32_t WK, float* dw,
                         int64_t wn, float* db, int32_t accumulate, void* stream);
+
+/* out[a][c] (+)= scale * sum over (n, b) of x[n][a][b][c], deterministic (G fixed-order partials of A * C floats each in `partial`):
+ * bias gradients (A = 1, rows folded into N) and the frequency-embedding gradient of Hybrid Demucs. */
+int rfx_cl_rowsum(const rfx_cl_tensor* x, int32_t N, int32_t A, int32_t B, int32_t C, int32_t G, float scale, float* partial, float* out,
+                  int32_t accumulate, void* stream);
 
 int rfx_abi_version(void);
 /* channel tiles per wave the MFMA forward kernel should use for M output rows and reduction length K

@@ -105,7 +105,7 @@ class ClConvDesc(C.Structure):
                                          "db_step", "wrapb")] + \
                [("apack", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("M", "BM", "mode", "G", "g_off", "OAo", "Co")] + \
-               [("bias", C.c_void_p), ("out0", ClTensor), ("out1", ClTensor), ("aux0", ClTensor), ("res", ClTensor)]
+               [("bias", C.c_void_p), ("rowadd", C.c_void_p), ("out0", ClTensor), ("out1", ClTensor), ("aux0", ClTensor), ("res", ClTensor)]
 
 
 class ClWgradDesc(C.Structure):
@@ -206,7 +206,9 @@ SIGNATURES = {
     "rfx_cl_wgrad_ws_floats": [_P],
     "rfx_cl_wgrad": [_P, _P],
     "rfx_cl_wgrad_reduce": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _I32, _P],
-    "rfx_cl_from_cm": [_P, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, C.POINTER(ClTensor), _P],
+    "rfx_cl_from_cm": [_P, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, C.POINTER(ClTensor), C.POINTER(ClTensor), C.POINTER(ClTensor),
+                       _I32, _P],
+    "rfx_cl_rowsum": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _I32, C.c_float, _P, _P, _I32, _P],
     "rfx_cl_to_cm": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _P, _I32, _I64, _I64, _I64, _P],
 }
 

@@ -37,16 +37,21 @@ def empty(N, A, B, Cc, device):
     return torch.empty((N, A, B, Cc), device=device, dtype=torch.bfloat16)
 
 
-def from_cm(x, out=None):
-    """(N, C, A, B) fp32 / bf16 channel-major (B contiguous) -> (N, A, B, C) bf16 channels-last."""
+FROM_CM_MODE = {"store": 0, "dgelu": 1, "dglu": 2}
+
+
+def from_cm(x, out=None, res=None, aux=None, mode="store"):
+    """(N, C, A, B) fp32 / bf16 channel-major (any strides with B contiguous) -> (N, A, B, C) bf16 channels-last, fused with what
+    would follow: v = x (+ res); "store": v; "dgelu": v * gelu'(aux); "dglu": GLU backward against aux = stored [a | b] (out then
+    has 2 C channels)."""
     N, Cc, A, B = x.shape
     if x.stride(3) != 1:
         x = x.contiguous()
     if out is None:
-        out = empty(N, A, B, Cc, x.device)
-    ct = cl_tensor(out)
+        out = empty(N, A, B, 2 * Cc if mode == "dglu" else Cc, x.device)
+    ct, cr, ca = cl_tensor(out), cl_tensor(res), cl_tensor(aux)
     check(_lib.lib().rfx_cl_from_cm(C.c_void_p(x.data_ptr()), int(x.dtype == torch.bfloat16), x.stride(0), x.stride(1), x.stride(2),
-                                    N, Cc, A, B, C.byref(ct), _stream()), "rfx_cl_from_cm")
+                                    N, Cc, A, B, C.byref(ct), C.byref(cr), C.byref(ca), FROM_CM_MODE[mode], _stream()), "rfx_cl_from_cm")
     return out
 
 
@@ -131,7 +136,8 @@ def pack(form, w):
     return out
 
 
-def conv(form, apack, x, N, IA, IB, OA, mode, bias=None, out0=None, out1=None, aux0=None, res=None, OAo=0, x_c0=0, wrapb=False):
+def conv(form, apack, x, N, IA, IB, OA, mode, bias=None, out0=None, out1=None, aux0=None, res=None, OAo=0, x_c0=0, wrapb=False,
+         rowadd=None):
     """Launch rfx_cl_conv for `form` on the channels-last operand x; outputs / auxiliaries are channels-last tensors."""
     d = ClConvDesc()
     d.inp = cl_tensor(x, x_c0)
@@ -143,6 +149,7 @@ def conv(form, apack, x, N, IA, IB, OA, mode, bias=None, out0=None, out1=None, a
     d.M, d.BM, d.mode = form.M, form.BM, EPI[mode]
     d.G, d.g_off, d.OAo, d.Co = form.G, form.g_off, OAo, form.Co
     d.bias = bias.data_ptr() if bias is not None else None
+    d.rowadd = rowadd.data_ptr() if rowadd is not None else None
     d.out0, d.out1, d.aux0, d.res = cl_tensor(out0), cl_tensor(out1), cl_tensor(aux0), cl_tensor(res)
     check(_lib.lib().rfx_cl_conv(C.byref(d), _stream()), "rfx_cl_conv")
 

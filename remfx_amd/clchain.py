@@ -1,0 +1,307 @@
+"""Channels-last bf16 trunk of Hybrid Demucs' frequency branch (bf16 arithmetic mode = BASELINE config 3): the autograd nodes that
+chain the kernels of csrc/cl_conv.hip / cl_wgrad.hip / cl_elem.hip over the norm-free layers of torchaudio HDemucs'
+`freq_encoder` / `freq_decoder` (reference call site remfx/models.py:308,317).
+
+Between those layers the activations stay (N, Fr, T, C) bf16.  What an elementwise pass used to do happens in the store of the GEMM
+that produces its operand: GLU, GELU (+ the next skip add), and in the backward pass the GELU / GLU derivatives and the skip-gradient
+add.  Three node types cover the branch:
+
+  EncMidFn    DConv_i output -> rewrite 1x1 + GLU (+ frequency embedding) = skip e_i -> conv (8, 1) / 4 + GELU -> DConv_{i+1} input
+  EncTailFn   DConv_J output -> rewrite 1x1 + GLU = skip e_J (channels-last) and the channel-major copy the normalised layers read
+  FreqDecoderFn  deep output + skips e_J .. e_0 -> [rewrite 3x3 + GLU -> conv_tr (8, 1) / 4 + GELU + next skip] x J -> rewrite 3x3 + GLU
+
+The DConv residual branches between them keep their own kernels (csrc/dconv.hip, norm.hip) on (N * Fr, C, T) fp32 samples; the
+layout conversion at their ends is fused with the neighbouring elementwise step (rfx_cl_from_cm modes).  Weight gradients are
+deterministic (fixed-order split reduction) and go straight into the GradSink slice when one is armed.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, clast, ops
+from ._lib import check
+
+_FORMS = {}
+_BUILD = {
+    "glu": clast.form_conv_glu, "dgrad": clast.form_conv_dgrad, "s4": clast.form_conv_s4, "s4d": clast.form_conv_s4_dgrad,
+    "tr": clast.form_convtr_s4, "trd": clast.form_convtr_s4_dgrad, "w": clast.wform_conv, "ws4": clast.wform_conv_s4,
+    "wtr": clast.wform_convtr_s4,
+}
+
+
+def form(kind, *a):
+    key = (kind,) + a
+    f = _FORMS.get(key)
+    if f is None:
+        f = _BUILD[kind](*a)
+        _FORMS[key] = f
+    return f
+
+
+_PACKS = {}
+
+
+def packed(f, w):
+    """MFMA fragments of weight w for GEMM form f, re-packed when the weight changed (ops.weights_changed / torch version)."""
+    key = (id(f), w.data_ptr(), ops.raw_stream())
+    try:
+        ver = w._version
+    except RuntimeError:
+        ver = None
+    e = _PACKS.get(key)
+    if e is not None and ver is not None and e[0] == ver and e[1] == ops._WEIGHT_EPOCH[0] and e[3] is f:
+        return e[2]
+    ap = clast.pack(f, w.detach())
+    if ver is not None:
+        _PACKS[key] = (ver, ops._WEIGHT_EPOCH[0], ap, f)
+    return ap
+
+
+def clear_packs():
+    _PACKS.clear()
+
+
+def rowsum(x, A, Cc, out, scale=1.0, accumulate=False):
+    """out[a][c] (+)= scale * sum_{n, b} x[n][a][b][c] for a contiguous channels-last x; A == 1 folds the rows into n."""
+    N, XA, B, XC = x.shape
+    ct = clast.cl_tensor(x)
+    if A == 1 and XA != 1:
+        if not x.is_contiguous():
+            raise ValueError("rowsum: folding rows needs a contiguous tensor")
+        N, ct.ns = N * XA, ct.as_
+    G = max(1, min(N, -(-2048 // A)))
+    partial = torch.empty((G, A, Cc), device=x.device, dtype=torch.float32)
+    check(_lib.lib().rfx_cl_rowsum(C.byref(ct), N, A, B, Cc, G, float(scale), C.c_void_p(partial.data_ptr()), C.c_void_p(out.data_ptr()),
+                                   int(accumulate), C.c_void_p(ops.raw_stream())), "rfx_cl_rowsum")
+    return out
+
+
+def _wgrad(f, p, q, N, OA, IA, B, w, b, bias_src=None):
+    """Weight (and bias) gradient of one layer: into the armed GradSink's slices on its side stream (returns None, None), else fresh
+    tensors for autograd.  bias_src: the channels-last tensor whose position sum is the bias gradient when the GEMM form does not
+    carry it (transposed convolutions: the bias gradient sums Q, not P)."""
+    sink = ops.SINK
+    tw = sink.lookup(w) if sink is not None else None
+    tb = sink.lookup(b) if (tw is not None and b is not None) else None
+    if tw is not None and (b is None or tb is not None):
+        with torch.cuda.stream(sink.stream_for_wgrad(p, q)):
+            clast.wgrad(f, p, q, N, OA, IA, B, tw[1], tb[1] if (f.bias and b is not None) else _scratch_bias(f, p), accumulate=True)
+            if b is not None and not f.bias:
+                rowsum(bias_src, 1, b.numel(), tb[1], accumulate=True)
+        sink.wrote(tw[0])
+        if b is not None:
+            sink.wrote(tb[0])
+        return None, None
+    dw = torch.empty(w.shape, device=w.device, dtype=torch.float32)
+    db = torch.empty(b.shape, device=w.device, dtype=torch.float32) if b is not None else None
+    clast.wgrad(f, p, q, N, OA, IA, B, dw, db if (f.bias and b is not None) else _scratch_bias(f, p))
+    if b is not None and not f.bias:
+        rowsum(bias_src, 1, b.numel(), db)
+    return dw, db
+
+
+def _scratch_bias(f, p):
+    return torch.empty(f.M, device=p.device, dtype=torch.float32) if f.bias else None
+
+
+def _as_ncab(x3, Bn, A):
+    """(Bn * A, C, T) sample-major tensor -> (Bn, C, A, T) strided view (no copy)."""
+    NA, Cc, T = x3.shape
+    return x3.view(Bn, A, Cc, T).permute(0, 2, 1, 3)
+
+
+class EncMidFn(torch.autograd.Function):
+    """d_i (Bn * A_i, C_i, T) fp32 -> e_i channels-last (Bn, A_i, T, C_i), y_{i+1} (Bn * A_i / 4, 2 C_i, T) fp32."""
+
+    @staticmethod
+    def forward(ctx, d, rw_w, rw_b, cv_w, cv_b, emb_rows, Bn):
+        NA, Cc, T = d.shape
+        A = NA // Bn
+        C1, A1 = cv_w.shape[0], A // 4
+        dev = d.device
+        train = any(ctx.needs_input_grad)
+        d_cl = clast.from_cm(_as_ncab(d, Bn, A))
+        zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
+        e = clast.empty(Bn, A, T, Cc, dev)
+        fg = form("glu", 2 * Cc, Cc, 1, 1)
+        clast.conv(fg, packed(fg, rw_w), d_cl, Bn, A, T, A, "glu", bias=rw_b, out0=zab, out1=e,
+                   rowadd=emb_rows.contiguous() if emb_rows is not None else None)
+        fs = form("s4", C1, Cc)
+        z1 = clast.empty(Bn, A1, T, C1, dev) if train else None
+        y1 = clast.empty(Bn, A1, T, C1, dev)
+        clast.conv(fs, packed(fs, cv_w), e, Bn, A, T, A1, "gelu", bias=cv_b, out0=z1, out1=y1)
+        y_cm = torch.empty((Bn * A1, C1, T), device=dev, dtype=torch.float32)
+        clast.to_cm(y1, out=_as_ncab(y_cm, Bn, A1))
+        if train:
+            ctx.save_for_backward(d_cl, zab, e, z1, rw_w, cv_w)
+            ctx.refs = (rw_b, cv_b)
+            ctx.geom = (Bn, A, T, Cc, C1, A1, emb_rows is not None)
+        return e, y_cm
+
+    @staticmethod
+    def backward(ctx, g_e, g_y):
+        d_cl, zab, e, z1, rw_w, cv_w = ctx.saved_tensors
+        rw_b, cv_b = ctx.refs
+        Bn, A, T, Cc, C1, A1, has_emb = ctx.geom
+        dev = d_cl.device
+        # gradient of the next DConv's input -> channels-last, times gelu'(z1)
+        dz1 = clast.empty(Bn, A1, T, C1, dev)
+        clast.from_cm(_as_ncab(g_y if g_y.is_contiguous() else g_y.contiguous(), Bn, A1), out=dz1, aux=z1, mode="dgelu")
+        dcw, dcb = _wgrad(form("ws4", C1, Cc), dz1, e, Bn, A1, A, T, cv_w, cv_b)
+        # conv input gradient + skip gradient, GLU backward against the stored [a | b]
+        fd = form("s4d", C1, Cc)
+        dzab = clast.empty(Bn, A, T, 2 * Cc, dev)
+        v = clast.empty(Bn, A, T, Cc, dev) if has_emb else None
+        clast.conv(fd, packed(fd, cv_w), dz1, Bn, A1, T, A1 + 1, "dglu", out0=dzab, out1=v, aux0=zab,
+                   res=(g_e if g_e.is_contiguous() else g_e.contiguous()) if g_e is not None else None, OAo=A)
+        demb = None
+        if has_emb:
+            demb = torch.empty((A, Cc), device=dev, dtype=torch.float32)
+            rowsum(v, A, Cc, demb)
+        drw, drb = _wgrad(form("w", 2 * Cc, Cc, 1, 1), dzab, d_cl, Bn, A, A, T, rw_w, rw_b)
+        fr = form("dgrad", 2 * Cc, Cc, 1, 1)
+        dd_cl = clast.empty(Bn, A, T, Cc, dev)
+        clast.conv(fr, packed(fr, rw_w), dzab, Bn, A, T, A, "store", out0=dd_cl)
+        dd = torch.empty((Bn * A, Cc, T), device=dev, dtype=torch.float32)
+        clast.to_cm(dd_cl, out=_as_ncab(dd, Bn, A))
+        return dd, drw, drb, dcw, dcb, demb, None
+
+
+class EncTailFn(torch.autograd.Function):
+    """d_J (Bn * A, C, T) fp32 -> e_J channels-last (the skip) and e_J (Bn, C, A, T) fp32 (what the normalised layer above reads)."""
+
+    @staticmethod
+    def forward(ctx, d, rw_w, rw_b, Bn):
+        NA, Cc, T = d.shape
+        A = NA // Bn
+        dev = d.device
+        train = any(ctx.needs_input_grad)
+        d_cl = clast.from_cm(_as_ncab(d, Bn, A))
+        zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
+        e = clast.empty(Bn, A, T, Cc, dev)
+        fg = form("glu", 2 * Cc, Cc, 1, 1)
+        clast.conv(fg, packed(fg, rw_w), d_cl, Bn, A, T, A, "glu", bias=rw_b, out0=zab, out1=e)
+        e_cm = clast.to_cm(e)
+        if train:
+            ctx.save_for_backward(d_cl, zab, rw_w)
+            ctx.refs = (rw_b,)
+            ctx.geom = (Bn, A, T, Cc)
+        return e, e_cm
+
+    @staticmethod
+    def backward(ctx, g_e, g_cm):
+        d_cl, zab, rw_w = ctx.saved_tensors
+        (rw_b,) = ctx.refs
+        Bn, A, T, Cc = ctx.geom
+        dev = d_cl.device
+        if g_cm is None:
+            raise RuntimeError("EncTailFn: the channel-major output carries no gradient")
+        if g_cm.stride(3) != 1:
+            g_cm = g_cm.contiguous()
+        dzab = clast.empty(Bn, A, T, 2 * Cc, dev)
+        clast.from_cm(g_cm, out=dzab, res=g_e, aux=zab, mode="dglu")
+        drw, drb = _wgrad(form("w", 2 * Cc, Cc, 1, 1), dzab, d_cl, Bn, A, A, T, rw_w, rw_b)
+        fr = form("dgrad", 2 * Cc, Cc, 1, 1)
+        dd_cl = clast.empty(Bn, A, T, Cc, dev)
+        clast.conv(fr, packed(fr, rw_w), dzab, Bn, A, T, A, "store", out0=dd_cl)
+        dd = torch.empty((Bn * A, Cc, T), device=dev, dtype=torch.float32)
+        clast.to_cm(dd_cl, out=_as_ncab(dd, Bn, A))
+        return dd, drw, drb, None
+
+
+class FreqDecoderFn(torch.autograd.Function):
+    """x (Bn, C_J, A_J, T) fp32 from the normalised layers, skips e_J .. e_0 channels-last, then per layer j = J .. 1 the weights
+    (rewrite w, b, conv_tr w, b) and the last layer's rewrite (w, b).  Returns y_0 = GLU(rewrite_0(.)) as (Bn, C_0, A_0, T) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, nsk, *rest):
+        skips, params = rest[:nsk], rest[nsk:]
+        J = nsk - 1
+        Bn, CJ, AJ, T = x.shape
+        dev = x.device
+        train = any(ctx.needs_input_grad)
+        if x.stride(3) != 1:
+            x = x.contiguous()
+        xin = clast.from_cm(x, res=skips[0])
+        saved = []
+        A, Cc = AJ, CJ
+        for k in range(J):                                      # layer j = J - k
+            rw_w, rw_b, ct_w, ct_b = params[4 * k:4 * k + 4]
+            Cn = ct_w.shape[1]
+            fg = form("glu", 2 * Cc, Cc, 3, 3)
+            zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
+            y = clast.empty(Bn, A, T, Cc, dev)
+            clast.conv(fg, packed(fg, rw_w), xin, Bn, A, T, A, "glu", bias=rw_b, out0=zab, out1=y)
+            ft = form("tr", Cc, Cn)
+            zt = clast.empty(Bn, 4 * A, T, Cn, dev) if train else None
+            nxt = clast.empty(Bn, 4 * A, T, Cn, dev)
+            clast.conv(ft, packed(ft, ct_w), y, Bn, A, T, A + 1, "gelu", bias=ct_b, out0=zt, out1=nxt, aux0=skips[k + 1], OAo=4 * A)
+            saved += [xin, zab, y, zt]
+            xin, A, Cc = nxt, 4 * A, Cn
+        rw_w, rw_b = params[4 * J:4 * J + 2]
+        fg = form("glu", 2 * Cc, Cc, 3, 3)
+        zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
+        y0 = clast.empty(Bn, A, T, Cc, dev)
+        clast.conv(fg, packed(fg, rw_w), xin, Bn, A, T, A, "glu", bias=rw_b, out0=zab, out1=y0)
+        saved += [xin, zab]
+        out = clast.to_cm(y0)
+        if train:
+            ctx.save_for_backward(*saved, *[p for p in params])
+            ctx.nsaved = len(saved)
+            ctx.geom = (Bn, AJ, CJ, T, J)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Bn, AJ, CJ, T, J = ctx.geom
+        saved, params = ctx.saved_tensors[:ctx.nsaved], ctx.saved_tensors[ctx.nsaved:]
+        dev = g.device
+        if g.stride(3) != 1:
+            g = g.contiguous()
+        grads_p = [None] * len(params)
+        grads_sk = [None] * (J + 1)
+        # layer 0: GLU backward fused with the layout conversion of the incoming gradient
+        A, Cc = AJ * 4 ** J, CJ // 2 ** J
+        xin, zab = saved[4 * J], saved[4 * J + 1]
+        dzab = clast.empty(Bn, A, T, 2 * Cc, dev)
+        clast.from_cm(g, out=dzab, aux=zab, mode="dglu")
+        for k in range(J, -1, -1):                              # rewrite of layer j = J - k, walking up from layer 0 (k = J)
+            rw_w, rw_b = params[4 * k], params[4 * k + 1]
+            grads_p[4 * k], grads_p[4 * k + 1] = _wgrad(form("w", 2 * Cc, Cc, 3, 3), dzab, xin, Bn, A, A, T, rw_w, rw_b)
+            fd = form("dgrad", 2 * Cc, Cc, 3, 3)
+            gx = clast.empty(Bn, A, T, Cc, dev)
+            if k == 0:
+                clast.conv(fd, packed(fd, rw_w), dzab, Bn, A, T, A, "store", out0=gx)
+                grads_sk[0] = gx
+                break
+            # this layer's input = gelu(z') + skip of the layer above: skip gradient = gx, pre-activation gradient = gx * gelu'(z')
+            xin_u, zab_u, y_u, zt_u = saved[4 * (k - 1):4 * (k - 1) + 4]
+            dzt = clast.empty(Bn, A, T, Cc, dev)
+            clast.conv(fd, packed(fd, rw_w), dzab, Bn, A, T, A, "dgelu", out0=gx, out1=dzt, aux0=zt_u)
+            grads_sk[k] = gx
+            ct_w, ct_b = params[4 * (k - 1) + 2], params[4 * (k - 1) + 3]
+            Cu, Au = 2 * Cc, A // 4
+            grads_p[4 * (k - 1) + 2], grads_p[4 * (k - 1) + 3] = _wgrad(form("wtr", Cu, Cc), y_u, dzt, Bn, Au, A, T, ct_w, ct_b, bias_src=dzt)
+            ftd = form("trd", Cu, Cc)
+            dzab = clast.empty(Bn, Au, T, 2 * Cu, dev)
+            clast.conv(ftd, packed(ftd, ct_w), dzt, Bn, A, T, Au, "dglu", out0=dzab, aux0=zab_u)
+            xin, A, Cc = xin_u, Au, Cu
+        gx_cm = clast.to_cm(grads_sk[0])
+        return (gx_cm, None, *grads_sk, *grads_p)
+
+
+def enc_mid(d, rewrite, conv_next, emb_rows, Bn):
+    return EncMidFn.apply(d, rewrite.weight, rewrite.bias, conv_next.weight, conv_next.bias, emb_rows, Bn)
+
+
+def enc_tail(d, rewrite, Bn):
+    return EncTailFn.apply(d, rewrite.weight, rewrite.bias, Bn)
+
+
+def freq_decoder(x, skips, layers):
+    """skips: [e_J, ..., e_0]; layers: the _HDecLayer modules of layers J .. 0."""
+    params = []
+    for m in layers[:-1]:
+        params += [m.rewrite.weight, m.rewrite.bias, m.conv_tr.weight, m.conv_tr.bias]
+    params += [layers[-1].rewrite.weight, layers[-1].rewrite.bias]
+    return FreqDecoderFn.apply(x, len(skips), *skips, *params)

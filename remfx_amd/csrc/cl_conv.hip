@@ -270,6 +270,23 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
   const __amdgpu_buffer_rsrc_t rs0 = cl_rs_sample(d.out0, n), rs1 = cl_rs_sample(d.out1, n);
   const __amdgpu_buffer_rsrc_t rsx = cl_rs_sample(d.aux0, n), rsr = cl_rs_sample(d.res, n);
   const bool has0 = d.out0.p != nullptr, has_aux = d.aux0.p != nullptr, has_res = d.res.p != nullptr;
+  const bool has1 = d.out1.p != nullptr;
+  // GLU + per-row vector (the frequency embedding of Hybrid Demucs, added to the first encoder layer's output): the values of this
+  // lane's channels, position-independent
+  float ra[RW][4][2];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      ra[i][gq][0] = ra[i][gq][1] = 0.f;
+      if (mode == RFX_CL_GLU && d.rowadd != nullptr) {
+        const int c = (mrow0 >> 1) + 16 * i + 4 * gq + 2 * h;
+        if (c < Cglu) {
+          ra[i][gq][0] = d.rowadd[(int64_t)oa * Cglu + c];
+          ra[i][gq][1] = d.rowadd[(int64_t)oa * Cglu + c + 1];
+        }
+      }
+    }
 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -287,7 +304,8 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
           const int cl = 16 * i + 4 * gq + 2 * h;
           *reinterpret_cast<uint32_t*>(ez + l31 * Cfg::EPI_RS + cl * 2) = rfx_cvt_pk_bf16(v[0], v[2]);
           *reinterpret_cast<uint32_t*>(ez + l31 * Cfg::EPI_RS + (16 * RW + cl) * 2) = rfx_cvt_pk_bf16(v[1], v[3]);
-          *reinterpret_cast<uint32_t*>(ey + l31 * Cfg::EPI_RSY + cl * 2) = rfx_cvt_pk_bf16(v[0] * rfx_sigmoid(v[1]), v[2] * rfx_sigmoid(v[3]));
+          *reinterpret_cast<uint32_t*>(ey + l31 * Cfg::EPI_RSY + cl * 2) =
+              rfx_cvt_pk_bf16(v[0] * rfx_sigmoid(v[1]) + ra[i][gq][0], v[2] * rfx_sigmoid(v[3]) + ra[i][gq][1]);
         } else {
           *reinterpret_cast<uint2*>(ez + l31 * Cfg::EPI_RS + (32 * i + 8 * gq + 4 * h) * 2) =
               make_uint2(rfx_cvt_pk_bf16(v[0], v[1]), rfx_cvt_pk_bf16(v[2], v[3]));
@@ -376,6 +394,7 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
           const uint32_t ax = (uint32_t)(((int64_t)orow * d.aux0.as + (int64_t)bp * d.aux0.bs + ch) * 2);
           const int half = d.aux0.bs >> 1;
           float a[8], b[8], ga[8], gb[8];
+          if (has1) cl_bst(rs1, (uint32_t)(((int64_t)orow * d.out1.as + (int64_t)bp * d.out1.bs + ch) * 2), raw);   // the summed gradient itself
           cl_unpack8(cl_bld(rsx, ax), a);
           cl_unpack8(cl_bld(rsx, ax + half * 2), b);
 #pragma unroll

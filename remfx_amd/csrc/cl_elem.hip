@@ -4,9 +4,12 @@
 #include "cl_common.h"
 
 // (N, C, A, B) channel-major, B contiguous  ->  [N][A][B][bs] channels-last bf16.  Tile = 64 positions x 32 channels through LDS.
-template <typename T>
+// MODE: 0 store | 1 v * gelu'(aux) | 2 GLU backward against aux = stored [a | b] (dst carries 2 C channels: [ga | gb])
+// res (optional, any mode): v += res first.  v and the sum are rounded to bf16 where a stored tensor would have been (the fused
+// passes replace "convert, store, re-read" chains and keep their roundings).
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void cl_from_cm_kernel(const T* __restrict__ src, int64_t s_ns, int64_t s_cs, int64_t s_as, int C,
-                                                         int A, int B, uint16_t* __restrict__ dst, int64_t d_ns, int64_t d_as, int d_bs) {
+                                                         int A, int B, rfx_cl_tensor dst, rfx_cl_tensor res, rfx_cl_tensor aux) {
   __shared__ uint16_t tile[32][66];
   const int tpb = B / 64;
   const int pt = blockIdx.x, cgp = blockIdx.y;
@@ -24,7 +27,42 @@ __global__ __launch_bounds__(256) void cl_from_cm_kernel(const T* __restrict__ s
     uint32_t w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[g8 * 8 + 2 * e][pp] | ((uint32_t)tile[g8 * 8 + 2 * e + 1][pp] << 16);
-    *reinterpret_cast<uint4*>(dst + (int64_t)n * d_ns + (int64_t)a * d_as + (int64_t)(b0 + pp) * d_bs + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+    uint4 raw = make_uint4(w[0], w[1], w[2], w[3]);
+    auto at = [&](const rfx_cl_tensor& q, int ch) {
+      return reinterpret_cast<uint16_t*>(q.p) + (int64_t)n * q.ns + (int64_t)a * q.as + (int64_t)(b0 + pp) * q.bs + q.c0 + ch;
+    };
+    float v[8];
+    if (res.p != nullptr) {
+      float r[8];
+      cl_unpack8(raw, v);
+      cl_unpack8(*reinterpret_cast<const uint4*>(at(res, c0)), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+      raw = cl_pack8(v);
+    }
+    if (MODE == 0) {
+      *reinterpret_cast<uint4*>(at(dst, c0)) = raw;
+    } else if (MODE == 1) {
+      float z[8], o[8];
+      cl_unpack8(raw, v);
+      cl_unpack8(*reinterpret_cast<const uint4*>(at(aux, c0)), z);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = v[e] * rfx_gelu_grad(z[e]);
+      *reinterpret_cast<uint4*>(at(dst, c0)) = cl_pack8(o);
+    } else {
+      float fa[8], fb[8], ga[8], gb[8];
+      cl_unpack8(raw, v);
+      cl_unpack8(*reinterpret_cast<const uint4*>(at(aux, c0)), fa);
+      cl_unpack8(*reinterpret_cast<const uint4*>(at(aux, C + c0)), fb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sg = rfx_sigmoid(fb[e]);
+        ga[e] = v[e] * sg;
+        gb[e] = v[e] * fa[e] * sg * (1.f - sg);
+      }
+      *reinterpret_cast<uint4*>(at(dst, c0)) = cl_pack8(ga);
+      *reinterpret_cast<uint4*>(at(dst, C + c0)) = cl_pack8(gb);
+    }
   }
 }
 
@@ -56,17 +94,29 @@ __global__ __launch_bounds__(256) void cl_to_cm_kernel(const uint16_t* __restric
   }
 }
 
+template <typename T>
+static void cl_from_cm_launch(int mode, dim3 grid, hipStream_t st, const T* src, int64_t s_ns, int64_t s_cs, int64_t s_as, int C, int A,
+                              int B, const rfx_cl_tensor& dst, const rfx_cl_tensor& res, const rfx_cl_tensor& aux) {
+  if (mode == 0) hipLaunchKernelGGL((cl_from_cm_kernel<T, 0>), grid, dim3(256), 0, st, src, s_ns, s_cs, s_as, C, A, B, dst, res, aux);
+  else if (mode == 1) hipLaunchKernelGGL((cl_from_cm_kernel<T, 1>), grid, dim3(256), 0, st, src, s_ns, s_cs, s_as, C, A, B, dst, res, aux);
+  else hipLaunchKernelGGL((cl_from_cm_kernel<T, 2>), grid, dim3(256), 0, st, src, s_ns, s_cs, s_as, C, A, B, dst, res, aux);
+}
+
 extern "C" int rfx_cl_from_cm(const void* src, int32_t src_bf16, int64_t s_ns, int64_t s_cs, int64_t s_as, int32_t N, int32_t C,
-                              int32_t A, int32_t B, const rfx_cl_tensor* dst, void* stream) {
+                              int32_t A, int32_t B, const rfx_cl_tensor* dst, const rfx_cl_tensor* res, const rfx_cl_tensor* aux,
+                              int32_t mode, void* stream) {
   if (!src || !dst || !dst->p || N <= 0 || C <= 0 || A <= 0 || B <= 0 || B % 64 || C % 8 || dst->c0 % 8 || dst->bs % 8) return -1;
+  if (mode < 0 || mode > 2 || (mode != 0 && (!aux || !aux->p || aux->bs % 8 || aux->c0 % 8))) return -1;
+  if (res && res->p && (res->bs % 8 || res->c0 % 8)) return -1;
+  if (mode == 2 && (dst->bs < 2 * C || aux->bs < 2 * C)) return -1;
   const dim3 grid((unsigned)(N * A * (B / 64)), (unsigned)((C + 31) / 32));
-  uint16_t* d = reinterpret_cast<uint16_t*>(dst->p) + dst->c0;
+  const rfx_cl_tensor none = {nullptr, 0, 0, 0, 0};
+  const rfx_cl_tensor& r = (res && res->p) ? *res : none;
+  const rfx_cl_tensor& x = (aux && aux->p) ? *aux : none;
   if (src_bf16)
-    hipLaunchKernelGGL(cl_from_cm_kernel<rfx_bf16s>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const rfx_bf16s*>(src),
-                       s_ns, s_cs, s_as, C, A, B, d, dst->ns, dst->as, dst->bs);
+    cl_from_cm_launch(mode, grid, (hipStream_t)stream, reinterpret_cast<const rfx_bf16s*>(src), s_ns, s_cs, s_as, C, A, B, *dst, r, x);
   else
-    hipLaunchKernelGGL(cl_from_cm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(src), s_ns,
-                       s_cs, s_as, C, A, B, d, dst->ns, dst->as, dst->bs);
+    cl_from_cm_launch(mode, grid, (hipStream_t)stream, reinterpret_cast<const float*>(src), s_ns, s_cs, s_as, C, A, B, *dst, r, x);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -82,6 +132,60 @@ extern "C" int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int3
   else
     hipLaunchKernelGGL(cl_to_cm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s, src->ns, src->as, src->bs, C, A, B,
                        reinterpret_cast<float*>(dst), d_ns, d_cs, d_as);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ---- deterministic sums over positions ------------------------------------------------------------------------------------------
+// out[a][c] (+)= scale * sum over (n, b) of x[n][a][b][c]  (A = 1 with the rows folded into N: the per-channel sum = a bias
+// gradient; A = frequency rows: the gradient of the frequency embedding, torchaudio HDemucs `freq_emb`).  Stage 1: block (a, g)
+// sums the samples n = g, g + G, ... in a fixed order into partial[g][a][c]; stage 2 adds the G partials in order.  No atomics.
+__global__ __launch_bounds__(256) void cl_rowsum_partial_kernel(rfx_cl_tensor x, int N, int A, int B, int C, int G, float* __restrict__ partial) {
+  __shared__ float red[256][8];
+  const int a = blockIdx.x, g = blockIdx.y, t = threadIdx.x;
+  const int CG = C >> 3, PT = 256 / CG;                      // channel groups of 8, positions walked in parallel
+  const int grp = t % CG, pl = t / CG;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pl < PT) {
+    for (int n = g; n < N; n += G) {
+      const uint16_t* row = reinterpret_cast<const uint16_t*>(x.p) + (int64_t)n * x.ns + (int64_t)a * x.as + x.c0 + grp * 8;
+      for (int b = pl; b < B; b += PT) {
+        float v[8];
+        cl_unpack8(*reinterpret_cast<const uint4*>(row + (int64_t)b * x.bs), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[t][e] = acc[e];
+  __syncthreads();
+  if (t < C) {                                               // channel t: groups' partials of the PT position lanes, in order
+    const int gq = t >> 3, e = t & 7;
+    float s = 0.f;
+    for (int q = 0; q < PT; ++q) s += red[q * CG + gq][e];
+    partial[((int64_t)g * A + a) * C + t] = s;
+  }
+}
+__global__ __launch_bounds__(256) void cl_rowsum_final_kernel(const float* __restrict__ partial, int64_t n, int G, float scale,
+                                                              float* __restrict__ out, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += partial[(int64_t)g * n + i];
+  s *= scale;
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+extern "C" int rfx_cl_rowsum(const rfx_cl_tensor* x, int32_t N, int32_t A, int32_t B, int32_t C, int32_t G, float scale, float* partial,
+                             float* out, int32_t accumulate, void* stream) {
+  if (!x || !x->p || !partial || !out || N <= 0 || A <= 0 || B <= 0 || C <= 0 || C % 8 || C > 256 || G < 1 || x->bs % 8 || x->c0 % 8)
+    return -1;
+  hipLaunchKernelGGL(cl_rowsum_partial_kernel, dim3((unsigned)A, (unsigned)G), dim3(256), 0, (hipStream_t)stream, *x, N, A, B, C, G, partial);
+  const int64_t n = (int64_t)A * C;
+  hipLaunchKernelGGL(cl_rowsum_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, n, G, scale, out,
+                     accumulate);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -13,12 +13,17 @@ time branch (B, C, L) with L contiguous -- the gather-GEMM kernels take the posi
 axis from the contiguous dimension, so both branches are read coalesced.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import lstm, nnops, ops, stft
+from . import clchain, lstm, nnops, ops, stft
+
+# bf16 mode: the norm-free frequency layers run on the channels-last bf16 trunk (remfx_amd/clchain.py); RFX_CL_TRUNK=0 keeps the
+# channel-major kernels of rounds 1-4 for same-box A/B runs
+CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
 
 
 class _ScaledEmbedding(nn.Module):
@@ -205,6 +210,13 @@ class _HEncLayer(nn.Module):
         out = self._rest(y, inject)
         return (out, alias) if want_pair else out
 
+    def head(self, x):
+        """conv + GELU of a norm-free frequency layer as (B * Fr, C, T) samples, the DConv branch's input (channels-last trunk)."""
+        y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0), out_bf16=ENC_Z16)
+        y = ops.activation_to(y, "gelu", (0, 2, 1))
+        B, C, Fr, T = y.shape
+        return y.permute(0, 2, 1, 3).reshape(-1, C, T)
+
     def _rest(self, y, inject):
         if self.empty:
             return y
@@ -363,6 +375,25 @@ class HDemucs(nn.Module):
                 if m.bias is not None:
                     m.bias.data /= s
 
+    def _cl_layers(self, le, device):
+        """How many leading frequency layers take the channels-last bf16 trunk (0: none).  Conditions: bf16 arithmetic mode, whole
+        256-frame tiles, norm-free layers of the standard geometry (conv (8, 1) / 4 pad 2, 1x1 encoder rewrite, 3x3 decoder rewrite),
+        channel counts in whole 16-channel K steps."""
+        if not CL_TRUNK or ops.GEMM_PREC != 2 or device.type != "cuda" or le % 256 or le <= 0:
+            return 0
+        n, rows = 0, self.nfft // 2
+        for i, enc in enumerate(self.freq_encoder):
+            dec = self.freq_decoder[self.depth - 1 - i]
+            ok = (enc.freq and not enc.empty and enc.context == 0 and enc.kernel_size == 8 and enc.stride == 4 and enc.pad == 2
+                  and not isinstance(enc.norm1, nn.GroupNorm) and not isinstance(enc.norm2, nn.GroupNorm)
+                  and enc.conv.out_channels % 16 == 0 and rows % 4 == 0
+                  and dec.freq and not dec.empty and dec.context == 1 and dec.kernel_size == 8 and dec.stride == 4 and dec.pad == 2
+                  and not isinstance(dec.norm1, nn.GroupNorm) and not isinstance(dec.norm2, nn.GroupNorm))
+            if not ok:
+                break
+            n, rows = n + 1, rows // 4
+        return n if 2 <= n < self.depth else 0
+
     def forward(self, input):
         if input.ndim != 3 or input.shape[1] != self.audio_channels:
             raise ValueError(f"expected (batch, {self.audio_channels}, frames), got {tuple(input.shape)}")
@@ -381,6 +412,8 @@ class HDemucs(nn.Module):
         x, mean, std = nnops.row_standardize(x.detach(), 1e-5)      # over (C, Fr, T) per clip, unbiased std
         xt, meant, stdt = nnops.row_standardize(input, 1e-5)        # over (C, T) per clip
         saved, saved_t, lengths, lengths_t = [], [], [], []
+        Lc = self._cl_layers(le, input.device)
+        samp = None
         for idx, encode in enumerate(self.freq_encoder):
             lengths.append(x.shape[-1])
             inject = None
@@ -397,6 +430,16 @@ class HDemucs(nn.Module):
                     saved_t.append(xt)
                 else:
                     inject = xt
+            if idx < Lc:
+                # channels-last trunk: the DConv branch on (B * Fr, C, T) samples, everything between two branches in one node
+                d = encode.dconv(encode.head(x) if idx == 0 else samp)
+                if idx < Lc - 1:
+                    emb_rows = self.freq_emb.table() * self.freq_emb_scale if (idx == 0 and self.freq_emb is not None) else None
+                    e, samp = clchain.enc_mid(d, encode.rewrite, self.freq_encoder[idx + 1].conv, emb_rows, B)
+                else:
+                    e, x = clchain.enc_tail(d, encode.rewrite, B)
+                saved.append(e)
+                continue
             if saved and saved[-1] is x:
                 x, alias = encode(x, inject, fork=True)
                 if alias is not None:
@@ -412,9 +455,23 @@ class HDemucs(nn.Module):
         offset = self.depth - len(self.time_decoder)
         fadd = tadd = False                      # the previous layer already added this layer's skip (activation_add)
         for idx, decode in enumerate(self.freq_decoder):
-            skip = saved.pop(-1)
-            x, pre = decode(x, skip, lengths.pop(-1), next_skip=saved[-1] if saved else None, skip_added=fadd)
-            fadd = decode.fused_next_add
+            j = self.depth - 1 - idx
+            if j < Lc:
+                pre = None
+                lengths.pop(-1)
+                if j == Lc - 1:                   # layers Lc - 1 .. 0 in one node; the last transposed convolution (C -> 2 audio) stays channel-major
+                    skips = [saved.pop(-1) for _ in range(Lc)]
+                    y0 = clchain.freq_decoder(x, skips, list(self.freq_decoder[idx:]))
+                    last = self.freq_decoder[-1]
+                    full = (y0.shape[2] - 1) * last.stride + last.kernel_size
+                    x = ops.conv_transpose2d(y0, last.conv_tr.weight, last.conv_tr.bias, (last.stride, 1), (1, 1), (last.pad, 0),
+                                             (full - 2 * last.pad, y0.shape[3]))
+                    if not last.last:
+                        x = nnops.gelu(x)
+            else:
+                skip = saved.pop(-1)
+                x, pre = decode(x, skip, lengths.pop(-1), next_skip=saved[-1] if (saved and j != Lc) else None, skip_added=fadd)
+                fadd = decode.fused_next_add
             if idx >= offset:
                 tdec = self.time_decoder[idx - offset]
                 length_t = lengths_t.pop(-1)
