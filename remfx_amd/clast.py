@@ -289,8 +289,8 @@ class WgradForm:
         return np.ascontiguousarray(flat.astype(np.int32))
 
     def splits(self, steps):
-        """Position splits: about two workgroups per CU in all, every split non-empty."""
-        S = max(1, min(steps, -(-512 // self.DT)))
+        """Position splits: one workgroup per CU in all (a workgroup fills a CU's LDS), every split non-empty."""
+        S = max(1, min(steps, -(-256 // self.DT)))
         sps = -(-steps // S)
         return -(-steps // sps)
 

@@ -168,14 +168,16 @@ __global__ __launch_bounds__(256) void cl_rowsum_partial_kernel(rfx_cl_tensor x,
     partial[((int64_t)g * A + a) * C + t] = s;
   }
 }
+// one wave per output: lane l adds partials l, l + 64, ... in order, then a fixed butterfly over the lanes
 __global__ __launch_bounds__(256) void cl_rowsum_final_kernel(const float* __restrict__ partial, int64_t n, int G, float scale,
                                                               float* __restrict__ out, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
   if (i >= n) return;
   float s = 0.f;
-  for (int g = 0; g < G; ++g) s += partial[(int64_t)g * n + i];
-  s *= scale;
-  out[i] = accumulate ? out[i] + s : s;
+  for (int g = l; g < G; g += 64) s += partial[(int64_t)g * n + i];
+  s = rfx_wave_sum(s) * scale;
+  if (l == 0) out[i] = accumulate ? out[i] + s : s;
 }
 
 extern "C" int rfx_cl_rowsum(const rfx_cl_tensor* x, int32_t N, int32_t A, int32_t B, int32_t C, int32_t G, float scale, float* partial,
@@ -184,7 +186,7 @@ extern "C" int rfx_cl_rowsum(const rfx_cl_tensor* x, int32_t N, int32_t A, int32
     return -1;
   hipLaunchKernelGGL(cl_rowsum_partial_kernel, dim3((unsigned)A, (unsigned)G), dim3(256), 0, (hipStream_t)stream, *x, N, A, B, C, G, partial);
   const int64_t n = (int64_t)A * C;
-  hipLaunchKernelGGL(cl_rowsum_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, n, G, scale, out,
+  hipLaunchKernelGGL(cl_rowsum_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, partial, n, G, scale, out,
                      accumulate);
   RFX_CHECK_LAUNCH();
   return 0;

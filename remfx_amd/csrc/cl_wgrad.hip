@@ -324,24 +324,44 @@ extern "C" int rfx_cl_wgrad(const rfx_cl_wgrad_desc* dp, void* stream) {
 // ---- fixed-order reduction + scatter ----------------------------------------------------------------------------------------------
 // map: one int32 per accumulator element of the kq == 0 waves of every D tile ([DT][WC][RW * 2 * 16][64]): flat index into the weight
 // gradient, wn + m for the bias gradient, -1 for cells outside the layer.  Sources are summed split by split, K wave by K wave.
+// A block = 64 consecutive map cells x 4 groups of splits: each thread adds its splits in order (8 loads in flight), the four
+// group sums are added in group order -- the same tree whatever the launch, so the result is reproducible bit for bit.
 __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const float* __restrict__ ws, const int32_t* __restrict__ map, int64_t nmap,
                                                               int S, int DT, int WC, int WK, int per_wave, float* __restrict__ dw,
                                                               int64_t wn, float* __restrict__ db, int accumulate) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= nmap) return;
-  const int32_t dst = map[e];
-  if (dst < 0) return;
-  const int64_t inner = e % per_wave;
-  const int64_t dc = e / per_wave;                             // dt * WC + cw
-  const int cw = (int)(dc % WC);
-  const int64_t dt = dc / WC;
+  __shared__ float part[4][64];
+  const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + l;
+  const int32_t dst = e < nmap ? map[e] : -1;
   float sum = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float* b = ws + ((int64_t)s * DT + dt) * 8 * per_wave + inner;
-    for (int kq = 0; kq < WK; ++kq) sum += b[(int64_t)(kq * WC + cw) * per_wave];
+  if (dst >= 0) {
+    const int64_t inner = e % per_wave;
+    const int64_t dc = e / per_wave;                             // dt * WC + cw
+    const int cw = (int)(dc % WC);
+    const int64_t dt = dc / WC;
+    const int nsrc = S * WK;                                     // source i = (split i / WK, K wave i % WK)
+    const int per = (nsrc + 3) / 4;
+    const int i0 = sg * per, i1 = min(i0 + per, nsrc);
+    const int64_t sstride = (int64_t)DT * 8 * per_wave;
+    const float* base = ws + dt * 8 * per_wave + (int64_t)cw * per_wave + inner;
+    auto src = [&](int i) { return base[(int64_t)(i / WK) * sstride + (int64_t)(i % WK) * WC * per_wave]; };
+    int i = i0;
+    for (; i + 8 <= i1; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src(i + u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; i < i1; ++i) sum += src(i);
   }
-  float* o = dst >= wn ? db + (dst - wn) : dw + dst;
-  *o = accumulate ? *o + sum : sum;
+  part[sg][l] = sum;
+  __syncthreads();
+  if (sg == 0 && dst >= 0) {
+    const float tot = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+    float* o = dst >= wn ? db + (dst - wn) : dw + dst;
+    *o = accumulate ? *o + tot : tot;
+  }
 }
 
 extern "C" int rfx_cl_wgrad_reduce(const float* ws, const int32_t* map, int64_t nmap, int32_t S, int32_t DT, int32_t RW, int32_t WK,
@@ -349,7 +369,7 @@ extern "C" int rfx_cl_wgrad_reduce(const float* ws, const int32_t* map, int64_t 
   if (!ws || !map || !dw || nmap <= 0 || S < 1 || DT < 1 || (RW != 2 && RW != 3) || (WK != 1 && WK != 2 && WK != 4)) return -1;
   const int WC = 8 / WK, per_wave = RW * 2 * 16 * 64;
   if (nmap != (int64_t)DT * WC * per_wave) return -1;
-  hipLaunchKernelGGL(cl_wgrad_reduce_kernel, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, map, nmap, S,
+  hipLaunchKernelGGL(cl_wgrad_reduce_kernel, dim3((unsigned)((nmap + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ws, map, nmap, S,
                      DT, WC, WK, per_wave, dw, wn, db, accumulate);
   RFX_CHECK_LAUNCH();
   return 0;
