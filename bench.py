@@ -121,12 +121,12 @@ class KernelTimer:
         tcn_mod.ops.gemm_fwd = timed
         orig_w = ops.gemm_wgrad
 
-        def timed_w(dp, x, g, dapack):                     # weight-gradient launches: only listed by --dump-launches
+        def timed_w(dp, x, g):                             # weight-gradient launches: only listed by --dump-launches
             if not timer.enabled:
-                return orig_w(dp, x, g, dapack)
+                return orig_w(dp, x, g)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = orig_w(dp, x, g, dapack)
+            r = orig_w(dp, x, g)
             e.record()
             p = dp.p
             timer.wgrad.append((s, e, {"M": p.M, "K": p.K, "N": p.N, "OA": p.OA, "OB": p.OB, "x": list(x.shape), "g": list(g.shape),

@@ -148,17 +148,20 @@ enum rfx_gemm_prec { RFX_PREC_F32 = 0, RFX_PREC_BF16X3 = 1, RFX_PREC_BF16 = 2 };
  * operand prefetch is branch-free. */
 int rfx_pack_a(const float* w, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
                int32_t Mpad, int32_t Kpad, int32_t prec, float* apack, void* stream);
-/* w[m*w_ms + woff[k]] += dapack[m][k]  (dapack is the [M][Kpad] output of rfx_gemm_wgrad). */
+/* w[m*w_ms + woff[k]] += sum over the `splits` slices [M][Kpad] rfx_gemm_wgrad left in dapack, added in a fixed order
+ * (deterministic: the weight-gradient family carries no atomics). */
 int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
-                   int32_t Kpad, float* dw, void* stream);
-/* rfx_unpack_add + the bias gradient in the same launch: db[m] += dapack[m][bias_col] (the constant-one column rfx_gemm_wgrad
- * appends for plans built with a bias row).  Replaces the separate strided add per biased convolution (128 launches per Demucs step). */
+                   int32_t Kpad, float* dw, int32_t splits, void* stream);
+/* rfx_unpack_add + the bias gradient in the same launch: db[m] += sum over splits of dapack[split][m][bias_col] (the constant-one
+ * column rfx_gemm_wgrad appends for plans built with a bias row). */
 int rfx_unpack_add_bias(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K, int32_t Kpad, float* dw,
-                        int32_t bias_col, float* db, void* stream);
+                        int32_t bias_col, float* db, int32_t splits, void* stream);
 /* Same with `=` instead of `+=`: for a plan whose K rows cover every weight element exactly once (a dense
  * convolution's own plan) the caller need not zero-fill dw first. */
 int rfx_unpack_set(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
-                   int32_t Kpad, float* dw, void* stream);
+                   int32_t Kpad, float* dw, int32_t splits, void* stream);
+/* out[m] = sum over splits of dapack[split][m][col] (the bias-gradient column, for callers that return fresh tensors). */
+int rfx_unpack_col(const float* dapack, int32_t M, int32_t Kpad, int32_t col, int32_t splits, float* out, void* stream);
 
 /* Forward gather-GEMM on the fp32 MFMA path (v_mfma_f32_32x32x2_f32).
  * Optional second phase (apack2/ktab2/K2 != 0): after phase 1 the epilogue
@@ -174,10 +177,11 @@ int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rfx_ktab_entr
 /* Weight gradient of the same descriptor:
  * dapack[m][k] += sum_{n,a,b} g[n*g_ns + m*g_cs + a'*g_as + b'*g_bs] * In(n,k,a,b)   (dapack: [M][Kpad])
  * (g indexed with OUT coordinates/strides of the descriptor: out_* fields).
- * Rows k with ktab flag bit0 use In == 1 (bias gradient).  dapack must be
- * zero-initialised by the caller; partial sums are combined with fp32 atomics. */
+ * Rows k with ktab flag bit0 use In == 1 (bias gradient).  The positions are cut into *splits_out splits (chosen here, at most
+ * ws_floats / (M * Kpad)); split s STORES its partial matrix to dapack + s * M * Kpad -- no zero fill, no atomics; the unpack
+ * entry points add the slices in a fixed order. */
 int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const float* in,
-                   const float* g, float* dapack, int32_t prec, void* stream);
+                   const float* g, float* dapack, int64_t ws_floats, int32_t* splits_out, int32_t prec, void* stream);
 
 /* ---- framed FFT front / back end ---------------------------------------------
  * rfx_fft_analysis : frames -> window -> real FFT -> epilogue.  As STFT it reproduces

@@ -121,12 +121,13 @@ SIGNATURES = {
     "rfx_abi_version": [],
     "rfx_gemm_pick_r": [_I32, _I32],
     "rfx_pack_a": [_P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
-    "rfx_unpack_add": [_P, _P, _I64, _I32, _I32, _I32, _P, _P],
-    "rfx_unpack_add_bias": [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P],
-    "rfx_unpack_set": [_P, _P, _I64, _I32, _I32, _I32, _P, _P],
+    "rfx_unpack_add": [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P],
+    "rfx_unpack_add_bias": [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I32, _P],
+    "rfx_unpack_set": [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P],
+    "rfx_unpack_col": [_P, _I32, _I32, _I32, _I32, _P, _P],
     "rfx_gemm_fwd": [C.POINTER(GemmDesc), _P, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _I32, _I32, _P, _I32, _P],
     "rfx_gemm_fwd_variant": [C.POINTER(GemmDesc), C.POINTER(Epilogue), _I32, _I32],
-    "rfx_gemm_wgrad": [C.POINTER(GemmDesc), _P, _P, _P, _P, _I32, _P],
+    "rfx_gemm_wgrad": [C.POINTER(GemmDesc), _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I32, _P],
     "rfx_fft_analysis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
     "rfx_fft_synthesis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
     "rfx_stft_loss_reduce": [_P, _P, _I32, _I64, C.c_float, _P, _P],

@@ -12,6 +12,7 @@ struct WgradArgs {
   int total_tiles;       // N * tiles_per_sample
   int tiles_per_block;
   int kt, mt, splits;
+  int64_t split_stride;  // floats between the result slices of two position splits (fixed-order reduction in the unpack kernels: no atomics)
   int xcd_grouped;       // 1: 1-D grid, all (k, m) tiles of one position split share an XCD (ids congruent mod 8)
   uint32_t in_bytes, g_bytes;   // wide kernel: exact span of one sample of each operand (buffer num_records)
 };
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf_kernel(const WgradArgs w) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int k = k0 + wk * 32 * TK + tk * 32 + l31;
-        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
+        if (m < d.M && k < d.K) w.dapack[(int64_t)zsplit * w.split_stride + (int64_t)m * d.Kpad + k] = acc[tm][tk][r];
       }
 }
 
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256, (MODE == 2 && TM * TK <= 4) ? 3 : 2) void gemm
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int k = k0 + wk * 32 * TK + tk * 32 + l31;
-        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
+        if (m < d.M && k < d.K) w.dapack[(int64_t)zsplit * w.split_stride + (int64_t)m * d.Kpad + k] = acc[tm][tk][r];
       }
 }
 

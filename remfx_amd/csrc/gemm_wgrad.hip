@@ -1,19 +1,50 @@
 // Weight-gradient kernels of the gather-GEMM family (see gemm_fwd.h for the family overview).
 #include "gemm_wgrad.h"
 
+// dw (+)= sum over the position splits' slices of dapack, in split order (fixed tree: 4 groups of consecutive splits per cell,
+// each added in order with 8 loads in flight, then the 4 group sums in order) -- the weight gradients carry no atomics.
 template <bool ADD>
-__global__ void unpack_add_kernel(const float* __restrict__ dapack, const int32_t* __restrict__ woff,
-                                  int64_t w_ms, int M, int K, int Kpad, float* __restrict__ dw,
-                                  int bias_col = -1, float* __restrict__ db = nullptr) {
+__global__ __launch_bounds__(256) void unpack_add_kernel(const float* __restrict__ dapack, const int32_t* __restrict__ woff,
+                                                         int64_t w_ms, int M, int K, int Kpad, float* __restrict__ dw, int splits,
+                                                         int64_t split_stride, int bias_col = -1, float* __restrict__ db = nullptr) {
+  __shared__ float part[4][64];
+  __shared__ float bpart[4][64];
+  const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int64_t total = (int64_t)K * M;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i / K), k = (int)(i % K);
-    if (db && k == 0) db[m] += dapack[(int64_t)m * Kpad + bias_col];      // the bias-gradient column of the same matrix, one thread per row
-    // distinct (k, m) map to distinct weight elements within one descriptor, but
-    // several descriptors (stride phases) may run back to back on the stream.
-    if (ADD) dw[(int64_t)m * w_ms + woff[k]] += dapack[(int64_t)m * Kpad + k];
-    else dw[(int64_t)m * w_ms + woff[k]] = dapack[(int64_t)m * Kpad + k];
+  const int per = (splits + 3) / 4;
+  const int s0 = sg * per, s1 = min(s0 + per, splits);
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + l;
+    const bool ok = i < total;
+    const int m = ok ? (int)(i / K) : 0, k = ok ? (int)(i % K) : 0;
+    const bool isb = ok && db != nullptr && k == 0;              // this thread also carries row m's bias-gradient column
+    float sum = 0.f, bsum = 0.f;
+    if (ok) {
+      const float* src = dapack + (int64_t)m * Kpad + k;
+      int s = s0;
+      for (; s + 8 <= s1; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(s + u) * split_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+      }
+      for (; s < s1; ++s) sum += src[(int64_t)s * split_stride];
+      if (isb)
+        for (int q = s0; q < s1; ++q) bsum += dapack[(int64_t)q * split_stride + (int64_t)m * Kpad + bias_col];
+    }
+    part[sg][l] = sum;
+    bpart[sg][l] = bsum;
+    __syncthreads();
+    if (sg == 0 && ok) {
+      const float tot = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+      if (isb) db[m] += ((bpart[0][l] + bpart[1][l]) + bpart[2][l]) + bpart[3][l];
+      // distinct (k, m) map to distinct weight elements within one descriptor, but
+      // several descriptors (stride phases) may run back to back on the stream.
+      float* o = dw + (int64_t)m * w_ms + woff[k];
+      if (ADD) *o += tot; else *o = tot;
+    }
+    __syncthreads();
   }
 }
 
@@ -122,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs w) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int k = k0 + wk * 32 * TK + tk * 32 + l31;
-        if (m < d.M && k < d.K) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, acc[tm][tk][r]);
+        if (m < d.M && k < d.K) w.dapack[(int64_t)zsplit * w.split_stride + (int64_t)m * d.Kpad + k] = acc[tm][tk][r];
       }
 }
 
@@ -164,54 +195,69 @@ __global__ __launch_bounds__(256) void gemm_thin_wgrad_kernel(const WgradArgs w)
 #pragma unroll
   for (int m = 0; m < MM; ++m) {
     const float s = rfx_wave_sum(acc[m]);
-    if (lane == 0 && m < d.M) atomicAdd(w.dapack + (int64_t)m * d.Kpad + k, s);
+    if (lane == 0 && m < d.M) w.dapack[(int64_t)blockIdx.y * w.split_stride + (int64_t)m * d.Kpad + k] = s;
   }
 }
 
 
 static int unpack_launch(bool add, const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K,
-                         int32_t Kpad, float* dw, void* stream) {
-  if (!dapack || !woff || !dw || M <= 0 || K < 0 || Kpad < K) return -1;
+                         int32_t Kpad, float* dw, int32_t splits, int32_t bias_col, float* db, void* stream) {
+  if (!dapack || !woff || !dw || M <= 0 || K < 0 || Kpad < K || splits < 1) return -1;
   const int64_t total = (int64_t)K * M;
   if (total == 0) return 0;
-  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  const int64_t stride = (int64_t)M * Kpad;
+  const int grid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
   if (add) hipLaunchKernelGGL(unpack_add_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff,
-                              w_ms, M, K, Kpad, dw);
+                              w_ms, M, K, Kpad, dw, splits, stride, bias_col, db);
   else hipLaunchKernelGGL(unpack_add_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff,
-                          w_ms, M, K, Kpad, dw);
+                          w_ms, M, K, Kpad, dw, splits, stride, bias_col, db);
   RFX_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int rfx_unpack_add(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
-                              int32_t K, int32_t Kpad, float* dw, void* stream) {
-  return unpack_launch(true, dapack, woff, w_ms, M, K, Kpad, dw, stream);
+                              int32_t K, int32_t Kpad, float* dw, int32_t splits, void* stream) {
+  return unpack_launch(true, dapack, woff, w_ms, M, K, Kpad, dw, splits, -1, nullptr, stream);
 }
 extern "C" int rfx_unpack_add_bias(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M, int32_t K, int32_t Kpad,
-                                   float* dw, int32_t bias_col, float* db, void* stream) {
-  if (!dapack || !woff || !dw || !db || M <= 0 || K <= 0 || Kpad < K || bias_col < 0 || bias_col >= Kpad) return -1;
-  const int64_t total = (int64_t)K * M;
-  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(unpack_add_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dapack, woff, w_ms, M, K, Kpad, dw,
-                     bias_col, db);
-  RFX_CHECK_LAUNCH();
-  return 0;
+                                   float* dw, int32_t bias_col, float* db, int32_t splits, void* stream) {
+  if (!db || K <= 0 || bias_col < 0 || bias_col >= Kpad) return -1;
+  return unpack_launch(true, dapack, woff, w_ms, M, K, Kpad, dw, splits, bias_col, db, stream);
 }
 extern "C" int rfx_unpack_set(const float* dapack, const int32_t* woff, int64_t w_ms, int32_t M,
-                              int32_t K, int32_t Kpad, float* dw, void* stream) {
-  return unpack_launch(false, dapack, woff, w_ms, M, K, Kpad, dw, stream);
+                              int32_t K, int32_t Kpad, float* dw, int32_t splits, void* stream) {
+  return unpack_launch(false, dapack, woff, w_ms, M, K, Kpad, dw, splits, -1, nullptr, stream);
+}
+// out[m] (+)= sum over splits of dapack[split][m][col] -- the bias-gradient column when the weight part goes through unpack_set
+__global__ __launch_bounds__(256) void unpack_col_kernel(const float* __restrict__ dapack, int M, int Kpad, int col, int splits,
+                                                         float* __restrict__ out) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s = 0.f;
+  for (int q = 0; q < splits; ++q) s += dapack[(int64_t)q * M * Kpad + (int64_t)m * Kpad + col];
+  out[m] = s;
+}
+extern "C" int rfx_unpack_col(const float* dapack, int32_t M, int32_t Kpad, int32_t col, int32_t splits, float* out, void* stream) {
+  if (!dapack || !out || M <= 0 || col < 0 || col >= Kpad || splits < 1) return -1;
+  hipLaunchKernelGGL(unpack_col_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, dapack, M, Kpad, col, splits, out);
+  RFX_CHECK_LAUNCH();
+  return 0;
 }
 
 // R (channel tiles per wave) is a pure function of M so that host-side packing
 // and the kernel agree on Mpad = ceil(M / 32R) * 32R.
 
 extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const float* in,
-                              const float* gout, float* dapack, int32_t prec, void* stream) {
-  if (!desc_ok(d) || !ktab || !in || !gout || !dapack) return -1;
+                              const float* gout, float* dapack, int64_t ws_floats, int32_t* splits_out, int32_t prec, void* stream) {
+  if (!desc_ok(d) || !ktab || !in || !gout || !dapack || !splits_out) return -1;
+  *splits_out = 1;
   if (d->K == 0) return 0;
+  const int64_t slice = (int64_t)d->M * d->Kpad;
+  const int max_splits = (int)(ws_floats / slice < 1 ? 0 : (ws_floats / slice > 4096 ? 4096 : ws_floats / slice));
+  if (max_splits < 1) return -1;
   if (d->in_bf16) return -1;                          // bf16 storage is implemented for the gradient operand only (wide kernel)
   if (d->out_bf16 && (prec != 2 || d->M <= 8 || ((d->out_b0 | d->out_cs | d->out_as | d->out_ns) & 1))) return -1;
   WgradArgs w;
-  w.d = *d; w.ktab = ktab; w.in = in; w.g = gout; w.dapack = dapack;
+  w.d = *d; w.ktab = ktab; w.in = in; w.g = gout; w.dapack = dapack; w.split_stride = slice;
   const int P = d->OA * d->OB;
   w.tiles_per_sample = (P + 31) / 32;
   w.total_tiles = d->N * w.tiles_per_sample;
@@ -219,6 +265,8 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   if (d->M <= 8) {
     const int64_t total = (int64_t)d->N * P;
     int splits = (int)(total / 4096 < 1 ? 1 : (total / 4096 > 64 ? 64 : total / 4096));
+    splits = min(splits, max_splits);
+    *splits_out = splits;
     dim3 grid((d->K + 3) / 4, splits);
     w.tiles_per_block = 0;
     if (d->M <= 1) hipLaunchKernelGGL(gemm_thin_wgrad_kernel<1>, grid, dim3(256), 0, s, w);
@@ -245,11 +293,12 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
     const int chunks = d->N * d->OA * ((d->OB + 63) / 64);          // 64-position chunks of one (n, a) row
     int splits = max(1, 2048 / (mt * kt));
     const int min_chunks = (int64_t)mt * kt * (chunks / 32) >= 512 ? 32 : 8;
-    splits = min(splits, max(1, chunks / min_chunks));
+    splits = min(min(splits, max_splits), max(1, chunks / min_chunks));
     w.total_tiles = chunks;
     w.tiles_per_block = (chunks + splits - 1) / splits;
     splits = (chunks + w.tiles_per_block - 1) / w.tiles_per_block;
     w.kt = kt; w.mt = mt; w.splits = splits;
+    *splits_out = splits;
     // every (k, m) tile of a position split re-reads the same g rows / input rows: group them behind one L2
     // (measured on the Demucs B=64 step, bf16: 44.3 -> 40.2 ms of weight-gradient launches)
     w.xcd_grouped = splits >= 8;
@@ -271,10 +320,11 @@ extern "C" int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab
   // >= 64 position tiles per workgroup when there is plenty of work; short sequences (LSTM / attention projections,
   // P ~ 8-38 k positions) would otherwise launch a few dozen workgroups on 256 CUs: go down to 16 tiles there
   const int min_tiles = (int64_t)mt * kt * (w.total_tiles / 64) >= 512 ? 64 : 16;
-  splits = min(splits, max(1, w.total_tiles / min_tiles));
+  splits = min(min(splits, max_splits), max(1, w.total_tiles / min_tiles));
   w.tiles_per_block = (w.total_tiles + splits - 1) / splits;
   splits = (w.total_tiles + w.tiles_per_block - 1) / w.tiles_per_block;
   w.kt = kt; w.mt = mt; w.splits = splits;
+  *splits_out = splits;
   dim3 grid(kt, mt, splits);
   w.xcd_grouped = 0;
   if (prec != 0) {

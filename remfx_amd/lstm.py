@@ -122,8 +122,7 @@ class _LSTMLayerFn(torch.autograd.Function):
             dwhh = []
             for d in range(2):
                 dp, xs, gs = _whh_plan(out4, dG, H, d, Bn)
-                dap = ops.zeros((dp.p.M, dp.p.Kpad), g.device)
-                ops.gemm_wgrad(dp, xs, gs, dap)
+                dap = ops.gemm_wgrad(dp, xs, gs)
                 if sunk:                     # straight into the parameter's slice of the flat gradient buffer (no temporary, no add)
                     ops.unpack_add(dp, dap, tg[1 + 4 * d][1])
                     dwhh.append(None)

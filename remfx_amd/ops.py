@@ -374,32 +374,55 @@ def gemm_fwd(dp, apack, x, out, bias=None, act=None, act_param=None, res=None, a
     return out
 
 
-def gemm_wgrad(dp, x, g, dapack):
+class WgradOut:
+    """What rfx_gemm_wgrad leaves behind: `splits` partial [M][Kpad] matrices, one per position split, to be added in order by an
+    unpack entry point (fixed-order reduction: the weight gradients are deterministic, nothing is zero-filled)."""
+    __slots__ = ("ws", "splits")
+
+    def __init__(self, ws, splits):
+        self.ws, self.splits = ws, splits
+
+
+def gemm_wgrad(dp, x, g):
+    p = dp.p
+    sl = p.M * p.Kpad
+    cap = sl * min(2048, max(4, (1 << 25) // sl))
+    ws = torch.empty(cap, device=x.device, dtype=torch.float32)
+    ns = C.c_int32(0)
     if x.dtype == torch.bfloat16:                            # bf16 storage is implemented for the gradient operand only
         x = x.float()
     if g.dtype == torch.bfloat16:
-        rc = _lib.lib().rfx_gemm_wgrad(C.byref(dp.desc_for(x, g)), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(dapack),
+        rc = _lib.lib().rfx_gemm_wgrad(C.byref(dp.desc_for(x, g)), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(ws), cap, C.byref(ns),
                                        GEMM_PREC, _stream())
         if rc == 0:
-            return
+            return WgradOut(ws, ns.value)
         if rc != -1:                                         # -1 = "plan not supported by the 16-bit path"; anything else is a real failure
             check(rc, "rfx_gemm_wgrad")
         g = g.float()                                        # a plan the wide-load kernel does not take: widen once
-    check(_lib.lib().rfx_gemm_wgrad(C.byref(dp.desc), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(dapack),
+    check(_lib.lib().rfx_gemm_wgrad(C.byref(dp.desc), _ptr(dp.ktab), _ptr(x), _ptr(g), _ptr(ws), cap, C.byref(ns),
                                     GEMM_PREC, _stream()), "rfx_gemm_wgrad")
+    return WgradOut(ws, ns.value)
 
 
-def unpack_set(dp, dapack, dw):
-    """dw = unpacked dapack; only for plans whose rows cover every element of dw exactly once (dense conv plans)."""
+def unpack_set(dp, wg, dw):
+    """dw = sum of the split matrices, unpacked; only for plans whose rows cover every element of dw exactly once (dense conv plans)."""
     p = dp.p
-    check(_lib.lib().rfx_unpack_set(_ptr(dapack), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"],
-                                    p.Kpad, _ptr(dw), _stream()), "rfx_unpack_set")
+    check(_lib.lib().rfx_unpack_set(_ptr(wg.ws), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"],
+                                    p.Kpad, _ptr(dw), wg.splits, _stream()), "rfx_unpack_set")
 
 
-def unpack_add(dp, dapack, dw):
+def unpack_add(dp, wg, dw):
     p = dp.p
-    check(_lib.lib().rfx_unpack_add(_ptr(dapack), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"],
-                                    p.Kpad, _ptr(dw), _stream()), "rfx_unpack_add")
+    check(_lib.lib().rfx_unpack_add(_ptr(wg.ws), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"],
+                                    p.Kpad, _ptr(dw), wg.splits, _stream()), "rfx_unpack_add")
+
+
+def unpack_col(dp, wg, col):
+    """(M,) = column `col` of the summed split matrices (the bias-gradient column)."""
+    p = dp.p
+    out = torch.empty(p.M, device=wg.ws.device, dtype=torch.float32)
+    check(_lib.lib().rfx_unpack_col(_ptr(wg.ws), p.M, p.Kpad, col, wg.splits, _ptr(out), _stream()), "rfx_unpack_col")
+    return out
 
 
 # ---- convolution (4-D view: N, C, A, B) ----------------------------------------------
@@ -496,22 +519,20 @@ def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias, w=None, b=N
     tb = sink.lookup(b) if (tw is not None and need_bias) else None
     if tw is not None and (tb is not None or not need_bias):
         with torch.cuda.stream(sink.stream_for_wgrad(x, g)):
-            dapack = zeros((p.M, p.Kpad), x.device)
-            gemm_wgrad(dp, x, g, dapack)
-            if need_bias:       # weight + bias gradient out of the same matrix in one launch
-                check(_lib.lib().rfx_unpack_add_bias(_ptr(dapack), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"], p.Kpad,
-                                                     _ptr(tw[1]), p.K - 1, _ptr(tb[1]), _stream()), "rfx_unpack_add_bias")
+            wg = gemm_wgrad(dp, x, g)
+            if need_bias:       # weight + bias gradient out of the same matrices in one launch
+                check(_lib.lib().rfx_unpack_add_bias(_ptr(wg.ws), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"], p.Kpad,
+                                                     _ptr(tw[1]), p.K - 1, _ptr(tb[1]), wg.splits, _stream()), "rfx_unpack_add_bias")
             else:
-                unpack_add(dp, dapack, tw[1])                  # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
+                unpack_add(dp, wg, tw[1])                  # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
         sink.wrote(tw[0])
         if need_bias:
             sink.wrote(tb[0])
         return None, None
-    dapack = zeros((p.M, p.Kpad), x.device)
-    gemm_wgrad(dp, x, g, dapack)
+    wg = gemm_wgrad(dp, x, g)
     dw = torch.empty(wshape, device=x.device, dtype=torch.float32)
-    unpack_set(dp, dapack, dw)                             # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
-    db = dapack[:, p.K - 1] if need_bias else None       # a strided view: autograd's accumulation reads it in place
+    unpack_set(dp, wg, dw)                                 # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
+    db = unpack_col(dp, wg, p.K - 1) if need_bias else None
     return dw, db
 
 
@@ -698,10 +719,7 @@ class ConvT2dFn(torch.autograd.Function):
             if tw is not None and (tb is not None or not has_bias):
                 # in place on the sink's side stream (see conv2d_wgrad)
                 with torch.cuda.stream(sink.stream_for_wgrad(x, g)):
-                    p = dp.p
-                    dapack = zeros((p.M, p.Kpad), x.device)
-                    gemm_wgrad(dp, g, x, dapack)
-                    unpack_add(dp, dapack, tw[1])
+                    unpack_add(dp, gemm_wgrad(dp, g, x), tw[1])
                     if has_bias:
                         tb[1].add_(channel_sum(g))
                 sink.wrote(tw[0])
@@ -709,11 +727,8 @@ class ConvT2dFn(torch.autograd.Function):
                     sink.wrote(tb[0])
                 return dx, None, None, None, None, None, None
             if need_w:
-                p = dp.p
-                dapack = zeros((p.M, p.Kpad), x.device)
-                gemm_wgrad(dp, g, x, dapack)
                 dw = zeros(tuple(w.shape), w.device)
-                unpack_add(dp, dapack, dw)
+                unpack_add(dp, gemm_wgrad(dp, g, x), dw)
         if has_bias and ctx.needs_input_grad[2]:
             db = channel_sum(g)
         return dx, dw, db, None, None, None, None

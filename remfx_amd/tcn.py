@@ -94,8 +94,7 @@ class TCNBlockFn(torch.autograd.Function):
         # 2. weight gradients: conv1 from (x, g1) with the bias row; residual 1x1 from (x shifted, g)
         dw1, db1 = ops.conv2d_wgrad(x4, g14, (Cout, Cin, 1, ksize), (1, 1), (0, 0), (1, dilation), True)
         p2 = dp2.p
-        dap = torch.zeros((p2.M, p2.Kpad), device=x.device, dtype=torch.float32)
-        ops.gemm_wgrad(dp2, x4, g4, dap)
+        dap = ops.gemm_wgrad(dp2, x4, g4)
         dwres = torch.zeros_like(wres)
         ops.unpack_add(dp2, dap, dwres)
         # 3. input gradient: conv1^T over g1 (phase 1) + res^T over g at the crop offset (phase 2)

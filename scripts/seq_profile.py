@@ -15,7 +15,7 @@ VARIANT = L.rfx_gemm_fwd_variant
 ops.set_gemm_precision(os.environ.get("RFX_GEMM_PREC", "bf16"))
 ops.GradSink.MODE = "main"
 rec = []
-FILES = ("hdemucs.py", "nnops.py", "ops.py", "stft.py", "losses.py", "lstm.py", "models.py", "optim.py")
+FILES = ("hdemucs.py", "nnops.py", "ops.py", "stft.py", "losses.py", "lstm.py", "models.py", "optim.py", "clchain.py", "clast.py")
 
 
 def site():
@@ -43,6 +43,12 @@ def wrap(name):
                 pv = getattr(args[11], "value", args[11])
                 v = VARIANT(args[0], args[5], int(bool(getattr(a2, "value", a2))), pv)
                 info += f" v={v >> 4}/{v & 15}"
+        elif name == "rfx_cl_conv":
+            d = args[0]._obj
+            info = f"N={d.N} M={d.M} K={d.NTR}x{d.NTC}x{d.NCH * 16 * d.KS} rows {d.IA}->{d.OA} BM={d.BM} mode={d.mode}"
+        elif name == "rfx_cl_wgrad":
+            d = args[0]._obj
+            info = f"N={d.N} M={d.M} Cq={d.Cq} taps={d.NTR}x{d.NTC} rows {d.OA}/{d.IA} S={d.S} WK={d.WK}"
         elif name.startswith("rfx_groupnorm"):
             a = args[3:7] if name.endswith("fwd") or "fwd" in name else args[6:10]
             info = "N,C,S,G=" + ",".join(str(getattr(v, "value", v)) for v in a)
