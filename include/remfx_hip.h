@@ -580,11 +580,14 @@ int rfx_cl_conv(const rfx_cl_conv_desc* d, void* stream);
 int rfx_cl_pack(const float* src, const int32_t* idx, int64_t n, void* dst, void* stream);
 /* channel-major fp32 / bf16 (N, C, A, B) [strides in elements, B contiguous] <-> channels-last bf16; B % 64 == 0, C % 8 == 0.
  * rfx_cl_from_cm fuses what would follow the conversion: v = src (+ res); mode 0: dst = v; 1: dst = v * gelu'(aux);
- * 2: GLU backward against aux = stored [a | b] (2 C channels), dst = [v * sigmoid(b) | v * a * sigmoid(b) (1 - sigmoid(b))]. */
+ * 2: GLU backward against aux = stored [a | b] (2 C channels), dst = [v * sigmoid(b) | v * a * sigmoid(b) (1 - sigmoid(b))];
+ * 3: dst = gelu(v).  rfx_cl_to_cm with aux16 (bf16, channel-major, dst's strides; may be NULL): dst = v * gelu'(aux16). */
 int rfx_cl_from_cm(const void* src, int32_t src_bf16, int64_t s_ns, int64_t s_cs, int64_t s_as, int32_t N, int32_t C, int32_t A,
                    int32_t B, const rfx_cl_tensor* dst, const rfx_cl_tensor* res, const rfx_cl_tensor* aux, int32_t mode, void* stream);
 int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int32_t A, int32_t B, void* dst, int32_t dst_bf16, int64_t d_ns,
-                 int64_t d_cs, int64_t d_as, void* stream);
+                 int64_t d_cs, int64_t d_as, const void* aux16, void* stream);
+/* out = g * gelu'(z) over n bf16 values of dense channels-last tensors (n % 8 == 0) */
+int rfx_cl_dgelu(const void* g, const void* z, void* out, int64_t n, void* stream);
 
 /* Weight gradients on channels-last operands, deterministic (no atomics):
  *   D[m][(r, t, c)] = sum over (n, oa, b) of P[n][oa][b][m] * Q[n][oa*SA + da0 + r][b + db0 + t*db_step][c]     (Q = 0 outside)
@@ -608,6 +611,29 @@ int64_t rfx_cl_wgrad_ws_floats(const rfx_cl_wgrad_desc* d);
 int rfx_cl_wgrad(const rfx_cl_wgrad_desc* d, void* stream);
 int rfx_cl_wgrad_reduce(const float* ws, const int32_t* map, int64_t nmap, int32_t S, int32_t DT, int32_t RW, int32_t WK, float* dw,
                         int64_t wn, float* db, int32_t accumulate, void* stream);
+
+/* Fused DConv depth-layer on channels-last samples (csrc/cl_dconv.hip): torchaudio HDemucs `_DConv` layers of the frequency
+ * encoder (reference call site remfx/models.py:319), samples x [S][256][C] bf16 (S = clips x frequency rows), H = C / 4:
+ *   h = conv1d(x; W1, b1, dilation dil); a = GELU(GN(1, H)(h)); z = conv1d(a; W2, b2); y = x + scale * GLU(GN(1, 2C)(z)).
+ * forward: y; with a / hpre / stats non-NULL (training) also a and h as [S][256][Hp] bf16 (Hp = H rounded up to 16, pad channels 0)
+ * and (mean1, rstd1, mean2, rstd2) per sample.  backward: dx into y, dz [S][256][2C] and dh [S][256][Hp] for the two
+ * weight-gradient GEMMs (rfx_cl_wgrad), parameter-gradient partials per workgroup into `partial` ([grid][5C + 2H]) and their
+ * fixed-order sum into pgrad (dscale[C] | dgn2w[2C] | dgn2b[2C] | dgn1w[H] | dgn1b[H]).  w*p: MFMA fragments packed by
+ * rfx_cl_pack from the index tables of remfx_amd/cldconv.py.  rfx_cl_dconv_ok: shapes the kernels take. */
+typedef struct rfx_cl_dconv_desc {
+  const void* x;           /* forward input */
+  const void* gy;          /* backward: gradient of y */
+  void* y;                 /* forward: y; backward: dx */
+  void* a; void* hpre; float* stats;
+  void* dz; void* dh; float* partial;
+  const void* w1p; const void* w2p; const void* w2dp; const void* w1dp;
+  const float *b1, *g1w, *g1b, *b2, *g2w, *g2b, *scale;
+  int32_t S, C, H, dil, grid, x_or_gy_ok;
+  float eps;
+} rfx_cl_dconv_desc;
+int rfx_cl_dconv_ok(int32_t C, int32_t H, int32_t T, int32_t backward);
+int rfx_cl_dconv_fwd(const rfx_cl_dconv_desc* d, void* stream);
+int rfx_cl_dconv_bwd(const rfx_cl_dconv_desc* d, float* pgrad, void* stream);
 
 /* out[a][c] (+)= scale * sum over (n, b) of x[n][a][b][c], deterministic (G fixed-order partials of A * C floats each in `partial`):
  * bias gradients (A = 1, rows folded into N) and the frequency-embedding gradient of Hybrid Demucs. */

@@ -108,6 +108,12 @@ class ClConvDesc(C.Structure):
                [("bias", C.c_void_p), ("rowadd", C.c_void_p), ("out0", ClTensor), ("out1", ClTensor), ("aux0", ClTensor), ("res", ClTensor)]
 
 
+class ClDconvDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "gy", "y", "a", "hpre", "stats", "dz", "dh", "partial", "w1p", "w2p", "w2dp", "w1dp",
+                                          "b1", "g1w", "g1b", "b2", "g2w", "g2b", "scale")] + \
+               [(n, C.c_int32) for n in ("S", "C", "H", "dil", "grid", "x_or_gy_ok")] + [("eps", C.c_float)]
+
+
 class ClWgradDesc(C.Structure):
     _fields_ = [("p", ClTensor), ("q", ClTensor)] + \
                [(n, C.c_int32) for n in ("N", "OA", "IA", "B", "SA", "da0", "NTR", "NTC", "db0", "db_step", "M", "Cq", "CW", "RW", "WK",
@@ -210,7 +216,11 @@ SIGNATURES = {
     "rfx_cl_from_cm": [_P, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, C.POINTER(ClTensor), C.POINTER(ClTensor), C.POINTER(ClTensor),
                        _I32, _P],
     "rfx_cl_rowsum": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _I32, C.c_float, _P, _P, _I32, _P],
-    "rfx_cl_to_cm": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _P, _I32, _I64, _I64, _I64, _P],
+    "rfx_cl_to_cm": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _P, _I32, _I64, _I64, _I64, _P, _P],
+    "rfx_cl_dgelu": [_P, _P, _P, _I64, _P],
+    "rfx_cl_dconv_ok": [_I32, _I32, _I32, _I32],
+    "rfx_cl_dconv_fwd": [_P, _P],
+    "rfx_cl_dconv_bwd": [_P, _P, _P],
 }
 
 _RET64 = {"rfx_cl_wgrad_ws_floats"}

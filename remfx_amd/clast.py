@@ -37,7 +37,7 @@ def empty(N, A, B, Cc, device):
     return torch.empty((N, A, B, Cc), device=device, dtype=torch.bfloat16)
 
 
-FROM_CM_MODE = {"store": 0, "dgelu": 1, "dglu": 2}
+FROM_CM_MODE = {"store": 0, "dgelu": 1, "dglu": 2, "gelu": 3}
 
 
 def from_cm(x, out=None, res=None, aux=None, mode="store"):
@@ -55,14 +55,26 @@ def from_cm(x, out=None, res=None, aux=None, mode="store"):
     return out
 
 
-def to_cm(x, dtype=torch.float32, out=None):
-    """(N, A, B, C) bf16 channels-last -> (N, C, A, B) channel-major fp32 / bf16."""
+def to_cm(x, dtype=torch.float32, out=None, aux16=None):
+    """(N, A, B, C) bf16 channels-last -> (N, C, A, B) channel-major fp32 / bf16; aux16 (bf16 tensor with out's strides):
+    out = x * gelu'(aux16)."""
     N, A, B, Cc = x.shape
     if out is None:
         out = torch.empty((N, Cc, A, B), device=x.device, dtype=dtype)
     ct = cl_tensor(x)
     check(_lib.lib().rfx_cl_to_cm(C.byref(ct), N, Cc, A, B, C.c_void_p(out.data_ptr()), int(out.dtype == torch.bfloat16),
-                                  out.stride(0), out.stride(1), out.stride(2), _stream()), "rfx_cl_to_cm")
+                                  out.stride(0), out.stride(1), out.stride(2),
+                                  C.c_void_p(aux16.data_ptr()) if aux16 is not None else None, _stream()), "rfx_cl_to_cm")
+    return out
+
+
+def dgelu(g, z):
+    """g * gelu'(z) for dense channels-last tensors of one shape."""
+    if g.shape != z.shape or not g.is_contiguous() or not z.is_contiguous():
+        raise ValueError("dgelu: dense tensors of one shape")
+    out = torch.empty_like(g)
+    check(_lib.lib().rfx_cl_dgelu(C.c_void_p(g.data_ptr()), C.c_void_p(z.data_ptr()), C.c_void_p(out.data_ptr()), g.numel(), _stream()),
+          "rfx_cl_dgelu")
     return out
 
 

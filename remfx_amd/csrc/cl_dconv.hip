@@ -1,0 +1,551 @@
+// Fused DConv depth-layer on channels-last bf16 samples (rfx_cl_dconv_fwd / rfx_cl_dconv_bwd): the residual branch of the
+// frequency encoder layers of Hybrid Demucs (torchaudio HDemucs `_DConv`, reached from remfx/models.py:319), bf16
+// arithmetic mode, for samples x of [256 frames][C channels] (one (clip, frequency row) each):
+//     h = conv1d(x; W1 (H, C, 3), b1, dilation d, padding d)            H = C / 4
+//     a = GELU(GroupNorm(1, H)(h))
+//     z = conv1d(a; W2 (2C, H, 1), b2)
+//     y = x + scale[c] * GLU(GroupNorm(1, 2C)(z))
+// One workgroup (8 waves) holds a sample; wave w owns positions [32 w, 32 w + 32).  The sample arrives by DMA as a dense
+// [position][C] image -- the layout it has in memory.  All products run on v_mfma_f32_32x32x16_bf16:
+//   * GEMM1  h[h][pos]  = W1 x        A = packed W1 fragments, B = the image (8 channels of a position = one 16-byte read per tap)
+//   * GEMM2  z^T[pos][m] = a^T W2^T   A = GELU(GN(h)) straight from GEMM1's C/D registers (lane = position = A row; the packed W2
+//     fragments enumerate k in the register order), B = packed W2^T.  The result has lane = CHANNEL, registers = positions: every
+//     per-channel quantity (bias, affine, LayerScale, and in the backward pass the parameter-gradient sums) is per-lane, a GLU
+//     pair (value tile t, gate tile t + NTV) sits in one lane, and the sample statistics are one cross-lane sum per sample.
+//   * x (and gy, h in the backward pass) reach that same layout through an MFMA against identity fragments: exact for bf16.
+// Backward (recompute z from the stored a; nothing of width 2C is read): GLU / LayerScale / GroupNorm-2 backward in registers,
+// dz -> LDS image -> da^T = dz^T W2 (A = image rows), GELU / GroupNorm-1 backward, dh -> LDS image (with halo) ->
+// dx^T = gy^T + sum_t dh^T(shifted) W1_t.  dz and dh also leave as channels-last tensors: the two weight-gradient GEMMs run on
+// csrc/cl_wgrad.hip (deterministic).  The affine / LayerScale gradients are per-lane sums, reduced over waves and workgroups in a
+// fixed order (no atomics: the LDS float atomics of the round-4 backward kernel cost 7 of its 13.7 ms).
+#include "cl_common.h"
+
+#define CLD_T 256
+#define CLD_HALO 2
+
+struct ClDconvK {
+  rfx_cl_dconv_desc d;
+};
+
+typedef short cld_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ cl_bf16x8 cld_ld16(const unsigned char* p) {
+  return __builtin_bit_cast(cl_bf16x8, *reinterpret_cast<const uint4*>(p));
+}
+// registers 8 s .. 8 s + 7 of a C/D tile as an MFMA A / B operand (k in register order)
+__device__ __forceinline__ cl_bf16x8 cld_pack8(const float* v) {
+  const uint4 u = make_uint4(rfx_cvt_pk_bf16(v[0], v[1]), rfx_cvt_pk_bf16(v[2], v[3]), rfx_cvt_pk_bf16(v[4], v[5]), rfx_cvt_pk_bf16(v[6], v[7]));
+  return __builtin_bit_cast(cl_bf16x8, u);
+}
+// identity fragment u (k = 16 u + 8 khalf + e against column n): B operand that copies A's columns 16 u .. 16 u + 15 of a 32-column tile
+__device__ __forceinline__ cl_bf16x8 cld_ident(int u, int lane) {
+  const int n = lane & 31, k0 = 16 * u + 8 * (lane >> 5);
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = (k0 + 2 * q == n ? 0x3f80u : 0u) | (k0 + 2 * q + 1 == n ? 0x3f800000u : 0u);
+  return __builtin_bit_cast(cl_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+}
+__device__ __forceinline__ float cld_bf16r(float v) { return __uint_as_float(rfx_cvt_pk_bf16(v, 0.f) << 16); }
+// sigmoid on the raw v_exp_f32 / v_rcp_f32 (no denormal fix-up sequence around the exponential: its argument is clamped instead)
+__device__ __forceinline__ float cld_sigmoid(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(-1.44269504088896f * v, 126.0f)));
+}
+
+template <int C, int H>
+struct CldCfg {
+  static constexpr int HP = (H + 15) / 16 * 16, KC = C / 16, KH = HP / 16, NTV = (C + 31) / 32, NT2 = 2 * NTV, RH = 8 * KH;
+  static constexpr int RS = 2 * C, RSH = 2 * HP, RSZ = 4 * C;                       // image row strides in bytes
+  static constexpr int XIMG = (CLD_T + 2 * CLD_HALO) * RS;
+  // forward LDS: x image | W1 A fragments (3 KC KiB) | W2^T B fragments (KH NT2 KiB) | reduction scratch
+  static constexpr int F_W1 = XIMG, F_W2 = F_W1 + 3 * KC * 1024, F_RED = F_W2 + KH * NT2 * 1024, F_LDS = F_RED + 256;
+  // backward LDS: gy image (later dx) | a image | h image | dz image | dh image (halo) | W2^T frags | W2 frags (da) | W1 frags (dx) | scratch
+  static constexpr int B_A = CLD_T * RS, B_HI = B_A + CLD_T * RSH, B_DZ = B_HI + CLD_T * RSH, B_DH = B_DZ + CLD_T * RSZ,
+                       B_W2 = B_DH + (CLD_T + 2 * CLD_HALO) * RSH, B_W2D = B_W2 + KH * NT2 * 1024, B_W1D = B_W2D + (2 * C / 16) * 1024,
+                       B_RED = B_W1D + 3 * KH * NTV * 1024, B_LDS = B_RED + 8 * 64 * 4 * 0 + 512;
+  static_assert(C % 16 == 0 && H * 4 == C && HP <= 32, "");
+};
+
+// cooperative copy of `bytes` (a multiple of 1024) from global to LDS, linear
+__device__ __forceinline__ void cld_copy_in(unsigned char* lds, const void* src, int bytes, int tid) {
+  for (int o = tid * 16; o < bytes; o += 512 * 16) *reinterpret_cast<uint4*>(lds + o) = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + o);
+}
+
+// sum of v over the workgroup (all lanes get it); `red` = 8 floats of LDS; two barriers
+__device__ __forceinline__ void cld_block_sum2(float& a, float& b, float* red, int wave, int lane) {
+  a = rfx_wave_sum(a);
+  b = rfx_wave_sum(b);
+  if (lane == 0) { red[wave] = a; red[8 + wave] = b; }
+  __syncthreads();
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) { sa += red[w]; sb += red[8 + w]; }
+  __syncthreads();
+  a = sa; b = sb;
+}
+
+template <int C, int H>
+__global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) {
+  using Cfg = CldCfg<C, H>;
+  constexpr int HP = Cfg::HP, KC = Cfg::KC, KH = Cfg::KH, NTV = Cfg::NTV, NT2 = Cfg::NT2, RH = Cfg::RH, RS = Cfg::RS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char cld_smem[];
+  const rfx_cl_dconv_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  unsigned char* ximg = cld_smem;
+  float* red = reinterpret_cast<float*>(cld_smem + Cfg::F_RED);
+  const bool train = d.a != nullptr;
+
+  // ---- once per workgroup: packed weights, zero halo rows
+  cld_copy_in(cld_smem + Cfg::F_W1, d.w1p, 3 * KC * 1024, tid);
+  cld_copy_in(cld_smem + Cfg::F_W2, d.w2p, KH * NT2 * 1024, tid);
+  for (int o = tid * 4; o < CLD_HALO * RS; o += 512 * 4) {
+    *reinterpret_cast<uint32_t*>(ximg + o) = 0u;
+    *reinterpret_cast<uint32_t*>(ximg + (CLD_T + CLD_HALO) * RS + o) = 0u;
+  }
+  // per-register parameters of the h tile (row h = (r & 3) + 8 (r >> 2) + 4 half), zero beyond H: padded rows stay exactly 0
+  float b1r[RH], g1r[RH], e1r[RH];
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {
+    const int h = (r & 3) + 8 * (r >> 2) + 4 * half;
+    b1r[r] = h < H ? d.b1[h] : 0.f;
+    g1r[r] = h < H ? d.g1w[h] : 0.f;
+    e1r[r] = h < H ? d.g1b[h] : 0.f;
+  }
+  // per-lane parameters of the z^T tiles: tile t < NTV = value channel 32 t + n, t >= NTV = its gate (W2 row C + channel)
+  float b2v[NTV], b2g[NTV], gv[NTV], ev[NTV], gg[NTV], eg[NTV], sc[NTV];
+  bool cok[NTV];
+#pragma unroll
+  for (int t = 0; t < NTV; ++t) {
+    const int c = 32 * t + l31;
+    cok[t] = c < C;
+    b2v[t] = cok[t] ? d.b2[c] : 0.f;      b2g[t] = cok[t] ? d.b2[C + c] : 0.f;
+    gv[t] = cok[t] ? d.g2w[c] : 0.f;      gg[t] = cok[t] ? d.g2w[C + c] : 0.f;
+    ev[t] = cok[t] ? d.g2b[c] : 0.f;      eg[t] = cok[t] ? d.g2b[C + c] : 0.f;
+    sc[t] = cok[t] ? d.scale[c] : 0.f;
+  }
+  const cl_bf16x8 id0 = cld_ident(0, lane), id1 = cld_ident(1, lane);
+  const int p0 = 32 * wave;
+  const unsigned char* xrow = ximg + (CLD_HALO + p0 + l31) * RS + 16 * half;          // this lane's position, channel half 8 * half
+  const __amdgpu_buffer_rsrc_t rs_x = cl_rsrc(d.x, (uint32_t)min((int64_t)0x7ffffff0, (int64_t)d.S * CLD_T * RS));
+  const float n1 = 1.0f / (H * CLD_T), n2 = 1.0f / (2 * C * CLD_T);
+  __syncthreads();
+
+  for (int s = blockIdx.x; s < d.S; s += gridDim.x) {
+    // ---- this wave's rows of the sample: KC pieces of 1 KiB, contiguous in memory and in the image
+    const uint32_t sbase = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) cl_glds16(rs_x, ximg + (CLD_HALO + p0) * RS + i * 1024, sbase + i * 1024);
+    CL_VMCNT(0);
+    __syncthreads();
+    // ---- GEMM1
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KC; ++ks) {
+        const cl_bf16x8 af = cld_ld16(cld_smem + Cfg::F_W1 + (t * KC + ks) * 1024 + lane * 16);
+        const cl_bf16x8 bf = cld_ld16(xrow + (t - 1) * d.dil * RS + ks * 32);
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, hacc, 0, 0, 0);
+      }
+    float hv[RH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      hv[r] = hacc[r] + b1r[r];
+      s1 += hv[r];
+      s2 = fmaf(hv[r], hv[r], s2);
+    }
+    cld_block_sum2(s1, s2, red, wave, lane);
+    const float mu1 = s1 * n1;
+    const float rs1 = rsqrtf(fmaxf(s2 * n1 - mu1 * mu1, 0.f) + d.eps);
+    float av[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) av[r] = cld_bf16r(rfx_gelu(fmaf((hv[r] - mu1) * rs1, g1r[r], e1r[r])));
+    if (train) {
+      // [pos][HP]: registers 4 q .. 4 q + 3 are rows 8 q + 4 half + 0..3 = 8 consecutive bytes
+      uint16_t* ap = reinterpret_cast<uint16_t*>(d.a) + ((int64_t)s * CLD_T + p0 + l31) * HP + 4 * half;
+      uint16_t* hp = reinterpret_cast<uint16_t*>(d.hpre) + ((int64_t)s * CLD_T + p0 + l31) * HP + 4 * half;
+#pragma unroll
+      for (int q = 0; q < RH / 4; ++q) {
+        *reinterpret_cast<uint2*>(ap + 8 * q) = make_uint2(rfx_cvt_pk_bf16(av[4 * q], av[4 * q + 1]), rfx_cvt_pk_bf16(av[4 * q + 2], av[4 * q + 3]));
+        *reinterpret_cast<uint2*>(hp + 8 * q) = make_uint2(rfx_cvt_pk_bf16(hv[4 * q], hv[4 * q + 1]), rfx_cvt_pk_bf16(hv[4 * q + 2], hv[4 * q + 3]));
+      }
+    }
+    // ---- GEMM2 (transposed): z^T tiles, lane = channel
+    f32x16 z[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+      const cl_bf16x8 af = cld_pack8(av + 8 * ks);
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
+        z[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, cld_ld16(cld_smem + Cfg::F_W2 + (ks * NT2 + t) * 1024 + lane * 16), z[t], 0, 0, 0);
+    }
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTV; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        z[t][r] += b2v[t];
+        z[NTV + t][r] += b2g[t];
+        if (cok[t]) {
+          s1 += z[t][r] + z[NTV + t][r];
+          s2 = fmaf(z[t][r], z[t][r], fmaf(z[NTV + t][r], z[NTV + t][r], s2));
+        }
+      }
+    cld_block_sum2(s1, s2, red, wave, lane);
+    const float mu2 = s1 * n2;
+    const float rs2 = rsqrtf(fmaxf(s2 * n2 - mu2 * mu2, 0.f) + d.eps);
+    if (train && tid == 0) *reinterpret_cast<float4*>(d.stats + (int64_t)s * 4) = make_float4(mu1, rs1, mu2, rs2);
+    // ---- residual in the same layout, GLU, LayerScale; y over this wave's own rows of the image
+#pragma unroll
+    for (int t = 0; t < NTV; ++t) {
+      f32x16 xr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xr[r] = 0.f;
+      xr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(xrow + (2 * t) * 32), id0, xr, 0, 0, 0);
+      if (2 * t + 1 < KC) xr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(xrow + (2 * t + 1) * 32), id1, xr, 0, 0, 0);
+      if (cok[t]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float zv = fmaf((z[t][r] - mu2) * rs2, gv[t], ev[t]);
+          const float zg = fmaf((z[NTV + t][r] - mu2) * rs2, gg[t], eg[t]);
+          xr[r] = fmaf(sc[t], zv * cld_sigmoid(zg), xr[r]);
+        }
+      }
+      // all lanes of the wave have read the x rows of tile t's channels (the MFMAs above) before they are overwritten
+      __builtin_amdgcn_wave_barrier();
+      if (cok[t]) {
+        unsigned char* yb = ximg + (CLD_HALO + p0 + 4 * half) * RS + (32 * t + l31) * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          *reinterpret_cast<uint16_t*>(yb + ((r & 3) + 8 * (r >> 2)) * RS) = (uint16_t)rfx_bf16_bits(xr[r]);
+      }
+    }
+    CL_LGKM0();
+    __builtin_amdgcn_wave_barrier();
+    {
+      unsigned char* yo = reinterpret_cast<unsigned char*>(d.y) + (int64_t)s * (CLD_T * RS) + p0 * RS + lane * 16;
+      const unsigned char* yi = ximg + (CLD_HALO + p0) * RS + lane * 16;
+#pragma unroll
+      for (int i = 0; i < KC; ++i) *reinterpret_cast<uint4*>(yo + i * 1024) = *reinterpret_cast<const uint4*>(yi + i * 1024);
+    }
+    // the next sample's DMA overwrites this wave's rows: its own LDS reads above are done (program order + the waits), the
+    // other waves' halo reads of them happened before the first statistics barrier of this sample
+    CL_LGKM0();
+  }
+}
+
+// Backward.  Per-lane parameter-gradient sums (lane = channel): LayerScale, GroupNorm-2 weight / bias (value and gate rows),
+// GroupNorm-1 weight / bias; written per workgroup to `partial` ([gridDim.x][5 C + 2 H]: dscale | dgn2w | dgn2b | dgn1w | dgn1b)
+// and added over workgroups in a fixed order by the second launch of rfx_cl_dconv_bwd.
+template <int C, int H>
+__global__ __launch_bounds__(512, 2) void cl_dconv_bwd_kernel(const ClDconvK g) {
+  using Cfg = CldCfg<C, H>;
+  constexpr int HP = Cfg::HP, KC = Cfg::KC, KH = Cfg::KH, NTV = Cfg::NTV, NT2 = Cfg::NT2, RS = Cfg::RS, RSH = Cfg::RSH, RSZ = Cfg::RSZ;
+  constexpr int KZ = 2 * C / 16;                                  // K steps of da^T = dz^T W2 (k = the 2 C channels, natural order)
+  extern __shared__ __attribute__((aligned(16))) unsigned char cld_smem[];
+  const rfx_cl_dconv_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  unsigned char* gimg = cld_smem;                                 // gy, later dx: [256][C]
+  unsigned char* aimg = cld_smem + Cfg::B_A;                      // [256][HP]
+  unsigned char* himg = cld_smem + Cfg::B_HI;                     // [256][HP]
+  unsigned char* zimg = cld_smem + Cfg::B_DZ;                     // dz [256][2 C]
+  unsigned char* dhimg = cld_smem + Cfg::B_DH;                    // dh [2 + 256 + 2][HP]
+  float* red = reinterpret_cast<float*>(cld_smem + Cfg::B_RED);
+
+  cld_copy_in(cld_smem + Cfg::B_W2, d.w2p, KH * NT2 * 1024, tid);
+  cld_copy_in(cld_smem + Cfg::B_W2D, d.w2dp, KZ * 1024, tid);
+  cld_copy_in(cld_smem + Cfg::B_W1D, d.w1dp, 3 * KH * NTV * 1024, tid);
+  for (int o = tid * 4; o < CLD_HALO * RSH; o += 512 * 4) {
+    *reinterpret_cast<uint32_t*>(dhimg + o) = 0u;
+    *reinterpret_cast<uint32_t*>(dhimg + (CLD_T + CLD_HALO) * RSH + o) = 0u;
+  }
+  float b2v[NTV], b2g[NTV], gv[NTV], ev[NTV], gg[NTV], eg[NTV], sc[NTV];
+  bool cok[NTV];
+#pragma unroll
+  for (int t = 0; t < NTV; ++t) {
+    const int c = 32 * t + l31;
+    cok[t] = c < C;
+    b2v[t] = cok[t] ? d.b2[c] : 0.f;      b2g[t] = cok[t] ? d.b2[C + c] : 0.f;
+    gv[t] = cok[t] ? d.g2w[c] : 0.f;      gg[t] = cok[t] ? d.g2w[C + c] : 0.f;
+    ev[t] = cok[t] ? d.g2b[c] : 0.f;      eg[t] = cok[t] ? d.g2b[C + c] : 0.f;
+    sc[t] = cok[t] ? d.scale[c] : 0.f;
+  }
+  const bool hok = l31 < H;                                       // h-domain tiles: lane = hidden channel
+  const float g1 = hok ? d.g1w[l31] : 0.f, e1 = hok ? d.g1b[l31] : 0.f;
+  float a_ds[NTV], a_gwv[NTV], a_gwg[NTV], a_gbv[NTV], a_gbg[NTV], a_g1w = 0.f, a_g1b = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTV; ++t) a_ds[t] = a_gwv[t] = a_gwg[t] = a_gbv[t] = a_gbg[t] = 0.f;
+  const cl_bf16x8 id0 = cld_ident(0, lane), id1 = cld_ident(1, lane);
+  const int p0 = 32 * wave;
+  const int64_t big = 0x7ffffff0;
+  const __amdgpu_buffer_rsrc_t rs_g = cl_rsrc(d.gy, (uint32_t)min(big, (int64_t)d.S * CLD_T * RS));
+  const __amdgpu_buffer_rsrc_t rs_a = cl_rsrc(d.a, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
+  const __amdgpu_buffer_rsrc_t rs_h = cl_rsrc(d.hpre, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
+  const float n1 = 1.0f / (H * CLD_T), n2 = 1.0f / (2 * C * CLD_T);
+  const int prow = p0 + 4 * half;                                 // transposed tiles: register r = position prow + (r & 3) + 8 (r >> 2)
+  const unsigned char* grow = gimg + (p0 + l31) * RS + 16 * half;
+  __syncthreads();
+
+  for (int s = blockIdx.x; s < d.S; s += gridDim.x) {
+    {
+      const uint32_t gb = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+#pragma unroll
+      for (int i = 0; i < KC; ++i) cl_glds16(rs_g, gimg + p0 * RS + i * 1024, gb + i * 1024);
+      const uint32_t hb = (uint32_t)s * (CLD_T * RSH) + (uint32_t)p0 * RSH + lane * 16;       // 32 rows x RSH bytes = KH KiB
+#pragma unroll
+      for (int i = 0; i < KH; ++i) {
+        cl_glds16(rs_a, aimg + p0 * RSH + i * 1024, hb + i * 1024);
+        cl_glds16(rs_h, himg + p0 * RSH + i * 1024, hb + i * 1024);
+      }
+    }
+    const float4 st = *reinterpret_cast<const float4*>(d.stats + (int64_t)s * 4);
+    const float mu1 = st.x, rs1 = st.y, mu2 = st.z, rs2 = st.w;
+    CL_VMCNT(0);
+    __builtin_amdgcn_wave_barrier();                              // up to the halo barrier everything reads this wave's OWN rows
+    // ---- pass A, one (value, gate) tile pair at a time: z^T recomputed from a (k in the register order of the forward pass: two
+    // 8-byte runs per lane), GLU / LayerScale / GroupNorm-2 backward up to d(zhat); d(zhat) is parked as bf16 in the dz image until the
+    // sample sums are known (holding zhat and d(zhat) of all tiles in fp32 is 128 registers: the first build of this kernel spilled 145)
+    cl_bf16x8 afr[KH];
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+      const unsigned char* ar = aimg + (p0 + l31) * RSH + (16 * ks + 4 * half) * 2;
+      const uint2 lo = *reinterpret_cast<const uint2*>(ar), hi = *reinterpret_cast<const uint2*>(ar + 16);
+      afr[ks] = __builtin_bit_cast(cl_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTV; ++t) {
+      f32x16 zv, zg, gy;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zv[r] = zg[r] = gy[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+        zv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + t) * 1024 + lane * 16), zv, 0, 0, 0);
+        zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + NTV + t) * 1024 + lane * 16), zg, 0, 0, 0);
+      }
+      gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), id0, gy, 0, 0, 0);
+      if (2 * t + 1 < KC) gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), id1, gy, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
+        const float v = fmaf(zhv, gv[t], ev[t]), gt = fmaf(zhg, gg[t], eg[t]);
+        const float sg = cld_sigmoid(gt);
+        const float gyr = cok[t] ? gy[r] : 0.f;
+        a_ds[t] = fmaf(gyr, v * sg, a_ds[t]);
+        const float dg = gyr * sc[t];
+        const float dv = dg * sg, dgt = dg * v * sg * (1.f - sg);
+        a_gbv[t] += dv;  a_gwv[t] = fmaf(dv, zhv, a_gwv[t]);
+        a_gbg[t] += dgt; a_gwg[t] = fmaf(dgt, zhg, a_gwg[t]);
+        const uint32_t pk = rfx_cvt_pk_bf16(dv * gv[t], dgt * gg[t]);
+        const float dzv = __uint_as_float(pk << 16), dzg = __uint_as_float(pk & 0xffff0000u);     // the parked values: the sums match them
+        s1 += dzv + dzg;
+        s2 = fmaf(dzv, zhv, fmaf(dzg, zhg, s2));
+        if (cok[t]) {
+          unsigned char* zb = zimg + (prow + (r & 3) + 8 * (r >> 2)) * RSZ + (32 * t + l31) * 2;
+          *reinterpret_cast<uint16_t*>(zb) = (uint16_t)pk;
+          *reinterpret_cast<uint16_t*>(zb + 2 * C) = (uint16_t)(pk >> 16);
+        }
+      }
+    }
+    cld_block_sum2(s1, s2, red, wave, lane);
+    // ---- pass B: zhat again (two MFMAs per tile), dz = rstd (d(zhat) - mean(d(zhat)) - zhat mean(d(zhat) zhat)) -> image
+    {
+      const float m1 = s1 * n2, m2 = s2 * n2;
+#pragma unroll
+      for (int t = 0; t < NTV; ++t) {
+        f32x16 zv, zg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zv[r] = zg[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+          zv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + t) * 1024 + lane * 16), zv, 0, 0, 0);
+          zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + NTV + t) * 1024 + lane * 16), zg, 0, 0, 0);
+        }
+        if (cok[t]) {
+          unsigned char* zb = zimg + prow * RSZ + (32 * t + l31) * 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = ((r & 3) + 8 * (r >> 2)) * RSZ;
+            const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
+            const float dzv = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro) << 16);
+            const float dzg = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + 2 * C) << 16);
+            *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)rfx_bf16_bits(rs2 * (dzv - m1 - zhv * m2));
+            *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)rfx_bf16_bits(rs2 * (dzg - m1 - zhg * m2));
+          }
+        }
+      }
+    }
+    // ---- da^T = dz^T W2 (rows = own positions), h^T through the identity: lane = hidden channel
+    f32x16 da, ht;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) da[r] = ht[r] = 0.f;
+#pragma unroll
+    for (int kz = 0; kz < KZ; ++kz)
+      da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(zimg + (p0 + l31) * RSZ + (16 * kz + 8 * half) * 2),
+                                                    cld_ld16(cld_smem + Cfg::B_W2D + kz * 1024 + lane * 16), da, 0, 0, 0);
+    ht = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(himg + (p0 + l31) * RSH + 16 * half), id0, ht, 0, 0, 0);
+    if (KH > 1) ht = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(himg + (p0 + l31) * RSH + 32 + 16 * half), id1, ht, 0, 0, 0);
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float hh = (ht[r] - mu1) * rs1;
+      const float dhn = hok ? da[r] * rfx_gelu_grad(fmaf(hh, g1, e1)) : 0.f;
+      a_g1b += dhn;
+      a_g1w = fmaf(dhn, hh, a_g1w);
+      const float dhh = dhn * g1;
+      s1 += dhh;
+      s2 = fmaf(dhh, hh, s2);
+      ht[r] = hh; da[r] = dhh;
+    }
+    cld_block_sum2(s1, s2, red, wave, lane);
+    {
+      const float m1 = s1 * n1, m2 = s2 * n1;
+      if (l31 < HP) {
+        unsigned char* hb = dhimg + (CLD_HALO + prow) * RSH + l31 * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          *reinterpret_cast<uint16_t*>(hb + ((r & 3) + 8 * (r >> 2)) * RSH) = hok ? (uint16_t)rfx_bf16_bits(rs1 * (da[r] - m1 - ht[r] * m2)) : (uint16_t)0;
+      }
+    }
+    __syncthreads();                                              // the taps read the neighbouring waves' rows of dh
+    // ---- dx^T = gy^T + sum_t dh^T(pos - (t - 1) d) W1_t; written over gy (own rows)
+#pragma unroll
+    for (int t = 0; t < NTV; ++t) {
+      f32x16 dx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+      dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), id0, dx, 0, 0, 0);
+      if (2 * t + 1 < KC) dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), id1, dx, 0, 0, 0);
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks)
+          dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(dhimg + (CLD_HALO + p0 + l31 - (tp - 1) * d.dil) * RSH + (16 * ks + 8 * half) * 2),
+                                                        cld_ld16(cld_smem + Cfg::B_W1D + ((tp * KH + ks) * NTV + t) * 1024 + lane * 16), dx, 0, 0, 0);
+      if (cok[t]) {
+        unsigned char* xb = gimg + prow * RS + (32 * t + l31) * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *reinterpret_cast<uint16_t*>(xb + ((r & 3) + 8 * (r >> 2)) * RS) = (uint16_t)rfx_bf16_bits(dx[r]);
+      }
+    }
+    CL_LGKM0();
+    __builtin_amdgcn_wave_barrier();
+    {
+      unsigned char* o = reinterpret_cast<unsigned char*>(d.y) + (int64_t)s * (CLD_T * RS) + p0 * RS + lane * 16;
+#pragma unroll
+      for (int i = 0; i < KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(gimg + p0 * RS + i * 1024 + lane * 16);
+      o = reinterpret_cast<unsigned char*>(d.dz) + (int64_t)s * (CLD_T * RSZ) + p0 * RSZ + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 2 * KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(zimg + p0 * RSZ + i * 1024 + lane * 16);
+      o = reinterpret_cast<unsigned char*>(d.dh) + (int64_t)s * (CLD_T * RSH) + p0 * RSH + lane * 16;
+#pragma unroll
+      for (int i = 0; i < KH; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(dhimg + (CLD_HALO + p0) * RSH + i * 1024 + lane * 16);
+    }
+    CL_LGKM0();
+  }
+
+  // ---- parameter-gradient sums of this workgroup: lanes l and l + 32 hold the same channel, the 8 waves different positions
+  __syncthreads();
+  float* acc = reinterpret_cast<float*>(zimg);                    // [8 waves][5 NTV + 2][64]
+  constexpr int NQ = 5 * NTV + 2;
+#pragma unroll
+  for (int t = 0; t < NTV; ++t) {
+    acc[(wave * NQ + 5 * t + 0) * 64 + lane] = a_ds[t];
+    acc[(wave * NQ + 5 * t + 1) * 64 + lane] = a_gwv[t];
+    acc[(wave * NQ + 5 * t + 2) * 64 + lane] = a_gwg[t];
+    acc[(wave * NQ + 5 * t + 3) * 64 + lane] = a_gbv[t];
+    acc[(wave * NQ + 5 * t + 4) * 64 + lane] = a_gbg[t];
+  }
+  acc[(wave * NQ + 5 * NTV) * 64 + lane] = a_g1w;
+  acc[(wave * NQ + 5 * NTV + 1) * 64 + lane] = a_g1b;
+  __syncthreads();
+  float* prow_out = d.partial + (int64_t)blockIdx.x * (5 * C + 2 * H);
+  for (int i = tid; i < 5 * C + 2 * H; i += 512) {
+    // i -> (quantity q, lane n): dscale[c] | dgn2w[value c | gate c] | dgn2b[value c | gate c] | dgn1w[h] | dgn1b[h]
+    int q, n;
+    if (i < C) { q = 5 * (i >> 5) + 0; n = i & 31; }
+    else if (i < 2 * C) { const int c = i - C; q = 5 * (c >> 5) + 1; n = c & 31; }
+    else if (i < 3 * C) { const int c = i - 2 * C; q = 5 * (c >> 5) + 2; n = c & 31; }
+    else if (i < 4 * C) { const int c = i - 3 * C; q = 5 * (c >> 5) + 3; n = c & 31; }
+    else if (i < 5 * C) { const int c = i - 4 * C; q = 5 * (c >> 5) + 4; n = c & 31; }
+    else if (i < 5 * C + H) { q = 5 * NTV; n = i - 5 * C; }
+    else { q = 5 * NTV + 1; n = i - 5 * C - H; }
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += acc[(w * NQ + q) * 64 + n] + acc[(w * NQ + q) * 64 + 32 + n];
+    prow_out[i] = sum;
+  }
+}
+
+// out[i] = sum over workgroups of partial[g][i], one wave per output, fixed order
+__global__ __launch_bounds__(256) void cl_dconv_pgrad_kernel(const float* __restrict__ partial, int n, int G, float* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int gidx = l; gidx < G; gidx += 64) s += partial[(int64_t)gidx * n + i];
+  s = rfx_wave_sum(s);
+  if (l == 0) out[i] = s;
+}
+
+template <int C, int H>
+static int cld_launch(const rfx_cl_dconv_desc& d, bool bwd, hipStream_t st) {
+  using Cfg = CldCfg<C, H>;
+  static bool attr[2] = {false, false};
+  const int lds = bwd ? Cfg::B_LDS : Cfg::F_LDS;
+  const void* fn = bwd ? reinterpret_cast<const void*>(&cl_dconv_bwd_kernel<C, H>) : reinterpret_cast<const void*>(&cl_dconv_fwd_kernel<C, H>);
+  if (!attr[bwd]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
+    attr[bwd] = true;
+  }
+  ClDconvK k;
+  k.d = d;
+  const int grid = d.S < d.grid ? d.S : d.grid;
+  if (bwd) hipLaunchKernelGGL((cl_dconv_bwd_kernel<C, H>), dim3(grid), dim3(512), lds, st, k);
+  else hipLaunchKernelGGL((cl_dconv_fwd_kernel<C, H>), dim3(grid), dim3(512), lds, st, k);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+static bool cld_common_ok(const rfx_cl_dconv_desc* d) {
+  return d && d->x_or_gy_ok && d->S > 0 && (d->dil == 1 || d->dil == 2) && d->w2p && d->b1 && d->g1w && d->g1b && d->b2 && d->g2w && d->g2b &&
+         d->scale && d->grid > 0 && (int64_t)d->S * CLD_T * 4 * d->C < 0x7ffffff0LL;
+}
+
+extern "C" int rfx_cl_dconv_ok(int32_t C, int32_t H, int32_t T, int32_t backward) {
+  if (T != CLD_T || H * 4 != C) return 0;
+  if (C == 48) return 1;
+  if (C == 96) return backward ? 0 : 1;
+  return 0;
+}
+
+extern "C" int rfx_cl_dconv_fwd(const rfx_cl_dconv_desc* dp, void* stream) {
+  if (!dp || !dp->x || !dp->y || !dp->w1p) return -1;
+  rfx_cl_dconv_desc d = *dp;
+  d.x_or_gy_ok = 1;
+  if (!cld_common_ok(&d) || !rfx_cl_dconv_ok(d.C, d.H, CLD_T, 0)) return -1;
+  if ((d.a == nullptr) != (d.hpre == nullptr) || (d.a == nullptr) != (d.stats == nullptr)) return -1;
+  if (d.C == 48) return cld_launch<48, 12>(d, false, (hipStream_t)stream);
+  return cld_launch<96, 24>(d, false, (hipStream_t)stream);
+}
+
+extern "C" int rfx_cl_dconv_bwd(const rfx_cl_dconv_desc* dp, float* pgrad, void* stream) {
+  if (!dp || !dp->gy || !dp->y || !dp->a || !dp->hpre || !dp->stats || !dp->dz || !dp->dh || !dp->w2dp || !dp->w1dp || !dp->partial || !pgrad)
+    return -1;
+  rfx_cl_dconv_desc d = *dp;
+  d.x_or_gy_ok = 1;
+  if (!cld_common_ok(&d) || !rfx_cl_dconv_ok(d.C, d.H, CLD_T, 1)) return -1;
+  const int rc = cld_launch<48, 12>(d, true, (hipStream_t)stream);
+  if (rc) return rc;
+  const int n = 5 * d.C + 2 * d.H, G = d.S < d.grid ? d.S : d.grid;
+  hipLaunchKernelGGL(cl_dconv_pgrad_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, d.partial, n, G, pgrad);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

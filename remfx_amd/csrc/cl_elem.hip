@@ -4,7 +4,7 @@
 #include "cl_common.h"
 
 // (N, C, A, B) channel-major, B contiguous  ->  [N][A][B][bs] channels-last bf16.  Tile = 64 positions x 32 channels through LDS.
-// MODE: 0 store | 1 v * gelu'(aux) | 2 GLU backward against aux = stored [a | b] (dst carries 2 C channels: [ga | gb])
+// MODE: 0 store | 1 v * gelu'(aux) | 2 GLU backward against aux = stored [a | b] (dst carries 2 C channels: [ga | gb]) | 3 gelu(v)
 // res (optional, any mode): v += res first.  v and the sum are rounded to bf16 where a stored tensor would have been (the fused
 // passes replace "convert, store, re-read" chains and keep their roundings).
 template <typename T, int MODE>
@@ -42,6 +42,12 @@ __global__ __launch_bounds__(256) void cl_from_cm_kernel(const T* __restrict__ s
     }
     if (MODE == 0) {
       *reinterpret_cast<uint4*>(at(dst, c0)) = raw;
+    } else if (MODE == 3) {
+      float o[8];
+      cl_unpack8(raw, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rfx_gelu(v[e]);
+      *reinterpret_cast<uint4*>(at(dst, c0)) = cl_pack8(o);
     } else if (MODE == 1) {
       float z[8], o[8];
       cl_unpack8(raw, v);
@@ -66,9 +72,12 @@ __global__ __launch_bounds__(256) void cl_from_cm_kernel(const T* __restrict__ s
   }
 }
 
+// aux16 (optional, bf16 channel-major with dst's strides): dst = v * gelu'(aux16) -- the backward of a GELU whose input is stored
+// channel-major (the first encoder layer's convolution output)
 template <typename T>
 __global__ __launch_bounds__(256) void cl_to_cm_kernel(const uint16_t* __restrict__ src, int64_t s_ns, int64_t s_as, int s_bs, int C, int A,
-                                                       int B, T* __restrict__ dst, int64_t d_ns, int64_t d_cs, int64_t d_as) {
+                                                       int B, T* __restrict__ dst, int64_t d_ns, int64_t d_cs, int64_t d_as,
+                                                       const rfx_bf16s* __restrict__ aux16) {
   __shared__ uint16_t tile[32][66];
   const int tpb = B / 64;
   const int pt = blockIdx.x, cgp = blockIdx.y;
@@ -86,11 +95,15 @@ __global__ __launch_bounds__(256) void cl_to_cm_kernel(const uint16_t* __restric
   }
   __syncthreads();
   const int p = t & 63, cr = t >> 6;
-  T* o = dst + (int64_t)n * d_ns + (int64_t)a * d_as + b0 + p;
+  const int64_t ob = (int64_t)n * d_ns + (int64_t)a * d_as + b0 + p;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = cr + 4 * k, cc = cgp * 32 + c;
-    if (cc < C) rfx_st1(o + (int64_t)cc * d_cs, cl_bf2f(tile[c][p]));
+    if (cc < C) {
+      float v = cl_bf2f(tile[c][p]);
+      if (aux16 != nullptr) v *= rfx_gelu_grad(rfx_ld1(aux16 + ob + (int64_t)cc * d_cs));
+      rfx_st1(dst + ob + (int64_t)cc * d_cs, v);
+    }
   }
 }
 
@@ -99,6 +112,7 @@ static void cl_from_cm_launch(int mode, dim3 grid, hipStream_t st, const T* src,
                               int B, const rfx_cl_tensor& dst, const rfx_cl_tensor& res, const rfx_cl_tensor& aux) {
   if (mode == 0) hipLaunchKernelGGL((cl_from_cm_kernel<T, 0>), grid, dim3(256), 0, st, src, s_ns, s_cs, s_as, C, A, B, dst, res, aux);
   else if (mode == 1) hipLaunchKernelGGL((cl_from_cm_kernel<T, 1>), grid, dim3(256), 0, st, src, s_ns, s_cs, s_as, C, A, B, dst, res, aux);
+  else if (mode == 3) hipLaunchKernelGGL((cl_from_cm_kernel<T, 3>), grid, dim3(256), 0, st, src, s_ns, s_cs, s_as, C, A, B, dst, res, aux);
   else hipLaunchKernelGGL((cl_from_cm_kernel<T, 2>), grid, dim3(256), 0, st, src, s_ns, s_cs, s_as, C, A, B, dst, res, aux);
 }
 
@@ -106,7 +120,7 @@ extern "C" int rfx_cl_from_cm(const void* src, int32_t src_bf16, int64_t s_ns, i
                               int32_t A, int32_t B, const rfx_cl_tensor* dst, const rfx_cl_tensor* res, const rfx_cl_tensor* aux,
                               int32_t mode, void* stream) {
   if (!src || !dst || !dst->p || N <= 0 || C <= 0 || A <= 0 || B <= 0 || B % 64 || C % 8 || dst->c0 % 8 || dst->bs % 8) return -1;
-  if (mode < 0 || mode > 2 || (mode != 0 && (!aux || !aux->p || aux->bs % 8 || aux->c0 % 8))) return -1;
+  if (mode < 0 || mode > 3 || ((mode == 1 || mode == 2) && (!aux || !aux->p || aux->bs % 8 || aux->c0 % 8))) return -1;
   if (res && res->p && (res->bs % 8 || res->c0 % 8)) return -1;
   if (mode == 2 && (dst->bs < 2 * C || aux->bs < 2 * C)) return -1;
   const dim3 grid((unsigned)(N * A * (B / 64)), (unsigned)((C + 31) / 32));
@@ -122,16 +136,16 @@ extern "C" int rfx_cl_from_cm(const void* src, int32_t src_bf16, int64_t s_ns, i
 }
 
 extern "C" int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int32_t A, int32_t B, void* dst, int32_t dst_bf16,
-                            int64_t d_ns, int64_t d_cs, int64_t d_as, void* stream) {
+                            int64_t d_ns, int64_t d_cs, int64_t d_as, const void* aux16, void* stream) {
   if (!src || !src->p || !dst || N <= 0 || C <= 0 || A <= 0 || B <= 0 || B % 64 || C % 8 || src->c0 % 8 || src->bs % 8) return -1;
   const dim3 grid((unsigned)(N * A * (B / 64)), (unsigned)((C + 31) / 32));
   const uint16_t* s = reinterpret_cast<const uint16_t*>(src->p) + src->c0;
   if (dst_bf16)
     hipLaunchKernelGGL(cl_to_cm_kernel<rfx_bf16s>, grid, dim3(256), 0, (hipStream_t)stream, s, src->ns, src->as, src->bs, C, A, B,
-                       reinterpret_cast<rfx_bf16s*>(dst), d_ns, d_cs, d_as);
+                       reinterpret_cast<rfx_bf16s*>(dst), d_ns, d_cs, d_as, reinterpret_cast<const rfx_bf16s*>(aux16));
   else
     hipLaunchKernelGGL(cl_to_cm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s, src->ns, src->as, src->bs, C, A, B,
-                       reinterpret_cast<float*>(dst), d_ns, d_cs, d_as);
+                       reinterpret_cast<float*>(dst), d_ns, d_cs, d_as, reinterpret_cast<const rfx_bf16s*>(aux16));
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -188,6 +202,29 @@ extern "C" int rfx_cl_rowsum(const rfx_cl_tensor* x, int32_t N, int32_t A, int32
   const int64_t n = (int64_t)A * C;
   hipLaunchKernelGGL(cl_rowsum_final_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, partial, n, G, scale, out,
                      accumulate);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ---- flat elementwise on dense channels-last tensors -----------------------------------------------------------------------------
+// out = g * gelu'(z) over n8 groups of 8 bf16 (the backward of a GELU between two channels-last nodes)
+__global__ __launch_bounds__(256) void cl_dgelu_kernel(const uint4* __restrict__ g, const uint4* __restrict__ z, uint4* __restrict__ out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float a[8], b[8], o[8];
+    cl_unpack8(g[i], a);
+    cl_unpack8(z[i], b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] * rfx_gelu_grad(b[e]);
+    out[i] = cl_pack8(o);
+  }
+}
+extern "C" int rfx_cl_dgelu(const void* g, const void* z, void* out, int64_t n, void* stream) {
+  if (!g || !z || !out || n <= 0 || n % 8) return -1;
+  const int64_t n8 = n / 8;
+  const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+  hipLaunchKernelGGL(cl_dgelu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(g),
+                     reinterpret_cast<const uint4*>(z), reinterpret_cast<uint4*>(out), n8);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -123,6 +123,48 @@ def test_hdemucs_full_config_bf16_forward():
     assert e_hip < 2.0 * e_auto, (e_hip, e_auto)
 
 
+def test_hdemucs_full_config_bf16_gradients_vs_autocast(golden_dir):
+    """cfg/model/demucs.yaml geometry, one 262144-sample clip, EVERY parameter gradient (strided slices of <= 256 values per tensor,
+    395 tensors): the HIP bf16 mode -- the mode BENCH reports, channels-last trunk included -- is not further from the fp32 CPU oracle
+    than 2x the oracle's own error under torch.autocast("cpu", bfloat16) (fixture: oracle/gen_hdemucs_autocast_golden.py)."""
+    import os
+    import numpy as np
+    from oracle.gen_hdemucs_grad_golden import build, inputs
+    from remfx_amd.hdemucs import HDemucs
+    gd = np.load(os.path.join(golden_dir, "hdemucs_full_grad_autocast.npz"))
+    ref = build()
+    net = HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    del ref
+    net = net.to(DEV)
+    x, gy = inputs()
+    y = net(x.to(DEV))
+    y.backward(gy.to(DEV))
+    ys = y.detach().cpu().reshape(-1)[::4099].numpy()
+    e_hip = float(np.sqrt(((ys - gd["y32"]) ** 2).sum() / (gd["y32"] ** 2).sum()))
+    e_auto = float(np.sqrt(((gd["yauto"] - gd["y32"]) ** 2).sum() / (gd["y32"] ** 2).sum()))
+    print(f"output: relative error vs fp32 oracle: hip bf16 {e_hip:.3e}, autocast oracle {e_auto:.3e}")
+    assert e_hip < 2.0 * e_auto
+    params = dict(net.named_parameters())
+    num_h = num_a = den = 0.0
+    worst = (0.0, "")
+    for i, n in enumerate(gd["names"].tolist()):
+        g32, ga = gd[f"f{i}"].astype(np.float64), gd[f"a{i}"].astype(np.float64)
+        gr = params[n].grad.detach().cpu().reshape(-1)
+        step = max(1, gr.numel() // 256)
+        gh = gr[::step][:256].double().numpy()
+        eh, ea, nn = float(((gh - g32) ** 2).sum()), float(((ga - g32) ** 2).sum()), float((g32 ** 2).sum())
+        num_h += eh; num_a += ea; den += nn
+        ratio = (eh / max(ea, 1e-6 * nn, 1e-300)) ** 0.5
+        if ratio > worst[0]:
+            worst = (ratio, n)
+    rel_h, rel_a = (num_h / den) ** 0.5, (num_a / den) ** 0.5
+    print(f"gradients (395 tensors, sliced): relative error vs fp32 oracle: hip bf16 {rel_h:.3e}, autocast oracle {rel_a:.3e} "
+          f"(fixture {float(gd['auto_rel']):.3e}); worst per-tensor ratio {worst[0]:.2f} at {worst[1]}")
+    assert rel_h < 2.0 * rel_a
+    assert worst[0] < 6.0, worst
+
+
 @pytest.mark.one_mode
 def test_bf16_storage_is_exactly_rounding():
     """bf16 STORAGE of a conv output / its gradient (ops.bf16_storage) changes nothing but the stored bits: the 16-bit paths of the

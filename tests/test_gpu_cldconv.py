@@ -1,0 +1,84 @@
+"""GPU: the fused channels-last DConv depth-layer kernels (csrc/cl_dconv.hip) against the channel-major DConv of hdemucs._DConv
+(torchaudio HDemucs `_DConv`; reference call site remfx/models.py:319): forward and every gradient.  Reference = the channel-major
+path in the exact-fp32 mode; the channels-last kernels must not be further from it than the channel-major bf16 path is."""
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.one_mode]
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float(((a.double() - b.double()) ** 2).sum().sqrt() / (b.double() ** 2).sum().sqrt().clamp_min(1e-30))
+
+
+def _run_cm(mod, x, gy, mode):
+    from remfx_amd import ops
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision(mode)
+    try:
+        mod.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return y.detach(), xr.grad.detach(), {n: p.grad.detach().clone() for n, p in mod.named_parameters()}
+    finally:
+        ops.set_gemm_precision(prev)
+
+
+def _run_cl(mod, x, gy, Bn, A):
+    from remfx_amd import cldconv, ops
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision("bf16")
+    try:
+        mod.zero_grad(set_to_none=True)
+        S, Cc, T = x.shape
+        xc = x.view(Bn, A, Cc, T).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).requires_grad_(True)
+        gc = gy.view(Bn, A, Cc, T).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+        h = xc
+        for seq, (dil, pad, lstm, attn) in zip(mod.layers, mod.spec):
+            m = list(seq)
+            h = cldconv.dconv_layer(h, m[0], m[1], m[3], m[4], m[6].scale, dil)
+        h.backward(gc)
+        torch.cuda.synchronize()
+        back = lambda t: t.detach().float().permute(0, 1, 3, 2).reshape(S, Cc, T)
+        return back(h), back(xc.grad), {n: p.grad.detach().clone() for n, p in mod.named_parameters()}
+    finally:
+        ops.set_gemm_precision(prev)
+
+
+@pytest.mark.parametrize("Cc,Bn,A", [(48, 2, 3), (48, 3, 130)])
+def test_cl_dconv_vs_channel_major(Cc, Bn, A):
+    from remfx_amd.hdemucs import _DConv
+    torch.manual_seed(0)
+    mod = _DConv(Cc, depth=2, init=0.3).to(DEV)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if p.dim() == 1 and ("1.weight" in n or "4.weight" in n):        # GroupNorm weights away from 1, biases away from 0
+                p.add_(torch.randn_like(p) * 0.2)
+            if p.dim() == 1 and ("1.bias" in n or "4.bias" in n):
+                p.add_(torch.randn_like(p) * 0.2)
+    g = torch.Generator().manual_seed(1)
+    S = Bn * A
+    x = torch.randn(S, Cc, 256, generator=g).to(DEV)
+    x = x.to(torch.bfloat16).float()                                        # both paths see the same (bf16-representable) input
+    gy = torch.randn(S, Cc, 256, generator=g).to(DEV).to(torch.bfloat16).float()
+    y32, dx32, g32 = _run_cm(mod, x, gy, "f32")
+    y16, dx16, g16 = _run_cm(mod, x, gy, "bf16")
+    ycl, dxcl, gcl = _run_cl(mod, x, gy, Bn, A)
+    e16, ecl = _rel(y16, y32), _rel(ycl, y32)
+    print(f"y: channel-major bf16 {e16:.3e}, channels-last {ecl:.3e}")
+    assert ecl < 2.0 * e16 + 4e-3                                           # + the bf16 rounding of the stored y itself
+    e16, ecl = _rel(dx16, dx32), _rel(dxcl, dx32)
+    print(f"dx: channel-major bf16 {e16:.3e}, channels-last {ecl:.3e}")
+    assert ecl < 2.0 * e16 + 4e-3
+    for n in g32:
+        e16, ecl = _rel(g16[n], g32[n]), _rel(gcl[n], g32[n])
+        print(f"{n:28s} channel-major bf16 {e16:.3e}, channels-last {ecl:.3e}")
+        assert ecl < 2.5 * e16 + 5e-3, n
+    # deterministic
+    ycl2, dxcl2, gcl2 = _run_cl(mod, x, gy, Bn, A)
+    assert torch.equal(ycl, ycl2) and torch.equal(dxcl, dxcl2)
+    for n in gcl:
+        assert torch.equal(gcl[n], gcl2[n]), n
