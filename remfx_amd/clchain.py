@@ -42,7 +42,9 @@ _PACKS = {}
 
 
 def packed(f, w):
-    """MFMA fragments of weight w for GEMM form f, re-packed when the weight changed (ops.weights_changed / torch version)."""
+    """MFMA fragments of weight w for GEMM form f, re-packed when the weight changed (ops.weights_changed / torch version).  An
+    entry holds a reference to the tensor it was packed from: its storage cannot be freed and handed to another weight under the
+    same address while the entry lives (the keys are addresses)."""
     key = (id(f), w.data_ptr(), ops.raw_stream())
     try:
         ver = w._version
@@ -53,7 +55,9 @@ def packed(f, w):
         return e[2]
     ap = clast.pack(f, w.detach())
     if ver is not None:
-        _PACKS[key] = (ver, ops._WEIGHT_EPOCH[0], ap, f)
+        if len(_PACKS) > 2048:
+            _PACKS.clear()
+        _PACKS[key] = (ver, ops._WEIGHT_EPOCH[0], ap, f, w.detach())
     return ap
 
 
@@ -114,13 +118,18 @@ class EncMidFn(torch.autograd.Function):
     """d_i (Bn * A_i, C_i, T) fp32 -> e_i channels-last (Bn, A_i, T, C_i), y_{i+1} (Bn * A_i / 4, 2 C_i, T) fp32."""
 
     @staticmethod
-    def forward(ctx, d, rw_w, rw_b, cv_w, cv_b, emb_rows, Bn):
-        NA, Cc, T = d.shape
-        A = NA // Bn
+    def forward(ctx, d, rw_w, rw_b, cv_w, cv_b, emb_rows, Bn, y_cl):
+        d_is_cl = d.dim() == 4                      # the DConv branch in front ran on channels-last samples (cldconv)
+        if d_is_cl:
+            _, A, T, Cc = d.shape
+            d_cl = d if d.is_contiguous() else d.contiguous()
+        else:
+            NA, Cc, T = d.shape
+            A = NA // Bn
+            d_cl = clast.from_cm(_as_ncab(d if d.is_contiguous() else d.contiguous(), Bn, A))
         C1, A1 = cv_w.shape[0], A // 4
         dev = d.device
         train = any(ctx.needs_input_grad)
-        d_cl = clast.from_cm(_as_ncab(d, Bn, A))
         zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
         e = clast.empty(Bn, A, T, Cc, dev)
         fg = form("glu", 2 * Cc, Cc, 1, 1)
@@ -130,23 +139,29 @@ class EncMidFn(torch.autograd.Function):
         z1 = clast.empty(Bn, A1, T, C1, dev) if train else None
         y1 = clast.empty(Bn, A1, T, C1, dev)
         clast.conv(fs, packed(fs, cv_w), e, Bn, A, T, A1, "gelu", bias=cv_b, out0=z1, out1=y1)
-        y_cm = torch.empty((Bn * A1, C1, T), device=dev, dtype=torch.float32)
-        clast.to_cm(y1, out=_as_ncab(y_cm, Bn, A1))
+        if y_cl:                                    # the next DConv branch takes channels-last samples
+            y_out = y1
+        else:
+            y_out = torch.empty((Bn * A1, C1, T), device=dev, dtype=torch.float32)
+            clast.to_cm(y1, out=_as_ncab(y_out, Bn, A1))
         if train:
             ctx.save_for_backward(d_cl, zab, e, z1, rw_w, cv_w)
             ctx.refs = (rw_b, cv_b)
-            ctx.geom = (Bn, A, T, Cc, C1, A1, emb_rows is not None)
-        return e, y_cm
+            ctx.geom = (Bn, A, T, Cc, C1, A1, emb_rows is not None, d_is_cl, y_cl)
+        return e, y_out
 
     @staticmethod
     def backward(ctx, g_e, g_y):
         d_cl, zab, e, z1, rw_w, cv_w = ctx.saved_tensors
         rw_b, cv_b = ctx.refs
-        Bn, A, T, Cc, C1, A1, has_emb = ctx.geom
+        Bn, A, T, Cc, C1, A1, has_emb, d_is_cl, y_cl = ctx.geom
         dev = d_cl.device
-        # gradient of the next DConv's input -> channels-last, times gelu'(z1)
-        dz1 = clast.empty(Bn, A1, T, C1, dev)
-        clast.from_cm(_as_ncab(g_y if g_y.is_contiguous() else g_y.contiguous(), Bn, A1), out=dz1, aux=z1, mode="dgelu")
+        # gradient of the next DConv's input (-> channels-last) times gelu'(z1)
+        if y_cl:
+            dz1 = clast.dgelu(g_y if g_y.is_contiguous() else g_y.contiguous(), z1)
+        else:
+            dz1 = clast.empty(Bn, A1, T, C1, dev)
+            clast.from_cm(_as_ncab(g_y if g_y.is_contiguous() else g_y.contiguous(), Bn, A1), out=dz1, aux=z1, mode="dgelu")
         dcw, dcb = _wgrad(form("ws4", C1, Cc), dz1, e, Bn, A1, A, T, cv_w, cv_b)
         # conv input gradient + skip gradient, GLU backward against the stored [a | b]
         fd = form("s4d", C1, Cc)
@@ -162,9 +177,12 @@ class EncMidFn(torch.autograd.Function):
         fr = form("dgrad", 2 * Cc, Cc, 1, 1)
         dd_cl = clast.empty(Bn, A, T, Cc, dev)
         clast.conv(fr, packed(fr, rw_w), dzab, Bn, A, T, A, "store", out0=dd_cl)
-        dd = torch.empty((Bn * A, Cc, T), device=dev, dtype=torch.float32)
-        clast.to_cm(dd_cl, out=_as_ncab(dd, Bn, A))
-        return dd, drw, drb, dcw, dcb, demb, None
+        if d_is_cl:
+            dd = dd_cl
+        else:
+            dd = torch.empty((Bn * A, Cc, T), device=dev, dtype=torch.float32)
+            clast.to_cm(dd_cl, out=_as_ncab(dd, Bn, A))
+        return dd, drw, drb, dcw, dcb, demb, None, None
 
 
 class EncTailFn(torch.autograd.Function):
@@ -172,11 +190,16 @@ class EncTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, d, rw_w, rw_b, Bn):
-        NA, Cc, T = d.shape
-        A = NA // Bn
+        d_is_cl = d.dim() == 4
+        if d_is_cl:
+            _, A, T, Cc = d.shape
+            d_cl = d if d.is_contiguous() else d.contiguous()
+        else:
+            NA, Cc, T = d.shape
+            A = NA // Bn
+            d_cl = clast.from_cm(_as_ncab(d if d.is_contiguous() else d.contiguous(), Bn, A))
         dev = d.device
         train = any(ctx.needs_input_grad)
-        d_cl = clast.from_cm(_as_ncab(d, Bn, A))
         zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
         e = clast.empty(Bn, A, T, Cc, dev)
         fg = form("glu", 2 * Cc, Cc, 1, 1)
@@ -185,14 +208,14 @@ class EncTailFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(d_cl, zab, rw_w)
             ctx.refs = (rw_b,)
-            ctx.geom = (Bn, A, T, Cc)
+            ctx.geom = (Bn, A, T, Cc, d_is_cl)
         return e, e_cm
 
     @staticmethod
     def backward(ctx, g_e, g_cm):
         d_cl, zab, rw_w = ctx.saved_tensors
         (rw_b,) = ctx.refs
-        Bn, A, T, Cc = ctx.geom
+        Bn, A, T, Cc, d_is_cl = ctx.geom
         dev = d_cl.device
         if g_cm is None:
             raise RuntimeError("EncTailFn: the channel-major output carries no gradient")
@@ -204,8 +227,11 @@ class EncTailFn(torch.autograd.Function):
         fr = form("dgrad", 2 * Cc, Cc, 1, 1)
         dd_cl = clast.empty(Bn, A, T, Cc, dev)
         clast.conv(fr, packed(fr, rw_w), dzab, Bn, A, T, A, "store", out0=dd_cl)
-        dd = torch.empty((Bn * A, Cc, T), device=dev, dtype=torch.float32)
-        clast.to_cm(dd_cl, out=_as_ncab(dd, Bn, A))
+        if d_is_cl:
+            dd = dd_cl
+        else:
+            dd = torch.empty((Bn * A, Cc, T), device=dev, dtype=torch.float32)
+            clast.to_cm(dd_cl, out=_as_ncab(dd, Bn, A))
         return dd, drw, drb, None
 
 
@@ -290,8 +316,31 @@ class FreqDecoderFn(torch.autograd.Function):
         return (gx_cm, None, *grads_sk, *grads_p)
 
 
-def enc_mid(d, rewrite, conv_next, emb_rows, Bn):
-    return EncMidFn.apply(d, rewrite.weight, rewrite.bias, conv_next.weight, conv_next.bias, emb_rows, Bn)
+class HeadGeluFn(torch.autograd.Function):
+    """z (Bn, C, A, T) bf16 channel-major -- the first encoder layer's convolution output, whose two input channels keep it off the
+    channels-last kernels -- -> gelu(z) as channels-last samples (Bn, A, T, C); backward: g * gelu'(z) back in z's layout."""
+
+    @staticmethod
+    def forward(ctx, z):
+        ctx.save_for_backward(z)
+        return clast.from_cm(z, mode="gelu")
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        gz = torch.empty_like(z)
+        clast.to_cm(g if g.is_contiguous() else g.contiguous(), out=gz, aux16=z)
+        return gz
+
+
+def head_gelu(z):
+    if z.dtype != torch.bfloat16 or not z.is_contiguous():
+        raise ValueError("head_gelu: contiguous bf16 (N, C, A, T)")
+    return HeadGeluFn.apply(z)
+
+
+def enc_mid(d, rewrite, conv_next, emb_rows, Bn, y_cl=False):
+    return EncMidFn.apply(d, rewrite.weight, rewrite.bias, conv_next.weight, conv_next.bias, emb_rows, Bn, y_cl)
 
 
 def enc_tail(d, rewrite, Bn):

@@ -21,6 +21,10 @@
 #include "cl_common.h"
 
 #define CLD_T 256
+// The packed-weight fragment reads are loop-invariant LDS loads: without a memory clobber in the sample loop LICM hoists all of them
+// (52 - 64 registers of fragments, spilled to scratch on the spot and re-read from SCRATCH inside the loop: the first build of the
+// backward kernel spent 80 % of its wave cycles parked on those reloads, SQ_WAIT_ANY / SQ_WAVE_CYCLES, r05 counters)
+#define CLD_NO_HOIST() asm volatile("" ::: "memory")
 #define CLD_HALO 2
 
 struct ClDconvK {
@@ -66,11 +70,12 @@ struct CldCfg {
 };
 
 // cooperative copy of `bytes` (a multiple of 1024) from global to LDS, linear
-__device__ __forceinline__ void cld_copy_in(unsigned char* lds, const void* src, int bytes, int tid) {
-  for (int o = tid * 16; o < bytes; o += 512 * 16) *reinterpret_cast<uint4*>(lds + o) = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + o);
+__device__ __forceinline__ void cld_copy_in(unsigned char* lds, const void* src, int bytes, int tid, int nthreads = 512) {
+  for (int o = tid * 16; o < bytes; o += nthreads * 16) *reinterpret_cast<uint4*>(lds + o) = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + o);
 }
 
 // sum of v over the workgroup (all lanes get it); `red` = 8 floats of LDS; two barriers
+template <int NW = 8>
 __device__ __forceinline__ void cld_block_sum2(float& a, float& b, float* red, int wave, int lane) {
   a = rfx_wave_sum(a);
   b = rfx_wave_sum(b);
@@ -78,7 +83,7 @@ __device__ __forceinline__ void cld_block_sum2(float& a, float& b, float* red, i
   __syncthreads();
   float sa = 0.f, sb = 0.f;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) { sa += red[w]; sb += red[8 + w]; }
+  for (int w = 0; w < NW; ++w) { sa += red[w]; sb += red[8 + w]; }
   __syncthreads();
   a = sa; b = sb;
 }
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
   __syncthreads();
 
   for (int s = blockIdx.x; s < d.S; s += gridDim.x) {
+    CLD_NO_HOIST();
     // ---- this wave's rows of the sample: KC pieces of 1 KiB, contiguous in memory and in the image
     const uint32_t sbase = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
 #pragma unroll
@@ -244,11 +250,15 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
 // Backward.  Per-lane parameter-gradient sums (lane = channel): LayerScale, GroupNorm-2 weight / bias (value and gate rows),
 // GroupNorm-1 weight / bias; written per workgroup to `partial` ([gridDim.x][5 C + 2 H]: dscale | dgn2w | dgn2b | dgn1w | dgn1b)
 // and added over workgroups in a fixed order by the second launch of rfx_cl_dconv_bwd.
+// FOUR waves per workgroup, one per SIMD, each walking its 64 positions as two 32-position tiles: with eight waves (256 registers
+// each) the compiler spilled 104 registers and the waves sat parked on scratch reloads 80 % of their cycles (4.98 ms per launch at
+// S = 32768, r05 SQ counters); one wave per SIMD has the whole 512-register file, what does not fit the 256 VGPRs goes to AGPRs.
 template <int C, int H>
-__global__ __launch_bounds__(512, 2) void cl_dconv_bwd_kernel(const ClDconvK g) {
+__global__ __launch_bounds__(256, 1) void cl_dconv_bwd_kernel(const ClDconvK g) {
   using Cfg = CldCfg<C, H>;
   constexpr int HP = Cfg::HP, KC = Cfg::KC, KH = Cfg::KH, NTV = Cfg::NTV, NT2 = Cfg::NT2, RS = Cfg::RS, RSH = Cfg::RSH, RSZ = Cfg::RSZ;
   constexpr int KZ = 2 * C / 16;                                  // K steps of da^T = dz^T W2 (k = the 2 C channels, natural order)
+  constexpr int NW = 4, SUB = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char cld_smem[];
   const rfx_cl_dconv_desc& d = g.d;
   const int tid = threadIdx.x;
@@ -260,10 +270,10 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_bwd_kernel(const ClDconvK g) 
   unsigned char* dhimg = cld_smem + Cfg::B_DH;                    // dh [2 + 256 + 2][HP]
   float* red = reinterpret_cast<float*>(cld_smem + Cfg::B_RED);
 
-  cld_copy_in(cld_smem + Cfg::B_W2, d.w2p, KH * NT2 * 1024, tid);
-  cld_copy_in(cld_smem + Cfg::B_W2D, d.w2dp, KZ * 1024, tid);
-  cld_copy_in(cld_smem + Cfg::B_W1D, d.w1dp, 3 * KH * NTV * 1024, tid);
-  for (int o = tid * 4; o < CLD_HALO * RSH; o += 512 * 4) {
+  cld_copy_in(cld_smem + Cfg::B_W2, d.w2p, KH * NT2 * 1024, tid, 256);
+  cld_copy_in(cld_smem + Cfg::B_W2D, d.w2dp, KZ * 1024, tid, 256);
+  cld_copy_in(cld_smem + Cfg::B_W1D, d.w1dp, 3 * KH * NTV * 1024, tid, 256);
+  for (int o = tid * 4; o < CLD_HALO * RSH; o += 256 * 4) {
     *reinterpret_cast<uint32_t*>(dhimg + o) = 0u;
     *reinterpret_cast<uint32_t*>(dhimg + (CLD_T + CLD_HALO) * RSH + o) = 0u;
   }
@@ -284,26 +294,24 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_bwd_kernel(const ClDconvK g) 
 #pragma unroll
   for (int t = 0; t < NTV; ++t) a_ds[t] = a_gwv[t] = a_gwg[t] = a_gbv[t] = a_gbg[t] = 0.f;
   const cl_bf16x8 id0 = cld_ident(0, lane), id1 = cld_ident(1, lane);
-  const int p0 = 32 * wave;
+  const int w0 = 64 * wave;                                       // this wave's rows: [w0, w0 + 64)
   const int64_t big = 0x7ffffff0;
   const __amdgpu_buffer_rsrc_t rs_g = cl_rsrc(d.gy, (uint32_t)min(big, (int64_t)d.S * CLD_T * RS));
   const __amdgpu_buffer_rsrc_t rs_a = cl_rsrc(d.a, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
   const __amdgpu_buffer_rsrc_t rs_h = cl_rsrc(d.hpre, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
   const float n1 = 1.0f / (H * CLD_T), n2 = 1.0f / (2 * C * CLD_T);
-  const int prow = p0 + 4 * half;                                 // transposed tiles: register r = position prow + (r & 3) + 8 (r >> 2)
-  const unsigned char* grow = gimg + (p0 + l31) * RS + 16 * half;
   __syncthreads();
 
   for (int s = blockIdx.x; s < d.S; s += gridDim.x) {
     {
-      const uint32_t gb = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+      const uint32_t gb = (uint32_t)s * (CLD_T * RS) + (uint32_t)w0 * RS + lane * 16;
 #pragma unroll
-      for (int i = 0; i < KC; ++i) cl_glds16(rs_g, gimg + p0 * RS + i * 1024, gb + i * 1024);
-      const uint32_t hb = (uint32_t)s * (CLD_T * RSH) + (uint32_t)p0 * RSH + lane * 16;       // 32 rows x RSH bytes = KH KiB
+      for (int i = 0; i < 2 * KC; ++i) cl_glds16(rs_g, gimg + w0 * RS + i * 1024, gb + i * 1024);
+      const uint32_t hb = (uint32_t)s * (CLD_T * RSH) + (uint32_t)w0 * RSH + lane * 16;       // 64 rows x RSH bytes = 2 KH KiB
 #pragma unroll
-      for (int i = 0; i < KH; ++i) {
-        cl_glds16(rs_a, aimg + p0 * RSH + i * 1024, hb + i * 1024);
-        cl_glds16(rs_h, himg + p0 * RSH + i * 1024, hb + i * 1024);
+      for (int i = 0; i < 2 * KH; ++i) {
+        cl_glds16(rs_a, aimg + w0 * RSH + i * 1024, hb + i * 1024);
+        cl_glds16(rs_h, himg + w0 * RSH + i * 1024, hb + i * 1024);
       }
     }
     const float4 st = *reinterpret_cast<const float4*>(d.stats + (int64_t)s * 4);
@@ -311,150 +319,182 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_bwd_kernel(const ClDconvK g) 
     CL_VMCNT(0);
     __builtin_amdgcn_wave_barrier();                              // up to the halo barrier everything reads this wave's OWN rows
     // ---- pass A, one (value, gate) tile pair at a time: z^T recomputed from a (k in the register order of the forward pass: two
-    // 8-byte runs per lane), GLU / LayerScale / GroupNorm-2 backward up to d(zhat); d(zhat) is parked as bf16 in the dz image until the
-    // sample sums are known (holding zhat and d(zhat) of all tiles in fp32 is 128 registers: the first build of this kernel spilled 145)
-    cl_bf16x8 afr[KH];
-#pragma unroll
-    for (int ks = 0; ks < KH; ++ks) {
-      const unsigned char* ar = aimg + (p0 + l31) * RSH + (16 * ks + 4 * half) * 2;
-      const uint2 lo = *reinterpret_cast<const uint2*>(ar), hi = *reinterpret_cast<const uint2*>(ar + 16);
-      afr[ks] = __builtin_bit_cast(cl_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-    }
+    // 8-byte runs per lane), GLU / LayerScale / GroupNorm-2 backward up to d(zhat), parked as bf16 in the dz image until the sample
+    // sums are known
     float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < NTV; ++t) {
-      f32x16 zv, zg, gy;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) zv[r] = zg[r] = gy[r] = 0.f;
+    // (not unrolled: with both tiles' bodies in one block the parameter-gradient accumulators made the register allocator spill 182
+    // registers past the 512 it has)
+#pragma unroll 1
+    for (int sub = 0; sub < SUB; ++sub) {
+      const int p0 = w0 + 32 * sub, prow = p0 + 4 * half;
+      const unsigned char* grow = gimg + (p0 + l31) * RS + 16 * half;
+      cl_bf16x8 afr[KH];
 #pragma unroll
       for (int ks = 0; ks < KH; ++ks) {
-        zv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + t) * 1024 + lane * 16), zv, 0, 0, 0);
-        zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + NTV + t) * 1024 + lane * 16), zg, 0, 0, 0);
+        const unsigned char* ar = aimg + (p0 + l31) * RSH + (16 * ks + 4 * half) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(ar), hi = *reinterpret_cast<const uint2*>(ar + 16);
+        afr[ks] = __builtin_bit_cast(cl_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
       }
-      gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), id0, gy, 0, 0, 0);
-      if (2 * t + 1 < KC) gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), id1, gy, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
-        const float v = fmaf(zhv, gv[t], ev[t]), gt = fmaf(zhg, gg[t], eg[t]);
-        const float sg = cld_sigmoid(gt);
-        const float gyr = cok[t] ? gy[r] : 0.f;
-        a_ds[t] = fmaf(gyr, v * sg, a_ds[t]);
-        const float dg = gyr * sc[t];
-        const float dv = dg * sg, dgt = dg * v * sg * (1.f - sg);
-        a_gbv[t] += dv;  a_gwv[t] = fmaf(dv, zhv, a_gwv[t]);
-        a_gbg[t] += dgt; a_gwg[t] = fmaf(dgt, zhg, a_gwg[t]);
-        const uint32_t pk = rfx_cvt_pk_bf16(dv * gv[t], dgt * gg[t]);
-        const float dzv = __uint_as_float(pk << 16), dzg = __uint_as_float(pk & 0xffff0000u);     // the parked values: the sums match them
-        s1 += dzv + dzg;
-        s2 = fmaf(dzv, zhv, fmaf(dzg, zhg, s2));
-        if (cok[t]) {
-          unsigned char* zb = zimg + (prow + (r & 3) + 8 * (r >> 2)) * RSZ + (32 * t + l31) * 2;
-          *reinterpret_cast<uint16_t*>(zb) = (uint16_t)pk;
-          *reinterpret_cast<uint16_t*>(zb + 2 * C) = (uint16_t)(pk >> 16);
-        }
-      }
-    }
-    cld_block_sum2(s1, s2, red, wave, lane);
-    // ---- pass B: zhat again (two MFMAs per tile), dz = rstd (d(zhat) - mean(d(zhat)) - zhat mean(d(zhat) zhat)) -> image
-    {
-      const float m1 = s1 * n2, m2 = s2 * n2;
 #pragma unroll
       for (int t = 0; t < NTV; ++t) {
-        f32x16 zv, zg;
+        f32x16 zv, zg, gy;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zv[r] = zg[r] = 0.f;
+        for (int r = 0; r < 16; ++r) zv[r] = zg[r] = gy[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
           zv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + t) * 1024 + lane * 16), zv, 0, 0, 0);
           zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + NTV + t) * 1024 + lane * 16), zg, 0, 0, 0);
         }
-        if (cok[t]) {
-          unsigned char* zb = zimg + prow * RSZ + (32 * t + l31) * 2;
+        gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), id0, gy, 0, 0, 0);
+        if (2 * t + 1 < KC) gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), id1, gy, 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ro = ((r & 3) + 8 * (r >> 2)) * RSZ;
-            const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
-            const float dzv = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro) << 16);
-            const float dzg = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + 2 * C) << 16);
-            *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)rfx_bf16_bits(rs2 * (dzv - m1 - zhv * m2));
-            *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)rfx_bf16_bits(rs2 * (dzg - m1 - zhg * m2));
+        for (int r = 0; r < 16; ++r) {
+          const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
+          const float v = fmaf(zhv, gv[t], ev[t]), gt = fmaf(zhg, gg[t], eg[t]);
+          const float sg = cld_sigmoid(gt);
+          const float gyr = cok[t] ? gy[r] : 0.f;
+          a_ds[t] = fmaf(gyr, v * sg, a_ds[t]);
+          const float dg = gyr * sc[t];
+          const float dv = dg * sg, dgt = dg * v * sg * (1.f - sg);
+          a_gbv[t] += dv;  a_gwv[t] = fmaf(dv, zhv, a_gwv[t]);
+          a_gbg[t] += dgt; a_gwg[t] = fmaf(dgt, zhg, a_gwg[t]);
+          const uint32_t pk = rfx_cvt_pk_bf16(dv * gv[t], dgt * gg[t]);
+          const float dzv = __uint_as_float(pk << 16), dzg = __uint_as_float(pk & 0xffff0000u);     // the parked values: the sums match them
+          s1 += dzv + dzg;
+          s2 = fmaf(dzv, zhv, fmaf(dzg, zhg, s2));
+          if (cok[t]) {
+            unsigned char* zb = zimg + (prow + (r & 3) + 8 * (r >> 2)) * RSZ + (32 * t + l31) * 2;
+            *reinterpret_cast<uint16_t*>(zb) = (uint16_t)pk;
+            *reinterpret_cast<uint16_t*>(zb + 2 * C) = (uint16_t)(pk >> 16);
           }
         }
       }
     }
-    // ---- da^T = dz^T W2 (rows = own positions), h^T through the identity: lane = hidden channel
-    f32x16 da, ht;
+    cld_block_sum2<NW>(s1, s2, red, wave, lane);
+    // ---- pass B: zhat again (two MFMAs per tile), dz = rstd (d(zhat) - mean(d(zhat)) - zhat mean(d(zhat) zhat)) -> image; then
+    // da^T = dz^T W2 (rows = own positions) and h^T through the identity: lane = hidden channel
+    f32x16 da[SUB], ht[SUB];
+    {
+      const float m1 = s1 * n2, m2 = s2 * n2;
+      s1 = 0.f; s2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) da[r] = ht[r] = 0.f;
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int p0 = w0 + 32 * sub, prow = p0 + 4 * half;
+        cl_bf16x8 afr[KH];
 #pragma unroll
-    for (int kz = 0; kz < KZ; ++kz)
-      da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(zimg + (p0 + l31) * RSZ + (16 * kz + 8 * half) * 2),
-                                                    cld_ld16(cld_smem + Cfg::B_W2D + kz * 1024 + lane * 16), da, 0, 0, 0);
-    ht = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(himg + (p0 + l31) * RSH + 16 * half), id0, ht, 0, 0, 0);
-    if (KH > 1) ht = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(himg + (p0 + l31) * RSH + 32 + 16 * half), id1, ht, 0, 0, 0);
-    s1 = 0.f; s2 = 0.f;
+        for (int ks = 0; ks < KH; ++ks) {
+          const unsigned char* ar = aimg + (p0 + l31) * RSH + (16 * ks + 4 * half) * 2;
+          const uint2 lo = *reinterpret_cast<const uint2*>(ar), hi = *reinterpret_cast<const uint2*>(ar + 16);
+          afr[ks] = __builtin_bit_cast(cl_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float hh = (ht[r] - mu1) * rs1;
-      const float dhn = hok ? da[r] * rfx_gelu_grad(fmaf(hh, g1, e1)) : 0.f;
-      a_g1b += dhn;
-      a_g1w = fmaf(dhn, hh, a_g1w);
-      const float dhh = dhn * g1;
-      s1 += dhh;
-      s2 = fmaf(dhh, hh, s2);
-      ht[r] = hh; da[r] = dhh;
+        for (int t = 0; t < NTV; ++t) {
+          f32x16 zv, zg;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zv[r] = zg[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KH; ++ks) {
+            zv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + t) * 1024 + lane * 16), zv, 0, 0, 0);
+            zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + NTV + t) * 1024 + lane * 16), zg, 0, 0, 0);
+          }
+          if (cok[t]) {
+            unsigned char* zb = zimg + prow * RSZ + (32 * t + l31) * 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ro = ((r & 3) + 8 * (r >> 2)) * RSZ;
+              const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
+              const float dzv = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro) << 16);
+              const float dzg = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + 2 * C) << 16);
+              *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)rfx_bf16_bits(rs2 * (dzv - m1 - zhv * m2));
+              *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)rfx_bf16_bits(rs2 * (dzg - m1 - zhg * m2));
+            }
+          }
+        }
+        f32x16 dat, htt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dat[r] = htt[r] = 0.f;
+#pragma unroll
+        for (int kz = 0; kz < KZ; ++kz)
+          dat = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(zimg + (p0 + l31) * RSZ + (16 * kz + 8 * half) * 2),
+                                                         cld_ld16(cld_smem + Cfg::B_W2D + kz * 1024 + lane * 16), dat, 0, 0, 0);
+        htt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(himg + (p0 + l31) * RSH + 16 * half), id0, htt, 0, 0, 0);
+        if (KH > 1) htt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(himg + (p0 + l31) * RSH + 32 + 16 * half), id1, htt, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float hh = (htt[r] - mu1) * rs1;
+          const float dhn = hok ? dat[r] * rfx_gelu_grad(fmaf(hh, g1, e1)) : 0.f;
+          a_g1b += dhn;
+          a_g1w = fmaf(dhn, hh, a_g1w);
+          const float dhh = dhn * g1;
+          s1 += dhh;
+          s2 = fmaf(dhh, hh, s2);
+          htt[r] = hh; dat[r] = dhh;
+        }
+        da[sub] = dat; ht[sub] = htt;
+      }
     }
-    cld_block_sum2(s1, s2, red, wave, lane);
+    cld_block_sum2<NW>(s1, s2, red, wave, lane);
     {
       const float m1 = s1 * n1, m2 = s2 * n1;
       if (l31 < HP) {
-        unsigned char* hb = dhimg + (CLD_HALO + prow) * RSH + l31 * 2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          *reinterpret_cast<uint16_t*>(hb + ((r & 3) + 8 * (r >> 2)) * RSH) = hok ? (uint16_t)rfx_bf16_bits(rs1 * (da[r] - m1 - ht[r] * m2)) : (uint16_t)0;
+        for (int sub = 0; sub < SUB; ++sub) {
+          unsigned char* hb = dhimg + (CLD_HALO + w0 + 32 * sub + 4 * half) * RSH + l31 * 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            *reinterpret_cast<uint16_t*>(hb + ((r & 3) + 8 * (r >> 2)) * RSH) =
+                hok ? (uint16_t)rfx_bf16_bits(rs1 * (da[sub][r] - m1 - ht[sub][r] * m2)) : (uint16_t)0;
+        }
       }
     }
     __syncthreads();                                              // the taps read the neighbouring waves' rows of dh
     // ---- dx^T = gy^T + sum_t dh^T(pos - (t - 1) d) W1_t; written over gy (own rows)
 #pragma unroll
-    for (int t = 0; t < NTV; ++t) {
-      f32x16 dx;
+    for (int sub = 0; sub < SUB; ++sub) {
+      const int p0 = w0 + 32 * sub, prow = p0 + 4 * half;
+      const unsigned char* grow = gimg + (p0 + l31) * RS + 16 * half;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dx[r] = 0.f;
-      dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), id0, dx, 0, 0, 0);
-      if (2 * t + 1 < KC) dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), id1, dx, 0, 0, 0);
+      for (int t = 0; t < NTV; ++t) {
+        f32x16 dx;
 #pragma unroll
-      for (int tp = 0; tp < 3; ++tp)
+        for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+        dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), id0, dx, 0, 0, 0);
+        if (2 * t + 1 < KC) dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), id1, dx, 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < KH; ++ks)
-          dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(dhimg + (CLD_HALO + p0 + l31 - (tp - 1) * d.dil) * RSH + (16 * ks + 8 * half) * 2),
-                                                        cld_ld16(cld_smem + Cfg::B_W1D + ((tp * KH + ks) * NTV + t) * 1024 + lane * 16), dx, 0, 0, 0);
-      if (cok[t]) {
-        unsigned char* xb = gimg + prow * RS + (32 * t + l31) * 2;
+        for (int tp = 0; tp < 3; ++tp)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) *reinterpret_cast<uint16_t*>(xb + ((r & 3) + 8 * (r >> 2)) * RS) = (uint16_t)rfx_bf16_bits(dx[r]);
+          for (int ks = 0; ks < KH; ++ks)
+            dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(dhimg + (CLD_HALO + p0 + l31 - (tp - 1) * d.dil) * RSH + (16 * ks + 8 * half) * 2),
+                                                          cld_ld16(cld_smem + Cfg::B_W1D + ((tp * KH + ks) * NTV + t) * 1024 + lane * 16), dx, 0, 0, 0);
+        // every lane of the wave has read tile t's channels of these rows (the identity MFMAs) before they are overwritten: LDS
+        // operations of one wave execute in order
+        if (cok[t]) {
+          unsigned char* xb = gimg + prow * RS + (32 * t + l31) * 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) *reinterpret_cast<uint16_t*>(xb + ((r & 3) + 8 * (r >> 2)) * RS) = (uint16_t)rfx_bf16_bits(dx[r]);
+        }
       }
     }
     CL_LGKM0();
     __builtin_amdgcn_wave_barrier();
     {
-      unsigned char* o = reinterpret_cast<unsigned char*>(d.y) + (int64_t)s * (CLD_T * RS) + p0 * RS + lane * 16;
+      unsigned char* o = reinterpret_cast<unsigned char*>(d.y) + (int64_t)s * (CLD_T * RS) + w0 * RS + lane * 16;
 #pragma unroll
-      for (int i = 0; i < KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(gimg + p0 * RS + i * 1024 + lane * 16);
-      o = reinterpret_cast<unsigned char*>(d.dz) + (int64_t)s * (CLD_T * RSZ) + p0 * RSZ + lane * 16;
+      for (int i = 0; i < 2 * KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(gimg + w0 * RS + i * 1024 + lane * 16);
+      o = reinterpret_cast<unsigned char*>(d.dz) + (int64_t)s * (CLD_T * RSZ) + w0 * RSZ + lane * 16;
 #pragma unroll
-      for (int i = 0; i < 2 * KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(zimg + p0 * RSZ + i * 1024 + lane * 16);
-      o = reinterpret_cast<unsigned char*>(d.dh) + (int64_t)s * (CLD_T * RSH) + p0 * RSH + lane * 16;
+      for (int i = 0; i < 4 * KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(zimg + w0 * RSZ + i * 1024 + lane * 16);
+      o = reinterpret_cast<unsigned char*>(d.dh) + (int64_t)s * (CLD_T * RSH) + w0 * RSH + lane * 16;
 #pragma unroll
-      for (int i = 0; i < KH; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(dhimg + (CLD_HALO + p0) * RSH + i * 1024 + lane * 16);
+      for (int i = 0; i < 2 * KH; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(dhimg + (CLD_HALO + w0) * RSH + i * 1024 + lane * 16);
     }
     CL_LGKM0();
+    // the next sample's dh rows are written only after its own block sums: every wave has finished its taps by then
   }
 
-  // ---- parameter-gradient sums of this workgroup: lanes l and l + 32 hold the same channel, the 8 waves different positions
+  // ---- parameter-gradient sums of this workgroup: lanes l and l + 32 hold the same channel, the waves different positions
   __syncthreads();
-  float* acc = reinterpret_cast<float*>(zimg);                    // [8 waves][5 NTV + 2][64]
+  float* acc = reinterpret_cast<float*>(zimg);                    // [NW waves][5 NTV + 2][64]
   constexpr int NQ = 5 * NTV + 2;
 #pragma unroll
   for (int t = 0; t < NTV; ++t) {
@@ -468,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_bwd_kernel(const ClDconvK g) 
   acc[(wave * NQ + 5 * NTV + 1) * 64 + lane] = a_g1b;
   __syncthreads();
   float* prow_out = d.partial + (int64_t)blockIdx.x * (5 * C + 2 * H);
-  for (int i = tid; i < 5 * C + 2 * H; i += 512) {
+  for (int i = tid; i < 5 * C + 2 * H; i += 256) {
     // i -> (quantity q, lane n): dscale[c] | dgn2w[value c | gate c] | dgn2b[value c | gate c] | dgn1w[h] | dgn1b[h]
     int q, n;
     if (i < C) { q = 5 * (i >> 5) + 0; n = i & 31; }
@@ -480,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_bwd_kernel(const ClDconvK g) 
     else { q = 5 * NTV + 1; n = i - 5 * C - H; }
     float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) sum += acc[(w * NQ + q) * 64 + n] + acc[(w * NQ + q) * 64 + 32 + n];
+    for (int w = 0; w < NW; ++w) sum += acc[(w * NQ + q) * 64 + n] + acc[(w * NQ + q) * 64 + 32 + n];
     prow_out[i] = sum;
   }
 }
@@ -508,7 +548,7 @@ static int cld_launch(const rfx_cl_dconv_desc& d, bool bwd, hipStream_t st) {
   ClDconvK k;
   k.d = d;
   const int grid = d.S < d.grid ? d.S : d.grid;
-  if (bwd) hipLaunchKernelGGL((cl_dconv_bwd_kernel<C, H>), dim3(grid), dim3(512), lds, st, k);
+  if (bwd) hipLaunchKernelGGL((cl_dconv_bwd_kernel<C, H>), dim3(grid), dim3(256), lds, st, k);
   else hipLaunchKernelGGL((cl_dconv_fwd_kernel<C, H>), dim3(grid), dim3(512), lds, st, k);
   RFX_CHECK_LAUNCH();
   return 0;

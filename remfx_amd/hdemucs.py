@@ -19,11 +19,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import clchain, lstm, nnops, ops, stft
+from . import clchain, cldconv, lstm, nnops, ops, stft
 
 # bf16 mode: the norm-free frequency layers run on the channels-last bf16 trunk (remfx_amd/clchain.py); RFX_CL_TRUNK=0 keeps the
 # channel-major kernels of rounds 1-4 for same-box A/B runs
 CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
+CL_DCONV = os.environ.get("RFX_CL_DCONV", "1") != "0"       # ... and their DConv branches on the fused channels-last kernels (cldconv.py)
 
 
 class _ScaledEmbedding(nn.Module):
@@ -113,6 +114,23 @@ class _DConv(nn.Module):
                 mods.insert(3, _BLSTM(hidden, layers=2, skip=True))
             self.layers.append(nn.Sequential(*mods))
             self.spec.append((dil, dil * (kernel_size // 2), lstm, attn))
+
+    def cl_ok(self):
+        """The fused channels-last kernels (csrc/cl_dconv.hip) take every depth-layer of this branch, forward and backward."""
+        for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
+            m = list(seq)
+            if lstm or attn or m[0].kernel_size[0] != 3 or dil not in (1, 2) or m[1].eps != m[4].eps or m[1].num_groups != 1:
+                return False
+            if not cldconv.supported(m[0].in_channels, m[0].out_channels, True):
+                return False
+        return True
+
+    def forward_cl(self, x):
+        """x: (B, Fr, T, C) channels-last bf16 samples."""
+        for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
+            m = list(seq)
+            x = cldconv.dconv_layer(x, m[0], m[1], m[3], m[4], m[6].scale, dil)
+        return x
 
     def forward(self, x):
         for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
@@ -210,9 +228,12 @@ class _HEncLayer(nn.Module):
         out = self._rest(y, inject)
         return (out, alias) if want_pair else out
 
-    def head(self, x):
-        """conv + GELU of a norm-free frequency layer as (B * Fr, C, T) samples, the DConv branch's input (channels-last trunk)."""
-        y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0), out_bf16=ENC_Z16)
+    def head(self, x, cl=False):
+        """conv + GELU of a norm-free frequency layer as (B * Fr, C, T) samples, the DConv branch's input (channels-last trunk);
+        cl: as (B, Fr, T, C) channels-last bf16 samples (the fused channels-last DConv kernels)."""
+        y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0), out_bf16=ENC_Z16 or cl)
+        if cl:
+            return clchain.head_gelu(y)
         y = ops.activation_to(y, "gelu", (0, 2, 1))
         B, C, Fr, T = y.shape
         return y.permute(0, 2, 1, 3).reshape(-1, C, T)
@@ -432,10 +453,14 @@ class HDemucs(nn.Module):
                     inject = xt
             if idx < Lc:
                 # channels-last trunk: the DConv branch on (B * Fr, C, T) samples, everything between two branches in one node
-                d = encode.dconv(encode.head(x) if idx == 0 else samp)
+                dcl = CL_DCONV and encode.dconv.cl_ok()      # this layer's DConv branch runs on channels-last samples
+                if idx == 0:
+                    samp = encode.head(x, cl=dcl)
+                d = encode.dconv.forward_cl(samp) if dcl else encode.dconv(samp)
                 if idx < Lc - 1:
                     emb_rows = self.freq_emb.table() * self.freq_emb_scale if (idx == 0 and self.freq_emb is not None) else None
-                    e, samp = clchain.enc_mid(d, encode.rewrite, self.freq_encoder[idx + 1].conv, emb_rows, B)
+                    nxt = CL_DCONV and self.freq_encoder[idx + 1].dconv.cl_ok()
+                    e, samp = clchain.enc_mid(d, encode.rewrite, self.freq_encoder[idx + 1].conv, emb_rows, B, y_cl=nxt)
                 else:
                     e, x = clchain.enc_tail(d, encode.rewrite, B)
                 saved.append(e)
