@@ -605,6 +605,7 @@ typedef struct rfx_cl_wgrad_desc {
   int32_t M, Cq, CW;             /* D rows (channels of P from p.c0); channels of Q (from q.c0); Q channels per D tile (% 16 == 0) */
   int32_t RW, WK;                /* 32-row tiles per D tile (2 | 3); K split inside a workgroup (1 | 2 | 4) */
   int32_t S, ahead, bias;        /* position splits (every split non-empty); prefetch distance in steps; 1 = also sum P over positions */
+  int32_t PW;                    /* positions per step: 64 | 128 (B % PW == 0) */
   float* ws;
 } rfx_cl_wgrad_desc;
 int64_t rfx_cl_wgrad_ws_floats(const rfx_cl_wgrad_desc* d);

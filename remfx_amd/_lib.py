@@ -117,7 +117,7 @@ class ClDconvDesc(C.Structure):
 class ClWgradDesc(C.Structure):
     _fields_ = [("p", ClTensor), ("q", ClTensor)] + \
                [(n, C.c_int32) for n in ("N", "OA", "IA", "B", "SA", "da0", "NTR", "NTC", "db0", "db_step", "M", "Cq", "CW", "RW", "WK",
-                                         "S", "ahead", "bias")] + \
+                                         "S", "ahead", "bias", "PW")] + \
                [("ws", C.c_void_p)]
 
 

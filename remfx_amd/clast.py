@@ -7,6 +7,7 @@ LDS by DMA.  This module holds the host side: the packing index of every layer f
 fragment cell), descriptors, and the autograd nodes of the encoder / decoder chains.
 """
 import ctypes as C
+import os as _os
 
 import numpy as np
 import torch
@@ -261,14 +262,21 @@ class WgradForm:
         self.MTn, self.CTn = -(-M // (32 * self.RW)), -(-Cq // self.CW)
         self.DT = self.MTn * self.CTn
         hb = max(abs(db0 + t * db_step) for t in range(NTC))
-        NP = 4 * self.RW
-        NQ = -(-((64 + 2 * hb) * self.CW * 2) // 1024)
-        PPW = -(-(NP + SA * NQ) // 8)
+        # 128 positions per step (twice the MFMA work per barrier and per scalar bookkeeping section) when two steps of prefetch
+        # still fit the LDS, else 64; the prefetch depth itself measured irrelevant beyond 1 (r05 ablations)
         self.ahead = None
-        for ahead in (6, 5, 4, 3, 2, 1):
-            R = -(-(NTR + ahead * SA) // SA) * SA
-            if (ahead + 1) * NP * 1024 + R * NQ * 1024 <= self.LDS_MAX and (ahead - 1) * PPW <= 24:
-                self.ahead = ahead
+        for PW, amin in (((128, 2), (64, 1)) if _os.environ.get("RFX_CLW_PW", "128") == "128" else ((64, 1),)):
+            NP = PW // 16 * self.RW
+            NQ = -(-((PW + 2 * hb) * self.CW * 2) // 1024)
+            PPW = -(-(NP + SA * NQ) // 8)
+            if PPW > 6 or (PW // 16) % self.WK:
+                continue
+            for ahead in (4, 3, 2, 1):
+                R = -(-(NTR + ahead * SA) // SA) * SA
+                if ahead >= amin and (ahead + 1) * NP * 1024 + R * NQ * 1024 <= self.LDS_MAX and (ahead - 1) * PPW <= 24:
+                    self.ahead, self.PW = ahead, PW
+                    break
+            if self.ahead is not None:
                 break
         if self.ahead is None:
             raise ValueError("channels-last weight gradient: tile does not fit LDS")
@@ -327,8 +335,10 @@ def wgrad(form, p, q, N, OA, IA, B, dw, db=None, accumulate=False, p_c0=0, q_c0=
     d.N, d.OA, d.IA, d.B = N, OA, IA, B
     d.SA, d.da0, d.NTR, d.NTC, d.db0, d.db_step = form.SA, form.da0, form.NTR, form.NTC, form.db0, form.db_step
     d.M, d.Cq, d.CW, d.RW, d.WK = form.M, form.Cq, form.CW, form.RW, form.WK
-    d.S = form.splits(N * (B // 64) * OA)
-    d.ahead, d.bias = form.ahead, int(form.bias)
+    PW = form.PW if B % form.PW == 0 else 64
+    d.PW = PW
+    d.S = form.splits(N * (B // PW) * OA)
+    d.ahead, d.bias = min(form.ahead, int(_os.environ.get("RFX_CLW_AHEAD", "99"))), int(form.bias)
     L = _lib.lib()
     nws = L.rfx_cl_wgrad_ws_floats(C.byref(d))
     if nws <= 0:

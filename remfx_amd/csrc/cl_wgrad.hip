@@ -21,6 +21,7 @@
 // Determinism: every workgroup dumps its accumulators into its own workspace slot; rfx_cl_wgrad_reduce sums the slots in a fixed
 // order and scatters through a host-built index map into the weight (and bias: a column tile fed with ones) gradient.  No atomics.
 #include "cl_common.h"
+#include <stdlib.h>
 
 struct ClWgK {
   rfx_cl_wgrad_desc d;
@@ -29,6 +30,7 @@ struct ClWgK {
   int32_t NP, NQ, TP, PPW;            // P pieces, Q pieces per row, pieces per step, pieces per wave and step
   int32_t PSLOT, QROWB, QROWP, R, PD, PRE, HB;
   int32_t HN, NCG, bias_tile;
+  int32_t dbg;                        // ablation switches (RFX_CLW_DBG, dev only): 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no barrier
   uint32_t p_bytes, q_bytes;
 };
 
@@ -57,12 +59,12 @@ __device__ __forceinline__ cl_bf16x8 clw_frag(const unsigned char* p, int step4)
 }
 
 struct ClwIt {                       // walks the steps of a range: PRE load-only steps in front of the range and of every column
-  int col, oa, pre;
+  int n, bq, oa, pre;                // column = (sample n, position block bq)
 };
 
-template <int RW, int WK>
+template <int RW, int WK, int PW>
 __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
-  constexpr int NT = 2, WC = 8 / WK, KSW = 4 / WK;
+  constexpr int NT = 2, WC = 8 / WK, KSW = (PW / 16) / WK;      // PW positions per step
   constexpr int PROWB = 64 * RW;                               // bytes of one position in the P image
   extern __shared__ __attribute__((aligned(16))) unsigned char clw_smem[];
   const rfx_cl_wgrad_desc& d = g.d;
@@ -70,8 +72,10 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int kq = wave / WC, cw = wave % WC;
   // the D tiles of one position split read the same P / Q bytes: they sit on ONE XCD (one L2), adjacent in dispatch order
+  // (fewer than 8 splits: plain order, the D tiles of a split spread over the XCDs -- grouping them would leave XCDs idle)
   const int bid = blockIdx.x, xcd = bid & 7, qx = bid >> 3;
-  const int dt = qx % g.DT, split = xcd * g.spx + qx / g.DT;
+  const bool grouped = d.S >= 8;
+  const int dt = grouped ? qx % g.DT : bid % g.DT, split = grouped ? xcd * g.spx + qx / g.DT : bid / g.DT;
   if (split >= d.S) return;
   const int mt = dt / g.CTn, ct = dt - mt * g.CTn;
   const int tau0 = split * g.sps;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
       lds_off[i] = e * 1024;
       const int o = e * 1024 + lane * 16;
       const int pos = o / PROWB, cb = o - pos * PROWB;
-      const bool ok = pos < 64 && (mt * 32 * RW + (cb >> 1)) < d.M;
+      const bool ok = pos < PW && (mt * 32 * RW + (cb >> 1)) < d.M;
       rel[i] = ok ? (int32_t)((pos * d.p.bs + d.p.c0 + mt * 32 * RW) * 2 + cb) : (int32_t)CL_OOB;
       bpos[i] = 0;
     } else {
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
       lds_off[i] = rr * g.QROWB + qi * 1024;
       const int o = qi * 1024 + lane * 16;
       const int pos = o / g.QROWP, cb = o - pos * g.QROWP;
-      const bool ok = pos < 64 + 2 * g.HB && (ct * d.CW + (cb >> 1)) < d.Cq;
+      const bool ok = pos < PW + 2 * g.HB && (ct * d.CW + (cb >> 1)) < d.Cq;
       rel[i] = ok ? (int32_t)(((pos - g.HB) * d.q.bs + d.q.c0 + ct * d.CW) * 2 + cb) : (int32_t)CL_OOB;
       bpos[i] = ok ? pos - g.HB : 0x40000000;
     }
@@ -139,18 +143,29 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
   const int col0 = tau0 / OA;
   const int ncols = (tau1 - 1) / OA - col0 + 1;
   const int L = (tau1 - tau0) + g.PRE * ncols;
-  ClwIt it_i = {col0, tau0 - col0 * OA - g.PRE, g.PRE}, it_c = it_i;
+  ClwIt it_i = {col0 / g.nbq, col0 % g.nbq, tau0 - col0 * OA - g.PRE, g.PRE}, it_c = it_i;
   auto advance = [&](ClwIt& it) {
     ++it.oa;
     if (it.pre > 0) --it.pre;
-    if (it.oa == OA) { ++it.col; it.oa = -g.PRE; it.pre = g.PRE; }
+    if (it.oa == OA) {
+      it.oa = -g.PRE; it.pre = g.PRE;
+      if (++it.bq == g.nbq) { it.bq = 0; ++it.n; }
+    }
   };
+  // sample descriptors: rebuilt only when the issue side moves to another sample
+  int rs_n = it_i.n;
+  __amdgpu_buffer_rsrc_t rs_p = cl_rsrc(reinterpret_cast<const uint16_t*>(d.p.p) + (int64_t)rs_n * d.p.ns, g.p_bytes);
+  __amdgpu_buffer_rsrc_t rs_q = cl_rsrc(reinterpret_cast<const uint16_t*>(d.q.p) + (int64_t)rs_n * d.q.ns, g.q_bytes);
   int iu = 0, wp = 0, ps_i = 0;                                 // issue side: next step, ring write row, P slot
   auto issue_next = [&]() {
-    const int n = it_i.col / g.nbq, b0 = (it_i.col - n * g.nbq) * 64;
+    if (g.dbg & 1) { advance(it_i); ++iu; return; }
+    const int b0 = it_i.bq * PW;
     const bool real = it_i.pre == 0;
-    const __amdgpu_buffer_rsrc_t rs_p = cl_rsrc(reinterpret_cast<const uint16_t*>(d.p.p) + (int64_t)n * d.p.ns, g.p_bytes);
-    const __amdgpu_buffer_rsrc_t rs_q = cl_rsrc(reinterpret_cast<const uint16_t*>(d.q.p) + (int64_t)n * d.q.ns, g.q_bytes);
+    if (it_i.n != rs_n) {
+      rs_n = it_i.n;
+      rs_p = cl_rsrc(reinterpret_cast<const uint16_t*>(d.p.p) + (int64_t)rs_n * d.p.ns, g.p_bytes);
+      rs_q = cl_rsrc(reinterpret_cast<const uint16_t*>(d.q.p) + (int64_t)rs_n * d.q.ns, g.q_bytes);
+    }
     const int32_t pb = (int32_t)(((int64_t)it_i.oa * d.p.as + (int64_t)b0 * d.p.bs) * 2);
     const int ia0 = it_i.oa * d.SA + d.da0 + d.NTR - d.SA;
 #pragma unroll
@@ -180,14 +195,34 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
   const int ahead = g.PD - 1;
   for (int i = 0; i < ahead; ++i)
     if (iu < L) issue_next();
+  // Waves w and w + 4 share a SIMD.  After the barrier waves 0..3 issue their DMA pieces FIRST and then compute, waves 4..7 compute
+  // first and issue at the END of the step: one wave of a SIMD feeds the matrix pipe while the other is busy issuing loads.  (With
+  // all eight waves in the same phase nothing overlapped -- ablation builds, r05: 1.29 ms = skeleton 0.18 + DMA issue 0.29 + fragment
+  // reads 0.25 + MFMA 0.58 for the 48 -> 96 3x3 layer, exactly additive.)  Both orders have issued groups 0 .. i + ahead - 1 when
+  // they wait in step i, so the counted wait is the same.
+  const bool late = wave >= 4 && !(g.dbg & 16);
+  auto frags = [&](int ks, const unsigned char* pb, const unsigned char* const (&qb)[NT], cl_bf16x8 (&af)[RW], cl_bf16x8 (&bf)[NT], int i) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+      af[r] = (g.dbg & 2) ? __builtin_bit_cast(cl_bf16x8, make_uint4(lane, r, ks, i)) : clw_frag(pb + ks * 16 * PROWB + r * 64, 4 * PROWB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (ones_wave && t == ones_t) {
+        const clw_s16x8 one = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+        bf[t] = __builtin_bit_cast(cl_bf16x8, one);
+      } else {
+        bf[t] = (g.dbg & 2) ? __builtin_bit_cast(cl_bf16x8, make_uint4(lane, t, ks, i)) : clw_frag(qb[t] + ks * 16 * g.QROWP, 4 * g.QROWP);
+      }
+    }
+  };
   for (int i = 0; i < L; ++i) {
     const int left = L - 1 - i;
     clw_wait_vm((left < ahead - 1 ? left : ahead - 1) * g.PPW);
-    __builtin_amdgcn_s_barrier();
+    if (!(g.dbg & 8)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (iu < L) issue_next();
+    if (!late && iu < L) issue_next();
     __builtin_amdgcn_sched_barrier(0);
-    if (it_c.pre == 0) {
+    if (it_c.pre == 0 && !(g.dbg & 4)) {
       const unsigned char* pb = pbase_lds + ps_c * g.PSLOT + a0;
       const unsigned char* qb[NT];
 #pragma unroll
@@ -196,27 +231,20 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
         sl = sl >= g.R ? sl - g.R : sl;
         qb[t] = qbase_lds + sl * g.QROWB + bconst[t];
       }
+      // fragments of K step k + 1 are read while the MFMAs of step k run
+      cl_bf16x8 af[2][RW], bf[2][NT];
+      frags(kq, pb, qb, af[0], bf[0], i);
 #pragma unroll
       for (int ksi = 0; ksi < KSW; ++ksi) {
-        const int ks = kq + ksi * WK;
-        cl_bf16x8 af[RW], bf[NT];
-#pragma unroll
-        for (int r = 0; r < RW; ++r) af[r] = clw_frag(pb + ks * 16 * PROWB + r * 64, 4 * PROWB);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (ones_wave && t == ones_t) {
-            const clw_s16x8 one = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-            bf[t] = __builtin_bit_cast(cl_bf16x8, one);
-          } else {
-            bf[t] = clw_frag(qb[t] + ks * 16 * g.QROWP, 4 * g.QROWP);
-          }
-        }
+        if (ksi + 1 < KSW) frags(kq + (ksi + 1) * WK, pb, qb, af[(ksi + 1) & 1], bf[(ksi + 1) & 1], i);
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r], bf[t], acc[r][t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ksi & 1][r], bf[ksi & 1][t], acc[r][t], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (late && iu < L) issue_next();
     cpm += d.SA;
     cpm = cpm >= g.R ? cpm - g.R : cpm;
     ps_c = ps_c + 1 == g.PD ? 0 : ps_c + 1;
@@ -234,10 +262,11 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
 }
 
 static int clw_geometry(const rfx_cl_wgrad_desc& d, ClWgK& k) {
-  if (d.N <= 0 || d.OA <= 0 || d.IA <= 0 || d.B <= 0 || d.B % 64) return -1;
+  if (d.N <= 0 || d.OA <= 0 || d.IA <= 0 || d.B <= 0 || (d.PW != 64 && d.PW != 128) || d.B % d.PW) return -1;
   if (d.NTR < 1 || d.NTR > 16 || d.NTC < 1 || d.NTC > 9 || d.SA < 1 || d.SA > d.NTR) return -1;
   if (d.M <= 0 || d.Cq <= 0 || d.CW < 16 || d.CW % 16 || d.CW > 128) return -1;
   if ((d.RW != 2 && d.RW != 3) || (d.WK != 1 && d.WK != 2 && d.WK != 4)) return -1;
+  if (d.PW == 64 && d.WK == 4 && false) return -1;
   if (d.p.bs % 8 || d.p.c0 % 8 || d.q.bs % 8 || d.q.c0 % 8 || d.S < 1 || d.ahead < 1) return -1;
   int hb = 0;
   for (int t = 0; t < d.NTC; ++t) {
@@ -246,8 +275,11 @@ static int clw_geometry(const rfx_cl_wgrad_desc& d, ClWgK& k) {
   }
   if (hb > 8) return -1;
   k.d = d;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("RFX_CLW_DBG"); dbg = e ? atoi(e) : 0; }
+  k.dbg = dbg;
   k.HB = hb;
-  k.nbq = d.B / 64;
+  k.nbq = d.B / d.PW;
   k.MTn = (d.M + 32 * d.RW - 1) / (32 * d.RW);
   k.CTn = (d.Cq + d.CW - 1) / d.CW;
   k.DT = k.MTn * k.CTn;
@@ -263,9 +295,9 @@ static int clw_geometry(const rfx_cl_wgrad_desc& d, ClWgK& k) {
   if (tiles > WC * 2) return -1;
   k.bias_tile = d.bias ? tiles : -1;
   if (d.bias && tiles + 1 > WC * 2) return -1;
-  k.NP = (64 * 64 * d.RW + 1023) / 1024;
+  k.NP = (d.PW * 64 * d.RW + 1023) / 1024;
   k.QROWP = d.CW * 2;
-  k.NQ = ((64 + 2 * hb) * k.QROWP + 1023) / 1024;
+  k.NQ = ((d.PW + 2 * hb) * k.QROWP + 1023) / 1024;
   k.TP = k.NP + d.SA * k.NQ;
   k.PPW = (k.TP + 7) / 8;
   if (k.PPW > CL_WG_MAXP) return -1;
@@ -284,18 +316,22 @@ static int clw_geometry(const rfx_cl_wgrad_desc& d, ClWgK& k) {
   return 0;
 }
 
-template <int RW, int WK>
-static int clw_launch(const ClWgK& k, int lds, hipStream_t s) {
+template <int RW, int WK, int PW>
+static int clw_launch1(const ClWgK& k, int lds, hipStream_t s) {
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_wgrad_kernel<RW, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_wgrad_kernel<RW, WK, PW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
         hipSuccess)
       return -3;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((cl_wgrad_kernel<RW, WK>), dim3((unsigned)(8 * k.spx * k.DT)), dim3(512), lds, s, k);
+  hipLaunchKernelGGL((cl_wgrad_kernel<RW, WK, PW>), dim3((unsigned)(k.d.S >= 8 ? 8 * k.spx * k.DT : k.d.S * k.DT)), dim3(512), lds, s, k);
   RFX_CHECK_LAUNCH();
   return 0;
+}
+template <int RW, int WK>
+static int clw_launch(const ClWgK& k, int lds, hipStream_t s) {
+  return k.d.PW == 128 ? clw_launch1<RW, WK, 128>(k, lds, s) : clw_launch1<RW, WK, 64>(k, lds, s);
 }
 
 extern "C" int64_t rfx_cl_wgrad_ws_floats(const rfx_cl_wgrad_desc* dp) {
