@@ -13,7 +13,8 @@ PEAK_HBM = 8.0e12
 FAMILIES = [
     ("channels-last conv (fwd + dgrad)", ("cl_conv",)),
     ("channels-last weight gradient", ("cl_wgrad",)),
-    ("channels-last layout / sums / pack", ("cl_from_cm", "cl_to_cm", "cl_rowsum", "cl_pack")),
+    ("channels-last fused DConv", ("cl_dconv",)),
+    ("channels-last layout / sums / pack", ("cl_from_cm", "cl_to_cm", "cl_rowsum", "cl_pack", "cl_dgelu")),
     ("gemm forward family", ("gemm_fwd", "gemm_tap", "gemm_thin_fwd", "gemm_halo")),
     ("gemm weight gradient", ("gemm_wgrad", "gemm_thin_wgrad")),
     ("GroupNorm / BatchNorm", ("gn_", "bn_")),
