@@ -571,7 +571,7 @@ typedef struct rfx_cl_conv_desc {
   int32_t M, BM;          /* GEMM rows; rows per workgroup: 32, 64, 96 or 192 */
   int32_t mode;           /* enum rfx_cl_epi */
   int32_t G, g_off, OAo, Co;
-  const float* bias;      /* the layer's bias in ITS channel order (GLU: [a | b]; merged: [Co]), or NULL */
+  const float* bias;      /* the layer's bias in ITS channel order (GLU: [a | b]; merged / folded rows (Co < M): bias[m % Co]), or NULL */
   const float* rowadd;    /* RFX_CL_GLU only: fp32 [OA][M / 2] added to out1 (a per-row vector: the frequency embedding), or NULL */
   rfx_cl_tensor out0, out1, aux0, res;
 } rfx_cl_conv_desc;
@@ -588,6 +588,8 @@ int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int32_t A, int3
                  int64_t d_cs, int64_t d_as, const void* aux16, void* stream);
 /* out = g * gelu'(z) over n bf16 values of dense channels-last tensors (n % 8 == 0) */
 int rfx_cl_dgelu(const void* g, const void* z, void* out, int64_t n, void* stream);
+/* GLU backward on dense channels-last tensors: g [npos][C], zab [npos][2C] = stored [a | b] -> out [npos][2C] */
+int rfx_cl_dglu(const void* g, const void* zab, void* out, int64_t npos, int32_t C, void* stream);
 
 /* Weight gradients on channels-last operands, deterministic (no atomics):
  *   D[m][(r, t, c)] = sum over (n, oa, b) of P[n][oa][b][m] * Q[n][oa*SA + da0 + r][b + db0 + t*db_step][c]     (Q = 0 outside)

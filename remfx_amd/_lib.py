@@ -218,6 +218,7 @@ SIGNATURES = {
     "rfx_cl_rowsum": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _I32, C.c_float, _P, _P, _I32, _P],
     "rfx_cl_to_cm": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _P, _I32, _I64, _I64, _I64, _P, _P],
     "rfx_cl_dgelu": [_P, _P, _P, _I64, _P],
+    "rfx_cl_dglu": [_P, _P, _P, _I64, _I32, _P],
     "rfx_cl_dconv_ok": [_I32, _I32, _I32, _I32],
     "rfx_cl_dconv_fwd": [_P, _P],
     "rfx_cl_dconv_bwd": [_P, _P, _P],

@@ -79,6 +79,17 @@ def dgelu(g, z):
     return out
 
 
+def dglu(g, zab):
+    """GLU backward: g (..., C) against the stored zab (..., 2C) = [a | b], dense channels-last tensors -> (..., 2C)."""
+    Cc = g.shape[-1]
+    if zab.shape[-1] != 2 * Cc or g.numel() * 2 != zab.numel() or not g.is_contiguous() or not zab.is_contiguous():
+        raise ValueError("dglu: dense tensors (..., C) and (..., 2C)")
+    out = torch.empty_like(zab)
+    check(_lib.lib().rfx_cl_dglu(C.c_void_p(g.data_ptr()), C.c_void_p(zab.data_ptr()), C.c_void_p(out.data_ptr()), g.numel() // Cc, Cc,
+                                 _stream()), "rfx_cl_dglu")
+    return out
+
+
 # ---- tile choice ----------------------------------------------------------------------------------------------------------------
 def pick_bm(M):
     """Rows per workgroup: 192 (two wave rows of 96) for the wide layers, else the smallest of 32 / 64 / 96 that holds M in
@@ -228,6 +239,57 @@ def form_conv_s4_dgrad(Cout, Cin):
     return ConvForm(4 * Cin, Cout, 2, 1, -1, 1, 0, 0, 1, widx, G=4, g_off=-2, Co=Cin)
 
 
+# ---- stride-4 convolutions ALONG the position axis (the time branch: A = 1): the operand is read / written through its folded view
+# [L / 4][4 C] -- four consecutive positions are 4 C consecutive channels of one folded position -- which turns the (8, stride 4)
+# kernel into a 3-tap stride-1 convolution over folded positions whose weight image has structural zeros (8 of the 12 (tap,
+# sub-position) slots are taps of the kernel); the index functions return -1 there.
+def _k_down(t, j):
+    """kernel tap read by folded tap t (offset t - 1), sub-position j of the FINE operand, for a coarse position: 4 (t - 1) + j + 2"""
+    return 4 * (t - 1) + j + 2
+
+
+def _k_up(t, j):
+    """kernel tap that sends coarse position q' + t - 1 to fine position 4 q' + j: j + 6 - 4 t"""
+    return j + 6 - 4 * t
+
+
+def form_conv_s4_fold(Cout, Cin):
+    """Conv1d(Cin -> Cout, 8, stride 4, padding 2) over folded input (.., L / 4, 4 Cin); weight (Cout, Cin, 8)."""
+    def widx(m, r, t, ch):
+        j, ci = ch // Cin, ch % Cin
+        k = _k_down(t, j)
+        return np.where((k >= 0) & (k < 8), (m * Cin + ci) * 8 + np.clip(k, 0, 7), -1)
+    return ConvForm(Cout, 4 * Cin, 1, 3, 0, 0, -1, 1, 1, widx)
+
+
+def form_convtr_fold(Cin, Cout):
+    """ConvTranspose1d(Cin -> Cout, 8, stride 4) cropped by 2 either side, output through its folded view (.., L, 4 Cout): rows
+    m = j * Cout + co; weight (Cin, Cout, 8); bias index m % Cout."""
+    def widx(m, r, t, ch):
+        j, co = m // Cout, m % Cout
+        k = _k_up(t, j)
+        return np.where((k >= 0) & (k < 8), (ch * Cout + co) * 8 + np.clip(k, 0, 7), -1)
+    return ConvForm(4 * Cout, Cin, 1, 3, 0, 0, -1, 1, 1, widx, Co=Cout)
+
+
+def form_conv_s4_fold_dgrad(Cout, Cin):
+    """Input gradient of form_conv_s4_fold's layer, written through the folded view (.., L / 4, 4 Cin): rows m = j * Cin + ci."""
+    def widx(m, r, t, ch):
+        j, ci = m // Cin, m % Cin
+        k = _k_up(t, j)
+        return np.where((k >= 0) & (k < 8), (ch * Cin + ci) * 8 + np.clip(k, 0, 7), -1)
+    return ConvForm(4 * Cin, Cout, 1, 3, 0, 0, -1, 1, 1, widx, Co=Cin)
+
+
+def form_convtr_fold_dgrad(Cin, Cout):
+    """Input gradient of form_convtr_fold's layer: rows = Cin, reads the output gradient through its folded view (.., L, 4 Cout)."""
+    def widx(m, r, t, ch):
+        j, co = ch // Cout, ch % Cout
+        k = _k_down(t, j)
+        return np.where((k >= 0) & (k < 8), (m * Cout + co) * 8 + np.clip(k, 0, 7), -1)
+    return ConvForm(Cin, 4 * Cout, 1, 3, 0, 0, -1, 1, 1, widx)
+
+
 # ---- weight gradients -------------------------------------------------------------------------------------------------------------
 class WgradForm:
     """One weight-gradient GEMM (csrc/cl_wgrad.hip): D[m][(r, t, c)] = sum_pos P[pos][m] * Q[pos shifted by tap (r, t)][c].
@@ -372,3 +434,21 @@ def wform_convtr_s4(Cin, Cout):
     def widx(m, r, t, c):
         return (m * Cout + c) * 8 + r
     return WgradForm(Cin, Cout, 8, 1, 4, -2, 0, 0, widx, Cin * Cout * 8, bias=False)
+
+
+def wform_conv_s4_fold(Cout, Cin):
+    """dW of Conv1d(Cin -> Cout, 8, stride 4, padding 2): P = output gradient (.., L / 4, Cout), Q = input, folded (.., L / 4, 4 Cin)."""
+    def widx(m, r, t, c):
+        j, ci = c // Cin, c % Cin
+        k = _k_down(t, j)
+        return np.where((k >= 0) & (k < 8), (m * Cin + ci) * 8 + np.clip(k, 0, 7), -1)
+    return WgradForm(Cout, 4 * Cin, 1, 3, 1, 0, -1, 1, widx, Cout * Cin * 8)
+
+
+def wform_convtr_fold(Cin, Cout):
+    """dW of the cropped ConvTranspose1d(Cin -> Cout, 8, stride 4): P = its input (.., L, Cin), Q = output gradient, folded (.., L, 4 Cout)."""
+    def widx(m, r, t, c):
+        j, co = c // Cout, c % Cout
+        k = _k_down(t, j)
+        return np.where((k >= 0) & (k < 8), (m * Cout + co) * 8 + np.clip(k, 0, 7), -1)
+    return WgradForm(Cin, 4 * Cout, 1, 3, 1, 0, -1, 1, widx, Cin * Cout * 8, bias=False)

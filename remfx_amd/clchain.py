@@ -26,7 +26,16 @@ _BUILD = {
     "glu": clast.form_conv_glu, "dgrad": clast.form_conv_dgrad, "s4": clast.form_conv_s4, "s4d": clast.form_conv_s4_dgrad,
     "tr": clast.form_convtr_s4, "trd": clast.form_convtr_s4_dgrad, "w": clast.wform_conv, "ws4": clast.wform_conv_s4,
     "wtr": clast.wform_convtr_s4,
+    # the time branch: stride 4 along the position axis through folded views
+    "s4f": clast.form_conv_s4_fold, "s4fd": clast.form_conv_s4_fold_dgrad, "trf": clast.form_convtr_fold,
+    "trfd": clast.form_convtr_fold_dgrad, "ws4f": clast.wform_conv_s4_fold, "wtrf": clast.wform_convtr_fold,
 }
+
+
+def _fold(t, k=4):
+    """(N, 1, L, C) -> its folded view (N, 1, L / k, k C): k consecutive positions as channels."""
+    N, A, L, Cc = t.shape
+    return t.view(N, A, L // k, k * Cc)
 
 
 def form(kind, *a):
@@ -118,7 +127,8 @@ class EncMidFn(torch.autograd.Function):
     """d_i (Bn * A_i, C_i, T) fp32 -> e_i channels-last (Bn, A_i, T, C_i), y_{i+1} (Bn * A_i / 4, 2 C_i, T) fp32."""
 
     @staticmethod
-    def forward(ctx, d, rw_w, rw_b, cv_w, cv_b, emb_rows, Bn, y_cl):
+    def forward(ctx, d, rw_w, rw_b, cv_w, cv_b, emb_rows, Bn, y_cl, fold):
+        """fold: the time branch -- A = 1, the stride-4 convolution runs along the position axis (folded views)."""
         d_is_cl = d.dim() == 4                      # the DConv branch in front ran on channels-last samples (cldconv)
         if d_is_cl:
             _, A, T, Cc = d.shape
@@ -127,7 +137,8 @@ class EncMidFn(torch.autograd.Function):
             NA, Cc, T = d.shape
             A = NA // Bn
             d_cl = clast.from_cm(_as_ncab(d if d.is_contiguous() else d.contiguous(), Bn, A))
-        C1, A1 = cv_w.shape[0], A // 4
+        C1 = cv_w.shape[0]
+        A1, T1 = (A, T // 4) if fold else (A // 4, T)
         dev = d.device
         train = any(ctx.needs_input_grad)
         zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
@@ -135,40 +146,53 @@ class EncMidFn(torch.autograd.Function):
         fg = form("glu", 2 * Cc, Cc, 1, 1)
         clast.conv(fg, packed(fg, rw_w), d_cl, Bn, A, T, A, "glu", bias=rw_b, out0=zab, out1=e,
                    rowadd=emb_rows.contiguous() if emb_rows is not None else None)
-        fs = form("s4", C1, Cc)
-        z1 = clast.empty(Bn, A1, T, C1, dev) if train else None
-        y1 = clast.empty(Bn, A1, T, C1, dev)
-        clast.conv(fs, packed(fs, cv_w), e, Bn, A, T, A1, "gelu", bias=cv_b, out0=z1, out1=y1)
+        z1 = clast.empty(Bn, A1, T1, C1, dev) if train else None
+        y1 = clast.empty(Bn, A1, T1, C1, dev)
+        if fold:
+            fs = form("s4f", C1, Cc)
+            clast.conv(fs, packed(fs, cv_w), _fold(e), Bn, 1, T1, 1, "gelu", bias=cv_b, out0=z1, out1=y1)
+        else:
+            fs = form("s4", C1, Cc)
+            clast.conv(fs, packed(fs, cv_w), e, Bn, A, T, A1, "gelu", bias=cv_b, out0=z1, out1=y1)
         if y_cl:                                    # the next DConv branch takes channels-last samples
             y_out = y1
         else:
-            y_out = torch.empty((Bn * A1, C1, T), device=dev, dtype=torch.float32)
+            y_out = torch.empty((Bn * A1, C1, T1), device=dev, dtype=torch.float32)
             clast.to_cm(y1, out=_as_ncab(y_out, Bn, A1))
         if train:
             ctx.save_for_backward(d_cl, zab, e, z1, rw_w, cv_w)
             ctx.refs = (rw_b, cv_b)
-            ctx.geom = (Bn, A, T, Cc, C1, A1, emb_rows is not None, d_is_cl, y_cl)
+            ctx.geom = (Bn, A, T, Cc, C1, A1, T1, emb_rows is not None, d_is_cl, y_cl, fold)
         return e, y_out
 
     @staticmethod
     def backward(ctx, g_e, g_y):
         d_cl, zab, e, z1, rw_w, cv_w = ctx.saved_tensors
         rw_b, cv_b = ctx.refs
-        Bn, A, T, Cc, C1, A1, has_emb, d_is_cl, y_cl = ctx.geom
+        Bn, A, T, Cc, C1, A1, T1, has_emb, d_is_cl, y_cl, fold = ctx.geom
         dev = d_cl.device
         # gradient of the next DConv's input (-> channels-last) times gelu'(z1)
         if y_cl:
             dz1 = clast.dgelu(g_y if g_y.is_contiguous() else g_y.contiguous(), z1)
         else:
-            dz1 = clast.empty(Bn, A1, T, C1, dev)
+            dz1 = clast.empty(Bn, A1, T1, C1, dev)
             clast.from_cm(_as_ncab(g_y if g_y.is_contiguous() else g_y.contiguous(), Bn, A1), out=dz1, aux=z1, mode="dgelu")
-        dcw, dcb = _wgrad(form("ws4", C1, Cc), dz1, e, Bn, A1, A, T, cv_w, cv_b)
-        # conv input gradient + skip gradient, GLU backward against the stored [a | b]
-        fd = form("s4d", C1, Cc)
-        dzab = clast.empty(Bn, A, T, 2 * Cc, dev)
-        v = clast.empty(Bn, A, T, Cc, dev) if has_emb else None
-        clast.conv(fd, packed(fd, cv_w), dz1, Bn, A1, T, A1 + 1, "dglu", out0=dzab, out1=v, aux0=zab,
-                   res=(g_e if g_e.is_contiguous() else g_e.contiguous()) if g_e is not None else None, OAo=A)
+        g_e = (g_e if g_e.is_contiguous() else g_e.contiguous()) if g_e is not None else None
+        if fold:
+            dcw, dcb = _wgrad(form("ws4f", C1, Cc), dz1, _fold(e), Bn, 1, 1, T1, cv_w, cv_b)
+            # conv input gradient (written through the folded view) + skip gradient; the GLU backward is a pass of its own here:
+            # folded rows are (sub-position, channel), the stored [a | b] pairs are not where the fused store looks for them
+            fd = form("s4fd", C1, Cc)
+            v = clast.empty(Bn, A, T, Cc, dev)
+            clast.conv(fd, packed(fd, cv_w), dz1, Bn, 1, T1, 1, "store", out0=_fold(v), res=_fold(g_e) if g_e is not None else None)
+            dzab = clast.dglu(v, zab)
+        else:
+            dcw, dcb = _wgrad(form("ws4", C1, Cc), dz1, e, Bn, A1, A, T, cv_w, cv_b)
+            # conv input gradient + skip gradient, GLU backward against the stored [a | b]
+            fd = form("s4d", C1, Cc)
+            dzab = clast.empty(Bn, A, T, 2 * Cc, dev)
+            v = clast.empty(Bn, A, T, Cc, dev) if has_emb else None
+            clast.conv(fd, packed(fd, cv_w), dz1, Bn, A1, T, A1 + 1, "dglu", out0=dzab, out1=v, aux0=zab, res=g_e, OAo=A)
         demb = None
         if has_emb:
             demb = torch.empty((A, Cc), device=dev, dtype=torch.float32)
@@ -182,7 +206,7 @@ class EncMidFn(torch.autograd.Function):
         else:
             dd = torch.empty((Bn * A, Cc, T), device=dev, dtype=torch.float32)
             clast.to_cm(dd_cl, out=_as_ncab(dd, Bn, A))
-        return dd, drw, drb, dcw, dcb, demb, None, None
+        return dd, drw, drb, dcw, dcb, demb, None, None, None
 
 
 class EncTailFn(torch.autograd.Function):
@@ -240,10 +264,12 @@ class FreqDecoderFn(torch.autograd.Function):
     (rewrite w, b, conv_tr w, b) and the last layer's rewrite (w, b).  Returns y_0 = GLU(rewrite_0(.)) as (Bn, C_0, A_0, T) fp32."""
 
     @staticmethod
-    def forward(ctx, x, nsk, *rest):
+    def forward(ctx, x, nsk, fold, *rest):
+        """fold: the time branch (A = 1, 1 x 3 rewrites, the transposed convolutions through folded views)."""
         skips, params = rest[:nsk], rest[nsk:]
         J = nsk - 1
         Bn, CJ, AJ, T = x.shape
+        KA = 1 if fold else 3
         dev = x.device
         train = any(ctx.needs_input_grad)
         if x.stride(3) != 1:
@@ -254,10 +280,19 @@ class FreqDecoderFn(torch.autograd.Function):
         for k in range(J):                                      # layer j = J - k
             rw_w, rw_b, ct_w, ct_b = params[4 * k:4 * k + 4]
             Cn = ct_w.shape[1]
-            fg = form("glu", 2 * Cc, Cc, 3, 3)
+            fg = form("glu", 2 * Cc, Cc, KA, 3)
             zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
             y = clast.empty(Bn, A, T, Cc, dev)
             clast.conv(fg, packed(fg, rw_w), xin, Bn, A, T, A, "glu", bias=rw_b, out0=zab, out1=y)
+            if fold:
+                ft = form("trf", Cc, Cn)
+                zt = clast.empty(Bn, 1, 4 * T, Cn, dev) if train else None
+                nxt = clast.empty(Bn, 1, 4 * T, Cn, dev)
+                clast.conv(ft, packed(ft, ct_w), y, Bn, 1, T, 1, "gelu", bias=ct_b, out0=_fold(zt) if train else None, out1=_fold(nxt),
+                           aux0=_fold(skips[k + 1]))
+                saved += [xin, zab, y, zt]
+                xin, T, Cc = nxt, 4 * T, Cn
+                continue
             ft = form("tr", Cc, Cn)
             zt = clast.empty(Bn, 4 * A, T, Cn, dev) if train else None
             nxt = clast.empty(Bn, 4 * A, T, Cn, dev)
@@ -265,7 +300,7 @@ class FreqDecoderFn(torch.autograd.Function):
             saved += [xin, zab, y, zt]
             xin, A, Cc = nxt, 4 * A, Cn
         rw_w, rw_b = params[4 * J:4 * J + 2]
-        fg = form("glu", 2 * Cc, Cc, 3, 3)
+        fg = form("glu", 2 * Cc, Cc, KA, 3)
         zab = clast.empty(Bn, A, T, 2 * Cc, dev) if train else None
         y0 = clast.empty(Bn, A, T, Cc, dev)
         clast.conv(fg, packed(fg, rw_w), xin, Bn, A, T, A, "glu", bias=rw_b, out0=zab, out1=y0)
@@ -274,12 +309,13 @@ class FreqDecoderFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(*saved, *[p for p in params])
             ctx.nsaved = len(saved)
-            ctx.geom = (Bn, AJ, CJ, T, J)
+            ctx.geom = (Bn, AJ, CJ, x.shape[3], J, fold)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        Bn, AJ, CJ, T, J = ctx.geom
+        Bn, AJ, CJ, TJ, J, fold = ctx.geom
+        KA = 1 if fold else 3
         saved, params = ctx.saved_tensors[:ctx.nsaved], ctx.saved_tensors[ctx.nsaved:]
         dev = g.device
         if g.stride(3) != 1:
@@ -287,14 +323,14 @@ class FreqDecoderFn(torch.autograd.Function):
         grads_p = [None] * len(params)
         grads_sk = [None] * (J + 1)
         # layer 0: GLU backward fused with the layout conversion of the incoming gradient
-        A, Cc = AJ * 4 ** J, CJ // 2 ** J
+        A, T, Cc = (AJ, TJ * 4 ** J, CJ // 2 ** J) if fold else (AJ * 4 ** J, TJ, CJ // 2 ** J)
         xin, zab = saved[4 * J], saved[4 * J + 1]
         dzab = clast.empty(Bn, A, T, 2 * Cc, dev)
         clast.from_cm(g, out=dzab, aux=zab, mode="dglu")
         for k in range(J, -1, -1):                              # rewrite of layer j = J - k, walking up from layer 0 (k = J)
             rw_w, rw_b = params[4 * k], params[4 * k + 1]
-            grads_p[4 * k], grads_p[4 * k + 1] = _wgrad(form("w", 2 * Cc, Cc, 3, 3), dzab, xin, Bn, A, A, T, rw_w, rw_b)
-            fd = form("dgrad", 2 * Cc, Cc, 3, 3)
+            grads_p[4 * k], grads_p[4 * k + 1] = _wgrad(form("w", 2 * Cc, Cc, KA, 3), dzab, xin, Bn, A, A, T, rw_w, rw_b)
+            fd = form("dgrad", 2 * Cc, Cc, KA, 3)
             gx = clast.empty(Bn, A, T, Cc, dev)
             if k == 0:
                 clast.conv(fd, packed(fd, rw_w), dzab, Bn, A, T, A, "store", out0=gx)
@@ -306,6 +342,15 @@ class FreqDecoderFn(torch.autograd.Function):
             clast.conv(fd, packed(fd, rw_w), dzab, Bn, A, T, A, "dgelu", out0=gx, out1=dzt, aux0=zt_u)
             grads_sk[k] = gx
             ct_w, ct_b = params[4 * (k - 1) + 2], params[4 * (k - 1) + 3]
+            if fold:
+                Cu, Tu = 2 * Cc, T // 4
+                grads_p[4 * (k - 1) + 2], grads_p[4 * (k - 1) + 3] = _wgrad(form("wtrf", Cu, Cc), y_u, _fold(dzt), Bn, 1, 1, Tu, ct_w, ct_b,
+                                                                            bias_src=dzt.view(Bn * 64, 1, T // 64, Cc))
+                ftd = form("trfd", Cu, Cc)
+                dzab = clast.empty(Bn, 1, Tu, 2 * Cu, dev)
+                clast.conv(ftd, packed(ftd, ct_w), _fold(dzt), Bn, 1, Tu, 1, "dglu", out0=dzab, aux0=zab_u)
+                xin, T, Cc = xin_u, Tu, Cu
+                continue
             Cu, Au = 2 * Cc, A // 4
             grads_p[4 * (k - 1) + 2], grads_p[4 * (k - 1) + 3] = _wgrad(form("wtr", Cu, Cc), y_u, dzt, Bn, Au, A, T, ct_w, ct_b, bias_src=dzt)
             ftd = form("trd", Cu, Cc)
@@ -313,7 +358,7 @@ class FreqDecoderFn(torch.autograd.Function):
             clast.conv(ftd, packed(ftd, ct_w), dzt, Bn, A, T, Au, "dglu", out0=dzab, aux0=zab_u)
             xin, A, Cc = xin_u, Au, Cu
         gx_cm = clast.to_cm(grads_sk[0])
-        return (gx_cm, None, *grads_sk, *grads_p)
+        return (gx_cm, None, None, *grads_sk, *grads_p)
 
 
 class HeadGeluFn(torch.autograd.Function):
@@ -339,18 +384,23 @@ def head_gelu(z):
     return HeadGeluFn.apply(z)
 
 
-def enc_mid(d, rewrite, conv_next, emb_rows, Bn, y_cl=False):
-    return EncMidFn.apply(d, rewrite.weight, rewrite.bias, conv_next.weight, conv_next.bias, emb_rows, Bn, y_cl)
+def _w4(w):
+    """Conv1d / ConvTranspose1d weights as the 4-D tensors the 2-D forms index (a view: the GradSink recognises the storage)."""
+    return w if w.dim() == 4 else w.unsqueeze(2)
+
+
+def enc_mid(d, rewrite, conv_next, emb_rows, Bn, y_cl=False, fold=False):
+    return EncMidFn.apply(d, _w4(rewrite.weight), rewrite.bias, _w4(conv_next.weight), conv_next.bias, emb_rows, Bn, y_cl, fold)
 
 
 def enc_tail(d, rewrite, Bn):
-    return EncTailFn.apply(d, rewrite.weight, rewrite.bias, Bn)
+    return EncTailFn.apply(d, _w4(rewrite.weight), rewrite.bias, Bn)
 
 
-def freq_decoder(x, skips, layers):
-    """skips: [e_J, ..., e_0]; layers: the _HDecLayer modules of layers J .. 0."""
+def freq_decoder(x, skips, layers, fold=False):
+    """skips: [e_J, ..., e_0]; layers: the _HDecLayer modules of layers J .. 0; fold: the time branch's decoder (x: (B, C, 1, L))."""
     params = []
     for m in layers[:-1]:
-        params += [m.rewrite.weight, m.rewrite.bias, m.conv_tr.weight, m.conv_tr.bias]
-    params += [layers[-1].rewrite.weight, layers[-1].rewrite.bias]
-    return FreqDecoderFn.apply(x, len(skips), *skips, *params)
+        params += [_w4(m.rewrite.weight), m.rewrite.bias, _w4(m.conv_tr.weight), m.conv_tr.bias]
+    params += [_w4(layers[-1].rewrite.weight), layers[-1].rewrite.bias]
+    return FreqDecoderFn.apply(x, len(skips), fold, *skips, *params)

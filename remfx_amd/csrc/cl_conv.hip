@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
     const int m = mg * BM + tid;
     float bv = 0.f;
     if (d.bias != nullptr && m < d.M) {
-      const int bi = mode == RFX_CL_GLU ? (m & 1) * (d.M >> 1) + (m >> 1) : (d.G > 1 ? m % d.Co : m);
+      const int bi = mode == RFX_CL_GLU ? (m & 1) * (d.M >> 1) + (m >> 1) : ((d.Co > 0 && d.Co < d.M) ? m % d.Co : m);   // folded / merged rows: (phase, channel)
       bv = d.bias[bi];
     }
     bias_lds[tid] = bv;

@@ -228,3 +228,33 @@ extern "C" int rfx_cl_dgelu(const void* g, const void* z, void* out, int64_t n, 
   RFX_CHECK_LAUNCH();
   return 0;
 }
+
+// out [n][2 C] = GLU backward of g [n][C] against the stored zab [n][2 C] = [a | b]: [g * sigmoid(b) | g * a * sigmoid(b) (1 - sigmoid(b))]
+__global__ __launch_bounds__(256) void cl_dglu_kernel(const uint4* __restrict__ g, const uint4* __restrict__ zab, uint4* __restrict__ out, int64_t npos, int CG) {
+  const int64_t total = npos * CG;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / CG;
+    const int cg = (int)(i - p * CG);
+    float v[8], a[8], b[8], ga[8], gb[8];
+    cl_unpack8(g[i], v);
+    cl_unpack8(zab[p * 2 * CG + cg], a);
+    cl_unpack8(zab[p * 2 * CG + CG + cg], b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float sg = rfx_sigmoid(b[e]);
+      ga[e] = v[e] * sg;
+      gb[e] = v[e] * a[e] * sg * (1.f - sg);
+    }
+    out[p * 2 * CG + cg] = cl_pack8(ga);
+    out[p * 2 * CG + CG + cg] = cl_pack8(gb);
+  }
+}
+extern "C" int rfx_cl_dglu(const void* g, const void* zab, void* out, int64_t npos, int32_t C, void* stream) {
+  if (!g || !zab || !out || npos <= 0 || C <= 0 || C % 8) return -1;
+  const int64_t total = npos * (C / 8);
+  const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(cl_dglu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(g),
+                     reinterpret_cast<const uint4*>(zab), reinterpret_cast<uint4*>(out), npos, C / 8);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

@@ -24,6 +24,7 @@ from . import clchain, cldconv, lstm, nnops, ops, stft
 # bf16 mode: the norm-free frequency layers run on the channels-last bf16 trunk (remfx_amd/clchain.py); RFX_CL_TRUNK=0 keeps the
 # channel-major kernels of rounds 1-4 for same-box A/B runs
 CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
+CL_TIME = os.environ.get("RFX_CL_TIME", "1") != "0"         # ... and the time branch's norm-free layers (folded-view forms, clast.py)
 CL_DCONV = os.environ.get("RFX_CL_DCONV", "1") != "0"       # ... and their DConv branches on the fused channels-last kernels (cldconv.py)
 
 
@@ -238,6 +239,11 @@ class _HEncLayer(nn.Module):
         B, C, Fr, T = y.shape
         return y.permute(0, 2, 1, 3).reshape(-1, C, T)
 
+    def head_t(self, x):
+        """conv + GELU of a norm-free TIME layer, (B, C, L / stride) fp32: the DConv branch's input (channels-last trunk)."""
+        y = ops.conv1d(x, self.conv.weight, self.conv.bias, self.stride, self.pad, out_bf16=ENC_Z16 and ENC_Z16_TIME)
+        return nnops.gelu(y)
+
     def _rest(self, y, inject):
         if self.empty:
             return y
@@ -415,6 +421,22 @@ class HDemucs(nn.Module):
             n, rows = n + 1, rows // 4
         return n if 2 <= n < self.depth else 0
 
+    def _cl_layers_time(self, length, device, Lc):
+        """The time branch follows the frequency branch onto the channels-last trunk (same layer count) when its layers have the same
+        norm-free geometry and every level is whole 256-position tiles."""
+        if not CL_TIME or Lc == 0 or len(self.time_encoder) <= Lc or length % (4 ** Lc * 256):
+            return 0
+        for i in range(Lc):
+            enc, dec = self.time_encoder[i], self.time_decoder[len(self.time_decoder) - 1 - i]
+            ok = (not enc.freq and not enc.empty and enc.context == 0 and enc.kernel_size == 8 and enc.stride == 4 and enc.pad == 2
+                  and not isinstance(enc.norm1, nn.GroupNorm) and not isinstance(enc.norm2, nn.GroupNorm)
+                  and enc.conv.out_channels % 16 == 0
+                  and not dec.freq and not dec.empty and dec.context == 1 and dec.kernel_size == 8 and dec.stride == 4 and dec.pad == 2
+                  and not isinstance(dec.norm1, nn.GroupNorm) and not isinstance(dec.norm2, nn.GroupNorm))
+            if not ok:
+                return 0
+        return Lc
+
     def forward(self, input):
         if input.ndim != 3 or input.shape[1] != self.audio_channels:
             raise ValueError(f"expected (batch, {self.audio_channels}, frames), got {tuple(input.shape)}")
@@ -434,11 +456,27 @@ class HDemucs(nn.Module):
         xt, meant, stdt = nnops.row_standardize(input, 1e-5)        # over (C, T) per clip
         saved, saved_t, lengths, lengths_t = [], [], [], []
         Lc = self._cl_layers(le, input.device)
-        samp = None
+        Lt = self._cl_layers_time(length, input.device, Lc)
+        samp = samp_t = None
+        len_t = length
         for idx, encode in enumerate(self.freq_encoder):
             lengths.append(x.shape[-1])
             inject = None
-            if idx < len(self.time_encoder):
+            if idx < Lt:
+                # time branch on the channels-last trunk: as the frequency layers below, with A = 1 and the stride along positions
+                lengths_t.append(len_t)
+                len_t = len_t // 4
+                tenc = self.time_encoder[idx]
+                if idx == 0:
+                    samp_t = tenc.head_t(xt)
+                dt_ = tenc.dconv(samp_t)
+                if idx < Lt - 1:
+                    et, samp_t = clchain.enc_mid(dt_, tenc.rewrite, self.time_encoder[idx + 1].conv, None, B, fold=True)
+                else:
+                    et, xt = clchain.enc_tail(dt_, tenc.rewrite, B)
+                    xt = xt.squeeze(2)
+                saved_t.append(et)
+            elif idx < len(self.time_encoder):
                 lengths_t.append(xt.shape[-1])
                 tenc = self.time_encoder[idx]
                 if saved_t and saved_t[-1] is xt:          # xt is the previous layer's output = a skip connection: see fork
@@ -497,7 +535,17 @@ class HDemucs(nn.Module):
                 skip = saved.pop(-1)
                 x, pre = decode(x, skip, lengths.pop(-1), next_skip=saved[-1] if (saved and j != Lc) else None, skip_added=fadd)
                 fadd = decode.fused_next_add
-            if idx >= offset:
+            if idx >= offset and j < Lt:
+                length_t = lengths_t.pop(-1)
+                if j == Lt - 1:
+                    skips_t = [saved_t.pop(-1) for _ in range(Lt)]
+                    yt0 = clchain.freq_decoder(xt.unsqueeze(2), skips_t, list(self.time_decoder[idx - offset:]), fold=True)
+                    lastt = self.time_decoder[-1]
+                    xt = ops.conv_transpose1d(yt0.squeeze(2), lastt.conv_tr.weight, lastt.conv_tr.bias, lastt.stride, 1, lastt.pad,
+                                              lengths_t[0] if lengths_t else length_t)
+                    if not lastt.last:
+                        xt = nnops.gelu(xt)
+            elif idx >= offset:
                 tdec = self.time_decoder[idx - offset]
                 length_t = lengths_t.pop(-1)
                 if tdec.empty:

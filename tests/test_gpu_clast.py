@@ -262,3 +262,94 @@ def test_wgrad_conv_s4_and_convtr(Cin, Cout, OA, N):
     wt = torch.zeros(Cout, Cin, 8, 1, dtype=torch.float64, requires_grad=True)
     F.conv_transpose2d(_r(y), wt, None, stride=(4, 1))[:, :, 2:2 + IA].backward(_r(dzt))
     _wclose(dwt, wt.grad, "conv_tr dW")
+
+
+@pytest.mark.parametrize("Cin,Cout,L,N", [(48, 96, 1024, 2), (96, 192, 2048, 1)])
+def test_time_branch_folded_forms(Cin, Cout, L, N):
+    """The time branch's Conv1d(8, stride 4, padding 2) / cropped ConvTranspose1d(8, stride 4) through folded views (four consecutive
+    positions = 4 C channels of a folded position; a 3-tap stride-1 convolution with structural zeros): forward, input gradients,
+    weight gradients against torch conv1d / conv_transpose1d in fp64 on the bf16-rounded operands."""
+    from remfx_amd import clast
+    g = torch.Generator().manual_seed(7)
+    Lo = L // 4
+    fold = lambda t: t.view(t.shape[0], 1, t.shape[2] // 4, 4 * t.shape[3])
+    cl1 = lambda t: t.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV).unsqueeze(1)            # (N, C, L) -> (N, 1, L, C)
+    cm1 = lambda t: t.detach().cpu().to(torch.float64).squeeze(1).permute(0, 2, 1).contiguous()
+    # ---- encoder conv + GELU
+    x = torch.randn(N, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, 8, generator=g) / (Cin * 8) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    f = clast.form_conv_s4_fold(Cout, Cin)
+    ap = clast.pack(f, w.to(DEV))
+    xc = cl1(x)
+    z = clast.empty(N, 1, Lo, Cout, DEV)
+    y = clast.empty(N, 1, Lo, Cout, DEV)
+    clast.conv(f, ap, fold(xc), N, 1, Lo, 1, "gelu", bias=b.to(DEV), out0=z, out1=y)
+    torch.cuda.synchronize()
+    zr = F.conv1d(_r(x), _r(w), b.double(), stride=4, padding=2)
+    _close(cm1(z), zr, "conv1d s4 z")
+    _close(cm1(y), F.gelu(_r(zr)), "gelu", ulps=3.0)
+    # ---- its input gradient (+ skip gradient), written through the folded view
+    dz = torch.randn(N, Cout, Lo, generator=g)
+    gsk = torch.randn(N, Cin, L, generator=g)
+    fd = clast.form_conv_s4_fold_dgrad(Cout, Cin)
+    apd = clast.pack(fd, w.to(DEV))
+    dx = clast.empty(N, 1, L, Cin, DEV)
+    clast.conv(fd, apd, cl1(dz), N, 1, Lo, 1, "store", out0=fold(dx), res=fold(cl1(gsk)))
+    torch.cuda.synchronize()
+    xv = _r(x).requires_grad_(True)
+    F.conv1d(xv, _r(w), None, stride=4, padding=2).backward(_r(dz))
+    _close(cm1(dx), _r(xv.grad) + _r(gsk), "conv1d s4 dgrad + skip", ulps=3.0, mag=_r(xv.grad).abs() + _r(gsk).abs())
+    # ---- its weight gradient
+    wf = clast.wform_conv_s4_fold(Cout, Cin)
+    dw = torch.empty(Cout, Cin, 8, device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    clast.wgrad(wf, cl1(dz), fold(xc), N, 1, 1, Lo, dw, db)
+    torch.cuda.synchronize()
+    wv = torch.zeros(Cout, Cin, 8, dtype=torch.float64, requires_grad=True)
+    bv = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    F.conv1d(_r(x), wv, bv, stride=4, padding=2).backward(_r(dz))
+    _wclose(dw, wv.grad, "conv1d s4 dW")
+    _wclose(db, bv.grad, "conv1d s4 db")
+    # ---- decoder transposed conv Cout -> Cin (coarse Lo -> fine L), GELU + next skip
+    yy = torch.randn(N, Cout, Lo, generator=g)
+    wt = torch.randn(Cout, Cin, 8, generator=g) / (Cout * 2) ** 0.5
+    bt = torch.randn(Cin, generator=g) * 0.1
+    skip = torch.randn(N, Cin, L, generator=g)
+    ft = clast.form_convtr_fold(Cout, Cin)
+    apt = clast.pack(ft, wt.to(DEV))
+    zt = clast.empty(N, 1, L, Cin, DEV)
+    st = clast.empty(N, 1, L, Cin, DEV)
+    clast.conv(ft, apt, cl1(yy), N, 1, Lo, 1, "gelu", bias=bt.to(DEV), out0=fold(zt), out1=fold(st), aux0=fold(cl1(skip)))
+    torch.cuda.synchronize()
+    ztr = F.conv_transpose1d(_r(yy), _r(wt), bt.double(), stride=4)[:, :, 2:2 + L]
+    _close(cm1(zt), ztr, "conv_transpose1d z")
+    _close(cm1(st), F.gelu(_r(ztr)) + _r(skip), "gelu + skip", ulps=3.0, mag=F.gelu(_r(ztr)).abs() + _r(skip).abs())
+    # ---- its input gradient + GLU backward, and weight gradient
+    dzt = torch.randn(N, Cin, L, generator=g)
+    zab = torch.randn(N, 2 * Cout, Lo, generator=g)
+    ftd = clast.form_convtr_fold_dgrad(Cout, Cin)
+    aptd = clast.pack(ftd, wt.to(DEV))
+    dzab = clast.empty(N, 1, Lo, 2 * Cout, DEV)
+    clast.conv(ftd, aptd, fold(cl1(dzt)), N, 1, Lo, 1, "dglu", out0=dzab, aux0=cl1(zab))
+    dyp = clast.empty(N, 1, Lo, Cout, DEV)
+    clast.conv(ftd, aptd, fold(cl1(dzt)), N, 1, Lo, 1, "store", out0=dyp)
+    torch.cuda.synchronize()
+    yv = _r(yy).requires_grad_(True)
+    F.conv_transpose1d(yv, _r(wt), None, stride=4)[:, :, 2:2 + L].backward(_r(dzt))
+    _close(cm1(dyp), yv.grad, "conv_transpose1d dgrad")
+    zq = _r(zab).requires_grad_(True)
+    F.glu(zq, dim=1).backward(_r(yv.grad))
+    _close(cm1(dzab), zq.grad, "glu backward", ulps=3.0)
+    # standalone GLU backward kernel
+    d2 = clast.dglu(dyp, cl1(zab))
+    zq2 = _r(zab).requires_grad_(True)
+    F.glu(zq2, dim=1).backward(_r(cm1(dyp)))
+    _close(cm1(d2), zq2.grad, "dglu kernel", ulps=3.0)
+    wft = clast.wform_convtr_fold(Cout, Cin)
+    dwt = torch.empty(Cout, Cin, 8, device=DEV)
+    clast.wgrad(wft, cl1(yy), fold(cl1(dzt)), N, 1, 1, Lo, dwt)
+    torch.cuda.synchronize()
+    wtv = torch.zeros(Cout, Cin, 8, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose1d(_r(yy), wtv, None, stride=4)[:, :, 2:2 + L].backward(_r(dzt))
+    _wclose(dwt, wtv.grad, "conv_transpose1d dW")

@@ -22,11 +22,12 @@ def _net():
     return net.to(DEV)
 
 
-def _run(net, x, gy, mode, trunk):
+def _run(net, x, gy, mode, trunk, time=True):
     from remfx_amd import hdemucs, ops
-    prev, prev_t = ops.gemm_precision(), hdemucs.CL_TRUNK
+    prev, prev_t, prev_tt = ops.gemm_precision(), hdemucs.CL_TRUNK, hdemucs.CL_TIME
     ops.set_gemm_precision(mode)
     hdemucs.CL_TRUNK = trunk
+    hdemucs.CL_TIME = time
     try:
         net.zero_grad(set_to_none=True)
         y = net(x)
@@ -36,6 +37,7 @@ def _run(net, x, gy, mode, trunk):
     finally:
         ops.set_gemm_precision(prev)
         hdemucs.CL_TRUNK = prev_t
+        hdemucs.CL_TIME = prev_tt
 
 
 def _rel(a, b):
