@@ -547,6 +547,8 @@ enum rfx_cl_epi {
   RFX_CL_GELU = 1,       /* out0 = v (may be absent), out1 = gelu(v) [+ aux0]   (encoder conv; decoder conv_tr + next skip) */
   RFX_CL_GLU = 2,        /* rows interleaved (a_c, b_c): out0 = v in natural order [a | b] (may be absent), out1 = a * sigmoid(b) */
   RFX_CL_DGELU = 3,      /* out0 = v (may be absent), out1 = v * gelu'(aux0)    (backward of GELU_ADD: skip gradient + pre-activation gradient) */
+  RFX_CL_STORE_CM = 5,   /* v as fp32 CHANNEL-MAJOR through cm_out (rows = (sub-row | sub-position, channel), Co channels; BM = 32): the last
+                          * decoder layer's transposed convolution, whose 1 - 2 output channels are no channels-last tensor */
   RFX_CL_DGLU = 4        /* aux0 = stored [a | b] of the forward GLU: out0 = [v * sigmoid(b) | v * a * sigmoid(b) (1 - sigmoid(b))]; out1 = v (optional) */
 };
 
@@ -574,6 +576,9 @@ typedef struct rfx_cl_conv_desc {
   const float* bias;      /* the layer's bias in ITS channel order (GLU: [a | b]; merged / folded rows (Co < M): bias[m % Co]), or NULL */
   const float* rowadd;    /* RFX_CL_GLU only: fp32 [OA][M / 2] added to out1 (a per-row vector: the frequency embedding), or NULL */
   rfx_cl_tensor out0, out1, aux0, res;
+  void* cm_out;           /* RFX_CL_STORE_CM: fp32 [N][Co][rows][positions], element strides cm_ns, cm_cs, cm_as */
+  int64_t cm_ns, cm_cs, cm_as;
+  int32_t cm_fold;        /* 0: merged row phases (output row oa*G + psi + g_off); 1: folded positions (position b * (M / Co) + psi) */
 } rfx_cl_conv_desc;
 int rfx_cl_conv(const rfx_cl_conv_desc* d, void* stream);
 /* dst[i] = bf16(idx[i] < 0 ? 0 : src[idx[i]]): weights -> packed MFMA fragments (idx built once per layer by the host planner) */
@@ -586,6 +591,12 @@ int rfx_cl_from_cm(const void* src, int32_t src_bf16, int64_t s_ns, int64_t s_cs
                    int32_t B, const rfx_cl_tensor* dst, const rfx_cl_tensor* res, const rfx_cl_tensor* aux, int32_t mode, void* stream);
 int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int32_t A, int32_t B, void* dst, int32_t dst_bf16, int64_t d_ns,
                  int64_t d_cs, int64_t d_as, const void* aux16, void* stream);
+/* dst [N][OA][B][16] bf16 = the 8 taps x Cs (1 | 2) channels of a (8, stride 4, padding 2) convolution gathered per output position from
+ * the channel-major fp32 src [N][Cs][rows][positions] (strides in elements; along_b = 0: taps over rows 4 oa + k - 2, 1: over positions
+ * 4 b + k - 2), channel k * Cs + c, zero outside and beyond 8 Cs: the operand of the 16-channel GEMMs that stand for the network's first
+ * convolution (2 spectrogram / 1 waveform channels) and for the input gradient of its last transposed one. */
+int rfx_cl_im2col_s4(const float* src, int64_t s_ns, int64_t s_cs, int64_t s_as, int32_t N, int32_t Cs, int32_t IA, int32_t IB, int32_t OA,
+                     int32_t OB, int32_t along_b, void* dst, void* stream);
 /* out = g * gelu'(z) over n bf16 values of dense channels-last tensors (n % 8 == 0) */
 int rfx_cl_dgelu(const void* g, const void* z, void* out, int64_t n, void* stream);
 /* GLU backward on dense channels-last tensors: g [npos][C], zab [npos][2C] = stored [a | b] -> out [npos][2C] */

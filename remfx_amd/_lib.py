@@ -105,7 +105,8 @@ class ClConvDesc(C.Structure):
                                          "db_step", "wrapb")] + \
                [("apack", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("M", "BM", "mode", "G", "g_off", "OAo", "Co")] + \
-               [("bias", C.c_void_p), ("rowadd", C.c_void_p), ("out0", ClTensor), ("out1", ClTensor), ("aux0", ClTensor), ("res", ClTensor)]
+               [("bias", C.c_void_p), ("rowadd", C.c_void_p), ("out0", ClTensor), ("out1", ClTensor), ("aux0", ClTensor), ("res", ClTensor),
+                ("cm_out", C.c_void_p), ("cm_ns", C.c_int64), ("cm_cs", C.c_int64), ("cm_as", C.c_int64), ("cm_fold", C.c_int32)]
 
 
 class ClDconvDesc(C.Structure):
@@ -219,6 +220,7 @@ SIGNATURES = {
     "rfx_cl_to_cm": [C.POINTER(ClTensor), _I32, _I32, _I32, _I32, _P, _I32, _I64, _I64, _I64, _P, _P],
     "rfx_cl_dgelu": [_P, _P, _P, _I64, _P],
     "rfx_cl_dglu": [_P, _P, _P, _I64, _I32, _P],
+    "rfx_cl_im2col_s4": [_P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "rfx_cl_dconv_ok": [_I32, _I32, _I32, _I32],
     "rfx_cl_dconv_fwd": [_P, _P],
     "rfx_cl_dconv_bwd": [_P, _P, _P],

@@ -15,7 +15,7 @@ import torch
 from . import _lib, ops
 from ._lib import ClConvDesc, ClTensor, ClWgradDesc, check
 
-EPI = {"store": 0, "gelu": 1, "glu": 2, "dgelu": 3, "dglu": 4}
+EPI = {"store": 0, "gelu": 1, "glu": 2, "dgelu": 3, "dglu": 4, "store_cm": 5}
 
 
 def _stream():
@@ -161,7 +161,7 @@ def pack(form, w):
 
 
 def conv(form, apack, x, N, IA, IB, OA, mode, bias=None, out0=None, out1=None, aux0=None, res=None, OAo=0, x_c0=0, wrapb=False,
-         rowadd=None):
+         rowadd=None, cm_out=None, cm_fold=False):
     """Launch rfx_cl_conv for `form` on the channels-last operand x; outputs / auxiliaries are channels-last tensors."""
     d = ClConvDesc()
     d.inp = cl_tensor(x, x_c0)
@@ -175,6 +175,10 @@ def conv(form, apack, x, N, IA, IB, OA, mode, bias=None, out0=None, out1=None, a
     d.bias = bias.data_ptr() if bias is not None else None
     d.rowadd = rowadd.data_ptr() if rowadd is not None else None
     d.out0, d.out1, d.aux0, d.res = cl_tensor(out0), cl_tensor(out1), cl_tensor(aux0), cl_tensor(res)
+    if cm_out is not None:                       # (N, Co, rows, positions) fp32, positions contiguous
+        if cm_out.dtype != torch.float32 or cm_out.stride(3) != 1:
+            raise ValueError("store_cm: fp32 (N, C, rows, positions) with contiguous positions")
+        d.cm_out, d.cm_ns, d.cm_cs, d.cm_as, d.cm_fold = cm_out.data_ptr(), cm_out.stride(0), cm_out.stride(1), cm_out.stride(2), int(cm_fold)
     check(_lib.lib().rfx_cl_conv(C.byref(d), _stream()), "rfx_cl_conv")
 
 
@@ -288,6 +292,57 @@ def form_convtr_fold_dgrad(Cin, Cout):
         k = _k_down(t, j)
         return np.where((k >= 0) & (k < 8), (m * Cout + co) * 8 + np.clip(k, 0, 7), -1)
     return ConvForm(Cin, 4 * Cout, 1, 3, 0, 0, -1, 1, 1, widx)
+
+
+# ---- the network's ends: 1 - 2 channel tensors (the spectrogram's real / imaginary parts, the waveform) are no channels-last tensors.
+# Their (8, stride 4) convolutions become 16-channel GEMMs over an im2col operand (rfx_cl_im2col_s4: channel k * Cs + c).
+def im2col_s4(x, OA, OB, along_b):
+    """x (N, Cs, IA, IB) fp32 channel-major (Cs = 1 | 2) -> (N, OA, OB, 16) bf16."""
+    N, Cs, IA, IB = x.shape
+    if x.dtype != torch.float32 or x.stride(3) != 1:
+        x = x.float().contiguous()
+    out = empty(N, OA, OB, 16, x.device)
+    check(_lib.lib().rfx_cl_im2col_s4(C.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), x.stride(2), N, Cs, IA, IB, OA, OB, int(along_b),
+                                      C.c_void_p(out.data_ptr()), _stream()), "rfx_cl_im2col_s4")
+    return out
+
+
+def form_head(Cout, Cs):
+    """Conv (Cs -> Cout, 8 taps, stride 4, padding 2) on the im2col operand; weight (Cout, Cs, 8[, 1])."""
+    def widx(m, r, t, ch):
+        k, c = ch // Cs, ch % Cs
+        return np.where(k < 8, (m * Cs + c) * 8 + np.minimum(k, 7), -1)
+    return ConvForm(Cout, 16, 1, 1, 0, 0, 0, 0, 1, widx, KS=1)
+
+
+def wform_head(Cout, Cs):
+    """its weight gradient: P = output gradient (Cout), Q = the im2col operand."""
+    def widx(m, r, t, c):
+        return (m * Cs + c % Cs) * 8 + c // Cs
+    return WgradForm(Cout, 8 * Cs, 1, 1, 1, 0, 0, 0, widx, Cout * Cs * 8)
+
+
+def form_tail_tr(Cc, Cs):
+    """ConvTranspose2d(Cc -> Cs, (8, 1), stride (4, 1)) cropped by 2 rows, merged row phases, stored channel-major (store_cm)."""
+    def widx(m, r, t, ch):
+        psi, co = m // Cs, m % Cs
+        return (ch * Cs + co) * 8 + psi + 4 * (1 - r)
+    return ConvForm(4 * Cs, Cc, 2, 1, -1, 1, 0, 0, 1, widx, G=4, g_off=-2, Co=Cs)
+
+
+def form_tail_dgrad(Cc, Cs):
+    """Input gradient of the last transposed convolution from the im2col of its output gradient: rows = Cc; weight (Cc, Cs, 8[, 1])."""
+    def widx(m, r, t, ch):
+        k, co = ch // Cs, ch % Cs
+        return np.where(k < 8, (m * Cs + co) * 8 + np.minimum(k, 7), -1)
+    return ConvForm(Cc, 16, 1, 1, 0, 0, 0, 0, 1, widx, KS=1)
+
+
+def wform_tail(Cc, Cs):
+    """its weight gradient: P = the layer's input (Cc), Q = the im2col of the output gradient."""
+    def widx(m, r, t, c):
+        return (m * Cs + c % Cs) * 8 + c // Cs
+    return WgradForm(Cc, 8 * Cs, 1, 1, 1, 0, 0, 0, widx, Cc * Cs * 8, bias=False)
 
 
 # ---- weight gradients -------------------------------------------------------------------------------------------------------------

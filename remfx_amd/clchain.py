@@ -29,6 +29,8 @@ _BUILD = {
     # the time branch: stride 4 along the position axis through folded views
     "s4f": clast.form_conv_s4_fold, "s4fd": clast.form_conv_s4_fold_dgrad, "trf": clast.form_convtr_fold,
     "trfd": clast.form_convtr_fold_dgrad, "ws4f": clast.wform_conv_s4_fold, "wtrf": clast.wform_convtr_fold,
+    # the network's ends (1 - 2 channel tensors): 16-channel GEMMs over im2col operands, channel-major store
+    "head": clast.form_head, "whead": clast.wform_head, "tail": clast.form_tail_tr, "taild": clast.form_tail_dgrad, "wtail": clast.wform_tail,
 }
 
 
@@ -264,8 +266,9 @@ class FreqDecoderFn(torch.autograd.Function):
     (rewrite w, b, conv_tr w, b) and the last layer's rewrite (w, b).  Returns y_0 = GLU(rewrite_0(.)) as (Bn, C_0, A_0, T) fp32."""
 
     @staticmethod
-    def forward(ctx, x, nsk, fold, *rest):
-        """fold: the time branch (A = 1, 1 x 3 rewrites, the transposed convolutions through folded views)."""
+    def forward(ctx, x, nsk, fold, tail, *rest):
+        """fold: the time branch (A = 1, 1 x 3 rewrites, the transposed convolutions through folded views).  tail: the parameters end
+        with the LAST layer's transposed convolution (w, b; C -> 1 | 2 channels): the node returns its channel-major fp32 output."""
         skips, params = rest[:nsk], rest[nsk:]
         J = nsk - 1
         Bn, CJ, AJ, T = x.shape
@@ -305,16 +308,29 @@ class FreqDecoderFn(torch.autograd.Function):
         y0 = clast.empty(Bn, A, T, Cc, dev)
         clast.conv(fg, packed(fg, rw_w), xin, Bn, A, T, A, "glu", bias=rw_b, out0=zab, out1=y0)
         saved += [xin, zab]
-        out = clast.to_cm(y0)
+        if tail:
+            tw, tb = params[4 * J + 2], params[4 * J + 3]
+            Cs = tw.shape[1]
+            if fold:
+                out = torch.empty((Bn, Cs, 1, 4 * T), device=dev, dtype=torch.float32)
+                ftl = form("trf", Cc, Cs)
+                clast.conv(ftl, packed(ftl, tw), y0, Bn, 1, T, 1, "store_cm", bias=tb, cm_out=out, cm_fold=True)
+            else:
+                out = torch.empty((Bn, Cs, 4 * A, T), device=dev, dtype=torch.float32)
+                ftl = form("tail", Cc, Cs)
+                clast.conv(ftl, packed(ftl, tw), y0, Bn, A, T, A + 1, "store_cm", bias=tb, cm_out=out, OAo=4 * A)
+            saved += [y0]
+        else:
+            out = clast.to_cm(y0)
         if train:
             ctx.save_for_backward(*saved, *[p for p in params])
             ctx.nsaved = len(saved)
-            ctx.geom = (Bn, AJ, CJ, x.shape[3], J, fold)
+            ctx.geom = (Bn, AJ, CJ, x.shape[3], J, fold, tail)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        Bn, AJ, CJ, TJ, J, fold = ctx.geom
+        Bn, AJ, CJ, TJ, J, fold, tail = ctx.geom
         KA = 1 if fold else 3
         saved, params = ctx.saved_tensors[:ctx.nsaved], ctx.saved_tensors[ctx.nsaved:]
         dev = g.device
@@ -326,7 +342,26 @@ class FreqDecoderFn(torch.autograd.Function):
         A, T, Cc = (AJ, TJ * 4 ** J, CJ // 2 ** J) if fold else (AJ * 4 ** J, TJ, CJ // 2 ** J)
         xin, zab = saved[4 * J], saved[4 * J + 1]
         dzab = clast.empty(Bn, A, T, 2 * Cc, dev)
-        clast.from_cm(g, out=dzab, aux=zab, mode="dglu")
+        if tail:
+            # the last transposed convolution: its output gradient gathered per input position (16 channels = 8 taps x Cs), the input
+            # gradient as a 16-channel GEMM with the rewrite's GLU backward in its store
+            y0 = saved[4 * J + 2]
+            tw, tb = params[4 * J + 2], params[4 * J + 3]
+            Cs = tw.shape[1]
+            g16 = clast.im2col_s4(g, A, T, fold)
+            grads_p[4 * J + 2], _ = _wgrad(form("wtail", Cc, Cs), y0, g16, Bn, A, A, T, tw, None)
+            sink = ops.SINK
+            tbs = sink.lookup(tb) if sink is not None else None
+            dtb = ops.channel_sum(g)
+            if tbs is not None:
+                tbs[1].add_(dtb)
+                sink.wrote(tbs[0])
+            else:
+                grads_p[4 * J + 3] = dtb
+            ftd = form("taild", Cc, Cs)
+            clast.conv(ftd, packed(ftd, tw), g16, Bn, A, T, A, "dglu", out0=dzab, aux0=zab)
+        else:
+            clast.from_cm(g, out=dzab, aux=zab, mode="dglu")
         for k in range(J, -1, -1):                              # rewrite of layer j = J - k, walking up from layer 0 (k = J)
             rw_w, rw_b = params[4 * k], params[4 * k + 1]
             grads_p[4 * k], grads_p[4 * k + 1] = _wgrad(form("w", 2 * Cc, Cc, KA, 3), dzab, xin, Bn, A, A, T, rw_w, rw_b)
@@ -358,7 +393,7 @@ class FreqDecoderFn(torch.autograd.Function):
             clast.conv(ftd, packed(ftd, ct_w), dzt, Bn, A, T, Au, "dglu", out0=dzab, aux0=zab_u)
             xin, A, Cc = xin_u, Au, Cu
         gx_cm = clast.to_cm(grads_sk[0])
-        return (gx_cm, None, None, *grads_sk, *grads_p)
+        return (gx_cm, None, None, None, *grads_sk, *grads_p)
 
 
 class HeadGeluFn(torch.autograd.Function):
@@ -397,10 +432,47 @@ def enc_tail(d, rewrite, Bn):
     return EncTailFn.apply(d, _w4(rewrite.weight), rewrite.bias, Bn)
 
 
-def freq_decoder(x, skips, layers, fold=False):
-    """skips: [e_J, ..., e_0]; layers: the _HDecLayer modules of layers J .. 0; fold: the time branch's decoder (x: (B, C, 1, L))."""
+def freq_decoder(x, skips, layers, fold=False, tail=False):
+    """skips: [e_J, ..., e_0]; layers: the _HDecLayer modules of layers J .. 0; fold: the time branch's decoder (x: (B, C, 1, L));
+    tail: the last layer's transposed convolution too (returns its channel-major output instead of its input)."""
     params = []
     for m in layers[:-1]:
         params += [_w4(m.rewrite.weight), m.rewrite.bias, _w4(m.conv_tr.weight), m.conv_tr.bias]
     params += [_w4(layers[-1].rewrite.weight), layers[-1].rewrite.bias]
-    return FreqDecoderFn.apply(x, len(skips), fold, *skips, *params)
+    if tail:
+        params += [_w4(layers[-1].conv_tr.weight), layers[-1].conv_tr.bias]
+    return FreqDecoderFn.apply(x, len(skips), fold, tail, *skips, *params)
+
+
+class HeadConvFn(torch.autograd.Function):
+    """The frequency branch's first convolution (2 spectrogram channels -> C, (8, 1) / 4, padding 2) + GELU as a 16-channel GEMM over the
+    im2col of its channel-major fp32 input: x (Bn, 2, 4 A, T) -> gelu(z) channels-last (Bn, A, T, C).  The input carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        Bn, Cs, IA, T = x.shape
+        A, Cc = IA // 4, w.shape[0]
+        dev = x.device
+        train = any(ctx.needs_input_grad[1:])
+        x16 = clast.im2col_s4(x, A, T, False)
+        f = form("head", Cc, Cs)
+        z = clast.empty(Bn, A, T, Cc, dev) if train else None
+        y = clast.empty(Bn, A, T, Cc, dev)
+        clast.conv(f, packed(f, w), x16, Bn, A, T, A, "gelu", bias=b, out0=z, out1=y)
+        if train:
+            ctx.save_for_backward(x16, z, w)
+            ctx.refs = (b,)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x16, z, w = ctx.saved_tensors
+        (b,) = ctx.refs
+        Bn, A, T, Cc = z.shape
+        dz = clast.dgelu(g if g.is_contiguous() else g.contiguous(), z)
+        dw, db = _wgrad(form("whead", Cc, w.shape[1]), dz, x16, Bn, A, A, T, w, b)
+        return None, dw, db
+
+
+def head_conv(x, conv):
+    return HeadConvFn.apply(x, conv.weight, conv.bias)

@@ -290,6 +290,27 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if (mode == RFX_CL_STORE_CM) {
+      // channel-major fp32 straight from the accumulators: a register is one GEMM row = (sub-row / sub-position, channel), the lanes
+      // are 32 consecutive positions -- 128-byte runs.  The last decoder layer's transposed convolution (C -> 1 or 2 channels).
+      const int bp = b0 + 32 * (wn * NT + t) + l31;
+      float* cm = reinterpret_cast<float*>(d.cm_out) + (int64_t)n * d.cm_ns;
+      const int nsub = d.M / d.Co;
+#pragma unroll
+      for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, m = mrow0 + row;
+          if (m < d.M) {
+            const int psi = m / d.Co, co = m - psi * d.Co;
+            const int orow = d.cm_fold ? oa : oa * d.G + psi + d.g_off;
+            const int64_t pos = d.cm_fold ? (int64_t)bp * nsub + psi : bp;
+            if (d.cm_fold || (unsigned)orow < (unsigned)d.OAo)
+              cm[(int64_t)co * d.cm_cs + (int64_t)orow * d.cm_as + pos] = acc[i][t][r] + bias_lds[wm * 32 * RW + row];
+          }
+        }
+      continue;
+    }
     // registers -> transpose tile
 #pragma unroll
     for (int i = 0; i < RW; ++i)
@@ -451,13 +472,15 @@ extern "C" int rfx_cl_conv(const rfx_cl_conv_desc* dp, void* stream) {
   const rfx_cl_conv_desc& d = *dp;
   if (d.N <= 0 || d.OA <= 0 || d.OB <= 0 || d.OB % 256 || d.OB != d.IB || d.M <= 0 || d.NTR <= 0 || d.NTR > 16 || d.NCH <= 0) return -1;
   if (d.in.bs % 8 || d.in.c0 % 8 || (d.NCH * 16 * d.KS + d.in.c0) > d.in.bs) return -1;
-  if (d.G < 1 || d.G > 4 || (d.G > 1 && (d.Co % 8 || d.Co * d.G != d.M))) return -1;
-  if (d.mode < 0 || d.mode > RFX_CL_DGLU) return -1;
+  const bool cm = d.mode == RFX_CL_STORE_CM;
+  if (d.G < 1 || d.G > 4 || (d.G > 1 && ((!cm && d.Co % 8) || d.Co * d.G != d.M))) return -1;
+  if (d.mode < 0 || d.mode > RFX_CL_STORE_CM) return -1;
+  if (cm && (!d.cm_out || d.Co <= 0 || d.M % d.Co || d.BM != 32)) return -1;
   if (d.mode == RFX_CL_GLU && (d.M % 16 || !d.out1.p || d.G != 1)) return -1;
   if ((d.mode == RFX_CL_STORE || d.mode == RFX_CL_DGLU) && !d.out0.p) return -1;
   if ((d.mode == RFX_CL_GELU || d.mode == RFX_CL_DGELU) && !d.out1.p) return -1;
   if ((d.mode == RFX_CL_DGELU || d.mode == RFX_CL_DGLU) && !d.aux0.p) return -1;
-  if (d.M % 8) return -1;
+  if (d.M % 8 && !cm) return -1;
   const int orows = d.G > 1 ? d.OAo : d.OA;
   if (!cl_fits32(d.out0, orows, d.IB) || !cl_fits32(d.out1, orows, d.IB) || !cl_fits32(d.aux0, orows, d.IB) || !cl_fits32(d.res, orows, d.IB))
     return -1;

@@ -258,3 +258,41 @@ extern "C" int rfx_cl_dglu(const void* g, const void* zab, void* out, int64_t np
   RFX_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- the 16-channel operand of the network's first convolution / last transposed convolution (see remfx_hip.h)
+__global__ __launch_bounds__(256) void cl_im2col_s4_kernel(const float* __restrict__ src, int64_t s_ns, int64_t s_cs, int64_t s_as, int N, int Cs,
+                                                           int IA, int IB, int OA, int OB, int along_b, uint4* __restrict__ dst) {
+  const int64_t total = (int64_t)N * OA * OB;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i % OB);
+    const int64_t q = i / OB;
+    const int oa = (int)(q % OA), n = (int)(q / OA);
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    const float* s = src + (int64_t)n * s_ns;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ia = along_b ? oa : 4 * oa + k - 2, ib = along_b ? 4 * b + k - 2 : b;
+      if ((unsigned)ia < (unsigned)IA && (unsigned)ib < (unsigned)IB) {
+        v[k * Cs] = s[(int64_t)ia * s_as + ib];
+        if (Cs == 2) v[k * 2 + 1] = s[s_cs + (int64_t)ia * s_as + ib];
+      }
+    }
+    float lo[8], hi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[8 + e]; }
+    dst[2 * i] = cl_pack8(lo);
+    dst[2 * i + 1] = cl_pack8(hi);
+  }
+}
+extern "C" int rfx_cl_im2col_s4(const float* src, int64_t s_ns, int64_t s_cs, int64_t s_as, int32_t N, int32_t Cs, int32_t IA, int32_t IB, int32_t OA,
+                                int32_t OB, int32_t along_b, void* dst, void* stream) {
+  if (!src || !dst || N <= 0 || (Cs != 1 && Cs != 2) || IA <= 0 || IB <= 0 || OA <= 0 || OB <= 0) return -1;
+  const int64_t total = (int64_t)N * OA * OB;
+  const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  hipLaunchKernelGGL(cl_im2col_s4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, s_ns, s_cs, s_as, N, Cs, IA, IB, OA, OB, along_b,
+                     reinterpret_cast<uint4*>(dst));
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

@@ -25,6 +25,7 @@ from . import clchain, cldconv, lstm, nnops, ops, stft
 # channel-major kernels of rounds 1-4 for same-box A/B runs
 CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
 CL_TIME = os.environ.get("RFX_CL_TIME", "1") != "0"         # ... and the time branch's norm-free layers (folded-view forms, clast.py)
+CL_ENDS = os.environ.get("RFX_CL_ENDS", "1") != "0"         # ... and the 1 - 2 channel convolutions at the network's ends as im2col GEMMs
 CL_DCONV = os.environ.get("RFX_CL_DCONV", "1") != "0"       # ... and their DConv branches on the fused channels-last kernels (cldconv.py)
 
 
@@ -229,9 +230,11 @@ class _HEncLayer(nn.Module):
         out = self._rest(y, inject)
         return (out, alias) if want_pair else out
 
-    def head(self, x, cl=False):
+    def head(self, x, cl=False, ends=True):
         """conv + GELU of a norm-free frequency layer as (B * Fr, C, T) samples, the DConv branch's input (channels-last trunk);
         cl: as (B, Fr, T, C) channels-last bf16 samples (the fused channels-last DConv kernels)."""
+        if cl and ends and x.shape[1] <= 2 and x.shape[2] % 4 == 0 and not x.requires_grad:
+            return clchain.head_conv(x, self.conv)          # 16-channel GEMM over the im2col of the 2-channel spectrogram
         y = ops.conv2d(x, self.conv.weight, self.conv.bias, (self.stride, 1), (self.pad, 0), out_bf16=ENC_Z16 or cl)
         if cl:
             return clchain.head_gelu(y)
@@ -493,7 +496,7 @@ class HDemucs(nn.Module):
                 # channels-last trunk: the DConv branch on (B * Fr, C, T) samples, everything between two branches in one node
                 dcl = CL_DCONV and encode.dconv.cl_ok()      # this layer's DConv branch runs on channels-last samples
                 if idx == 0:
-                    samp = encode.head(x, cl=dcl)
+                    samp = encode.head(x, cl=dcl, ends=CL_ENDS)
                 d = encode.dconv.forward_cl(samp) if dcl else encode.dconv(samp)
                 if idx < Lc - 1:
                     emb_rows = self.freq_emb.table() * self.freq_emb_scale if (idx == 0 and self.freq_emb is not None) else None
@@ -524,13 +527,16 @@ class HDemucs(nn.Module):
                 lengths.pop(-1)
                 if j == Lc - 1:                   # layers Lc - 1 .. 0 in one node; the last transposed convolution (C -> 2 audio) stays channel-major
                     skips = [saved.pop(-1) for _ in range(Lc)]
-                    y0 = clchain.freq_decoder(x, skips, list(self.freq_decoder[idx:]))
                     last = self.freq_decoder[-1]
-                    full = (y0.shape[2] - 1) * last.stride + last.kernel_size
-                    x = ops.conv_transpose2d(y0, last.conv_tr.weight, last.conv_tr.bias, (last.stride, 1), (1, 1), (last.pad, 0),
-                                             (full - 2 * last.pad, y0.shape[3]))
-                    if not last.last:
-                        x = nnops.gelu(x)
+                    if CL_ENDS and last.last and last.conv_tr.out_channels <= 2:
+                        x = clchain.freq_decoder(x, skips, list(self.freq_decoder[idx:]), tail=True)
+                    else:
+                        y0 = clchain.freq_decoder(x, skips, list(self.freq_decoder[idx:]))
+                        full = (y0.shape[2] - 1) * last.stride + last.kernel_size
+                        x = ops.conv_transpose2d(y0, last.conv_tr.weight, last.conv_tr.bias, (last.stride, 1), (1, 1), (last.pad, 0),
+                                                 (full - 2 * last.pad, y0.shape[3]))
+                        if not last.last:
+                            x = nnops.gelu(x)
             else:
                 skip = saved.pop(-1)
                 x, pre = decode(x, skip, lengths.pop(-1), next_skip=saved[-1] if (saved and j != Lc) else None, skip_added=fadd)
@@ -539,12 +545,15 @@ class HDemucs(nn.Module):
                 length_t = lengths_t.pop(-1)
                 if j == Lt - 1:
                     skips_t = [saved_t.pop(-1) for _ in range(Lt)]
-                    yt0 = clchain.freq_decoder(xt.unsqueeze(2), skips_t, list(self.time_decoder[idx - offset:]), fold=True)
                     lastt = self.time_decoder[-1]
-                    xt = ops.conv_transpose1d(yt0.squeeze(2), lastt.conv_tr.weight, lastt.conv_tr.bias, lastt.stride, 1, lastt.pad,
-                                              lengths_t[0] if lengths_t else length_t)
-                    if not lastt.last:
-                        xt = nnops.gelu(xt)
+                    if CL_ENDS and lastt.last and lastt.conv_tr.out_channels <= 2:
+                        xt = clchain.freq_decoder(xt.unsqueeze(2), skips_t, list(self.time_decoder[idx - offset:]), fold=True, tail=True).squeeze(2)
+                    else:
+                        yt0 = clchain.freq_decoder(xt.unsqueeze(2), skips_t, list(self.time_decoder[idx - offset:]), fold=True)
+                        xt = ops.conv_transpose1d(yt0.squeeze(2), lastt.conv_tr.weight, lastt.conv_tr.bias, lastt.stride, 1, lastt.pad,
+                                                  lengths_t[0] if lengths_t else length_t)
+                        if not lastt.last:
+                            xt = nnops.gelu(xt)
             elif idx >= offset:
                 tdec = self.time_decoder[idx - offset]
                 length_t = lengths_t.pop(-1)

@@ -54,6 +54,19 @@ def test_trunk_vs_channel_major_full_config():
     y_cm, g_cm = _run(net, x, gy, "bf16", False)
     y_cl, g_cl = _run(net, x, gy, "bf16", True)
     y_cl2, g_cl2 = _run(net, x, gy, "bf16", True)
+    # the same with the pieces of the trunk switched off one at a time (A/B flags of hdemucs.py): every combination stays in the band
+    from remfx_amd import hdemucs
+    for flag in ("CL_TIME", "CL_ENDS", "CL_DCONV"):
+        prev = getattr(hdemucs, flag)
+        setattr(hdemucs, flag, False)
+        try:
+            y_v, g_v = _run(net, x, gy, "bf16", True, time=flag != "CL_TIME")
+        finally:
+            setattr(hdemucs, flag, prev)
+        num = sum(float(((g_v[n].double() - g32[n].double()) ** 2).sum()) for n in g32)
+        den_ = sum(float((g32[n].double() ** 2).sum()) for n in g32)
+        print(f"{flag} off: output {_rel(y_v, y32):.3e}, global gradient {(num / den_) ** 0.5:.3e}")
+        assert _rel(y_v, y32) < 1.5 * _rel(y_cm, y32) + 1e-4 and (num / den_) ** 0.5 < 0.04
     e_cm, e_cl = _rel(y_cm, y32), _rel(y_cl, y32)
     print(f"output: relative error vs fp32 mode: channel-major bf16 {e_cm:.3e}, channels-last trunk {e_cl:.3e}")
     assert e_cl < 1.5 * e_cm + 1e-4
