@@ -216,7 +216,11 @@ extern "C" int rfx_gemm_fwd(const rfx_gemm_desc* d, const float* apack, const rf
   }
   // stride-1 multi-tap plans in the bf16 mode: halo-tile kernel (gemm_halo.h) -- the input tile of a 256-position row segment is
   // staged once per 16-channel chunk in LDS and serves every tap
-  if (prec == 2 && !apack2 && d->in_bf16 != 3 && rfx_halo_takes(*d)) return rfx_launch_gemm_halo(g, s);
+  // (the halo kernel builds 32-bit byte offsets against a sample descriptor too: same extent limits as the tap-major path below)
+  if (prec == 2 && !apack2 && d->in_bf16 != 3 && rfx_halo_takes(*d)) {
+    if (d->in_extent <= 0 || d->in_extent > 0x7fffffffLL) return -1;
+    return rfx_launch_gemm_halo(g, s);
+  }
   const int bm = 32 * r;
   if (d->Mpad % bm != 0) return -1;
   const int64_t work = (int64_t)((P + 127) / 128) * d->N;          // (sample, position tile) items

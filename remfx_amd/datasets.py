@@ -227,6 +227,11 @@ class EffectDataset(Dataset):
         from .effects import LoudnessNormalize
         if not torch.cuda.is_available():
             raise RuntimeError("EffectDataset(render_files=True) renders on the GPU (remfx_amd.effects has no CPU path)")
+        # scripts/train.py instantiates the datamodule BEFORE the Trainer brings the process group up: under a launcher (WORLD_SIZE > 1
+        # in the environment) join the group here, or every rank would think it is rank 0 of 1 and render into the same directory
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and torch.distributed.is_available() and not torch.distributed.is_initialized():
+            from . import ddp
+            ddp.init_from_env()
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
         rank = torch.distributed.get_rank() if dist_on else 0
         try:

@@ -87,6 +87,7 @@ class GradSync:
         self._seen = [0] * len(flat.params)
         self._hook_seen = [False] * len(flat.params)
         self._counted = [False] * len(flat.params)  # a parameter enters its bucket's `ready` count once per step
+        self._next = 0                              # first bucket whose all-reduce has not been issued in this step (_launch_in_order)
         self._late = False                          # a gradient write arrived after its bucket's all-reduce was queued
         self._late_info = []                        # (route, parameter index, expected sink writes, seen) of those writes, for the error text
         self.measure_stall = False                  # bench.py: time the compute stream's stall on the collectives (exposed_ms)
@@ -104,7 +105,11 @@ class GradSync:
         for idx in range(len(self.flat.params)):
             if self.expected[idx] == 0 and not self.hooked[idx]:
                 self._counted[idx] = True
-                self.buckets[self.bucket_of[idx]]["ready"] += 1
+                b = self.buckets[self.bucket_of[idx]]
+                b["ready"] += 1
+                if b["ready"] == b["n"]:
+                    b["complete"] = True             # goes out when the buckets in front of it have (never at step start: the
+                                                     # gradient buffer is zeroed after this bookkeeping)
 
     def _maybe_complete(self, idx):
         if self.expected is None or self._counted[idx]:
@@ -115,7 +120,20 @@ class GradSync:
         self._counted[idx] = True
         b["ready"] += 1
         if b["ready"] == b["n"]:
+            b["complete"] = True
+            self._launch_in_order()
+
+    def _launch_in_order(self):
+        """Collectives are issued in BUCKET INDEX order on every rank: a complete bucket goes out early only once all buckets in
+        front of it have gone out, otherwise it waits (finish() sends the rest, in index order too).  A rank whose step deviates from
+        the calibration step (a held or never-completed bucket) therefore still issues the same sequence of all-reduces over the same
+        slices as the others -- it only issues them later."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if not b.get("complete") or b.get("hold"):
+                return
             self._launch(b)
+            self._next += 1
 
     def _make_hook(self, idx):
         def hook(_p):
@@ -166,7 +184,8 @@ class GradSync:
         if self.world == 1:
             return 1.0
         for b in self.buckets:
-            self._launch(b)           # whatever the hooks have not launched (parameters without a gradient never fire theirs)
+            self._launch(b)           # whatever the hooks have not launched (parameters without a gradient never fire theirs), in index order
+        self._next = 0
         timed = self.flat.grad.is_cuda and self.measure_stall
         if timed:                     # GPU time the compute stream spends stalled on the collectives = what backward did not hide
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -182,6 +201,7 @@ class GradSync:
             b["ready"] = 0
             b["launched"] = False
             b["hold"] = False
+            b["complete"] = False
         self._counted = [False] * len(self.flat.params)
         late, self._late = self._late, False
         if self.overlap:

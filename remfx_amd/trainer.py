@@ -136,9 +136,12 @@ class Trainer:
         if sched is not None and ck.get("lr_schedulers"):
             sched.load_state_dict(ck["lr_schedulers"][0])
         self.global_step, self.current_epoch = int(ck.get("global_step", 0)), int(ck.get("epoch", 0))
-        cb = (ck.get("callbacks") or {}).get("ModelCheckpoint") or {}
+        # Lightning keys the callback state by the callback's state_key ("ModelCheckpoint{'monitor': ...}"): take any key of that family
+        cbs = ck.get("callbacks") or {}
+        cb = next((v for k, v in cbs.items() if str(k).startswith("ModelCheckpoint") and isinstance(v, dict)), {})
         if cb.get("best_model_score") is not None:
             self._resumed_best = float(cb["best_model_score"])
+            self._resumed_best_path = cb.get("best_model_path") or None
 
     def fit(self, model, datamodule=None, ckpt_dir=None, ckpt_path=None):
         """ckpt_dir: where last.ckpt is written (every ckpt_every_n_steps steps when set, every epoch, and at the end);
@@ -163,7 +166,19 @@ class Trainer:
         # THIS fit wrote best.ckpt -- test(ckpt_path="best") never picks up a stale file an earlier run left in ckpt_dir
         self.best_path, self._best_state = (os.path.join(ckpt_dir, "best.ckpt") if ckpt_dir else None), None
         self.best_score, self._best_written = getattr(self, "_resumed_best", None), False
-        self._resumed_best = None
+        # a resumed fit that never beats the restored score must still find the best weights: the restored best_model_path is valid when
+        # the file is there and carries exactly the restored score
+        self._restored_best_file = None
+        rb = getattr(self, "_resumed_best_path", None)
+        if self.best_score is not None and rb and os.path.exists(rb):
+            try:
+                cbr = (load_checkpoint_file(rb, map_location="cpu").get("callbacks") or {})
+                sc = next((v.get("best_model_score") for k, v in cbr.items() if str(k).startswith("ModelCheckpoint") and isinstance(v, dict)), None)
+                if sc is not None and float(sc) == float(self.best_score):
+                    self._restored_best_file = rb
+            except Exception:
+                pass
+        self._resumed_best = self._resumed_best_path = None
         while self.global_step < self.max_steps and (self.max_epochs < 0 or self.current_epoch < self.max_epochs):
             model.train()
             if hasattr(datamodule, "set_epoch"):
@@ -222,6 +237,12 @@ class Trainer:
                 model.load_state_dict(load_checkpoint_file(best, map_location=self.device)["state_dict"])
             elif getattr(self, "_best_state", None) is not None:
                 model.load_state_dict(self._best_state)
+            elif getattr(self, "_restored_best_file", None):
+                model.load_state_dict(load_checkpoint_file(self._restored_best_file, map_location=self.device)["state_dict"])
+            elif getattr(self, "best_score", None) is not None:
+                import warnings
+                warnings.warn("Trainer.test(ckpt_path='best'): the restored best score has no matching checkpoint file; evaluating the "
+                              "last-step weights", stacklevel=2)
             # no validation ran: the last-step weights, as Lightning falls back to
         elif ckpt_path:
             ck = load_checkpoint_file(ckpt_path, map_location=self.device)

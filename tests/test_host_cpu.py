@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from remfx_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "remfx_hip.h")).read()
-    declared = set(re.findall(r"\bint\s+(rfx_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|int64_t)\s+(rfx_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = ctypes.CDLL(_lib.build())                      # hipcc cross-compiles without a GPU
