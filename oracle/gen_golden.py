@@ -189,6 +189,32 @@ def gen_tcn_full():
     print("tcn_full_fwd_bwd", tuple(y.shape), "y rms", float(y.pow(2).mean().sqrt()), "gnorm", float(gtot))
 
 
+def gen_tcn_full_length():
+    """BASELINE config 2 at its REAL shape: the full cfg/model/tcn.yaml network of the imported reference (remfx/tcn.py:62-138) on one
+    262144-sample clip, forward only (the reference takes ~16 s per clip on the build container's cores): strided output slices and
+    the output norm -> tests/golden/tcn_full_length_fwd.npz.  Same seeded weights as gen_tcn_full."""
+    import yaml
+    from remfx.tcn import TCN
+    full = yaml.safe_load(open(os.path.join(REF, "cfg/model/tcn.yaml")))["model"]["network"]
+    for k in ("_target_", "sample_rate", "num_bins"):
+        full.pop(k)
+    net = TCN(**full).eval()
+    sd = ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7, seed=31)
+    for i, k in enumerate([k for k in sd if k.endswith("relu.weight")]):
+        sd[k] = torch.linspace(0.05, 0.45, sd[k].numel()).roll(7 * i)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(132)
+    T = 262144
+    x = torch.randn(1, 1, T, generator=g) * 0.5
+    with torch.no_grad():
+        y = net(x)
+    yf = y.reshape(-1)
+    np.savez_compressed(os.path.join(OUT, "tcn_full_length_fwd.npz"), seed=np.int64(31), x_seed=np.int64(132), T=np.int64(T),
+                        y_len=np.int64(yf.numel()), y_stride=np.int64(61), y_slice=yf[::61].numpy().copy(),
+                        y_head=yf[:2048].numpy().copy(), y_tail=yf[-2048:].numpy().copy(), y_norm=np.float64(yf.double().norm()))
+    print("tcn_full_length_fwd", tuple(y.shape), "y rms", float(y.pow(2).mean().sqrt()))
+
+
 def gen_cnn14():
     from remfx.classifier import Cnn14
     net = Cnn14(num_classes=5, sample_rate=48000, model_sample_rate=48000, n_fft=2048,
@@ -289,7 +315,8 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     only = sys.argv[1:]                      # e.g. `python oracle/gen_golden.py tcn_full` regenerates one fixture
-    for name, fn in (("utils", gen_utils), ("tcn", gen_tcn), ("tcn_full", gen_tcn_full), ("cnn14", gen_cnn14),
+    for name, fn in (("utils", gen_utils), ("tcn", gen_tcn), ("tcn_full", gen_tcn_full), ("tcn_full_length", gen_tcn_full_length),
+                     ("cnn14", gen_cnn14),
                      ("flow", gen_flow)):
         if not only or name in only:
             fn()

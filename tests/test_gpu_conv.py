@@ -179,6 +179,34 @@ def test_tcn_full_width_golden(golden_dir):
         check(e, 1e-3, float(np.abs(ref).max()), bf16x3=1e-2, bf16=0.2, what=(n, e))
 
 
+def test_tcn_full_width_full_length_golden(golden_dir):
+    """BASELINE config 2 at its REAL shape: the 20-block x 256-channel TCN on one 262144-sample clip against the
+    forward output of the imported reference remfx.tcn.TCN (tests/golden/tcn_full_length_fwd.npz, oracle/gen_golden.py::
+    gen_tcn_full_length; reference remfx/tcn.py:62-138): output length, norm, head / tail runs and a stride-61 slice over the whole clip."""
+    from oracle import ref_tcn
+    from remfx_amd.tcn import TCN
+    dev = _dev()
+    gd = np.load(os.path.join(golden_dir, "tcn_full_length_fwd.npz"))
+    sd = ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7, seed=int(gd["seed"]))
+    for i, k in enumerate([k for k in sd if k.endswith("relu.weight")]):
+        sd[k] = torch.linspace(0.05, 0.45, sd[k].numel()).roll(7 * i)
+    net = TCN(ninputs=1, noutputs=1, nblocks=20, channel_growth=0, channel_width=256, kernel_size=7, stack_size=10,
+              dilation_growth=2, condition=False, latent_dim=2, norm_type="identity", causal=False, estimate_loudness=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    gen = torch.Generator().manual_seed(int(gd["x_seed"]))
+    x = torch.randn(1, 1, int(gd["T"]), generator=gen) * 0.5
+    with torch.no_grad():
+        y = net(x.to(dev)).reshape(-1).cpu().numpy()
+    assert y.size == int(gd["y_len"])
+    rms = float(np.sqrt((gd["y_slice"] ** 2).mean()))
+    for name, got, ref in (("slice", y[::int(gd["y_stride"])], gd["y_slice"]), ("head", y[:2048], gd["y_head"]), ("tail", y[-2048:], gd["y_tail"])):
+        err = float(np.sqrt(((got - ref) ** 2).mean()))
+        print(f"full-length TCN {name}: rms error {err:.3e} (output rms {rms:.3e})")
+        check(err, 1e-4, rms, bf16=5e-2, what=(name, err))
+    check(abs(float(np.sqrt((y.astype(np.float64) ** 2).sum())) - float(gd["y_norm"])), 1e-4, float(gd["y_norm"]), bf16=2e-2, what="norm")
+
+
 def test_tcn_backward_vs_oracle():
     """fwd + all gradients of a reduced TCN vs autograd over the CPU oracle."""
     from oracle import ref_tcn
