@@ -91,10 +91,19 @@ def dglu(g, zab):
 
 
 # ---- tile choice ----------------------------------------------------------------------------------------------------------------
-def pick_bm(M):
-    """Rows per workgroup: 192 (two wave rows of 96) for the wide layers, else the smallest of 32 / 64 / 96 that holds M in
-    the fewest tiles."""
+BM96_MAX_K = int(_os.environ.get("RFX_CL_BM96_K", "800"))    # 96-row tiles for layers whose reduction is at most this long (0: A/B off)
+
+
+def pick_bm(M, K=1 << 30, NTC=1):
+    """Rows per workgroup.  96-row tiles (48 accumulator registers, four waves per SIMD, two workgroups per CU: one workgroup's store
+    tail runs under the other's loads) for the multi-column-tap layers and for every layer with a short reduction -- the merged /
+    folded stride-4 forms and the 1 x 1 rewrites are HBM-class and spend their time in the store (same-box A/B at 64 clips, r05:
+    transposed convolution 96 -> 48 1.45 -> 0.82 ms, encoder input gradient + skip + GLU backward 1.68 -> 1.03 ms, 1 x 1 rewrite
+    96 -> 192 0.74 -> 0.42 ms, 3 x 3 rewrites 4 - 10 % faster); 192 rows (two wave rows of 96) for the long stride-4 reductions
+    (K >= 1536: 6 - 15 % faster there); else the smallest of 32 / 64 / 96 that holds M in the fewest tiles."""
     if M > 96:
+        if BM96_MAX_K and (K <= BM96_MAX_K or NTC > 1) and M % 96 == 0:
+            return 96
         return 192 if (M % 192 == 0 or M > 288) else 96
     if M > 64:
         return 96
@@ -113,7 +122,7 @@ class ConvForm:
         self.M, self.Cin, self.NTR, self.NTC = M, Cin, NTR, NTC
         self.da0, self.da_step, self.db0, self.db_step, self.SA = da0, da_step, db0, db_step, SA
         self.G, self.g_off, self.Co = G, g_off, (Co or M)
-        self.BM = pick_bm(M)
+        self.BM = pick_bm(M, NTR * NTC * Cin, NTC)
         self.MG = -(-M // self.BM)
         if KS is None:
             KS = 1 if NTC > 1 else (2 if Cin % 32 == 0 else 1)

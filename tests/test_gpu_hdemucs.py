@@ -152,10 +152,16 @@ def test_hdemucs_full_config_gradients_golden(golden_dir):
     y = net(x.to(DEV))
     y.backward(gy.to(DEV))
     ys = y.detach().cpu().reshape(-1)[::4099].numpy()
-    check(float(np.sqrt(((ys - gd["y_slice"]) ** 2).mean())), 1e-4, max(1.0, float(np.abs(gd["y_slice"]).max())), bf16=2e-2, what="y")
+    # bf16 bounds of this test = 2x what round 5 measured (RFX_TOL_LOG, channels-last trunk on): y 5.5e-5, global norm 1.4e-3, worst
+    # slice 5.2e-2 and worst norm 1.2e-2 (both freq_encoder.1.dconv.layers.1.0.weight); the statement against the autocast oracle is
+    # tests/test_gpu_bf16_mixed.py::test_hdemucs_full_config_bf16_gradients_vs_autocast
+    e_y = float(np.sqrt(((ys - gd["y_slice"]) ** 2).mean()))
+    print(f"y slice rms error {e_y:.3e}")
+    check(e_y, 1e-4, max(1.0, float(np.abs(gd["y_slice"]).max())), bf16=1.2e-4, what="y")
     params = dict(net.named_parameters())
     tot = sum(float(p.grad.double().pow(2).sum()) for p in params.values() if p.grad is not None) ** 0.5
-    check(abs(tot - float(gd["grad_global_norm"])), 2e-3, float(gd["grad_global_norm"]), bf16=5e-2, what="global grad norm")
+    print(f"global gradient norm: relative error {abs(tot - float(gd['grad_global_norm'])) / float(gd['grad_global_norm']):.3e}")
+    check(abs(tot - float(gd["grad_global_norm"])), 2e-3, float(gd["grad_global_norm"]), bf16=3e-3, what="global grad norm")
     for i, n in enumerate(gd["names"].tolist()):
         gr = params[n].grad.detach().cpu().reshape(-1)
         step = max(1, gr.numel() // 512)
@@ -163,8 +169,9 @@ def test_hdemucs_full_config_gradients_golden(golden_dir):
         ref_sl, ref_norm = gd[f"g{i}_slice"], float(gd[f"g{i}_norm"])
         err = float(np.sqrt(((sl - ref_sl) ** 2).mean())) / max(1e-12, float(np.sqrt((ref_sl ** 2).mean())))
         # slice RMS error relative to the slice RMS; bias-like tensors are cancelling sums (see test_hdemucs_small_fwd_bwd)
-        check(err, 2e-2, bf16x3=2e-2, bf16=0.25, what=(n, "slice", err))
-        check(abs(float(gr.double().norm()) - ref_norm), 1e-2, ref_norm, bf16=0.1, what=(n, "norm"))
+        print(f"  {n:52s} slice {err:.3e} norm {abs(float(gr.double().norm()) - ref_norm) / ref_norm:.3e}")
+        check(err, 2e-2, bf16x3=2e-2, bf16=0.11, what=(n, "slice", err))
+        check(abs(float(gr.double().norm()) - ref_norm), 1e-2, ref_norm, bf16=0.025, what=(n, "norm"))
 
 
 @pytest.mark.one_mode
