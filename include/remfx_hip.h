@@ -644,6 +644,11 @@ typedef struct rfx_cl_dconv_desc {
   const float *b1, *g1w, *g1b, *b2, *g2w, *g2b, *scale;
   int32_t S, C, H, dil, grid, x_or_gy_ok;
   float eps;
+  int32_t TPS;             /* 256-position tiles per sample (S counts TILES): 1 = the frequency branch; > 1 = the time branch, whose GroupNorm
+                            * spans a whole clip -- forward in three passes with the statistics reduced in between (stats and `partial`,
+                            * 2 floats per tile, required) */
+  float* tsum; float* sums; /* backward in passes (TPS > 1 or C = 96): tile sums [S][2], per-sample means [S / TPS][4]; dz / dh come out final,
+                            * dx is left to the caller (rfx_cl_conv: gy + the transposed 3-tap convolution of dh) */
 } rfx_cl_dconv_desc;
 int rfx_cl_dconv_ok(int32_t C, int32_t H, int32_t T, int32_t backward);
 int rfx_cl_dconv_fwd(const rfx_cl_dconv_desc* d, void* stream);

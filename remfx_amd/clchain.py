@@ -449,12 +449,14 @@ class HeadConvFn(torch.autograd.Function):
     im2col of its channel-major fp32 input: x (Bn, 2, 4 A, T) -> gelu(z) channels-last (Bn, A, T, C).  The input carries no gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, along_b):
+        """along_b: the time branch's first convolution (1 waveform channel, stride along the samples): x (Bn, 1, 1, L) -> (Bn, 1, L / 4, C)."""
         Bn, Cs, IA, T = x.shape
-        A, Cc = IA // 4, w.shape[0]
+        A, T = (IA, T // 4) if along_b else (IA // 4, T)
+        Cc = w.shape[0]
         dev = x.device
         train = any(ctx.needs_input_grad[1:])
-        x16 = clast.im2col_s4(x, A, T, False)
+        x16 = clast.im2col_s4(x, A, T, along_b)
         f = form("head", Cc, Cs)
         z = clast.empty(Bn, A, T, Cc, dev) if train else None
         y = clast.empty(Bn, A, T, Cc, dev)
@@ -471,8 +473,8 @@ class HeadConvFn(torch.autograd.Function):
         Bn, A, T, Cc = z.shape
         dz = clast.dgelu(g if g.is_contiguous() else g.contiguous(), z)
         dw, db = _wgrad(form("whead", Cc, w.shape[1]), dz, x16, Bn, A, A, T, w, b)
-        return None, dw, db
+        return None, dw, db, None
 
 
-def head_conv(x, conv):
-    return HeadConvFn.apply(x, conv.weight, conv.bias)
+def head_conv(x, conv, along_b=False):
+    return HeadConvFn.apply(x, _w4(conv.weight), conv.bias, along_b)

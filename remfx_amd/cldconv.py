@@ -70,8 +70,22 @@ def tables(Cc, H):
     return t
 
 
-def supported(Cc, H, backward):
-    return bool(_lib.lib().rfx_cl_dconv_ok(int(Cc), int(H), T, int(backward)))
+def supported(Cc, H, backward, positions=T):
+    return bool(_lib.lib().rfx_cl_dconv_ok(int(Cc), int(H), int(positions), int(backward)))
+
+
+def _dx_form(Cc, H, dil):
+    """dx = gy + sum_t dh(pos - (t - 1) dil) W1_t as a channels-last convolution over dh (HP stored channels): rows = C."""
+    key = ("dconv_dx", Cc, H, dil)
+    f = clchain._FORMS.get(key)
+    if f is None:
+        HP = -(-H // 16) * 16
+
+        def widx(m, r, t, ch):
+            return np.where(ch < H, (np.minimum(ch, H - 1) * Cc + m) * 3 + (2 - t), -1)
+        f = clast.ConvForm(Cc, HP, 1, 3, 0, 0, -dil, dil, 1, widx, KS=1)
+        clchain._FORMS[key] = f
+    return f
 
 
 def _wforms(Cc, H, dil):
@@ -103,22 +117,29 @@ class ClDconvLayerFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale, dil, eps):
         Bn, A, Tt, Cc = x.shape
         H = w1.shape[0]
-        if Tt != T or not x.is_contiguous() or x.dtype != torch.bfloat16:
-            raise ValueError("ClDconvLayerFn: dense (N, A, 256, C) bf16 input")
+        if Tt % T or not x.is_contiguous() or x.dtype != torch.bfloat16:
+            raise ValueError("ClDconvLayerFn: dense (N, A, 256 k, C) bf16 input")
         tb = tables(Cc, H)
-        HP, S, dev = tb["HP"], Bn * A, x.device
+        TPS = Tt // T                                   # tiles per sample: 1 = frequency branch, > 1 = a time-branch clip
+        HP, S, dev = tb["HP"], Bn * A * TPS, x.device
         train = any(ctx.needs_input_grad)
         y = torch.empty_like(x)
         d = _desc(Cc, H, dil, eps, S, b1, g1w, g1b, b2, g2w, g2b, scale)
+        d.TPS = TPS
         d.x, d.y = x.data_ptr(), y.data_ptr()
         d.w1p = clchain.packed(tb["w1p"], w1).data_ptr()
         d.w2p = clchain.packed(tb["w2p"], w2).data_ptr()
-        a = hpre = stats = None
+        a = hpre = stats = part = None
+        if train or TPS > 1:
+            stats = torch.empty((Bn * A, 4), device=dev, dtype=torch.float32)
+            d.stats = stats.data_ptr()
+        if TPS > 1:
+            part = torch.empty((S, 2), device=dev, dtype=torch.float32)
+            d.partial = part.data_ptr()
         if train:
-            a = torch.empty((Bn, A, T, HP), device=dev, dtype=torch.bfloat16)
+            a = torch.empty((Bn, A, Tt, HP), device=dev, dtype=torch.bfloat16)
             hpre = torch.empty_like(a)
-            stats = torch.empty((S, 4), device=dev, dtype=torch.float32)
-            d.a, d.hpre, d.stats = a.data_ptr(), hpre.data_ptr(), stats.data_ptr()
+            d.a, d.hpre = a.data_ptr(), hpre.data_ptr()
         check(_lib.lib().rfx_cl_dconv_fwd(C.byref(d), C.c_void_p(ops.raw_stream())), "rfx_cl_dconv_fwd")
         if train:
             ctx.save_for_backward(x, a, hpre, stats, w1, b1, g1w, g1b, w2, b2, g2w, g2b, scale)
@@ -132,25 +153,36 @@ class ClDconvLayerFn(torch.autograd.Function):
         Bn, A, Tt, Cc = x.shape
         H = w1.shape[0]
         tb = tables(Cc, H)
-        HP, S, dev = tb["HP"], Bn * A, x.device
+        TPS = Tt // T
+        HP, S, dev = tb["HP"], Bn * A * TPS, x.device
+        passes = TPS > 1 or Cc != 48                    # several tiles per sample, or images too large for the one-pass kernel's LDS
         if not gy.is_contiguous():
             gy = gy.contiguous()
         dx = torch.empty_like(x)
-        dz = torch.empty((Bn, A, T, 2 * Cc), device=dev, dtype=torch.bfloat16)
-        dh = torch.empty((Bn, A, T, HP), device=dev, dtype=torch.bfloat16)
+        dz = torch.empty((Bn, A, Tt, 2 * Cc), device=dev, dtype=torch.bfloat16)
+        dh = torch.empty((Bn, A, Tt, HP), device=dev, dtype=torch.bfloat16)
         npg = 5 * Cc + 2 * H
         partial = torch.empty((min(GRID, S), npg), device=dev, dtype=torch.float32)
         pg = torch.empty(npg, device=dev, dtype=torch.float32)
         d = _desc(Cc, H, dil, eps, S, b1, g1w, g1b, b2, g2w, g2b, scale)
+        d.TPS = TPS
         d.gy, d.y, d.a, d.hpre, d.stats = gy.data_ptr(), dx.data_ptr(), a.data_ptr(), hpre.data_ptr(), stats.data_ptr()
         d.dz, d.dh, d.partial = dz.data_ptr(), dh.data_ptr(), partial.data_ptr()
         d.w2p = clchain.packed(tb["w2p"], w2).data_ptr()
         d.w2dp = clchain.packed(tb["w2dp"], w2).data_ptr()
-        d.w1dp = clchain.packed(tb["w1dp"], w1).data_ptr()
+        if passes:
+            tsum = torch.empty((S, 2), device=dev, dtype=torch.float32)
+            sums = torch.empty((Bn * A, 4), device=dev, dtype=torch.float32)
+            d.tsum, d.sums = tsum.data_ptr(), sums.data_ptr()
+        else:
+            d.w1dp = clchain.packed(tb["w1dp"], w1).data_ptr()
         check(_lib.lib().rfx_cl_dconv_bwd(C.byref(d), C.c_void_p(pg.data_ptr()), C.c_void_p(ops.raw_stream())), "rfx_cl_dconv_bwd")
+        if passes:                                      # dx = gy + the transposed 3-tap convolution of dh (taps cross tile edges)
+            fx = _dx_form(Cc, H, dil)
+            clast.conv(fx, clchain.packed(fx, w1), dh, Bn, A, Tt, A, "store", out0=dx, res=gy)
         f1, f2 = _wforms(Cc, H, dil)
-        dw2, db2 = clchain._wgrad(f2, dz, a, Bn, A, A, T, w2, b2)
-        dw1, db1 = clchain._wgrad(f1, dh, x, Bn, A, A, T, w1, b1)
+        dw2, db2 = clchain._wgrad(f2, dz, a, Bn, A, A, Tt, w2, b2)
+        dw1, db1 = clchain._wgrad(f1, dh, x, Bn, A, A, Tt, w1, b1)
         dscale, dg2w, dg2b = pg[:Cc], pg[Cc:3 * Cc], pg[3 * Cc:5 * Cc]
         dg1w, dg1b = pg[5 * Cc:5 * Cc + H], pg[5 * Cc + H:]
         return dx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None

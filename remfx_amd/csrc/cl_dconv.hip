@@ -88,7 +88,11 @@ __device__ __forceinline__ void cld_block_sum2(float& a, float& b, float* red, i
   a = sa; b = sb;
 }
 
-template <int C, int H>
+// PH: 0 = a sample is one 256-position tile, statistics inside the kernel (the frequency branch); 1 / 2 / 3 = a sample is TPS
+// consecutive tiles (the time branch: a whole clip), GroupNorm statistics span all of them: pass 1 leaves the tile sums of h, pass 2
+// (statistics 1 given) those of z, pass 3 (both given) finishes -- each pass recomputes the cheap front of the layer from x
+// (K = 3 C and K = H GEMMs) instead of storing anything of width 2 C.  Tile edges inside a sample read the neighbour's rows.
+template <int C, int H, int PH>
 __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) {
   using Cfg = CldCfg<C, H>;
   constexpr int HP = Cfg::HP, KC = Cfg::KC, KH = Cfg::KH, NTV = Cfg::NTV, NT2 = Cfg::NT2, RH = Cfg::RH, RS = Cfg::RS;
@@ -141,6 +145,17 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
     const uint32_t sbase = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
 #pragma unroll
     for (int i = 0; i < KC; ++i) cl_glds16(rs_x, ximg + (CLD_HALO + p0) * RS + i * 1024, sbase + i * 1024);
+    if (PH != 0 && (wave == 0 || wave == 7) && lane < CLD_HALO * RS / 16) {
+      // halo rows: the neighbouring tile's edge rows inside a sample, zeros at the sample's ends
+      const int tile = s % d.TPS;
+      const bool left = wave == 0;
+      const bool inside = left ? tile > 0 : tile + 1 < d.TPS;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (inside)
+        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(d.x) + (int64_t)s * (CLD_T * RS) +
+                                            (left ? -(int64_t)CLD_HALO * RS : (int64_t)CLD_T * RS) + lane * 16);
+      *reinterpret_cast<uint4*>(ximg + (left ? 0 : (CLD_T + CLD_HALO) * RS) + lane * 16) = v;
+    }
     CL_VMCNT(0);
     __syncthreads();
     // ---- GEMM1
@@ -163,13 +178,24 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
       s1 += hv[r];
       s2 = fmaf(hv[r], hv[r], s2);
     }
-    cld_block_sum2(s1, s2, red, wave, lane);
-    const float mu1 = s1 * n1;
-    const float rs1 = rsqrtf(fmaxf(s2 * n1 - mu1 * mu1, 0.f) + d.eps);
+    float mu1, rs1;
+    if (PH == 0) {
+      cld_block_sum2(s1, s2, red, wave, lane);
+      mu1 = s1 * n1;
+      rs1 = rsqrtf(fmaxf(s2 * n1 - mu1 * mu1, 0.f) + d.eps);
+    } else if (PH == 1) {
+      cld_block_sum2(s1, s2, red, wave, lane);
+      if (tid == 0) *reinterpret_cast<float2*>(d.partial + (int64_t)s * 2) = make_float2(s1, s2);
+      continue;
+    } else {
+      const float4 st = *reinterpret_cast<const float4*>(d.stats + (int64_t)(s / d.TPS) * 4);
+      mu1 = st.x; rs1 = st.y;
+      __syncthreads();                               // the neighbours' tap reads of this wave's rows are done before they are overwritten
+    }
     float av[RH];
 #pragma unroll
     for (int r = 0; r < RH; ++r) av[r] = cld_bf16r(rfx_gelu(fmaf((hv[r] - mu1) * rs1, g1r[r], e1r[r])));
-    if (train) {
+    if (train && PH != 2) {
       // [pos][HP]: registers 4 q .. 4 q + 3 are rows 8 q + 4 half + 0..3 = 8 consecutive bytes
       uint16_t* ap = reinterpret_cast<uint16_t*>(d.a) + ((int64_t)s * CLD_T + p0 + l31) * HP + 4 * half;
       uint16_t* hp = reinterpret_cast<uint16_t*>(d.hpre) + ((int64_t)s * CLD_T + p0 + l31) * HP + 4 * half;
@@ -204,10 +230,20 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
           s2 = fmaf(z[t][r], z[t][r], fmaf(z[NTV + t][r], z[NTV + t][r], s2));
         }
       }
-    cld_block_sum2(s1, s2, red, wave, lane);
-    const float mu2 = s1 * n2;
-    const float rs2 = rsqrtf(fmaxf(s2 * n2 - mu2 * mu2, 0.f) + d.eps);
-    if (train && tid == 0) *reinterpret_cast<float4*>(d.stats + (int64_t)s * 4) = make_float4(mu1, rs1, mu2, rs2);
+    float mu2, rs2;
+    if (PH == 0) {
+      cld_block_sum2(s1, s2, red, wave, lane);
+      mu2 = s1 * n2;
+      rs2 = rsqrtf(fmaxf(s2 * n2 - mu2 * mu2, 0.f) + d.eps);
+      if (train && tid == 0) *reinterpret_cast<float4*>(d.stats + (int64_t)s * 4) = make_float4(mu1, rs1, mu2, rs2);
+    } else if (PH == 2) {
+      cld_block_sum2(s1, s2, red, wave, lane);
+      if (tid == 0) *reinterpret_cast<float2*>(d.partial + (int64_t)s * 2) = make_float2(s1, s2);
+      continue;
+    } else {
+      const float4 st = *reinterpret_cast<const float4*>(d.stats + (int64_t)(s / d.TPS) * 4);
+      mu2 = st.z; rs2 = st.w;
+    }
     // ---- residual in the same layout, GLU, LayerScale; y over this wave's own rows of the image
 #pragma unroll
     for (int t = 0; t < NTV; ++t) {
@@ -525,6 +561,260 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwd_kernel(const ClDconvK g) 
   }
 }
 
+// ---- backward in passes, for samples of several tiles (the time branch) and for widths whose single-pass images do not fit the LDS
+// (C = 96).  Everything a pass needs from another tile is a per-sample scalar, reduced between the passes in a fixed order:
+//   B1  z recomputed from a; GLU / LayerScale / GroupNorm-2 backward up to d(zhat); d(zhat) PARKED in the dz tensor (bf16); tile sums
+//       of d(zhat) and d(zhat) zhat; per-lane sums for dscale / dgn2w / dgn2b
+//   B2  (sample means given) zhat again, dz finalised in place; da^T = dz^T W2; GELU / GroupNorm-1 backward up to d(hhat), parked in
+//       the dh tensor; tile sums; per-lane sums for dgn1w / dgn1b
+//   B3  (means given) dh finalised in place (flat elementwise); dx = gy + conv^T(dh) then runs on cl_conv (taps across tile edges).
+// Four waves, each staging its own 32-position sub-tiles in LDS (two per wave and tile).
+template <int C, int H, int PASS>
+__global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g) {
+  using Cfg = CldCfg<C, H>;
+  constexpr int HP = Cfg::HP, KC = Cfg::KC, KH = Cfg::KH, NTV = Cfg::NTV, NT2 = Cfg::NT2, RS = Cfg::RS, RSH = Cfg::RSH, RSZ = Cfg::RSZ;
+  constexpr int KZ = 2 * C / 16, NW = 4, SUB = 2;
+  // LDS: per wave [gy sub-tile 32 RS | a sub-tile 32 RSH | h sub-tile 32 RSH | z sub-tile 32 RSZ | dh sub-tile 32 RSH], then the fragments
+  constexpr int WV = 32 * (RS + 3 * RSH + RSZ), O_A = 32 * RS, O_H = O_A + 32 * RSH, O_Z = O_H + 32 * RSH, O_DH = O_Z + 32 * RSZ;
+  constexpr int O_W2 = NW * WV, O_W2D = O_W2 + KH * NT2 * 1024, O_RED = O_W2D + KZ * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char cld_smem[];
+  const rfx_cl_dconv_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  unsigned char* wv = cld_smem + wave * WV;
+  unsigned char* gsub = wv, *asub = wv + O_A, *hsub = wv + O_H, *zsub = wv + O_Z, *dhsub = wv + O_DH;
+  float* red = reinterpret_cast<float*>(cld_smem + O_RED);
+  cld_copy_in(cld_smem + O_W2, d.w2p, KH * NT2 * 1024, tid, 256);
+  if (PASS == 2) cld_copy_in(cld_smem + O_W2D, d.w2dp, KZ * 1024, tid, 256);
+  float b2v[NTV], b2g[NTV], gv[NTV], ev[NTV], gg[NTV], eg[NTV], sc[NTV];
+  bool cok[NTV];
+#pragma unroll
+  for (int t = 0; t < NTV; ++t) {
+    const int c = 32 * t + l31;
+    cok[t] = c < C;
+    b2v[t] = cok[t] ? d.b2[c] : 0.f;      b2g[t] = cok[t] ? d.b2[C + c] : 0.f;
+    gv[t] = cok[t] ? d.g2w[c] : 0.f;      gg[t] = cok[t] ? d.g2w[C + c] : 0.f;
+    ev[t] = cok[t] ? d.g2b[c] : 0.f;      eg[t] = cok[t] ? d.g2b[C + c] : 0.f;
+    sc[t] = cok[t] ? d.scale[c] : 0.f;
+  }
+  const bool hok = l31 < H;
+  const float g1 = hok ? d.g1w[l31] : 0.f, e1 = hok ? d.g1b[l31] : 0.f;
+  float a_ds[NTV], a_gwv[NTV], a_gwg[NTV], a_gbv[NTV], a_gbg[NTV], a_g1w = 0.f, a_g1b = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTV; ++t) a_ds[t] = a_gwv[t] = a_gwg[t] = a_gbv[t] = a_gbg[t] = 0.f;
+  const cl_bf16x8 id0 = cld_ident(0, lane), id1 = cld_ident(1, lane);
+  const int64_t big = 0x7ffffff0;
+  const __amdgpu_buffer_rsrc_t rs_g = cl_rsrc(d.gy, (uint32_t)min(big, (int64_t)d.S * CLD_T * RS));
+  const __amdgpu_buffer_rsrc_t rs_a = cl_rsrc(d.a, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
+  const __amdgpu_buffer_rsrc_t rs_h = cl_rsrc(d.hpre, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
+  const __amdgpu_buffer_rsrc_t rs_z = cl_rsrc(d.dz, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSZ));
+  __syncthreads();
+
+  for (int s = blockIdx.x; s < d.S; s += gridDim.x) {
+    CLD_NO_HOIST();
+    const int smp = s / d.TPS;
+    const float4 st = *reinterpret_cast<const float4*>(d.stats + (int64_t)smp * 4);
+    const float mu1 = st.x, rs1 = st.y, mu2 = st.z, rs2 = st.w;
+    float m1 = 0.f, m2 = 0.f;
+    if (PASS == 2) {
+      const float2 mm = *reinterpret_cast<const float2*>(d.sums + (int64_t)smp * 4);
+      m1 = mm.x; m2 = mm.y;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+    for (int sub = 0; sub < SUB; ++sub) {
+      const int p0 = 64 * wave + 32 * sub;                       // first position of this sub-tile inside the tile
+      const int prow = 4 * half;                                 // its rows inside the per-wave staging buffers
+      // ---- loads of this sub-tile (own rows only)
+      {
+        const uint32_t hb = (uint32_t)s * (CLD_T * RSH) + (uint32_t)p0 * RSH + lane * 16;
+#pragma unroll
+        for (int i = 0; i < KH; ++i) cl_glds16(rs_a, asub + i * 1024, hb + i * 1024);
+        if (PASS == 1) {
+          const uint32_t gb = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+#pragma unroll
+          for (int i = 0; i < KC; ++i) cl_glds16(rs_g, gsub + i * 1024, gb + i * 1024);
+        } else {
+#pragma unroll
+          for (int i = 0; i < KH; ++i) cl_glds16(rs_h, hsub + i * 1024, hb + i * 1024);
+          const uint32_t zb = (uint32_t)s * (CLD_T * RSZ) + (uint32_t)p0 * RSZ + lane * 16;
+#pragma unroll
+          for (int i = 0; i < 2 * KC; ++i) cl_glds16(rs_z, zsub + i * 1024, zb + i * 1024);
+        }
+      }
+      CL_VMCNT(0);
+      __builtin_amdgcn_wave_barrier();
+      cl_bf16x8 afr[KH];
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+        const unsigned char* ar = asub + l31 * RSH + (16 * ks + 4 * half) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(ar), hi = *reinterpret_cast<const uint2*>(ar + 16);
+        afr[ks] = __builtin_bit_cast(cl_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
+      const unsigned char* grow = gsub + l31 * RS + 16 * half;
+#pragma unroll
+      for (int t = 0; t < NTV; ++t) {
+        f32x16 zv, zg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zv[r] = zg[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+          zv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + O_W2 + (ks * NT2 + t) * 1024 + lane * 16), zv, 0, 0, 0);
+          zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + O_W2 + (ks * NT2 + NTV + t) * 1024 + lane * 16), zg, 0, 0, 0);
+        }
+        unsigned char* zb = zsub + prow * RSZ + (32 * t + l31) * 2;
+        if (PASS == 1) {
+          f32x16 gy;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gy[r] = 0.f;
+          gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), id0, gy, 0, 0, 0);
+          if (2 * t + 1 < KC) gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), id1, gy, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
+            const float v = fmaf(zhv, gv[t], ev[t]), gt = fmaf(zhg, gg[t], eg[t]);
+            const float sg = cld_sigmoid(gt);
+            const float gyr = cok[t] ? gy[r] : 0.f;
+            a_ds[t] = fmaf(gyr, v * sg, a_ds[t]);
+            const float dg = gyr * sc[t];
+            const float dv = dg * sg, dgt = dg * v * sg * (1.f - sg);
+            a_gbv[t] += dv;  a_gwv[t] = fmaf(dv, zhv, a_gwv[t]);
+            a_gbg[t] += dgt; a_gwg[t] = fmaf(dgt, zhg, a_gwg[t]);
+            const uint32_t pk = rfx_cvt_pk_bf16(dv * gv[t], dgt * gg[t]);
+            const float dzv = __uint_as_float(pk << 16), dzg = __uint_as_float(pk & 0xffff0000u);
+            s1 += dzv + dzg;
+            s2 = fmaf(dzv, zhv, fmaf(dzg, zhg, s2));
+            if (cok[t]) {
+              const int ro = ((r & 3) + 8 * (r >> 2)) * RSZ;
+              *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)pk;
+              *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)(pk >> 16);
+            }
+          }
+        } else if (cok[t]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = ((r & 3) + 8 * (r >> 2)) * RSZ;
+            const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
+            const float dzv = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro) << 16);
+            const float dzg = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + 2 * C) << 16);
+            *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)rfx_bf16_bits(rs2 * (dzv - m1 - zhv * m2));
+            *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)rfx_bf16_bits(rs2 * (dzg - m1 - zhg * m2));
+          }
+        }
+      }
+      if (PASS == 2) {
+        f32x16 dat, htt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dat[r] = htt[r] = 0.f;
+#pragma unroll
+        for (int kz = 0; kz < KZ; ++kz)
+          dat = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(zsub + l31 * RSZ + (16 * kz + 8 * half) * 2),
+                                                         cld_ld16(cld_smem + O_W2D + kz * 1024 + lane * 16), dat, 0, 0, 0);
+        htt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(hsub + l31 * RSH + 16 * half), id0, htt, 0, 0, 0);
+        if (KH > 1) htt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(hsub + l31 * RSH + 32 + 16 * half), id1, htt, 0, 0, 0);
+        if (l31 < HP) {
+          unsigned char* hb = dhsub + prow * RSH + l31 * 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float hh = (htt[r] - mu1) * rs1;
+            const float dhn = hok ? dat[r] * rfx_gelu_grad(fmaf(hh, g1, e1)) : 0.f;
+            a_g1b += dhn;
+            a_g1w = fmaf(dhn, hh, a_g1w);
+            const uint32_t pk = rfx_cvt_pk_bf16(dhn * g1, 0.f);                              // d(hhat), parked
+            const float dhh = __uint_as_float(pk << 16);
+            s1 += dhh;
+            s2 = fmaf(dhh, hh, s2);
+            *reinterpret_cast<uint16_t*>(hb + ((r & 3) + 8 * (r >> 2)) * RSH) = (uint16_t)pk;
+          }
+        }
+      }
+      CL_LGKM0();
+      __builtin_amdgcn_wave_barrier();
+      {
+        unsigned char* o = reinterpret_cast<unsigned char*>(d.dz) + (int64_t)s * (CLD_T * RSZ) + p0 * RSZ + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 2 * KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(zsub + i * 1024 + lane * 16);
+        if (PASS == 2) {
+          o = reinterpret_cast<unsigned char*>(d.dh) + (int64_t)s * (CLD_T * RSH) + p0 * RSH + lane * 16;
+#pragma unroll
+          for (int i = 0; i < KH; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = *reinterpret_cast<const uint4*>(dhsub + i * 1024 + lane * 16);
+        }
+      }
+      CL_LGKM0();
+    }
+    cld_block_sum2<NW>(s1, s2, red, wave, lane);
+    if (tid == 0) *reinterpret_cast<float2*>(d.tsum + (int64_t)s * 2) = make_float2(s1, s2);
+  }
+
+  // ---- parameter-gradient sums of this workgroup (pass 1: LayerScale / GroupNorm-2, pass 2: GroupNorm-1), as in the one-pass kernel
+  __syncthreads();
+  float* acc = reinterpret_cast<float*>(cld_smem);
+  constexpr int NQ = 5 * NTV + 2;
+#pragma unroll
+  for (int t = 0; t < NTV; ++t) {
+    acc[(wave * NQ + 5 * t + 0) * 64 + lane] = a_ds[t];
+    acc[(wave * NQ + 5 * t + 1) * 64 + lane] = a_gwv[t];
+    acc[(wave * NQ + 5 * t + 2) * 64 + lane] = a_gwg[t];
+    acc[(wave * NQ + 5 * t + 3) * 64 + lane] = a_gbv[t];
+    acc[(wave * NQ + 5 * t + 4) * 64 + lane] = a_gbg[t];
+  }
+  acc[(wave * NQ + 5 * NTV) * 64 + lane] = a_g1w;
+  acc[(wave * NQ + 5 * NTV + 1) * 64 + lane] = a_g1b;
+  __syncthreads();
+  float* prow_out = d.partial + (int64_t)blockIdx.x * (5 * C + 2 * H);
+  const int i_lo = PASS == 1 ? 0 : 5 * C, i_hi = PASS == 1 ? 5 * C : 5 * C + 2 * H;
+  for (int i = i_lo + tid; i < i_hi; i += 256) {
+    int q, n;
+    if (i < C) { q = 5 * (i >> 5) + 0; n = i & 31; }
+    else if (i < 2 * C) { const int c = i - C; q = 5 * (c >> 5) + 1; n = c & 31; }
+    else if (i < 3 * C) { const int c = i - 2 * C; q = 5 * (c >> 5) + 2; n = c & 31; }
+    else if (i < 4 * C) { const int c = i - 3 * C; q = 5 * (c >> 5) + 3; n = c & 31; }
+    else if (i < 5 * C) { const int c = i - 4 * C; q = 5 * (c >> 5) + 4; n = c & 31; }
+    else if (i < 5 * C + H) { q = 5 * NTV; n = i - 5 * C; }
+    else { q = 5 * NTV + 1; n = i - 5 * C - H; }
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += acc[(w * NQ + q) * 64 + n] + acc[(w * NQ + q) * 64 + 32 + n];
+    prow_out[i] = sum;
+  }
+}
+
+// per-sample means of the tile sums of a backward pass: sums[sample][2 which + {0, 1}] = (sum a, sum b) / n, fixed order
+__global__ __launch_bounds__(256) void cl_dconv_means_kernel(const float* __restrict__ tsum, int nsamp, int TPS, double inv_n, int which,
+                                                             float* __restrict__ sums) {
+  const int smp = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (smp >= nsamp) return;
+  double a = 0.0, b = 0.0;
+  for (int t = l; t < TPS; t += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(tsum + ((int64_t)smp * TPS + t) * 2);
+    a += v.x; b += v.y;
+  }
+  a = rfx_wave_sum_d(a); b = rfx_wave_sum_d(b);
+  if (l == 0) {
+    sums[(int64_t)smp * 4 + 2 * which] = (float)(a * inv_n);
+    sums[(int64_t)smp * 4 + 2 * which + 1] = (float)(b * inv_n);
+  }
+}
+
+// pass B3: dh = rstd1 (d(hhat) - mean(d(hhat)) - hhat mean(d(hhat) hhat)) in place over the parked values; pad channels stay 0
+__global__ __launch_bounds__(256) void cl_dconv_dh_kernel(uint16_t* __restrict__ dh, const uint16_t* __restrict__ hpre, const float* __restrict__ stats,
+                                                          const float* __restrict__ sums, int64_t npos, int HP, int H, int64_t pos_per_sample) {
+  const int g8 = HP / 8;
+  const int64_t total = npos * g8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / g8;
+    const int c0 = (int)(i - p * g8) * 8;
+    const int64_t smp = p / pos_per_sample;
+    const float mu1 = stats[smp * 4], rs1 = stats[smp * 4 + 1], m1 = sums[smp * 4 + 2], m2 = sums[smp * 4 + 3];
+    float dv[8], hv[8], o[8];
+    cl_unpack8(*reinterpret_cast<const uint4*>(dh + i * 8), dv);
+    cl_unpack8(*reinterpret_cast<const uint4*>(hpre + i * 8), hv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (c0 + e < H) ? rs1 * (dv[e] - m1 - (hv[e] - mu1) * rs1 * m2) : 0.f;
+    *reinterpret_cast<uint4*>(dh + i * 8) = cl_pack8(o);
+  }
+}
+
 // out[i] = sum over workgroups of partial[g][i], one wave per output, fixed order
 __global__ __launch_bounds__(256) void cl_dconv_pgrad_kernel(const float* __restrict__ partial, int n, int G, float* __restrict__ out) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
@@ -535,21 +825,68 @@ __global__ __launch_bounds__(256) void cl_dconv_pgrad_kernel(const float* __rest
   if (l == 0) out[i] = s;
 }
 
-template <int C, int H>
-static int cld_launch(const rfx_cl_dconv_desc& d, bool bwd, hipStream_t st) {
+// statistics of multi-tile samples: one wave per sample adds the TPS tile sums in a fixed order (double), writes (mean, rstd) into
+// fields (2 which, 2 which + 1) of stats[sample]
+__global__ __launch_bounds__(256) void cl_dconv_stats_kernel(const float* __restrict__ part, int nsamp, int TPS, double inv_n, float eps, int which,
+                                                             float* __restrict__ stats) {
+  const int smp = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (smp >= nsamp) return;
+  double a = 0.0, b = 0.0;
+  for (int t = l; t < TPS; t += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)smp * TPS + t) * 2);
+    a += v.x; b += v.y;
+  }
+  a = rfx_wave_sum_d(a); b = rfx_wave_sum_d(b);
+  if (l == 0) {
+    const double mu = a * inv_n, var = b * inv_n - mu * mu;
+    stats[(int64_t)smp * 4 + 2 * which] = (float)mu;
+    stats[(int64_t)smp * 4 + 2 * which + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+  }
+}
+
+template <int C, int H, int PH>
+static int cld_launch_fwd(const rfx_cl_dconv_desc& d, hipStream_t st) {
   using Cfg = CldCfg<C, H>;
-  static bool attr[2] = {false, false};
-  const int lds = bwd ? Cfg::B_LDS : Cfg::F_LDS;
-  const void* fn = bwd ? reinterpret_cast<const void*>(&cl_dconv_bwd_kernel<C, H>) : reinterpret_cast<const void*>(&cl_dconv_fwd_kernel<C, H>);
-  if (!attr[bwd]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
-    attr[bwd] = true;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_dconv_fwd_kernel<C, H, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::F_LDS) !=
+        hipSuccess)
+      return -3;
+    attr = true;
   }
   ClDconvK k;
   k.d = d;
-  const int grid = d.S < d.grid ? d.S : d.grid;
-  if (bwd) hipLaunchKernelGGL((cl_dconv_bwd_kernel<C, H>), dim3(grid), dim3(256), lds, st, k);
-  else hipLaunchKernelGGL((cl_dconv_fwd_kernel<C, H>), dim3(grid), dim3(512), lds, st, k);
+  hipLaunchKernelGGL((cl_dconv_fwd_kernel<C, H, PH>), dim3(d.S < d.grid ? d.S : d.grid), dim3(512), Cfg::F_LDS, st, k);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int C, int H>
+static int cld_forward(const rfx_cl_dconv_desc& d, hipStream_t st) {
+  if (d.TPS <= 1) return cld_launch_fwd<C, H, 0>(d, st);
+  const int nsamp = d.S / d.TPS;
+  int rc = cld_launch_fwd<C, H, 1>(d, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cl_dconv_stats_kernel, dim3((nsamp + 3) / 4), dim3(256), 0, st, d.partial, nsamp, d.TPS, 1.0 / ((double)H * CLD_T * d.TPS), d.eps, 0, d.stats);
+  rc = cld_launch_fwd<C, H, 2>(d, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cl_dconv_stats_kernel, dim3((nsamp + 3) / 4), dim3(256), 0, st, d.partial, nsamp, d.TPS, 1.0 / ((double)2 * C * CLD_T * d.TPS), d.eps, 1, d.stats);
+  return cld_launch_fwd<C, H, 3>(d, st);
+}
+
+template <int C, int H>
+static int cld_launch(const rfx_cl_dconv_desc& d, bool bwd, hipStream_t st) {
+  using Cfg = CldCfg<C, H>;
+  static bool attr = false;
+  if (!bwd) return cld_forward<C, H>(d, st);
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_dconv_bwd_kernel<C, H>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::B_LDS) != hipSuccess)
+      return -3;
+    attr = true;
+  }
+  ClDconvK k;
+  k.d = d;
+  hipLaunchKernelGGL((cl_dconv_bwd_kernel<C, H>), dim3(d.S < d.grid ? d.S : d.grid), dim3(256), Cfg::B_LDS, st, k);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -560,10 +897,8 @@ static bool cld_common_ok(const rfx_cl_dconv_desc* d) {
 }
 
 extern "C" int rfx_cl_dconv_ok(int32_t C, int32_t H, int32_t T, int32_t backward) {
-  if (T != CLD_T || H * 4 != C) return 0;
-  if (C == 48) return 1;
-  if (C == 96) return backward ? 0 : 1;
-  return 0;
+  if (T <= 0 || T % CLD_T || H * 4 != C) return 0;          // T: positions per sample (a multiple of the 256-position tile)
+  return C == 48 || C == 96;
 }
 
 extern "C" int rfx_cl_dconv_fwd(const rfx_cl_dconv_desc* dp, void* stream) {
@@ -571,18 +906,65 @@ extern "C" int rfx_cl_dconv_fwd(const rfx_cl_dconv_desc* dp, void* stream) {
   rfx_cl_dconv_desc d = *dp;
   d.x_or_gy_ok = 1;
   if (!cld_common_ok(&d) || !rfx_cl_dconv_ok(d.C, d.H, CLD_T, 0)) return -1;
-  if ((d.a == nullptr) != (d.hpre == nullptr) || (d.a == nullptr) != (d.stats == nullptr)) return -1;
+  if (d.TPS < 1 || d.S % d.TPS) return -1;
+  if ((d.a == nullptr) != (d.hpre == nullptr)) return -1;
+  if (d.TPS == 1 ? (d.a == nullptr) != (d.stats == nullptr) : (!d.stats || !d.partial)) return -1;
   if (d.C == 48) return cld_launch<48, 12>(d, false, (hipStream_t)stream);
   return cld_launch<96, 24>(d, false, (hipStream_t)stream);
 }
 
+template <int C, int H, int PASS>
+static int cld_launch_bwdp(const rfx_cl_dconv_desc& d, hipStream_t st) {
+  using Cfg = CldCfg<C, H>;
+  constexpr int lds = 4 * 32 * (Cfg::RS + 3 * Cfg::RSH + Cfg::RSZ) + Cfg::KH * Cfg::NT2 * 1024 + (2 * C / 16) * 1024 + 512;
+  static_assert(lds <= 160 * 1024 && lds >= 4 * (5 * Cfg::NTV + 2) * 256, "");
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_dconv_bwdp_kernel<C, H, PASS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return -3;
+    attr = true;
+  }
+  ClDconvK k;
+  k.d = d;
+  hipLaunchKernelGGL((cl_dconv_bwdp_kernel<C, H, PASS>), dim3(d.S < d.grid ? d.S : d.grid), dim3(256), lds, st, k);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward in passes (see cl_dconv_bwdp_kernel); leaves dz and dh final, the parameter partials in d.partial; dx is the caller's
+// (cl_conv: gy + transposed 3-tap convolution of dh)
+template <int C, int H>
+static int cld_backward_passes(const rfx_cl_dconv_desc& d, hipStream_t st) {
+  const int nsamp = d.S / d.TPS;
+  int rc = cld_launch_bwdp<C, H, 1>(d, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cl_dconv_means_kernel, dim3((nsamp + 3) / 4), dim3(256), 0, st, d.tsum, nsamp, d.TPS, 1.0 / ((double)2 * C * CLD_T * d.TPS), 0, d.sums);
+  rc = cld_launch_bwdp<C, H, 2>(d, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cl_dconv_means_kernel, dim3((nsamp + 3) / 4), dim3(256), 0, st, d.tsum, nsamp, d.TPS, 1.0 / ((double)H * CLD_T * d.TPS), 1, d.sums);
+  const int64_t npos = (int64_t)d.S * CLD_T;
+  constexpr int HP = CldCfg<C, H>::HP;
+  const int64_t tot = npos * (HP / 8);
+  hipLaunchKernelGGL(cl_dconv_dh_kernel, dim3((unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192)), dim3(256), 0, st,
+                     reinterpret_cast<uint16_t*>(d.dh), reinterpret_cast<const uint16_t*>(d.hpre), d.stats, d.sums, npos, HP, H, (int64_t)d.TPS * CLD_T);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int rfx_cl_dconv_bwd(const rfx_cl_dconv_desc* dp, float* pgrad, void* stream) {
-  if (!dp || !dp->gy || !dp->y || !dp->a || !dp->hpre || !dp->stats || !dp->dz || !dp->dh || !dp->w2dp || !dp->w1dp || !dp->partial || !pgrad)
+  if (!dp || !dp->gy || !dp->a || !dp->hpre || !dp->stats || !dp->dz || !dp->dh || !dp->w2dp || !dp->partial || !pgrad)
     return -1;
   rfx_cl_dconv_desc d = *dp;
   d.x_or_gy_ok = 1;
-  if (!cld_common_ok(&d) || !rfx_cl_dconv_ok(d.C, d.H, CLD_T, 1)) return -1;
-  const int rc = cld_launch<48, 12>(d, true, (hipStream_t)stream);
+  if (!cld_common_ok(&d) || !rfx_cl_dconv_ok(d.C, d.H, CLD_T, 1) || d.TPS < 1 || d.S % d.TPS) return -1;
+  int rc;
+  if (d.TPS > 1 || d.C != 48) {                       // passes: the caller computes dx (y unused)
+    if (!d.tsum || !d.sums) return -1;
+    rc = d.C == 48 ? cld_backward_passes<48, 12>(d, (hipStream_t)stream) : cld_backward_passes<96, 24>(d, (hipStream_t)stream);
+  } else {
+    if (!d.y || !d.w1dp) return -1;
+    rc = cld_launch<48, 12>(d, true, (hipStream_t)stream);
+  }
   if (rc) return rc;
   const int n = 5 * d.C + 2 * d.H, G = d.S < d.grid ? d.S : d.grid;
   hipLaunchKernelGGL(cl_dconv_pgrad_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, d.partial, n, G, pgrad);

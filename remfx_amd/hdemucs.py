@@ -26,7 +26,8 @@ from . import clchain, cldconv, lstm, nnops, ops, stft
 CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
 CL_TIME = os.environ.get("RFX_CL_TIME", "1") != "0"         # ... and the time branch's norm-free layers (folded-view forms, clast.py)
 CL_ENDS = os.environ.get("RFX_CL_ENDS", "1") != "0"         # ... and the 1 - 2 channel convolutions at the network's ends as im2col GEMMs
-CL_DCONV = os.environ.get("RFX_CL_DCONV", "1") != "0"       # ... and their DConv branches on the fused channels-last kernels (cldconv.py)
+CL_DCONV = os.environ.get("RFX_CL_DCONV", "1") != "0"
+CL_TIME_DCONV = os.environ.get("RFX_CL_TIME_DCONV", "1") != "0"    # ... the time branch's too (whole-clip GroupNorm: the kernels run in passes)       # ... and their DConv branches on the fused channels-last kernels (cldconv.py)
 
 
 class _ScaledEmbedding(nn.Module):
@@ -117,13 +118,14 @@ class _DConv(nn.Module):
             self.layers.append(nn.Sequential(*mods))
             self.spec.append((dil, dil * (kernel_size // 2), lstm, attn))
 
-    def cl_ok(self):
-        """The fused channels-last kernels (csrc/cl_dconv.hip) take every depth-layer of this branch, forward and backward."""
+    def cl_ok(self, positions=256):
+        """The fused channels-last kernels (csrc/cl_dconv.hip) take every depth-layer of this branch, forward and backward, for samples
+        of `positions` positions (256: a frequency row; the time branch: a whole clip, in 256-position tiles)."""
         for seq, (dil, pad, lstm, attn) in zip(self.layers, self.spec):
             m = list(seq)
             if lstm or attn or m[0].kernel_size[0] != 3 or dil not in (1, 2) or m[1].eps != m[4].eps or m[1].num_groups != 1:
                 return False
-            if not cldconv.supported(m[0].in_channels, m[0].out_channels, True):
+            if not cldconv.supported(m[0].in_channels, m[0].out_channels, True, positions):
                 return False
         return True
 
@@ -470,11 +472,16 @@ class HDemucs(nn.Module):
                 lengths_t.append(len_t)
                 len_t = len_t // 4
                 tenc = self.time_encoder[idx]
+                tdcl = CL_DCONV and CL_TIME_DCONV and tenc.dconv.cl_ok(len_t)      # len_t: this layer's clip length after its convolution
                 if idx == 0:
-                    samp_t = tenc.head_t(xt)
-                dt_ = tenc.dconv(samp_t)
+                    if tdcl and CL_ENDS and xt.shape[1] == 1 and not xt.requires_grad:
+                        samp_t = clchain.head_conv(xt.unsqueeze(2), tenc.conv, along_b=True)     # (B, 1, L / 4, C) channels-last
+                    else:
+                        samp_t, tdcl = tenc.head_t(xt), False
+                dt_ = tenc.dconv.forward_cl(samp_t) if tdcl else tenc.dconv(samp_t)
                 if idx < Lt - 1:
-                    et, samp_t = clchain.enc_mid(dt_, tenc.rewrite, self.time_encoder[idx + 1].conv, None, B, fold=True)
+                    nxt_t = CL_DCONV and CL_TIME_DCONV and self.time_encoder[idx + 1].dconv.cl_ok(len_t // 4)
+                    et, samp_t = clchain.enc_mid(dt_, tenc.rewrite, self.time_encoder[idx + 1].conv, None, B, y_cl=nxt_t, fold=True)
                 else:
                     et, xt = clchain.enc_tail(dt_, tenc.rewrite, B)
                     xt = xt.squeeze(2)

@@ -57,6 +57,15 @@ def main(path, steps, marker="adamw"):
     for nm in set(alone) | set(shared):
         key = nm.replace("void ", "").split("(")[0][:60]
         fam[key][0] += alone.get(nm, 0.0); fam[key][1] += shared.get(nm, 0.0)
+    # per kernel: launches in the window and the spread of their durations (a launch that waits for a concurrent kernel's workgroups
+    # to drain shows up as a long maximum)
+    dur = defaultdict(list)
+    for s_, e_, n_, q_ in win:
+        dur[n_.replace("void ", "").split("(")[0][:60]].append((e_ - s_) / 1e3)
+    print("| kernel | launches | min us | median us | max us |\n|---|---|---|---|---|")
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:30]:
+        v = sorted(v)
+        print(f"| `{k}` | {len(v) // nst} | {v[0]:.0f} | {v[len(v) // 2]:.0f} | {v[-1]:.0f} |")
     print("| kernel | alone ms/step | overlapped ms/step |\n|---|---|---|")
     for k, (a, sh) in sorted(fam.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:45]:
         print(f"| `{k}` | {a / nst / 1e6:.2f} | {sh / nst / 1e6:.2f} |")

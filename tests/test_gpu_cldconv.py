@@ -48,8 +48,9 @@ def _run_cl(mod, x, gy, Bn, A):
         ops.set_gemm_precision(prev)
 
 
-@pytest.mark.parametrize("Cc,Bn,A", [(48, 2, 3), (48, 3, 130)])
-def test_cl_dconv_vs_channel_major(Cc, Bn, A):
+@pytest.mark.parametrize("Cc,Bn,A,T", [(48, 2, 3, 256), (48, 3, 130, 256), (96, 2, 3, 256), (96, 1, 70, 256), (48, 3, 1, 1024), (96, 2, 1, 2048),
+                                        (48, 2, 2, 512)])
+def test_cl_dconv_vs_channel_major(Cc, Bn, A, T):
     from remfx_amd.hdemucs import _DConv
     torch.manual_seed(0)
     mod = _DConv(Cc, depth=2, init=0.3).to(DEV)
@@ -61,9 +62,9 @@ def test_cl_dconv_vs_channel_major(Cc, Bn, A):
                 p.add_(torch.randn_like(p) * 0.2)
     g = torch.Generator().manual_seed(1)
     S = Bn * A
-    x = torch.randn(S, Cc, 256, generator=g).to(DEV)
+    x = torch.randn(S, Cc, T, generator=g).to(DEV)
     x = x.to(torch.bfloat16).float()                                        # both paths see the same (bf16-representable) input
-    gy = torch.randn(S, Cc, 256, generator=g).to(DEV).to(torch.bfloat16).float()
+    gy = torch.randn(S, Cc, T, generator=g).to(DEV).to(torch.bfloat16).float()
     y32, dx32, g32 = _run_cm(mod, x, gy, "f32")
     y16, dx16, g16 = _run_cm(mod, x, gy, "bf16")
     ycl, dxcl, gcl = _run_cl(mod, x, gy, Bn, A)
