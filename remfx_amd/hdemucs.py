@@ -26,6 +26,20 @@ from . import clchain, cldconv, lstm, nnops, ops, stft
 CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
 CL_TIME = os.environ.get("RFX_CL_TIME", "1") != "0"         # ... and the time branch's norm-free layers (folded-view forms, clast.py)
 CL_ENDS = os.environ.get("RFX_CL_ENDS", "1") != "0"         # ... and the 1 - 2 channel convolutions at the network's ends as im2col GEMMs
+TWO_STREAMS = os.environ.get("RFX_TWO_STREAMS", "0") != "0"   # the time branch on a second high-priority stream (its layers 0-3 and the
+                                                               # frequency layers 0-3 are independent between the input and layer 4)
+_TIME_STREAMS = {}
+
+
+def _time_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _TIME_STREAMS.get(idx)
+    if st is None:
+        st = torch.cuda.Stream(device=idx, priority=-1)
+        _TIME_STREAMS[idx] = st
+    return st
+
+
 CL_DCONV = os.environ.get("RFX_CL_DCONV", "1") != "0"
 CL_TIME_DCONV = os.environ.get("RFX_CL_TIME_DCONV", "1") != "0"    # ... the time branch's too (whole-clip GroupNorm: the kernels run in passes)       # ... and their DConv branches on the fused channels-last kernels (cldconv.py)
 
@@ -442,6 +456,43 @@ class HDemucs(nn.Module):
                 return 0
         return Lc
 
+    def _time_encoder_step(self, idx, Lt, B, saved_t, lengths_t, xt, samp_t, len_t):
+        """Layer idx of the time encoder (on whatever stream is current).  Returns (xt, samp_t, len_t, inject): inject = the tensor the
+        frequency branch's layer reads (the empty time layer's output), else None."""
+        inject = None
+        tenc = self.time_encoder[idx]
+        if idx < Lt:
+            # time branch on the channels-last trunk: as the frequency layers, with A = 1 and the stride along positions
+            lengths_t.append(len_t)
+            len_t = len_t // 4
+            tdcl = CL_DCONV and CL_TIME_DCONV and tenc.dconv.cl_ok(len_t)      # len_t: this layer's clip length after its convolution
+            if idx == 0:
+                if tdcl and CL_ENDS and xt.shape[1] == 1 and not xt.requires_grad:
+                    samp_t = clchain.head_conv(xt.unsqueeze(2), tenc.conv, along_b=True)     # (B, 1, L / 4, C) channels-last
+                else:
+                    samp_t, tdcl = tenc.head_t(xt), False
+            dt_ = tenc.dconv.forward_cl(samp_t) if tdcl else tenc.dconv(samp_t)
+            if idx < Lt - 1:
+                nxt_t = CL_DCONV and CL_TIME_DCONV and self.time_encoder[idx + 1].dconv.cl_ok(len_t // 4)
+                et, samp_t = clchain.enc_mid(dt_, tenc.rewrite, self.time_encoder[idx + 1].conv, None, B, y_cl=nxt_t, fold=True)
+            else:
+                et, xt = clchain.enc_tail(dt_, tenc.rewrite, B)
+                xt = xt.squeeze(2)
+            saved_t.append(et)
+        else:
+            lengths_t.append(xt.shape[-1])
+            if saved_t and saved_t[-1] is xt:          # xt is the previous layer's output = a skip connection: see fork
+                xt, alias = tenc(xt, fork=True)
+                if alias is not None:
+                    saved_t[-1] = alias
+            else:
+                xt = tenc(xt)
+            if not tenc.empty:
+                saved_t.append(xt)
+            else:
+                inject = xt
+        return xt, samp_t, len_t, inject
+
     def forward(self, input):
         if input.ndim != 3 or input.shape[1] != self.audio_channels:
             raise ValueError(f"expected (batch, {self.audio_channels}, frames), got {tuple(input.shape)}")
@@ -464,41 +515,22 @@ class HDemucs(nn.Module):
         Lt = self._cl_layers_time(length, input.device, Lc)
         samp = samp_t = None
         len_t = length
+        import contextlib
+        two = TWO_STREAMS and input.is_cuda and Lt > 0
+        if two:
+            main_s, time_s = torch.cuda.current_stream(), _time_stream(input.device)
+            time_s.wait_stream(main_s)
+            xt.record_stream(time_s)
+        tctx = (lambda: torch.cuda.stream(time_s)) if two else contextlib.nullcontext
         for idx, encode in enumerate(self.freq_encoder):
             lengths.append(x.shape[-1])
             inject = None
-            if idx < Lt:
-                # time branch on the channels-last trunk: as the frequency layers below, with A = 1 and the stride along positions
-                lengths_t.append(len_t)
-                len_t = len_t // 4
-                tenc = self.time_encoder[idx]
-                tdcl = CL_DCONV and CL_TIME_DCONV and tenc.dconv.cl_ok(len_t)      # len_t: this layer's clip length after its convolution
-                if idx == 0:
-                    if tdcl and CL_ENDS and xt.shape[1] == 1 and not xt.requires_grad:
-                        samp_t = clchain.head_conv(xt.unsqueeze(2), tenc.conv, along_b=True)     # (B, 1, L / 4, C) channels-last
-                    else:
-                        samp_t, tdcl = tenc.head_t(xt), False
-                dt_ = tenc.dconv.forward_cl(samp_t) if tdcl else tenc.dconv(samp_t)
-                if idx < Lt - 1:
-                    nxt_t = CL_DCONV and CL_TIME_DCONV and self.time_encoder[idx + 1].dconv.cl_ok(len_t // 4)
-                    et, samp_t = clchain.enc_mid(dt_, tenc.rewrite, self.time_encoder[idx + 1].conv, None, B, y_cl=nxt_t, fold=True)
-                else:
-                    et, xt = clchain.enc_tail(dt_, tenc.rewrite, B)
-                    xt = xt.squeeze(2)
-                saved_t.append(et)
-            elif idx < len(self.time_encoder):
-                lengths_t.append(xt.shape[-1])
-                tenc = self.time_encoder[idx]
-                if saved_t and saved_t[-1] is xt:          # xt is the previous layer's output = a skip connection: see fork
-                    xt, alias = tenc(xt, fork=True)
-                    if alias is not None:
-                        saved_t[-1] = alias
-                else:
-                    xt = tenc(xt)
-                if not tenc.empty:
-                    saved_t.append(xt)
-                else:
-                    inject = xt
+            if idx < len(self.time_encoder):
+                with tctx():
+                    xt, samp_t, len_t, inject = self._time_encoder_step(idx, Lt, B, saved_t, lengths_t, xt, samp_t, len_t)
+                if two and inject is not None:                 # the merge: layer 4 of the frequency branch reads the time branch
+                    main_s.wait_stream(time_s)
+                    inject.record_stream(main_s)
             if idx < Lc:
                 # channels-last trunk: the DConv branch on (B * Fr, C, T) samples, everything between two branches in one node
                 dcl = CL_DCONV and encode.dconv.cl_ok()      # this layer's DConv branch runs on channels-last samples
@@ -548,29 +580,36 @@ class HDemucs(nn.Module):
                 skip = saved.pop(-1)
                 x, pre = decode(x, skip, lengths.pop(-1), next_skip=saved[-1] if (saved and j != Lc) else None, skip_added=fadd)
                 fadd = decode.fused_next_add
-            if idx >= offset and j < Lt:
-                length_t = lengths_t.pop(-1)
-                if j == Lt - 1:
-                    skips_t = [saved_t.pop(-1) for _ in range(Lt)]
-                    lastt = self.time_decoder[-1]
-                    if CL_ENDS and lastt.last and lastt.conv_tr.out_channels <= 2:
-                        xt = clchain.freq_decoder(xt.unsqueeze(2), skips_t, list(self.time_decoder[idx - offset:]), fold=True, tail=True).squeeze(2)
+            if idx >= offset and two and (self.time_decoder[idx - offset].empty):
+                time_s.wait_stream(main_s)                     # the empty time layer reads the frequency branch's layer-4 tensor
+                pre.record_stream(time_s)
+            with tctx():
+                if idx >= offset and j < Lt:
+                    length_t = lengths_t.pop(-1)
+                    if j == Lt - 1:
+                        skips_t = [saved_t.pop(-1) for _ in range(Lt)]
+                        lastt = self.time_decoder[-1]
+                        if CL_ENDS and lastt.last and lastt.conv_tr.out_channels <= 2:
+                            xt = clchain.freq_decoder(xt.unsqueeze(2), skips_t, list(self.time_decoder[idx - offset:]), fold=True, tail=True).squeeze(2)
+                        else:
+                            yt0 = clchain.freq_decoder(xt.unsqueeze(2), skips_t, list(self.time_decoder[idx - offset:]), fold=True)
+                            xt = ops.conv_transpose1d(yt0.squeeze(2), lastt.conv_tr.weight, lastt.conv_tr.bias, lastt.stride, 1, lastt.pad,
+                                                      lengths_t[0] if lengths_t else length_t)
+                            if not lastt.last:
+                                xt = nnops.gelu(xt)
+                elif idx >= offset:
+                    tdec = self.time_decoder[idx - offset]
+                    length_t = lengths_t.pop(-1)
+                    if tdec.empty:
+                        xt, _ = tdec(pre[:, :, 0], None, length_t)
+                        tadd = False
                     else:
-                        yt0 = clchain.freq_decoder(xt.unsqueeze(2), skips_t, list(self.time_decoder[idx - offset:]), fold=True)
-                        xt = ops.conv_transpose1d(yt0.squeeze(2), lastt.conv_tr.weight, lastt.conv_tr.bias, lastt.stride, 1, lastt.pad,
-                                                  lengths_t[0] if lengths_t else length_t)
-                        if not lastt.last:
-                            xt = nnops.gelu(xt)
-            elif idx >= offset:
-                tdec = self.time_decoder[idx - offset]
-                length_t = lengths_t.pop(-1)
-                if tdec.empty:
-                    xt, _ = tdec(pre[:, :, 0], None, length_t)
-                    tadd = False
-                else:
-                    skip_t = saved_t.pop(-1)
-                    xt, _ = tdec(xt, skip_t, length_t, next_skip=saved_t[-1] if saved_t else None, skip_added=tadd)
-                    tadd = tdec.fused_next_add
+                        skip_t = saved_t.pop(-1)
+                        xt, _ = tdec(xt, skip_t, length_t, next_skip=saved_t[-1] if saved_t else None, skip_added=tadd)
+                        tadd = tdec.fused_next_add
+        if two:
+            main_s.wait_stream(time_s)
+            xt.record_stream(main_s)
         S = len(self.sources)
         x = nnops.row_affine(x.reshape(B, -1), std, mean)          # S == 1 for RemFX: one (std, mean) per clip
         if S != 1:
