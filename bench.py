@@ -194,7 +194,11 @@ class KernelTimer:
                     pos = float(d.S) * 256
                     fl = 2.0 * pos * (3 * d.C * d.H + d.H * 2 * d.C) * (3 if bwd else 1)
                     by = pos * 2.0 * ((d.C + 2 * hp + d.C + 2 * d.C + hp) if bwd else (2 * d.C + (2 * hp if d.a else 0)))
-                    timer.launches.append((s, e, fl, by, f"cl_dconv_{'bwd' if bwd else 'fwd'}_kernel<{d.C}, {d.H}>"))
+                    passes = d.TPS > 1 or (bwd and d.C != 48)            # several kernels inside one bracket: no single rocprof name
+                    nm_k = (f"cl_dconv_bwdp_kernel<{d.C}, {d.H}, 1+2> (+ means, dh)" if (bwd and passes) else
+                            f"cl_dconv_bwd_kernel<{d.C}, {d.H}>" if bwd else
+                            f"cl_dconv_fwd_kernel<{d.C}, {d.H}, 1+2+3> (+ stats)" if passes else f"cl_dconv_fwd_kernel<{d.C}, {d.H}, 0>")
+                    timer.launches.append((s, e, fl, by, nm_k))
                     timer.desc.append({"M": 2 * d.C, "K": d.H, "N": d.S, "OA": 1, "OB": 256, "kernel": nm})
                     return rc
                 return timed_d
