@@ -24,6 +24,11 @@
 // per-unit integer division, a jump table for the counted wait, 48 scalar bias loads, 64-bit address arithmetic per stored group.
 #include "cl_common.h"
 
+// ablation builds (scripts/build_abl.py, dev only): 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue, 16 no unit barrier
+#ifndef RFX_CLC_DBG_BUILD
+#define RFX_CLC_DBG_BUILD 0
+#endif
+
 struct ClConvK {
   rfx_cl_conv_desc d;
   int32_t ptiles, chunk, MG, tpr;
@@ -161,7 +166,9 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
   uint32_t abase = (uint32_t)((r_lo * d.NCH * g.MG + mg) * Cfg::A_KB) * 1024u + lane * 16;
   const uint32_t a_step = (uint32_t)(g.MG * Cfg::A_KB) * 1024u;
 
+  constexpr int dbg = RFX_CLC_DBG_BUILD;
   auto issue_next = [&]() {
+    if (dbg & 1) { ++iu; return; }
     if (bload) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -220,16 +227,30 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         cl_bf16x8 bf[NT], af[RW];
+        if (dbg & 2) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) bf[t] = __builtin_bit_cast(cl_bf16x8, make_uint4(baddr[t][k], sa, sb, lane));
+#pragma unroll
+          for (int i = 0; i < RW; ++i) af[i] = __builtin_bit_cast(cl_bf16x8, make_uint4(afrag, sa + i, sb, lane));
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
           bf[t] = __builtin_bit_cast(cl_bf16x8, *reinterpret_cast<const uint4*>(bbuf + ks * Cfg::PLANE + baddr[t][k]));
 #pragma unroll
         for (int i = 0; i < RW; ++i)
           af[i] = __builtin_bit_cast(cl_bf16x8, *reinterpret_cast<const uint4*>(abuf + ((k * KS + ks) * MT + i) * 1024));
+        }
+        if (dbg & 4) {
+#pragma unroll
+          for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[i][t][0] += __builtin_bit_cast(float, (uint32_t)af[i][0] ^ (uint32_t)bf[t][1]);
+        } else {
 #pragma unroll
         for (int i = 0; i < RW; ++i)
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[t], acc[i][t], 0, 0, 0);
+        }
       }
   };
 
@@ -247,7 +268,7 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
       } else {
         if (left >= DA - 2) cl_wait_vm_c<(DA - 2) * Cfg::PA>(); else cl_wait_vm(left * Cfg::PA);
       }
-      __builtin_amdgcn_s_barrier();
+      if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (iu < nu) issue_next();                     // into the slot whose unit every wave finished before this barrier
       __builtin_amdgcn_sched_barrier(0);
@@ -258,6 +279,17 @@ __global__ __launch_bounds__(512, (RW * NT <= 3 ? 4 : 2)) void cl_conv_kernel(co
   }
   __builtin_amdgcn_s_barrier();                 // every wave is done reading the rings: their memory becomes the transpose tiles
 
+  if (dbg & 8) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][t][r];
+    if (sum == 12345.678f) reinterpret_cast<float*>(d.out0.p ? d.out0.p : d.out1.p)[tid] = sum;
+    return;
+  }
   // ---- epilogue
   unsigned char* ez = cl_smem + wave * Cfg::EPI_WAVE;            // [32 positions][32 RW rows] bf16, row stride EPI_RS
   unsigned char* ey = ez + 32 * Cfg::EPI_RS;                     // GLU: [32][16 RW] bf16, row stride EPI_RSY
@@ -493,6 +525,7 @@ extern "C" int rfx_cl_conv(const rfx_cl_conv_desc* dp, void* stream) {
   k.chunk = (k.ptiles + 7) / 8;
   k.MG = (d.M + d.BM - 1) / d.BM;
   k.in_bytes = (uint32_t)ext;
+
   const dim3 grid((unsigned)(8 * k.chunk * k.MG));
   hipStream_t s = (hipStream_t)stream;
   switch (d.BM) {
