@@ -143,11 +143,11 @@ class KernelTimer:
         # channels-last family (round 5): the same event bracket around clast.conv / clast.wgrad and the fused DConv launches
         from remfx_amd import clast, cldconv
 
-        def cl_conv_name(f, halo):
+        def cl_conv_name(f, halo, mode):                  # the rocprof name: <epilogue mode, RW, NT, WM, NTC, KS, DA, DB, HALO>
             rw, nt, wm = {192: (3, 2, 2), 96: (3, 1, 1), 64: (2, 1, 1), 32: (1, 1, 1)}[f.BM]
             mt = rw * wm
             db = (4 if mt >= 6 else 6) if (f.NTC == 3 and f.KS == 1) else ((3 if mt >= 6 else 4) if f.KS == 2 else 6)
-            return f"cl_conv_kernel<{rw}, {nt}, {wm}, {f.NTC}, {f.KS}, 2, {db}, {'true' if halo else 'false'}>"
+            return f"cl_conv_kernel<{clast.EPI[mode]}, {rw}, {nt}, {wm}, {f.NTC}, {f.KS}, 2, {db}, {'true' if halo else 'false'}>"
         orig_c, orig_cw = clast.conv, clast.wgrad
 
         def timed_c(form, apack, x, N, IA, IB, OA, mode, **kw):
@@ -160,7 +160,7 @@ class KernelTimer:
             fl = 2.0 * N * OA * IB * form.M * form.NTR * form.NTC * form.Cin
             by = 2.0 * (N * IA * IB * form.Cin + sum(t.numel() for t in (kw.get("out0"), kw.get("out1"), kw.get("aux0"), kw.get("res"))
                                                         if t is not None) + apack.numel())
-            timer.launches.append((s, e, fl, by, cl_conv_name(form, form.NTC > 1 or form.db0 != 0)))
+            timer.launches.append((s, e, fl, by, cl_conv_name(form, form.NTC > 1 or form.db0 != 0, mode)))
             timer.desc.append({"M": form.M, "K": form.NTR * form.NTC * form.Cin, "N": N, "OA": OA, "OB": IB, "kernel": "cl_conv", "mode": mode})
             return r
 

@@ -91,18 +91,18 @@ def dglu(g, zab):
 
 
 # ---- tile choice ----------------------------------------------------------------------------------------------------------------
-BM96_MAX_K = int(_os.environ.get("RFX_CL_BM96_K", "800"))    # 96-row tiles for layers whose reduction is at most this long (0: A/B off)
+BM96_NTC = _os.environ.get("RFX_CL_BM96_NTC", "0") != "0"   # 96-row tiles for every multi-column-tap layer (the first form of round 5)
+BM96_MAX_K = int(_os.environ.get("RFX_CL_BM96_K", "0"))    # 96-row tiles for layers whose reduction is at most this long (0: A/B off)
 
 
 def pick_bm(M, K=1 << 30, NTC=1):
-    """Rows per workgroup.  96-row tiles (48 accumulator registers, four waves per SIMD, two workgroups per CU: one workgroup's store
-    tail runs under the other's loads) for the multi-column-tap layers and for every layer with a short reduction -- the merged /
-    folded stride-4 forms and the 1 x 1 rewrites are HBM-class and spend their time in the store (same-box A/B at 64 clips, r05:
-    transposed convolution 96 -> 48 1.45 -> 0.82 ms, encoder input gradient + skip + GLU backward 1.68 -> 1.03 ms, 1 x 1 rewrite
-    96 -> 192 0.74 -> 0.42 ms, 3 x 3 rewrites 4 - 10 % faster); 192 rows (two wave rows of 96) for the long stride-4 reductions
-    (K >= 1536: 6 - 15 % faster there); else the smallest of 32 / 64 / 96 that holds M in the fewest tiles."""
+    """Rows per workgroup: 192 (two wave rows of 96) wherever M allows, else the smallest of 32 / 64 / 96 that holds M in the fewest
+    tiles.  History (same-box A/B at 64 clips, r05): while the kernel carried every epilogue mode it needed 256 registers on the
+    192-row tiles -- one workgroup per CU -- and 96-row tiles (two per CU: one's store tail under the other's loads) won for K <= 800
+    and for the multi-column-tap layers (-5.5 ms on the step).  Compiled per mode the 192-row tiles fit 128 registers, run two per CU
+    as well, and fetch every input slab once per 192 rows instead of once per 96: 107.6 -> 106.0 ms (RFX_CL_BM96_K=800 RFX_CL_BM96_NTC=1 restores the old rule)."""
     if M > 96:
-        if BM96_MAX_K and (K <= BM96_MAX_K or NTC > 1) and M % 96 == 0:
+        if ((BM96_MAX_K and K <= BM96_MAX_K) or (BM96_NTC and NTC > 1)) and M % 96 == 0:
             return 96
         return 192 if (M % 192 == 0 or M > 288) else 96
     if M > 64:

@@ -21,6 +21,13 @@
 // Determinism: every workgroup dumps its accumulators into its own workspace slot; rfx_cl_wgrad_reduce sums the slots in a fixed
 // order and scatters through a host-built index map into the weight (and bias: a column tile fed with ones) gradient.  No atomics.
 #include "cl_common.h"
+
+// ablation builds (scripts/build_abl.py cl_wgrad RFX_CLW_DBG_BUILD n, dev only): 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no barrier,
+// 16 no staggering of the two waves of a SIMD.  Compile-time: as run-time switches they put a select in front of every fragment read.
+#ifndef RFX_CLW_DBG_BUILD
+#define RFX_CLW_DBG_BUILD 0
+#endif
+#define CLW_DBG RFX_CLW_DBG_BUILD
 #include <stdlib.h>
 
 struct ClWgK {
@@ -30,7 +37,6 @@ struct ClWgK {
   int32_t NP, NQ, TP, PPW;            // P pieces, Q pieces per row, pieces per step, pieces per wave and step
   int32_t PSLOT, QROWB, QROWP, R, PD, PRE, HB;
   int32_t HN, NCG, bias_tile;
-  int32_t dbg;                        // ablation switches (RFX_CLW_DBG, dev only): 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no barrier
   uint32_t p_bytes, q_bytes;
 };
 
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
   __amdgpu_buffer_rsrc_t rs_q = cl_rsrc(reinterpret_cast<const uint16_t*>(d.q.p) + (int64_t)rs_n * d.q.ns, g.q_bytes);
   int iu = 0, wp = 0, ps_i = 0;                                 // issue side: next step, ring write row, P slot
   auto issue_next = [&]() {
-    if (g.dbg & 1) { advance(it_i); ++iu; return; }
+    if (CLW_DBG & 1) { advance(it_i); ++iu; return; }
     const int b0 = it_i.bq * PW;
     const bool real = it_i.pre == 0;
     if (it_i.n != rs_n) {
@@ -200,29 +206,29 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
   // all eight waves in the same phase nothing overlapped -- ablation builds, r05: 1.29 ms = skeleton 0.18 + DMA issue 0.29 + fragment
   // reads 0.25 + MFMA 0.58 for the 48 -> 96 3x3 layer, exactly additive.)  Both orders have issued groups 0 .. i + ahead - 1 when
   // they wait in step i, so the counted wait is the same.
-  const bool late = wave >= 4 && !(g.dbg & 16);
+  const bool late = wave >= 4 && !(CLW_DBG & 16);
   auto frags = [&](int ks, const unsigned char* pb, const unsigned char* const (&qb)[NT], cl_bf16x8 (&af)[RW], cl_bf16x8 (&bf)[NT], int i) {
 #pragma unroll
     for (int r = 0; r < RW; ++r)
-      af[r] = (g.dbg & 2) ? __builtin_bit_cast(cl_bf16x8, make_uint4(lane, r, ks, i)) : clw_frag(pb + ks * 16 * PROWB + r * 64, 4 * PROWB);
+      af[r] = (CLW_DBG & 2) ? __builtin_bit_cast(cl_bf16x8, make_uint4(lane, r, ks, i)) : clw_frag(pb + ks * 16 * PROWB + r * 64, 4 * PROWB);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (ones_wave && t == ones_t) {
         const clw_s16x8 one = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
         bf[t] = __builtin_bit_cast(cl_bf16x8, one);
       } else {
-        bf[t] = (g.dbg & 2) ? __builtin_bit_cast(cl_bf16x8, make_uint4(lane, t, ks, i)) : clw_frag(qb[t] + ks * 16 * g.QROWP, 4 * g.QROWP);
+        bf[t] = (CLW_DBG & 2) ? __builtin_bit_cast(cl_bf16x8, make_uint4(lane, t, ks, i)) : clw_frag(qb[t] + ks * 16 * g.QROWP, 4 * g.QROWP);
       }
     }
   };
   for (int i = 0; i < L; ++i) {
     const int left = L - 1 - i;
     clw_wait_vm((left < ahead - 1 ? left : ahead - 1) * g.PPW);
-    if (!(g.dbg & 8)) __builtin_amdgcn_s_barrier();
+    if (!(CLW_DBG & 8)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (!late && iu < L) issue_next();
     __builtin_amdgcn_sched_barrier(0);
-    if (it_c.pre == 0 && !(g.dbg & 4)) {
+    if (it_c.pre == 0 && !(CLW_DBG & 4)) {
       const unsigned char* pb = pbase_lds + ps_c * g.PSLOT + a0;
       const unsigned char* qb[NT];
 #pragma unroll
@@ -275,9 +281,6 @@ static int clw_geometry(const rfx_cl_wgrad_desc& d, ClWgK& k) {
   }
   if (hb > 8) return -1;
   k.d = d;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("RFX_CLW_DBG"); dbg = e ? atoi(e) : 0; }
-  k.dbg = dbg;
   k.HB = hb;
   k.nbq = d.B / d.PW;
   k.MTn = (d.M + 32 * d.RW - 1) / (32 * d.RW);
