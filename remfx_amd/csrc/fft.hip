@@ -27,6 +27,12 @@
 //     partial-line stores merge in one L2.
 #include "common.h"
 #include <math.h>
+#ifndef RFX_FFT_PAIR_OCC
+// waves per SIMD the pair-loss kernel is compiled for where three workgroups fit a CU's LDS (n_fft 2048 / 4096; n_fft 1024 needs
+// 53 KB): 3 = 168 registers + 44 spilled instead of 220, MRSTFT forward + backward at 64 clips 7.80 -> 7.23 ms (A/B:
+// scripts/build_abl.py fft RFX_FFT_PAIR_OCC 2, scripts/perf_loss.py)
+#define RFX_FFT_PAIR_OCC 3
+#endif
 #include <mutex>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -637,7 +643,7 @@ struct PairArgs {
 };
 
 template <int LOGN>
-__global__ __launch_bounds__(256, 2) void fft_pair_loss_kernel(const PairArgs a) {
+__global__ __launch_bounds__(256, (LOGN == 9 ? 2 : RFX_FFT_PAIR_OCC)) void fft_pair_loss_kernel(const PairArgs a) {
   typedef FftCfg<LOGN> K;
   constexpr int NC = K::NC, T = K::T, FB = K::FB, N = NC;
   constexpr int NIT = (K::NH * FB + 255) / 256;                 // epilogue items per thread
