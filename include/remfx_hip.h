@@ -649,6 +649,8 @@ typedef struct rfx_cl_dconv_desc {
                             * 2 floats per tile, required) */
   float* tsum; float* sums; /* backward in passes (TPS > 1 or C = 96): tile sums [S][2], per-sample means [S / TPS][4]; dz / dh come out final,
                             * dx is left to the caller (rfx_cl_conv: gy + the transposed 3-tap convolution of dh) */
+  float* pg_dst[5];        /* backward, optional (all five or none): where dscale[C], dgn2w[2C], dgn2b[2C], dgn1w[H], dgn1b[H] are ADDED
+                            * (the parameters' slices of a flat gradient buffer) instead of being written to pgrad */
 } rfx_cl_dconv_desc;
 int rfx_cl_dconv_ok(int32_t C, int32_t H, int32_t T, int32_t backward);
 int rfx_cl_dconv_fwd(const rfx_cl_dconv_desc* d, void* stream);

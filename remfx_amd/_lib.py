@@ -112,7 +112,7 @@ class ClConvDesc(C.Structure):
 class ClDconvDesc(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "gy", "y", "a", "hpre", "stats", "dz", "dh", "partial", "w1p", "w2p", "w2dp", "w1dp",
                                           "b1", "g1w", "g1b", "b2", "g2w", "g2b", "scale")] + \
-               [(n, C.c_int32) for n in ("S", "C", "H", "dil", "grid", "x_or_gy_ok")] + [("eps", C.c_float), ("TPS", C.c_int32), ("tsum", C.c_void_p), ("sums", C.c_void_p)]
+               [(n, C.c_int32) for n in ("S", "C", "H", "dil", "grid", "x_or_gy_ok")] + [("eps", C.c_float), ("TPS", C.c_int32), ("tsum", C.c_void_p), ("sums", C.c_void_p), ("pg_dst", C.c_void_p * 5)]
 
 
 class ClWgradDesc(C.Structure):

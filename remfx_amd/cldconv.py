@@ -163,7 +163,12 @@ class ClDconvLayerFn(torch.autograd.Function):
         dh = torch.empty((Bn, A, Tt, HP), device=dev, dtype=torch.bfloat16)
         npg = 5 * Cc + 2 * H
         partial = torch.empty((min(GRID, S), npg), device=dev, dtype=torch.float32)
-        pg = torch.empty(npg, device=dev, dtype=torch.float32)
+        # the five small gradients go straight into the parameters' slices of the flat gradient buffer when a GradSink is armed
+        # (autograd would add each returned tensor into .grad with a launch of its own)
+        sink = ops.SINK
+        tgt = [sink.lookup(p) for p in (scale, g2w, g2b, g1w, g1b)] if sink is not None else [None]
+        direct = all(t is not None for t in tgt)
+        pg = None if direct else torch.empty(npg, device=dev, dtype=torch.float32)
         d = _desc(Cc, H, dil, eps, S, b1, g1w, g1b, b2, g2w, g2b, scale)
         d.TPS = TPS
         d.gy, d.y, d.a, d.hpre, d.stats = gy.data_ptr(), dx.data_ptr(), a.data_ptr(), hpre.data_ptr(), stats.data_ptr()
@@ -176,15 +181,25 @@ class ClDconvLayerFn(torch.autograd.Function):
             d.tsum, d.sums = tsum.data_ptr(), sums.data_ptr()
         else:
             d.w1dp = clchain.packed(tb["w1dp"], w1).data_ptr()
-        check(_lib.lib().rfx_cl_dconv_bwd(C.byref(d), C.c_void_p(pg.data_ptr()), C.c_void_p(ops.raw_stream())), "rfx_cl_dconv_bwd")
+        if direct:
+            for q, t in enumerate(tgt):
+                d.pg_dst[q] = t[1].data_ptr()
+        check(_lib.lib().rfx_cl_dconv_bwd(C.byref(d), C.c_void_p(pg.data_ptr() if pg is not None else None), C.c_void_p(ops.raw_stream())),
+              "rfx_cl_dconv_bwd")
+        if direct:
+            for t in tgt:
+                sink.wrote(t[0])
         if passes:                                      # dx = gy + the transposed 3-tap convolution of dh (taps cross tile edges)
             fx = _dx_form(Cc, H, dil)
             clast.conv(fx, clchain.packed(fx, w1), dh, Bn, A, Tt, A, "store", out0=dx, res=gy)
         f1, f2 = _wforms(Cc, H, dil)
         dw2, db2 = clchain._wgrad(f2, dz, a, Bn, A, A, Tt, w2, b2)
         dw1, db1 = clchain._wgrad(f1, dh, x, Bn, A, A, Tt, w1, b1)
-        dscale, dg2w, dg2b = pg[:Cc], pg[Cc:3 * Cc], pg[3 * Cc:5 * Cc]
-        dg1w, dg1b = pg[5 * Cc:5 * Cc + H], pg[5 * Cc + H:]
+        if direct:
+            dscale = dg2w = dg2b = dg1w = dg1b = None
+        else:
+            dscale, dg2w, dg2b = pg[:Cc], pg[Cc:3 * Cc], pg[3 * Cc:5 * Cc]
+            dg1w, dg1b = pg[5 * Cc:5 * Cc + H], pg[5 * Cc + H:]
         return dx, dw1, db1, dg1w, dg1b, dw2, db2, dg2w, dg2b, dscale, None, None
 
 

@@ -816,13 +816,22 @@ __global__ __launch_bounds__(256) void cl_dconv_dh_kernel(uint16_t* __restrict__
 }
 
 // out[i] = sum over workgroups of partial[g][i], one wave per output, fixed order
-__global__ __launch_bounds__(256) void cl_dconv_pgrad_kernel(const float* __restrict__ partial, int n, int G, float* __restrict__ out) {
+struct CldPgDst { float* p[5]; };
+// dst given: the sum is ADDED to the parameter's own gradient slice (segments dscale[C] | dgn2w[2C] | dgn2b[2C] | dgn1w[H] | dgn1b[H])
+__global__ __launch_bounds__(256) void cl_dconv_pgrad_kernel(const float* __restrict__ partial, int n, int G, float* __restrict__ out,
+                                                             const CldPgDst dst, int C, int H) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
   if (i >= n) return;
   float s = 0.f;
   for (int gidx = l; gidx < G; gidx += 64) s += partial[(int64_t)gidx * n + i];
   s = rfx_wave_sum(s);
-  if (l == 0) out[i] = s;
+  if (l != 0) return;
+  if (dst.p[0] == nullptr) { out[i] = s; return; }
+  if (i < C) dst.p[0][i] += s;
+  else if (i < 3 * C) dst.p[1][i - C] += s;
+  else if (i < 5 * C) dst.p[2][i - 3 * C] += s;
+  else if (i < 5 * C + H) dst.p[3][i - 5 * C] += s;
+  else dst.p[4][i - 5 * C - H] += s;
 }
 
 // statistics of multi-tile samples: one wave per sample adds the TPS tile sums in a fixed order (double), writes (mean, rstd) into
@@ -952,8 +961,11 @@ static int cld_backward_passes(const rfx_cl_dconv_desc& d, hipStream_t st) {
 }
 
 extern "C" int rfx_cl_dconv_bwd(const rfx_cl_dconv_desc* dp, float* pgrad, void* stream) {
-  if (!dp || !dp->gy || !dp->a || !dp->hpre || !dp->stats || !dp->dz || !dp->dh || !dp->w2dp || !dp->partial || !pgrad)
-    return -1;
+  if (!dp || !dp->gy || !dp->a || !dp->hpre || !dp->stats || !dp->dz || !dp->dh || !dp->w2dp || !dp->partial) return -1;
+  const bool direct = dp->pg_dst[0] != nullptr;
+  for (int q = 0; q < 5; ++q)
+    if ((dp->pg_dst[q] != nullptr) != direct) return -1;
+  if (!direct && !pgrad) return -1;
   rfx_cl_dconv_desc d = *dp;
   d.x_or_gy_ok = 1;
   if (!cld_common_ok(&d) || !rfx_cl_dconv_ok(d.C, d.H, CLD_T, 1) || d.TPS < 1 || d.S % d.TPS) return -1;
@@ -967,7 +979,9 @@ extern "C" int rfx_cl_dconv_bwd(const rfx_cl_dconv_desc* dp, float* pgrad, void*
   }
   if (rc) return rc;
   const int n = 5 * d.C + 2 * d.H, G = d.S < d.grid ? d.S : d.grid;
-  hipLaunchKernelGGL(cl_dconv_pgrad_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, d.partial, n, G, pgrad);
+  CldPgDst dst;
+  for (int q = 0; q < 5; ++q) dst.p[q] = d.pg_dst[q];
+  hipLaunchKernelGGL(cl_dconv_pgrad_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, d.partial, n, G, pgrad, dst, d.C, d.H);
   RFX_CHECK_LAUNCH();
   return 0;
 }

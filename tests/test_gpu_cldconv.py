@@ -83,3 +83,41 @@ def test_cl_dconv_vs_channel_major(Cc, Bn, A, T):
     assert torch.equal(ycl, ycl2) and torch.equal(dxcl, dxcl2)
     for n in gcl:
         assert torch.equal(gcl[n], gcl2[n]), n
+
+
+def test_cl_dconv_small_gradients_through_the_sink():
+    """With a GradSink armed (parameters in an optim.FlatParams buffer) the backward writes dscale / GroupNorm affine gradients
+    straight into the flat gradient buffer -- same values as the tensors it returns to autograd without a sink, twice in a row
+    (the second pass accumulates: 2x)."""
+    from remfx_amd import cldconv, ops
+    from remfx_amd.hdemucs import _DConv
+    from remfx_amd.optim import FlatParams
+    torch.manual_seed(3)
+    Cc, Bn, A, T = 48, 2, 5, 256
+    mod = _DConv(Cc, depth=2, init=0.3).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(Bn * A, Cc, T, generator=g).to(DEV).to(torch.bfloat16).float()
+    gy = torch.randn(Bn * A, Cc, T, generator=g).to(DEV).to(torch.bfloat16).float()
+    _, _, ref = _run_cl(mod, x, gy, Bn, A)
+    flat = FlatParams(list(mod.parameters()))
+    assert flat.sink is not None
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision("bf16")
+    try:
+        flat.zero_grad()
+        for rep in range(2):
+            xc = x.view(Bn, A, Cc, T).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).requires_grad_(True)
+            gc = gy.view(Bn, A, Cc, T).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+            h = xc
+            for seq, (dil, pad, lstm, attn) in zip(mod.layers, mod.spec):
+                m = list(seq)
+                h = cldconv.dconv_layer(h, m[0], m[1], m[3], m[4], m[6].scale, dil)
+            h.backward(gc)
+        nsunk = sum(1 for w in flat.sink.writes if w)
+        flat.join()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_precision(prev)
+    assert nsunk == len(flat.params), (nsunk, len(flat.params))            # every parameter of the branch, the five small ones included
+    for n, p in mod.named_parameters():
+        assert torch.allclose(p.grad, 2 * ref[n], rtol=1e-6, atol=1e-7), n
