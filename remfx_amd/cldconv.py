@@ -14,7 +14,9 @@ from . import _lib, clast, clchain, ops
 from ._lib import ClDconvDesc, check
 
 T = 256
-GRID = 256            # persistent workgroups: one per CU (a workgroup holds a sample's images in LDS)
+import os as _os
+GRID = 256            # persistent workgroups of the backward kernels: one per CU (a workgroup holds a sample's images in LDS)
+GRID_FWD = int(_os.environ.get("RFX_CLD_GRID_FWD", "256"))   # forward kernels: 128 registers, two workgroups fit a CU
 
 
 class _Idx:
@@ -126,6 +128,7 @@ class ClDconvLayerFn(torch.autograd.Function):
         y = torch.empty_like(x)
         d = _desc(Cc, H, dil, eps, S, b1, g1w, g1b, b2, g2w, g2b, scale)
         d.TPS = TPS
+        d.grid = GRID_FWD
         d.x, d.y = x.data_ptr(), y.data_ptr()
         d.w1p = clchain.packed(tb["w1p"], w1).data_ptr()
         d.w2p = clchain.packed(tb["w2p"], w2).data_ptr()
