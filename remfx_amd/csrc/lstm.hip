@@ -22,6 +22,7 @@
 //   Workgroup ids are laid out so that the waves of a cluster are congruent mod 8, i.e. on one XCD / one L2 when
 //   the dispatcher round-robins (performance only; correctness relies on agent scope, not on placement).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -516,10 +517,280 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
 }
 
-static int64_t lstm_pack_uint4_per_dir(int H) {
+// ---- single-workgroup clusters (H <= 192, bf16 operands) ---------------------------------------------------------------------
+// The cluster form above spreads a cluster's W_hh over H/16 CUs and pays three L2 round trips per time step for it (publish, arrive,
+// fetch: ~1.5 of the 2.3 us of a forward step at H = 192, and 295 KB of fp32 partial tiles per backward step).  At H = 192 the whole
+// bf16 W_hh (295 KB) fits ONE CU's register file: a cluster = (tile of 16 sequences, direction) is then ONE workgroup of H/16 waves,
+// each wave keeps its 16 units' rows of W_hh (forward) resp. columns (backward) in 96 registers, and h_t / the gate gradients are
+// exchanged through LDS with one barrier per step.  Sequences are independent, so the batch is simply split over CUs (16 sequences
+// each: v_mfma_f32_16x16x32_bf16, rows = this wave's units, columns = sequences) -- no cross-CU traffic at all, no co-residency rule.
+// Backward: every wave contracts ALL gate gradients (K = 4 H, read from LDS) with its own units' columns of W_hh, so dh_{t-1} of its
+// units stays in its registers: one exchange per step (48 KB of bf16 gate gradients per cluster in LDS) instead of the partial tiles.
+// Lane l: sequence l & 15, units 4 (l >> 4) + r (r = 0..3) of the wave's 16 -- the C/D layout of the 16 x 16 MFMA, so the four gates
+// of a (unit, sequence) meet in one lane (four accumulators, one per gate) and the cell update is local.
+typedef float lstm_f32x4 __attribute__((ext_vector_type(4)));
+
+// localA: per direction [fwd | bwd]; fwd[w][g][ks][lane]: W_hh[g H + 16 w + (lane & 15)][32 ks + 8 (lane >> 4) + j];
+//                                    bwd[w][ks][lane]:    W_hh[32 ks + 8 (lane >> 4) + j][16 w + (lane & 15)]   (j = 0..7, bf16)
+__global__ void lstm_pack_local_kernel(const float* __restrict__ whh, int H, uint4* __restrict__ dst) {
+  const int nw = H / 16, nk = H / 32, nk4 = 4 * nk;
+  const int64_t nf = (int64_t)nw * 4 * nk * 64, nb = (int64_t)nw * nk4 * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nb; idx += (int64_t)gridDim.x * blockDim.x) {
+    const bool f = idx < nf;
+    const int64_t i = f ? idx : idx - nf;
+    const int lane = (int)(i & 63), row = lane & 15, kb = lane >> 4;
+    int64_t r = i >> 6;
+    uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v;
+      if (f) {
+        const int ks = (int)(r % nk), g = (int)((r / nk) % 4), w = (int)(r / (4 * nk));
+        v = whh[(int64_t)(g * H + 16 * w + row) * H + 32 * ks + 8 * kb + j];
+      } else {
+        const int ks = (int)(r % nk4), w = (int)(r / nk4);
+        v = whh[(int64_t)(32 * ks + 8 * kb + j) * H + 16 * w + row];
+      }
+      pk[j >> 1] |= lstm_bf16_rne(v) << (16 * (j & 1));
+    }
+    dst[idx] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  }
+}
+static int64_t lstm_local_uint4_per_dir(int H) { return (H <= 192) ? (int64_t)2 * (H / 16) * 4 * (H / 32) * 64 : 0; }
+
+// h (or a gate gradient) of this lane's four units -> the B fragment slot its consumers read: k = unit index within the operand
+__device__ __forceinline__ void lstm_local_publish(unsigned char* buf, int k0, int sq, float v0, float v1, float v2, float v3) {
+  // k = k0 .. k0 + 3 (k0 % 4 == 0): k-step k / 32, fragment lane 16 ((k % 32) / 8) + sequence, bytes 2 (k % 8) ..
+  const int ks = k0 >> 5, kk = k0 & 31;
+  *reinterpret_cast<uint2*>(buf + ks * 1024 + (16 * (kk >> 3) + sq) * 16 + 2 * (kk & 7)) =
+      make_uint2(rfx_cvt_pk_bf16(v0, v1), rfx_cvt_pk_bf16(v2, v3));
+}
+__device__ __forceinline__ void lstm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (The other MFMA orientation -- rows = sequences, a lane = one unit at four consecutive sequences, 16-byte accesses -- was built
+// too: a quarter of the memory instructions, but every lane of an instruction then touches its own cache line (units are P floats
+// apart): forward step 2.4 -> 3.9 us.  Lanes along the sequences keep the 64-byte runs.)
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void lstm_fwd_local_kernel(const LstmArgs a, const uint4* __restrict__ lpack,
+                                                                                                             int64_t lstride) {
+  constexpr int H = 16 * NW, NK = H / 32;
+  const int cluster = blockIdx.x, dir = cluster & 1, tile = cluster >> 1;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, sq = lane & 15, qb = lane >> 4;
+  const int Bn = a.Bn, T = a.T, P = a.P;
+  const int b = tile * 16 + sq;
+  const bool rvalid = b < Bn;
+  const int bc = rvalid ? b : 0;          // idle lanes read sequence 0 and never store
+  const float* __restrict__ xp = a.xp + (int64_t)dir * 4 * H * P;
+  float* outp = a.out + (int64_t)dir * H * P;
+  float* gsave = a.gates ? a.gates + (int64_t)dir * 4 * H * P : nullptr;
+  float* csave = a.gates ? a.cstate + (int64_t)dir * H * P : nullptr;
+  const uint32_t uP = (uint32_t)P, HP = (uint32_t)H * uP;
+  const int u0 = 16 * w + 4 * qb;                                   // first of this lane's four units
+  const uint32_t ubase = (uint32_t)u0 * uP + (uint32_t)bc;
+  // this wave's rows of W_hh, all four gates: 4 NK fragments = 96 registers at H = 192
+  uint4 wf[4][NK];
+  {
+    const uint4* A = lpack + (int64_t)dir * lstride + (int64_t)w * 4 * NK * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) wf[g][ks] = A[(g * NK + ks) * 64];
+  }
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  float xpv[4][4];
+  {
+    const uint32_t o0 = ubase + (uint32_t)((dir == 0 ? 0 : T - 1) * Bn);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xpv[g][r] = xp[o0 + (uint32_t)g * HP + (uint32_t)r * uP];
+  }
+  for (int s = 0; s < T; ++s) {
+    const int t = dir == 0 ? s : T - 1 - s;
+    const uint32_t o0 = ubase + (uint32_t)(t * Bn);
+    lstm_f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = lstm_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const unsigned char* hb = lstm_smem + ((s - 1) & 1) * (NK * 1024) + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hb + ks * 1024);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[g][ks]), bh, acc[g], 0, 0, 0);
+      }
+    }
+    float hv[4], gi[4], gf[4], gc[4], go[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ig = lstm_sigmoid(acc[0][r] + xpv[0][r]), fg = lstm_sigmoid(acc[1][r] + xpv[1][r]);
+      const float gg = lstm_tanh(acc[2][r] + xpv[2][r]), og = lstm_sigmoid(acc[3][r] + xpv[3][r]);
+      c[r] = fg * c[r] + ig * gg;
+      hv[r] = og * lstm_tanh(c[r]);
+      gi[r] = ig; gf[r] = fg; gc[r] = gg; go[r] = og;
+    }
+    if (s + 1 < T) {                     // h_t for everybody's next step: LDS, one barrier
+      lstm_local_publish(lstm_smem + (s & 1) * (NK * 1024), u0, sq, hv[0], hv[1], hv[2], hv[3]);
+      // the next step's input projections fly under the barrier and the MFMA chain
+      const uint32_t on = ubase + (uint32_t)((dir == 0 ? s + 1 : T - 2 - s) * Bn);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xpv[g][r] = xp[on + (uint32_t)g * HP + (uint32_t)r * uP];
+      lstm_lds_barrier();
+    }
+    if (rvalid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t o = o0 + (uint32_t)r * uP;
+        outp[o] = hv[r];
+        if (gsave) {
+          gsave[o] = gi[r]; gsave[o + HP] = gf[r]; gsave[o + 2 * HP] = gc[r]; gsave[o + 3 * HP] = go[r];
+          csave[o] = c[r];
+        }
+      }
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void lstm_bwd_local_kernel(const LstmArgs a, const uint4* __restrict__ lpack,
+                                                                                                             int64_t lstride) {
+  constexpr int H = 16 * NW, NK = H / 32, NK4 = 4 * NK;
+  const int cluster = blockIdx.x, dir = cluster & 1, tile = cluster >> 1;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, sq = lane & 15, qb = lane >> 4;
+  const int Bn = a.Bn, T = a.T, P = a.P;
+  const int b = tile * 16 + sq;
+  const bool rvalid = b < Bn;
+  const int bc = rvalid ? b : 0;
+  const float* __restrict__ gates = a.gates + (int64_t)dir * 4 * H * P;
+  const float* __restrict__ cst = a.cstate + (int64_t)dir * H * P;
+  float* __restrict__ dG = a.dG + (int64_t)dir * 4 * H * P;
+  const float* __restrict__ goutp = a.gout + (int64_t)dir * H * P;
+  const uint32_t uP = (uint32_t)P, HP = (uint32_t)H * uP;
+  const int u0 = 16 * w + 4 * qb;
+  const uint32_t ubase = (uint32_t)u0 * uP + (uint32_t)bc;
+  // this wave's columns of W_hh (rows of W_hh^T) over all 4 H gate rows: NK4 fragments = 96 registers at H = 192
+  uint4 wb[NK4];
+  {
+    const uint4* A = lpack + (int64_t)dir * lstride + (int64_t)NW * 4 * NK * 64 + (int64_t)w * NK4 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < NK4; ++ks) wb[ks] = A[ks * 64];
+  }
+  float dcc[4] = {0.f, 0.f, 0.f, 0.f}, ct[4], sg[4][4], cp[4], gy[4];
+  {
+    const uint32_t o0 = ubase + (uint32_t)((dir == 0 ? T - 1 : 0) * Bn);
+    const uint32_t op0 = ubase + (uint32_t)((T > 1 ? (dir == 0 ? T - 2 : 1) : (dir == 0 ? T - 1 : 0)) * Bn);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t du = (uint32_t)r * uP;
+      ct[r] = cst[o0 + du];
+      sg[0][r] = gates[o0 + du]; sg[1][r] = gates[o0 + du + HP]; sg[2][r] = gates[o0 + du + 2 * HP]; sg[3][r] = gates[o0 + du + 3 * HP];
+      cp[r] = cst[op0 + du];
+      gy[r] = goutp[o0 + du];
+    }
+  }
+  lstm_f32x4 rec = lstm_f32x4{0.f, 0.f, 0.f, 0.f};          // W_hh^T . (gate gradients of the step before): dh of this lane's units
+  for (int s = T - 1; s >= 0; --s) {                          // reverse of the forward processing order
+    const int step = T - 1 - s;
+    const int t = dir == 0 ? s : T - 1 - s;
+    const uint32_t o0 = ubase + (uint32_t)(t * Bn);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dh = gy[r] + rec[r];
+      const float ig = sg[0][r], fg = sg[1][r], gg = sg[2][r], og = sg[3][r];
+      const float cprev = s > 0 ? cp[r] : 0.f;
+      const float th = lstm_tanh(ct[r]);
+      const float dc = dh * og * (1.f - th * th) + dcc[r];
+      sg[3][r] = dh * th * og * (1.f - og);
+      sg[0][r] = dc * gg * ig * (1.f - ig);
+      sg[1][r] = dc * cprev * fg * (1.f - fg);
+      sg[2][r] = dc * ig * (1.f - gg * gg);
+      dcc[r] = dc * fg;
+      ct[r] = cp[r];
+    }
+    unsigned char* gb = lstm_smem + (step & 1) * (NK4 * 1024);
+    if (s > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) lstm_local_publish(gb, g * H + u0, sq, sg[g][0], sg[g][1], sg[g][2], sg[g][3]);
+    }
+    if (rvalid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t o = o0 + (uint32_t)r * uP;
+        dG[o] = sg[0][r]; dG[o + HP] = sg[1][r]; dG[o + 2 * HP] = sg[2][r]; dG[o + 3 * HP] = sg[3][r];
+      }
+    }
+    if (s > 0) {
+      lstm_lds_barrier();
+      lstm_f32x4 p[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p[q] = lstm_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NK4; ++ks) {                      // four independent chains
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(gb + ks * 1024 + lane * 16);
+        p[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[ks]), bh, p[ks & 3], 0, 0, 0);
+      }
+      // the next step's operands (issuing them in front of the barrier, under the MFMA chain, measured slower: 683 -> 814 us at 8 sequences)
+      const int s1 = s - 1, s2 = s1 > 0 ? s1 - 1 : 0;
+      const uint32_t on = ubase + (uint32_t)((dir == 0 ? s1 : T - 1 - s1) * Bn);
+      const uint32_t opn = ubase + (uint32_t)((dir == 0 ? s2 : T - 1 - s2) * Bn);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t du = (uint32_t)r * uP;
+        sg[0][r] = gates[on + du]; sg[1][r] = gates[on + du + HP]; sg[2][r] = gates[on + du + 2 * HP]; sg[3][r] = gates[on + du + 3 * HP];
+        cp[r] = cst[opn + du];
+        gy[r] = goutp[on + du];
+      }
+      rec = (p[0] + p[1]) + (p[2] + p[3]);
+    }
+  }
+}
+
+static int64_t lstm_cluster_uint4_per_dir(int H) {
   const int64_t nf = (int64_t)(H / 32) * 4 * (H / 16) * 64, nb = (int64_t)(H / 32) * (4 * H / 16) * 64;
   return 2 * nf + 2 * nb;
 }
+// a direction's pack: the cluster-form fragments (hi, lo), then the single-workgroup form's (H <= 192)
+static int64_t lstm_pack_uint4_per_dir(int H) { return lstm_cluster_uint4_per_dir(H) + lstm_local_uint4_per_dir(H); }
+// launches of the single-workgroup form: one workgroup per (16-sequence tile, direction)
+// Which launches take the single-workgroup form (H = 192, T = 256, kernel time alone): forward 513 / 519 / 540 / 579 us at 8 / 16 /
+// 32 / 64 sequences against 656 - 681 us for the cluster form; backward 683 - 778 / 870 / 1150 / 1207 - 1350 us against 896 - 982.  Its
+// 40 memory instructions per wave and step (64-byte runs: sixteen sequences of one tensor row) queue up as more workgroups run, so:
+// forward up to RFX_LSTM_LOCAL sequences (default 64), backward up to RFX_LSTM_LOCAL_BWD (default 16).  In the Demucs step the
+// layer-4 BLSTM sees 3 x the clips (torchaudio _BLSTM unfolds 256 frames into three overlapping 200-frame chunks): 64 clips stay on
+// the cluster form (the single-workgroup form measured +0.5 ms there), 8 clips per rank take the forward form (-0.8 ms of 33).
+static int lstm_local_max_bn(bool bwd) {
+  static int m[2] = {-1, -1};
+  if (m[0] < 0) {
+    const char* e = getenv("RFX_LSTM_LOCAL");
+    const char* eb = getenv("RFX_LSTM_LOCAL_BWD");
+    m[0] = e ? atoi(e) : 64;
+    m[1] = m[0] > 0 ? (eb ? atoi(eb) : 16) : 0;
+  }
+  return m[bwd];
+}
+static bool lstm_local_ok(int H, int prec, int Bn, bool bwd) { return prec == RFX_PREC_BF16 && H == 192 && Bn <= lstm_local_max_bn(bwd); }
+template <int NW>
+static int lstm_local_launch(bool bwd, LstmArgs a, hipStream_t s) {
+  constexpr int H = 16 * NW;
+  const int ntiles = (a.Bn + 15) / 16;
+  const uint4* lpack = a.packA + lstm_cluster_uint4_per_dir(H);       // behind the direction's cluster-form fragments
+  const int64_t lstride = a.pack_stride;
+  const size_t smem = (size_t)2 * (bwd ? 4 : 1) * (H / 32) * 1024;
+  static bool attr[2] = {false, false};
+  if (!attr[bwd]) {
+    const void* k = bwd ? reinterpret_cast<const void*>(&lstm_bwd_local_kernel<NW>) : reinterpret_cast<const void*>(&lstm_fwd_local_kernel<NW>);
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -3;
+    attr[bwd] = true;
+  }
+  if (bwd) hipLaunchKernelGGL((lstm_bwd_local_kernel<NW>), dim3(2 * ntiles), dim3(64 * NW), smem, s, a, lpack, lstride);
+  else hipLaunchKernelGGL((lstm_fwd_local_kernel<NW>), dim3(2 * ntiles), dim3(64 * NW), smem, s, a, lpack, lstride);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
 static bool lstm_bad_h(int H) { return H <= 0 || H % 32 || H > 512; }
 static size_t lstm_smem_bytes(int H) { return (size_t)(H / 32) * 4096; }   // fwd: 2*nks KB, bwd: 4*nwc KB (equal)
 // workspace: [0,256) error flag | counters (64 B per cluster) | exchange buffers sized for the backward sweep
@@ -541,10 +812,16 @@ extern "C" int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stre
   if (!whh || !pack || lstm_bad_h(H)) return -1;
   const int64_t nf = (int64_t)(H / 32) * 4 * (H / 16) * 64;
   uint4* p = reinterpret_cast<uint4*>(pack);
-  const int64_t total = lstm_pack_uint4_per_dir(H) / 2;
+  const int64_t total = lstm_cluster_uint4_per_dir(H) / 2;
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(lstm_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, whh, H, p, p + 2 * nf);
   RFX_CHECK_LAUNCH();
+  const int64_t nl = lstm_local_uint4_per_dir(H);
+  if (nl > 0) {
+    const int gl = (int)((nl + 255) / 256 < 2048 ? (nl + 255) / 256 : 2048);
+    hipLaunchKernelGGL(lstm_pack_local_kernel, dim3(gl), dim3(256), 0, (hipStream_t)stream, whh, H, p + lstm_cluster_uint4_per_dir(H));
+    RFX_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -605,6 +882,7 @@ extern "C" int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_
   a.xp = xp; a.packA = reinterpret_cast<const uint4*>(pack); a.out = out; a.gates = gates; a.cstate = cstate;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
   const int wf = H / 16;
+  if (lstm_local_ok(H, prec, Bn, false)) return lstm_local_launch<12>(false, a, (hipStream_t)stream);
   if (prec == RFX_PREC_BF16) {                 // bf16 operands (bf16-mixed): no lo fragments
     // the wave's whole W_hh slice (2 tiles x H/16 k-steps: 96 VGPRs at H = 192, 192 at H = 384) stays in registers instead of being
     // re-streamed through L1 every time step
@@ -629,6 +907,7 @@ extern "C" int rfx_lstm_bwd(const float* gout, const void* pack, const float* ga
   a.cstate = const_cast<float*>(cstate); a.dG = dG;
   a.pack_stride = lstm_pack_uint4_per_dir(H); a.T = T; a.Bn = Bn; a.H = H; a.P = T * Bn;
   const int wb = H / 16;
+  if (lstm_local_ok(H, prec, Bn, true)) return lstm_local_launch<12>(true, a, (hipStream_t)stream);
   if (prec == RFX_PREC_BF16) {
     // single-fragment products: the wave's W_hh^T slice (4 fragments per output tile: 96 VGPRs at H = 192, 192 at H = 384) is resident
     if (H == 192) return lstm_launch(lstm_bwd_kernel<3, 6, false, true>, a, wb, ws, stream);

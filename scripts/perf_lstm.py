@@ -1,38 +1,37 @@
-"""Time the LSTM recurrence kernels alone (HDemucs DConv shapes at the BASELINE batch)."""
-import sys
-import torch
-sys.path.insert(0, ".")
-from remfx_amd import _lib, lstm
-from remfx_amd.ops import _ptr, _stream
-
-L = _lib.lib()
+"""Dev tool: time the HDemucs DConv BLSTM (2 layers, bidirectional) forward + backward alone, bf16 mode.
+usage: python scripts/perf_lstm.py [H] [T] [Bn]      (RFX_LSTM_LOCAL=0: cluster form only)"""
 import os
-PREC = int(os.environ.get("LSTM_PREC", "2"))     # 2 = bf16 mode (single bf16 fragments), 1 = bf16x3
-shapes = [(192, 200, 192), (384, 128, 64), (192, 200, 24), (384, 128, 8)]     # HDemucs B = 64 and B = 8
-for H, T, Bn in shapes:
-    P = T * Bn
-    w = torch.randn(4 * H, H, device="cuda") * 0.05
-    pack = lstm._pack_whh(w, w)
-    xp = torch.randn(2, 4 * H, P, device="cuda")
-    out = torch.empty(2 * H, P, device="cuda")
-    gates = torch.empty(2, 4 * H, P, device="cuda")
-    cst = torch.empty(2, H, P, device="cuda")
-    dG = torch.empty(2, 4 * H, P, device="cuda")
-    g = torch.randn(2 * H, P, device="cuda")
-    ws = lstm._workspace(g.device, H)
-    def fwd():
-        L.rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), _ptr(gates), _ptr(cst), _ptr(ws), PREC, _stream())
-    def inf():
-        L.rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), None, None, _ptr(ws), PREC, _stream())
-    def bwd():
-        L.rfx_lstm_bwd(_ptr(g), _ptr(pack), _ptr(gates), _ptr(cst), T, Bn, H, _ptr(dG), _ptr(ws), PREC, _stream())
-    for name, fn in (("fwd", fwd), ("inf", inf), ("bwd", bwd)):
-        fn(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 3
-        print(f"H={H} T={T} Bn={Bn} {name}: {ms:.3f} ms  {1e3 * ms / T:.2f} us/step", flush=True)
-print("error flag:", lstm.error_flag())
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn as nn
+
+from remfx_amd import lstm, ops
+
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+Bn = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+ops.set_gemm_precision("bf16")
+mod = nn.LSTM(H, H, num_layers=2, bidirectional=True).cuda()
+x = torch.randn(1, H, T * Bn, device="cuda", requires_grad=True)
+g = torch.randn(1, 2 * H, T * Bn, device="cuda")
+
+
+def step():
+    y = lstm.blstm(mod, x, T, Bn)
+    y.backward(g)
+    return y
+
+
+for _ in range(3):
+    y = step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    y = step()
+e1.record()
+torch.cuda.synchronize()
+print(f"BLSTM H={H} T={T} Bn={Bn} local={os.environ.get('RFX_LSTM_LOCAL', '1')}: {e0.elapsed_time(e1) / 10:.3f} ms fwd + bwd "
+      f"(2 layers), |y| {float(y.abs().sum()):.6e}, |dx| {float(x.grad.abs().sum()):.6e}, err {lstm.error_flag()}")
