@@ -239,6 +239,11 @@ int rfx_lstm_pack_bytes(int32_t H);
 int rfx_lstm_ws_bytes(int32_t H);
 /* whh: [4H][H] row-major -> pack (rfx_lstm_pack_bytes(H) bytes).  The two directions are packed back to back. */
 int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stream);
+/* Single-workgroup form of the recurrence (H = 192, bf16 operands, small batches: one workgroup per (16-sequence tile, direction), W_hh
+ * register-resident, exchange through LDS).  rfx_lstm_local: 1 if rfx_lstm_fwd (bwd = 0) / rfx_lstm_bwd (bwd = 1) will take it for this
+ * shape and arithmetic mode; the caller must then also have called rfx_lstm_pack_local on the same `pack` buffer (per direction). */
+int rfx_lstm_local(int32_t H, int32_t Bn, int32_t prec, int32_t bwd);
+int rfx_lstm_pack_local(const float* whh, int32_t H, void* pack, void* stream);
 /* xp [2][4H][P]; pack = both directions; out [2H][P] (forward dir rows 0..H-1, reverse H..2H-1);
  * gates [2][4H][P] and cstate [2][H][P] are saved for the backward sweep (both NULL for inference). */
 /* prec: RFX_PREC_BF16 = h and W_hh rounded to bf16 (one MFMA per product: bf16-mixed); any other value = the bf16x3

@@ -816,12 +816,24 @@ extern "C" int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stre
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(lstm_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, whh, H, p, p + 2 * nf);
   RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+// 1 if rfx_lstm_fwd (bwd = 0) / rfx_lstm_bwd (bwd = 1) will take the single-workgroup form for this shape: the caller must then have
+// packed its fragments too (rfx_lstm_pack_local; the same `pack` buffer, behind the cluster form's)
+extern "C" int rfx_lstm_local(int32_t H, int32_t Bn, int32_t prec, int32_t bwd) {
+  if (lstm_bad_h(H) || Bn <= 0) return 0;
+  return lstm_local_ok(H, prec, Bn, bwd != 0) ? 1 : 0;
+}
+
+extern "C" int rfx_lstm_pack_local(const float* whh, int32_t H, void* pack, void* stream) {
+  if (!whh || !pack || lstm_bad_h(H)) return -1;
   const int64_t nl = lstm_local_uint4_per_dir(H);
-  if (nl > 0) {
-    const int gl = (int)((nl + 255) / 256 < 2048 ? (nl + 255) / 256 : 2048);
-    hipLaunchKernelGGL(lstm_pack_local_kernel, dim3(gl), dim3(256), 0, (hipStream_t)stream, whh, H, p + lstm_cluster_uint4_per_dir(H));
-    RFX_CHECK_LAUNCH();
-  }
+  if (nl == 0) return 0;
+  uint4* p = reinterpret_cast<uint4*>(pack);
+  const int gl = (int)((nl + 255) / 256 < 2048 ? (nl + 255) / 256 : 2048);
+  hipLaunchKernelGGL(lstm_pack_local_kernel, dim3(gl), dim3(256), 0, (hipStream_t)stream, whh, H, p + lstm_cluster_uint4_per_dir(H));
+  RFX_CHECK_LAUNCH();
   return 0;
 }
 

@@ -21,15 +21,22 @@ from ._lib import check
 from .ops import _ptr, _stream
 
 
-def _pack_whh(w_hh, w_hh_r):
+def _pack_whh(w_hh, w_hh_r, Bn, train):
     H = w_hh.shape[1]
-    nb = _lib.lib().rfx_lstm_pack_bytes(H)
+    L = _lib.lib()
+    nb = L.rfx_lstm_pack_bytes(H)
     if nb <= 0:
         raise ValueError(f"LSTM hidden size {H} unsupported (multiple of 32, <= 512)")
     pack = torch.empty(2 * nb, device=w_hh.device, dtype=torch.uint8)
+    # the single-workgroup form (csrc/lstm.hip) has its own fragment order: packed only for the shapes that take it
+    fwd_l, bwd_l = L.rfx_lstm_local(H, Bn, ops.GEMM_PREC, 0), (train and L.rfx_lstm_local(H, Bn, ops.GEMM_PREC, 1))
     for d, w in enumerate((w_hh, w_hh_r)):
-        check(_lib.lib().rfx_lstm_pack(_ptr(w.contiguous()), H, C.c_void_p(pack.data_ptr() + d * nb), _stream()),
-              "rfx_lstm_pack")
+        wc = w.contiguous()
+        dst = C.c_void_p(pack.data_ptr() + d * nb)
+        if not (fwd_l and (bwd_l or not train)):           # some sweep still runs the cluster form
+            check(L.rfx_lstm_pack(_ptr(wc), H, dst, _stream()), "rfx_lstm_pack")
+        if fwd_l or bwd_l:
+            check(L.rfx_lstm_pack_local(_ptr(wc), H, dst, _stream()), "rfx_lstm_pack_local")
     return pack
 
 
@@ -80,9 +87,9 @@ class _LSTMLayerFn(torch.autograd.Function):
         wcat = torch.cat([w_ih, w_ih_r]).view(8 * H, Cin, 1, 1)
         bcat = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r])
         xp = ops.conv2d_forward(x4, wcat, bcat, (1, 1), (0, 0), (1, 1))           # (1, 8H, 1, P) == [2][4H][P]
-        pack = _pack_whh(w_hh, w_hh_r)
-        out = torch.empty((1, 2 * H, P), device=x.device, dtype=torch.float32)
         need = any(ctx.needs_input_grad)
+        pack = _pack_whh(w_hh, w_hh_r, Bn, need)
+        out = torch.empty((1, 2 * H, P), device=x.device, dtype=torch.float32)
         gates = torch.empty((2, 4 * H, P), device=x.device, dtype=torch.float32) if need else None
         cst = torch.empty((2, H, P), device=x.device, dtype=torch.float32) if need else None
         check(_lib.lib().rfx_lstm_fwd(_ptr(xp), _ptr(pack), T, Bn, H, _ptr(out), _ptr(gates), _ptr(cst),
