@@ -521,6 +521,15 @@ int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, const float*
 /* per row: sums[r] += { sum x, sum t, sum x t, sum x^2, sum t^2 } in fp64 (auraloss SISDRLoss) */
 int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t L, int64_t x_rs, int64_t t_rs,
                    double* sums, void* stream);
+/* The scalar tail of SISDRLoss in one launch: out[0] = -mean_r 10 log10(|a t|^2 / (|x - a t|^2 + eps) + eps), a = <x,t> / (|t|^2 + eps),
+ * from the row sums of rfx_sisdr_sums (row means removed when zero_mean); auraloss SISDRLoss behind models.py:227-255. */
+int rfx_sisdr_finish(const double* sums, int32_t R, int64_t L, int32_t zero_mean, double eps, float* out, void* stream);
+/* The scalar tail of MultiResolutionSTFTLoss in one launch: sums[k] = the [R][3] row sums of resolution k (rfx_stft_pair_loss /
+ * rfx_stft_loss_reduce), n[k] = spectrum cells per row; out[0] = mean_k (sc_k + lm_k) with sc_k = mean_r sqrt(A_r / B_r)
+ * (per_example_sc) or sqrt(sum A / sum B), lm_k = sum_r C_r / (R n_k).  sums / n are HOST arrays of nres <= 8 entries.
+ * auraloss MultiResolutionSTFTLoss behind models.py:320. */
+int rfx_mrstft_combine(const float* const* sums, const int64_t* n, int32_t nres, int32_t R, int32_t per_example_sc, float* out,
+                       void* stream);
 
 /* ---- optimiser (flat fp32 buffers) ----------------------------------------------
  * Replaces torch.optim.AdamW.step + Lightning gradient_clip_val (models.py:185-191,

@@ -143,6 +143,8 @@ SIGNATURES = {
     "rfx_stft_pair_loss": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P],
     "rfx_l1_grad": [_P, _P, _I64, C.c_float, _P, _P, _P],
     "rfx_sisdr_sums": [_P, _P, _I32, _I64, _I64, _I64, _P, _P],
+    "rfx_sisdr_finish": [_P, _I32, _I64, _I32, C.c_double, _P, _P],
+    "rfx_mrstft_combine": [_P, _P, _I32, _I32, _I32, _P, _P],
     "rfx_zero": [_P, _I64, _P],
     "rfx_sumsq": [_P, _I64, _P, _P],
     "rfx_clip_coef": [_P, C.c_float, C.c_float, _P, _P, _P],

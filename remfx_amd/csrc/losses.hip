@@ -130,6 +130,56 @@ __global__ __launch_bounds__(256) void sisdr_sums_kernel(const float* __restrict
   }
 }
 
+// The scalar tail of auraloss MultiResolutionSTFTLoss over the row sums of all resolutions in ONE launch (it was ~24 one-element torch
+// launches per evaluation, three evaluations per training step): per resolution k, sums_k [R][3] = { sum (ym - xm)^2, sum ym^2,
+// sum |log xm - log ym| } per row, n_k spectrum cells per row:
+//   sc_k = per_example ? mean_r sqrt(A_r) / sqrt(B_r) : sqrt(sum_r A_r) / sqrt(sum_r B_r);   lm_k = sum_r C_r / (R n_k)
+//   out[0] = (1 / nres) sum_k (sc_k + lm_k)
+// One wave; rows are taken in order by lane l = r mod 64 and reduced with the fixed butterfly (bit-reproducible).
+struct MrCombineArgs {
+  const float* sums[8];
+  double n[8];
+  int nres, R, per_example;
+  float* out;
+};
+__global__ __launch_bounds__(64) void mrstft_combine_kernel(const MrCombineArgs a) {
+  const int lane = threadIdx.x;
+  double total = 0.0;
+  for (int k = 0; k < a.nres; ++k) {
+    const float* s = a.sums[k];
+    double sc = 0.0, sa = 0.0, sb = 0.0, sl = 0.0;
+    for (int r = lane; r < a.R; r += 64) {
+      const float A = s[3 * r], B = s[3 * r + 1], C = s[3 * r + 2];
+      sc += (double)(sqrtf(A) / sqrtf(B));
+      sa += (double)A; sb += (double)B; sl += (double)C;
+    }
+    sc = rfx_wave_sum_d(sc); sa = rfx_wave_sum_d(sa); sb = rfx_wave_sum_d(sb); sl = rfx_wave_sum_d(sl);
+    const double scv = a.per_example ? sc / (double)a.R : (double)(sqrtf((float)sa) / sqrtf((float)sb));
+    total += scv + sl / ((double)a.R * a.n[k]);
+  }
+  if (lane == 0) a.out[0] = (float)(total / (double)a.nres);
+}
+
+// The scalar tail of auraloss SISDRLoss over the fp64 row sums of rfx_sisdr_sums: out[0] = -mean_r 10 log10(|alpha t|^2 / (|x - alpha t|^2 + eps) + eps),
+// alpha = <x, t> / (|t|^2 + eps), after removing the row means when zero_mean (the ~22 one-element torch launches it replaces ran
+// twice per training step).  One wave, rows in lane order, fixed butterfly.
+__global__ __launch_bounds__(64) void sisdr_finish_kernel(const double* __restrict__ sums, int R, double L, int zero_mean, double eps,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  double acc = 0.0;
+  for (int r = lane; r < R; r += 64) {
+    const double sx = sums[5 * r], st = sums[5 * r + 1];
+    double sxt = sums[5 * r + 2], sxx = sums[5 * r + 3], stt = sums[5 * r + 4];
+    if (zero_mean) { sxt -= sx * st / L; sxx -= sx * sx / L; stt -= st * st / L; }
+    const double alpha = sxt / (stt + eps);
+    const double tt = alpha * alpha * stt;
+    const double res = sxx - 2.0 * alpha * sxt + tt;
+    acc += 10.0 * log10(tt / (res + eps) + eps);
+  }
+  acc = rfx_wave_sum_d(acc);
+  if (lane == 0) out[0] = (float)(-acc / (double)R);
+}
+
 static int grid_x(int64_t n) {
   const int64_t b = (n + 2047) / 2048;
   return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
@@ -175,6 +225,27 @@ extern "C" int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t
   if (!x || !t || !sums || R <= 0 || L <= 0) return -1;
   hipLaunchKernelGGL(sisdr_sums_kernel, dim3(grid_x(L), R), dim3(256), 0, (hipStream_t)stream, x, t, L, x_rs,
                      t_rs, sums);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_mrstft_combine(const float* const* sums, const int64_t* n, int32_t nres, int32_t R, int32_t per_example_sc,
+                                  float* out, void* stream) {
+  if (!sums || !n || !out || nres <= 0 || nres > 8 || R <= 0) return -1;
+  MrCombineArgs a;
+  for (int k = 0; k < 8; ++k) { a.sums[k] = nullptr; a.n[k] = 1.0; }
+  for (int k = 0; k < nres; ++k) {
+    if (!sums[k] || n[k] <= 0) return -1;
+    a.sums[k] = sums[k];
+    a.n[k] = (double)n[k];
+  }
+  a.nres = nres; a.R = R; a.per_example = per_example_sc; a.out = out;
+  hipLaunchKernelGGL(mrstft_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_sisdr_finish(const double* sums, int32_t R, int64_t L, int32_t zero_mean, double eps, float* out, void* stream) {
+  if (!sums || !out || R <= 0 || L <= 0) return -1;
+  hipLaunchKernelGGL(sisdr_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, R, (double)L, zero_mean, eps, out);
   RFX_CHECK_LAUNCH();
   return 0;
 }

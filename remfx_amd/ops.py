@@ -526,14 +526,17 @@ def conv2d_wgrad(x, g, wshape, stride, padding, dilation, need_bias, w=None, b=N
                 check(_lib.lib().rfx_unpack_add_bias(_ptr(wg.ws), _ptr(dp.woff), p.w_ms, p.M, p.extra["n_weight_rows"], p.Kpad,
                                                      _ptr(tw[1]), p.K - 1, _ptr(tb[1]), wg.splits, _stream()), "rfx_unpack_add_bias")
             else:
-                unpack_add(dp, wg, tw[1])                  # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
+                unpack_add(dp, wg, tw[1])                  # conv_fwd_plan rows = every live (ci, ka, kb) of every output channel, once
         sink.wrote(tw[0])
         if need_bias:
             sink.wrote(tb[0])
         return None, None
     wg = gemm_wgrad(dp, x, g)
-    dw = torch.empty(wshape, device=x.device, dtype=torch.float32)
-    unpack_set(dp, wg, dw)                                 # conv_fwd_plan rows = every (ci, ka, kb) of every output channel, once
+    if p.extra.get("dense", True):
+        dw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+    else:                                                  # taps that only meet the padding have no row: their gradient is 0
+        dw = zeros(tuple(wshape), x.device)
+    unpack_set(dp, wg, dw)                                 # conv_fwd_plan rows = every live (ci, ka, kb) of every output channel, once
     db = unpack_col(dp, wg, p.K - 1) if need_bias else None
     return dw, db
 

@@ -39,6 +39,9 @@ CASES = [
     (48, 12, (1, 900), (1, 3), (1, 1), (0, 2), (1, 2), 3),       # DConv bottleneck: narrow wgrad tile (M <= 32), K = 145
     (96, 24, (1, 333), (1, 3), (1, 1), (0, 1), (1, 1), 2),       # narrow wgrad tile, two k tiles (K = 289)
     (20, 32, (6, 50), (1, 3), (1, 1), (0, 1), (1, 1), 2),        # narrow wgrad tile, M = 32 exactly, K = 61
+    (24, 40, (1, 96), (3, 3), (1, 1), (1, 1), (1, 1), 2),        # 3x3 over ONE row (HDemucs decoder 4 rewrite): 6 of 9 taps only meet padding and are pruned; their dW must come back 0
+    (16, 24, (2, 30), (5, 3), (1, 1), (2, 1), (1, 1), 2),        # 5x3 over two rows: the outermost row taps meet padding only for some outputs (kept), none pruned
+    (16, 24, (2, 30), (7, 1), (1, 1), (3, 0), (1, 1), 2),        # 7x1 over two rows: taps 0 and 6 pruned, 1-5 live
 ]
 
 
