@@ -253,6 +253,12 @@ int rfx_lstm_fwd(const float* xp, const void* pack, int32_t T, int32_t Bn, int32
 /* gout [2H][P] -> dG [2][4H][P], the gradients of the gate pre-activations. */
 int rfx_lstm_bwd(const float* gout, const void* pack, const float* gates, const float* cstate, int32_t T,
                  int32_t Bn, int32_t H, float* dG, void* ws, int32_t prec, void* stream);
+/* Form choice of the H = 192 bf16 recurrence (no reference counterpart: torch.nn.LSTM has one form): launches of at most
+ * fwd_max_sequences / bwd_max_sequences sequences take the single-workgroup form (defaults 64 / 16, RFX_LSTM_LOCAL /
+ * RFX_LSTM_LOCAL_BWD), larger ones the wave-cluster form; 0 = always the cluster form, negative = back to the defaults.  Both
+ * forms meet the oracle to the mode's tolerance but round h_t after differently ordered sums, so a test that compares a batch
+ * with its single clips at 1e-6 pins one form. */
+int rfx_lstm_set_local(int32_t fwd_max_sequences, int32_t bwd_max_sequences);
 
 /* ---- elementwise / reductions ------------------------------------------------ */
 /* y = act(x) elementwise over n contiguous floats; PReLU/bias not supported here. */
@@ -516,6 +522,12 @@ int rfx_stft_pair_loss(const rfx_stft_desc* d, const float* x, const float* y, c
 /* rfx_stft_loss_grad with the target given by its clamped magnitudes (rfx_stft_pair_loss's ymag) instead of its spectrum */
 int rfx_stft_loss_grad_m(const float* xc, const float* ymag, int32_t R, int64_t n, float eps, const float* sums, float w_sc,
                          float w_lm, const float* gup, float* gxc, void* stream);
+/* rfx_stft_loss_grad_m followed by rfx_fft_synthesis (in_mode 0, herm 0, RFX_STFT_COMPLEX_FM) in ONE launch: the gradient spectrum
+ * is computed where the inverse transform's merge step loads it (same arithmetic, instruction for instruction) and never written --
+ * 1.15 GB of the 64-clip step's traffic per resolution.  d as for rfx_fft_synthesis; out accumulates (zeroed by the caller).
+ * The backward of auraloss STFTLoss behind models.py:320. */
+int rfx_fft_synthesis_lossgrad(const rfx_stft_desc* d, const float* xspec, const float* ymag, const float* sums, float w_sc,
+                               float w_lm, float eps, const float* gup, const float* window, float* out, void* stream);
 /* g[i] = w * gup[0] * sign(a[i] - b[i])   (nn.L1Loss backward; gup as above, NULL = 1) */
 int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, const float* gup, float* g, void* stream);
 /* per row: sums[r] += { sum x, sum t, sum x t, sum x^2, sum t^2 } in fp64 (auraloss SISDRLoss) */

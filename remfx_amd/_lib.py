@@ -141,6 +141,7 @@ SIGNATURES = {
     "rfx_stft_loss_grad": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_stft_loss_grad_m": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_stft_pair_loss": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P],
+    "rfx_fft_synthesis_lossgrad": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P],
     "rfx_l1_grad": [_P, _P, _I64, C.c_float, _P, _P, _P],
     "rfx_sisdr_sums": [_P, _P, _I32, _I64, _I64, _I64, _P, _P],
     "rfx_sisdr_finish": [_P, _I32, _I64, _I32, C.c_double, _P, _P],
@@ -212,6 +213,7 @@ SIGNATURES = {
     "rfx_lstm_ws_bytes": [_I32],
     "rfx_lstm_fwd": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P],
     "rfx_lstm_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _P],
+    "rfx_lstm_set_local": [_I32, _I32],
     "rfx_channel_sum": [_P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _P, _P],
     "rfx_cl_conv": [C.POINTER(ClConvDesc), _P],
     "rfx_cl_pack": [_P, _P, _I64, _P, _P],

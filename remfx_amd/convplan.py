@@ -236,9 +236,14 @@ def _out_len(i, k, s, p, d):
     return (i + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+PRUNE_TAPS = os.environ.get("RFX_PRUNE_TAPS", "1") != "0"      # A/B: 0 keeps the padding-only taps in the reduction
+
+
 def _live_taps(I, O, K, S, P, D):
     """Taps k of one axis that meet the operand for at least one output index: o * S - P + k * D in [0, I) for some o in [0, O).
     (All of them unless the operand is shorter than the kernel's reach; never empty for a valid convolution.)"""
+    if not PRUNE_TAPS:
+        return np.arange(K)
     idx = np.arange(O)[:, None] * S - P + np.arange(K)[None, :] * D
     live = np.nonzero(((idx >= 0) & (idx < I)).any(0))[0]
     return live if len(live) else np.arange(K)
@@ -285,10 +290,10 @@ def conv_dgrad_plans(xshape, xstrides, wshape, stride, padding, dilation, gshape
     plans = []
     for pa in range(min(SA, IA)):
         QA = -(-(IA - pa) // SA)
-        ta = [(k, c) for (k, c) in _phase_taps(pa, KA, SA, PA, DA) if -QA < c < OA]      # q + c in [0, OA) for some q in [0, QA)
+        ta = [(k, c) for (k, c) in _phase_taps(pa, KA, SA, PA, DA) if -QA < c < OA or not PRUNE_TAPS]      # q + c in [0, OA) for some q in [0, QA)
         for pb in range(min(SB, IB)):
             QB = -(-(IB - pb) // SB)
-            tb = [(k, c) for (k, c) in _phase_taps(pb, KB, SB, PB, DB) if -QB < c < OB]
+            tb = [(k, c) for (k, c) in _phase_taps(pb, KB, SB, PB, DB) if -QB < c < OB or not PRUNE_TAPS]
             rows, woff = [], []
             for co in range(Cout):
                 for (ka, ca) in ta:

@@ -47,7 +47,26 @@ struct FftArgs {
   int groups_per_row;   // workgroups per row
   int nbatch;           // frame batches (FB frames each) a workgroup walks
   uint32_t hop_magic;   // ceil(2^32 / hop): q / hop = umulhi(q, hop_magic) for the q < 2^20 of one batch's span (hop <= 4096; else 0)
+  // synthesis, RFX_STFT_COMPLEX_FM only (rfx_fft_synthesis_lossgrad): x = the PREDICTION's spectrum, and what is transformed is the
+  // STFTLoss gradient at it -- the value rfx_stft_loss_grad_m would have written, computed where the merge step loads it
+  const float* lg_ymag;   // clamped target magnitudes [R][frames][bins]; NULL = x is the spectrum to transform
+  const float* lg_sums;   // [R][3] row sums of the forward
+  const float* lg_gup;    // optional device scalar multiplying both weights
+  float lg_wsc, lg_wlm, lg_eps;
 };
+
+// d [ w_sc sqrt(A) / sqrt(B) + w_lm sum |log|X| - log|Y|| ] / dX at one cell: stft_loss_grad_kernel's formula (csrc/losses.hip, paired
+// form) with its three divisions by |X| replaced by one reciprocal (1-ulp differences; |X| == |Y| still gives exactly 0: the
+// magnitude comes out of the same rfx_pow2 + hardware sqrt sequence as the forward's)
+__device__ __forceinline__ v2f fft_lossgrad_cell(v2f x, float ym, float ksc, float wlm, float eps) {
+  const float px = rfx_pow2(x.x, x.y);
+  const float xm = __builtin_amdgcn_sqrtf(fmaxf(px, eps));
+  const float r = 1.0f / xm;
+  const float sg = xm > ym ? wlm : (xm < ym ? -wlm : 0.f);
+  float sc = fmaf(ksc, xm - ym, sg * r) * r;
+  sc = px > eps ? sc : 0.f;                                   // clamp(min = eps) passes no gradient below eps
+  return v2f{sc * x.x, sc * x.y};
+}
 
 template <int LOGN>
 struct FftCfg {
@@ -395,7 +414,7 @@ __global__ __launch_bounds__(256, 3) void fft_analysis_kernel(const FftArgs a) {
   }
 }
 
-template <int LOGN>
+template <int LOGN, bool LG = false>
 __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) {
   typedef FftCfg<LOGN> K;
   constexpr int NC = K::NC, T = K::T, FB = K::FB, N = 2 * NC;
@@ -430,6 +449,15 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
   const int f_end = d.frame0 + d.frames_out;
   const int FO = d.frames_out;
   float* outr = a.out + (int64_t)row * d.T;
+  constexpr bool lg = LG;                                    // loss-gradient source (its own instantiation); the row's two weights
+  float lg_ksc = 0.f, lg_wlm = 0.f;
+  if (lg) {
+    float wsc = a.lg_wsc;
+    lg_wlm = a.lg_wlm;
+    if (a.lg_gup) { const float uu = a.lg_gup[0]; wsc *= uu; lg_wlm *= uu; }
+    const float A = a.lg_sums[3 * row], B = a.lg_sums[3 * row + 1];
+    lg_ksc = (A > 0.f && B > 0.f) ? wsc / (sqrtf(A) * sqrtf(B)) : 0.f;
+  }
   for (int g = 0; g < a.nbatch; ++g) {
     const int fb0 = f_first + g * FB;
     if (fb0 >= f_end) break;
@@ -440,6 +468,7 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     // memory round trip per item and batch
     constexpr int NIT = (K::NH * FB + 255) / 256;
     v2f xkv[NIT], xmv[NIT];
+    float ykv[NIT], ymv[NIT];                                // loss-gradient source: the target magnitudes of the same cells
     auto item = [&](int it, int& fl2, int& k) -> bool {
       const int idx = tid + 256 * it;
       const bool act = idx < K::NH * FB;
@@ -473,12 +502,22 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
       const int fo = f2 < f_end ? f2 - d.frame0 : 0;
       xkv[it] = fetch(k, fo);
       xmv[it] = fetch(NC - k, fo);
+      if (lg) {
+        const int64_t cell0 = ((int64_t)row * FO + fo) * d.bins;
+        ykv[it] = a.lg_ymag[cell0 + (k < d.bins ? k : 0)];
+        ymv[it] = a.lg_ymag[cell0 + (NC - k < d.bins ? NC - k : 0)];
+      }
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int fl2, k;
       if (!item(it, fl2, k)) continue;
       const bool fv = fb0 + fl2 < f_end;
+      if (LG) {                                               // one item at a time: unrolled together the reciprocals of all items spill
+        xkv[it] = fft_lossgrad_cell(xkv[it], ykv[it], lg_ksc, lg_wlm, a.lg_eps);
+        xmv[it] = fft_lossgrad_cell(xmv[it], ymv[it], lg_ksc, lg_wlm, a.lg_eps);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const v2f xk = fix(xkv[it], k), xm = cconj(fix(xmv[it], NC - k));
       v2f Z0 = v2f{0.f, 0.f}, Z1 = v2f{0.f, 0.f};
       if (fv) {
@@ -572,12 +611,23 @@ static const v2f* fft_tables(int nc) {
   return tab[dev][slot];
 }
 
+struct FftLossGradSrc {
+  const float* ymag; const float* sums; const float* gup;
+  float w_sc, w_lm, eps;
+};
 template <bool SYN>
 static int launch_fft(const rfx_stft_desc* d, const float* x, const float* window, const float* mul,
-                      float* out, void* stream) {
+                      float* out, void* stream, const FftLossGradSrc* lgsrc = nullptr) {
   if (!stft_desc_ok(d) || !x || !window || !out) return -1;
   FftArgs a;
   a.d = *d; a.x = x; a.window = window; a.mul = mul; a.out = out;
+  a.lg_ymag = a.lg_sums = a.lg_gup = nullptr;
+  a.lg_wsc = a.lg_wlm = a.lg_eps = 0.f;
+  if (lgsrc) {
+    if (!SYN || d->mode != RFX_STFT_COMPLEX_FM || !lgsrc->ymag || !lgsrc->sums) return -1;
+    a.lg_ymag = lgsrc->ymag; a.lg_sums = lgsrc->sums; a.lg_gup = lgsrc->gup;
+    a.lg_wsc = lgsrc->w_sc; a.lg_wlm = lgsrc->w_lm; a.lg_eps = lgsrc->eps;
+  }
   const int nc = d->n_fft / 2;
   a.tables = fft_tables(nc);
   if (!a.tables) return -3;
@@ -596,6 +646,16 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
   a.groups_per_row = (batches + nb - 1) / nb;
   const unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);
   hipStream_t s = (hipStream_t)stream;
+  if (SYN && lgsrc) {
+    switch (d->n_fft) {
+      case 512: hipLaunchKernelGGL((fft_synthesis_kernel<8, true>), dim3(grid), dim3(256), 0, s, a); break;
+      case 1024: hipLaunchKernelGGL((fft_synthesis_kernel<9, true>), dim3(grid), dim3(256), 0, s, a); break;
+      case 2048: hipLaunchKernelGGL((fft_synthesis_kernel<10, true>), dim3(grid), dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL((fft_synthesis_kernel<11, true>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   switch (d->n_fft) {
     case 512:
       if (SYN) hipLaunchKernelGGL(fft_synthesis_kernel<8>, dim3(grid), dim3(256), 0, s, a);
@@ -824,4 +884,12 @@ extern "C" int rfx_fft_synthesis(const rfx_stft_desc* d, const float* spec, cons
                                  const float* mul, float* out, void* stream) {
   if (d && d->mode != RFX_STFT_COMPLEX && d->mode != RFX_STFT_CAC && d->mode != RFX_STFT_COMPLEX_FM) return -1;
   return launch_fft<true>(d, spec, window, mul, out, stream);
+}
+// rfx_stft_loss_grad_m + rfx_fft_synthesis in one launch (the backward of one auraloss STFTLoss resolution behind models.py:320):
+// the gradient spectrum is never written -- the merge step computes it from the stored prediction spectrum and target magnitudes
+extern "C" int rfx_fft_synthesis_lossgrad(const rfx_stft_desc* d, const float* xspec, const float* ymag, const float* sums, float w_sc,
+                                          float w_lm, float eps, const float* gup, const float* window, float* out, void* stream) {
+  if (!d || d->mode != RFX_STFT_COMPLEX_FM || !ymag || !sums) return -1;
+  FftLossGradSrc src{ymag, sums, gup, w_sc, w_lm, eps};
+  return launch_fft<true>(d, xspec, window, nullptr, out, stream, &src);
 }

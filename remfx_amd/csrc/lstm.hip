@@ -761,8 +761,9 @@ static int64_t lstm_pack_uint4_per_dir(int H) { return lstm_cluster_uint4_per_di
 // forward up to RFX_LSTM_LOCAL sequences (default 64), backward up to RFX_LSTM_LOCAL_BWD (default 16).  In the Demucs step the
 // layer-4 BLSTM sees 3 x the clips (torchaudio _BLSTM unfolds 256 frames into three overlapping 200-frame chunks): 64 clips stay on
 // the cluster form (the single-workgroup form measured +0.5 ms there), 8 clips per rank take the forward form (-0.8 ms of 33).
+static int lstm_local_m[2] = {-1, -1};
 static int lstm_local_max_bn(bool bwd) {
-  static int m[2] = {-1, -1};
+  int* m = lstm_local_m;
   if (m[0] < 0) {
     const char* e = getenv("RFX_LSTM_LOCAL");
     const char* eb = getenv("RFX_LSTM_LOCAL_BWD");
@@ -770,6 +771,15 @@ static int lstm_local_max_bn(bool bwd) {
     m[1] = m[0] > 0 ? (eb ? atoi(eb) : 16) : 0;
   }
   return m[bwd];
+}
+// Pin the form choice from the host (tests compare a batch with its single clips on ONE form: the two forms round h_t to bf16 after
+// differently ordered fp32 sums, which a 200-step recurrence amplifies to bf16-level differences).  Negative: back to the
+// environment / defaults.
+extern "C" int rfx_lstm_set_local(int32_t fwd_max_sequences, int32_t bwd_max_sequences) {
+  if (fwd_max_sequences < 0 || bwd_max_sequences < 0) { lstm_local_m[0] = lstm_local_m[1] = -1; return 0; }
+  lstm_local_m[0] = fwd_max_sequences;
+  lstm_local_m[1] = fwd_max_sequences > 0 ? bwd_max_sequences : 0;
+  return 0;
 }
 static bool lstm_local_ok(int H, int prec, int Bn, bool bwd) { return prec == RFX_PREC_BF16 && H == 192 && Bn <= lstm_local_max_bn(bwd); }
 template <int NW>

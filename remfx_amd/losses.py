@@ -10,6 +10,7 @@ Mirrors the auraloss objects the reference instantiates (remfx/models.py:7-8,
 (SURVEY App. B Q4).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -22,6 +23,8 @@ FFT_SIZES = (1024, 2048, 512)
 HOP_SIZES = (120, 240, 50)
 WIN_LENGTHS = (600, 1200, 240)
 
+
+FUSED_GRAD = os.environ.get("RFX_LOSS_FUSED_GRAD", "1") != "0"    # A/B: 0 = rfx_stft_loss_grad_m + rfx_fft_synthesis as two launches
 
 _MEMO = None
 
@@ -145,15 +148,19 @@ class _MRSTFTFn(torch.autograd.Function):
             else:
                 w_sc = gval / (nres * R)
             w_lm = gval / (nres * R * n)
+            w = stft.hann(win, g.device)
+            d = stft._desc(R, L, n_fft, hop, win, X.shape[2], 0, X.shape[1], _SPEC_MODE, in_mode=0, herm=0, scale=1.0)
+            if paired and FUSED_GRAD:   # Y = the clamped target magnitudes; the gradient spectrum is formed inside the synthesis
+                check(_lib.lib().rfx_fft_synthesis_lossgrad(C.byref(d), _ptr(X), _ptr(Y), _ptr(sums), w_sc, w_lm, eps, _ptr(gup),
+                                                            _ptr(w), _ptr(gx), _stream()), "rfx_fft_synthesis_lossgrad")
+                continue
             G = torch.empty_like(X)
-            if paired:                  # Y = the clamped target magnitudes
+            if paired:
                 check(_lib.lib().rfx_stft_loss_grad_m(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(gup), _ptr(G),
                                                       _stream()), "rfx_stft_loss_grad_m")
             else:
                 check(_lib.lib().rfx_stft_loss_grad(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(gup), _ptr(G),
                                                     _stream()), "rfx_stft_loss_grad")
-            w = stft.hann(win, g.device)
-            d = stft._desc(R, L, n_fft, hop, win, X.shape[2], 0, X.shape[1], _SPEC_MODE, in_mode=0, herm=0, scale=1.0)
             check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(G), _ptr(w), None, _ptr(gx), _stream()),
                   "rfx_fft_synthesis")
         ctx.saved = None

@@ -180,6 +180,33 @@ def test_pair_loss_kernel(geom):
     assert X2 is None and torch.allclose(s2.cpu(), ref.cpu(), rtol=2e-5, atol=0)
 
 
+@pytest.mark.parametrize("case", [(1024, 120, 600, 5, 30011), (2048, 240, 1200, 3, 20000), (512, 50, 240, 9, 7001)])
+def test_loss_gradient_inside_synthesis(case, monkeypatch):
+    """rfx_fft_synthesis_lossgrad (gradient spectrum formed in the inverse transform's merge step, never written) against
+    rfx_stft_loss_grad_m + rfx_fft_synthesis: the same per-cell arithmetic, so the two differ only by the order of the overlap-add
+    atomics; identical signals still get an exactly zero gradient."""
+    from remfx_amd import losses
+    n_fft, hop, win, R, L = case
+    g = torch.Generator().manual_seed(n_fft + R)
+    x = (torch.randn(R, 1, L, generator=g) * 0.3).to(DEV)
+    y = (x + 0.1 * torch.randn(R, 1, L, generator=g).to(DEV)).contiguous()
+    grads = []
+    for fused in (True, False):
+        monkeypatch.setattr(losses, "FUSED_GRAD", fused)
+        xd = x.clone().requires_grad_(True)
+        l = losses.MultiResolutionSTFTLoss(fft_sizes=(n_fft,), hop_sizes=(hop,), win_lengths=(win,))(xd, y)
+        (l * 1.7).backward()                      # upstream gradient != 1: the device-side gup path
+        grads.append(xd.grad.detach().cpu())
+    scale = float(grads[1].abs().max())
+    assert scale > 0
+    assert _rms(grads[0], grads[1]) < 1e-6 * scale, (_rms(grads[0], grads[1]), scale)
+    monkeypatch.setattr(losses, "FUSED_GRAD", True)
+    xd = x.clone().requires_grad_(True)
+    l = losses.MultiResolutionSTFTLoss(fft_sizes=(n_fft,), hop_sizes=(hop,), win_lengths=(win,))(xd, x.clone())
+    l.backward()
+    assert float(l) == 0.0 and float(xd.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", [(512, 75, 301, 1, 1500), (1024, 256, 1024, 9, 4099), (2048, 512, 2048, 2, 2049 + 512),
                                   (512, 128, 400, 17, 700)])
 def test_pair_loss_ragged(case):
