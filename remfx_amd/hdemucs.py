@@ -26,7 +26,7 @@ from . import clchain, cldconv, lstm, nnops, ops, stft
 CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
 CL_TIME = os.environ.get("RFX_CL_TIME", "1") != "0"         # ... and the time branch's norm-free layers (folded-view forms, clast.py)
 CL_ENDS = os.environ.get("RFX_CL_ENDS", "1") != "0"         # ... and the 1 - 2 channel convolutions at the network's ends as im2col GEMMs
-TWO_STREAMS = os.environ.get("RFX_TWO_STREAMS", "0") != "0"   # the time branch on a second high-priority stream (its layers 0-3 and the
+TWO_STREAMS = os.environ.get("RFX_TWO_STREAMS", "1") != "0"   # the time branch on a second high-priority stream (its layers 0-3 and the
                                                                # frequency layers 0-3 are independent between the input and layer 4)
 _TIME_STREAMS = {}
 
@@ -506,27 +506,30 @@ class HDemucs(nn.Module):
         hl = self.hop_length
         le = math.ceil(length / hl)
         pad = hl // 2 * 3
-        # _spec + _magnitude: STFT straight into complex-as-channels (B, 2*Cin, nfft/2, le)
-        cac = stft.stft(input.reshape(B * Cin, length), self.nfft, hl, mode="cac", normalized=True,
-                        bins=self.nfft // 2, frame0=2, frames_out=le, extra_pad=(pad, pad + le * hl - length))
-        Fq = self.nfft // 2
-        x = cac.view(B, Cin, 2, Fq, le).reshape(B, Cin * 2, Fq, le)
         if input.requires_grad:
             raise NotImplementedError("HDemucs: gradient w.r.t. the input waveform is not on the reference's path")
-        x, mean, std = nnops.row_standardize(x.detach(), 1e-5)      # over (C, Fr, T) per clip, unbiased std
-        xt, meant, stdt = nnops.row_standardize(input, 1e-5)        # over (C, T) per clip
         saved, saved_t, lengths, lengths_t = [], [], [], []
         Lc = self._cl_layers(le, input.device)
         Lt = self._cl_layers_time(length, input.device, Lc)
         samp = samp_t = None
         len_t = length
         import contextlib
+        # the time branch depends on the waveform only: it forks BEFORE the spectrogram, so its first layers run beside the STFT and
+        # the standardisation of the spectrum
         two = TWO_STREAMS and input.is_cuda and Lt > 0
         if two:
             main_s, time_s = torch.cuda.current_stream(), _time_stream(input.device)
             time_s.wait_stream(main_s)
-            xt.record_stream(time_s)
+            input.record_stream(time_s)
         tctx = (lambda: torch.cuda.stream(time_s)) if two else contextlib.nullcontext
+        with tctx():
+            xt, meant, stdt = nnops.row_standardize(input, 1e-5)        # over (C, T) per clip
+        # _spec + _magnitude: STFT straight into complex-as-channels (B, 2*Cin, nfft/2, le)
+        cac = stft.stft(input.reshape(B * Cin, length), self.nfft, hl, mode="cac", normalized=True,
+                        bins=self.nfft // 2, frame0=2, frames_out=le, extra_pad=(pad, pad + le * hl - length))
+        Fq = self.nfft // 2
+        x = cac.view(B, Cin, 2, Fq, le).reshape(B, Cin * 2, Fq, le)
+        x, mean, std = nnops.row_standardize(x.detach(), 1e-5)      # over (C, Fr, T) per clip, unbiased std
         for idx, encode in enumerate(self.freq_encoder):
             lengths.append(x.shape[-1])
             inject = None
@@ -614,7 +617,8 @@ class HDemucs(nn.Module):
                         tadd = tdec.fused_next_add
         if two:
             main_s.wait_stream(time_s)
-            xt.record_stream(main_s)
+            for t_ in (xt, meant, stdt):
+                t_.record_stream(main_s)
         S = len(self.sources)
         x = nnops.row_affine(x.reshape(B, -1), std, mean)          # S == 1 for RemFX: one (std, mean) per clip
         if S != 1:
