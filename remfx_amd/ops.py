@@ -278,7 +278,27 @@ def pack_a(dp, w, out=None):
 # built: 136.3 -> 138.7 ms at 64 clips -- the pack kernels' cost is their gather (a lane per output row: 64 cache lines per wave
 # load), not their launches, so one big launch in front of the forward pass is slower than 218 small ones spread through the step.)
 PACK_CACHE = _os.environ.get("RFX_PACK_CACHE", "1") != "0"
-PACK_CACHE_BYTES = 6 << 30
+PACK_CACHE_BYTES = 6 << 30        # upper bound; _pack_cache_limit() also keeps it below 1/16 of the device's memory
+_PACK_LIMIT = {}
+
+
+def _pack_cache_limit(device):
+    """Byte bound of the pack cache on `device`: PACK_CACHE_BYTES, at most 1/16 of the device's total memory (a fixed 6 GiB was a
+    quarter of a small card); RFX_PACK_CACHE_BYTES overrides."""
+    k = str(device)
+    v = _PACK_LIMIT.get(k)
+    if v is None:
+        env = _os.environ.get("RFX_PACK_CACHE_BYTES")
+        if env is not None:
+            v = int(env)
+        else:
+            v = PACK_CACHE_BYTES
+            try:
+                v = min(v, torch.cuda.get_device_properties(device).total_memory // 16)
+            except Exception:
+                pass
+        _PACK_LIMIT[k] = v
+    return v
 _PACKS = {}
 _PACKS_BYTES = [0]
 _WEIGHT_EPOCH = [0]
@@ -319,7 +339,7 @@ def pack_cached(dp, src, derive=None, tag=0):
             e.nbytes = apack.numel() * 4 + src.numel() * src.element_size()
             _PACKS[key] = e
             _PACKS_BYTES[0] += e.nbytes
-            while _PACKS_BYTES[0] > PACK_CACHE_BYTES and len(_PACKS) > 1:
+            while _PACKS_BYTES[0] > _pack_cache_limit(src.device) and len(_PACKS) > 1:
                 k0 = next(iter(_PACKS))
                 _PACKS_BYTES[0] -= _PACKS.pop(k0).nbytes
             return apack

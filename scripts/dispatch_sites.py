@@ -47,7 +47,13 @@ class Log(TorchDispatchMode):
                 if isinstance(a, torch.Tensor):
                     numel = a.numel()
                     break
-            self.agg[(name, site, "big" if numel > 65536 else "small")] += 1
+            shp = ""
+            if numel > 65536:
+                for a in args:
+                    if isinstance(a, torch.Tensor):
+                        shp = str(tuple(a.shape))
+                        break
+            self.agg[(name, site, ("big " + shp) if numel > 65536 else "small")] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -60,4 +66,4 @@ with Log() as L:
 tot = sum(L.agg.values())
 print(f"{tot} dispatched non-view ATen ops in one step at B = {B}")
 for (n, site, sz), c in L.agg.most_common(120):
-    print(f"{c:5d}  {n:26s} {sz:5s} {site}")
+    print(f"{c:5d}  {n:26s} {sz:34s} {site}")

@@ -10,6 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$MODE -o kt -- python $ROOT/bench.py --steps 4 --warmup 2 --preheat 0 --no-cpu-baseline --no-also --gemm $MODE > $OUT/kt_$MODE.log 2>&1
 find $OUT/kt_$MODE -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_demucs_b64_kernel_stats_$MODE.csv \;
 rm -rf $OUT/kt_$MODE
+# the one-stream configuration roofline.exclusive is measured in (bench.py picks and prices the dominant kernel there)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1_$MODE -o kt -- python $ROOT/bench.py --one-stream --steps 4 --warmup 2 --preheat 0 --no-cpu-baseline --no-also --gemm $MODE > $OUT/kt1_$MODE.log 2>&1
+find $OUT/kt1_$MODE -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_demucs_b64_kernel_stats_${MODE}_onestream.csv \;
+rm -rf $OUT/kt1_$MODE
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o r -- python $ROOT/bench.py --steps 1 --warmup 1 --preheat 0 --no-cpu-baseline --no-also --gemm $MODE > $OUT/pmc_$c.log 2>&1
   find $OUT/pmc_$c -name "*counter_collection.csv" -exec cp {} $OUT/pmc_$c.csv \;
