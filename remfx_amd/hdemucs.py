@@ -31,6 +31,13 @@ TWO_STREAMS = os.environ.get("RFX_TWO_STREAMS", "1") != "0"   # the time branch 
 _TIME_STREAMS = {}
 
 
+def _data_parallel():
+    """More than one rank: the step stays on the compute + weight-gradient streams.  ddp.GradSync orders a bucket's all-reduce behind
+    the stream its LAST gradient was written on and behind the weight-gradient stream; a bucket that also holds a gradient autograd
+    accumulated on the time-branch stream would need a third dependency, and no multi-GPU box was available to prove that path."""
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+
 def _time_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _TIME_STREAMS.get(idx)
@@ -516,7 +523,7 @@ class HDemucs(nn.Module):
         import contextlib
         # the time branch depends on the waveform only: it forks BEFORE the spectrogram, so its first layers run beside the STFT and
         # the standardisation of the spectrum
-        two = TWO_STREAMS and input.is_cuda and Lt > 0
+        two = TWO_STREAMS and input.is_cuda and Lt > 0 and not _data_parallel()
         if two:
             main_s, time_s = torch.cuda.current_stream(), _time_stream(input.device)
             time_s.wait_stream(main_s)
