@@ -239,6 +239,15 @@ int rfx_lstm_pack_bytes(int32_t H);
 int rfx_lstm_ws_bytes(int32_t H);
 /* whh: [4H][H] row-major -> pack (rfx_lstm_pack_bytes(H) bytes).  The two directions are packed back to back. */
 int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stream);
+/* Host glue of one bidirectional nn.LSTM layer as single launches (models.py:319 / 297-298 reach it through torchaudio HDemucs'
+ * _BLSTM and Open-Unmix): wcat [8H][Cin] = [w_ih ; w_ih_r] and bcat [8H] = [b_ih + b_hh ; b_ih_r + b_hh_r], the operands of the
+ * input-projection GEMM of both directions ... */
+int rfx_lstm_cat_params(const float* w_ih, const float* w_ih_r, const float* b_ih, const float* b_hh, const float* b_ih_r,
+                        const float* b_hh_r, int32_t H, int32_t Cin, float* wcat, float* bcat, void* stream);
+/* ... and that GEMM's weight / bias gradients (dwcat [8H][Cin], dbcat [8H]) ADDED into the six parameter gradients they belong to
+ * (both biases of a direction receive the same gradient). */
+int rfx_lstm_grad_scatter(const float* dwcat, const float* dbcat, int32_t H, int32_t Cin, float* g_w_ih, float* g_w_ih_r,
+                          float* g_b_ih, float* g_b_hh, float* g_b_ih_r, float* g_b_hh_r, void* stream);
 /* Single-workgroup form of the recurrence (H = 192, bf16 operands, small batches: one workgroup per (16-sequence tile, direction), W_hh
  * register-resident, exchange through LDS).  rfx_lstm_local: 1 if rfx_lstm_fwd (bwd = 0) / rfx_lstm_bwd (bwd = 1) will take it for this
  * shape and arithmetic mode; the caller must then also have called rfx_lstm_pack_local on the same `pack` buffer (per direction). */

@@ -208,6 +208,8 @@ SIGNATURES = {
     "rfx_row_affine": [_P, _P, _P, _P, _I32, _I64, _P],
     "rfx_lstm_pack_bytes": [_I32],
     "rfx_lstm_pack": [_P, _I32, _P, _P],
+    "rfx_lstm_cat_params": [_P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P],
+    "rfx_lstm_grad_scatter": [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rfx_lstm_local": [_I32, _I32, _I32, _I32],
     "rfx_lstm_pack_local": [_P, _I32, _P, _P],
     "rfx_lstm_ws_bytes": [_I32],

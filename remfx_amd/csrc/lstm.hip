@@ -818,6 +818,51 @@ extern "C" int rfx_lstm_ws_bytes(int32_t H) {
   return (int)(lstm_ws_xch_off(H) + (RFX_LSTM_MAX_WAVES / nwc) * 2 * nwc * nwc * 4096);
 }
 
+// Host glue of one bidirectional layer as single launches (they were 2 cat + 2 add launches per forward call and 6 add_ launches per
+// backward call: 64 of the Demucs step's launches).
+//   cat:     wcat [8H][Cin] = [w_ih ; w_ih_r],  bcat [8H] = [b_ih + b_hh ; b_ih_r + b_hh_r]  (the operands of the input-projection GEMM)
+//   scatter: the projection GEMM's weight / bias gradients added into the six parameter gradients they belong to (both biases of a
+//            direction receive the same gradient)
+__global__ __launch_bounds__(256) void lstm_cat_kernel(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ bi0,
+                                                       const float* __restrict__ bh0, const float* __restrict__ bi1, const float* __restrict__ bh1,
+                                                       int64_t nw, int nb, float* __restrict__ wcat, float* __restrict__ bcat) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 2 * nw; i += stride) wcat[i] = i < nw ? w0[i] : w1[i - nw];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 2 * nb; i += stride)
+    bcat[i] = i < nb ? bi0[i] + bh0[i] : bi1[i - nb] + bh1[i - nb];
+}
+__global__ __launch_bounds__(256) void lstm_scatter_kernel(const float* __restrict__ dwcat, const float* __restrict__ dbcat, int64_t nw, int nb,
+                                                           float* __restrict__ gw0, float* __restrict__ gw1, float* __restrict__ gbi0,
+                                                           float* __restrict__ gbh0, float* __restrict__ gbi1, float* __restrict__ gbh1) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 2 * nw; i += stride) {
+    if (i < nw) gw0[i] += dwcat[i]; else gw1[i - nw] += dwcat[i];
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 2 * nb; i += stride) {
+    const float v = dbcat[i];
+    if (i < nb) { gbi0[i] += v; gbh0[i] += v; } else { gbi1[i - nb] += v; gbh1[i - nb] += v; }
+  }
+}
+extern "C" int rfx_lstm_cat_params(const float* w_ih, const float* w_ih_r, const float* b_ih, const float* b_hh, const float* b_ih_r,
+                                   const float* b_hh_r, int32_t H, int32_t Cin, float* wcat, float* bcat, void* stream) {
+  if (!w_ih || !w_ih_r || !b_ih || !b_hh || !b_ih_r || !b_hh_r || !wcat || !bcat || H <= 0 || Cin <= 0) return -1;
+  const int64_t nw = (int64_t)4 * H * Cin;
+  const int grid = (int)((2 * nw + 255) / 256 < 1024 ? (2 * nw + 255) / 256 : 1024);
+  hipLaunchKernelGGL(lstm_cat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_ih, w_ih_r, b_ih, b_hh, b_ih_r, b_hh_r, nw, 4 * H, wcat, bcat);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rfx_lstm_grad_scatter(const float* dwcat, const float* dbcat, int32_t H, int32_t Cin, float* g_w_ih, float* g_w_ih_r,
+                                     float* g_b_ih, float* g_b_hh, float* g_b_ih_r, float* g_b_hh_r, void* stream) {
+  if (!dwcat || !dbcat || !g_w_ih || !g_w_ih_r || !g_b_ih || !g_b_hh || !g_b_ih_r || !g_b_hh_r || H <= 0 || Cin <= 0) return -1;
+  const int64_t nw = (int64_t)4 * H * Cin;
+  const int grid = (int)((2 * nw + 255) / 256 < 1024 ? (2 * nw + 255) / 256 : 1024);
+  hipLaunchKernelGGL(lstm_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dwcat, dbcat, nw, 4 * H, g_w_ih, g_w_ih_r, g_b_ih, g_b_hh,
+                     g_b_ih_r, g_b_hh_r);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int rfx_lstm_pack(const float* whh, int32_t H, void* pack, void* stream) {
   if (!whh || !pack || lstm_bad_h(H)) return -1;
   const int64_t nf = (int64_t)(H / 32) * 4 * (H / 16) * 64;

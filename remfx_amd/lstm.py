@@ -84,8 +84,14 @@ class _LSTMLayerFn(torch.autograd.Function):
             raise ValueError(f"lstm: expected (1, {Cin}, {P}) channel-major input, got {tuple(x.shape)}")
         x = x.contiguous()
         x4 = x.unsqueeze(2)
-        wcat = torch.cat([w_ih, w_ih_r]).view(8 * H, Cin, 1, 1)
-        bcat = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r])
+        if x.is_cuda and all(t.is_contiguous() and t.dtype == torch.float32 for t in (w_ih, w_ih_r, b_ih, b_hh, b_ih_r, b_hh_r)):
+            wcat = torch.empty((8 * H, Cin, 1, 1), device=x.device, dtype=torch.float32)     # one launch instead of 2 cat + 2 add
+            bcat = torch.empty((8 * H,), device=x.device, dtype=torch.float32)
+            check(_lib.lib().rfx_lstm_cat_params(_ptr(w_ih), _ptr(w_ih_r), _ptr(b_ih), _ptr(b_hh), _ptr(b_ih_r), _ptr(b_hh_r), H, Cin,
+                                                 _ptr(wcat), _ptr(bcat), _stream()), "rfx_lstm_cat_params")
+        else:
+            wcat = torch.cat([w_ih, w_ih_r]).view(8 * H, Cin, 1, 1)
+            bcat = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r])
         xp = ops.conv2d_forward(x4, wcat, bcat, (1, 1), (0, 0), (1, 1))           # (1, 8H, 1, P) == [2][4H][P]
         need = any(ctx.needs_input_grad)
         pack = _pack_whh(w_hh, w_hh_r, Bn, need)
@@ -139,10 +145,10 @@ class _LSTMLayerFn(torch.autograd.Function):
                 dwhh.append(dw)
             db0, db1 = dbcat[:4 * H], dbcat[4 * H:]
             grads = (dwcat[:4 * H], dwhh[0], db0, db0, dwcat[4 * H:], dwhh[1], db1, db1)
-            if sunk:
-                for (i, view), gr in zip(tg, grads):
-                    if gr is not None:
-                        view.add_(gr.reshape(-1))
+            if sunk:                         # one launch instead of six add_ into the flat gradient buffer's views
+                v = [t[1] for t in tg]
+                check(_lib.lib().rfx_lstm_grad_scatter(_ptr(dwcat), _ptr(dbcat), H, Cin, _ptr(v[0]), _ptr(v[4]), _ptr(v[2]), _ptr(v[3]),
+                                                       _ptr(v[6]), _ptr(v[7]), _stream()), "rfx_lstm_grad_scatter")
         if sunk:
             for i, _ in tg:
                 sink.wrote(i)

@@ -61,3 +61,36 @@ def test_blstm_inference_no_saved_state():
         dev.load_state_dict(ref.state_dict())
         out = lstm.blstm(dev, x.permute(2, 0, 1).reshape(1, 64, 33).contiguous().cuda(), 11, 3)
     check(float((out.cpu() - y.permute(2, 0, 1).reshape(1, 128, 33)).abs().max()), 2e-5)
+
+
+def test_blstm_gradients_through_the_sink():
+    """With a GradSink armed (parameters in an optim.FlatParams buffer) the eight parameter gradients of a layer land in the flat
+    gradient buffer -- dW_hh by the weight-gradient unpack, the six others by ONE rfx_lstm_grad_scatter launch (both biases of a
+    direction receive the same gradient) -- with the values autograd gets without a sink; a second pass accumulates (2x)."""
+    from remfx_amd import lstm
+    from remfx_amd.optim import FlatParams
+    torch.manual_seed(5)
+    H, Cin, T, Bn = 64, 48, 9, 7
+    mod = nn.LSTM(Cin, H, num_layers=2, bidirectional=True).cuda()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, Cin, T * Bn, generator=g).cuda()
+    gy = torch.randn(1, 2 * H, T * Bn, generator=g).cuda()
+    xr = x.clone().requires_grad_(True)
+    (lstm.blstm(mod, xr, T, Bn) * gy).sum().backward()
+    ref = {n: p.grad.detach().clone() for n, p in mod.named_parameters()}
+    for p in mod.parameters():
+        p.grad = None
+    flat = FlatParams(list(mod.parameters()))
+    assert flat.sink is not None
+    flat.zero_grad()
+    for rep in range(2):
+        xs = x.clone().requires_grad_(True)
+        (lstm.blstm(mod, xs, T, Bn) * gy).sum().backward()
+    nsunk = sum(1 for w in flat.sink.writes if w)
+    flat.join()
+    torch.cuda.synchronize()
+    assert nsunk == len(flat.params), (nsunk, len(flat.params))
+    for n, p in mod.named_parameters():
+        scale = float(ref[n].abs().max())
+        assert float((p.grad - 2 * ref[n]).abs().max()) <= 2e-6 * max(scale, 1.0), n
+    assert not lstm.error_flag()
