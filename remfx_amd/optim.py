@@ -37,6 +37,10 @@ class FlatParams:
             p.data = v
             p.grad = self.grad[o:o + p.numel()].view_as(p)
         from . import ops
+        import weakref
+        # the pack cache pins the weight tensors it packed from (these views): drop its entries when this buffer goes away, or a
+        # discarded model's parameters and packed weights stay resident
+        weakref.finalize(self, ops.clear_pack_cache)
         self.sink = None                                                   # see ops.GradSink
         if dev.type == "cuda" and ops.GradSink.MODE != "off":
             self.sink = ops.GradSink(self, side_stream=ops.GradSink.MODE == "side")
