@@ -42,9 +42,9 @@ def wrap_fwd(fn):
 
 
 def wrap_wg(fn):
-    def f(dp, x, g, dapack):
+    def f(dp, x, g):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        r = fn(dp, x, g, dapack)
+        r = fn(dp, x, g)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
         p = dp.p
         fl = 2.0 * p.M * p.K * g.numel() / max(1, g.shape[1])
