@@ -355,6 +355,9 @@ def wform_tail(Cc, Cs):
 
 
 # ---- weight gradients -------------------------------------------------------------------------------------------------------------
+CLW_SPLITS = int(_os.environ.get("RFX_CLW_SPLITS", "256"))      # workgroups of a channels-last weight gradient launch (A/B)
+
+
 class WgradForm:
     """One weight-gradient GEMM (csrc/cl_wgrad.hip): D[m][(r, t, c)] = sum_pos P[pos][m] * Q[pos shifted by tap (r, t)][c].
 
@@ -436,7 +439,7 @@ class WgradForm:
 
     def splits(self, steps):
         """Position splits: one workgroup per CU in all (a workgroup fills a CU's LDS), every split non-empty."""
-        S = max(1, min(steps, -(-256 // self.DT)))
+        S = max(1, min(steps, -(-CLW_SPLITS // self.DT)))
         sps = -(-steps // S)
         return -(-steps // sps)
 

@@ -42,7 +42,7 @@ def _time_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _TIME_STREAMS.get(idx)
     if st is None:
-        st = torch.cuda.Stream(device=idx, priority=-1)
+        st = torch.cuda.Stream(device=idx, priority=int(os.environ.get("RFX_TIME_STREAM_PRIO", "-1")))
         _TIME_STREAMS[idx] = st
     return st
 

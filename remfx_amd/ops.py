@@ -403,12 +403,15 @@ class WgradOut:
         self.ws, self.splits = ws, splits
 
 
+WGRAD_SPLITS = int(_os.environ.get("RFX_WGRAD_SPLITS", "256"))     # position splits of a gather-GEMM weight gradient (A/B)
+
+
 def gemm_wgrad(dp, x, g):
     p = dp.p
     sl = p.M * p.Kpad
     # at most 256 position splits (one per CU): every split costs the fixed-order reduction in the unpack kernels a slice to read --
     # with up to 2048 slices those kernels took 8.3 ms per Demucs step (r05 kernel stats), 104 launches at 0.7 TB/s
-    cap = sl * min(256, max(4, (1 << 25) // sl))
+    cap = sl * min(WGRAD_SPLITS, max(4, (1 << 25) // sl))
     ws = torch.empty(cap, device=x.device, dtype=torch.float32)
     ns = C.c_int32(0)
     if x.dtype == torch.bfloat16:                            # bf16 storage is implemented for the gradient operand only
