@@ -27,6 +27,7 @@
 //     partial-line stores merge in one L2.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 #ifndef RFX_FFT_PAIR_OCC
 // waves per SIMD the pair-loss kernel is compiled for where three workgroups fit a CU's LDS (n_fft 2048 / 4096; n_fft 1024 needs
 // 53 KB): 3 = 168 registers + 44 spilled instead of 220, MRSTFT forward + backward at 64 clips 7.80 -> 7.23 ms (A/B:
@@ -640,8 +641,9 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
   // share a 128-byte line must run at the same time for their partial-line stores to merge in L2 (_spec: 253 us at one batch per
   // workgroup, 370 / 458 us at two / four -- measured).
   int nb = 1;
+  static const int syn_nb_max = [] { const char* e = getenv("RFX_FFT_SYN_NB"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
   if (d->mode == RFX_STFT_COMPLEX_FM)
-    while (nb < (SYN ? 2 : 4) && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
+    while (nb < (SYN ? syn_nb_max : 4) && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
   a.nbatch = nb;
   a.groups_per_row = (batches + nb - 1) / nb;
   const unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);
