@@ -38,6 +38,10 @@ def _data_parallel():
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
+_XIDX = int(os.environ.get("RFX_XSYNC_IDX", "-1"))
+_XSYNC = int(os.environ.get("RFX_XSYNC", "0"))      # dev: serialisation points of the two-stream hazard hunt
+
+
 def _time_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _TIME_STREAMS.get(idx)
@@ -542,8 +546,12 @@ class HDemucs(nn.Module):
             lengths.append(x.shape[-1])
             inject = None
             if idx < len(self.time_encoder):
+                if two and (_XSYNC & 2) and _XIDX in (-1, idx):
+                    time_s.wait_stream(main_s)
                 with tctx():
                     xt, samp_t, len_t, inject = self._time_encoder_step(idx, Lt, B, saved_t, lengths_t, xt, samp_t, len_t)
+                if two and (_XSYNC & 1) and _XIDX in (-1, idx):
+                    main_s.wait_stream(time_s)
                 if two and inject is not None:                 # the merge: layer 4 of the frequency branch reads the time branch
                     main_s.wait_stream(time_s)
                     inject.record_stream(main_s)
@@ -599,6 +607,8 @@ class HDemucs(nn.Module):
             if idx >= offset and two and (self.time_decoder[idx - offset].empty):
                 time_s.wait_stream(main_s)                     # the empty time layer reads the frequency branch's layer-4 tensor
                 pre.record_stream(time_s)
+            if two and (_XSYNC & 8):
+                time_s.wait_stream(main_s)
             with tctx():
                 if idx >= offset and j < Lt:
                     length_t = lengths_t.pop(-1)
@@ -623,9 +633,13 @@ class HDemucs(nn.Module):
                         skip_t = saved_t.pop(-1)
                         xt, _ = tdec(xt, skip_t, length_t, next_skip=saved_t[-1] if saved_t else None, skip_added=tadd)
                         tadd = tdec.fused_next_add
+            if two and (_XSYNC & 4):
+                main_s.wait_stream(time_s)
         if two:
             main_s.wait_stream(time_s)
             xt.record_stream(main_s)
+            if _XSYNC & 16:
+                torch.cuda.synchronize()
         S = len(self.sources)
         x = nnops.row_affine(x.reshape(B, -1), std, mean)          # S == 1 for RemFX: one (std, mean) per clip
         if S != 1:
