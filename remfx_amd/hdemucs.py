@@ -38,6 +38,8 @@ def _data_parallel():
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
+_XSUB = int(os.environ.get("RFX_XSYNC_SUB", "0"))
+_CUR = [None, None]
 _XIDX = int(os.environ.get("RFX_XSYNC_IDX", "-1"))
 _XSYNC = int(os.environ.get("RFX_XSYNC", "0"))      # dev: serialisation points of the two-stream hazard hunt
 
@@ -488,6 +490,11 @@ class HDemucs(nn.Module):
                 else:
                     samp_t, tdcl = tenc.head_t(xt), False
             dt_ = tenc.dconv.forward_cl(samp_t) if tdcl else tenc.dconv(samp_t)
+            if _XSUB and _CUR[0] is not None and _XIDX in (-1, idx):          # dev: the hazard hunt's sub-layer serialisation points
+                if _XSUB & 1:
+                    _CUR[0].wait_stream(_CUR[1])          # main waits for the time stream's DConv
+                if _XSUB & 2:
+                    _CUR[1].wait_stream(_CUR[0])          # the time stream's stride-4 node waits for what main has enqueued
             if idx < Lt - 1:
                 nxt_t = CL_DCONV and CL_TIME_DCONV and self.time_encoder[idx + 1].dconv.cl_ok(len_t // 4)
                 et, samp_t = clchain.enc_mid(dt_, tenc.rewrite, self.time_encoder[idx + 1].conv, None, B, y_cl=nxt_t, fold=True)
@@ -536,6 +543,7 @@ class HDemucs(nn.Module):
             time_s.wait_stream(main_s)
             xt.record_stream(time_s)
         tctx = (lambda: torch.cuda.stream(time_s)) if two else contextlib.nullcontext
+        _CUR[0], _CUR[1] = (main_s, time_s) if two else (None, None)
         # _spec + _magnitude: STFT straight into complex-as-channels (B, 2*Cin, nfft/2, le)
         cac = stft.stft(input.reshape(B * Cin, length), self.nfft, hl, mode="cac", normalized=True,
                         bins=self.nfft // 2, frame0=2, frames_out=le, extra_pad=(pad, pad + le * hl - length))
