@@ -17,6 +17,27 @@ with torch.no_grad():
             p.fill_(0.3)
 g = torch.Generator().manual_seed(12)
 x = (torch.randn(8, 1, 262144, generator=g) * 0.1).to(DEV)
+# RFX_PROBE_KEEP=1: every tensor torch.empty / empty_like / zeros hands out during a forward pass stays referenced until the pass has
+# finished on the device -- no block is reused inside a pass.  If the failures vanish with it, they are use-after-free across streams.
+KEEP = os.environ.get("RFX_PROBE_KEEP", "0") != "0"
+keep = []
+if KEEP:
+    for name in ("empty", "empty_like", "zeros", "empty_strided", "zeros_like"):
+        orig = getattr(torch, name)
+        def mk(orig):
+            def f(*a, **k):
+                t = orig(*a, **k)
+                keep.append(t)
+                return t
+            return f
+        setattr(torch, name, mk(orig))
+_net = net
+def net(x):
+    y = _net(x)
+    if KEEP:
+        torch.cuda.synchronize()
+        keep.clear()
+    return y
 junk = []
 for r in range(reps):
     with torch.no_grad():
