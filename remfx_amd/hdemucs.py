@@ -589,6 +589,12 @@ class HDemucs(nn.Module):
             saved.append(x)
         x = ops.zeros(x.shape, x.device)
         xt = ops.zeros(x.shape, x.device)
+        if getattr(self, "_dbg", None) is not None:        # dev (scripts/probes/first_wrong_tensor.py): per-clip checksums of the skips
+            cs = lambda t: t.float().abs().sum(dim=tuple(range(1, t.dim()))) if t.shape[0] == B else t.float().abs().view(B, -1).sum(1)
+            self._dbg["saved"] = [cs(t) for t in saved]
+            self._dbg["x"] = cs(x)
+            with tctx():
+                self._dbg["saved_t"] = [cs(t) for t in saved_t]
         offset = self.depth - len(self.time_decoder)
         fadd = tadd = False                      # the previous layer already added this layer's skip (activation_add)
         for idx, decode in enumerate(self.freq_decoder):
