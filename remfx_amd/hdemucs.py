@@ -126,6 +126,19 @@ class _LocalState(nn.Module):
         return nnops.add(x, ops.conv1d(res, self.proj.weight, self.proj.bias))
 
 
+_ST_MODE = int(os.environ.get("RFX_ST_MODE", "0"))     # dev: how the statistics buffer of the channel-major DConv is zeroed (hazard hunt)
+
+
+def _stat_buf(x):
+    if _ST_MODE == 1:
+        return torch.zeros((x.shape[0], _STAT_SLOTS, 2), device=x.device, dtype=torch.float64)
+    st = ops.zeros((x.shape[0], _STAT_SLOTS, 2), x.device, torch.float64)
+    if _ST_MODE == 2:                                   # a second fill: does a late write-back of the first one matter?
+        ops._lib.check(ops._lib.lib().rfx_zero(ops._ptr(st), st.numel() * 8, ops._stream()), "rfx_zero")
+    return st
+
+
+_DCONV_DBG = None       # dev (scripts/probes/dconv_steps.py): a list collects per-sample checksums after every step of the channel-major path
 _DBG_SKIP = {int(v) for v in os.environ.get('RFX_DBG_SKIP_DCONV_C', '').split(',') if v}   # measurement only
 
 
@@ -177,20 +190,28 @@ class _DConv(nn.Module):
                 # frequency-branch samples of (C, 256): the whole depth-layer in one launch per direction (csrc/dconv.hip)
                 x = nnops.dconv_layer(x, mods[0], mods[1], mods[3], mods[4], mods[6].scale, dil)
                 continue
-            st = ops.zeros((x.shape[0], _STAT_SLOTS, 2), x.device, torch.float64)   # GN(1, C) statistics
+            st = _stat_buf(x)   # GN(1, C) statistics
             y, x = ops.conv1d_fork(x, mods[0].weight, mods[0].bias, 1, pad, dil, stat_sums=st, out_bf16=True)   # statistics come out of the GEMM epilogue
+            if _DCONV_DBG is not None:
+                _DCONV_DBG.append(("conv1", y.float().abs().sum(dim=(1, 2)), st.sum(dim=1).clone()))
             y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu", sums=st)
+            if _DCONV_DBG is not None:
+                _DCONV_DBG.append(("gn1", y.float().abs().sum(dim=(1, 2)), None))
             i = 3
             if lstm:
                 y = mods[i](y); i += 1
             if attn:
                 y = mods[i](y); i += 1
-            st = ops.zeros((x.shape[0], _STAT_SLOTS, 2), x.device, torch.float64)
+            st = _stat_buf(x)
             # the 2C-channel tensor is read only by the GroupNorm + GLU kernel (and, in backward, its gradient only by GEMMs):
             # 16-bit storage in the bf16 mode
             y = ops.conv1d(y, mods[i].weight, mods[i].bias, stat_sums=st, out_bf16=True)
+            if _DCONV_DBG is not None:
+                _DCONV_DBG.append(("conv2", y.float().abs().sum(dim=(1, 2)), st.sum(dim=1).clone()))
             x = nnops.group_norm(y, 1, mods[i + 1].weight, mods[i + 1].bias, mods[i + 1].eps,
                                  mode="glu_scale_res", res=x, scale=mods[i + 3].scale, sums=st)
+            if _DCONV_DBG is not None:
+                _DCONV_DBG.append(("gn2", x.float().abs().sum(dim=(1, 2)), None))
         return x
 
 
@@ -569,6 +590,10 @@ class HDemucs(nn.Module):
                 if idx == 0:
                     samp = encode.head(x, cl=dcl, ends=CL_ENDS)
                 d = encode.dconv.forward_cl(samp) if dcl else encode.dconv(samp)
+                if getattr(self, "_dbg", None) is not None and not dcl:        # dev: per-clip checksums around the channel-major DConv branches
+                    csn = lambda t: t.float().abs().reshape(B, -1).sum(1) if t.is_contiguous() else t.float().abs().contiguous().reshape(B, -1).sum(1)
+                    self._dbg.setdefault("samp", {})[idx] = csn(samp)
+                    self._dbg.setdefault("d", {})[idx] = csn(d)
                 if idx < Lc - 1:
                     emb_rows = self.freq_emb.table() * self.freq_emb_scale if (idx == 0 and self.freq_emb is not None) else None
                     nxt = CL_DCONV and self.freq_encoder[idx + 1].dconv.cl_ok()
