@@ -432,8 +432,14 @@ int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int
                       int32_t G, float eps, int32_t mode, const float* res, const float* scale,
                       double* sums /* N*G*2 fp64 workspace; sums_given != 0: already holds {sum, sumsq} per
                                       (n, g) -- e.g. from rfx_epilogue.stat_sums -- and the statistics pass is skipped;
-                                      sums_given = k > 1: the buffer is [N*G][k][2] partial sums (rfx_epilogue.stat_slots) */,
+                                      sums_given = k > 1: the buffer is [N*G][k][2] partial sums (rfx_epilogue.stat_slots);
+                                      sums_given = -1: see rfx_groupnorm_stat_chunks */,
                       int32_t sums_given, float* mean, float* rstd, float* y, void* stream);
+/* Chunks the statistics kernel of rfx_groupnorm_fwd / _x16 cuts one group into.  sums_given = -1 in those entry points: no statistics
+ * are given and `sums` is a workspace of N * G * chunks pairs of doubles that the kernel fills with plain stores, one pair per
+ * (group, chunk), summed in chunk order -- no zero fill, no atomics (a fill followed by fp64 atomics lost contributions whenever a
+ * second stream kept the machine busy).  sums_given = 0 keeps the N * G pair buffer + atomics form. */
+int rfx_groupnorm_stat_chunks(int32_t C, int32_t S, int32_t G);
 /* dx (N, C, S); dgamma / dbeta (C) and dscale (C/2, mode 3) are OVERWRITTEN; `work` is a
  * caller-owned scratch of N*C*2 + N*(C/2) + N*G*2 floats; the residual gradient of mode 3 is gy. */
 int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,

@@ -150,6 +150,7 @@ SIGNATURES = {
     "rfx_sumsq": [_P, _I64, _P, _P],
     "rfx_clip_coef": [_P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_adamw_step": [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P, _P],
+    "rfx_groupnorm_stat_chunks": [_I32, _I32, _I32],
     "rfx_groupnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
     "rfx_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rfx_groupnorm_fwd_x16": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],

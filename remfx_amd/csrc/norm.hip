@@ -56,7 +56,7 @@ __device__ __forceinline__ int gn_sidx(const GnArgs& a, int n, int ch) {
 // left the first case at 64 workgroups on 256 CUs (rocprof r1a: 30 % of the Demucs step).
 constexpr int GN_CHUNK = 4096;
 
-template <typename XT>
+template <typename XT, bool SLOTTED = false>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* __restrict__ sums, int nchunks) {
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -80,8 +80,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* _
   const double dp = rfx_wave_sum_d((double)p), dq = rfx_wave_sum_d((double)q);
   if (lane == 0) {
     const int g = gn_sidx(a, n, ch);
-    atomicAdd(sums + 2 * g, dp);
-    atomicAdd(sums + 2 * g + 1, dq);
+    if (SLOTTED) {
+      // GroupNorm: (group, chunk) is THIS wave's alone -- a plain store into its own slot, summed in chunk order by gn_finalize_kernel.
+      // No zero fill, no atomics: a fill followed by fp64 atomics lost contributions whenever a second stream kept the machine busy
+      // (DESIGN.md 4.10), and the sum no longer depends on the order the waves finish in.
+      sums[2 * ((int64_t)g * nchunks + sc)] = dp;
+      sums[2 * ((int64_t)g * nchunks + sc) + 1] = dq;
+    } else {
+      atomicAdd(sums + 2 * g, dp);
+      atomicAdd(sums + 2 * g + 1, dq);
+    }
   }
 }
 
@@ -534,11 +542,13 @@ static int gn_grid(int64_t total) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-static int norm_fwd(int x16, int bn, int use_given_stats, int sums_given, const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
+static int norm_fwd(int x16, int bn, int use_given_stats, int sums_given_in, const float* x, const float* gamma, const float* beta, int32_t N, int32_t C,
                                  int32_t S, int32_t G, float eps, int32_t mode, const float* res,
                                  const float* scale, double* sums /* N*G*2 workspace */, float* mean,
                                  float* rstd, float* y, void* stream) {
   if (!x || !gamma || !beta || !mean || !rstd || !y || N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return -1;
+  const bool sums_slotted = sums_given_in == -1;          // -1: no statistics given, `sums` is the slotted workspace (one pair per chunk)
+  const int sums_given = sums_slotted ? 0 : sums_given_in;
   const bool glu = mode == GN_GLU || mode == GN_GLU_SCALE_RES;
   if (glu && (C % 2)) return -1;
   if (mode == GN_GLU_SCALE_RES && (!res || !scale)) return -1;
@@ -557,14 +567,22 @@ static int norm_fwd(int x16, int bn, int use_given_stats, int sums_given, const 
     if (!bn) { st.C = G; st.S = (C / G) * S; }
     const int nchunks = (st.S + GN_CHUNK - 1) / GN_CHUNK;
     const int64_t nitems = (int64_t)N * st.C * nchunks;
+    int slots = sums_given > 1 ? sums_given : 1;
     if (!sums_given) {
-      if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * nstat, s) != hipSuccess) return -3;
-      if (x16) hipLaunchKernelGGL(gn_stats_kernel<rfx_bf16s>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
-      else hipLaunchKernelGGL(gn_stats_kernel<float>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
+      if (sums_given == 0 && !bn && sums_slotted) {
+        // `sums` holds N * G * nchunks pairs (rfx_groupnorm_stat_chunks tells the caller): every (group, chunk) wave stores its own
+        if (x16) hipLaunchKernelGGL((gn_stats_kernel<rfx_bf16s, true>), dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
+        else hipLaunchKernelGGL((gn_stats_kernel<float, true>), dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
+        slots = nchunks;
+      } else {
+        if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * nstat, s) != hipSuccess) return -3;
+        if (x16) hipLaunchKernelGGL(gn_stats_kernel<rfx_bf16s>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
+        else hipLaunchKernelGGL(gn_stats_kernel<float>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
+      }
       RFX_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, sums, mean, rstd, nstat,
-                       bn ? (double)N * (double)S : (double)(C / G) * (double)S, eps, sums_given > 1 ? sums_given : 1);
+                       bn ? (double)N * (double)S : (double)(C / G) * (double)S, eps, slots);
     RFX_CHECK_LAUNCH();
   }
   const int64_t total = (int64_t)N * (glu ? C / 2 : C) * S;
@@ -1143,4 +1161,12 @@ extern "C" int rfx_glu_bwd_bf16(const void* x, const float* gy, void* gx, int64_
                      static_cast<const rfx_bf16s*>(x), gy, static_cast<rfx_bf16s*>(gx), nitems, ipr, (C / 2) * S);
   RFX_CHECK_LAUNCH();
   return 0;
+}
+
+// Chunks gn_stats_kernel cuts a group of a GroupNorm(G) over (C, S) into: a caller that passes sums_given = -1 to rfx_groupnorm_fwd
+// / _x16 hands over a workspace of N * G * chunks pairs of doubles, filled by plain stores (no zero fill, no atomics).
+extern "C" int rfx_groupnorm_stat_chunks(int32_t C, int32_t S, int32_t G) {
+  if (C <= 0 || S <= 0 || G <= 0 || C % G) return -1;
+  const int64_t L = (int64_t)(C / G) * S;
+  return (int)((L + GN_CHUNK - 1) / GN_CHUNK);
 }

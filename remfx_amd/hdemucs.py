@@ -126,6 +126,10 @@ class _LocalState(nn.Module):
         return nnops.add(x, ops.conv1d(res, self.proj.weight, self.proj.bias))
 
 
+# The C >= 192 DConv branches took their GroupNorm statistics from the producing GEMM's epilogue (fp64 atomics into a zero-filled slot
+# buffer): those lose contributions while a second stream keeps the machine busy.  Default now: the GroupNorm kernel
+# computes them from the stored 16-bit tensor with per-chunk stores (what autocast's GroupNorm sees); 1 = the epilogue form (A/B).
+DCONV_EPI_STATS = os.environ.get("RFX_DCONV_EPI_STATS", "0") != "0"
 _ST_MODE = int(os.environ.get("RFX_ST_MODE", "0"))     # dev: how the statistics buffer of the channel-major DConv is zeroed (hazard hunt)
 
 
@@ -190,10 +194,10 @@ class _DConv(nn.Module):
                 # frequency-branch samples of (C, 256): the whole depth-layer in one launch per direction (csrc/dconv.hip)
                 x = nnops.dconv_layer(x, mods[0], mods[1], mods[3], mods[4], mods[6].scale, dil)
                 continue
-            st = _stat_buf(x)   # GN(1, C) statistics
+            st = _stat_buf(x) if DCONV_EPI_STATS else None   # GN(1, C) statistics out of the GEMM epilogue (A/B), else from the stored tensor
             y, x = ops.conv1d_fork(x, mods[0].weight, mods[0].bias, 1, pad, dil, stat_sums=st, out_bf16=True)   # statistics come out of the GEMM epilogue
             if _DCONV_DBG is not None:
-                _DCONV_DBG.append(("conv1", y.float().abs().sum(dim=(1, 2)), st.sum(dim=1).clone()))
+                _DCONV_DBG.append(("conv1", y.float().abs().sum(dim=(1, 2)), st.sum(dim=1).clone() if st is not None else None))
             y = nnops.group_norm(y, 1, mods[1].weight, mods[1].bias, mods[1].eps, mode="gelu", sums=st)
             if _DCONV_DBG is not None:
                 _DCONV_DBG.append(("gn1", y.float().abs().sum(dim=(1, 2)), None))
@@ -202,12 +206,12 @@ class _DConv(nn.Module):
                 y = mods[i](y); i += 1
             if attn:
                 y = mods[i](y); i += 1
-            st = _stat_buf(x)
+            st = _stat_buf(x) if DCONV_EPI_STATS else None
             # the 2C-channel tensor is read only by the GroupNorm + GLU kernel (and, in backward, its gradient only by GEMMs):
             # 16-bit storage in the bf16 mode
             y = ops.conv1d(y, mods[i].weight, mods[i].bias, stat_sums=st, out_bf16=True)
             if _DCONV_DBG is not None:
-                _DCONV_DBG.append(("conv2", y.float().abs().sum(dim=(1, 2)), st.sum(dim=1).clone()))
+                _DCONV_DBG.append(("conv2", y.float().abs().sum(dim=(1, 2)), st.sum(dim=1).clone() if st is not None else None))
             x = nnops.group_norm(y, 1, mods[i + 1].weight, mods[i + 1].bias, mods[i + 1].eps,
                                  mode="glu_scale_res", res=x, scale=mods[i + 3].scale, sums=st)
             if _DCONV_DBG is not None:

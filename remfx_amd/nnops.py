@@ -50,7 +50,10 @@ class _GroupNormFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         given = (sums.shape[1] if sums.dim() == 3 else 1) if sums is not None else 0     # number of partial-sum slots
         if sums is None:
-            sums = torch.empty(N * groups * 2, device=x.device, dtype=torch.float64)
+            # the statistics kernel stores one pair per (group, chunk) into its own slot: no zero fill, no atomics
+            chunks = int(_lib.lib().rfx_groupnorm_stat_chunks(Cc, S, groups))
+            sums = torch.empty(N * groups * 2 * max(chunks, 1), device=x.device, dtype=torch.float64)
+            given = -1
         if res is not None:
             res = res.contiguous()
         fwd = _lib.lib().rfx_groupnorm_fwd_x16 if x16 else _lib.lib().rfx_groupnorm_fwd
