@@ -26,7 +26,7 @@ from . import clchain, cldconv, lstm, nnops, ops, stft
 CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
 CL_TIME = os.environ.get("RFX_CL_TIME", "1") != "0"         # ... and the time branch's norm-free layers (folded-view forms, clast.py)
 CL_ENDS = os.environ.get("RFX_CL_ENDS", "1") != "0"         # ... and the 1 - 2 channel convolutions at the network's ends as im2col GEMMs
-TWO_STREAMS = os.environ.get("RFX_TWO_STREAMS", "0") != "0"   # the time branch on a second high-priority stream (its layers 0-3 and the
+TWO_STREAMS = os.environ.get("RFX_TWO_STREAMS", "1") != "0"   # the time branch on a second high-priority stream (its layers 0-3 and the
                                                                # frequency layers 0-3 are independent between the input and layer 4)
 _TIME_STREAMS = {}
 
@@ -557,10 +557,9 @@ class HDemucs(nn.Module):
         samp = samp_t = None
         len_t = length
         import contextlib
-        # OFF by default: with the time branch on its own stream the batch-of-8 / single-clip comparison of
-        # tests/test_gpu_fullsize_properties.py differs in ~3 % of repetitions by 1e-3 in ONE clip (30 % when the fork sits before the
-        # spectrogram) -- a cross-stream hazard that scripts/probes/batch_invariance_loop.py reproduces and that was not found
-        # (DESIGN.md 4.10).  The flag stays for that investigation; the -1.7 ms it measured is not worth a wrong clip.
+        # ON again since the GroupNorm statistics are stored per chunk (with epilogue statistics -- a zero fill followed by
+        # fp64 atomics -- one clip of a batch came out 1e-3 wrong in ~3 % of forward passes whenever this stream ran beside the main one;
+        # scripts/probes/batch_invariance_loop.py is the acceptance test: 0 of 200).
         two = TWO_STREAMS and input.is_cuda and Lt > 0 and not _data_parallel()
         xt, meant, stdt = nnops.row_standardize(input, 1e-5)        # over (C, T) per clip
         if two:

@@ -36,11 +36,9 @@ except Exception:  # not installed in this image
             self.logged[name] = value.detach() if torch.is_tensor(value) else value
 
 
-# OFF by default since the end of round 5: what the two-stream hazard hunt found -- GroupNorm statistics that a GEMM
-# epilogue accumulates with fp64 atomics into a just-zeroed buffer lose contributions while ANOTHER stream keeps the machine busy --
-# is a property of forward-pass kernels, and this stream runs beside the forward pass.  Its own values were validated
-# (scripts/probes/metric_stream_check.py); the network's statistics beside it were not.  1 = -0.65 ms at 64 clips.
-METRIC_STREAM = os.environ.get("RFX_METRIC_STREAM", "0") != "0"
+# On by default: A/B 0 = the Input_* metrics after the network on the step's stream.  (It was off for the last hours of round 5, until
+# the GroupNorm statistics of the forward pass stopped depending on a zero fill + atomics: DESIGN.md 4.10.)
+METRIC_STREAM = os.environ.get("RFX_METRIC_STREAM", "1") != "0"
 _METRIC_STREAMS = {}
 
 
