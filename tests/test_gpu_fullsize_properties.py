@@ -274,3 +274,29 @@ def test_lstm_forms_agree_to_bf16_level():
     err = float((y_default - y_cluster).pow(2).mean().sqrt())
     print("lstm forms: rms difference / output rms =", err / scale)
     check(err, 1e-7, scale, bf16x3=1e-7, bf16=3e-3, what=("lstm forms", err, scale))
+
+
+def test_hdemucs_batching_invariance_repeated_with_streams():
+    """The batch-of-8 / single-clips comparison REPEATED with allocator churn in between, on the shipped stream configuration (time
+    branch on its own stream): the form of the check that exposed lost GroupNorm statistics beside a second stream (DESIGN.md 4.10:
+    one clip 1e-3 off in ~3 % of repetitions, 57 % when the branches' second layers were aligned).  25 repetitions here; the probe
+    scripts/probes/batch_invariance_loop.py runs hundreds."""
+    from remfx_amd.hdemucs import HDemucs
+    torch.manual_seed(11)
+    net = HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=48).to(DEV).eval()
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith(".scale"):
+                p.fill_(0.3)
+    x = (torch.randn(8, 1, CLIP, generator=torch.Generator().manual_seed(12)) * 0.1).to(DEV)
+    worst = 0.0
+    for r in range(25):
+        with torch.no_grad():
+            yb = net(x)
+            ys = torch.cat([net(x[i:i + 1]) for i in range(8)], 0)
+        scale = float(ys.pow(2).mean().sqrt())
+        worst = max(worst, float((yb - ys).pow(2).mean().sqrt()) / scale)
+        junk = [torch.empty((1 + (7919 * (r + 3) * k) % 50_000_000,), device=DEV) for k in range(1, 6)]
+        del junk[::2]
+    print("worst rms difference / output rms over 25 repetitions:", worst)
+    check(worst, 1e-6, 1.0, bf16x3=1e-6, bf16=1e-6, what=("batch vs singles, repeated", worst))
