@@ -37,6 +37,89 @@ DTYPES = {"f32": "f32", "bf16x3": "f32 via bf16x3 split MFMA (fp32 accumulate)",
 PEAK_HBM_GBS = 8000.0
 
 
+# ---- output: the FULL record goes to a file (and stderr on request); stdout carries ONE compact JSON line (< 4 KB) ---------------
+ALG = {  # algorithmic work of ONE clip, forward; fwd+bwd = 3x flops, 2.5x bytes.  bytes: (fp32 count, 16-bit count)
+    "demucs": {"flops_fwd": 117.2e9 + 0.13e9, "bytes_fwd": (396e6, 198e6), "weights": 83.63e6},
+    "tcn": {"flops_fwd": 5.14e12, "bytes_fwd": (10.7e9, 10.7e9), "weights": 9.974e6},
+    "dcunet": {"flops_fwd": 1705e9, "bytes_fwd": (None, None), "weights": 7.66e6},
+    "umx": {"flops_fwd": 2 * 6.5e9, "bytes_fwd": (None, None), "weights": 6.3e6},
+}
+
+
+def step_roofline(workload, gemm, batch, sec_per_step, peak_tflops, pmc_total_bytes):
+    """Whole-step roofline per SURVEY 8(d): achieved_mfma = flops_alg / (t * peak of the arithmetic mode), achieved_hbm =
+    bytes_alg / (t * 8.0e12), algorithmic work of forward + backward = 3x the forward flops and 2.5x the forward layer-boundary
+    bytes (in the width the mode stores activations in: 16-bit in the bf16 mode, fp32 otherwise) + the weights once per pass."""
+    a = ALG[workload]
+    fl = 3.0 * a["flops_fwd"] * batch
+    b32, b16 = a["bytes_fwd"]
+    bf = b16 if gemm == "bf16" else b32
+    by = (2.5 * bf * batch + 3 * 4.0 * a["weights"]) if bf else None
+    r = {"algorithmic_flops": round(fl), "algorithmic_bytes": round(by) if by else None,
+         "frac_mfma": round(fl / sec_per_step / 1e12 / peak_tflops, 4),
+         "frac_hbm": round(by / sec_per_step / 1e9 / PEAK_HBM_GBS, 4) if by else None,
+         "traffic_bytes": pmc_total_bytes,
+         "traffic_ratio": round(pmc_total_bytes / by, 2) if (by and pmc_total_bytes) else None}
+    return r
+
+
+def emit(out, tag):
+    """Write the full record to gpurun_out/ (scratch on the GPU box; falls back to profiles/) and print the compact line."""
+    full_path = None
+    for d in (os.environ.get("RFX_BENCH_FULL_DIR"), os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")):
+        if not d:
+            continue
+        try:
+            os.makedirs(d, exist_ok=True)
+            full_path = os.path.join(d, f"bench_full_{tag}.json")
+            json.dump(out, open(full_path, "w"))
+            break
+        except OSError:
+            full_path = None
+    if os.environ.get("RFX_BENCH_FULL_STDERR"):
+        print(json.dumps(out), file=sys.stderr)
+    keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_mfma", "frac_hbm", "traffic", "algorithmic_bytes_per_launch",
+                 "algorithmic_flops_per_launch", "avg_launch_us", "launches_per_step", "share_of_step", "frac_source")
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config", {})
+    c["config"] = {k: cfg[k] for k in ("workload", "clips_per_gpu", "global_batch", "clip_samples", "parallelism", "final_loss",
+                                       "rccl_ranks", "exposed_allreduce_ms", "param_abs_sum", "streams",
+                                       "removal_model_applications_per_step") if k in cfg}
+    roof = out.get("roofline")
+    c["roofline"] = {k: roof[k] for k in keep_roof if k in roof} if roof else None
+    if "step_roofline" in out:
+        c["step_roofline"] = out["step_roofline"]
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: (v if k != "sample" else v[:200]) for k, v in cb.items() if k in ("value", "unit", "cores", "kind", "sample")}
+    al = out.get("also")
+    if al:
+        ca = {}
+        if "train_step_bf16x3" in al:
+            ca["train_step_bf16x3_ms"] = al["train_step_bf16x3"]["ms_per_step"]
+        if "train_step_f32" in al:
+            ca["train_step_f32_ms"] = al["train_step_f32"]["ms_per_step"]
+        f = al.get("demucs_fwd")
+        if f:
+            ca["demucs_fwd"] = {"ms_per_pass": f["ms_per_pass"], "frac_hbm": f["frac_hbm"], "frac_hbm_fp32_bytes": f.get("frac_hbm_fp32_bytes"),
+                                "frac_mfma": f["frac_mfma"],
+                                "stft_frac_hbm": f["stages"]["stft"]["frac_hbm"], "istft_frac_hbm": f["stages"]["istft"]["frac_hbm"]}
+        for k in ("si_sdr_vs_cpu_oracle_db", "rms_vs_cpu_oracle", "parity_clip_samples"):
+            if k in al:
+                ca[k] = al[k]
+        c["also"] = ca
+    if "phases_s" in out:
+        c["phases_s"] = out["phases_s"]
+    c["full_record"] = os.path.relpath(full_path, ROOT) if full_path else None      # every per-kernel table of earlier rounds lives there
+    line = json.dumps(c)
+    if len(line) > 3900:                         # never let the driver see an unparseable tail again: drop the optional blocks
+        for k in ("phases_s", "also"):
+            c.pop(k, None)
+        line = json.dumps(c)
+    print(line, flush=True)
+
+
 def build_model(workload, device):
     from remfx_amd import models
     torch.manual_seed(12345)                                 # cfg/config.yaml:7
@@ -404,14 +487,15 @@ def bench_chain(args, rank, world, device):
     cpu = None
     if not args.no_cpu_baseline:
         cpu = cpu_baseline_chain(chain.last_labels.detach().cpu(), order)
-    print(json.dumps({"roofline": roof, "cpu_baseline": cpu,
+    emit({"roofline": roof, "cpu_baseline": cpu,
         "metric": "audio-seconds/sec chain inference (whole job)", "value": round(world * batch * CLIP / SR * args.steps / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": DTYPES[args.gemm],
         "data": "synthetic", "config": {"workload": "RemFX-detect chain inference (+exp=remfx_detect), inference only",
                                         "clips_per_gpu": batch, "clip_samples": CLIP, "sample_rate": SR,
-                                        "removal_model_applications_per_step": napplied, "parallelism": f"dp{world}"}}))
+                                        "removal_model_applications_per_step": napplied, "parallelism": f"dp{world}"}},
+         f"chain_{args.gemm}_b{batch}_n{world}")
 
 
 def measure_demucs_fwd(model, x, steps, warmup, gemm, world=1):
@@ -462,9 +546,12 @@ def measure_demucs_fwd(model, x, steps, warmup, gemm, world=1):
     dt = float(t) / steps
     batch = x.shape[0]
     flops = batch * (117.2e9 + 0.13e9)
-    nbytes = batch * 396e6 + 334e6                                  # fp32 layer-boundary bytes + weights once
+    # layer-boundary bytes in the width the mode stores activations in (396 MB fp32 / 198 MB 16-bit per clip) + weights once
+    nbytes32 = batch * 396e6 + 334e6
+    nbytes = (batch * 198e6 + 334e6) if gemm == "bf16" else nbytes32
     mfma_peak = {"f32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[gemm]
     f_hbm, f_mfma = nbytes / dt / 1e9 / PEAK_HBM_GBS, flops / dt / 1e12 / mfma_peak
+    f_hbm32 = nbytes32 / dt / 1e9 / PEAK_HBM_GBS
     # the HBM-bound end stages (SURVEY 8d "STFT-only sub-metric"): _spec reads B*T*4 and writes (B, 2, nfft/2, T/hop) fp32;
     # _ispec the reverse
     end_bytes = batch * CLIP * 4 + batch * 2 * 2048 * 256 * 4
@@ -476,7 +563,7 @@ def measure_demucs_fwd(model, x, steps, warmup, gemm, world=1):
     unet_ms = dt * 1e3 - stages["stft"]["ms"] - stages["istft"]["ms"]
     stages["unet"] = {"ms": round(unet_ms, 3), "frac_hbm": round((nbytes - 2 * end_bytes) / (unet_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                       "frac_mfma": round(batch * 117.2e9 / (unet_ms * 1e-3) / 1e12 / mfma_peak, 4)}
-    return {"seconds": dt, "flops": flops, "bytes": nbytes, "frac_hbm": f_hbm, "frac_mfma": f_mfma, "mfma_peak": mfma_peak,
+    return {"seconds": dt, "flops": flops, "bytes": nbytes, "frac_hbm": f_hbm, "frac_hbm_fp32_bytes": f_hbm32, "frac_mfma": f_mfma, "mfma_peak": mfma_peak,
             "stages": stages, "output_rms": float(out.float().pow(2).mean().sqrt())}
 
 
@@ -492,7 +579,7 @@ def bench_demucs_fwd(args, rank, world, device):
         return
     dt, f_hbm, f_mfma = m["seconds"], m["frac_hbm"], m["frac_mfma"]
     bound = "hbm" if f_hbm >= f_mfma else "mfma"
-    print(json.dumps({
+    emit({
         "metric": "audio-seconds/sec STFT + Demucs forward (whole job)", "value": round(world * batch * CLIP / SR / dt, 3),
         "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -503,8 +590,9 @@ def bench_demucs_fwd(args, rank, world, device):
         "roofline": {"bound": bound, "achieved": round(m["bytes"] / dt / 1e9, 1) if bound == "hbm" else round(m["flops"] / dt / 1e12, 2),
                      "peak": PEAK_HBM_GBS if bound == "hbm" else m["mfma_peak"], "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                      "frac": round(max(f_hbm, f_mfma), 4), "frac_hbm": round(f_hbm, 4), "frac_mfma": round(f_mfma, 4),
+                     "frac_hbm_fp32_bytes": round(m["frac_hbm_fp32_bytes"], 4),
                      "algorithmic_bytes_per_pass": m["bytes"], "algorithmic_flops_per_pass": m["flops"], "traffic": None,
-                     "stages": m["stages"]}}))
+                     "stages": m["stages"]}}, f"demucs_fwd_{args.gemm}_b{batch}_n{world}")
 
 
 def also_block(args, model, opt, sched, sync, data, device, step):
@@ -535,7 +623,8 @@ def also_block(args, model, opt, sched, sync, data, device, step):
     m = measure_demucs_fwd(model, data[0], max(3, min(args.steps, 10)), 2, args.gemm)
     res["demucs_fwd"] = {"metric": "audio-seconds/sec STFT + Demucs forward", "ms_per_pass": round(m["seconds"] * 1e3, 3),
                          "audio_seconds_per_sec": round(data[0].shape[0] * CLIP / SR / m["seconds"], 3), "dtype": DTYPES[args.gemm],
-                         "frac_hbm": round(m["frac_hbm"], 4), "frac_mfma": round(m["frac_mfma"], 4),
+                         "frac_hbm": round(m["frac_hbm"], 4), "frac_hbm_fp32_bytes": round(m["frac_hbm_fp32_bytes"], 4),
+                         "frac_mfma": round(m["frac_mfma"], 4),
                          "algorithmic_bytes_per_pass": m["bytes"], "algorithmic_flops_per_pass": m["flops"], "stages": m["stages"],
                          "target": "north_star: >= 0.5 of the HBM roofline on STFT + Demucs forward at 64 x 262144"}
     return res
@@ -578,6 +667,8 @@ def main():
     ap.add_argument("--no-enc-z16-time", action="store_true", help="A/B: time-branch encoder conv outputs stored as fp32 (hdemucs.ENC_Z16_TIME)")
     ap.add_argument("--no-enc-z16", action="store_true", help="A/B: encoder conv outputs stored as fp32 (hdemucs.ENC_Z16)")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (bf16x3 step + Demucs forward sub-metric)")
+    ap.add_argument("--no-exclusive", action="store_true",
+                    help="skip the 3 extra one-stream steps the dominant kernel is picked and priced on (profiling runs: keeps them out of the trace)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch plan / algorithmic work / event time list of the timed steps (JSON)")
     ap.add_argument("--union-ranks", type=int, default=0,
                     help="single process only: train on the concatenation of the synthetic batches ranks 0..N-1 would "
@@ -731,7 +822,7 @@ def main():
     excl = None
     t_x0 = time.time()
     sink = getattr(opt.flat, "sink", None)
-    if rank == 0 and world == 1 and sink is not None and sink.side is not None and not args.no_also:
+    if rank == 0 and world == 1 and sink is not None and sink.side is not None and not args.no_exclusive:
         timer2 = KernelTimer(ops.PREC_NAMES[args.gemm])
         timer2.install()
         from remfx_amd import hdemucs as _hd, models as _md
@@ -871,7 +962,11 @@ def main():
     # where the wall time of this process went (seconds; `timed` is the K steps `value` is computed from, everything else is untimed)
     PHASES["total"] = round(time.time() - T_PROC0, 2)
     out["phases_s"] = PHASES
-    print(json.dumps(out))
+    tot_traffic = None
+    if cands:
+        tot_traffic = json.load(open(cands[-1])).get("total_bytes_per_step")
+    out["step_roofline"] = dict(step_roofline(args.workload, args.gemm, batch, dt / args.steps, peak, tot_traffic), traffic_source=pmc_file)
+    emit(out, f"{args.workload}_{args.gemm}_b{batch}_n{world}")
 
 
 if __name__ == "__main__":

@@ -43,6 +43,14 @@ def _plain(o):
     return o
 
 
+def digest(cfg):
+    """sha256 of the composed tree as sorted JSON with `${now:...}` timestamps masked (tests/test_host_cpu.py recomputes it)."""
+    import hashlib
+    import re
+    text = re.sub(r"\d{4}-\d\d-\d\d-\d\d-\d\d-\d\d", "<now>", json.dumps(_plain(cfg), sort_keys=True))
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
 def main():
     os.environ.pop("DATASET_ROOT", None)
     os.environ.pop("WANDB_PROJECT", None)
@@ -55,6 +63,20 @@ def main():
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", path, os.path.getsize(path), "bytes")
+    # every experiment and every model file of the reference tree, as digests of the composed dictionary (timestamps masked):
+    # pins the files the 13 command lines above do not touch without committing 400 KB of near-identical trees
+    dig = {}
+    for f in sorted(os.listdir(os.path.join(REF_CFG, "exp"))):
+        argv = ["+exp=" + f[:-5]]
+        dig[" ".join(argv)] = digest(rcfg.compose(REF_CFG, "config.yaml", argv))
+    for f in sorted(os.listdir(os.path.join(REF_CFG, "model"))):
+        argv = ["+exp=5-5_full", "model=" + f[:-5]]
+        dig[" ".join(argv)] = digest(rcfg.compose(REF_CFG, "config.yaml", argv))
+    dig["+exp=default logger=wandb"] = digest(rcfg.compose(REF_CFG, "config.yaml", ["+exp=default", "logger=wandb"]))
+    path = os.path.join(ROOT, "tests", "golden", "cfg_digests.json")
+    with open(path, "w") as f:
+        json.dump(dig, f, indent=1, sort_keys=True)
+    print("wrote", path, len(dig), "digests")
 
 
 if __name__ == "__main__":

@@ -3,15 +3,16 @@
 # command, the two PMC passes (FETCH_SIZE / WRITE_SIZE, counters only, separate runs) turned into per-kernel HBM traffic, then the
 # bench line itself (roofline joined with that traffic, cpu_baseline on).   bash scripts/measure_configs.sh r04
 R=${1:-r04}
+export RFX_BENCH_FULL_DIR=$(pwd)/gpurun_out/$R
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {   # tag, steps-profiled, bench args...
   TAG=$1; NST=$2; shift 2
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$TAG -o kt -- python $ROOT/bench.py "$@" --no-cpu-baseline --no-also --preheat 0 > $OUT/kt_$TAG.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$TAG -o kt -- python $ROOT/bench.py "$@" --no-cpu-baseline --no-also --no-exclusive --preheat 0 > $OUT/kt_$TAG.log 2>&1
   find $OUT/kt_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_${TAG}_kernel_stats.csv \;
   rm -rf $OUT/kt_$TAG
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -o r -- python $ROOT/bench.py "$@" --no-cpu-baseline --no-also --preheat 0 > $OUT/pmc_${TAG}_$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -o r -- python $ROOT/bench.py "$@" --no-cpu-baseline --no-also --no-exclusive --preheat 0 > $OUT/pmc_${TAG}_$c.log 2>&1
     find $OUT/pmc_${TAG}_$c -name "*counter_collection.csv" -exec cp {} $OUT/pmc_${TAG}_$c.csv \;
     rm -rf $OUT/pmc_${TAG}_$c
   done

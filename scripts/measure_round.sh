@@ -5,17 +5,18 @@
 # (the stats cover 2 warm-up + 4 timed steps = 6 steps) turned into the per-kernel HBM traffic JSON, and the bench lines of every workload.  Copy the summaries you want judged
 # into profiles/ afterwards (gpurun_out/ is scratch).
 R=${1:-r03}; MODE=${2:-bf16}
+export RFX_BENCH_FULL_DIR=$(pwd)/gpurun_out/$R
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$MODE -o kt -- python $ROOT/bench.py --steps 4 --warmup 2 --preheat 0 --no-cpu-baseline --no-also --gemm $MODE > $OUT/kt_$MODE.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$MODE -o kt -- python $ROOT/bench.py --steps 4 --warmup 2 --preheat 0 --no-cpu-baseline --no-also --no-exclusive --gemm $MODE > $OUT/kt_$MODE.log 2>&1
 find $OUT/kt_$MODE -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_demucs_b64_kernel_stats_$MODE.csv \;
 rm -rf $OUT/kt_$MODE
 # the one-stream configuration roofline.exclusive is measured in (bench.py picks and prices the dominant kernel there)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1_$MODE -o kt -- python $ROOT/bench.py --one-stream --steps 4 --warmup 2 --preheat 0 --no-cpu-baseline --no-also --gemm $MODE > $OUT/kt1_$MODE.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1_$MODE -o kt -- python $ROOT/bench.py --one-stream --steps 4 --warmup 2 --preheat 0 --no-cpu-baseline --no-also --no-exclusive --gemm $MODE > $OUT/kt1_$MODE.log 2>&1
 find $OUT/kt1_$MODE -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_demucs_b64_kernel_stats_${MODE}_onestream.csv \;
 rm -rf $OUT/kt1_$MODE
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o r -- python $ROOT/bench.py --steps 1 --warmup 1 --preheat 0 --no-cpu-baseline --no-also --gemm $MODE > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o r -- python $ROOT/bench.py --steps 1 --warmup 1 --preheat 0 --no-cpu-baseline --no-also --no-exclusive --gemm $MODE > $OUT/pmc_$c.log 2>&1
   find $OUT/pmc_$c -name "*counter_collection.csv" -exec cp {} $OUT/pmc_$c.csv \;
   rm -rf $OUT/pmc_$c
 done

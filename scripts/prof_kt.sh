@@ -2,7 +2,7 @@
 TAG=${1:-kt}; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 4 --warmup 2 --preheat 0 --no-cpu-baseline --no-also "$@" > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 4 --warmup 2 --preheat 0 --no-cpu-baseline --no-also --no-exclusive "$@" > $OUT/kt.log 2>&1
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/kt -name "*kernel_trace.csv" -exec cp {} /tmp/kernel_trace.csv \;
 rm -rf $OUT/kt

@@ -2,7 +2,7 @@
 # dev: per-kernel VALU occupancy of the Demucs step (SQ counters, one rocprofv3 --pmc pass; kernels are serialised by the profiler)
 mkdir -p gpurun_out/valu; cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $R/gpurun_out/valu/pmc -o out --output-format csv -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --preheat 0 --no-also --sink main > $R/gpurun_out/valu/run.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $R/gpurun_out/valu/pmc -o out --output-format csv -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --preheat 0 --no-also --no-exclusive --sink main > $R/gpurun_out/valu/run.log 2>&1
 cd $R
 python - <<'P' > gpurun_out/valu/summary.txt
 import csv, glob, collections, re

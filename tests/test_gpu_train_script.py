@@ -13,7 +13,7 @@ DEV = "cuda:0"
 
 
 def test_train_script_tcn_two_steps(tmp_path):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train.py"), "+exp=reverb",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train.py"), "+exp=reverb", "model=tcn",
                         "model.network.nblocks=3", "model.network.channel_width=16", "chunk_size=16384",
                         "datamodule.train_batch_size=2", "datamodule.train_dataset.total_chunks=4",
                         "datamodule.val_dataset.total_chunks=2", "datamodule.test_dataset.total_chunks=2", "trainer.max_steps=2",
@@ -144,7 +144,7 @@ def test_gradient_sink_matches_autograd_accumulation():
 def test_test_script_loads_checkpoint_and_evaluates(tmp_path):
     """scripts/test.py (reference scripts/test.py:10-47): strict load of the checkpoint scripts/train.py wrote, then the test
     split -- same metrics as the post-fit test of the training run that produced the checkpoint (same weights, same data)."""
-    common = ["+exp=reverb", "model.network.nblocks=3", "model.network.channel_width=16", "chunk_size=16384",
+    common = ["+exp=reverb", "model=tcn", "model.network.nblocks=3", "model.network.channel_width=16", "chunk_size=16384",
               "datamodule.train_batch_size=2", "datamodule.train_dataset.total_chunks=4", "datamodule.val_dataset.total_chunks=2",
               "datamodule.test_dataset.total_chunks=2", f"logs_dir={tmp_path}"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train.py")] + common + ["trainer.max_steps=2"],

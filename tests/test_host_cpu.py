@@ -97,7 +97,8 @@ def test_config_composer(tmp_path):
 def test_repo_cfg_instantiates_reference_targets():
     """cfg/model/*.yaml use the reference's _target_ strings (remfx.models.RemFX ...)."""
     from remfx_amd import config, models
-    c = config.compose(os.path.join(ROOT, "cfg"), "config.yaml", ["+exp=reverb", "datamodule.train_batch_size=2",
+    c = config.compose(os.path.join(ROOT, "cfg"), "config.yaml", ["+exp=reverb", "model=tcn", "datamodule.train_batch_size=2",
+                                                                   "datamodule.train_dataset.total_chunks=4", "datamodule.num_workers=0",
                                                                    "model.network.nblocks=2", "model.network.channel_width=8"])
     model = config.instantiate(c["model"])
     assert isinstance(model, models.RemFX) and isinstance(model.model, models.TCNModel)
@@ -283,6 +284,72 @@ def test_dynamic_effect_config_instantiates():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="renders on the GPU"):
             tr[0]
+
+
+def _cfg_digest(cfg):
+    import hashlib
+    import json
+    import re
+    plain = lambda o: ({str(k): plain(v) for k, v in o.items()} if isinstance(o, dict) else
+                       [plain(v) for v in o] if isinstance(o, (list, tuple)) else o)
+    text = re.sub(r"\d{4}-\d\d-\d\d-\d\d-\d\d-\d\d", "<now>", json.dumps(plain(cfg), sort_keys=True))
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+def test_own_cfg_tree_matches_reference_composition(monkeypatch):
+    """The repo's OWN cfg/ (written by scripts/write_cfg_tree.py) composes every command line of BASELINE.md section 5 -- incl.
+    config 4's `+exp=5-5_full model=dcunet` -- to exactly the dictionary the reference's tree gives (tests/golden/cfg_composed.json,
+    recorded from /root/reference/cfg), and every experiment / model / logger file of the tree to the recorded digest
+    (tests/golden/cfg_digests.json): no REMFX_CFG_DIR needed."""
+    import json
+    from remfx_amd import config
+    for v in ("DATASET_ROOT", "WANDB_PROJECT", "WANDB_ENTITY"):
+        monkeypatch.delenv(v, raising=False)
+    own = os.path.join(ROOT, "cfg")
+    for name, rec in _composed().items():
+        assert _cfg_digest(config.compose(own, "config.yaml", rec["argv"])) == _cfg_digest(rec["cfg"]), name
+    with open(os.path.join(ROOT, "tests", "golden", "cfg_digests.json")) as f:
+        digests = json.load(f)
+    assert len(digests) == 45
+    for argv, d in digests.items():
+        assert _cfg_digest(config.compose(own, "config.yaml", argv.split())) == d, argv
+    n_files = sum(len(fs) for _, _, fs in os.walk(own))
+    assert n_files == 48                                   # config + 28 experiments + 16 models + effects + 2 loggers
+
+
+def test_bench_final_line_is_compact(tmp_path, monkeypatch, capsys):
+    """bench.py's last stdout line is what the driver parses: one JSON object under 4 KB with the contract's keys, whatever the
+    size of the full record (which goes to a file).  Round 5's 24 KB line was unparseable for the driver."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("RFX_BENCH_FULL_DIR", str(tmp_path))
+    fat = [{"kernel": f"cl_conv_kernel<{i}, 3, 2, 2, 3, 1, 2, 4, true>", "frac": 0.1, "pad": "x" * 300} for i in range(80)]
+    out = {"metric": "audio-seconds/sec fwd+bwd (whole job)", "value": 3500.0, "unit": "audio-seconds/sec", "n_gpus": 1, "steps": 20,
+           "warmup": 5, "ms_per_step": 99.0, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "bf16 (fp32 accumulate)", "data": "synthetic",
+           "config": {"workload": "Hybrid Demucs", "clips_per_gpu": 64, "global_batch": 64, "parallelism": "dp1", "junk": fat},
+           "roofline": {"bound": "mfma", "kernel": "k", "achieved": 1.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.2, "frac_mfma": 0.2,
+                        "frac_hbm": 0.1, "traffic": 1, "algorithmic_bytes_per_launch": 1, "avg_launch_us": 1.0, "launches_per_step": 1.0,
+                        "by_kernel": fat},
+           "step_roofline": bench.step_roofline("demucs", "bf16", 64, 0.099, 2500.0, 337e9),
+           "cpu_baseline": {"value": 4.0, "unit": "audio-seconds/sec", "cores": 32, "kind": "port", "sample": "s" * 1000},
+           "phases_s": {"timed": 2.0}}
+    bench.emit(out, "unit")
+    line = capsys.readouterr().out.strip().splitlines()[-1]
+    assert len(line) < 4096
+    rec = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "step_roofline"):
+        assert k in rec, k
+    assert "by_kernel" not in rec["roofline"] and rec["config"]["workload"] == "Hybrid Demucs"
+    sr = rec["step_roofline"]
+    assert abs(sr["frac_mfma"] - 3 * 117.33e9 * 64 / 0.099 / 2.5e15) < 1e-3 and sr["traffic_ratio"] > 5
+    full = json.load(open(os.path.join(tmp_path, "bench_full_unit.json")))
+    assert len(full["roofline"]["by_kernel"]) == 80
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/cfg"), reason="reference tree only exists in the build container")
