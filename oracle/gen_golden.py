@@ -61,7 +61,7 @@ def install_shims():
     sys.modules["asteroid"].models = sys.modules["asteroid.models"]
     _mod("umx.openunmix.model", OpenUnmix=object, Separator=object)
     tm = _mod("torchmetrics")
-    tm.classification = _mod("torchmetrics.classification", Accuracy=lambda **k: nn.Identity(),
+    tm.classification = _mod("torchmetrics.classification", Accuracy=lambda **k: _BinaryAccuracy(),
                              MultilabelF1Score=lambda *a, **k: nn.Identity())
     al = _mod("auraloss")
     al.time = _mod("auraloss.time", SISDRLoss=_SISDR)
@@ -88,6 +88,12 @@ class _MelStandIn(nn.Module):
 
     def forward(self, x):
         return ref_cnn14.mel_spectrogram(x, *self.a)
+
+
+class _BinaryAccuracy(nn.Module):
+    """torchmetrics.classification.Accuracy(task="binary") on one batch of probabilities: mean((p > 0.5) == target)."""
+    def forward(self, preds, target):
+        return ((preds > 0.5).float() == target.float()).float().mean()
 
 
 class _MRSTFT(nn.Module):
@@ -311,12 +317,78 @@ def gen_flow():
     print("flow", sorted(logged), float(loss), sorted(chain.logged))
 
 
+def tiny_heads_state(seed=5):
+    """Weights of the 5-head stand-in network of the mixup fixture (three waveform statistics -> sigmoid(linear) per head)."""
+    g = torch.Generator().manual_seed(seed)
+    return {"w": torch.randn(5, 3, generator=g), "b": 0.1 * torch.randn(5, generator=g)}
+
+
+def tiny_heads_forward(x, w, b):
+    """x (B, 1, T) -> list of 5 (B, 1) probabilities; shared by the fixture generator and tests/ (deterministic, no dropout)."""
+    f = torch.stack([x.abs().mean((1, 2)), x.pow(2).mean((1, 2)).sqrt(), x.amax((1, 2))], 1) * 4.0      # (B, 3)
+    z = f @ w.t() + b
+    return [torch.sigmoid(z[:, k:k + 1]) for k in range(5)]
+
+
+def gen_mixup():
+    """`mixup` and the mixup branch of FXClassifier.common_step (remfx/models.py:393-420, 491-500) of the imported reference,
+    seeded: numpy draws lambda ~ U(0.25, 0.75) per item, then ONE numpy uniform decides whether to mix, then torch.randperm picks
+    the partners; labels are OR-ed.  Several seeds so that both branches occur.  The network is a deterministic 5-head stand-in
+    subclassing the reference's Cnn14 (the reference tests isinstance(network, Cnn14) to pick BCELoss + per-effect accuracy)."""
+    sys.modules.setdefault("remfx.effects", _mod("remfx.effects", Pedalboard_Effects=[
+        type(n, (), {}) for n in ("RandomPedalboardReverb", "RandomPedalboardChorus", "RandomPedalboardDelay",
+                                  "RandomPedalboardDistortion", "RandomPedalboardCompressor")]))
+    import remfx.models as rm
+    import remfx.classifier as rc
+    rec = {}
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(6, 1, 256, generator=g) * 0.3
+    y = (torch.rand(6, 5, generator=g) > 0.6).float()
+    rec["x"], rec["y"] = x.numpy(), y.numpy()
+    mixed_any = plain_any = False
+    seeds = list(range(8))
+    for s in seeds:
+        np.random.seed(s)
+        torch.manual_seed(s)
+        mx, my, lam = rm.mixup(x, y)
+        did = not (mx is x)
+        mixed_any |= did
+        plain_any |= not did
+        rec[f"mx{s}"], rec[f"my{s}"], rec[f"lam{s}"], rec[f"did{s}"] = mx.numpy(), my.numpy(), lam.numpy(), np.bool_(did)
+    assert mixed_any and plain_any
+    rec["seeds"] = np.array(seeds)
+
+    class Tiny(rc.Cnn14):
+        def __init__(self, st):
+            nn.Module.__init__(self)
+            self.w, self.b = nn.Parameter(st["w"].clone()), nn.Parameter(st["b"].clone())
+
+        def forward(self, z, train=False):
+            return tiny_heads_forward(z, self.w, self.b)
+    st = tiny_heads_state()
+    for s in (1, 4):                                  # one seed of each branch (asserted below)
+        net = Tiny(st)
+        cls = rm.FXClassifier(3e-4, 1e-3, 48000, net, mixup=True)
+        np.random.seed(s)
+        torch.manual_seed(s)
+        loss = cls.training_step((x, None, None, y), 0)
+        loss.backward()
+        rec[f"cls_loss{s}"] = np.float32(loss.item())
+        rec[f"cls_gw{s}"], rec[f"cls_gb{s}"] = net.w.grad.numpy(), net.b.grad.numpy()
+        names = sorted(cls.logged)
+        rec[f"cls_log_names{s}"] = np.array(names)
+        rec[f"cls_log_vals{s}"] = np.array([cls.logged[k] for k in names], dtype=np.float32)
+    assert bool(rec["did1"]) != bool(rec["did4"]), (rec["did1"], rec["did4"])
+    np.savez_compressed(os.path.join(OUT, "mixup.npz"), **rec)
+    print("mixup", [bool(rec[f"did{s}"]) for s in seeds], float(rec["cls_loss1"]), float(rec["cls_loss4"]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     only = sys.argv[1:]                      # e.g. `python oracle/gen_golden.py tcn_full` regenerates one fixture
     for name, fn in (("utils", gen_utils), ("tcn", gen_tcn), ("tcn_full", gen_tcn_full), ("tcn_full_length", gen_tcn_full_length),
                      ("cnn14", gen_cnn14),
-                     ("flow", gen_flow)):
+                     ("flow", gen_flow), ("mixup", gen_mixup)):
         if not only or name in only:
             fn()

@@ -235,22 +235,23 @@ class DPTNetModel(_RemovalWrapper):
 
 
 def mixup(x: torch.Tensor, y: torch.Tensor, alpha: float = 1.0):
-    """models.py:393-420: per-item lambda ~ U(0.25, 0.75), applied with probability 0.5; labels are
-    the logical OR of the two clips (not a lambda blend)."""
+    """Mixup for time-domain clips, reference `remfx/models.py:393-420`.  The RANDOM-DRAW ORDER is the contract (the fixture
+    `tests/golden/mixup.npz` replays it from the imported reference): (1) numpy: one weight per clip, lambda ~ U(0.25, 0.75)
+    (only when alpha > 0; otherwise lambda = 1); (2) numpy: one uniform, mix iff it exceeds 0.5; (3) torch (CPU generator):
+    `randperm(B)` picks each clip's partner -- drawn only on the mixing path.  A mixed clip is `lambda x + (1 - lambda) x[partner]`,
+    its label vector the logical OR of the two label vectors (not a lambda blend).  Returns
+    `(clips, labels, lambda)`; on the non-mixing path the inputs come back as they are."""
     import numpy as np
-    batch_size = x.size(0)
+    n = x.size(0)
+    weights = 1
     if alpha > 0:
-        lam = np.random.uniform(0.25, 0.75, batch_size)
-        lam = torch.from_numpy(lam).float().to(x.device).view(batch_size, 1, 1)
-    else:
-        lam = 1
-    if np.random.rand() > 0.5:
-        index = torch.randperm(batch_size).to(x.device)
-        mixed_x = lam * x + (1 - lam) * x[index, :]
-        mixed_y = torch.logical_or(y, y[index, :]).float()
-    else:
-        mixed_x, mixed_y = x, y
-    return mixed_x, mixed_y, lam
+        weights = torch.from_numpy(np.random.uniform(0.25, 0.75, n)).float().to(x.device).view(n, 1, 1)
+    if not np.random.rand() > 0.5:
+        return x, y, weights
+    partner = torch.randperm(n).to(x.device)
+    blended = weights * x + (1 - weights) * x[partner, :]
+    either = torch.logical_or(y, y[partner, :]).float()
+    return blended, either, weights
 
 
 def _multilabel_f1(probs, target, threshold=0.5):

@@ -456,3 +456,65 @@ def test_missing_checkpoint_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setenv("RFX_ALLOW_RANDOM_INIT", "1")
     with pytest.warns(UserWarning):
         assert load_checkpoint_file(str(tmp_path / "nope.ckpt")) is None
+
+
+def _mixup_case():
+    import numpy as np
+    from oracle.gen_golden import tiny_heads_forward, tiny_heads_state      # the fixture's stand-in network (pure torch, no reference import)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "mixup.npz"))
+    return g, tiny_heads_forward, tiny_heads_state
+
+
+def test_mixup_replays_reference_draws():
+    """`remfx_amd.models.mixup` against the seeded fixture recorded from the imported reference (oracle/gen_golden.py::gen_mixup;
+    reference remfx/models.py:393-420): same numpy / torch draw order, so the same per-clip weights, the same mixing decision, the same
+    partners; labels OR-ed.  Eight seeds, both branches."""
+    import numpy as np
+    from remfx_amd.models import mixup
+    g, _, _ = _mixup_case()
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    branches = set()
+    for s in g["seeds"]:
+        np.random.seed(int(s))
+        torch.manual_seed(int(s))
+        mx, my, lam = mixup(x, y)
+        branches.add(bool(g[f"did{s}"]))
+        assert (mx is x) == (not bool(g[f"did{s}"]))
+        assert torch.equal(lam, torch.from_numpy(g[f"lam{s}"])) and torch.equal(my, torch.from_numpy(g[f"my{s}"]))
+        assert torch.equal(mx, torch.from_numpy(g[f"mx{s}"])), s             # same arithmetic order -> bit equal on the CPU
+    assert branches == {True, False}
+    np.random.seed(0)
+    assert mixup(x, y, alpha=0.0)[2] == 1                                    # alpha <= 0: no weights drawn
+
+
+def test_fxclassifier_mixup_training_branch_matches_reference():
+    """The mixup branch of `FXClassifier.common_step` (reference remfx/models.py:491-500): loss = sum over the 5 heads of BCE against
+    the OR-ed labels of the MIXED clips, accuracies against the unmixed labels; loss, parameter gradients and every logged scalar of
+    both branches against the values recorded from the reference's own class."""
+    import numpy as np
+    from remfx_amd.classifier import Cnn14
+    from remfx_amd.models import FXClassifier
+    g, heads_forward, heads_state = _mixup_case()
+
+    class Tiny(Cnn14):                                 # isinstance(network, Cnn14) selects BCELoss + per-effect accuracy, as upstream
+        def __init__(self, st):
+            torch.nn.Module.__init__(self)
+            self.w, self.b = torch.nn.Parameter(st["w"].clone()), torch.nn.Parameter(st["b"].clone())
+
+        def forward(self, z, train=False):
+            return heads_forward(z, self.w, self.b)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    for s in (1, 4):
+        net = Tiny(heads_state())
+        cls = FXClassifier(3e-4, 1e-3, 48000, net, mixup=True)
+        np.random.seed(s)
+        torch.manual_seed(s)
+        loss = cls.training_step((x, None, None, y), 0)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"cls_loss{s}"])) < 1e-6 * max(1.0, abs(float(loss)))
+        assert torch.allclose(net.w.grad, torch.from_numpy(g[f"cls_gw{s}"]), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(net.b.grad, torch.from_numpy(g[f"cls_gb{s}"]), rtol=1e-5, atol=1e-7)
+        names = sorted(cls.logged)
+        assert names == list(g[f"cls_log_names{s}"])
+        got = np.array([float(cls.logged[k]) for k in names], dtype=np.float32)
+        assert np.allclose(got, g[f"cls_log_vals{s}"], rtol=1e-5, atol=1e-6), (names, got, g[f"cls_log_vals{s}"])
