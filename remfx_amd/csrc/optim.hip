@@ -3,6 +3,10 @@
 // and AdamW (models.py:185-191: betas (0.95, 0.999), eps 1e-6, weight_decay 1e-3).
 // HBM-bound: 4 streams read (p, g, m, v), 3 written, float4 grid-stride.
 #include "common.h"
+#include <cstdlib>
+
+// rfx_zero: buffers up to this size are reduction targets (statistics, loss sums, counters) and are filled write-through
+constexpr int64_t RFX_ZERO_WT_MAX_BYTES = 4 << 20;
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
   double acc = 0.0;
@@ -52,6 +56,15 @@ __global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, int
   if (tail0 + gid < nwords) p[tail0 + gid] = 0u;
 }
 
+// Write-through zero fill: every word leaves as an agent-scope store (`global_store_dword ... sc1`), i.e. it is performed at the
+// memory side of the XCDs' L2s instead of sitting in one XCD's L2 as a dirty line until the end-of-kernel write-back.  For buffers
+// that agent-scope ATOMICS of a following kernel accumulate into (those execute at memory too): DESIGN.md 4.10.
+__global__ __launch_bounds__(256) void zero_wt_kernel(uint32_t* __restrict__ p, int64_t nwords) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride)
+    __hip_atomic_store(p + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // coef = min(1, max_norm / (sqrt(sumsq * pre^2) + 1e-6)) * pre      (torch clip_grad_norm_ semantics;
 // pre = scale already owed to the gradients, e.g. 1/world_size after a summing all-reduce)
 __global__ void clip_coef_kernel(const double* __restrict__ sumsq, float max_norm, float pre, float* __restrict__ coef,
@@ -71,6 +84,14 @@ extern "C" int rfx_zero(void* p, int64_t nbytes, void* stream) {
   if (nbytes < 0 || (nbytes & 3) || (nbytes && !p) || (reinterpret_cast<uintptr_t>(p) & 3)) return -1;
   if (nbytes == 0) return 0;
   const int64_t nwords = nbytes >> 2;
+  static const int wt_mode = [] { const char* e = getenv("RFX_ZERO_WT"); return e ? atoi(e) : 0; }();   // dev A/B (scripts/probes/zero_wt_ab.sh): 0 never (default), 1 small buffers, 2 always
+  if (wt_mode == 2 || (wt_mode == 1 && nbytes <= (int64_t)RFX_ZERO_WT_MAX_BYTES)) {
+    const int64_t bw = (nwords + 1023) / 1024;
+    hipLaunchKernelGGL(zero_wt_kernel, dim3((unsigned)(bw < 1 ? 1 : (bw > 4096 ? 4096 : bw))), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<uint32_t*>(p), nwords);
+    RFX_CHECK_LAUNCH();
+    return 0;
+  }
   const int64_t b = (nwords + 4095) / 4096;                       // four 16-byte stores per thread
   hipLaunchKernelGGL(zero_kernel, dim3((unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b))), dim3(256), 0, (hipStream_t)stream,
                      static_cast<uint32_t*>(p), nwords);

@@ -15,8 +15,17 @@ from . import ddp
 
 
 class CSVLogger:
-    def __init__(self, save_dir="./logs", name="", version=None, **_):
-        self.path = os.path.join(save_dir, name or "", "metrics.csv")
+    """pytorch_lightning.loggers.CSVLogger as cfg/logger/csv.yaml configures it (`save_dir: "."`, `version: ${now:...}`):
+    rows go to `<save_dir>/<name>/<version>/metrics.csv`, `name` defaulting to Lightning's "lightning_logs", an integer or missing
+    version spelled `version_<n>` (the next free n when missing); `name=""` drops that directory level, as in Lightning."""
+
+    def __init__(self, save_dir="./logs", name="lightning_logs", version=None, **_):
+        base = os.path.join(str(save_dir), name or "")
+        if version is None:
+            taken = [int(d[8:]) for d in (os.listdir(base) if os.path.isdir(base) else []) if d.startswith("version_") and d[8:].isdigit()]
+            version = max(taken, default=-1) + 1
+        self.log_dir = os.path.join(base, version if isinstance(version, str) else f"version_{version}")
+        self.path = os.path.join(self.log_dir, "metrics.csv")
         self.rows = []
 
     def log(self, step, metrics):

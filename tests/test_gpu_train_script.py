@@ -17,13 +17,14 @@ def test_train_script_tcn_two_steps(tmp_path):
                         "model.network.nblocks=3", "model.network.channel_width=16", "chunk_size=16384",
                         "datamodule.train_batch_size=2", "datamodule.train_dataset.total_chunks=4",
                         "datamodule.val_dataset.total_chunks=2", "datamodule.test_dataset.total_chunks=2", "trainer.max_steps=2",
-                        f"logs_dir={tmp_path}"],
+                        f"logs_dir={tmp_path}", f"logger.save_dir={tmp_path}"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "train_loss" in r.stdout and "valid_loss" in r.stdout and "test_loss" in r.stdout
     ck = torch.load(os.path.join(tmp_path, "ckpts", "last.ckpt"), map_location="cpu", weights_only=False)
     assert "state_dict" in ck and "model.model.process_blocks.0.conv1.weight" in ck["state_dict"]
-    assert os.path.exists(os.path.join(tmp_path, "csv", "metrics.csv"))
+    import glob
+    assert len(glob.glob(os.path.join(tmp_path, "lightning_logs", "*", "metrics.csv"))) == 1     # cfg/logger/csv.yaml: <save_dir>/lightning_logs/<stamp>/
 
 
 def test_flat_adamw_matches_torch():
