@@ -81,10 +81,10 @@ def emit(out, tag):
     keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_mfma", "frac_hbm", "traffic", "algorithmic_bytes_per_launch",
                  "algorithmic_flops_per_launch", "avg_launch_us", "launches_per_step", "share_of_step", "frac_source")
     c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                             "vs_baseline", "dtype", "data") if k in out}
+                             "vs_baseline", "dtype", "data", "preheat_steps") if k in out}
     cfg = out.get("config", {})
     c["config"] = {k: cfg[k] for k in ("workload", "clips_per_gpu", "global_batch", "clip_samples", "parallelism", "final_loss",
-                                       "rccl_ranks", "exposed_allreduce_ms", "param_abs_sum", "streams",
+                                       "rccl_ranks", "ranks", "dist_backend", "exposed_allreduce_ms", "param_abs_sum", "streams",
                                        "removal_model_applications_per_step") if k in cfg}
     roof = out.get("roofline")
     c["roofline"] = {k: roof[k] for k in keep_roof if k in roof} if roof else None
@@ -635,7 +635,15 @@ def _n_aux_streams(args):
     if args.workload != "demucs":
         return 0
     from remfx_amd import hdemucs as _hd, models as _md
-    return int(_hd.TWO_STREAMS and not _hd._data_parallel()) + int(_md.METRIC_STREAM)
+    sink_on = ops_sink_mode() != "off"
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return int(_hd.TWO_STREAMS and (sink_on or not multi)) + int(_md.METRIC_STREAM)
+
+
+def ops_sink_mode():
+    from remfx_amd import ops
+    return ops.GradSink.MODE
 
 
 def main():
@@ -930,6 +938,8 @@ def main():
                    "dist_backend": torch.distributed.get_backend() if world > 1 else None, "ranks": world,
                    "rccl_ranks": world if (world > 1 and torch.distributed.get_backend() == "nccl") else 0,
                    "exposed_allreduce_ms": round(sync.exposed_ms() / max(args.steps + args.warmup, 1), 3) if hasattr(sync, "exposed_ms") else None,
+                   # streams of the step: compute + weight-gradient (sink side) + time branch + Input_* metrics; the same for every N
+                   "streams": 1 + int(sink is not None and sink.side is not None) + _n_aux_streams(args),
                    "param_abs_sum": param_abs_sum},
         # roofline: the SINGLE dominant kernel instantiation of the step's dominant family (most event-timed ms): achieved =
         # its algorithmic bytes (or flops) per launch / its average launch duration; `bound` = the roof it sits closer to.

@@ -188,8 +188,12 @@ int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const flo
  *   torch.stft(center=True, pad_mode="reflect", onesided) : utils.py:148-154
  *   (spectrogram), HDemucs _spec, auraloss STFTLoss, Separator, MelSpectrogram.
  *   With in_mode=1 / herm=1 it is the backward of the iSTFT.
- * rfx_fft_synthesis: spectrum -> inverse real FFT -> window -> overlap-add (fp32
- *   atomics into a zero-initialised output).  With herm=1 / in_mode=1 it is
+ * rfx_fft_synthesis: spectrum -> inverse real FFT -> window -> overlap-add BY OWNERSHIP
+ *   (round 6: a workgroup walks consecutive frames of a row, carries the incomplete tail
+ *   of the running sum in LDS and stores every output sample exactly once: no atomics,
+ *   no zero fill, bit-reproducible; d->accum selects write / add).  Geometries outside
+ *   that form (extra reflect pads, rows shorter than 2 n_fft in the reflect mode) fall
+ *   back to fp32 atomics into an output the launcher zero-fills itself.  With herm=1 / in_mode=1 it is
  *   torch.istft (HDemucs _ispec, Separator); with herm=0 / in_mode=0 it is the
  *   backward (adjoint) of the STFT.
  * x: [R][T]; frame f covers padded samples [f*hop, f*hop + n_fft); the hann window
@@ -218,6 +222,8 @@ typedef struct rfx_stft_desc {
   int32_t herm;           /* 1: irfft semantics (istft fwd / bwd); 0: plain one-sided rfft adjoint */
   float scale;            /* multiplies every windowed sample */
   float eps, alpha;
+  int32_t accum;          /* synthesis: 0 = every element of out is WRITTEN (no initialisation needed); 1 = out += (the second and
+                             later resolutions of the MR-STFT loss gradient add into the first one's result) */
 } rfx_stft_desc;
 
 int rfx_fft_analysis(const rfx_stft_desc* d, const float* x, const float* window, const float* mul,
@@ -298,17 +304,23 @@ int rfx_prelu_fwd(const float* x, const float* slope, float* y, int64_t N, int64
 int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx, float* gslope,
                   int64_t N, int64_t C, int64_t L, void* stream);
 
-/* out[c] += sum over (n, a, b) of x[n*ns + c*cs + a*as + b*bs]  (bias gradients) */
+/* out[c] = sum over (n, a, b) of x[n*ns + c*cs + a*as + b*bs]  (bias gradients; written, not accumulated).  ws: rfx_channel_sum_ws(...)
+ * doubles of per-workgroup partials (no initialisation needed), added in a fixed order: bit-reproducible. */
+int64_t rfx_channel_sum_ws(const float* x, int32_t N, int32_t C, int32_t A, int32_t B, int64_t ns, int64_t cs, int64_t as, int64_t bs);
 int rfx_channel_sum(const float* x, int32_t N, int32_t C, int32_t A, int32_t B, int64_t ns, int64_t cs,
-                    int64_t as, int64_t bs, float* out, void* stream);
+                    int64_t as, int64_t bs, double* ws, float* out, void* stream);
 
 /* out = x + alpha * y, x / out contiguous (N, C, A, B), y read through element strides (0 = broadcast):
  * skip / inject / frequency-embedding adds inside HDemucs (models.py:319). */
 int rfx_add_bcast(const float* x, const float* y, float* out, int64_t N, int32_t C, int32_t A, int32_t B,
                   int64_t yn, int64_t yc, int64_t ya, int64_t yb, float alpha, void* stream);
-/* per-row mean / unbiased std of x[R][L] (sums: R*2 fp64 workspace) and out = x*a[r] + b[r] (b may be NULL):
- * HDemucs input and spectrogram standardisation / de-standardisation (x.mean/std over dims 1..). */
-int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv, void* stream);
+/* per-row mean / unbiased std of x[R][L] and out = x*a[r] + b[r] (b may be NULL): HDemucs input and spectrogram standardisation /
+ * de-standardisation (x.mean/std over dims 1..).  sums: fp64 workspace of 2 * R * rfx_row_moments_slots(L) values, no initialisation
+ * needed (one slot per workgroup, added in slot order: bit-reproducible, no atomics).  coef_a / coef_b (both or neither): the
+ * standardisation as one affine map, a = 1 / (eps + std), b = -mean * a. */
+int rfx_row_moments_slots(int64_t L);
+int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv, float eps, float* coef_a,
+                    float* coef_b, void* stream);
 int rfx_row_affine(const float* x, const float* a, const float* b, float* out, int32_t R, int64_t L, void* stream);
 
 /* Inverted dropout with a counter-based mask (keep(i) = u24(splitmix64(seed, i)) >= p; out = x / (1 - p) or 0); the backward pass
@@ -330,8 +342,10 @@ int rfx_span_mask(float* x, int32_t R, int32_t F, int32_t T, const int32_t* f0, 
 int rfx_blstm_frames(const float* src, const float* skip, float* dst, int32_t B, int32_t C, int32_t T, int32_t nfr,
                      int32_t width, int32_t stride, int32_t mode, void* stream);
 
-/* sum |a-b| over n elements -> *out (+=, caller zeroes).  nn.L1Loss numerator, models.py:320 */
-int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* out[0] = scale * sum |a-b| over n elements (nn.L1Loss, models.py:320: scale = 1 / n).  ws: RFX_L1_SLOTS doubles of per-workgroup
+ * partials (no initialisation needed), added in slot order. */
+#define RFX_L1_SLOTS 512
+int rfx_l1_sum(const float* a, const float* b, int64_t n, double* ws, float scale, float* out, void* stream);
 
 /* ---- LocalState attention (torchaudio HDemucs `_LocalState` inside the DConv blocks, reached from models.py:319) ----
  * q, k, cont: (B, heads*ch, T) contiguous, channel = head*ch + c; qd: (B, heads*nd, T) raw decay projections.
@@ -517,9 +531,10 @@ int rfx_phase_mask_bwd(const float* xc, const float* gout, float* gmag, int64_t 
 
 /* ---- losses -------------------------------------------------------------------
  * auraloss STFTLoss terms on complex spectra [R][n] (n = bins*frames, view_as_real layout):
- * sums[r] += { sum (|Y|-|X|)^2, sum |Y|^2, sum |log|X| - log|Y|| }, |.| = sqrt(max(re^2+im^2, eps)).
+ * sums[r] = { sum (|Y|-|X|)^2, sum |Y|^2, sum |log|X| - log|Y|| }, |.| = sqrt(max(re^2+im^2, eps)) (written, not accumulated).
  * Replaces auraloss.freq.STFTLoss.forward (models.py:299,320,362,385,107; metrics 237-255). */
-int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R, int64_t n, float eps, float* sums,
+#define RFX_STFT_REDUCE_SLOTS 64      /* ws: 3 * R * RFX_STFT_REDUCE_SLOTS doubles (per-workgroup partials, no initialisation needed) */
+int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R, int64_t n, float eps, double* ws, float* sums,
                          void* stream);
 /* gxc = w_sc * d[sqrt(A_r)/sqrt(B_r)]/dxc + w_lm * d[sum |log|X|-log|Y||]/dxc  (A_r, B_r from sums).  gup (may be NULL): one
  * device float that multiplies both weights -- the upstream gradient of the scalar loss, read on the device so that the backward
@@ -528,26 +543,30 @@ int rfx_stft_loss_grad(const float* xc, const float* yc, int32_t R, int64_t n, f
                        const float* sums, float w_sc, float w_lm, const float* gup, float* gxc, void* stream);
 /* The forward of one STFTLoss resolution in ONE launch (replaces two rfx_fft_analysis + rfx_stft_loss_reduce; auraloss STFTLoss behind
  * models.py:320): two frames of a signal come out of one complex FFT (w s_a + i w s_b), the prediction's clamped powers wait in
- * registers for the target's and the three row sums are accumulated into sums [R][3] (zeroed by the caller) in the epilogue.  d: R, T, n_fft (512 / 1024 / 2048), hop, win, frames_out = 1 + T / hop,
+ * registers for the target's and the three row sums are written to sums [R][3] (every workgroup stores its partial into its own slot of
+ * ws -- rfx_stft_pair_loss_ws(d) doubles, no initialisation needed -- and the slots are added in order: bit-reproducible).  d: R, T, n_fft (512 / 1024 / 2048), hop, win, frames_out = 1 + T / hop,
  * bins = n_fft / 2 + 1, frame0 = 0, in_mode 0.  xspec / ymag (both or neither): the prediction's spectrum, frame-major complex
  * [R][frames][bins][2], and the clamped target magnitudes [R][frames][bins], for rfx_stft_loss_grad_m + rfx_fft_synthesis
  * (RFX_STFT_COMPLEX_FM) in the backward. */
-int rfx_stft_pair_loss(const rfx_stft_desc* d, const float* x, const float* y, const float* window, float eps, float* sums,
+int64_t rfx_stft_pair_loss_ws(const rfx_stft_desc* d);
+int rfx_stft_pair_loss(const rfx_stft_desc* d, const float* x, const float* y, const float* window, float eps, double* ws, float* sums,
                        float* xspec, float* ymag, void* stream);
 /* rfx_stft_loss_grad with the target given by its clamped magnitudes (rfx_stft_pair_loss's ymag) instead of its spectrum */
 int rfx_stft_loss_grad_m(const float* xc, const float* ymag, int32_t R, int64_t n, float eps, const float* sums, float w_sc,
                          float w_lm, const float* gup, float* gxc, void* stream);
 /* rfx_stft_loss_grad_m followed by rfx_fft_synthesis (in_mode 0, herm 0, RFX_STFT_COMPLEX_FM) in ONE launch: the gradient spectrum
  * is computed where the inverse transform's merge step loads it (same arithmetic, instruction for instruction) and never written --
- * 1.15 GB of the 64-clip step's traffic per resolution.  d as for rfx_fft_synthesis; out accumulates (zeroed by the caller).
+ * 1.15 GB of the 64-clip step's traffic per resolution.  d as for rfx_fft_synthesis (d->accum: write / add).
  * The backward of auraloss STFTLoss behind models.py:320. */
 int rfx_fft_synthesis_lossgrad(const rfx_stft_desc* d, const float* xspec, const float* ymag, const float* sums, float w_sc,
                                float w_lm, float eps, const float* gup, const float* window, float* out, void* stream);
 /* g[i] = w * gup[0] * sign(a[i] - b[i])   (nn.L1Loss backward; gup as above, NULL = 1) */
 int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, const float* gup, float* g, void* stream);
-/* per row: sums[r] += { sum x, sum t, sum x t, sum x^2, sum t^2 } in fp64 (auraloss SISDRLoss) */
+/* per row: sums[r] = { sum x, sum t, sum x t, sum x^2, sum t^2 } in fp64 (auraloss SISDRLoss).  ws: 5 * R * RFX_SISDR_SLOTS doubles of
+ * per-workgroup partials (no initialisation needed), added in slot order. */
+#define RFX_SISDR_SLOTS 128
 int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t L, int64_t x_rs, int64_t t_rs,
-                   double* sums, void* stream);
+                   double* ws, double* sums, void* stream);
 /* The scalar tail of SISDRLoss in one launch: out[0] = -mean_r 10 log10(|a t|^2 / (|x - a t|^2 + eps) + eps), a = <x,t> / (|t|^2 + eps),
  * from the row sums of rfx_sisdr_sums (row means removed when zero_mean); auraloss SISDRLoss behind models.py:227-255. */
 int rfx_sisdr_finish(const double* sums, int32_t R, int64_t L, int32_t zero_mean, double eps, float* out, void* stream);
@@ -560,11 +579,13 @@ int rfx_mrstft_combine(const float* const* sums, const int64_t* n, int32_t nres,
 
 /* ---- optimiser (flat fp32 buffers) ----------------------------------------------
  * Replaces torch.optim.AdamW.step + Lightning gradient_clip_val (models.py:185-191,
- * cfg/config.yaml:119).  *out += sum g^2 (fp64). */
+ * cfg/config.yaml:119). */
 /* nbytes (multiple of 4) of zeros at p: optimizer.zero_grad() on the flat gradient buffer and the accumulation targets of the
  * atomics-based kernels (torch.zeros call sites of the hot path; Lightning's zero_grad behind models.py:185-191) */
 int rfx_zero(void* p, int64_t nbytes, void* stream);
-int rfx_sumsq(const float* g, int64_t n, double* out, void* stream);
+/* out[0] = sum g^2 (fp64).  ws: RFX_SUMSQ_SLOTS doubles of per-workgroup partials (no initialisation needed), added in slot order */
+#define RFX_SUMSQ_SLOTS 4096
+int rfx_sumsq(const float* g, int64_t n, double* ws, double* out, void* stream);
 /* *coef = min(1, max_norm / (sqrt(*sumsq) * pre + 1e-6)) * pre ; *norm_out = sqrt(*sumsq) * pre */
 int rfx_clip_coef(const double* sumsq, float max_norm, float pre, float* coef, float* norm_out, void* stream);
 /* decoupled-weight-decay Adam, torch.optim.AdamW semantics; gradients are multiplied by

@@ -91,7 +91,7 @@ class StftDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("R", "T", "n_fft", "hop", "win", "bins", "frame0", "frames_out",
                                          "mode", "extra_pad_l", "extra_pad_r", "in_mode", "in_offset",
                                          "herm")] + \
-               [(n, C.c_float) for n in ("scale", "eps", "alpha")]
+               [(n, C.c_float) for n in ("scale", "eps", "alpha")] + [("accum", C.c_int32)]
 
 
 class ClTensor(C.Structure):
@@ -137,17 +137,18 @@ SIGNATURES = {
     "rfx_gemm_wgrad": [C.POINTER(GemmDesc), _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I32, _P],
     "rfx_fft_analysis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
     "rfx_fft_synthesis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
-    "rfx_stft_loss_reduce": [_P, _P, _I32, _I64, C.c_float, _P, _P],
+    "rfx_stft_loss_reduce": [_P, _P, _I32, _I64, C.c_float, _P, _P, _P],
     "rfx_stft_loss_grad": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_stft_loss_grad_m": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P, _P],
-    "rfx_stft_pair_loss": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P],
+    "rfx_stft_pair_loss_ws": [C.POINTER(StftDesc)],
+    "rfx_stft_pair_loss": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P, _P],
     "rfx_fft_synthesis_lossgrad": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P],
     "rfx_l1_grad": [_P, _P, _I64, C.c_float, _P, _P, _P],
-    "rfx_sisdr_sums": [_P, _P, _I32, _I64, _I64, _I64, _P, _P],
+    "rfx_sisdr_sums": [_P, _P, _I32, _I64, _I64, _I64, _P, _P, _P],
     "rfx_sisdr_finish": [_P, _I32, _I64, _I32, C.c_double, _P, _P],
     "rfx_mrstft_combine": [_P, _P, _I32, _I32, _I32, _P, _P],
     "rfx_zero": [_P, _I64, _P],
-    "rfx_sumsq": [_P, _I64, _P, _P],
+    "rfx_sumsq": [_P, _I64, _P, _P, _P],
     "rfx_clip_coef": [_P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_adamw_step": [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P, _P],
     "rfx_groupnorm_stat_chunks": [_I32, _I32, _I32],
@@ -180,7 +181,7 @@ SIGNATURES = {
     "rfx_mul": [_P, _P, _P, _I64, _P],
     "rfx_prelu_fwd": [_P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
-    "rfx_l1_sum": [_P, _P, _I64, _P, _P],
+    "rfx_l1_sum": [_P, _P, _I64, _P, C.c_float, _P, _P],
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "rfx_localstate_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
@@ -205,7 +206,8 @@ SIGNATURES = {
     "rfx_blstm_frames": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "rfx_span_mask": [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_dropout": [_P, _P, _I64, C.c_float, C.c_uint64, _P],
-    "rfx_row_moments": [_P, _I32, _I64, _P, _P, _P, _P],
+    "rfx_row_moments_slots": [_I64],
+    "rfx_row_moments": [_P, _I32, _I64, _P, _P, _P, C.c_float, _P, _P, _P],
     "rfx_row_affine": [_P, _P, _P, _P, _I32, _I64, _P],
     "rfx_lstm_pack_bytes": [_I32],
     "rfx_lstm_pack": [_P, _I32, _P, _P],
@@ -217,7 +219,8 @@ SIGNATURES = {
     "rfx_lstm_fwd": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P],
     "rfx_lstm_bwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _P],
     "rfx_lstm_set_local": [_I32, _I32],
-    "rfx_channel_sum": [_P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _P, _P],
+    "rfx_channel_sum_ws": [_P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64],
+    "rfx_channel_sum": [_P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _P, _P, _P],
     "rfx_cl_conv": [C.POINTER(ClConvDesc), _P],
     "rfx_cl_pack": [_P, _P, _I64, _P, _P],
     "rfx_cl_wgrad_ws_floats": [_P],
@@ -235,7 +238,7 @@ SIGNATURES = {
     "rfx_cl_dconv_bwd": [_P, _P, _P],
 }
 
-_RET64 = {"rfx_cl_wgrad_ws_floats"}
+_RET64 = {"rfx_cl_wgrad_ws_floats", "rfx_stft_pair_loss_ws", "rfx_channel_sum_ws"}
 _lib = None
 
 

@@ -98,3 +98,36 @@ __device__ __forceinline__ double rfx_wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---- deterministic two-stage sums (round 6) -----------------------------------------------------------------------------------
+// A reduction over many workgroups used to end in `atomicAdd` into a zero-filled word: the result depended on the order the
+// workgroups finished in (run-to-run differences in the last bits of every loss / norm / statistic), and the fill + atomics pair lost
+// contributions when a second stream kept the machine busy.  Now every workgroup STORES its partial into its own
+// slot of a caller-owned workspace -- slots[(row * nslots + slot) * K + k], fp64, no initialisation needed -- and
+// rfx_slot_sum_kernel adds a row's slots in slot order: bit-reproducible, no fill, no atomics.
+template <typename OutT>
+__global__ __launch_bounds__(64) void rfx_slot_sum_kernel(const double* __restrict__ slots, int rows, int nslots, int K, OutT* __restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= rows * K) return;
+  const int r = i / K, k = i - r * K;
+  const double* p = slots + (int64_t)r * nslots * K + k;
+  double acc = 0.0;
+  for (int s = 0; s < nslots; ++s) acc += p[(int64_t)s * K];
+  out[i] = (OutT)acc;
+}
+// block-level sum of K per-thread doubles of a 256-thread workgroup into slot `slot` of row `row` (call from all threads)
+template <int K>
+__device__ __forceinline__ void rfx_block_store_slot(const double (&v)[K], double* __restrict__ slots, int row, int nslots, int slot) {
+  __shared__ double rfx_part_[K][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double w = rfx_wave_sum_d(v[k]);
+    if (lane == 0) rfx_part_[k][wave] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int k = threadIdx.x;
+    slots[((int64_t)row * nslots + slot) * K + k] = (rfx_part_[k][0] + rfx_part_[k][1]) + (rfx_part_[k][2] + rfx_part_[k][3]);
+  }
+}

@@ -72,23 +72,24 @@ __global__ void prelu_bwd_kernel(const float* __restrict__ x, const float* __res
   if (threadIdx.x == 0) atomicAdd(gslope + c, part[0] + part[1] + part[2] + part[3]);
 }
 
-__global__ void l1_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
-                              float* __restrict__ out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    acc += (double)fabsf(a[i] - b[i]);
-  acc = rfx_wave_sum_d(acc);
-  __shared__ double part[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) part[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (float)(part[0] + part[1] + part[2] + part[3]));
+__global__ __launch_bounds__(256) void l1_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                     double* __restrict__ slots) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  double acc[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    acc[0] += (double)fabsf(a[i] - b[i]);
+  rfx_block_store_slot<1>(acc, slots, 0, gridDim.x, blockIdx.x);
 }
 
-// out[c] += sum_{n,a,b} x[...]; grid = (C, chunks)
-__global__ void channel_sum_kernel(const float* __restrict__ x, int N, int Cn, int A, int B, int64_t ns,
-                                   int64_t cs, int64_t as, int64_t bs, float* __restrict__ out) {
+__global__ void l1_finish_kernel(const double* __restrict__ slots, int nslots, float scale, float* __restrict__ out) {
+  double acc = 0.0;
+  for (int k = 0; k < nslots; ++k) acc += slots[k];
+  out[0] = (float)acc * scale;          // torch: (fp32 sum) / numel
+}
+
+// slots[c][chunk] = partial sum_{n,a,b} x[...] of the chunk; grid = (C, chunks); added in chunk order by rfx_slot_sum_kernel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int N, int Cn, int A, int B, int64_t ns,
+                                                          int64_t cs, int64_t as, int64_t bs, double* __restrict__ slots) {
   const int c = blockIdx.x;
   const int64_t per = (int64_t)A * B, total = (int64_t)N * per;
   const int64_t chunk = (total + gridDim.y - 1) / gridDim.y;
@@ -108,12 +109,8 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int Cn, i
     r += blockDim.x;
     while (r >= per) { r -= per; ++n; }
   }
-  acc = rfx_wave_sum_d(acc);
-  __shared__ double part[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) part[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out + c, (float)(part[0] + part[1] + part[2] + part[3]));
+  const double v[1] = {acc};
+  rfx_block_store_slot<1>(v, slots, c, gridDim.y, blockIdx.y);
 }
 
 // out[n,c,a,b] = x[n,c,a,b] + alpha * y[n*yn + c*yc + a*ya + b*yb]   (x, out contiguous; y strided, stride 0 =
@@ -131,34 +128,35 @@ __global__ void add_bcast_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
-// per-row mean and UNBIASED std of x[R][L] (fp64 accumulation): HDemucs input / spectrogram standardisation
+// per-row mean and UNBIASED std of x[R][L] (fp64 accumulation): HDemucs input / spectrogram standardisation.
+// Every workgroup stores its pair into its own slot (sums[r][slot][2]); the finalize kernel adds a row's slots in order.
 __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ x, int64_t L, double* __restrict__ sums) {
   const int r = blockIdx.y;
   const float* xr = x + (int64_t)r * L;
-  double p = 0.0, q = 0.0;
+  double v[2] = {0.0, 0.0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L; i += (int64_t)gridDim.x * 256) {
-    const double v = xr[i];
-    p += v; q += v * v;
+    const double t = xr[i];
+    v[0] += t; v[1] += t * t;
   }
-  p = rfx_wave_sum_d(p); q = rfx_wave_sum_d(q);
-  __shared__ double part[2][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { part[0][wave] = p; part[1][wave] = q; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(sums + 2 * r, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-    atomicAdd(sums + 2 * r + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
-  }
+  rfx_block_store_slot<2>(v, sums, r, gridDim.x, blockIdx.x);
 }
-__global__ void row_moments_finalize_kernel(const double* __restrict__ sums, int R, double L, float* __restrict__ mean,
-                                            float* __restrict__ stdv) {
+__global__ void row_moments_finalize_kernel(const double* __restrict__ sums, int R, int nslots, double L, float* __restrict__ mean,
+                                            float* __restrict__ stdv, float eps, float* __restrict__ coef_a, float* __restrict__ coef_b) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
-  const double m = sums[2 * r] / L;
-  double var = (sums[2 * r + 1] - L * m * m) / (L - 1.0);
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nslots; ++k) { s1 += sums[2 * ((int64_t)r * nslots + k)]; s2 += sums[2 * ((int64_t)r * nslots + k) + 1]; }
+  const double m = s1 / L;
+  double var = (s2 - L * m * m) / (L - 1.0);
   var = var > 0.0 ? var : 0.0;
-  mean[r] = (float)m;
-  stdv[r] = (float)sqrt(var);
+  const float mf = (float)m, sf = (float)sqrt(var);
+  mean[r] = mf;
+  stdv[r] = sf;
+  if (coef_a) {                        // the standardisation as one affine map: y = x a + b, a = 1 / (eps + std), b = -mean a
+    const float a = 1.0f / (eps + sf);
+    coef_a[r] = a;
+    coef_b[r] = -mf * a;
+  }
 }
 // out[r][i] = x[r][i] * a[r] + b[r]
 __global__ void row_affine_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
@@ -326,10 +324,15 @@ extern "C" int rfx_prelu_bwd(const float* x, const float* gy, const float* slope
   RFX_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out, void* stream) {
-  if (!a || !b || !out || n < 0) return -1;
+// out[0] = scale * sum |a - b|; ws: RFX_L1_SLOTS doubles (per-workgroup partials, no initialisation needed)
+extern "C" int rfx_l1_sum(const float* a, const float* b, int64_t n, double* ws, float scale, float* out, void* stream) {
+  if (!a || !b || !out || !ws || n < 0) return -1;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(l1_sum_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+  int g = grid_for(n);
+  g = g > RFX_L1_SLOTS ? RFX_L1_SLOTS : g;
+  hipLaunchKernelGGL(l1_sum_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, b, n, ws);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ws, g, scale, out);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -338,7 +341,7 @@ extern "C" int rfx_l1_sum(const float* a, const float* b, int64_t n, float* out,
 // lanes (<= 4096 values per lane) and goes to fp64 for the cross-lane / cross-workgroup part.  The strided kernel above walks single
 // dwords and measured 1.9 TB/s on the transposed-conv bias gradients (r02 profile).
 __global__ __launch_bounds__(256) void channel_sum_plane_kernel(const float* __restrict__ x, int nseg, int64_t per, int64_t ns,
-                                                                int64_t cs, float* __restrict__ out) {
+                                                                int64_t cs, double* __restrict__ slots) {
   const int c = blockIdx.x, n = blockIdx.y / nseg, sg = blockIdx.y - n * nseg;
   const int64_t per4 = per >> 2, seg4 = (per4 + nseg - 1) / nseg;
   const int64_t q0 = (int64_t)sg * seg4, q1 = q0 + seg4 < per4 ? q0 + seg4 : per4;
@@ -356,34 +359,41 @@ __global__ __launch_bounds__(256) void channel_sum_plane_kernel(const float* __r
   for (; q < q1; q += 256) { const f32x4 v = x4[q]; a0 += (v[0] + v[1]) + (v[2] + v[3]); }
   if (sg == nseg - 1)                                       // the <= 3 values past the last whole vector
     for (int64_t t = (per4 << 2) + threadIdx.x; t < per; t += 256) a1 += xp[t];
-  double acc = rfx_wave_sum_d(((double)a0 + (double)a1) + ((double)a2 + (double)a3));
-  __shared__ double part[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) part[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out + c, (float)(part[0] + part[1] + part[2] + part[3]));
+  const double v[1] = {((double)a0 + (double)a1) + ((double)a2 + (double)a3)};
+  rfx_block_store_slot<1>(v, slots, c, gridDim.y, blockIdx.y);
 }
 
-extern "C" int rfx_channel_sum(const float* x, int32_t N, int32_t Cn, int32_t A, int32_t B, int64_t ns,
-                               int64_t cs, int64_t as, int64_t bs, float* out, void* stream) {
-  if (!x || !out || N <= 0 || Cn <= 0 || A <= 0 || B <= 0) return -1;
+// geometry of rfx_channel_sum: workgroups (= slots) per channel; nseg != 0: the vectorised contiguous-plane kernel
+static int channel_sum_geometry(const float* x, int32_t N, int32_t Cn, int32_t A, int32_t B, int64_t ns, int64_t cs, int64_t as, int64_t bs,
+                                int64_t* nseg_out) {
   const int64_t total = (int64_t)N * A * B, per = (int64_t)A * B;
+  *nseg_out = 0;
   if (bs == 1 && as == (int64_t)B && per >= 1024 && ns % 4 == 0 && cs % 4 == 0 && ((uintptr_t)x & 15) == 0) {
     int64_t nseg = per / (4 * 256 * 16);                    // ~16 vectors per lane and segment ...
     const int64_t want = (2048 + (int64_t)N * Cn - 1) / ((int64_t)N * Cn);     // ... but at least ~2048 workgroups in all
     nseg = nseg < want ? want : nseg;
     nseg = nseg < 1 ? 1 : (nseg > per / 1024 ? per / 1024 : nseg);
-    if ((int64_t)N * nseg <= 65535) {
-      hipLaunchKernelGGL(channel_sum_plane_kernel, dim3(Cn, (unsigned)(N * nseg)), dim3(256), 0, (hipStream_t)stream, x, (int)nseg,
-                         per, ns, cs, out);
-      RFX_CHECK_LAUNCH();
-      return 0;
-    }
+    if ((int64_t)N * nseg <= 65535) { *nseg_out = nseg; return (int)(N * nseg); }
   }
   int chunks = (int)(total / 16384);
-  chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(Cn, chunks), dim3(256), 0, (hipStream_t)stream, x, N, Cn, A, B,
-                     ns, cs, as, bs, out);
+  return chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+}
+extern "C" int64_t rfx_channel_sum_ws(const float* x, int32_t N, int32_t Cn, int32_t A, int32_t B, int64_t ns, int64_t cs, int64_t as,
+                                      int64_t bs) {
+  if (N <= 0 || Cn <= 0 || A <= 0 || B <= 0) return -1;
+  int64_t nseg;
+  return (int64_t)Cn * channel_sum_geometry(x, N, Cn, A, B, ns, cs, as, bs, &nseg);
+}
+extern "C" int rfx_channel_sum(const float* x, int32_t N, int32_t Cn, int32_t A, int32_t B, int64_t ns,
+                               int64_t cs, int64_t as, int64_t bs, double* ws, float* out, void* stream) {
+  if (!x || !out || !ws || N <= 0 || Cn <= 0 || A <= 0 || B <= 0) return -1;
+  int64_t nseg;
+  const int nslots = channel_sum_geometry(x, N, Cn, A, B, ns, cs, as, bs, &nseg);
+  if (nseg) hipLaunchKernelGGL(channel_sum_plane_kernel, dim3(Cn, (unsigned)nslots), dim3(256), 0, (hipStream_t)stream, x, (int)nseg,
+                               (int64_t)A * B, ns, cs, ws);
+  else hipLaunchKernelGGL(channel_sum_kernel, dim3(Cn, nslots), dim3(256), 0, (hipStream_t)stream, x, N, Cn, A, B, ns, cs, as, bs, ws);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, dim3((Cn + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, Cn, nslots, 1, out);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -509,16 +519,19 @@ extern "C" int rfx_blstm_frames(const float* src, const float* skip, float* dst,
   RFX_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv,
-                               void* stream) {
-  if (!x || !sums || !mean || !stdv || R <= 0 || L <= 1) return -1;
+extern "C" int rfx_row_moments_slots(int64_t L) {
+  const int64_t gx = (L + 16383) / 16384;
+  return (int)(gx < 1 ? 1 : (gx > 256 ? 256 : gx));
+}
+extern "C" int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sums, float* mean, float* stdv, float eps, float* coef_a,
+                               float* coef_b, void* stream) {
+  if (!x || !sums || !mean || !stdv || R <= 0 || L <= 1 || (!coef_a) != (!coef_b)) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * R, s) != hipSuccess) return -3;
-  int gx = (int)((L + 16383) / 16384);
-  gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  const int gx = rfx_row_moments_slots(L);
   hipLaunchKernelGGL(row_moments_kernel, dim3(gx, R), dim3(256), 0, s, x, L, sums);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(row_moments_finalize_kernel, dim3((R + 63) / 64), dim3(64), 0, s, sums, R, (double)L, mean, stdv);
+  hipLaunchKernelGGL(row_moments_finalize_kernel, dim3((R + 63) / 64), dim3(64), 0, s, sums, R, gx, (double)L, mean, stdv, eps, coef_a,
+                     coef_b);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -26,6 +26,8 @@
 //     two LDS reads; workgroups that write the same (row, bin) lines are placed on the same XCD (block b runs on XCD b % 8) so
 //     partial-line stores merge in one L2.
 #include "common.h"
+#include <algorithm>
+#include <climits>
 #include <math.h>
 #include <stdlib.h>
 #ifndef RFX_FFT_PAIR_OCC
@@ -54,6 +56,9 @@ struct FftArgs {
   const float* lg_sums;   // [R][3] row sums of the forward
   const float* lg_gup;    // optional device scalar multiplying both weights
   float lg_wsc, lg_wlm, lg_eps;
+  // synthesis by OWNERSHIP (round 6): a workgroup walks `walk_frames` consecutive frames of a row (the last walk of a row takes the
+  // remainder) after `halo_frames` frames of run-in, and stores every output sample of its range exactly once
+  int walk_frames, halo_frames, ring_floats;
 };
 
 // d [ w_sc sqrt(A) / sqrt(B) + w_lm sum |log|X| - log|Y|| ] / dX at one cell: stft_loss_grad_kernel's formula (csrc/losses.hip, paired
@@ -415,12 +420,20 @@ __global__ __launch_bounds__(256, 3) void fft_analysis_kernel(const FftArgs a) {
   }
 }
 
-template <int LOGN, bool LG = false>
+// OWN = overlap-add by ownership (no atomics, no zero fill, bit-reproducible): the frames of a row are cut into WALKS of
+// a.walk_frames frames; a workgroup runs the a.halo_frames = (win - 1) / hop frames in front of its walk first (they overlap its first
+// samples; the previous walk transforms them too: ~10 % more transforms), keeps the not-yet-complete tail of the running sum in an LDS
+// ring and stores a padded position as soon as no later frame can reach it -- positions in [F0 hop + woff, F1 hop + woff) of walk
+// [F0, F1) are its own, so every output sample is written by exactly one thread of one workgroup.  The adjoint of the reflect-padded
+// STFT (in_mode 0) folds the two edge zones of a row in LDS (each edge sample has exactly two contributions, direct and mirrored, so
+// the order of the two LDS adds does not matter) and stores them at the end of the first / last walk.
+template <int LOGN, bool LG = false, bool OWN = false>
 __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) {
   typedef FftCfg<LOGN> K;
   constexpr int NC = K::NC, T = K::T, FB = K::FB, N = 2 * NC;
   __shared__ v2f data[FB * K::FS];
   __shared__ FftTables<LOGN> tb;
+  extern __shared__ float own_lds[];                        // OWN: ring[ring_floats] | edgeL[NC + 1] | edgeR[NC + 1] (in_mode 0)
   const rfx_stft_desc& d = a.d;
   int row, f_first;
   block_coords<LOGN>(a, row, f_first);
@@ -459,9 +472,28 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     const float A = a.lg_sums[3 * row], B = a.lg_sums[3 * row + 1];
     lg_ksc = (A > 0.f && B > 0.f) ? wsc / (sqrtf(A) * sqrtf(B)) : 0.f;
   }
-  for (int g = 0; g < a.nbatch; ++g) {
-    const int fb0 = f_first + g * FB;
-    if (fb0 >= f_end) break;
+  // OWN: walk w = frames [F0, F1) of the row, run-in from hs
+  int F0 = 0, F1 = f_end, hs = f_first, rbase = 0;
+  int64_t own_lo = INT64_MIN, own_hi = INT64_MAX;
+  float* ring = own_lds;
+  float* edgeL = own_lds + a.ring_floats;
+  float* edgeR = edgeL + NC + 1;
+  bool first_walk = true, last_walk = true;
+  if (OWN) {
+    const int w = (blockIdx.x >> 3) % a.groups_per_row;
+    first_walk = w == 0; last_walk = w == a.groups_per_row - 1;
+    F0 = d.frame0 + w * a.walk_frames;
+    F1 = last_walk ? f_end : F0 + a.walk_frames;
+    hs = max(d.frame0, F0 - a.halo_frames);
+    if (!first_walk) own_lo = (int64_t)F0 * d.hop + woff;
+    if (!last_walk) own_hi = (int64_t)F1 * d.hop + woff;
+    for (int i = tid; i < a.ring_floats + (d.in_mode == 0 ? 2 * (NC + 1) : 0); i += 256) own_lds[i] = 0.f;
+    // (the first lds_barrier of the batch loop orders these stores before the first ring access)
+  }
+  const int f_stop = OWN ? F1 : f_end;                      // frames at and beyond f_stop are not this workgroup's
+  for (int g = 0; OWN || g < a.nbatch; ++g) {
+    const int fb0 = OWN ? hs + g * FB : f_first + g * FB;
+    if (fb0 >= f_stop) break;
     // merge step on bin pairs (k, NC - k), k in [0, NC / 2]: S = X[k] + conj X[NC-k], W = (X[k] - conj X[NC-k]) e^{+i pi k/NC}
     //   Z[k] = S + i W,  Z[NC - k] = conj S + i conj W;  conj Z is written in natural order (the inverse = conj FFT conj)
     const bool fm = d.mode == RFX_STFT_COMPLEX_FM;           // frame-major spectrum: lanes along bins
@@ -500,7 +532,7 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
       int fl2, k;
       item(it, fl2, k);
       const int f2 = fb0 + fl2;
-      const int fo = f2 < f_end ? f2 - d.frame0 : 0;
+      const int fo = f2 < f_stop ? f2 - d.frame0 : 0;
       xkv[it] = fetch(k, fo);
       xmv[it] = fetch(NC - k, fo);
       if (lg) {
@@ -513,7 +545,7 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     for (int it = 0; it < NIT; ++it) {
       int fl2, k;
       if (!item(it, fl2, k)) continue;
-      const bool fv = fb0 + fl2 < f_end;
+      const bool fv = fb0 + fl2 < f_stop;
       if (LG) {                                               // one item at a time: unrolled together the reciprocals of all items spill
         xkv[it] = fft_lossgrad_cell(xkv[it], ykv[it], lg_ksc, lg_wlm, a.lg_eps);
         xmv[it] = fft_lossgrad_cell(xmv[it], ymv[it], lg_ksc, lg_wlm, a.lg_eps);
@@ -538,12 +570,59 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     lds_barrier();
     fft_core<LOGN>(z, data, st, wout);
     lds_barrier();
+    const int nf = min(FB, f_stop - fb0);
+    const int span = (nf - 1) * d.hop + N;
+    const int64_t p0 = (int64_t)fb0 * d.hop;
+    if (OWN) {
+      // Every padded position q of the batch's span: the batch's frames that cover it (out of LDS, as below) + what earlier batches
+      // left in the ring.  Complete (no later frame of the row starts at or before it) -> stored if it is this walk's own, else it
+      // goes back into the ring.  A position is one thread's per batch: no LDS races; one barrier per batch (the loop's).
+      const int fin = (fb0 + nf >= f_end) ? span : nf * d.hop + woff;
+      for (int q = tid; q < span; q += 256) {
+        const int qw = q - woff;
+        if (qw < 0) continue;                          // complete (and cleared) since the previous batch
+        const int lo_num = qw - d.win + 1;
+        int fl_hi, fl_lo;
+        if (a.hop_magic) {
+          fl_hi = min(nf - 1, (int)__umulhi((uint32_t)qw, a.hop_magic));
+          fl_lo = lo_num > 0 ? (int)__umulhi((uint32_t)(lo_num + d.hop - 1), a.hop_magic) : 0;
+        } else {
+          fl_hi = min(nf - 1, qw / d.hop);
+          fl_lo = lo_num > 0 ? (lo_num + d.hop - 1) / d.hop : 0;
+        }
+        float v = 0.f;
+        for (int f2 = fl_lo; f2 <= fl_hi; ++f2) {
+          const int t = q - f2 * d.hop;
+          const v2f zz = data[f2 * K::FS + fft_phys3<LOGN>(t >> 1)];
+          v += (t & 1) ? -zz.y : zz.x;
+        }
+        int ri = rbase + q;
+        if (ri >= a.ring_floats) ri -= a.ring_floats;
+        v += ring[ri];
+        if (q >= fin) { ring[ri] = v; continue; }
+        ring[ri] = 0.f;
+        const int64_t p = p0 + q;
+        if (p < own_lo || p >= own_hi) continue;
+        v *= d.scale;
+        if (a.mul) v *= a.mul[p];
+        if (d.in_mode == 1) {
+          const int64_t sx = p - d.in_offset;
+          if (sx >= 0 && sx < d.T) outr[sx] = d.accum ? outr[sx] + v : v;
+        } else {                                        // adjoint of centre + reflect padding (no extra pads: the launcher checks)
+          const int sx = (int)p - NC;                   // NC = n_fft / 2
+          if (sx <= NC) atomicAdd(&edgeL[sx < 0 ? -sx : sx], v);                      // samples 0 .. NC: direct + mirrored
+          else if (sx >= d.T - 1 - NC) {
+            const int s2 = sx >= d.T ? 2 * (d.T - 1) - sx : sx;
+            if (s2 >= d.T - 1 - NC && s2 < d.T) atomicAdd(&edgeR[s2 - (d.T - 1 - NC)], v);
+          } else outr[sx] = d.accum ? outr[sx] + v : v;
+        }
+      }
+      rbase += nf * d.hop;
+      if (rbase >= a.ring_floats) rbase -= a.ring_floats;
+    } else {
     // Overlap-add by GATHER inside the workgroup: the batch's frames are consecutive, so every padded position p of their span
     // sums the <= ceil(win / hop) frames that cover it out of LDS and issues ONE global atomic (the scatter form issued
     // one per (frame, sample): 3.3-4.3x more, and the loss-gradient launches ran at the L2 atomic rate, 0.46 TB/s).
-    const int nf = min(FB, f_end - fb0);
-    const int span = (nf - 1) * d.hop + N;
-    const int64_t p0 = (int64_t)fb0 * d.hop;
     for (int q = tid; q < span; q += 256) {
       const int qw = q - woff;                       // window index of frame 0 at this position
       if (qw < 0) continue;
@@ -570,7 +649,12 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
       if (a.mul) v *= a.mul[p];
       atomicAdd(outr + sidx, v);
     }
+    }
     lds_barrier();
+  }
+  if (OWN && d.in_mode == 0) {                             // the folded edge zones: samples [0, NC] and [T - 1 - NC, T - 1]
+    if (first_walk) for (int i = tid; i <= NC; i += 256) outr[i] = d.accum ? outr[i] + edgeL[i] : edgeL[i];
+    if (last_walk) for (int i = tid; i <= NC; i += 256) { float* o = outr + (d.T - 1 - NC) + i; *o = d.accum ? *o + edgeR[i] : edgeR[i]; }
   }
 }
 
@@ -646,8 +730,60 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
     while (nb < (SYN ? syn_nb_max : 4) && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
   a.nbatch = nb;
   a.groups_per_row = (batches + nb - 1) / nb;
-  const unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);
+  a.walk_frames = a.halo_frames = a.ring_floats = 0;
+  unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);
   hipStream_t s = (hipStream_t)stream;
+  if (SYN) {
+    // Overlap-add by ownership wherever the geometry allows it (everything the networks and losses use); else the atomic form into
+    // a zero-filled output (extra reflect pads = the backward of HDemucs' _spec, which nothing differentiates; rows too short for two
+    // disjoint edge zones; hop > win).
+    static const int own_on = [] { const char* e = getenv("RFX_FFT_OWN"); return e ? atoi(e) : 1; }();
+    const int woff = (d->n_fft - d->win) / 2;
+    const bool own = own_on && d->hop <= d->win && (d->in_mode == 1 || (!d->extra_pad_l && !d->extra_pad_r && d->frame0 == 0 && d->T > 2 * d->n_fft + 2));
+    if (own) {
+      const int halo = (d->win - 1) / d->hop;
+      int fw_min = halo + 1;
+      if (d->in_mode == 0) {                                     // walk 0 owns samples [0, n_fft / 2], the last walk the mirror zone
+        fw_min = std::max(fw_min, (d->n_fft + 1 - woff + d->hop - 1) / d->hop + 1);
+        fw_min = std::max(fw_min, 2 + (woff + d->hop) / d->hop);
+      }
+      fw_min = std::max(fw_min, 2 * halo);                       // run-in <= half of a walk
+      int64_t fw = ((int64_t)d->frames_out * d->R + 2047) / 2048; // ~2048 workgroups ...
+      fw = std::min<int64_t>(fw, std::max(8 * halo, 4 * fb));     // ... of walks no longer than needed to make the run-in cheap
+      fw = std::max<int64_t>(fw, fw_min);
+      fw = (fw + fb - 1) / fb * fb;
+      const int nwalks = std::max<int>(1, (int)(d->frames_out / fw));   // the last walk takes the remainder (< 2 fw frames)
+      a.walk_frames = (int)fw; a.halo_frames = halo; a.groups_per_row = nwalks;
+      a.ring_floats = (fb - 1) * d->hop + d->n_fft;
+      grid = (unsigned)(rows8 * nwalks * 8);
+      const size_t dyn = sizeof(float) * ((size_t)a.ring_floats + (d->in_mode == 0 ? 2 * (size_t)(nc + 1) : 0));
+      // every sample stored?  covered padded positions: [frame0 hop + woff, (frame0 + frames_out - 1) hop + woff + win)
+      const int64_t c_lo = (int64_t)d->frame0 * d->hop + woff, c_hi = (int64_t)(d->frame0 + d->frames_out - 1) * d->hop + woff + d->win;
+      const bool full = d->in_mode == 1 ? (c_lo <= d->in_offset && c_hi >= (int64_t)d->in_offset + d->T)
+                                        : (c_lo <= 2 * (int64_t)nc + 1 && c_hi >= (int64_t)d->T - 1);
+      if (!full && !d->accum && hipMemsetAsync(out, 0, sizeof(float) * (size_t)d->R * d->T, s) != hipSuccess) return -3;
+#define RFX_SYN_OWN(LOGN, LGV) hipLaunchKernelGGL((fft_synthesis_kernel<LOGN, LGV, true>), dim3(grid), dim3(256), dyn, s, a)
+      if (lgsrc) {
+        switch (d->n_fft) {
+          case 512: RFX_SYN_OWN(8, true); break;
+          case 1024: RFX_SYN_OWN(9, true); break;
+          case 2048: RFX_SYN_OWN(10, true); break;
+          default: RFX_SYN_OWN(11, true); break;
+        }
+      } else {
+        switch (d->n_fft) {
+          case 512: RFX_SYN_OWN(8, false); break;
+          case 1024: RFX_SYN_OWN(9, false); break;
+          case 2048: RFX_SYN_OWN(10, false); break;
+          default: RFX_SYN_OWN(11, false); break;
+        }
+      }
+#undef RFX_SYN_OWN
+      RFX_CHECK_LAUNCH();
+      return 0;
+    }
+    if (!d->accum && hipMemsetAsync(out, 0, sizeof(float) * (size_t)d->R * d->T, s) != hipSuccess) return -3;   // atomic form
+  }
   if (SYN && lgsrc) {
     switch (d->n_fft) {
       case 512: hipLaunchKernelGGL((fft_synthesis_kernel<8, true>), dim3(grid), dim3(256), 0, s, a); break;
@@ -697,7 +833,7 @@ struct PairArgs {
   const float* y;
   const float* window;
   const v2f* tables;
-  float* sums;            // [R][3], accumulated atomically
+  double* slots;          // [R][groups_per_row][3]: one slot per workgroup
   v2f* xspec;             // optional [R][frames][bins]
   float* ymag;            // optional [R][frames][bins]
   float eps;
@@ -847,26 +983,37 @@ __global__ __launch_bounds__(256, (LOGN == 9 ? 2 : RFX_FFT_PAIR_OCC)) void fft_p
   const int lane = tid & 63, wave = tid >> 6;
   if (lane == 0) { part[0][wave] = accA; part[1][wave] = accB; part[2][wave] = accC; }
   lds_barrier();
-  if (tid < 3) atomicAdd(a.sums + 3 * row + tid, (float)(part[tid][0] + part[tid][1] + part[tid][2] + part[tid][3]));
+  // the (row, frame group) slot is this workgroup's alone: stored, then added in group order by rfx_slot_sum_kernel (no fill, no atomics)
+  if (tid < 3) a.slots[((int64_t)row * a.groups_per_row + grp) * 3 + tid] = (part[tid][0] + part[tid][1]) + (part[tid][2] + part[tid][3]);
 }
 
+static void pair_loss_geometry(const rfx_stft_desc* d, int& nb, int& groups) {
+  const int fb = 2 * (4096 / d->n_fft);                        // frames per batch (n_fft complex points per pair transform)
+  const int batches = (d->frames_out + fb - 1) / fb;
+  const int rows8 = (d->R + 7) / 8;
+  nb = 1;
+  while (nb < 4 && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
+  groups = (batches + nb - 1) / nb;
+}
+// doubles of workspace rfx_stft_pair_loss needs for this geometry (3 per row and workgroup)
+extern "C" int64_t rfx_stft_pair_loss_ws(const rfx_stft_desc* d) {
+  if (!stft_desc_ok(d) || d->n_fft > 2048) return -1;
+  int nb, groups;
+  pair_loss_geometry(d, nb, groups);
+  return (int64_t)3 * d->R * groups;
+}
 extern "C" int rfx_stft_pair_loss(const rfx_stft_desc* d, const float* x, const float* y, const float* window, float eps,
-                                  float* sums, float* xspec, float* ymag, void* stream) {
-  if (!stft_desc_ok(d) || !x || !y || !window || !sums || (xspec == nullptr) != (ymag == nullptr)) return -1;
+                                  double* ws, float* sums, float* xspec, float* ymag, void* stream) {
+  if (!stft_desc_ok(d) || !x || !y || !window || !sums || !ws || (xspec == nullptr) != (ymag == nullptr)) return -1;
   if (d->n_fft > 2048 || d->in_mode != 0 || d->extra_pad_l || d->extra_pad_r || d->frame0 != 0 || d->bins != d->n_fft / 2 + 1) return -1;
   PairArgs a;
-  a.d = *d; a.x = x; a.y = y; a.window = window; a.sums = sums; a.eps = eps;
+  a.d = *d; a.x = x; a.y = y; a.window = window; a.slots = ws; a.eps = eps;
   a.xspec = reinterpret_cast<v2f*>(xspec); a.ymag = ymag;
   const int nc = d->n_fft;                                     // complex points of the pair transform
   a.tables = fft_tables(nc);
   if (!a.tables) return -3;
-  const int fb = 2 * (4096 / nc);                              // frames per batch
-  const int batches = (d->frames_out + fb - 1) / fb;
   const int rows8 = (d->R + 7) / 8;
-  int nb = 1;
-  while (nb < 4 && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
-  a.nbatch = nb;
-  a.groups_per_row = (batches + nb - 1) / nb;
+  pair_loss_geometry(d, a.nbatch, a.groups_per_row);
   const unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);
   hipStream_t s = (hipStream_t)stream;
   switch (d->n_fft) {
@@ -874,6 +1021,8 @@ extern "C" int rfx_stft_pair_loss(const rfx_stft_desc* d, const float* x, const 
     case 1024: hipLaunchKernelGGL(fft_pair_loss_kernel<10>, dim3(grid), dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(fft_pair_loss_kernel<11>, dim3(grid), dim3(256), 0, s, a); break;
   }
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, dim3((3 * d->R + 63) / 64), dim3(64), 0, s, ws, d->R, a.groups_per_row, 3, sums);
   RFX_CHECK_LAUNCH();
   return 0;
 }

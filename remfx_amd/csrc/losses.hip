@@ -3,23 +3,10 @@
 // Replaces: models.py:107,299,320,362,385 (mrstft + 100*L1), models.py:227-255 (metrics).
 #include "common.h"
 
-__device__ __forceinline__ void block_atomic_add3(double a, double b, double c, float* out) {
-  a = rfx_wave_sum_d(a); b = rfx_wave_sum_d(b); c = rfx_wave_sum_d(c);
-  __shared__ double part[3][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { part[0][wave] = a; part[1][wave] = b; part[2][wave] = c; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(out + 0, (float)(part[0][0] + part[0][1] + part[0][2] + part[0][3]));
-    atomicAdd(out + 1, (float)(part[1][0] + part[1][1] + part[1][2] + part[1][3]));
-    atomicAdd(out + 2, (float)(part[2][0] + part[2][1] + part[2][2] + part[2][3]));
-  }
-}
-
 // xc, yc: [R][n] complex (float2); sums[r] = { sum (ym-xm)^2, sum ym^2, sum |log xm - log ym| }
 __global__ __launch_bounds__(256) void stft_loss_reduce_kernel(const float2* __restrict__ xc,
                                                                const float2* __restrict__ yc, int64_t n,
-                                                               float eps, float* __restrict__ sums) {
+                                                               float eps, double* __restrict__ slots) {
   const int r = blockIdx.y;
   const float2* xr = xc + (int64_t)r * n;
   const float2* yr = yc + (int64_t)r * n;
@@ -48,7 +35,8 @@ __global__ __launch_bounds__(256) void stft_loss_reduce_kernel(const float2* __r
     }
     a += (double)fa; b += (double)fb; c += (double)(fc * 0.34657359027997264f);   // log2 -> ln, halved
   }
-  block_atomic_add3(a, b, c, sums + 3 * r);
+  const double v[3] = {a, b, c};
+  rfx_block_store_slot<3>(v, slots, r, gridDim.x, blockIdx.x);
 }
 
 // gxc = d/dxc [ w_sc * sqrt(A_r)/sqrt(B_r) + w_lm * sum |log xm - log ym| ]
@@ -107,7 +95,7 @@ __global__ void l1_grad_kernel(const float* __restrict__ a, const float* __restr
 
 // per row r of [R][L]: sums[r] = { sum x, sum t, sum x*t, sum x*x, sum t*t }  (double accumulate)
 __global__ __launch_bounds__(256) void sisdr_sums_kernel(const float* __restrict__ x, const float* __restrict__ t,
-                                                         int64_t L, int64_t xs, int64_t ts, double* __restrict__ sums) {
+                                                         int64_t L, int64_t xs, int64_t ts, double* __restrict__ sums /* slots */) {
   const int r = blockIdx.y;
   const float* xr = x + (int64_t)r * xs;
   const float* tr = t + (int64_t)r * ts;
@@ -116,18 +104,7 @@ __global__ __launch_bounds__(256) void sisdr_sums_kernel(const float* __restrict
     const double a = xr[i], b = tr[i];
     s[0] += a; s[1] += b; s[2] += a * b; s[3] += a * a; s[4] += b * b;
   }
-  __shared__ double part[5][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const double v = rfx_wave_sum_d(s[q]);
-    if (lane == 0) part[q][wave] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 5) {
-    const int q = threadIdx.x;
-    atomicAdd(sums + 5 * r + q, part[q][0] + part[q][1] + part[q][2] + part[q][3]);
-  }
+  rfx_block_store_slot<5>(s, sums, r, gridDim.x, blockIdx.x);
 }
 
 // The scalar tail of auraloss MultiResolutionSTFTLoss over the row sums of all resolutions in ONE launch (it was ~24 one-element torch
@@ -184,17 +161,20 @@ static int grid_x(int64_t n) {
   const int64_t b = (n + 2047) / 2048;
   return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
-// reductions: fewer, longer workgroups per row (each ends in three same-address atomics)
+// reductions: fewer, longer workgroups per row (each ends in one slot store)
 static int grid_red(int64_t n) {
   const int64_t b = (n + 16383) / 16384;
   return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
 }
 
-extern "C" int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R, int64_t n, float eps,
+extern "C" int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R, int64_t n, float eps, double* ws,
                                     float* sums, void* stream) {
-  if (!xc || !yc || !sums || R <= 0 || n <= 0) return -1;
-  hipLaunchKernelGGL(stft_loss_reduce_kernel, dim3(grid_red(n), R), dim3(256), 0, (hipStream_t)stream,
-                     (const float2*)xc, (const float2*)yc, n, eps, sums);
+  if (!xc || !yc || !sums || !ws || R <= 0 || n <= 0) return -1;
+  const int g = grid_red(n);                                                 // <= RFX_STFT_REDUCE_SLOTS
+  hipLaunchKernelGGL(stft_loss_reduce_kernel, dim3(g, R), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)xc, (const float2*)yc, n, eps, ws);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, dim3((3 * R + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, R, g, 3, sums);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -221,10 +201,13 @@ extern "C" int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, c
   return 0;
 }
 extern "C" int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t L, int64_t x_rs,
-                              int64_t t_rs, double* sums, void* stream) {
-  if (!x || !t || !sums || R <= 0 || L <= 0) return -1;
-  hipLaunchKernelGGL(sisdr_sums_kernel, dim3(grid_x(L), R), dim3(256), 0, (hipStream_t)stream, x, t, L, x_rs,
-                     t_rs, sums);
+                              int64_t t_rs, double* ws, double* sums, void* stream) {
+  if (!x || !t || !sums || !ws || R <= 0 || L <= 0) return -1;
+  int g = grid_x(L);
+  g = g > RFX_SISDR_SLOTS ? RFX_SISDR_SLOTS : g;
+  hipLaunchKernelGGL(sisdr_sums_kernel, dim3(g, R), dim3(256), 0, (hipStream_t)stream, x, t, L, x_rs, t_rs, ws);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<double>, dim3((5 * R + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, R, g, 5, sums);
   RFX_CHECK_LAUNCH();
   return 0;
 }

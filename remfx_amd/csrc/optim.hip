@@ -16,12 +16,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     acc += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
   }
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += (double)g[i] * g[i];
-  acc = rfx_wave_sum_d(acc);
-  __shared__ double part[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) part[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  const double v[1] = {acc};
+  rfx_block_store_slot<1>(v, out, 0, gridDim.x, blockIdx.x);        // out = per-workgroup slots (rfx_sumsq adds them in order)
 }
 
 // gscale_ptr (device, optional): every gradient is multiplied by *gscale_ptr first (clip coefficient
@@ -98,10 +94,15 @@ extern "C" int rfx_zero(void* p, int64_t nbytes, void* stream) {
   RFX_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int rfx_sumsq(const float* g, int64_t n, double* out, void* stream) {
-  if (!g || !out || n < 0) return -1;
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(gridn(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+// out[0] = sum g^2 (fp64); ws: RFX_SUMSQ_SLOTS doubles of per-workgroup partials (no initialisation needed), added in slot order
+extern "C" int rfx_sumsq(const float* g, int64_t n, double* ws, double* out, void* stream) {
+  if (!g || !out || !ws || n < 0) return -1;
+  const int gr = n > 0 ? gridn(n) : 0;                                 // <= RFX_SUMSQ_SLOTS
+  if (gr) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(gr), dim3(256), 0, (hipStream_t)stream, g, n, ws);
+    RFX_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<double>, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, 1, gr, 1, out);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -138,6 +138,8 @@ class GradSync:
     def _make_hook(self, idx):
         def hook(_p):
             self._hook_seen[idx] = True
+            if self.sink is not None and self.flat.grad.is_cuda:
+                self.sink.note_stream()              # autograd accumulated on the node's stream (the time branch has its own)
             if self.expected is None:
                 return                               # calibration step: finish() launches everything
             b = self.buckets[self.bucket_of[idx]]
@@ -171,8 +173,10 @@ class GradSync:
         sl = self.flat.grad[b["lo"]:b["hi"]]
         side = self.sink.side if (self.sink is not None and sl.is_cuda) else None
         if side is not None:
-            # the bucket's gradients come from the compute stream AND the sink's side stream: order the collective after both
+            # the bucket's gradients come from the compute stream, the sink's side stream AND any other stream backward nodes ran on
+            # (Hybrid Demucs' time branch): order the collective after all of them
             side.wait_stream(torch.cuda.current_stream())
+            self.sink.order_after_writes(side)
             with torch.cuda.stream(side):
                 self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
             self.sink.used_side = True

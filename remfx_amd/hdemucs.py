@@ -32,10 +32,13 @@ _TIME_STREAMS = {}
 
 
 def _data_parallel():
-    """More than one rank: the step stays on the compute + weight-gradient streams.  ddp.GradSync orders a bucket's all-reduce behind
-    the stream its LAST gradient was written on and behind the weight-gradient stream; a bucket that also holds a gradient autograd
-    accumulated on the time-branch stream would need a third dependency, and no multi-GPU box was available to prove that path."""
-    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    """More than one rank AND no gradient sink to order the exchange: ddp.GradSync orders a bucket's all-reduce behind every stream
+    the sink has seen gradient writes on (ops.GradSink.write_streams: compute, weight-gradient, time-branch), so the multi-rank step
+    runs the same stream configuration as the single-rank one (round 6).  Without an armed sink (GradSink.MODE = "off") the collective
+    only follows the stream it is issued from, and the time branch stays on the compute stream."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+        return False
+    return torch.is_grad_enabled() and ops.SINK is None
 
 
 _XSUB = int(os.environ.get("RFX_XSYNC_SUB", "0"))

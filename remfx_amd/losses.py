@@ -81,12 +81,13 @@ def _pair_sums(x2, y2, n_fft, hop, win, w, eps, store):
     if n_fft // 2 >= L:
         raise ValueError("reflect padding needs n_fft/2 < signal length")
     frames, bins = 1 + L // hop, n_fft // 2 + 1
-    sums = zeros((R, 3), x2.device)
+    sums = torch.empty((R, 3), device=x2.device, dtype=torch.float32)       # written, not accumulated: no zero fill
     X = torch.empty((R, frames, bins, 2), device=x2.device, dtype=torch.float32) if store else None
     ym = torch.empty((R, frames, bins), device=x2.device, dtype=torch.float32) if store else None
     d = stft._desc(R, L, n_fft, hop, win, bins, 0, frames, _SPEC_MODE)
-    check(_lib.lib().rfx_stft_pair_loss(C.byref(d), _ptr(x2), _ptr(y2), _ptr(w), eps, _ptr(sums), _ptr(X), _ptr(ym), _stream()),
-          "rfx_stft_pair_loss")
+    ws = torch.empty(int(_lib.lib().rfx_stft_pair_loss_ws(C.byref(d))), device=x2.device, dtype=torch.float64)   # one slot per workgroup
+    check(_lib.lib().rfx_stft_pair_loss(C.byref(d), _ptr(x2), _ptr(y2), _ptr(w), eps, _ptr(ws), _ptr(sums), _ptr(X), _ptr(ym),
+                                        _stream()), "rfx_stft_pair_loss")
     if _MEMO is not None:
         _MEMO[key] = (sums, X, ym, x2, y2)      # holding the signals keeps their storage from being reused under the key
     return sums, X, ym
@@ -116,8 +117,9 @@ class _MRSTFTFn(torch.autograd.Function):
                 skey = ("sums", X.data_ptr(), Y.data_ptr(), eps)
                 sums = _MEMO.get(skey) if _MEMO is not None else None   # metric(output, target) repeats the loss's row sums
                 if sums is None:
-                    sums = zeros((R, 3), x.device)
-                    check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), _stream()),
+                    sums = torch.empty((R, 3), device=x.device, dtype=torch.float32)
+                    ws = torch.empty(3 * R * 64, device=x.device, dtype=torch.float64)        # RFX_STFT_REDUCE_SLOTS per row
+                    check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, eps, _ptr(ws), _ptr(sums), _stream()),
                           "rfx_stft_loss_reduce")
                     if _MEMO is not None and ("spec", X.data_ptr()) in _MEMO and ("spec", Y.data_ptr()) in _MEMO:
                         _MEMO[skey] = sums                               # both spectra are held by the memo: pointers stay valid
@@ -136,10 +138,10 @@ class _MRSTFTFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         shape, R, L, eps, per_example_sc, nres = ctx.meta
-        gx = zeros((R, L), g.device)
+        gx = torch.empty((R, L), device=g.device, dtype=torch.float32)    # the first resolution writes it, the others add (accum)
         gval = 1.0               # the scalar upstream gradient stays on the device: the kernels multiply their weights by *gup
         gup = g.detach().reshape(1).float().contiguous()
-        for paired, X, Y, sums, n, n_fft, hop, win in ctx.saved:
+        for ires, (paired, X, Y, sums, n, n_fft, hop, win) in enumerate(ctx.saved):
             if not per_example_sc:      # whole-batch Frobenius norm: same A, B for every row
                 sums = sums.clone()
                 sums[:, 0] = sums[:, 0].sum()
@@ -149,7 +151,8 @@ class _MRSTFTFn(torch.autograd.Function):
                 w_sc = gval / (nres * R)
             w_lm = gval / (nres * R * n)
             w = stft.hann(win, g.device)
-            d = stft._desc(R, L, n_fft, hop, win, X.shape[2], 0, X.shape[1], _SPEC_MODE, in_mode=0, herm=0, scale=1.0)
+            d = stft._desc(R, L, n_fft, hop, win, X.shape[2], 0, X.shape[1], _SPEC_MODE, in_mode=0, herm=0, scale=1.0,
+                           accum=1 if ires else 0)
             if paired and FUSED_GRAD:   # Y = the clamped target magnitudes; the gradient spectrum is formed inside the synthesis
                 check(_lib.lib().rfx_fft_synthesis_lossgrad(C.byref(d), _ptr(X), _ptr(Y), _ptr(sums), w_sc, w_lm, eps, _ptr(gup),
                                                             _ptr(w), _ptr(gx), _stream()), "rfx_fft_synthesis_lossgrad")
@@ -184,10 +187,11 @@ class _L1Fn(torch.autograd.Function):
     def forward(ctx, a, b):
         _req(a, "input"); _req(b, "target")
         a, b = a.contiguous(), b.contiguous()
-        out = torch.zeros(1, device=a.device, dtype=torch.float32)
-        check(_lib.lib().rfx_l1_sum(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream()), "rfx_l1_sum")
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        ws = torch.empty(512, device=a.device, dtype=torch.float64)                 # RFX_L1_SLOTS per-workgroup partials
+        check(_lib.lib().rfx_l1_sum(_ptr(a), _ptr(b), a.numel(), _ptr(ws), 1.0 / a.numel(), _ptr(out), _stream()), "rfx_l1_sum")
         ctx.save_for_backward(a, b)
-        return (out / a.numel()).reshape(())
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -222,8 +226,9 @@ class SISDRLoss(nn.Module):
         if t.stride(-1) != 1:
             t = t.contiguous()
         R = x.shape[0]
-        s = torch.zeros((R, 5), device=x.device, dtype=torch.float64)
-        check(_lib.lib().rfx_sisdr_sums(_ptr(x), _ptr(t), R, L, x.stride(0), t.stride(0), _ptr(s), _stream()),
+        s = torch.empty((R, 5), device=x.device, dtype=torch.float64)
+        ws = torch.empty(5 * R * 128, device=x.device, dtype=torch.float64)          # RFX_SISDR_SLOTS per-workgroup partials per row
+        check(_lib.lib().rfx_sisdr_sums(_ptr(x), _ptr(t), R, L, x.stride(0), t.stride(0), _ptr(ws), _ptr(s), _stream()),
               "rfx_sisdr_sums")
         out = torch.empty((), device=x.device, dtype=torch.float32)      # the scalar tail in one launch (fp64 inside)
         check(_lib.lib().rfx_sisdr_finish(_ptr(s), R, L, 1 if self.zero_mean else 0, float(self.eps), _ptr(out), _stream()),

@@ -414,12 +414,12 @@ def row_standardize(x, eps):
     x = x.contiguous()
     R = x.shape[0]
     L = x.numel() // R
-    sums = torch.empty(2 * R, device=x.device, dtype=torch.float64)
+    lib = _lib.lib()
+    sums = torch.empty(2 * R * lib.rfx_row_moments_slots(L), device=x.device, dtype=torch.float64)    # one slot per workgroup
     mean = torch.empty(R, device=x.device, dtype=torch.float32)
-    std = torch.empty_like(mean)
-    check(_lib.lib().rfx_row_moments(_ptr(x), R, L, _ptr(sums), _ptr(mean), _ptr(std), _stream()), "rfx_row_moments")
-    a = 1.0 / (eps + std)
-    b = -mean * a
+    std, a, b = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    check(lib.rfx_row_moments(_ptr(x), R, L, _ptr(sums), _ptr(mean), _ptr(std), float(eps), _ptr(a), _ptr(b), _stream()),
+          "rfx_row_moments")                                   # a = 1 / (eps + std), b = -mean a come out of the finalize kernel
     y = torch.empty_like(x)
     check(_lib.lib().rfx_row_affine(_ptr(x), _ptr(a), _ptr(b), _ptr(y), R, L, _stream()), "rfx_row_affine")
     return y, mean, std

@@ -79,6 +79,10 @@ class GradSink:
         self.used_side = False
         self.writes = [0] * len(flat.params)         # sink writes per parameter in the current step
         self.on_write = None                           # ddp.GradSync: called with the parameter index after each write
+        # every stream a gradient was written on in this step (raw handle -> torch stream): the time branch of Hybrid Demucs
+        # back-propagates on its own stream, and a node that writes through the sink returns None, so no AccumulateGrad orders its
+        # writes for the engine.  join() and ddp.GradSync order the optimiser step / a bucket's all-reduce behind all of them.
+        self.write_streams = {}
 
     def lookup(self, w):
         """(index, 1-D gradient view) of the parameter `w` is, or None."""
@@ -93,8 +97,22 @@ class GradSink:
         o = self.flat.offsets[i]
         return i, self.flat.grad[o:o + p.numel()]
 
+    def note_stream(self):
+        """Remember the current stream as one that carries gradient writes of this step."""
+        raw = _raw_stream(_cur_device())
+        if raw not in self.write_streams:
+            self.write_streams[raw] = torch.cuda.current_stream()
+
+    def order_after_writes(self, stream):
+        """`stream` waits for everything enqueued so far on every stream that has written gradients in this step."""
+        for raw, st in self.write_streams.items():
+            if st != stream:
+                stream.wait_stream(st)
+
     def wrote(self, i):
         self.writes[i] += 1
+        if self.flat.grad.is_cuda:
+            self.note_stream()
         if self.on_write is not None:
             self.on_write(i)
 
@@ -102,6 +120,7 @@ class GradSink:
         """The stream weight-gradient work goes to (ordered after everything already on the current stream).  The operands were
         allocated on the current stream: tell the caching allocator the side stream uses them too."""
         main = torch.cuda.current_stream()
+        self.note_stream()
         if self.side is None:
             return main
         self.side.wait_stream(main)
@@ -112,10 +131,15 @@ class GradSink:
         return self.side
 
     def join(self):
-        """Current stream waits for every queued weight gradient."""
+        """Current stream waits for every queued weight gradient: the side stream's, and whatever other streams (the time branch's)
+        backward nodes wrote gradients on."""
+        cur = torch.cuda.current_stream() if self.flat.grad.is_cuda else None
         if self.side is not None and self.used_side:
-            torch.cuda.current_stream().wait_stream(self.side)
+            cur.wait_stream(self.side)
             self.used_side = False
+        if cur is not None and self.write_streams:
+            self.order_after_writes(cur)
+            self.write_streams = {}
 
 
 _COMPUTE_STREAMS = {}
@@ -781,11 +805,12 @@ def conv_transpose1d(x, w, bias=None, stride=1, dilation=1, crop_lo=0, out_len=N
 def channel_sum(g):
     """sum over (N, A, B) of a (N, C, A, B) tensor -> (C,)"""
     g4 = g if g.dim() == 4 else g.unsqueeze(2)
-    out = zeros(g4.shape[1], g.device)
+    out = torch.empty(g4.shape[1], device=g.device, dtype=torch.float32)
     N, Cc, A, B = g4.shape
     s = g4.stride()
-    check(_lib.lib().rfx_channel_sum(_ptr(g4), N, Cc, A, B, s[0], s[1], s[2], s[3], _ptr(out), _stream()),
-          "rfx_channel_sum")
+    L = _lib.lib()
+    ws = torch.empty(int(L.rfx_channel_sum_ws(_ptr(g4), N, Cc, A, B, s[0], s[1], s[2], s[3])), device=g.device, dtype=torch.float64)
+    check(L.rfx_channel_sum(_ptr(g4), N, Cc, A, B, s[0], s[1], s[2], s[3], _ptr(ws), _ptr(out), _stream()), "rfx_channel_sum")
     return out
 
 

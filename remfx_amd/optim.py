@@ -82,6 +82,7 @@ class FlatAdamW:
         self.step_count = 0
         dev = flat.data.device
         self._sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+        self._sumsq_ws = torch.empty(4096, device=dev, dtype=torch.float64)        # RFX_SUMSQ_SLOTS per-workgroup partials
         self._coef = torch.ones(1, device=dev, dtype=torch.float32)
         self.last_grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.param_groups = [{"lr": lr}]                 # scheduler-facing, as torch optimisers
@@ -94,8 +95,7 @@ class FlatAdamW:
         self.step_count += 1
         gscale = None
         if clip_norm or grad_prescale != 1.0:
-            ops.zero_(self._sumsq)
-            check(L.rfx_sumsq(_ptr(f.grad), f.numel, _ptr(self._sumsq), _stream()), "rfx_sumsq")
+            check(L.rfx_sumsq(_ptr(f.grad), f.numel, _ptr(self._sumsq_ws), _ptr(self._sumsq), _stream()), "rfx_sumsq")
             check(L.rfx_clip_coef(_ptr(self._sumsq), float(clip_norm or 0.0), float(grad_prescale),
                                   _ptr(self._coef), _ptr(self.last_grad_norm), _stream()), "rfx_clip_coef")
             gscale = self._coef

@@ -27,7 +27,7 @@ def hann(win, device):
 
 
 def _desc(R, T, n_fft, hop, win, bins, frame0, frames_out, mode, extra_pad=(0, 0), in_mode=0,
-          in_offset=0, herm=0, scale=1.0, eps=0.0, alpha=1.0):
+          in_offset=0, herm=0, scale=1.0, eps=0.0, alpha=1.0, accum=0):
     if n_fft not in (512, 1024, 2048, 4096):
         raise ValueError(f"n_fft={n_fft}: the HIP FFT kernels cover 512/1024/2048/4096")
     d = StftDesc()
@@ -35,7 +35,7 @@ def _desc(R, T, n_fft, hop, win, bins, frame0, frames_out, mode, extra_pad=(0, 0
     d.bins, d.frame0, d.frames_out, d.mode = bins, frame0, frames_out, mode
     d.extra_pad_l, d.extra_pad_r = extra_pad
     d.in_mode, d.in_offset, d.herm = in_mode, in_offset, herm
-    d.scale, d.eps, d.alpha = scale, eps, alpha
+    d.scale, d.eps, d.alpha, d.accum = scale, eps, alpha, accum
     return d
 
 
@@ -86,7 +86,7 @@ class STFTFn(torch.autograd.Function):
         g = g.contiguous()
         fo = g.shape[2] if mode == 0 else g.shape[1] if mode == 5 else g.shape[3]
         nb = g.shape[1] if mode == 0 else g.shape[2]
-        gx = zeros((R, T), g.device)
+        gx = torch.empty((R, T), device=g.device, dtype=torch.float32)      # rfx_fft_synthesis writes every element (accum = 0)
         d = _desc(R, T, n_fft, hop, win, nb, frame0, fo, mode, extra_pad, in_mode=0, herm=0,
                   scale=(1.0 / math.sqrt(n_fft)) if normalized else 1.0)
         check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(g), _ptr(window), None, _ptr(gx), _stream()),
@@ -141,7 +141,7 @@ class ISTFTFn(torch.autograd.Function):
         fi = spec.shape[2] if mode == 0 else spec.shape[3]
         inv_env = _inv_envelope(window, n_fft, hop, win, frames, spec.device)
         scale = (math.sqrt(n_fft) if normalized else 1.0) / n_fft
-        out = zeros((R, length), spec.device)
+        out = torch.empty((R, length), device=spec.device, dtype=torch.float32)   # every sample is stored exactly once (overlap-add by ownership)
         d = _desc(R, length, n_fft, hop, win, nb, frame0, fi, mode, in_mode=1, in_offset=n_fft // 2 + crop,
                   herm=1, scale=scale)
         check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(spec), _ptr(window), _ptr(inv_env), _ptr(out),

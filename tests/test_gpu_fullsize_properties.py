@@ -300,3 +300,67 @@ def test_hdemucs_batching_invariance_repeated_with_streams():
         del junk[::2]
     print("worst rms difference / output rms over 25 repetitions:", worst)
     check(worst, 1e-6, 1.0, bf16x3=1e-6, bf16=1e-6, what=("batch vs singles, repeated", worst))
+
+
+def test_hdemucs_training_backward_repeated_with_streams():
+    """The BACKWARD twin of the test above: the flat gradient of an 8-clip RemFX training step on the shipped stream
+    configuration -- compute, weight-gradient side stream, time branch on its own stream, Input_* metrics on a fourth -- repeated 25
+    times with allocator churn and a step of another batch shape (3 clips) in between, against the SAME step with everything on one
+    stream.  Since round 6 every reduction of the step stores per-workgroup slots and adds them in a fixed order (no zero fill + atomics
+    anywhere on the path), so in the bf16 mode the comparison is BIT-EXACT: any lost or reordered contribution fails it.  The other
+    modes run the channel-major kernels, whose remaining fp32 atomics (GroupNorm affine sums of long rows) allow order noise: 1e-5 of
+    the gradient norm there."""
+    import bench
+    from remfx_amd import hdemucs as hd, models as md, ops
+    prev_mode = ops.GradSink.MODE
+    flags = (hd.TWO_STREAMS, md.METRIC_STREAM)
+    try:
+        ops.GradSink.MODE = "side"
+        model = bench.build_model("demucs", torch.device(DEV))
+        opt = model.configure_optimizers()["optimizer"]
+        flat = opt.flat
+        data8 = bench.synthetic_batch(8, 0, torch.device(DEV))
+        data3 = bench.synthetic_batch(3, 1, torch.device(DEV))
+
+        def grads(data, streams):
+            sink = flat.sink
+            keep = sink.side
+            hd.TWO_STREAMS, md.METRIC_STREAM = (flags if streams else (False, False))
+            if not streams:
+                sink.side = None
+            try:
+                opt.zero_grad()
+                loss = model.training_step(data, 0)
+                loss.backward()
+                flat.join()
+                torch.cuda.synchronize()
+                return flat.grad.detach().clone(), float(loss)
+            finally:
+                sink.side = keep
+                hd.TWO_STREAMS, md.METRIC_STREAM = flags
+        hd.TWO_STREAMS = md.METRIC_STREAM = True
+        flags = (True, True)
+        grads(data8, True)                                   # warm-up (pack caches, allocator)
+        ref, lref = grads(data8, False)
+        ref2, lref2 = grads(data8, False)
+        gnorm = float(ref.norm())
+        assert gnorm > 0 and lref == lref2
+        base = float((ref2 - ref).norm()) / gnorm
+        worst, nbad = 0.0, 0
+        for r in range(25):
+            g, l = grads(data8, True)
+            d = float((g - ref).norm()) / gnorm
+            worst = max(worst, d)
+            nbad += int(not torch.equal(g, ref))
+            if r % 2 == 0:
+                grads(data3, True)                           # another batch shape in between: allocator blocks change hands
+            junk = [torch.empty((1 + (7919 * (r + 3) * k) % 50_000_000,), device=DEV) for k in range(1, 6)]
+            del junk[::2]
+        print(f"one-stream run to run {base:.2e}; four streams vs one stream: worst {worst:.2e}, {nbad} of 25 not bit-equal")
+        if mode() == "bf16":
+            assert base == 0.0 and worst == 0.0 and nbad == 0, (base, worst, nbad)
+        else:
+            check(worst, 1e-5, 1.0, bf16x3=1e-5, bf16=1e-5, what=("four streams vs one stream", worst, base))
+    finally:
+        ops.GradSink.MODE = prev_mode
+        hd.TWO_STREAMS, md.METRIC_STREAM = flags if isinstance(flags, tuple) else (True, True)

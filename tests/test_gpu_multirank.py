@@ -60,3 +60,27 @@ def test_two_ranks_timed_preheat():
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 2 and 2 <= line["preheat_steps"] <= 12, line["preheat_steps"]
     assert torch.isfinite(torch.tensor(line["config"]["final_loss"]))
+
+
+def test_two_ranks_run_the_single_rank_stream_configuration():
+    """the multi-rank step used to switch the time-branch stream off (hdemucs._data_parallel) -- a different stream
+    configuration from the benchmarked one.  ddp.GradSync now orders a bucket's all-reduce behind every stream the gradient sink saw
+    writes on, so two ranks in the bf16 mode (channels-last trunk, time branch on its own stream) report the same `config.streams` as
+    one rank and end with the parameters of the 1-rank run on the union of their clips."""
+    common = ["--steps", "2", "--warmup", "1", "--preheat", "0", "--batch", "2", "--workload", "demucs", "--no-cpu-baseline", "--no-also",
+              "--gemm", "bf16"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    if torch.cuda.device_count() < 2:
+        env.update(RFX_FORCE_DEVICE="0", RFX_DIST_BACKEND="gloo")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+                        + common, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    two = _json_line(r2.stdout)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--union-ranks", "2"] + common,
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ))
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    one = _json_line(r1.stdout)
+    assert two["config"]["streams"] == one["config"]["streams"] == 4, (two["config"]["streams"], one["config"]["streams"])
+    a, b = two["config"]["param_abs_sum"], one["config"]["param_abs_sum"]
+    assert a > 0 and abs(a - b) < 2e-6 * b, (a, b)

@@ -168,8 +168,9 @@ def test_pair_loss_kernel(geom):
     X = stft.stft_raw(x, n_fft, hop, win, w, 5)
     Y = stft.stft_raw(y, n_fft, hop, win, w, 5)
     n = X.shape[1] * X.shape[2]
-    ref = torch.zeros(R, 3, device=DEV)
-    _lib.check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, 1e-8, _ptr(ref), _stream()), "reduce")
+    ref = torch.full((R, 3), float("nan"), device=DEV)                # written, not accumulated: no zero fill
+    ws = torch.empty(3 * R * 64, device=DEV, dtype=torch.float64)
+    _lib.check(_lib.lib().rfx_stft_loss_reduce(_ptr(X), _ptr(Y), R, n, 1e-8, _ptr(ws), _ptr(ref), _stream()), "reduce")
     sums, Xp, ym = losses._pair_sums(x, y, n_fft, hop, win, w, 1e-8, True)
     assert Xp.shape == X.shape and ym.shape == X.shape[:3]
     scale = float(X.abs().max())
@@ -178,6 +179,7 @@ def test_pair_loss_kernel(geom):
     assert torch.allclose(sums.cpu(), ref.cpu(), rtol=2e-5, atol=0)
     s2, X2, _ = losses._pair_sums(x, y, n_fft, hop, win, w, 1e-8, False)
     assert X2 is None and torch.allclose(s2.cpu(), ref.cpu(), rtol=2e-5, atol=0)
+    assert torch.equal(s2, sums)                          # per-workgroup slots added in order: bit-reproducible
 
 
 @pytest.mark.parametrize("case", [(1024, 120, 600, 5, 30011), (2048, 240, 1200, 3, 20000), (512, 50, 240, 9, 7001)])
