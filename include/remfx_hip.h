@@ -190,7 +190,7 @@ int rfx_gemm_wgrad(const rfx_gemm_desc* d, const rfx_ktab_entry* ktab, const flo
  *   With in_mode=1 / herm=1 it is the backward of the iSTFT.
  * rfx_fft_synthesis: spectrum -> inverse real FFT -> window -> overlap-add BY OWNERSHIP
  *   (round 6: a workgroup walks consecutive frames of a row, carries the incomplete tail
- *   of the running sum in LDS and stores every output sample exactly once: no atomics,
+ *   of the running sum in its own scratch and stores every output sample exactly once: no atomics,
  *   no zero fill, bit-reproducible; d->accum selects write / add).  Geometries outside
  *   that form (extra reflect pads, rows shorter than 2 n_fft in the reflect mode) fall
  *   back to fp32 atomics into an output the launcher zero-fills itself.  With herm=1 / in_mode=1 it is
@@ -228,8 +228,11 @@ typedef struct rfx_stft_desc {
 
 int rfx_fft_analysis(const rfx_stft_desc* d, const float* x, const float* window, const float* mul,
                      float* out, void* stream);
+/* ws: rfx_fft_synthesis_ws(d) floats of scratch (no initialisation needed): the running sums a workgroup carries from one frame
+ * batch to the next and the padded edge zones of the reflect-padded adjoint */
+int64_t rfx_fft_synthesis_ws(const rfx_stft_desc* d);
 int rfx_fft_synthesis(const rfx_stft_desc* d, const float* spec, const float* window, const float* mul,
-                      float* out, void* stream);
+                      float* ws, float* out, void* stream);
 
 /* ---- LSTM recurrence ------------------------------------------------------------
  * Bidirectional nn.LSTM layer (HDemucs DConv BLSTM through models.py:319; Open-Unmix models.py:297-298), one
@@ -559,7 +562,7 @@ int rfx_stft_loss_grad_m(const float* xc, const float* ymag, int32_t R, int64_t 
  * 1.15 GB of the 64-clip step's traffic per resolution.  d as for rfx_fft_synthesis (d->accum: write / add).
  * The backward of auraloss STFTLoss behind models.py:320. */
 int rfx_fft_synthesis_lossgrad(const rfx_stft_desc* d, const float* xspec, const float* ymag, const float* sums, float w_sc,
-                               float w_lm, float eps, const float* gup, const float* window, float* out, void* stream);
+                               float w_lm, float eps, const float* gup, const float* window, float* ws, float* out, void* stream);
 /* g[i] = w * gup[0] * sign(a[i] - b[i])   (nn.L1Loss backward; gup as above, NULL = 1) */
 int rfx_l1_grad(const float* a, const float* b, int64_t n, float w, const float* gup, float* g, void* stream);
 /* per row: sums[r] = { sum x, sum t, sum x t, sum x^2, sum t^2 } in fp64 (auraloss SISDRLoss).  ws: 5 * R * RFX_SISDR_SLOTS doubles of

@@ -136,13 +136,14 @@ SIGNATURES = {
     "rfx_gemm_fwd_variant": [C.POINTER(GemmDesc), C.POINTER(Epilogue), _I32, _I32],
     "rfx_gemm_wgrad": [C.POINTER(GemmDesc), _P, _P, _P, _P, _I64, C.POINTER(C.c_int32), _I32, _P],
     "rfx_fft_analysis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
-    "rfx_fft_synthesis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P],
+    "rfx_fft_synthesis_ws": [C.POINTER(StftDesc)],
+    "rfx_fft_synthesis": [C.POINTER(StftDesc), _P, _P, _P, _P, _P, _P],
     "rfx_stft_loss_reduce": [_P, _P, _I32, _I64, C.c_float, _P, _P, _P],
     "rfx_stft_loss_grad": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_stft_loss_grad_m": [_P, _P, _I32, _I64, C.c_float, _P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_stft_pair_loss_ws": [C.POINTER(StftDesc)],
     "rfx_stft_pair_loss": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P, _P],
-    "rfx_fft_synthesis_lossgrad": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P],
+    "rfx_fft_synthesis_lossgrad": [C.POINTER(StftDesc), _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P],
     "rfx_l1_grad": [_P, _P, _I64, C.c_float, _P, _P, _P],
     "rfx_sisdr_sums": [_P, _P, _I32, _I64, _I64, _I64, _P, _P, _P],
     "rfx_sisdr_finish": [_P, _I32, _I64, _I32, C.c_double, _P, _P],
@@ -238,7 +239,7 @@ SIGNATURES = {
     "rfx_cl_dconv_bwd": [_P, _P, _P],
 }
 
-_RET64 = {"rfx_cl_wgrad_ws_floats", "rfx_stft_pair_loss_ws", "rfx_channel_sum_ws"}
+_RET64 = {"rfx_cl_wgrad_ws_floats", "rfx_stft_pair_loss_ws", "rfx_channel_sum_ws", "rfx_fft_synthesis_ws"}
 _lib = None
 
 

@@ -58,7 +58,9 @@ struct FftArgs {
   float lg_wsc, lg_wlm, lg_eps;
   // synthesis by OWNERSHIP (round 6): a workgroup walks `walk_frames` consecutive frames of a row (the last walk of a row takes the
   // remainder) after `halo_frames` frames of run-in, and stores every output sample of its range exactly once
-  int walk_frames, halo_frames, ring_floats;
+  int walk_frames, halo_frames;
+  float* ws;              // OWN scratch: zone[R][2][n_fft + 1] | carry[grid][2][n_fft]
+  int64_t cover_lo, cover_hi;   // padded positions some frame covers
 };
 
 // d [ w_sc sqrt(A) / sqrt(B) + w_lm sum |log|X| - log|Y|| ] / dX at one cell: stft_loss_grad_kernel's formula (csrc/losses.hip, paired
@@ -433,7 +435,6 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
   constexpr int NC = K::NC, T = K::T, FB = K::FB, N = 2 * NC;
   __shared__ v2f data[FB * K::FS];
   __shared__ FftTables<LOGN> tb;
-  extern __shared__ float own_lds[];                        // OWN: ring[ring_floats] | edgeL[NC + 1] | edgeR[NC + 1] (in_mode 0)
   const rfx_stft_desc& d = a.d;
   int row, f_first;
   block_coords<LOGN>(a, row, f_first);
@@ -473,11 +474,15 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     lg_ksc = (A > 0.f && B > 0.f) ? wsc / (sqrtf(A) * sqrtf(B)) : 0.f;
   }
   // OWN: walk w = frames [F0, F1) of the row, run-in from hs
-  int F0 = 0, F1 = f_end, hs = f_first, rbase = 0;
+  int F0 = 0, F1 = f_end, hs = f_first;
   int64_t own_lo = INT64_MIN, own_hi = INT64_MAX;
-  float* ring = own_lds;
-  float* edgeL = own_lds + a.ring_floats;
-  float* edgeR = edgeL + NC + 1;
+  // OWN scratch in global memory (LDS has no room: a third workgroup per CU is worth more than the carry's L2 round trip, measured):
+  // the carry of this workgroup -- two buffers of N floats, written for the NEXT batch's positions while this batch's are read --
+  // and the row's two edge zones as PADDED positions (folded by fft_fold_zones_kernel after the launch)
+  float* carry = a.ws + (int64_t)d.R * 2 * (N + 1) + (int64_t)blockIdx.x * 2 * N;
+  float* zoneL = a.ws + ((int64_t)row * 2) * (N + 1);
+  float* zoneR = zoneL + (N + 1);
+  int cin = 0;                                              // positions q < cin of the current batch have a carry from the previous one
   bool first_walk = true, last_walk = true;
   if (OWN) {
     const int w = (blockIdx.x >> 3) % a.groups_per_row;
@@ -487,51 +492,46 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     hs = max(d.frame0, F0 - a.halo_frames);
     if (!first_walk) own_lo = (int64_t)F0 * d.hop + woff;
     if (!last_walk) own_hi = (int64_t)F1 * d.hop + woff;
-    for (int i = tid; i < a.ring_floats + (d.in_mode == 0 ? 2 * (NC + 1) : 0); i += 256) own_lds[i] = 0.f;
-    // (the first lds_barrier of the batch loop orders these stores before the first ring access)
   }
   const int f_stop = OWN ? F1 : f_end;                      // frames at and beyond f_stop are not this workgroup's
-  for (int g = 0; OWN || g < a.nbatch; ++g) {
-    const int fb0 = OWN ? hs + g * FB : f_first + g * FB;
-    if (fb0 >= f_stop) break;
-    // merge step on bin pairs (k, NC - k), k in [0, NC / 2]: S = X[k] + conj X[NC-k], W = (X[k] - conj X[NC-k]) e^{+i pi k/NC}
-    //   Z[k] = S + i W,  Z[NC - k] = conj S + i conj W;  conj Z is written in natural order (the inverse = conj FFT conj)
-    const bool fm = d.mode == RFX_STFT_COMPLEX_FM;           // frame-major spectrum: lanes along bins
-    // all loads of the thread's NIT items first (clamped indices, validity applied to the values): a load -> use loop costs one
-    // memory round trip per item and batch
-    constexpr int NIT = (K::NH * FB + 255) / 256;
-    v2f xkv[NIT], xmv[NIT];
-    float ykv[NIT], ymv[NIT];                                // loss-gradient source: the target magnitudes of the same cells
-    auto item = [&](int it, int& fl2, int& k) -> bool {
-      const int idx = tid + 256 * it;
-      const bool act = idx < K::NH * FB;
-      const int ii = act ? idx : 0;
-      fl2 = fm ? ii / K::NH : ii & (FB - 1);
-      k = fm ? ii - fl2 * K::NH : ii / FB;
-      return act;
-    };
-    auto fetch = [&](int kq, int fo) -> v2f {
-      const int kc = kq < d.bins ? kq : 0;
-      v2f v;
-      if (fm) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * FO + fo) * d.bins + kc];
-      else if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * d.bins + kc) * FO + fo];   // uniform
-      else {
-        v.x = a.x[((int64_t)row * 2 * d.bins + kc) * FO + fo];
-        v.y = a.x[((int64_t)row * 2 * d.bins + d.bins + kc) * FO + fo];
-      }
-      return v;
-    };
-    auto fix = [&](v2f v, int kq) -> v2f {
-      if (kq >= d.bins) v = v2f{0.f, 0.f};
-      if (kq == 0 || kq == NC) v.y = 0.f;             // real by construction / ignored by irfft
-      else if (!d.herm) v = v * 0.5f;                 // adjoint of the one-sided rfft
-      return v;
-    };
+  const bool fm = d.mode == RFX_STFT_COMPLEX_FM;           // frame-major spectrum: lanes along bins
+  // all loads of the thread's NIT items first (clamped indices, validity applied to the values): a load -> use loop costs one
+  // memory round trip per item and batch
+  constexpr int NIT = (K::NH * FB + 255) / 256;
+  v2f xkv[NIT], xmv[NIT];
+  float ykv[NIT], ymv[NIT];                                // loss-gradient source: the target magnitudes of the same cells
+  auto item = [&](int it, int& fl2, int& k) -> bool {
+    const int idx = tid + 256 * it;
+    const bool act = idx < K::NH * FB;
+    const int ii = act ? idx : 0;
+    fl2 = fm ? ii / K::NH : ii & (FB - 1);
+    k = fm ? ii - fl2 * K::NH : ii / FB;
+    return act;
+  };
+  auto fetch = [&](int kq, int fo) -> v2f {
+    const int kc = kq < d.bins ? kq : 0;
+    v2f v;
+    if (fm) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * FO + fo) * d.bins + kc];
+    else if (d.mode == RFX_STFT_COMPLEX) v = reinterpret_cast<const v2f*>(a.x)[((int64_t)row * d.bins + kc) * FO + fo];   // uniform
+    else {
+      v.x = a.x[((int64_t)row * 2 * d.bins + kc) * FO + fo];
+      v.y = a.x[((int64_t)row * 2 * d.bins + d.bins + kc) * FO + fo];
+    }
+    return v;
+  };
+  auto fix = [&](v2f v, int kq) -> v2f {
+    if (kq >= d.bins) v = v2f{0.f, 0.f};
+    if (kq == 0 || kq == NC) v.y = 0.f;             // real by construction / ignored by irfft
+    else if (!d.herm) v = v * 0.5f;                 // adjoint of the one-sided rfft
+    return v;
+  };
+  // all loads of a batch: the thread's NIT items (clamped indices, validity applied to the values)
+  auto load_batch = [&](int fb) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int fl2, k;
       item(it, fl2, k);
-      const int f2 = fb0 + fl2;
+      const int f2 = fb + fl2;
       const int fo = f2 < f_stop ? f2 - d.frame0 : 0;
       xkv[it] = fetch(k, fo);
       xmv[it] = fetch(NC - k, fo);
@@ -541,6 +541,13 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
         ymv[it] = a.lg_ymag[cell0 + (NC - k < d.bins ? NC - k : 0)];
       }
     }
+  };
+  for (int g = 0; OWN || g < a.nbatch; ++g) {
+    const int fb0 = OWN ? hs + g * FB : f_first + g * FB;
+    if (fb0 >= f_stop) break;
+    // merge step on bin pairs (k, NC - k), k in [0, NC / 2]: S = X[k] + conj X[NC-k], W = (X[k] - conj X[NC-k]) e^{+i pi k/NC}
+    //   Z[k] = S + i W,  Z[NC - k] = conj S + i conj W;  conj Z is written in natural order (the inverse = conj FFT conj)
+    load_batch(fb0);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int fl2, k;
@@ -575,12 +582,17 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     const int64_t p0 = (int64_t)fb0 * d.hop;
     if (OWN) {
       // Every padded position q of the batch's span: the batch's frames that cover it (out of LDS, as below) + what earlier batches
-      // left in the ring.  Complete (no later frame of the row starts at or before it) -> stored if it is this walk's own, else it
-      // goes back into the ring.  A position is one thread's per batch: no LDS races; one barrier per batch (the loop's).
-      const int fin = (fb0 + nf >= f_end) ? span : nf * d.hop + woff;
+      // carried over.  Complete (no later frame of the row starts at or before it) -> stored if it is this walk's own, else it is
+      // carried to the next batch.  A position is one thread's per batch; the carry buffers alternate, so no position is read and
+      // written in the same batch; the stores are drained (vmcnt) before the batch's barrier and read back past L1 (sc1).
+      const int adv = nf * d.hop;
+      const int fin = (fb0 + nf >= f_end) ? span : adv + woff;
+      const float* cr = carry + (g & 1) * N;
+      float* cw = carry + ((g + 1) & 1) * N;
       for (int q = tid; q < span; q += 256) {
         const int qw = q - woff;
-        if (qw < 0) continue;                          // complete (and cleared) since the previous batch
+        if (qw < 0) continue;                          // complete since the previous batch
+        float v = q < cin ? __hip_atomic_load(cr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
         const int lo_num = qw - d.win + 1;
         int fl_hi, fl_lo;
         if (a.hop_magic) {
@@ -590,17 +602,14 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
           fl_hi = min(nf - 1, qw / d.hop);
           fl_lo = lo_num > 0 ? (lo_num + d.hop - 1) / d.hop : 0;
         }
-        float v = 0.f;
+        float gsum = 0.f;
         for (int f2 = fl_lo; f2 <= fl_hi; ++f2) {
           const int t = q - f2 * d.hop;
           const v2f zz = data[f2 * K::FS + fft_phys3<LOGN>(t >> 1)];
-          v += (t & 1) ? -zz.y : zz.x;
+          gsum += (t & 1) ? -zz.y : zz.x;
         }
-        int ri = rbase + q;
-        if (ri >= a.ring_floats) ri -= a.ring_floats;
-        v += ring[ri];
-        if (q >= fin) { ring[ri] = v; continue; }
-        ring[ri] = 0.f;
+        v += gsum;
+        if (q >= fin) { cw[q - adv] = v; continue; }
         const int64_t p = p0 + q;
         if (p < own_lo || p >= own_hi) continue;
         v *= d.scale;
@@ -609,16 +618,14 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
           const int64_t sx = p - d.in_offset;
           if (sx >= 0 && sx < d.T) outr[sx] = d.accum ? outr[sx] + v : v;
         } else {                                        // adjoint of centre + reflect padding (no extra pads: the launcher checks)
-          const int sx = (int)p - NC;                   // NC = n_fft / 2
-          if (sx <= NC) atomicAdd(&edgeL[sx < 0 ? -sx : sx], v);                      // samples 0 .. NC: direct + mirrored
-          else if (sx >= d.T - 1 - NC) {
-            const int s2 = sx >= d.T ? 2 * (d.T - 1) - sx : sx;
-            if (s2 >= d.T - 1 - NC && s2 < d.T) atomicAdd(&edgeR[s2 - (d.T - 1 - NC)], v);
-          } else outr[sx] = d.accum ? outr[sx] + v : v;
+          const int sx = (int)p - NC;                   // NC = n_fft / 2: the sample this padded position is, before mirroring
+          if (sx <= NC) zoneL[p] = v;                   // padded positions [0, n_fft]: samples 0 .. NC, direct and mirrored
+          else if (sx >= d.T - 1 - NC) { if (p - (d.T - 1) <= N) zoneR[p - (d.T - 1)] = v; }   // padded [T - 1, T - 1 + n_fft]
+          else outr[sx] = d.accum ? outr[sx] + v : v;
         }
       }
-      rbase += nf * d.hop;
-      if (rbase >= a.ring_floats) rbase -= a.ring_floats;
+      cin = span - adv;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
     // Overlap-add by GATHER inside the workgroup: the batch's frames are consecutive, so every padded position p of their span
     // sums the <= ceil(win / hop) frames that cover it out of LDS and issues ONE global atomic (the scatter form issued
@@ -652,10 +659,26 @@ __global__ __launch_bounds__(256, 3) void fft_synthesis_kernel(const FftArgs a) 
     }
     lds_barrier();
   }
-  if (OWN && d.in_mode == 0) {                             // the folded edge zones: samples [0, NC] and [T - 1 - NC, T - 1]
-    if (first_walk) for (int i = tid; i <= NC; i += 256) outr[i] = d.accum ? outr[i] + edgeL[i] : edgeL[i];
-    if (last_walk) for (int i = tid; i <= NC; i += 256) { float* o = outr + (d.T - 1 - NC) + i; *o = d.accum ? *o + edgeR[i] : edgeR[i]; }
-  }
+}
+
+// The edge zones of the reflect-padded adjoint (in_mode 0, OWN): sample s in [0, NC] = padded position NC + s plus its mirror image
+// NC - s; sample T - 1 - NC + i = padded T - 1 + i plus the mirror image T - 1 + n_fft - i.  Positions no frame covers count 0.
+// One thread per sample: two adds in a fixed order.
+__global__ __launch_bounds__(256) void fft_fold_zones_kernel(const float* __restrict__ ws, float* __restrict__ out, int R, int T, int NC,
+                                                             int64_t c_lo, int64_t c_hi, int accum) {
+  const int per = 2 * (NC + 1);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * per) return;
+  const int row = idx / per, r = idx - row * per, side = r / (NC + 1), i = r - side * (NC + 1);
+  const float* z = ws + ((int64_t)row * 2 + side) * (2 * NC + 1);
+  const int64_t base = side ? (int64_t)T - 1 : 0;          // padded position of z[0]
+  auto at = [&](int k) -> float { const int64_t p = base + k; return (p >= c_lo && p < c_hi) ? z[k] : 0.f; };
+  float v;
+  int s;
+  if (side == 0) { s = i; v = at(NC + i); if (i >= 1) v += at(NC - i); }
+  else { s = T - 1 - NC + i; v = at(i); if (i < NC) v += at(2 * NC - i); }
+  float* o = out + (int64_t)row * T + s;
+  *o = accum ? *o + v : v;
 }
 
 static bool stft_desc_ok(const rfx_stft_desc* d) {
@@ -700,9 +723,43 @@ struct FftLossGradSrc {
   const float* ymag; const float* sums; const float* gup;
   float w_sc, w_lm, eps;
 };
+// Geometry of the ownership form of the synthesis (0 walks: the geometry takes the atomic form)
+struct SynOwn { int walk_frames, halo, nwalks; unsigned grid; int64_t ws_floats; };
+static SynOwn syn_own_geometry(const rfx_stft_desc* d) {
+  SynOwn o{0, 0, 0, 0, 0};
+  static const int own_on = [] { const char* e = getenv("RFX_FFT_OWN"); return e ? atoi(e) : 1; }();
+  const int woff = (d->n_fft - d->win) / 2, nc = d->n_fft / 2, fb = 4096 / nc;
+  const bool own = own_on && d->hop <= d->win &&
+                   (d->in_mode == 1 || (!d->extra_pad_l && !d->extra_pad_r && d->frame0 == 0 && d->T > 2 * d->n_fft + 2));
+  if (!own) return o;
+  const int halo = (d->win - 1) / d->hop;
+  int fw_min = halo + 1;
+  if (d->in_mode == 0) {                                     // walk 0 owns padded [0, n_fft], the last walk padded [T - 1, ...)
+    fw_min = std::max(fw_min, (d->n_fft + 1 - woff + d->hop - 1) / d->hop + 1);
+    fw_min = std::max(fw_min, 2 + (woff + d->hop) / d->hop);
+  }
+  fw_min = std::max(fw_min, 2 * halo);                       // run-in <= half of a walk
+  int64_t fw = ((int64_t)d->frames_out * d->R + 2047) / 2048; // ~2048 workgroups ...
+  fw = std::min<int64_t>(fw, std::max(16 * halo, 4 * fb));    // ... of walks no longer than needed to make the run-in cheap
+  static const int fw_env = [] { const char* e = getenv("RFX_FFT_OWN_FW"); return e ? atoi(e) : 0; }();      // dev: frames per walk
+  if (fw_env > 0) fw = fw_env;
+  fw = std::max<int64_t>(fw, fw_min);
+  fw = (fw + fb - 1) / fb * fb;
+  o.walk_frames = (int)fw; o.halo = halo;
+  o.nwalks = std::max<int>(1, (int)(d->frames_out / fw));     // the last walk takes the remainder (< 2 fw frames)
+  o.grid = (unsigned)((d->R + 7) / 8 * o.nwalks * 8);
+  o.ws_floats = (int64_t)d->R * 2 * (d->n_fft + 1) + (int64_t)o.grid * 2 * d->n_fft;
+  return o;
+}
+extern "C" int64_t rfx_fft_synthesis_ws(const rfx_stft_desc* d) {
+  if (!stft_desc_ok(d)) return -1;
+  const int64_t n = syn_own_geometry(d).ws_floats;
+  return n > 0 ? n : 1;
+}
+
 template <bool SYN>
 static int launch_fft(const rfx_stft_desc* d, const float* x, const float* window, const float* mul,
-                      float* out, void* stream, const FftLossGradSrc* lgsrc = nullptr) {
+                      float* out, void* stream, const FftLossGradSrc* lgsrc = nullptr, float* ws = nullptr) {
   if (!stft_desc_ok(d) || !x || !window || !out) return -1;
   FftArgs a;
   a.d = *d; a.x = x; a.window = window; a.mul = mul; a.out = out;
@@ -730,39 +787,26 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
     while (nb < (SYN ? syn_nb_max : 4) && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
   a.nbatch = nb;
   a.groups_per_row = (batches + nb - 1) / nb;
-  a.walk_frames = a.halo_frames = a.ring_floats = 0;
+  a.walk_frames = a.halo_frames = 0; a.ws = nullptr; a.cover_lo = a.cover_hi = 0;
   unsigned grid = (unsigned)(rows8 * a.groups_per_row * 8);
   hipStream_t s = (hipStream_t)stream;
   if (SYN) {
     // Overlap-add by ownership wherever the geometry allows it (everything the networks and losses use); else the atomic form into
     // a zero-filled output (extra reflect pads = the backward of HDemucs' _spec, which nothing differentiates; rows too short for two
     // disjoint edge zones; hop > win).
-    static const int own_on = [] { const char* e = getenv("RFX_FFT_OWN"); return e ? atoi(e) : 1; }();
     const int woff = (d->n_fft - d->win) / 2;
-    const bool own = own_on && d->hop <= d->win && (d->in_mode == 1 || (!d->extra_pad_l && !d->extra_pad_r && d->frame0 == 0 && d->T > 2 * d->n_fft + 2));
-    if (own) {
-      const int halo = (d->win - 1) / d->hop;
-      int fw_min = halo + 1;
-      if (d->in_mode == 0) {                                     // walk 0 owns samples [0, n_fft / 2], the last walk the mirror zone
-        fw_min = std::max(fw_min, (d->n_fft + 1 - woff + d->hop - 1) / d->hop + 1);
-        fw_min = std::max(fw_min, 2 + (woff + d->hop) / d->hop);
-      }
-      fw_min = std::max(fw_min, 2 * halo);                       // run-in <= half of a walk
-      int64_t fw = ((int64_t)d->frames_out * d->R + 2047) / 2048; // ~2048 workgroups ...
-      fw = std::min<int64_t>(fw, std::max(8 * halo, 4 * fb));     // ... of walks no longer than needed to make the run-in cheap
-      fw = std::max<int64_t>(fw, fw_min);
-      fw = (fw + fb - 1) / fb * fb;
-      const int nwalks = std::max<int>(1, (int)(d->frames_out / fw));   // the last walk takes the remainder (< 2 fw frames)
-      a.walk_frames = (int)fw; a.halo_frames = halo; a.groups_per_row = nwalks;
-      a.ring_floats = (fb - 1) * d->hop + d->n_fft;
-      grid = (unsigned)(rows8 * nwalks * 8);
-      const size_t dyn = sizeof(float) * ((size_t)a.ring_floats + (d->in_mode == 0 ? 2 * (size_t)(nc + 1) : 0));
+    const SynOwn own = syn_own_geometry(d);
+    if (own.nwalks) {
+      if (!ws) return -1;
+      a.walk_frames = own.walk_frames; a.halo_frames = own.halo; a.groups_per_row = own.nwalks; a.ws = ws;
+      grid = own.grid;
       // every sample stored?  covered padded positions: [frame0 hop + woff, (frame0 + frames_out - 1) hop + woff + win)
       const int64_t c_lo = (int64_t)d->frame0 * d->hop + woff, c_hi = (int64_t)(d->frame0 + d->frames_out - 1) * d->hop + woff + d->win;
       const bool full = d->in_mode == 1 ? (c_lo <= d->in_offset && c_hi >= (int64_t)d->in_offset + d->T)
                                         : (c_lo <= 2 * (int64_t)nc + 1 && c_hi >= (int64_t)d->T - 1);
       if (!full && !d->accum && hipMemsetAsync(out, 0, sizeof(float) * (size_t)d->R * d->T, s) != hipSuccess) return -3;
-#define RFX_SYN_OWN(LOGN, LGV) hipLaunchKernelGGL((fft_synthesis_kernel<LOGN, LGV, true>), dim3(grid), dim3(256), dyn, s, a)
+      a.cover_lo = c_lo; a.cover_hi = c_hi;
+#define RFX_SYN_OWN(LOGN, LGV) hipLaunchKernelGGL((fft_synthesis_kernel<LOGN, LGV, true>), dim3(grid), dim3(256), 0, s, a)
       if (lgsrc) {
         switch (d->n_fft) {
           case 512: RFX_SYN_OWN(8, true); break;
@@ -780,6 +824,11 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
       }
 #undef RFX_SYN_OWN
       RFX_CHECK_LAUNCH();
+      if (d->in_mode == 0) {
+        const int n = d->R * 2 * (nc + 1);
+        hipLaunchKernelGGL(fft_fold_zones_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, out, d->R, d->T, nc, c_lo, c_hi, d->accum);
+        RFX_CHECK_LAUNCH();
+      }
       return 0;
     }
     if (!d->accum && hipMemsetAsync(out, 0, sizeof(float) * (size_t)d->R * d->T, s) != hipSuccess) return -3;   // atomic form
@@ -1032,15 +1081,16 @@ extern "C" int rfx_fft_analysis(const rfx_stft_desc* d, const float* x, const fl
   return launch_fft<false>(d, x, window, mul, out, stream);
 }
 extern "C" int rfx_fft_synthesis(const rfx_stft_desc* d, const float* spec, const float* window,
-                                 const float* mul, float* out, void* stream) {
+                                 const float* mul, float* ws, float* out, void* stream) {
   if (d && d->mode != RFX_STFT_COMPLEX && d->mode != RFX_STFT_CAC && d->mode != RFX_STFT_COMPLEX_FM) return -1;
-  return launch_fft<true>(d, spec, window, mul, out, stream);
+  return launch_fft<true>(d, spec, window, mul, out, stream, nullptr, ws);
 }
 // rfx_stft_loss_grad_m + rfx_fft_synthesis in one launch (the backward of one auraloss STFTLoss resolution behind models.py:320):
 // the gradient spectrum is never written -- the merge step computes it from the stored prediction spectrum and target magnitudes
 extern "C" int rfx_fft_synthesis_lossgrad(const rfx_stft_desc* d, const float* xspec, const float* ymag, const float* sums, float w_sc,
-                                          float w_lm, float eps, const float* gup, const float* window, float* out, void* stream) {
+                                          float w_lm, float eps, const float* gup, const float* window, float* ws, float* out,
+                                          void* stream) {
   if (!d || d->mode != RFX_STFT_COMPLEX_FM || !ymag || !sums) return -1;
   FftLossGradSrc src{ymag, sums, gup, w_sc, w_lm, eps};
-  return launch_fft<true>(d, xspec, window, nullptr, out, stream, &src);
+  return launch_fft<true>(d, xspec, window, nullptr, out, stream, &src, ws);
 }

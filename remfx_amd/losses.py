@@ -155,7 +155,8 @@ class _MRSTFTFn(torch.autograd.Function):
                            accum=1 if ires else 0)
             if paired and FUSED_GRAD:   # Y = the clamped target magnitudes; the gradient spectrum is formed inside the synthesis
                 check(_lib.lib().rfx_fft_synthesis_lossgrad(C.byref(d), _ptr(X), _ptr(Y), _ptr(sums), w_sc, w_lm, eps, _ptr(gup),
-                                                            _ptr(w), _ptr(gx), _stream()), "rfx_fft_synthesis_lossgrad")
+                                                            _ptr(w), _ptr(stft.syn_ws(d, g.device)), _ptr(gx), _stream()),
+                      "rfx_fft_synthesis_lossgrad")
                 continue
             G = torch.empty_like(X)
             if paired:
@@ -164,7 +165,7 @@ class _MRSTFTFn(torch.autograd.Function):
             else:
                 check(_lib.lib().rfx_stft_loss_grad(_ptr(X), _ptr(Y), R, n, eps, _ptr(sums), w_sc, w_lm, _ptr(gup), _ptr(G),
                                                     _stream()), "rfx_stft_loss_grad")
-            check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(G), _ptr(w), None, _ptr(gx), _stream()),
+            check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(G), _ptr(w), None, _ptr(stft.syn_ws(d, g.device)), _ptr(gx), _stream()),
                   "rfx_fft_synthesis")
         ctx.saved = None
         return gx.view(shape), None, None, None, None, None, None

@@ -39,6 +39,11 @@ def _desc(R, T, n_fft, hop, win, bins, frame0, frames_out, mode, extra_pad=(0, 0
     return d
 
 
+def syn_ws(d, device):
+    """Scratch of one rfx_fft_synthesis launch (uninitialised): carried sums + padded edge zones (include/remfx_hip.h)."""
+    return torch.empty(int(_lib.lib().rfx_fft_synthesis_ws(C.byref(d))), device=device, dtype=torch.float32)
+
+
 def _out_shape(R, bins, frames, mode):
     if mode == 0:
         return (R, bins, frames, 2)
@@ -89,7 +94,7 @@ class STFTFn(torch.autograd.Function):
         gx = torch.empty((R, T), device=g.device, dtype=torch.float32)      # rfx_fft_synthesis writes every element (accum = 0)
         d = _desc(R, T, n_fft, hop, win, nb, frame0, fo, mode, extra_pad, in_mode=0, herm=0,
                   scale=(1.0 / math.sqrt(n_fft)) if normalized else 1.0)
-        check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(g), _ptr(window), None, _ptr(gx), _stream()),
+        check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(g), _ptr(window), None, _ptr(syn_ws(d, g.device)), _ptr(gx), _stream()),
               "rfx_fft_synthesis")
         return (gx,) + (None,) * 10
 
@@ -144,7 +149,7 @@ class ISTFTFn(torch.autograd.Function):
         out = torch.empty((R, length), device=spec.device, dtype=torch.float32)   # every sample is stored exactly once (overlap-add by ownership)
         d = _desc(R, length, n_fft, hop, win, nb, frame0, fi, mode, in_mode=1, in_offset=n_fft // 2 + crop,
                   herm=1, scale=scale)
-        check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(spec), _ptr(window), _ptr(inv_env), _ptr(out),
+        check(_lib.lib().rfx_fft_synthesis(C.byref(d), _ptr(spec), _ptr(window), _ptr(inv_env), _ptr(syn_ws(d, spec.device)), _ptr(out),
                                            _stream()), "rfx_fft_synthesis")
         ctx.save_for_backward(window, inv_env)
         ctx.cfg = (spec.shape, n_fft, hop, win, mode, frames, frame0, crop, length, scale, nb, fi)
