@@ -41,10 +41,25 @@ def _data_parallel():
     return torch.is_grad_enabled() and ops.SINK is None
 
 
-_XSUB = int(os.environ.get("RFX_XSYNC_SUB", "0"))
+def _dev_env(name, default):
+    """Hazard-hunt / measurement switches (they serialise streams, skip whole DConv branches or re-enable a known-bad statistics
+    path): honoured only under RFX_DEV=1, and then announced -- a leaked variable must not silently change results."""
+    v = os.environ.get(name)
+    if v is None or v == default:
+        return default
+    if os.environ.get("RFX_DEV") != "1":
+        import warnings
+        warnings.warn(f"{name}={v} ignored: development switch, set RFX_DEV=1 to honour it")
+        return default
+    import warnings
+    warnings.warn(f"RFX_DEV=1: development switch {name}={v} is ACTIVE and changes what the network computes or how it is ordered")
+    return v
+
+
+_XSUB = int(_dev_env("RFX_XSYNC_SUB", "0"))
 _CUR = [None, None]
-_XIDX = int(os.environ.get("RFX_XSYNC_IDX", "-1"))
-_XSYNC = int(os.environ.get("RFX_XSYNC", "0"))      # dev: serialisation points of the two-stream hazard hunt
+_XIDX = int(_dev_env("RFX_XSYNC_IDX", "-1"))
+_XSYNC = int(_dev_env("RFX_XSYNC", "0"))      # dev: serialisation points of the two-stream hazard hunt (DESIGN.md 4.10)
 
 
 def _time_stream(device):
@@ -132,8 +147,8 @@ class _LocalState(nn.Module):
 # The C >= 192 DConv branches took their GroupNorm statistics from the producing GEMM's epilogue (fp64 atomics into a zero-filled slot
 # buffer): those lose contributions while a second stream keeps the machine busy.  Default now: the GroupNorm kernel
 # computes them from the stored 16-bit tensor with per-chunk stores (what autocast's GroupNorm sees); 1 = the epilogue form (A/B).
-DCONV_EPI_STATS = os.environ.get("RFX_DCONV_EPI_STATS", "0") != "0"
-_ST_MODE = int(os.environ.get("RFX_ST_MODE", "0"))     # dev: how the statistics buffer of the channel-major DConv is zeroed (hazard hunt)
+DCONV_EPI_STATS = _dev_env("RFX_DCONV_EPI_STATS", "0") != "0"
+_ST_MODE = int(_dev_env("RFX_ST_MODE", "0"))     # dev: how the statistics buffer of the channel-major DConv is zeroed (hazard hunt)
 
 
 def _stat_buf(x):
@@ -146,7 +161,7 @@ def _stat_buf(x):
 
 
 _DCONV_DBG = None       # dev (scripts/probes/dconv_steps.py): a list collects per-sample checksums after every step of the channel-major path
-_DBG_SKIP = {int(v) for v in os.environ.get('RFX_DBG_SKIP_DCONV_C', '').split(',') if v}   # measurement only
+_DBG_SKIP = {int(v) for v in _dev_env('RFX_DBG_SKIP_DCONV_C', '').split(',') if v}   # measurement only
 
 
 class _DConv(nn.Module):

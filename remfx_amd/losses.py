@@ -126,11 +126,15 @@ class _MRSTFTFn(torch.autograd.Function):
             saved.append((paired, X, Y, sums, n, n_fft, hop, win))
         # sc + lm of every resolution and their mean: one launch on the row sums (was ~24 one-element torch launches per evaluation)
         nres = len(saved)
-        total = torch.empty((), device=x.device, dtype=torch.float32)
-        sp = (C.c_void_p * nres)(*[_ptr(e[3]) for e in saved])
-        nn_ = (C.c_int64 * nres)(*[int(e[4]) for e in saved])
-        check(_lib.lib().rfx_mrstft_combine(sp, nn_, nres, R, 1 if per_example_sc else 0, _ptr(total), _stream()),
-              "rfx_mrstft_combine")
+        total = None
+        for c0 in range(0, nres, 8):               # rfx_mrstft_combine takes up to 8 resolutions per launch (auraloss's default has 3)
+            part, m = saved[c0:c0 + 8], len(saved[c0:c0 + 8])
+            t = torch.empty((), device=x.device, dtype=torch.float32)
+            sp = (C.c_void_p * m)(*[_ptr(e[3]) for e in part])
+            nn_ = (C.c_int64 * m)(*[int(e[4]) for e in part])
+            check(_lib.lib().rfx_mrstft_combine(sp, nn_, m, R, 1 if per_example_sc else 0, _ptr(t), _stream()),
+                  "rfx_mrstft_combine")
+            total = t if nres <= 8 else (t * (m / nres) if total is None else total + t * (m / nres))
         ctx.saved = saved
         ctx.meta = (x.shape, R, L, eps, per_example_sc, nres)
         return total

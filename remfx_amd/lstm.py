@@ -44,8 +44,10 @@ _WS = {}
 
 
 def _workspace(device, H):
-    """Per (device, H) scratch for the cluster exchange; byte 0..3 = sticky error flag (see error_flag)."""
-    key = (device.index, H)
+    """Per (device, H, stream) scratch for the cluster exchange; byte 0..3 = sticky error flag (see error_flag).  Keyed by the
+    stream too: two recurrences of one H on two streams (a model whose time branch carries a BLSTM beside the frequency branch's)
+    must not share exchange buffers and arrival counters."""
+    key = (device.index, H, ops.raw_stream())
     ws = _WS.get(key)
     if ws is None:
         nb = _lib.lib().rfx_lstm_ws_bytes(H)
