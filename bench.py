@@ -336,7 +336,7 @@ def cpu_baseline(workload):
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     torch.manual_seed(0)
-    T = {"tcn": 16384, "demucs": CLIP, "dcunet": 32768, "umx": 65536}[workload]     # headline: one full 262144-sample clip
+    T = {"tcn": 16384, "demucs": CLIP, "dcunet": CLIP, "umx": 65536}[workload]     # Demucs / DCUNet (configs 3, 4): one full 262144-sample clip
     x, y = torch.randn(1, 1, T, generator=g) * 0.1, torch.randn(1, 1, T, generator=g) * 0.1
     if workload == "tcn":
         sd = {k: v.requires_grad_(True) for k, v in ref_tcn.tcn_init_state_dict(1, 1, 20, 256, 7).items()}
@@ -628,6 +628,31 @@ def also_block(args, model, opt, sched, sync, data, device, step):
                          "algorithmic_bytes_per_pass": m["bytes"], "algorithmic_flops_per_pass": m["flops"], "stages": m["stages"],
                          "target": "north_star: >= 0.5 of the HBM roofline on STFT + Demucs forward at 64 x 262144"}
     return res
+
+
+def dcunet_quality(model, data, device):
+    """BASELINE config 4's quality figure: SI-SDR (auraloss definition, negated) and RMS difference of the device output
+    against the CPU oracle restatement on IDENTICAL input and weights -- one full 262144-sample clip, inference mode (running
+    statistics), the session's arithmetic mode."""
+    from oracle import ref_dcunet, ref_losses
+    net = model.model.model                                  # RemFX -> DCUNetModel -> DCUNet
+    ref = ref_dcunet.DCUNet(stft_kernel_size=512, fix_length_mode="pad")
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    ref.eval()
+    was = net.training
+    net.eval()
+    x = data[0][:1]
+    try:
+        with torch.no_grad():
+            y_dev = net(x.squeeze(1)).float().cpu()
+            torch.set_num_threads(min(_host_cpu()[0], 32))
+            y_cpu = ref(x.squeeze(1).cpu())
+    finally:
+        net.train(was)
+    rms = float((y_dev - y_cpu).pow(2).mean().sqrt())
+    return {"si_sdr_vs_cpu_oracle_db": round(-float(ref_losses.sisdr_loss(y_dev, y_cpu)), 2),
+            "rms_vs_cpu_oracle": float(f"{rms:.3e}"), "output_rms": float(f"{float(y_cpu.pow(2).mean().sqrt()):.3e}"),
+            "parity_clip_samples": int(x.shape[-1]), "parity_mode": "eval (running statistics), identical weights and input"}
 
 
 def _n_aux_streams(args):
@@ -964,6 +989,28 @@ def main():
     if args.workload == "demucs" and world == 1 and not args.no_also:
         t_a0 = time.time()
         out["also"] = also_block(args, model, opt, sched, sync, data, device, step)
+        PHASES["also"] = round(time.time() - t_a0, 2)
+    if args.workload == "dcunet" and world == 1 and not args.no_also:
+        t_a0 = time.time()
+        out["also"] = dcunet_quality(model, data, device)
+        PHASES["also"] = round(time.time() - t_a0, 2)
+    if args.workload == "tcn" and world == 1 and not args.no_also and args.gemm != "f32":
+        # BASELINE config 2 is quoted in fp32: the exact-fp32 MFMA step (v_mfma_f32_32x32x2_f32) next to the bf16x3 headline
+        t_a0 = time.time()
+        prev = ops.gemm_precision()
+        ops.set_gemm_precision("f32")
+        try:
+            step(30_000)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            step(30_001)
+            torch.cuda.synchronize()
+            dt32 = time.time() - t1
+        finally:
+            ops.set_gemm_precision(prev)
+        out["also"] = {"train_step_f32": {"ms_per_step": round(dt32 * 1e3, 1), "audio_seconds_per_sec": round(batch * CLIP / SR / dt32, 3),
+                                          "dtype": DTYPES["f32"], "steps": 1,
+                                          "frac_mfma_f32_peak": round(3 * ALG["tcn"]["flops_fwd"] * batch / dt32 / 1e12 / PEAK_F32_TFLOPS, 4)}}
         PHASES["also"] = round(time.time() - t_a0, 2)
     if not args.no_cpu_baseline:
         t_c0 = time.time()
