@@ -105,16 +105,20 @@ __device__ __forceinline__ double rfx_wave_sum_d(double v) {
 // contributions when a second stream kept the machine busy.  Now every workgroup STORES its partial into its own
 // slot of a caller-owned workspace -- slots[(row * nslots + slot) * K + k], fp64, no initialisation needed -- and
 // rfx_slot_sum_kernel adds a row's slots in slot order: bit-reproducible, no fill, no atomics.
+// One WAVE per output value: lane l adds slots l, l + 64, ... in order, then the fixed butterfly -- a single thread walking thousands of
+// dependent loads took 60 - 120 us per launch (r06 8-clip profile).  blockDim = 256 = four outputs per workgroup.
 template <typename OutT>
-__global__ __launch_bounds__(64) void rfx_slot_sum_kernel(const double* __restrict__ slots, int rows, int nslots, int K, OutT* __restrict__ out) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void rfx_slot_sum_kernel(const double* __restrict__ slots, int rows, int nslots, int K, OutT* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= rows * K) return;
   const int r = i / K, k = i - r * K;
   const double* p = slots + (int64_t)r * nslots * K + k;
   double acc = 0.0;
-  for (int s = 0; s < nslots; ++s) acc += p[(int64_t)s * K];
-  out[i] = (OutT)acc;
+  for (int s = lane; s < nslots; s += 64) acc += p[(int64_t)s * K];
+  acc = rfx_wave_sum_d(acc);
+  if (lane == 0) out[i] = (OutT)acc;
 }
+#define RFX_SLOT_SUM_GRID(n_outputs) dim3(((n_outputs) + 3) / 4), dim3(256)
 // block-level sum of K per-thread doubles of a 256-thread workgroup into slot `slot` of row `row` (call from all threads)
 template <int K>
 __device__ __forceinline__ void rfx_block_store_slot(const double (&v)[K], double* __restrict__ slots, int row, int nslots, int slot) {

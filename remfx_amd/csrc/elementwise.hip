@@ -81,10 +81,11 @@ __global__ __launch_bounds__(256) void l1_sum_kernel(const float* __restrict__ a
   rfx_block_store_slot<1>(acc, slots, 0, gridDim.x, blockIdx.x);
 }
 
-__global__ void l1_finish_kernel(const double* __restrict__ slots, int nslots, float scale, float* __restrict__ out) {
-  double acc = 0.0;
-  for (int k = 0; k < nslots; ++k) acc += slots[k];
-  out[0] = (float)acc * scale;          // torch: (fp32 sum) / numel
+__global__ __launch_bounds__(64) void l1_finish_kernel(const double* __restrict__ slots, int nslots, float scale, float* __restrict__ out) {
+  double acc = 0.0;                     // one wave: lane l adds slots l, l + 64, ... in order, then the fixed butterfly
+  for (int k = threadIdx.x; k < nslots; k += 64) acc += slots[k];
+  acc = rfx_wave_sum_d(acc);
+  if (threadIdx.x == 0) out[0] = (float)acc * scale;          // torch: (fp32 sum) / numel
 }
 
 // slots[c][chunk] = partial sum_{n,a,b} x[...] of the chunk; grid = (C, chunks); added in chunk order by rfx_slot_sum_kernel
@@ -140,12 +141,16 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
   }
   rfx_block_store_slot<2>(v, sums, r, gridDim.x, blockIdx.x);
 }
-__global__ void row_moments_finalize_kernel(const double* __restrict__ sums, int R, int nslots, double L, float* __restrict__ mean,
-                                            float* __restrict__ stdv, float eps, float* __restrict__ coef_a, float* __restrict__ coef_b) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per row: lane l adds the row's slots l, l + 64, ... in order, then the fixed butterfly
+__global__ __launch_bounds__(256) void row_moments_finalize_kernel(const double* __restrict__ sums, int R, int nslots, double L, float* __restrict__ mean,
+                                                                   float* __restrict__ stdv, float eps, float* __restrict__ coef_a,
+                                                                   float* __restrict__ coef_b) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nslots; ++k) { s1 += sums[2 * ((int64_t)r * nslots + k)]; s2 += sums[2 * ((int64_t)r * nslots + k) + 1]; }
+  for (int k = lane; k < nslots; k += 64) { s1 += sums[2 * ((int64_t)r * nslots + k)]; s2 += sums[2 * ((int64_t)r * nslots + k) + 1]; }
+  s1 = rfx_wave_sum_d(s1); s2 = rfx_wave_sum_d(s2);
+  if (lane != 0) return;
   const double m = s1 / L;
   double var = (s2 - L * m * m) / (L - 1.0);
   var = var > 0.0 ? var : 0.0;
@@ -332,7 +337,7 @@ extern "C" int rfx_l1_sum(const float* a, const float* b, int64_t n, double* ws,
   g = g > RFX_L1_SLOTS ? RFX_L1_SLOTS : g;
   hipLaunchKernelGGL(l1_sum_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, b, n, ws);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ws, g, scale, out);
+  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, g, scale, out);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -393,7 +398,7 @@ extern "C" int rfx_channel_sum(const float* x, int32_t N, int32_t Cn, int32_t A,
                                (int64_t)A * B, ns, cs, ws);
   else hipLaunchKernelGGL(channel_sum_kernel, dim3(Cn, nslots), dim3(256), 0, (hipStream_t)stream, x, N, Cn, A, B, ns, cs, as, bs, ws);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, dim3((Cn + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, Cn, nslots, 1, out);
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, RFX_SLOT_SUM_GRID(Cn), 0, (hipStream_t)stream, ws, Cn, nslots, 1, out);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -530,7 +535,7 @@ extern "C" int rfx_row_moments(const float* x, int32_t R, int64_t L, double* sum
   const int gx = rfx_row_moments_slots(L);
   hipLaunchKernelGGL(row_moments_kernel, dim3(gx, R), dim3(256), 0, s, x, L, sums);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(row_moments_finalize_kernel, dim3((R + 63) / 64), dim3(64), 0, s, sums, R, gx, (double)L, mean, stdv, eps, coef_a,
+  hipLaunchKernelGGL(row_moments_finalize_kernel, dim3((R + 3) / 4), dim3(256), 0, s, sums, R, gx, (double)L, mean, stdv, eps, coef_a,
                      coef_b);
   RFX_CHECK_LAUNCH();
   return 0;

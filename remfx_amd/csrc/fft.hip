@@ -1071,7 +1071,7 @@ extern "C" int rfx_stft_pair_loss(const rfx_stft_desc* d, const float* x, const 
     default: hipLaunchKernelGGL(fft_pair_loss_kernel<11>, dim3(grid), dim3(256), 0, s, a); break;
   }
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, dim3((3 * d->R + 63) / 64), dim3(64), 0, s, ws, d->R, a.groups_per_row, 3, sums);
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, RFX_SLOT_SUM_GRID(3 * d->R), 0, s, ws, d->R, a.groups_per_row, 3, sums);
   RFX_CHECK_LAUNCH();
   return 0;
 }

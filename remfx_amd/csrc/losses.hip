@@ -174,7 +174,7 @@ extern "C" int rfx_stft_loss_reduce(const float* xc, const float* yc, int32_t R,
   hipLaunchKernelGGL(stft_loss_reduce_kernel, dim3(g, R), dim3(256), 0, (hipStream_t)stream,
                      (const float2*)xc, (const float2*)yc, n, eps, ws);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, dim3((3 * R + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, R, g, 3, sums);
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, RFX_SLOT_SUM_GRID(3 * R), 0, (hipStream_t)stream, ws, R, g, 3, sums);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -207,7 +207,7 @@ extern "C" int rfx_sisdr_sums(const float* x, const float* t, int32_t R, int64_t
   g = g > RFX_SISDR_SLOTS ? RFX_SISDR_SLOTS : g;
   hipLaunchKernelGGL(sisdr_sums_kernel, dim3(g, R), dim3(256), 0, (hipStream_t)stream, x, t, L, x_rs, t_rs, ws);
   RFX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rfx_slot_sum_kernel<double>, dim3((5 * R + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, R, g, 5, sums);
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<double>, RFX_SLOT_SUM_GRID(5 * R), 0, (hipStream_t)stream, ws, R, g, 5, sums);
   RFX_CHECK_LAUNCH();
   return 0;
 }

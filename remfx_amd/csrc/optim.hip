@@ -102,7 +102,7 @@ extern "C" int rfx_sumsq(const float* g, int64_t n, double* ws, double* out, voi
     hipLaunchKernelGGL(sumsq_kernel, dim3(gr), dim3(256), 0, (hipStream_t)stream, g, n, ws);
     RFX_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(rfx_slot_sum_kernel<double>, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, 1, gr, 1, out);
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<double>, RFX_SLOT_SUM_GRID(1), 0, (hipStream_t)stream, ws, 1, gr, 1, out);
   RFX_CHECK_LAUNCH();
   return 0;
 }

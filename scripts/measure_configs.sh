@@ -38,3 +38,6 @@ python bench.py --workload chain 2>> $OUT/cfg.err | tail -1 > $OUT/bench_chain_b
 python bench.py --workload umx 2>> $OUT/cfg.err | tail -1 > $OUT/bench_umx_bf16x3.json
 python bench.py --workload demucs --batch 8 --steps 20 --warmup 5 --no-also 2>> $OUT/cfg.err | tail -1 > $OUT/bench_demucs_bf16_b8.json
 grep -ho '"ms_per_step": [0-9.]*' $OUT/bench_tcn_bf16x3.json $OUT/bench_dcunet_bf16x3.json $OUT/bench_chain_bf16x3.json $OUT/bench_demucs_bf16_b8.json | tr '\n' ' '
+# the per-rank shares of config 3 at 4 / 2 GPUs (16 / 32 clips): the projected-scaling table of DESIGN.md section 7
+python bench.py --workload demucs --batch 16 --steps 20 --warmup 5 --no-also --no-cpu-baseline 2>> $OUT/cfg.err | tail -1 > $OUT/bench_demucs_bf16_b16.json
+python bench.py --workload demucs --batch 32 --steps 20 --warmup 5 --no-also --no-cpu-baseline 2>> $OUT/cfg.err | tail -1 > $OUT/bench_demucs_bf16_b32.json
