@@ -188,6 +188,8 @@ class Trainer:
             except Exception:
                 pass
         self._resumed_best = self._resumed_best_path = None
+        from . import ops as _ops
+        step_gc = _ops.StepGC().__enter__()                      # no cyclic-GC pauses inside the enqueue loop (ops.StepGC)
         while self.global_step < self.max_steps and (self.max_epochs < 0 or self.current_epoch < self.max_epochs):
             model.train()
             if hasattr(datamodule, "set_epoch"):
@@ -204,6 +206,7 @@ class Trainer:
                 if sched is not None:
                     sched.step()
                 self.global_step += 1
+                step_gc.tick()
                 last = self._log(model)
                 if last_path and self.ckpt_every_n_steps and self.global_step % self.ckpt_every_n_steps == 0:
                     self.save_checkpoint(last_path, model, opt, sched)
@@ -227,6 +230,7 @@ class Trainer:
                         self._best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
             if last_path:
                 self.save_checkpoint(last_path, model, opt, sched)
+        step_gc.__exit__(None, None, None)
         if last_path:
             self.save_checkpoint(last_path, model, opt, sched)
         ddp.barrier()                                            # rank 0's files are complete before any rank reads them (test(ckpt_path="best"))
