@@ -662,6 +662,16 @@ int rfx_cl_to_cm(const rfx_cl_tensor* src, int32_t N, int32_t C, int32_t A, int3
  * convolution (2 spectrogram / 1 waveform channels) and for the input gradient of its last transposed one. */
 int rfx_cl_im2col_s4(const float* src, int64_t s_ns, int64_t s_cs, int64_t s_as, int32_t N, int32_t Cs, int32_t IA, int32_t IB, int32_t OA,
                      int32_t OB, int32_t along_b, void* dst, void* stream);
+/* Frame-major ends of the Hybrid Demucs frequency branch (round 6; torchaudio HDemucs `_spec` / `_magnitude` / standardisation in front of
+ * `freq_encoder[0]`, and the de-standardisation / `_mask` / `_ispec` behind `freq_decoder[-1]`, reached from models.py:319):
+ * rfx_cl_im2col_fm: the 16-channel im2col operand of the first convolution from a FRAME-MAJOR spectrum src [N][F][bins][2] fp32
+ *   (RFX_STFT_COMPLEX_FM) with the per-clip standardisation folded in: dst [N][bins / 4][F][16] bf16, element k * 2 + c of
+ *   (n, oa, f) = a[n] src[n][f][4 oa + k - 2][c] + b[n], zero outside [0, bins).  bins % 4 == 0, src 16-byte aligned.
+ * rfx_fm_cm_affine: to_fm = 1: out[n][f][bin][c] = in[n][c][bin][f] a[n] + b[n]; to_fm = 0: out[n][c][bin][f] = in[n][f][bin][c] a[n] + b[n]
+ *   (b may be NULL): the de-standardisation fused with the layout change in front of the inverse STFT, and its backward. */
+int rfx_cl_im2col_fm(const float* src, const float* coef_a, const float* coef_b, int32_t N, int32_t F, int32_t bins, void* dst, void* stream);
+int rfx_fm_cm_affine(const float* in, float* out, const float* coef_a, const float* coef_b, int32_t N, int32_t bins, int32_t F, int32_t to_fm,
+                     void* stream);
 /* out = g * gelu'(z) over n bf16 values of dense channels-last tensors (n % 8 == 0) */
 int rfx_cl_dgelu(const void* g, const void* z, void* out, int64_t n, void* stream);
 /* GLU backward on dense channels-last tensors: g [npos][C], zab [npos][2C] = stored [a | b] -> out [npos][2C] */

@@ -234,6 +234,8 @@ SIGNATURES = {
     "rfx_cl_dgelu": [_P, _P, _P, _I64, _P],
     "rfx_cl_dglu": [_P, _P, _P, _I64, _I32, _P],
     "rfx_cl_im2col_s4": [_P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
+    "rfx_cl_im2col_fm": [_P, _P, _P, _I32, _I32, _I32, _P, _P],
+    "rfx_fm_cm_affine": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "rfx_cl_dconv_ok": [_I32, _I32, _I32, _I32],
     "rfx_cl_dconv_fwd": [_P, _P],
     "rfx_cl_dconv_bwd": [_P, _P, _P],

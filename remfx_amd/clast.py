@@ -316,6 +316,18 @@ def im2col_s4(x, OA, OB, along_b):
     return out
 
 
+def im2col_fm(spec, a, b):
+    """spec (N, F, bins, 2) fp32 frame-major spectrum, a / b (N,) standardisation coefficients -> (N, bins / 4, F, 16) bf16: the im2col
+    operand of the first convolution of the standardised spectrum (rfx_cl_im2col_fm)."""
+    N, F, bins, two = spec.shape
+    if two != 2 or spec.dtype != torch.float32 or not spec.is_contiguous() or bins % 4:
+        raise ValueError("im2col_fm: contiguous (N, frames, bins, 2) fp32 with bins % 4 == 0")
+    out = empty(N, bins // 4, F, 16, spec.device)
+    check(_lib.lib().rfx_cl_im2col_fm(C.c_void_p(spec.data_ptr()), C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), N, F, bins,
+                                      C.c_void_p(out.data_ptr()), _stream()), "rfx_cl_im2col_fm")
+    return out
+
+
 def form_head(Cout, Cs):
     """Conv (Cs -> Cout, 8 taps, stride 4, padding 2) on the im2col operand; weight (Cout, Cs, 8[, 1])."""
     def widx(m, r, t, ch):

@@ -449,14 +449,20 @@ class HeadConvFn(torch.autograd.Function):
     im2col of its channel-major fp32 input: x (Bn, 2, 4 A, T) -> gelu(z) channels-last (Bn, A, T, C).  The input carries no gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, along_b):
-        """along_b: the time branch's first convolution (1 waveform channel, stride along the samples): x (Bn, 1, 1, L) -> (Bn, 1, L / 4, C)."""
-        Bn, Cs, IA, T = x.shape
-        A, T = (IA, T // 4) if along_b else (IA // 4, T)
+    def forward(ctx, x, w, b, along_b, coef=None):
+        """along_b: the time branch's first convolution (1 waveform channel, stride along the samples): x (Bn, 1, 1, L) -> (Bn, 1, L / 4, C).
+        coef = (a, b): x is the UN-standardised frame-major spectrum (Bn, T, 4 A, 2) and the operand is a x + b (round 6: clast.im2col_fm)."""
+        if coef is not None:
+            Bn, T, IA, Cs = x.shape
+            A = IA // 4
+            x16 = clast.im2col_fm(x, coef[0], coef[1])
+        else:
+            Bn, Cs, IA, T = x.shape
+            A, T = (IA, T // 4) if along_b else (IA // 4, T)
+            x16 = clast.im2col_s4(x, A, T, along_b)
         Cc = w.shape[0]
         dev = x.device
-        train = any(ctx.needs_input_grad[1:])
-        x16 = clast.im2col_s4(x, A, T, along_b)
+        train = any(ctx.needs_input_grad[1:3])
         f = form("head", Cc, Cs)
         z = clast.empty(Bn, A, T, Cc, dev) if train else None
         y = clast.empty(Bn, A, T, Cc, dev)
@@ -473,8 +479,14 @@ class HeadConvFn(torch.autograd.Function):
         Bn, A, T, Cc = z.shape
         dz = clast.dgelu(g if g.is_contiguous() else g.contiguous(), z)
         dw, db = _wgrad(form("whead", Cc, w.shape[1]), dz, x16, Bn, A, A, T, w, b)
-        return None, dw, db, None
+        return None, dw, db, None, None
 
 
 def head_conv(x, conv, along_b=False):
     return HeadConvFn.apply(x, _w4(conv.weight), conv.bias, along_b)
+
+
+def head_conv_fm(spec_fm, a, b, conv):
+    """The frequency branch's first convolution + GELU on the frame-major spectrum (Bn, frames, bins, 2), standardisation a x + b folded
+    into the operand: -> (Bn, bins / 4, frames, C) channels-last."""
+    return HeadConvFn.apply(spec_fm, _w4(conv.weight), conv.bias, False, (a, b))

@@ -296,3 +296,94 @@ extern "C" int rfx_cl_im2col_s4(const float* src, int64_t s_ns, int64_t s_cs, in
   RFX_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- frame-major ends of the Hybrid Demucs frequency branch (round 6) ---------------------------------------------------------------
+// The STFT kernels store and load a frame's bins as one contiguous run when the spectrum is frame-major ([R][frames][bins][2],
+// RFX_STFT_COMPLEX_FM); the [bin][frame] layout of torch.stft costs them 8-byte pieces of 128-byte lines.  The two
+// kernels below are what lets HDemucs keep its spectrum frame-major on both sides of the U-Net.
+//
+// (1) The first convolution's 16-channel im2col operand straight from the frame-major spectrum, with the per-clip standardisation
+// (x a[n] + b[n]) applied on the way: element k * 2 + c of output position (n, oa, f) = a x[n][f][4 oa + k - 2][c] + b, zero where the bin
+// is outside [0, bins) (the convolution's zero padding applies to the STANDARDISED tensor).  The 16 values are 64 contiguous bytes of
+// the source.  A workgroup transposes a tile of 32 frames x 32 output rows through LDS: reads run along bins, writes along frames.
+__global__ __launch_bounds__(256) void cl_im2col_fm_kernel(const float* __restrict__ src, const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           int F, int bins, int OA, uint4* __restrict__ dst) {
+  constexpr int TF = 32, TA = 32, ROWF = 4 * TA * 2 + 8;         // floats of one frame's slab: bins [4 oa0 - 2, 4 oa0 + 4 TA + 2) x (re, im)
+  __shared__ __attribute__((aligned(16))) float slab[TF][ROWF + 4];
+  const int n = blockIdx.z, f0 = blockIdx.y * TF, oa0 = blockIdx.x * TA;
+  const float a = ca[n], b = cb[n];
+  const float* s = src + (int64_t)n * F * bins * 2;
+  const int bin0 = 4 * oa0 - 2;
+  for (int i = threadIdx.x; i < TF * (ROWF / 4); i += 256) {     // float4 = two bins
+    const int fl = i / (ROWF / 4), q = i - fl * (ROWF / 4);
+    const int bin = bin0 + 2 * q, f = f0 + fl;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (f < F && bin >= 0 && bin + 1 < bins + 1 && bin < bins) {
+      v = *reinterpret_cast<const f32x4*>(s + ((int64_t)f * bins + bin) * 2);
+      v[0] = fmaf(v[0], a, b); v[1] = fmaf(v[1], a, b); v[2] = fmaf(v[2], a, b); v[3] = fmaf(v[3], a, b);
+    }
+    *reinterpret_cast<f32x4*>(&slab[fl][4 * q]) = v;
+  }
+  __syncthreads();
+  const int fl = threadIdx.x & 31;
+  for (int al = threadIdx.x >> 5; al < TA; al += 8) {
+    const int oa = oa0 + al, f = f0 + fl;
+    if (oa >= OA || f >= F) continue;
+    float lo[8], hi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lo[e] = slab[fl][8 * al + e]; hi[e] = slab[fl][8 * al + 8 + e]; }
+    const int64_t i = ((int64_t)n * OA + oa) * F + f;
+    dst[2 * i] = cl_pack8(lo);
+    dst[2 * i + 1] = cl_pack8(hi);
+  }
+}
+extern "C" int rfx_cl_im2col_fm(const float* src, const float* coef_a, const float* coef_b, int32_t N, int32_t F, int32_t bins, void* dst,
+                                void* stream) {
+  if (!src || !coef_a || !coef_b || !dst || N <= 0 || F <= 0 || bins <= 0 || (bins & 3) || (reinterpret_cast<uintptr_t>(src) & 15)) return -1;
+  const int OA = bins / 4;
+  hipLaunchKernelGGL(cl_im2col_fm_kernel, dim3((OA + 31) / 32, (F + 31) / 32, N), dim3(256), 0, (hipStream_t)stream, src, coef_a, coef_b, F,
+                     bins, OA, reinterpret_cast<uint4*>(dst));
+  RFX_CHECK_LAUNCH();
+  return 0;
+}
+
+// (2) Layout change between the channel-major spectrum of the last transposed convolution, x[n][c][bin][frame], and the frame-major
+// one the inverse STFT reads, y[n][frame][bin][c], fused with the per-clip affine map of HDemucs' de-standardisation (y = x a[n] + b[n];
+// b == NULL: scale only -- the backward direction, to_fm = 0: x[n][c][bin][frame] = y[n][frame][bin][c] a[n]).  32 x 32 x 2 tiles through
+// LDS: both sides move full 128 / 256-byte runs.
+__global__ __launch_bounds__(256) void fm_cm_affine_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ ca,
+                                                           const float* __restrict__ cb, int bins, int F, int to_fm) {
+  __shared__ float tile[2][32][33];
+  const int n = blockIdx.z, k0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+  const float a = ca[n], b = cb ? cb[n] : 0.f;
+  const int64_t cm_n = (int64_t)n * 2 * bins * F, fm_n = (int64_t)n * F * bins * 2;
+  if (to_fm) {
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+      const int c = i >> 10, k = (i >> 5) & 31, f = i & 31;
+      tile[c][k][f] = (k0 + k < bins && f0 + f < F) ? fmaf(in[cm_n + ((int64_t)c * bins + k0 + k) * F + f0 + f], a, b) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+      const int f = i >> 6, k = (i >> 1) & 31, c = i & 1;
+      if (k0 + k < bins && f0 + f < F) out[fm_n + ((int64_t)(f0 + f) * bins + k0 + k) * 2 + c] = tile[c][k][f];
+    }
+  } else {
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+      const int f = i >> 6, k = (i >> 1) & 31, c = i & 1;
+      tile[c][k][f] = (k0 + k < bins && f0 + f < F) ? fmaf(in[fm_n + ((int64_t)(f0 + f) * bins + k0 + k) * 2 + c], a, b) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+      const int c = i >> 10, k = (i >> 5) & 31, f = i & 31;
+      if (k0 + k < bins && f0 + f < F) out[cm_n + ((int64_t)c * bins + k0 + k) * F + f0 + f] = tile[c][k][f];
+    }
+  }
+}
+extern "C" int rfx_fm_cm_affine(const float* in, float* out, const float* coef_a, const float* coef_b, int32_t N, int32_t bins, int32_t F,
+                                int32_t to_fm, void* stream) {
+  if (!in || !out || !coef_a || N <= 0 || bins <= 0 || F <= 0) return -1;
+  hipLaunchKernelGGL(fm_cm_affine_kernel, dim3((bins + 31) / 32, (F + 31) / 32, N), dim3(256), 0, (hipStream_t)stream, in, out, coef_a, coef_b,
+                     bins, F, to_fm);
+  RFX_CHECK_LAUNCH();
+  return 0;
+}

@@ -783,8 +783,9 @@ static int launch_fft(const rfx_stft_desc* d, const float* x, const float* windo
   // workgroup, 370 / 458 us at two / four -- measured).
   int nb = 1;
   static const int syn_nb_max = [] { const char* e = getenv("RFX_FFT_SYN_NB"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  static const int ana_nb_max = [] { const char* e = getenv("RFX_FFT_ANA_NB"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
   if (d->mode == RFX_STFT_COMPLEX_FM)
-    while (nb < (SYN ? syn_nb_max : 4) && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
+    while (nb < (SYN ? syn_nb_max : ana_nb_max) && (int64_t)rows8 * 8 * ((batches + 2 * nb - 1) / (2 * nb)) >= 4096) nb *= 2;
   a.nbatch = nb;
   a.groups_per_row = (batches + nb - 1) / nb;
   a.walk_frames = a.halo_frames = 0; a.ws = nullptr; a.cover_lo = a.cover_hi = 0;

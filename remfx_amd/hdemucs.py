@@ -26,6 +26,7 @@ from . import clchain, cldconv, lstm, nnops, ops, stft
 CL_TRUNK = os.environ.get("RFX_CL_TRUNK", "1") != "0"
 CL_TIME = os.environ.get("RFX_CL_TIME", "1") != "0"         # ... and the time branch's norm-free layers (folded-view forms, clast.py)
 CL_ENDS = os.environ.get("RFX_CL_ENDS", "1") != "0"         # ... and the 1 - 2 channel convolutions at the network's ends as im2col GEMMs
+FM_ENDS = os.environ.get("RFX_FM_ENDS", "1") != "0"           # round 6: frame-major spectrum on both sides of the U-Net (A/B: 0)
 TWO_STREAMS = os.environ.get("RFX_TWO_STREAMS", "1") != "0"   # the time branch on a second high-priority stream (its layers 0-3 and the
                                                                # frequency layers 0-3 are independent between the input and layer 4)
 _TIME_STREAMS = {}
@@ -586,14 +587,26 @@ class HDemucs(nn.Module):
             xt.record_stream(time_s)
         tctx = (lambda: torch.cuda.stream(time_s)) if two else contextlib.nullcontext
         _CUR[0], _CUR[1] = (main_s, time_s) if two else (None, None)
-        # _spec + _magnitude: STFT straight into complex-as-channels (B, 2*Cin, nfft/2, le)
-        cac = stft.stft(input.reshape(B * Cin, length), self.nfft, hl, mode="cac", normalized=True,
-                        bins=self.nfft // 2, frame0=2, frames_out=le, extra_pad=(pad, pad + le * hl - length))
         Fq = self.nfft // 2
-        x = cac.view(B, Cin, 2, Fq, le).reshape(B, Cin * 2, Fq, le)
-        x, mean, std = nnops.row_standardize(x.detach(), 1e-5)      # over (C, Fr, T) per clip, unbiased std
+        # Frame-major ends (round 6): on the channels-last trunk the spectrum never takes torch.stft's [bin][frame] layout, which costs
+        # the FFT kernels 8-byte pieces of 128-byte lines on both sides of the U-Net.  _spec stores frame-major (full lines); the first
+        # convolution's im2col operand is built straight from it with the standardisation folded in (no separate affine pass); the
+        # de-standardisation behind the last transposed convolution is fused with the layout change to frame-major, which _ispec reads.
+        fm = (FM_ENDS and Lc > 0 and CL_ENDS and CL_DCONV and Cin == 1 and Fq % 4 == 0 and len(self.sources) == 1
+              and self.freq_encoder[0].dconv.cl_ok())
+        if fm:
+            spec_fm = stft.stft(input.reshape(B * Cin, length), self.nfft, hl, mode="complex_fm", normalized=True,
+                                bins=Fq, frame0=2, frames_out=le, extra_pad=(pad, pad + le * hl - length)).detach()    # (B, le, Fq, 2)
+            mean, std, coef_a, coef_b = nnops.row_moments(spec_fm, 1e-5)                                             # over (C, Fr, T) per clip
+            x = None
+        else:
+            # _spec + _magnitude: STFT straight into complex-as-channels (B, 2*Cin, nfft/2, le)
+            cac = stft.stft(input.reshape(B * Cin, length), self.nfft, hl, mode="cac", normalized=True,
+                            bins=self.nfft // 2, frame0=2, frames_out=le, extra_pad=(pad, pad + le * hl - length))
+            x = cac.view(B, Cin, 2, Fq, le).reshape(B, Cin * 2, Fq, le)
+            x, mean, std = nnops.row_standardize(x.detach(), 1e-5)      # over (C, Fr, T) per clip, unbiased std
         for idx, encode in enumerate(self.freq_encoder):
-            lengths.append(x.shape[-1])
+            lengths.append(le if x is None else x.shape[-1])
             inject = None
             if idx < len(self.time_encoder):
                 if two and (_XSYNC & 2) and _XIDX in (-1, idx):
@@ -609,7 +622,7 @@ class HDemucs(nn.Module):
                 # channels-last trunk: the DConv branch on (B * Fr, C, T) samples, everything between two branches in one node
                 dcl = CL_DCONV and encode.dconv.cl_ok()      # this layer's DConv branch runs on channels-last samples
                 if idx == 0:
-                    samp = encode.head(x, cl=dcl, ends=CL_ENDS)
+                    samp = clchain.head_conv_fm(spec_fm, coef_a, coef_b, encode.conv) if fm else encode.head(x, cl=dcl, ends=CL_ENDS)
                 d = encode.dconv.forward_cl(samp) if dcl else encode.dconv(samp)
                 if getattr(self, "_dbg", None) is not None and not dcl:        # dev: per-clip checksums around the channel-major DConv branches
                     csn = lambda t: t.float().abs().reshape(B, -1).sum(1) if t.is_contiguous() else t.float().abs().contiguous().reshape(B, -1).sum(1)
@@ -701,12 +714,18 @@ class HDemucs(nn.Module):
             if _XSYNC & 16:
                 torch.cuda.synchronize()
         S = len(self.sources)
-        x = nnops.row_affine(x.reshape(B, -1), std, mean)          # S == 1 for RemFX: one (std, mean) per clip
         if S != 1:
             raise NotImplementedError("multi-source de-standardisation")
-        # _mask + _ispec: (B, S, Cin*2, Fq, le) complex-as-channels -> time, one row per (b, s, c)
-        spec = x.view(B * S * Cin, 2, Fq, le)
-        xo = stft.istft(spec, self.nfft, hl, mode="cac", normalized=True, frames=le + 4, frame0=2, crop=pad,
-                        length=length).view(B, S, Cin, length)
+        if fm and x.shape == (B, 2, Fq, le):
+            # de-standardisation + _mask's layout change in one pass, then _ispec on the frame-major spectrum
+            spec = nnops.cm_to_fm_affine(x, std, mean)                 # (B, le, Fq, 2)
+            xo = stft.istft(spec, self.nfft, hl, mode="complex_fm", normalized=True, frames=le + 4, frame0=2, crop=pad,
+                            length=length).view(B, S, Cin, length)
+        else:
+            x = nnops.row_affine(x.reshape(B, -1), std, mean)          # S == 1 for RemFX: one (std, mean) per clip
+            # _mask + _ispec: (B, S, Cin*2, Fq, le) complex-as-channels -> time, one row per (b, s, c)
+            spec = x.view(B * S * Cin, 2, Fq, le)
+            xo = stft.istft(spec, self.nfft, hl, mode="cac", normalized=True, frames=le + 4, frame0=2, crop=pad,
+                            length=length).view(B, S, Cin, length)
         xt = nnops.row_affine(xt.reshape(B, -1), stdt, meant).view(B, S, -1, length)
         return nnops.add(xt.reshape(B, S * Cin, 1, length), xo.reshape(B, S * Cin, 1, length)).view(B, S, Cin, length)

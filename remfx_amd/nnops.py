@@ -445,6 +445,51 @@ class _RowAffineFn(torch.autograd.Function):
         return gx, None, None
 
 
+def row_moments(x, eps):
+    """Per-row (leading dim) mean, unbiased std and the standardisation coefficients a = 1 / (eps + std), b = -mean a of a tensor that
+    carries no gradient -- row_standardize without the affine pass (the consumer applies x a + b itself: clchain.head_conv_fm)."""
+    ops._req(x, "x")
+    x = x.contiguous()
+    R = x.shape[0]
+    L = x.numel() // R
+    lib = _lib.lib()
+    sums = torch.empty(2 * R * lib.rfx_row_moments_slots(L), device=x.device, dtype=torch.float64)
+    mean = torch.empty(R, device=x.device, dtype=torch.float32)
+    std, a, b = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    check(lib.rfx_row_moments(_ptr(x), R, L, _ptr(sums), _ptr(mean), _ptr(std), float(eps), _ptr(a), _ptr(b), _stream()), "rfx_row_moments")
+    return mean, std, a, b
+
+
+class _CmToFmAffineFn(torch.autograd.Function):
+    """y[n][frame][bin][c] = x[n][c][bin][frame] a[n] + b[n]: HDemucs' de-standardisation fused with the layout change in front of the
+    frame-major inverse STFT (rfx_fm_cm_affine); the gradient reaches x only (a, b are detached statistics of the input)."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ops._req(x, "x")
+        x = x.contiguous()
+        N, Cc, bins, F = x.shape
+        if Cc != 2 or x.dtype != torch.float32:
+            raise ValueError("cm_to_fm_affine: (N, 2, bins, frames) fp32")
+        y = torch.empty((N, F, bins, 2), device=x.device, dtype=torch.float32)
+        check(_lib.lib().rfx_fm_cm_affine(_ptr(x), _ptr(y), _ptr(a), _ptr(b), N, bins, F, 1, _stream()), "rfx_fm_cm_affine")
+        ctx.save_for_backward(a)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        g = g.contiguous()
+        N, F, bins, _ = g.shape
+        gx = torch.empty((N, 2, bins, F), device=g.device, dtype=torch.float32)
+        check(_lib.lib().rfx_fm_cm_affine(_ptr(g), _ptr(gx), _ptr(a), None, N, bins, F, 0, _stream()), "rfx_fm_cm_affine")
+        return gx, None, None
+
+
+def cm_to_fm_affine(x, a, b):
+    return _CmToFmAffineFn.apply(x, a.contiguous(), b.contiguous())
+
+
 def row_affine(x, a, b):
     """x * a[r] + b[r] per leading-dim row (de-standardisation); gradient flows to x only."""
     return _RowAffineFn.apply(x, a.contiguous(), b.contiguous())

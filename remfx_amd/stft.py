@@ -142,8 +142,8 @@ class ISTFTFn(torch.autograd.Function):
     def forward(ctx, spec, window, n_fft, hop, win, mode, normalized, frames, frame0, crop, length):
         spec = spec.contiguous()
         R = spec.shape[0]
-        nb = spec.shape[1] if mode == 0 else spec.shape[2]
-        fi = spec.shape[2] if mode == 0 else spec.shape[3]
+        nb = spec.shape[1] if mode == 0 else spec.shape[2]                 # complex (R, bins, frames, 2) | cac (R, 2, bins, frames) | fm (R, frames, bins, 2)
+        fi = spec.shape[2] if mode == 0 else spec.shape[1] if mode == 5 else spec.shape[3]
         inv_env = _inv_envelope(window, n_fft, hop, win, frames, spec.device)
         scale = (math.sqrt(n_fft) if normalized else 1.0) / n_fft
         out = torch.empty((R, length), device=spec.device, dtype=torch.float32)   # every sample is stored exactly once (overlap-add by ownership)
@@ -174,7 +174,9 @@ def istft(spec, n_fft, hop, win=None, window=None, mode="complex", normalized=Fa
     win = n_fft if win is None else win
     window = hann(win, spec.device) if window is None else window
     m = MODES[mode]
-    fi = spec.shape[2] if m == 0 else spec.shape[3]
+    if m not in (0, 1, 5):
+        raise ValueError("istft: mode 'complex', 'cac' or 'complex_fm'")
+    fi = spec.shape[2] if m == 0 else spec.shape[1] if m == 5 else spec.shape[3]
     frames = fi + frame0 if frames is None else frames
     if length is None:
         length = (frames - 1) * hop

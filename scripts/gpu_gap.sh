@@ -3,7 +3,7 @@
 # plus what runs next to the largest zero fill
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/gap; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 4 --warmup 3 --preheat 0 --no-cpu-baseline --no-also --no-exclusive > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --steps 4 --warmup 3 --preheat 0 --no-cpu-baseline --no-also --no-exclusive "$@" > $OUT/kt.log 2>&1
 cd $ROOT
 F=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
 python - "$F" <<'P' | tee $OUT/gap.txt

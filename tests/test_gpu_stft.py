@@ -279,3 +279,45 @@ def test_spectrogram_golden(golden_dir):
     S = spectrogram(x, torch.hann_window(512).to(DEV), 512, 128, 0.3).cpu().numpy()
     assert S.shape == gd["spec"].shape
     assert float(np.sqrt(((S - gd["spec"]) ** 2).mean())) < 1e-5
+
+
+def test_frame_major_ends_kernels():
+    """Round 6: the kernels that keep HDemucs' spectrum frame-major on both sides of the U-Net.  (1) `rfx_cl_im2col_fm`: the first
+    convolution's 16-channel operand from the frame-major spectrum with the standardisation folded in, against the channel-major
+    im2col of the standardised tensor; (2) `rfx_fm_cm_affine` in both directions against permute + affine; (3) the inverse STFT of
+    a frame-major spectrum against the same spectrum in torch's [bin][frame] layout (HDemucs `_ispec` geometry)."""
+    from remfx_amd import clast, nnops, stft
+    g = torch.Generator().manual_seed(5)
+    N, F, bins = 3, 96, 72
+    spec = torch.randn(N, F, bins, 2, generator=g).to(DEV)
+    a = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.3).to(DEV)
+    got = clast.im2col_fm(spec, a, b).float()                                  # (N, bins / 4, F, 16)
+    x_cm = (spec * a.view(N, 1, 1, 1) + b.view(N, 1, 1, 1)).permute(0, 3, 2, 1).contiguous()   # (N, 2, bins, F)
+    ref = clast.im2col_s4(x_cm, bins // 4, F, False).float()
+    assert got.shape == ref.shape == (N, bins // 4, F, 16)
+    # fma against mul + add in front of the bf16 rounding: at most one bf16 ulp apart, and zero padding exactly zero
+    assert float((got - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    assert float(((got - ref).abs() > 0).float().mean()) < 0.02
+    assert float(got[:, 0, :, :4].abs().max()) == 0.0 and float(got[:, -1, :, 12:].abs().max()) == 0.0   # bins -2, -1 and bins, bins + 1
+    x = torch.randn(N, 2, bins, F, generator=g).to(DEV).requires_grad_(True)
+    y = nnops.cm_to_fm_affine(x, a, b)
+    yr = x.detach().permute(0, 3, 2, 1) * a.view(N, 1, 1, 1) + b.view(N, 1, 1, 1)
+    assert y.shape == (N, F, bins, 2) and float((y.detach() - yr).abs().max()) <= 1e-6 * float(yr.abs().max())
+    gy = torch.randn(N, F, bins, 2, generator=g).to(DEV)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    gr = gy.permute(0, 3, 2, 1) * a.view(N, 1, 1, 1)
+    assert float((gx - gr).abs().max()) <= 1e-6 * float(gr.abs().max())
+    # _ispec geometry: 4096 / 1024, Nyquist dropped, frames [2 : 2 + le] of le + 4
+    R, le, hl = 2, 64, 1024
+    L = le * hl
+    cac = (torch.randn(R, 2, 2048, le, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    fm = cac.detach().permute(0, 3, 2, 1).contiguous().requires_grad_(True)
+    pad = hl // 2 * 3
+    o1 = stft.istft(cac, 4096, hl, mode="cac", normalized=True, frames=le + 4, frame0=2, crop=pad, length=L)
+    o2 = stft.istft(fm, 4096, hl, mode="complex_fm", normalized=True, frames=le + 4, frame0=2, crop=pad, length=L)
+    assert float((o1 - o2).abs().max()) <= 1e-6 * float(o1.abs().max())
+    go = torch.randn(R, L, generator=g).to(DEV)
+    (g1,) = torch.autograd.grad(o1, cac, go)
+    (g2,) = torch.autograd.grad(o2, fm, go)
+    assert float((g1 - g2.permute(0, 3, 2, 1)).abs().max()) <= 1e-6 * float(g1.abs().max())
