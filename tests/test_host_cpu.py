@@ -518,3 +518,21 @@ def test_fxclassifier_mixup_training_branch_matches_reference():
         assert names == list(g[f"cls_log_names{s}"])
         got = np.array([float(cls.logged[k]) for k in names], dtype=np.float32)
         assert np.allclose(got, g[f"cls_log_vals{s}"], rtol=1e-5, atol=1e-6), (names, got, g[f"cls_log_vals{s}"])
+
+
+def test_cfg_tree_is_what_its_author_script_writes(tmp_path, monkeypatch):
+    """cfg/ is written by scripts/write_cfg_tree.py (experiments as rows of a table): the committed files are exactly its output."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("write_cfg_tree", os.path.join(ROOT, "scripts", "write_cfg_tree.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "CFG", str(tmp_path))
+    mod.main()
+    n = 0
+    for d, _, fs in os.walk(os.path.join(ROOT, "cfg")):
+        for f in fs:
+            rel = os.path.relpath(os.path.join(d, f), os.path.join(ROOT, "cfg"))
+            with open(os.path.join(d, f)) as a, open(os.path.join(tmp_path, rel)) as b:
+                assert a.read() == b.read(), rel
+            n += 1
+    assert n == 48 and sum(len(fs) for _, _, fs in os.walk(tmp_path)) == 48
