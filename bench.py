@@ -714,7 +714,8 @@ def main():
     ap.add_argument("--no-enc-z16", action="store_true", help="A/B: encoder conv outputs stored as fp32 (hdemucs.ENC_Z16)")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (bf16x3 step + Demucs forward sub-metric)")
     ap.add_argument("--no-exclusive", action="store_true",
-                    help="skip the 3 extra one-stream steps the dominant kernel is picked and priced on (profiling runs: keeps them out of the trace)")
+                    help="skip the 3 instrumented and the 3 one-stream steps behind the timed region (the per-kernel table and the dominant "
+                         "kernel's price): profiler runs then contain exactly preheat + W + K steps")
     ap.add_argument("--dump-launches", default="", help="write the per-launch plan / algorithmic work / event time list of the timed steps (JSON)")
     ap.add_argument("--union-ranks", type=int, default=0,
                     help="single process only: train on the concatenation of the synthetic batches ranks 0..N-1 would "
@@ -854,7 +855,7 @@ def main():
     fence()
     dt = time.time() - t0
     PHASES["timed"] = round(dt, 2)
-    OBS = 3
+    OBS = 0 if args.no_exclusive else 3       # profiler runs (--no-exclusive) execute exactly preheat + W + K steps
     timer.enabled = True
     for i in range(OBS):
         step(args.warmup + args.steps + i)
@@ -916,7 +917,7 @@ def main():
             return {"launches": 0}
         tf, gb = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
         fm, fh = tf / peak, gb / PEAK_HBM_GBS
-        return {"launches_per_step": round(n / OBS, 2), "ms_per_step": round(ms / OBS, 3), "avg_launch_us": round(ms / n * 1e3, 2),
+        return {"launches_per_step": round(n / max(OBS, 1), 2), "ms_per_step": round(ms / max(OBS, 1), 3), "avg_launch_us": round(ms / n * 1e3, 2),
                 "algorithmic_flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(by / n),
                 "tflops": round(tf, 2), "gbs": round(gb, 1), "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
                 "bound": "hbm" if fh >= fm else "mfma", "frac": round(max(fh, fm), 4)}
@@ -1010,7 +1011,7 @@ def main():
                      "concurrent_streams": (1 + int(sink is not None and sink.side is not None) + _n_aux_streams(args)), "exclusive": exclusive,
                      "frac_source": "one-stream pass" if exclusive else "timed region", "in_step": in_step,
                      "ridge_flop_per_byte": round(ridge, 1), "by_kernel": by_kernel,
-                     "family": dict(fam, kernel=fam_name, traffic=fam_traffic, share_of_step=round((kms / OBS) / (dt / args.steps * 1e3), 3)),
+                     "family": dict(fam, kernel=fam_name, traffic=fam_traffic, share_of_step=round((kms / max(OBS, 1)) / (dt / args.steps * 1e3), 3)),
                      "by_bound": {"mfma": _price(*cls["mfma"]), "hbm": _price(*cls["hbm"])}},
     }
     if args.workload == "demucs" and world == 1 and not args.no_also:
