@@ -190,47 +190,49 @@ class Trainer:
         self._resumed_best = self._resumed_best_path = None
         from . import ops as _ops
         step_gc = _ops.StepGC().__enter__()                      # no cyclic-GC pauses inside the enqueue loop (ops.StepGC)
-        while self.global_step < self.max_steps and (self.max_epochs < 0 or self.current_epoch < self.max_epochs):
-            model.train()
-            if hasattr(datamodule, "set_epoch"):
-                datamodule.set_epoch(self.current_epoch)         # reshuffles the per-rank shards
-            for i, batch in enumerate(datamodule.train_dataloader()):
-                if self.global_step >= self.max_steps:
-                    break
-                opt.zero_grad()
-                loss = model.training_step(self._to(batch), i)
-                loss.backward()
-                pre = sync.finish()
-                _check_lstm("before the optimiser step")         # never apply gradients of a timed-out exchange
-                opt.step(clip_norm=self.gradient_clip_val, grad_prescale=pre)
-                if sched is not None:
-                    sched.step()
-                self.global_step += 1
-                step_gc.tick()
-                last = self._log(model)
-                if last_path and self.ckpt_every_n_steps and self.global_step % self.ckpt_every_n_steps == 0:
+        try:
+            while self.global_step < self.max_steps and (self.max_epochs < 0 or self.current_epoch < self.max_epochs):
+                model.train()
+                if hasattr(datamodule, "set_epoch"):
+                    datamodule.set_epoch(self.current_epoch)         # reshuffles the per-rank shards
+                for i, batch in enumerate(datamodule.train_dataloader()):
+                    if self.global_step >= self.max_steps:
+                        break
+                    opt.zero_grad()
+                    loss = model.training_step(self._to(batch), i)
+                    loss.backward()
+                    pre = sync.finish()
+                    _check_lstm("before the optimiser step")         # never apply gradients of a timed-out exchange
+                    opt.step(clip_norm=self.gradient_clip_val, grad_prescale=pre)
+                    if sched is not None:
+                        sched.step()
+                    self.global_step += 1
+                    step_gc.tick()
+                    last = self._log(model)
+                    if last_path and self.ckpt_every_n_steps and self.global_step % self.ckpt_every_n_steps == 0:
+                        self.save_checkpoint(last_path, model, opt, sched)
+                self.current_epoch += 1
+                if hasattr(datamodule, "val_dataloader"):
+                    model.eval()
+                    with torch.no_grad():
+                        for i, batch in enumerate(datamodule.val_dataloader()):
+                            if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                                break
+                            model.validation_step(self._to(batch), i)
+                    _check_lstm("validation")
+                    last.update(self._log(model))
+                    score = last.get("valid_loss")
+                    if score is not None and (self.best_score is None or float(score) < self.best_score):
+                        self.best_score = float(score)               # `score` is the all-reduced mean: every rank takes the same branch
+                        if self.best_path:
+                            self.save_checkpoint(self.best_path, model, opt, sched)
+                            self._best_written = True
+                        else:                                        # no checkpoint directory: keep the weights in memory
+                            self._best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+                if last_path:
                     self.save_checkpoint(last_path, model, opt, sched)
-            self.current_epoch += 1
-            if hasattr(datamodule, "val_dataloader"):
-                model.eval()
-                with torch.no_grad():
-                    for i, batch in enumerate(datamodule.val_dataloader()):
-                        if self.limit_val_batches is not None and i >= self.limit_val_batches:
-                            break
-                        model.validation_step(self._to(batch), i)
-                _check_lstm("validation")
-                last.update(self._log(model))
-                score = last.get("valid_loss")
-                if score is not None and (self.best_score is None or float(score) < self.best_score):
-                    self.best_score = float(score)               # `score` is the all-reduced mean: every rank takes the same branch
-                    if self.best_path:
-                        self.save_checkpoint(self.best_path, model, opt, sched)
-                        self._best_written = True
-                    else:                                        # no checkpoint directory: keep the weights in memory
-                        self._best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-            if last_path:
-                self.save_checkpoint(last_path, model, opt, sched)
-        step_gc.__exit__(None, None, None)
+        finally:
+            step_gc.__exit__(None, None, None)          # the collector comes back on whatever ends the loop
         if last_path:
             self.save_checkpoint(last_path, model, opt, sched)
         ddp.barrier()                                            # rank 0's files are complete before any rank reads them (test(ckpt_path="best"))
