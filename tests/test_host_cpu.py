@@ -536,3 +536,17 @@ def test_cfg_tree_is_what_its_author_script_writes(tmp_path, monkeypatch):
                 assert a.read() == b.read(), rel
             n += 1
     assert n == 48 and sum(len(fs) for _, _, fs in os.walk(tmp_path)) == 48
+
+
+def test_product_crops_match_reference_golden():
+    """`remfx_amd.utils.center_crop` / `causal_crop` (the product's own, not the oracle's) against the values recorded from the imported
+    reference (`remfx/utils.py:202-211`; `causal_crop` drops the LAST sample); views, no copy."""
+    import numpy as np
+    from remfx_amd import utils
+    import remfx.utils
+    g = np.load(os.path.join(ROOT, "tests", "golden", "utils_small.npz"))
+    x = torch.from_numpy(g["crop_in"])
+    c, k = utils.center_crop(x, 7), utils.causal_crop(x, 7)
+    assert torch.equal(c, torch.from_numpy(g["center7"])) and torch.equal(k, torch.from_numpy(g["causal7"]))
+    assert c.data_ptr() == x[..., (20 - 7) // 2:].data_ptr() and k.data_ptr() == x[..., 20 - 1 - 7:].data_ptr()
+    assert remfx.utils.causal_crop is utils.causal_crop and utils.crop_start(True, 20, 7) == 12 and utils.crop_start(False, 20, 7) == 6
