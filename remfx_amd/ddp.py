@@ -65,10 +65,12 @@ class GradSync:
         self.buckets, self.bucket_of = [], {}
         hi = flat.numel
         cur_lo, cur_params = hi, []
-        for idx in range(len(flat.params) - 1, -1, -1):
+        by_offset = sorted(range(len(flat.params)), key=lambda i: flat.offsets[i])      # memory order (FlatParams(layout=...)), high end first
+        for k in range(len(by_offset) - 1, -1, -1):
+            idx = by_offset[k]
             cur_lo = flat.offsets[idx]
             cur_params.append(idx)
-            if hi - cur_lo >= limit or idx == 0:
+            if hi - cur_lo >= limit or k == 0:
                 b = len(self.buckets)
                 self.buckets.append({"lo": cur_lo, "hi": hi, "n": len(cur_params), "ready": 0})
                 for i in cur_params:

@@ -483,6 +483,26 @@ class HDemucs(nn.Module):
                 if m.bias is not None:
                     m.bias.data /= s
 
+    def forward_use_order(self):
+        """The parameters in the order forward() first uses their layers: time / frequency encoders interleaved, the frequency embedding
+        behind layer 0, then the decoders interleaved.  Backward completes their gradients in the reverse order; optim.FlatParams lays the
+        flat buffers out this way so that ddp.GradSync's buckets finish one after the other during backward (registration order puts the
+        frequency embedding and every time layer behind all frequency layers: the first bucket then waits for the end of backward and
+        holds the in-order all-reduces of all the others back)."""
+        out, offset = [], self.depth - len(self.time_decoder)
+        for idx, enc in enumerate(self.freq_encoder):
+            if idx < len(self.time_encoder):
+                out += list(self.time_encoder[idx].parameters())
+            out += list(enc.parameters())
+            if idx == 0 and self.freq_emb is not None:
+                out += list(self.freq_emb.parameters())
+        for idx, dec in enumerate(self.freq_decoder):
+            out += list(dec.parameters())
+            if idx >= offset:
+                out += list(self.time_decoder[idx - offset].parameters())
+        seen = {id(p) for p in out}
+        return out + [p for p in self.parameters() if id(p) not in seen]
+
     def _cl_layers(self, le, device):
         """How many leading frequency layers take the channels-last bf16 trunk (0: none).  Conditions: bf16 arithmetic mode, whole
         256-frame tiles, norm-free layers of the standard geometry (conv (8, 1) / 4 pad 2, 1x1 encoder rewrite, 3x3 decoder rewrite),

@@ -75,7 +75,11 @@ class RemFX(_Base):
         """models.py:185-206.  Returns the same structure; the optimiser is the flat HIP AdamW
         when the parameters live on the GPU."""
         from .optim import FlatAdamW, FlatParams, MultiStepLR
-        flat = FlatParams(list(self.model.parameters()))
+        # memory order = forward-use order where the network knows one that differs from its registration order (Hybrid Demucs): the
+        # gradient exchange then overlaps backward bucket by bucket (optim.FlatParams, ddp.GradSync)
+        inner = getattr(self.model, "model", None)
+        layout = inner.forward_use_order() if hasattr(inner, "forward_use_order") else None
+        flat = FlatParams(list(self.model.parameters()), layout=layout)
         optimizer = FlatAdamW(flat, lr=self.lr, betas=(self.lr_beta1, self.lr_beta2), eps=self.lr_eps,
                               weight_decay=self.lr_weight_decay)
         max_steps = self.trainer.max_steps if self.trainer is not None else 50000

@@ -17,17 +17,28 @@ from .ops import _ptr, _stream
 
 
 class FlatParams:
-    def __init__(self, params, allow_cpu=False):
+    def __init__(self, params, allow_cpu=False, layout=None):
+        """`params` keeps its order as the optimiser's parameter list (torch.optim state_dict indices, checkpoints).  `layout`
+        (optional): the same parameters in the order they should lie in MEMORY -- the order the forward pass uses them in, so that the
+        flat gradient buffer fills from its high end downwards during backward and ddp.GradSync's buckets (contiguous slices, taken
+        from the high end) complete one after the other instead of all at the end (a network whose registration order is not its
+        execution order: Hybrid Demucs registers all frequency layers before the time layers they interleave with)."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         if dev.type != "cuda" and not allow_cpu:   # allow_cpu: collective-plumbing tests only (gloo)
             raise ValueError("FlatParams needs parameters on the GPU (no CPU fallback)")
-        self.offsets, n = [], 0
-        for p in self.params:
-            self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4           # keep every view 16-byte aligned
+        order = list(range(len(self.params)))
+        if layout is not None:
+            pos = {id(p): i for i, p in enumerate(self.params)}
+            order = [pos[id(p)] for p in layout if id(p) in pos]
+            if sorted(order) != list(range(len(self.params))):
+                raise ValueError("FlatParams(layout=...): must name every trainable parameter exactly once")
+        self.offsets, n = [0] * len(self.params), 0
+        for i in order:
+            self.offsets[i] = n
+            n += (self.params[i].numel() + 3) // 4 * 4     # keep every view 16-byte aligned
         self.numel = n
         self.data = torch.zeros(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)

@@ -550,3 +550,34 @@ def test_product_crops_match_reference_golden():
     assert torch.equal(c, torch.from_numpy(g["center7"])) and torch.equal(k, torch.from_numpy(g["causal7"]))
     assert c.data_ptr() == x[..., (20 - 7) // 2:].data_ptr() and k.data_ptr() == x[..., 20 - 1 - 7:].data_ptr()
     assert remfx.utils.causal_crop is utils.causal_crop and utils.crop_start(True, 20, 7) == 12 and utils.crop_start(False, 20, 7) == 6
+
+
+def test_flat_layout_follows_forward_use_order_and_buckets_complete_in_backward_order():
+    """Hybrid Demucs registers every frequency layer before the time layers it interleaves with and the frequency embedding last; in
+    registration order the FIRST gradient bucket (taken from the high end of the flat buffer) would hold the embedding and the time
+    encoders, whose gradients arrive at the very end of backward, and hold back the in-order all-reduces of all other buckets.
+    `HDemucs.forward_use_order()` + `FlatParams(layout=...)` put memory in execution order: every bucket's parameters are used later
+    in forward (= finished earlier in backward) than those of the next bucket; indices, views and the optimiser's parameter order stay."""
+    from remfx_amd import ddp
+    from remfx_amd.hdemucs import HDemucs
+    from remfx_amd.optim import FlatParams
+    net = HDemucs(sources=["mixture"], audio_channels=1, nfft=4096, channels=16)
+    plist = list(net.parameters())
+    order = net.forward_use_order()
+    assert len(order) == len(plist) and {id(p) for p in order} == {id(p) for p in plist}
+    use = {id(p): k for k, p in enumerate(order)}
+    ref = [p.detach().clone() for p in plist]
+    flat = FlatParams(plist, allow_cpu=True, layout=order)
+    assert [id(p) for p in flat.params] == [id(p) for p in plist]                       # optimiser order unchanged
+    for p, r, o in zip(plist, ref, flat.offsets):
+        assert torch.equal(p, r) and p.data_ptr() == flat.data.data_ptr() + 4 * o and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o
+    assert sorted(range(len(plist)), key=lambda i: flat.offsets[i]) == [next(i for i, q in enumerate(plist) if q is p) for p in order]
+    sync = ddp.GradSync(flat, bucket_mb=0.25)
+    assert len(sync.buckets) >= 4
+    lo_use = [min(use[id(plist[i])] for i in range(len(plist)) if sync.bucket_of[i] == b) for b in range(len(sync.buckets))]
+    hi_use = [max(use[id(plist[i])] for i in range(len(plist)) if sync.bucket_of[i] == b) for b in range(len(sync.buckets))]
+    assert all(lo_use[b] > hi_use[b + 1] for b in range(len(sync.buckets) - 1))       # bucket b is used strictly later than bucket b + 1
+    names = {id(p): n for n, p in net.named_parameters()}
+    assert names[id(order[0])].startswith("time_encoder.0") and names[id(order[-1])].startswith("time_decoder.4")
+    with pytest.raises(ValueError):
+        FlatParams(plist, allow_cpu=True, layout=order[:-1])
