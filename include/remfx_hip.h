@@ -302,9 +302,10 @@ int rfx_act_rows16(const void* x, int64_t xs0, int64_t xs1, int64_t xs2, const f
  * DPTNet (reference remfx/models.py:327-344). */
 int rfx_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
 /* nn.PReLU over [N][C][L] contiguous with a per-channel slope (C = 1: the single-parameter form of asteroid DPTNet's
- * `first_out`, reference remfx/models.py:327-344; per-channel: remfx/tcn.py:46).  Forward; backward: gx, and gslope[C] (+=, atomics). */
+ * `first_out`, reference remfx/models.py:327-344; per-channel: remfx/tcn.py:46).  Forward; backward: gx, and gslope[C] WRITTEN (one fp64
+ * slot per (channel, sample) in `ws`, N * C doubles, added in sample order). */
 int rfx_prelu_fwd(const float* x, const float* slope, float* y, int64_t N, int64_t C, int64_t L, void* stream);
-int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx, float* gslope,
+int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx, double* ws, float* gslope,
                   int64_t N, int64_t C, int64_t L, void* stream);
 
 /* out[c] = sum over (n, a, b) of x[n*ns + c*cs + a*as + b*bs]  (bias gradients; written, not accumulated).  ws: rfx_channel_sum_ws(...)
@@ -457,8 +458,12 @@ int rfx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int
  * (group, chunk), summed in chunk order -- no zero fill, no atomics (a fill followed by fp64 atomics lost contributions whenever a
  * second stream kept the machine busy).  sums_given = 0 keeps the N * G pair buffer + atomics form. */
 int rfx_groupnorm_stat_chunks(int32_t C, int32_t S, int32_t G);
+/* Floats of `work` the three backward entry points below need (G = 0: rfx_batchnorm_bwd): N*C*2 + N*(C/2) + 2 max(N*G, C) and, for
+ * rows longer than one 4096-sample chunk, one slot per (sample, channel, chunk) partial -- plain stores added in chunk order (no zero
+ * fill, no atomics: DESIGN.md 4.11). */
+int64_t rfx_norm_bwd_work_floats(int32_t N, int32_t C, int32_t S, int32_t G);
 /* dx (N, C, S); dgamma / dbeta (C) and dscale (C/2, mode 3) are OVERWRITTEN; `work` is a
- * caller-owned scratch of N*C*2 + N*(C/2) + N*G*2 floats; the residual gradient of mode 3 is gy. */
+ * caller-owned scratch of rfx_norm_bwd_work_floats(N, C, S, G) floats; the residual gradient of mode 3 is gy. */
 int rfx_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
                       const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S, int32_t G,
                       int32_t mode, const float* scale, float* work, float* dx, float* dgamma, float* dbeta,
@@ -474,11 +479,14 @@ int rfx_groupnorm_bwd_x16(const void* x, const float* gamma, const float* beta, 
                           float* work, void* dx, float* dgamma, float* dbeta, float* dscale, void* stream);
 /* BatchNorm2d (+ReLU, mode 4) over (N, S) per channel -- classifier.py:271-272 (ConvBlock).
  * use_given_stats != 0: eval mode, mean = running_mean, rstd = 1/sqrt(running_var + eps) are inputs;
- * otherwise batch statistics are computed into mean / rstd (biased variance).  sums: C*2 fp64 workspace. */
+ * otherwise batch statistics are computed into mean / rstd (biased variance).  sums: fp64 workspace of
+ * C * rfx_batchnorm_stat_slots(N, S) PAIRS -- one per (channel, sample, 4096-value chunk), stored by the wave that owns it and added
+ * in slot order (no zero fill, no atomics). */
+int rfx_batchnorm_stat_slots(int32_t N, int32_t S);
 int rfx_batchnorm_fwd(const float* x, const float* gamma, const float* beta, int32_t N, int32_t C, int32_t S,
                       float eps, int32_t mode, int32_t use_given_stats, double* sums, float* mean, float* rstd,
                       float* y, void* stream);
-/* train-mode backward; work: N*C*2 + N*(C/2) + C*2 floats */
+/* train-mode backward; work: rfx_norm_bwd_work_floats(N, C, S, 0) floats */
 int rfx_batchnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
                       const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S, int32_t mode,
                       float* work, float* dx, float* dgamma, float* dbeta, void* stream);
@@ -497,8 +505,11 @@ int rfx_glu_bwd_bf16(const void* x, const float* gy, void* gx, int64_t N, int64_
 /* ---- complex-valued pieces of DCUNet (asteroid DCUNet via models.py:347-367) -------
  * Complex tensors are real tensors (N, 2C, S): channels [0,C) real parts, [C,2C) imaginary parts; a complex
  * convolution is then ONE rfx_gemm_fwd with the block weight [[Wr,-Wi],[Wi,Wr]].
- * sums (5, per channel c at c*5+q): sum xr, xi, xr^2, xr*xi, xi^2 in fp64 (ComplexBatchNorm statistics). */
-int rfx_cplx_moments(const float* x, int32_t N, int32_t C, int64_t S, double* sums, void* stream);
+ * sums (5, per channel c at c*5+q): sum xr, xi, xr^2, xr*xi, xi^2 in fp64 (ComplexBatchNorm statistics).
+ * ws: fp64 workspace of 5 * C * rfx_cplx_slots(N, S) values (rfx_cplx_affine_act_bwd: 6 * C * rfx_cplx_slots) -- one slot per
+ * (sample, 4096-value chunk), stored by the wave that owns it and added in slot order: no zero fill, no atomics. */
+int64_t rfx_cplx_slots(int32_t N, int64_t S);
+int rfx_cplx_moments(const float* x, int32_t N, int32_t C, int64_t S, double* ws, double* sums, void* stream);
 /* ComplexBatchNorm coefficients (asteroid complex_nn BatchNorm inside DCUNet, models.py:356-367) in one launch: per channel
  * coef (6, C) = Zrr, Zri, Zir, Zii, Br', Bi' with y = Z x + B', Z = W V^{-1/2} (2x2 inverse square root of the covariance + eps)
  * and the mean folded into the bias.  Statistics come from `sums` (rfx_cplx_moments, inv_count = 1 / (N S); training) or from
@@ -521,7 +532,7 @@ int rfx_cplx_affine_act_fwd(const float* x, const float* coef, int32_t N, int32_
                             float* out, int64_t out_ns, int64_t out_im_off, void* stream);
 /* gx (N, 2C, S) written, gcoef (6, C) overwritten */
 int rfx_cplx_affine_act_bwd(const float* x, const float* coef, const float* gy, int64_t gy_ns, int64_t gy_im_off,
-                            int32_t N, int32_t C, int64_t S, float slope, float* gx, float* gcoef, void* stream);
+                            int32_t N, int32_t C, int64_t S, float slope, float* gx, double* ws, float* gcoef, void* stream);
 /* BoundComplexMask("tanh") applied to the mixture STFT: out = tanh(|m|) m/|m| (*) tf; planes (N, 2, P) */
 int rfx_bound_mask_fwd(const float* m, const float* tf, float* out, int32_t N, int64_t P, int64_t m_ns,
                        int64_t tf_ns, int64_t out_ns, void* stream);

@@ -153,6 +153,8 @@ SIGNATURES = {
     "rfx_clip_coef": [_P, C.c_float, C.c_float, _P, _P, _P],
     "rfx_adamw_step": [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P, _P],
     "rfx_groupnorm_stat_chunks": [_I32, _I32, _I32],
+    "rfx_norm_bwd_work_floats": [_I32, _I32, _I32, _I32],
+    "rfx_batchnorm_stat_slots": [_I32, _I32],
     "rfx_groupnorm_fwd": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
     "rfx_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "rfx_groupnorm_fwd_x16": [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P, _I32, _P, _P, _P, _P],
@@ -161,12 +163,13 @@ SIGNATURES = {
     "rfx_batchnorm_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "rfx_avgpool2d_fwd": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "rfx_avgpool2d_bwd": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P],
-    "rfx_cplx_moments": [_P, _I32, _I32, _I64, _P, _P],
+    "rfx_cplx_slots": [_I32, _I64],
+    "rfx_cplx_moments": [_P, _I32, _I32, _I64, _P, _P, _P],
     "rfx_cplx_moments_bwd": [_P, _P, _I32, _I32, _I64, _P, _P],
     "rfx_cplx_coef_fwd": [_P, C.c_double, _P, _P, _P, _P, _P, _P, C.c_float, _I32, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P],
     "rfx_cplx_coef_bwd": [_P, C.c_double, _P, _P, _P, _P, _P, _P, C.c_float, _I32, _P, _P, _P, _P],
     "rfx_cplx_affine_act_fwd": [_P, _P, _I32, _I32, _I64, C.c_float, _P, _I64, _I64, _P],
-    "rfx_cplx_affine_act_bwd": [_P, _P, _P, _I64, _I64, _I32, _I32, _I64, C.c_float, _P, _P, _P],
+    "rfx_cplx_affine_act_bwd": [_P, _P, _P, _I64, _I64, _I32, _I32, _I64, C.c_float, _P, _P, _P, _P],
     "rfx_bound_mask_fwd": [_P, _P, _P, _I32, _I64, _I64, _I64, _I64, _P],
     "rfx_bound_mask_bwd": [_P, _P, _P, _P, _I32, _I64, _I64, _I64, _I64, _I64, _P],
     "rfx_phase_mask_fwd": [_P, _P, _P, _I64, _P],
@@ -181,7 +184,7 @@ SIGNATURES = {
     "rfx_act_rows16": [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P],
     "rfx_mul": [_P, _P, _P, _I64, _P],
     "rfx_prelu_fwd": [_P, _P, _P, _I64, _I64, _I64, _P],
-    "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
+    "rfx_prelu_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "rfx_l1_sum": [_P, _P, _I64, _P, C.c_float, _P, _P],
     "rfx_add_bcast": [_P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I64, _I64, _I64, C.c_float, _P],
     "rfx_localstate_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
@@ -241,7 +244,7 @@ SIGNATURES = {
     "rfx_cl_dconv_bwd": [_P, _P, _P],
 }
 
-_RET64 = {"rfx_cl_wgrad_ws_floats", "rfx_stft_pair_loss_ws", "rfx_channel_sum_ws", "rfx_fft_synthesis_ws"}
+_RET64 = {"rfx_cl_wgrad_ws_floats", "rfx_cplx_slots", "rfx_norm_bwd_work_floats", "rfx_stft_pair_loss_ws", "rfx_channel_sum_ws", "rfx_fft_synthesis_ws"}
 _lib = None
 
 

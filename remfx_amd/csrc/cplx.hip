@@ -12,9 +12,10 @@
 
 constexpr int CX_CHUNK = 4096;
 
-// sums[c*5 + {0..4}] += { sum xr, sum xi, sum xr^2, sum xr*xi, sum xi^2 }   (fp64)
+// slots[(c * N * nchunks + n * nchunks + chunk) * 5 + {0..4}] = { sum xr, sum xi, sum xr^2, sum xr*xi, sum xi^2 } of one (n, c) row
+// chunk (fp64; the wave's own slot -- a plain store, added in slot order by rfx_slot_sum_kernel: DESIGN.md 4.11)
 __global__ __launch_bounds__(256) void cplx_moments_kernel(const float* __restrict__ x, int N, int C, int64_t S,
-                                                           int nchunks, double* __restrict__ sums) {
+                                                           int nchunks, double* __restrict__ slots) {
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= (int64_t)N * C * nchunks) return;
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void cplx_moments_kernel(const float* __restri
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const double d = rfx_wave_sum_d((double)v[q]);
-    if (lane == 0) atomicAdd(sums + c * 5 + q, d);
+    if (lane == 0) slots[(((int64_t)c * N + n) * nchunks + sc) * 5 + q] = d;
   }
 }
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void cplx_affine_act_bwd_kernel(const float* _
                                                                   const float* __restrict__ gy, int64_t gy_ns,
                                                                   int64_t gy_im_off, int N, int C, int64_t S,
                                                                   int nchunks, float slope, float* __restrict__ gx,
-                                                                  float* __restrict__ gcoef) {
+                                                                  double* __restrict__ slots /* [6][C][N * nchunks] */) {
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= (int64_t)N * C * nchunks) return;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void cplx_affine_act_bwd_kernel(const float* _
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
     const float d = rfx_wave_sum(v[q]);
-    if (lane == 0) atomicAdd(gcoef + q * C + c, d);
+    if (lane == 0) slots[(((int64_t)q * C + c) * N + n) * nchunks + sc] = (double)d;
   }
 }
 
@@ -177,13 +178,20 @@ static int cx_grid(int64_t total) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-extern "C" int rfx_cplx_moments(const float* x, int32_t N, int32_t C, int64_t S, double* sums, void* stream) {
-  if (!x || !sums || N <= 0 || C <= 0 || S <= 0) return -1;
+// slots per channel of the two reductions below: one per (sample, 4096-value chunk)
+extern "C" int64_t rfx_cplx_slots(int32_t N, int64_t S) {
+  if (N <= 0 || S <= 0) return -1;
+  return (int64_t)N * ((S + CX_CHUNK - 1) / CX_CHUNK);
+}
+extern "C" int rfx_cplx_moments(const float* x, int32_t N, int32_t C, int64_t S, double* ws, double* sums, void* stream) {
+  if (!x || !ws || !sums || N <= 0 || C <= 0 || S <= 0) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 5 * C, s) != hipSuccess) return -3;
   const int nchunks = (int)((S + CX_CHUNK - 1) / CX_CHUNK);
   const int64_t items = (int64_t)N * C * nchunks;
-  hipLaunchKernelGGL(cplx_moments_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, x, N, C, S, nchunks, sums);
+  if ((int64_t)N * nchunks > 0x7fffffff) return -1;
+  hipLaunchKernelGGL(cplx_moments_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, x, N, C, S, nchunks, ws);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<double>, RFX_SLOT_SUM_GRID(5 * C), 0, s, ws, C, N * nchunks, 5, sums);
   RFX_CHECK_LAUNCH();
   return 0;
 }
@@ -210,14 +218,16 @@ extern "C" int rfx_cplx_affine_act_fwd(const float* x, const float* coef, int32_
 }
 extern "C" int rfx_cplx_affine_act_bwd(const float* x, const float* coef, const float* gy, int64_t gy_ns,
                                        int64_t gy_im_off, int32_t N, int32_t C, int64_t S, float slope, float* gx,
-                                       float* gcoef, void* stream) {
-  if (!x || !coef || !gy || !gx || !gcoef || N <= 0 || C <= 0 || S <= 0) return -1;
+                                       double* ws, float* gcoef, void* stream) {
+  if (!x || !coef || !gy || !gx || !ws || !gcoef || N <= 0 || C <= 0 || S <= 0) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(gcoef, 0, sizeof(float) * 6 * C, s) != hipSuccess) return -3;
   const int nchunks = (int)((S + CX_CHUNK - 1) / CX_CHUNK);
   const int64_t items = (int64_t)N * C * nchunks;
+  if ((int64_t)N * nchunks > 0x7fffffff) return -1;
   hipLaunchKernelGGL(cplx_affine_act_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, x, coef, gy, gy_ns,
-                     gy_im_off, N, C, S, nchunks, slope, gx, gcoef);
+                     gy_im_off, N, C, S, nchunks, slope, gx, ws);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, RFX_SLOT_SUM_GRID(6 * C), 0, s, ws, 6 * C, N * nchunks, 1, gcoef);
   RFX_CHECK_LAUNCH();
   return 0;
 }

@@ -51,7 +51,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restr
 // x, gy: [N][C][L] contiguous; one block per (n-chunk, c) row set.
 __global__ void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                  const float* __restrict__ slope, float* __restrict__ gx,
-                                 float* __restrict__ gslope, int64_t N, int64_t C, int64_t L) {
+                                 double* __restrict__ slots /* [C][N] */, int64_t N, int64_t C, int64_t L) {
   const int64_t row = blockIdx.x;  // n*C + c
   const int c = (int)(row % C);
   const float s = slope[c];
@@ -69,7 +69,7 @@ __global__ void prelu_bwd_kernel(const float* __restrict__ x, const float* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) part[wave] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(gslope + c, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) slots[(int64_t)c * N + row / C] = (double)((part[0] + part[1]) + (part[2] + part[3]));
 }
 
 __global__ __launch_bounds__(256) void l1_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
@@ -322,10 +322,12 @@ extern "C" int rfx_prelu_fwd(const float* x, const float* slope, float* y, int64
   return 0;
 }
 extern "C" int rfx_prelu_bwd(const float* x, const float* gy, const float* slope, float* gx,
-                             float* gslope, int64_t N, int64_t C, int64_t L, void* stream) {
-  if (!x || !gy || !slope || !gx || !gslope || N <= 0 || C <= 0 || L <= 0) return -1;
+                             double* ws /* N * C doubles */, float* gslope, int64_t N, int64_t C, int64_t L, void* stream) {
+  if (!x || !gy || !slope || !gx || !ws || !gslope || N <= 0 || C <= 0 || L <= 0 || N * C > 0x7fffffff) return -1;
   hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, x, gy,
-                     slope, gx, gslope, N, C, L);
+                     slope, gx, ws, N, C, L);
+  RFX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rfx_slot_sum_kernel<float>, RFX_SLOT_SUM_GRID((int)C), 0, (hipStream_t)stream, ws, (int)C, (int)N, 1, gslope);
   RFX_CHECK_LAUNCH();
   return 0;
 }

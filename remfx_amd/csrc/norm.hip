@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* _
   if (lane == 0) {
     const int g = gn_sidx(a, n, ch);
     if (SLOTTED) {
-      // GroupNorm: (group, chunk) is THIS wave's alone -- a plain store into its own slot, summed in chunk order by gn_finalize_kernel.
-      // No zero fill, no atomics: a fill followed by fp64 atomics lost contributions whenever a second stream kept the machine busy
-      // (DESIGN.md 4.10), and the sum no longer depends on the order the waves finish in.
-      sums[2 * ((int64_t)g * nchunks + sc)] = dp;
-      sums[2 * ((int64_t)g * nchunks + sc) + 1] = dq;
+      // (group, chunk) -- BatchNorm: (channel, sample, chunk) -- is THIS wave's alone: a plain store into its own slot, summed in slot
+      // order by gn_finalize_kernel.  No zero fill, no atomics: a fill followed by fp64 atomics lost contributions whenever a second
+      // stream kept the machine busy, and the sum no longer depends on the order the waves finish in.
+      const int64_t slot = a.bn ? ((int64_t)g * a.N + n) * nchunks + sc : (int64_t)g * nchunks + sc;
+      sums[2 * slot] = dp;
+      sums[2 * slot + 1] = dq;
     } else {
       atomicAdd(sums + 2 * g, dp);
       atomicAdd(sums + 2 * g + 1, dq);
@@ -93,12 +94,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a, double* _
   }
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
-                                   float* __restrict__ rstd, int ngroups, double len, float eps, int slots) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per group: lane l adds the group's slots l, l + 64, ... in order, then the fixed butterfly (BatchNorm over a batch has
+// samples x chunks slots per channel: hundreds; a single thread would walk them as dependent loads)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, int ngroups, double len, float eps, int slots) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= ngroups) return;
-  double s1 = 0.0, s2 = 0.0;                     // slots > 1: partial sums a producing GEMM spread over several addresses
-  for (int k = 0; k < slots; ++k) { s1 += sums[2 * ((int64_t)i * slots + k)]; s2 += sums[2 * ((int64_t)i * slots + k) + 1]; }
+  double s1 = 0.0, s2 = 0.0;                     // slots > 1: partial sums spread over several addresses
+  for (int k = lane; k < slots; k += 64) { s1 += sums[2 * ((int64_t)i * slots + k)]; s2 += sums[2 * ((int64_t)i * slots + k) + 1]; }
+  s1 = rfx_wave_sum_d(s1); s2 = rfx_wave_sum_d(s2);
+  if (lane != 0) return;
   const double m = s1 / len;
   double var = s2 / len - m * m;
   var = var > 0.0 ? var : 0.0;
@@ -210,6 +215,8 @@ __device__ __forceinline__ float gn_du_single(const GnArgs& a, int n, int ch, in
 }
 
 // part: (N, C, 2) = { sum du, sum du*xhat } per (n, channel);  psc: (N, C/2) = sum gy*f (mode 3)
+// nchunks > 1: `part` / `psc` are SLOT arrays ((n, channel, chunk) is one wave's alone: plain stores), added in chunk order by
+// gn_bwd_slotsum_kernel -- the fill + atomics form this replaced depended on the order the waves finished in
 template <typename XT>
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const GnArgs a, float* __restrict__ part,
                                                              float* __restrict__ psc, int nchunks) {
@@ -292,12 +299,29 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const GnArgs a, flo
       if (a.mode == GN_GLU_SCALE_RES) psc[(int64_t)n * Cw + cw] = v[4];
     }
   } else {
-    atomicAdd(pa, v[0]); atomicAdd(pa + 1, v[1]);
+    float* sa = part + (((int64_t)n * a.C + cw) * nchunks + sc) * 2;
+    sa[0] = v[0]; sa[1] = v[1];
     if (pair) {
-      float* pb = part + ((int64_t)n * a.C + cw + Cw) * 2;
-      atomicAdd(pb, v[2]); atomicAdd(pb + 1, v[3]);
-      if (a.mode == GN_GLU_SCALE_RES) atomicAdd(psc + (int64_t)n * Cw + cw, v[4]);
+      float* sb = part + (((int64_t)n * a.C + cw + Cw) * nchunks + sc) * 2;
+      sb[0] = v[2]; sb[1] = v[3];
+      if (a.mode == GN_GLU_SCALE_RES) psc[((int64_t)n * Cw + cw) * nchunks + sc] = v[4];
     }
+  }
+}
+
+// part[n][ch][0..1] = sum over chunks of the slots (in chunk order); psc[n][cw] likewise
+__global__ __launch_bounds__(256) void gn_bwd_slotsum_kernel(const float* __restrict__ pslot, const float* __restrict__ scslot, float* __restrict__ part,
+                                                             float* __restrict__ psc, int64_t nrows, int64_t nsc, int nchunks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nrows) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < nchunks; ++k) { s0 += pslot[(i * nchunks + k) * 2]; s1 += pslot[(i * nchunks + k) * 2 + 1]; }
+    part[2 * i] = s0; part[2 * i + 1] = s1;
+  }
+  if (i < nsc) {
+    float s2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) s2 += scslot[i * nchunks + k];
+    psc[i] = s2;
   }
 }
 
@@ -569,11 +593,12 @@ static int norm_fwd(int x16, int bn, int use_given_stats, int sums_given_in, con
     const int64_t nitems = (int64_t)N * st.C * nchunks;
     int slots = sums_given > 1 ? sums_given : 1;
     if (!sums_given) {
-      if (sums_given == 0 && !bn && sums_slotted) {
-        // `sums` holds N * G * nchunks pairs (rfx_groupnorm_stat_chunks tells the caller): every (group, chunk) wave stores its own
+      if (sums_given == 0 && (sums_slotted || bn)) {
+        // `sums` holds N * G * nchunks pairs (rfx_groupnorm_stat_chunks; BatchNorm: C * N * nchunks, rfx_batchnorm_stat_slots): every
+        // (group, chunk) wave stores its own
         if (x16) hipLaunchKernelGGL((gn_stats_kernel<rfx_bf16s, true>), dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
         else hipLaunchKernelGGL((gn_stats_kernel<float, true>), dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
-        slots = nchunks;
+        slots = bn ? N * nchunks : nchunks;
       } else {
         if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * nstat, s) != hipSuccess) return -3;
         if (x16) hipLaunchKernelGGL(gn_stats_kernel<rfx_bf16s>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, st, sums, nchunks);
@@ -581,7 +606,7 @@ static int norm_fwd(int x16, int bn, int use_given_stats, int sums_given_in, con
       }
       RFX_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, s, sums, mean, rstd, nstat,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 3) / 4), dim3(256), 0, s, sums, mean, rstd, nstat,
                        bn ? (double)N * (double)S : (double)(C / G) * (double)S, eps, slots);
     RFX_CHECK_LAUNCH();
   }
@@ -923,7 +948,7 @@ __global__ __launch_bounds__(256) void gn_bwd_sample_wave_kernel(const GnArgs a,
 static int norm_bwd(int x16, int bn, const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t G, int32_t mode, const float* scale,
-                                 float* work /* N*C*2 + N*(C/2) + max(N*G, C)*2 floats */, float* dx, float* dgamma,
+                                 float* work /* rfx_norm_bwd_work_floats */, float* dx, float* dgamma,
                                  float* dbeta, float* dscale, void* stream) {
   if (!x || !gamma || !beta || !mean || !rstd || !gy || !work || !dx || !dgamma || !dbeta) return -1;
   if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return -1;
@@ -942,8 +967,9 @@ static int norm_bwd(int x16, int bn, const float* x, const float* gamma, const f
   const int nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
   const int Cw = glu ? C / 2 : C;
   const int64_t nitems = (int64_t)N * Cw * nchunks;
-  if (nchunks > 1 && hipMemsetAsync(work, 0, sizeof(float) * ((int64_t)N * C * 2 + (int64_t)N * (C / 2)), s) != hipSuccess)
-    return -3;
+  // nchunks > 1: the per-chunk slots live behind the group sums (rfx_norm_bwd_work_floats sizes `work`)
+  float* pslot = a.gsum + (int64_t)2 * (bn ? C : (N * G > C ? N * G : C));
+  float* scslot = pslot + (int64_t)N * C * 2 * nchunks;
   if (!bn && G == 1 && N >= 512 && (int64_t)C * S <= 65536) {
     // many small samples: one workgroup per sample, both passes fused (gn_bwd_sample_kernel); the GLU modes of the
     // HDemucs freq-branch shapes keep the sample in registers (gn_bwd_sample_reg_kernel)
@@ -976,7 +1002,15 @@ static int norm_bwd(int x16, int bn, const float* x, const float* gamma, const f
     RFX_CHECK_LAUNCH();
     return 0;
   }
-  GN_LAUNCH_X(gn_bwd_partial_kernel<float>, gn_bwd_partial_kernel<rfx_bf16s>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, part, psc, nchunks);
+  if (nchunks > 1) {
+    GN_LAUNCH_X(gn_bwd_partial_kernel<float>, gn_bwd_partial_kernel<rfx_bf16s>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, pslot, scslot, nchunks);
+    RFX_CHECK_LAUNCH();
+    const int64_t nrows = (int64_t)N * C, nsc = (int64_t)N * (C / 2);
+    hipLaunchKernelGGL(gn_bwd_slotsum_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, pslot, scslot, part, psc, nrows,
+                       mode == GN_GLU_SCALE_RES ? nsc : 0, nchunks);
+  } else {
+    GN_LAUNCH_X(gn_bwd_partial_kernel<float>, gn_bwd_partial_kernel<rfx_bf16s>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, s, a, part, psc, nchunks);
+  }
   RFX_CHECK_LAUNCH();
   if (!bn) {
     hipLaunchKernelGGL(gn_bwd_groupsum_kernel, dim3((N * G + 3) / 4), dim3(256), 0, s, a, part);
@@ -1008,7 +1042,7 @@ extern "C" int rfx_groupnorm_bwd_x16(const void* x, const float* gamma, const fl
   return norm_bwd(1, 0, static_cast<const float*>(x), gamma, beta, mean, rstd, gy, N, C, S, G, mode, scale, work,
                   static_cast<float*>(dx), dgamma, dbeta, dscale, stream);
 }
-// train-mode BatchNorm backward (batch statistics); work: N*C*2 + N*(C/2) + C*2 floats
+// train-mode BatchNorm backward (batch statistics); work: rfx_norm_bwd_work_floats(N, C, S, 0) floats
 extern "C" int rfx_batchnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const float* gy, int32_t N, int32_t C, int32_t S,
                                  int32_t mode, float* work, float* dx, float* dgamma, float* dbeta, void* stream) {
@@ -1165,6 +1199,21 @@ extern "C" int rfx_glu_bwd_bf16(const void* x, const float* gy, void* gx, int64_
 
 // Chunks gn_stats_kernel cuts a group of a GroupNorm(G) over (C, S) into: a caller that passes sums_given = -1 to rfx_groupnorm_fwd
 // / _x16 hands over a workspace of N * G * chunks pairs of doubles, filled by plain stores (no zero fill, no atomics).
+// floats of `work` rfx_groupnorm_bwd[_x16] (G groups) / rfx_batchnorm_bwd (G = 0) need: per-(sample, channel) partial pairs, the
+// LayerScale partials, the group (BatchNorm: channel) sums and, for rows longer than one 4096-sample chunk, the per-chunk slots
+extern "C" int64_t rfx_norm_bwd_work_floats(int32_t N, int32_t C, int32_t S, int32_t G) {
+  if (N <= 0 || C <= 0 || S <= 0 || G < 0) return -1;
+  const int64_t nchunks = (S + GN_CHUNK - 1) / GN_CHUNK;
+  const int64_t g = G == 0 ? C : ((int64_t)N * G > C ? (int64_t)N * G : C);
+  int64_t n = (int64_t)N * C * 2 + (int64_t)N * (C / 2) + 2 * g;
+  if (nchunks > 1) n += (int64_t)N * C * 2 * nchunks + (int64_t)N * (C / 2) * nchunks;
+  return n;
+}
+// fp64 PAIRS of `sums` rfx_batchnorm_fwd needs per channel when it computes the batch statistics: one slot per (sample, chunk)
+extern "C" int rfx_batchnorm_stat_slots(int32_t N, int32_t S) {
+  if (N <= 0 || S <= 0) return -1;
+  return N * ((S + GN_CHUNK - 1) / GN_CHUNK);
+}
 extern "C" int rfx_groupnorm_stat_chunks(int32_t C, int32_t S, int32_t G) {
   if (C <= 0 || S <= 0 || G <= 0 || C % G) return -1;
   const int64_t L = (int64_t)(C / G) * S;

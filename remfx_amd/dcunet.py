@@ -156,7 +156,8 @@ class _CplxNormActFn(torch.autograd.Function):
         coefc = torch.empty((6, Cc), device=y.device, dtype=torch.float32)
         if norm.training:
             sums = torch.empty(Cc * 5, device=y.device, dtype=torch.float64)
-            check(L.rfx_cplx_moments(_ptr(y), N, Cc, S, _ptr(sums), _stream()), "rfx_cplx_moments")
+            ws = torch.empty(5 * Cc * int(L.rfx_cplx_slots(N, S)), device=y.device, dtype=torch.float64)
+            check(L.rfx_cplx_moments(_ptr(y), N, Cc, S, _ptr(ws), _ptr(sums), _stream()), "rfx_cplx_moments")
             inv = 1.0 / float(N * S)
             check(L.rfx_cplx_coef_fwd(_ptr(sums), inv, None, *[_ptr(t) for t in pw], norm.eps, Cc, _ptr(coefc), None,
                                       _ptr(norm.RMr), _ptr(norm.RMi), _ptr(norm.RVrr), _ptr(norm.RVri), _ptr(norm.RVii),
@@ -188,8 +189,9 @@ class _CplxNormActFn(torch.autograd.Function):
             g = g.contiguous()
         gx = torch.empty_like(y)
         gcoef = torch.empty((6, Cc), device=y.device, dtype=torch.float32)
+        ws = torch.empty(6 * Cc * int(L.rfx_cplx_slots(N, S)), device=y.device, dtype=torch.float64)
         check(L.rfx_cplx_affine_act_bwd(_ptr(y), _ptr(coefc), _ptr(g), g.stride(0), Cc, N, Cc, S, LEAKY, _ptr(gx),
-                                        _ptr(gcoef), _stream()), "rfx_cplx_affine_act_bwd")
+                                        _ptr(ws), _ptr(gcoef), _stream()), "rfx_cplx_affine_act_bwd")
         sums, inv, stats_in = ctx.stat
         gw = torch.empty((5, Cc), device=y.device, dtype=torch.float32)
         cm = torch.empty((5, Cc), device=y.device, dtype=torch.float32) if sums is not None else None

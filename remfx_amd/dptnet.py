@@ -91,8 +91,9 @@ class _PReLUFn(torch.autograd.Function):
     def backward(ctx, g):
         x, slope = ctx.saved_tensors
         N, C, L = ctx.cfg
-        gx, gs = torch.empty_like(x), torch.zeros_like(slope)
-        check(_lib.lib().rfx_prelu_bwd(_ptr(x), _ptr(g.contiguous()), _ptr(slope), _ptr(gx), _ptr(gs), N, C, L, _stream()),
+        gx, gs = torch.empty_like(x), torch.empty_like(slope)
+        ws = torch.empty(N * C, device=x.device, dtype=torch.float64)
+        check(_lib.lib().rfx_prelu_bwd(_ptr(x), _ptr(g.contiguous()), _ptr(slope), _ptr(gx), _ptr(ws), _ptr(gs), N, C, L, _stream()),
               "rfx_prelu_bwd")
         return gx, gs
 

@@ -84,7 +84,7 @@ class _GroupNormFn(torch.autograd.Function):
         dgamma = tg[1] if tg else torch.empty_like(gamma)
         dbeta = tb[1] if tb else torch.empty_like(beta)
         dscale = (ts[1] if ts else torch.empty_like(scale)) if mode == 3 else None
-        gsum = torch.empty(N * Cc * 2 + N * (Cc // 2) + N * groups * 2, device=x.device, dtype=torch.float32)
+        gsum = torch.empty(int(_lib.lib().rfx_norm_bwd_work_floats(N, Cc, S, groups)), device=x.device, dtype=torch.float32)
         bwd = _lib.lib().rfx_groupnorm_bwd_x16 if x.dtype == torch.bfloat16 else _lib.lib().rfx_groupnorm_bwd
         check(bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gy),
                   N, Cc, S, groups, mode, _ptr(scale), _ptr(gsum), _ptr(dx),
@@ -119,7 +119,7 @@ class _BatchNormFn(torch.autograd.Function):
         if training:
             mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
             rstd = torch.empty_like(mean)
-            sums = torch.empty(Cc * 2, device=x.device, dtype=torch.float64)
+            sums = torch.empty(Cc * 2 * int(_lib.lib().rfx_batchnorm_stat_slots(N, S)), device=x.device, dtype=torch.float64)
             given = 0
         else:
             mean = running_mean.contiguous()
@@ -147,7 +147,7 @@ class _BatchNormFn(torch.autograd.Function):
         gy = gy.contiguous()
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
-        work = torch.empty(N * Cc * 2 + N * (Cc // 2) + Cc * 2, device=x.device, dtype=torch.float32)
+        work = torch.empty(int(_lib.lib().rfx_norm_bwd_work_floats(N, Cc, S, 0)), device=x.device, dtype=torch.float32)
         check(_lib.lib().rfx_batchnorm_bwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(gy),
                                            N, Cc, S, mode, _ptr(work), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
                                            _stream()), "rfx_batchnorm_bwd")
@@ -307,7 +307,7 @@ class _DConvLayerFn(torch.autograd.Function):
         # GroupNorm(1, 2C) + GLU + LayerScale backward (mode 3): dz (bf16), dgamma2 / dbeta2 / dscale; the residual passes gy on
         dz = torch.empty_like(z16)
         dg2w, dg2b, dscale = torch.empty_like(g2w), torch.empty_like(g2b), torch.empty_like(scale)
-        work = torch.empty(N * 2 * Cc * 2 + N * Cc + N * 2, device=x.device, dtype=torch.float32)
+        work = torch.empty(int(L.rfx_norm_bwd_work_floats(N, 2 * Cc, T, 1)), device=x.device, dtype=torch.float32)
         check(L.rfx_groupnorm_bwd_x16(_ptr(z16), _ptr(g2w), _ptr(g2b), _ptr(stats[2]), _ptr(stats[3]), _ptr(gy), N, 2 * Cc, T, 1, 3,
                                       _ptr(scale), _ptr(work), _ptr(dz), _ptr(dg2w), _ptr(dg2b), _ptr(dscale), _stream()),
               "rfx_groupnorm_bwd")
@@ -319,7 +319,7 @@ class _DConvLayerFn(torch.autograd.Function):
         # GroupNorm(1, H) + GELU backward (mode 1): dh (bf16), dgamma1 / dbeta1
         dh = torch.empty_like(h16)
         dg1w, dg1b = torch.empty_like(g1w), torch.empty_like(g1b)
-        work1 = torch.empty(N * H * 2 + N * (H // 2) + N * 2, device=x.device, dtype=torch.float32)
+        work1 = torch.empty(int(L.rfx_norm_bwd_work_floats(N, H, T, 1)), device=x.device, dtype=torch.float32)
         check(L.rfx_groupnorm_bwd_x16(_ptr(h16), _ptr(g1w), _ptr(g1b), _ptr(stats[0]), _ptr(stats[1]), _ptr(da), N, H, T, 1, 1,
                                       None, _ptr(work1), _ptr(dh), _ptr(dg1w), _ptr(dg1b), None, _stream()), "rfx_groupnorm_bwd")
         # dilated convolution: dx = W1^T * dh + gy (the residual rides in the GEMM's store);  dW1, db1

@@ -13,6 +13,7 @@ def _rms(a, b):
 
 @pytest.mark.parametrize("shape,groups", [((1024, 2, 20), 1), ((3, 48, 7, 33), 4), ((2, 12, 5000), 1),
                                           ((5, 96, 64), 4), ((2, 8, 3, 50), 1),
+                                          ((2, 6, 13000), 3),     # four 4096-sample chunks per row: slotted backward partials
                                           ((600, 12, 150), 1),    # 600 small samples: fused per-sample backward
                                           ((520, 20, 70), 1),     # 13-24 channels: the wider wave-per-sample variant
                                           ((513, 130, 40), 1),    # 65 channel pairs: register kernel that streams gy twice
@@ -55,6 +56,44 @@ def test_groupnorm_modes(shape, groups, mode):
         r = tr[i].grad
         scale = max(1.0, float(r.abs().max()))
         assert _rms(td[i].grad.cpu(), r) < 2e-5 * scale, (i, _rms(td[i].grad.cpu(), r), scale)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 9, 31), (2, 8, 70, 130), (40, 4, 33, 7)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_train_and_repeat(shape, relu):
+    """nn.BatchNorm2d (+ReLU) in training mode, forward / backward / running statistics, against torch on the CPU; rows of 9100 values
+    span three statistics chunks.  The statistics and the backward partials are slot stores added in a fixed order: a second call
+    returns the same bits."""
+    from remfx_amd import nnops
+    g = torch.Generator().manual_seed(sum(shape) + relu)
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 1.5 - 0.3
+    gy = torch.randn(shape, generator=g)
+    bn_ref = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.randn(C, generator=g)); bn_ref.bias.copy_(torch.randn(C, generator=g))
+    outs = []
+    for _ in range(2):
+        bn_dev = torch.nn.BatchNorm2d(C)
+        bn_dev.load_state_dict(bn_ref.state_dict())
+        bn_dev = bn_dev.to(DEV)
+        xd = x.to(DEV).requires_grad_(True)
+        y = nnops.batch_norm(xd, bn_dev, True, relu=relu)
+        y.backward(gy.to(DEV))
+        outs.append((y.detach().cpu(), xd.grad.cpu(), bn_dev.weight.grad.cpu(), bn_dev.bias.grad.cpu(),
+                     bn_dev.running_mean.cpu(), bn_dev.running_var.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    xr = x.clone().requires_grad_(True)
+    bn_ref.train()
+    yr = bn_ref(xr)
+    yr = F.relu(yr) if relu else yr
+    yr.backward(gy)
+    y, dx, dw, db, rm, rv = outs[0]
+    assert _rms(y, yr.detach()) < 1e-5
+    for got, want in ((dx, xr.grad), (dw, bn_ref.weight.grad), (db, bn_ref.bias.grad), (rm, bn_ref.running_mean), (rv, bn_ref.running_var)):
+        scale = max(1.0, float(want.abs().max()))
+        assert _rms(got, want) < 2e-5 * scale
 
 
 def test_glu_plain():
