@@ -19,6 +19,7 @@
 // csrc/cl_wgrad.hip (deterministic).  The affine / LayerScale gradients are per-lane sums, reduced over waves and workgroups in a
 // fixed order (no atomics: the LDS float atomics of the round-4 backward kernel cost 7 of its 13.7 ms).
 #include "cl_common.h"
+#include <stdlib.h>
 
 #define CLD_T 256
 // The packed-weight fragment reads are loop-invariant LDS loads: without a memory clobber in the sample loop LICM hoists all of them
@@ -86,6 +87,54 @@ __device__ __forceinline__ void cld_block_sum2(float& a, float& b, float* red, i
   for (int w = 0; w < NW; ++w) { sa += red[w]; sb += red[8 + w]; }
   __syncthreads();
   a = sa; b = sb;
+}
+
+// workgroup barrier that leaves this wave's VMEM operations (LDS-DMA pieces, output stores) in flight: __syncthreads() fences and
+// drains them
+#define CLD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+typedef float cld_f2 __attribute__((ext_vector_type(2)));
+// GELU'(x) on a register pair (rfx_gelu_parts' polynomial; raw v_exp_f32 on a clamped argument)
+__device__ __forceinline__ cld_f2 cld_gelu_grad2(cld_f2 x) {
+  const cld_f2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const cld_f2 q = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+  const cld_f2 t = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  const cld_f2 xx = x * x * (-0.5f * 1.44269504088896f);
+  const cld_f2 ex = {__builtin_amdgcn_exp2f(fmaxf(xx[0], -126.0f)), __builtin_amdgcn_exp2f(fmaxf(xx[1], -126.0f))};
+  cld_f2 p = t * 1.061405429f + -1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t + -0.284496736f;
+  p = p * t + 0.254829592f;
+  const cld_f2 e = 1.0f - (p * t) * ex;                  // erf(|x| / sqrt2)
+  const cld_f2 cdf = {0.5f + copysignf(0.5f * e[0], x[0]), 0.5f + copysignf(0.5f * e[1], x[1])};
+  return (x * 0.39894228040143267794f) * ex + cdf;
+}
+// LDS-DMA the compiler does not track: with the builtin in flight it puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot
+// prove disjoint (any read through a run-time buffer choice), which ends a prefetch where it began.  The issuing wave orders its own
+// reads behind the pieces with explicit counted waits (cld_wait_vm) + a barrier for the other waves'.
+typedef int cld_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cld_i32x4 cld_rsrc_words(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)p;
+  cld_i32x4 r = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  return r;
+}
+__device__ __forceinline__ void cld_glds16_quiet(const cld_i32x4& rs, unsigned char* lds_base, uint32_t voff) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)CL_LDS(lds_base));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(m), "v"(voff), "s"(rs) : "memory", "m0");
+}
+// 16 bytes of LDS, read and waited for inside one asm block
+__device__ __forceinline__ uint4 cld_lds_read16(const unsigned char* p) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void cld_wait_vm() {
+  static_assert(N >= 0 && N <= 16, "");
+  if (N == 0) CL_VMCNT(0); else if (N == 1) CL_VMCNT(1); else if (N == 2) CL_VMCNT(2); else if (N == 3) CL_VMCNT(3);
+  else if (N == 4) CL_VMCNT(4); else if (N == 5) CL_VMCNT(5); else if (N == 6) CL_VMCNT(6); else if (N == 7) CL_VMCNT(7);
+  else if (N == 8) CL_VMCNT(8); else if (N == 9) CL_VMCNT(9); else if (N == 10) CL_VMCNT(10); else if (N == 11) CL_VMCNT(11);
+  else if (N == 12) CL_VMCNT(12); else if (N == 13) CL_VMCNT(13); else if (N == 14) CL_VMCNT(14); else if (N == 15) CL_VMCNT(15);
+  else CL_VMCNT(16);
 }
 
 // PH: 0 = a sample is one 256-position tile, statistics inside the kernel (the frequency branch); 1 / 2 / 3 = a sample is TPS
@@ -561,6 +610,322 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwd_kernel(const ClDconvK g) 
   }
 }
 
+// ---- the same backward pass on EIGHT waves (two per SIMD), C = 48 / 64 (two channel tiles) --------------------------------------
+// cl_dconv_bwd_kernel above keeps 400 registers live per wave (four waves, one per SIMD): every LDS / MFMA / transcendental latency
+// and the DMA wait at the top of a sample is exposed, and the kernel ran at 0.22 of HBM, VALU-issue-bound on paper but with ~45 %
+// of the cycles idle.  Here a wave owns (64-position group pg, channel tile ts) in the channel-domain phases (pass A, the dz
+// finalisation, dx) and the 32-position sub-tile 32 * wave in the hidden-channel phase (da, GELU / GroupNorm-1 backward): half the
+// accumulators, constants and tiles per wave, < 256 registers, two waves per SIMD.  The price is workgroup barriers where the
+// four-wave form had wave-private rows: after the DMA, between the dz finalisation and da (a row's 2 C channels come from both
+// waves of a pair), and before the output stores.  Same arithmetic, same order of the block sums' terms within a wave.
+template <int C, int H>
+__global__ __launch_bounds__(512, 1) void cl_dconv_bwd8_kernel(const ClDconvK g) {
+  using Cfg = CldCfg<C, H>;
+  constexpr int HP = Cfg::HP, KC = Cfg::KC, KH = Cfg::KH, NTV = Cfg::NTV, NT2 = Cfg::NT2, RS = Cfg::RS, RSH = Cfg::RSH, RSZ = Cfg::RSZ;
+  constexpr int KZ = 2 * C / 16;
+  static_assert(NTV == 2, "one channel tile per wave of a pair");
+  extern __shared__ __attribute__((aligned(16))) unsigned char cld_smem[];
+  const rfx_cl_dconv_desc& d = g.d;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int pg = wave >> 1, ts = wave & 1;
+  unsigned char* aimg = cld_smem + Cfg::B_A;                      // [256][HP]
+  unsigned char* himg = cld_smem + Cfg::B_HI;                     // [256][HP]
+  unsigned char* zimg = cld_smem + Cfg::B_DZ;                     // dz [256][2 C]
+  unsigned char* dhimg = cld_smem + Cfg::B_DH;                    // dh [2 + 256 + 2][HP]
+  float* red = reinterpret_cast<float*>(cld_smem + Cfg::B_RED);   // two block sums per sample, each with its own 16 floats
+
+  cld_copy_in(cld_smem + Cfg::B_W2, d.w2p, KH * NT2 * 1024, tid, 512);
+  cld_copy_in(cld_smem + Cfg::B_W2D, d.w2dp, KZ * 1024, tid, 512);
+  cld_copy_in(cld_smem + Cfg::B_W1D, d.w1dp, 3 * KH * NTV * 1024, tid, 512);
+  for (int o = tid * 4; o < CLD_HALO * RSH; o += 512 * 4) {
+    *reinterpret_cast<uint32_t*>(dhimg + o) = 0u;
+    *reinterpret_cast<uint32_t*>(dhimg + (CLD_T + CLD_HALO) * RSH + o) = 0u;
+  }
+  const int c = 32 * ts + l31;
+  const bool cok = c < C;
+  const float b2v = cok ? d.b2[c] : 0.f, b2g = cok ? d.b2[C + c] : 0.f;
+  const float gv = cok ? d.g2w[c] : 0.f, gg = cok ? d.g2w[C + c] : 0.f;
+  const float ev = cok ? d.g2b[c] : 0.f, eg = cok ? d.g2b[C + c] : 0.f;
+  const float sc = cok ? d.scale[c] : 0.f;
+  const bool hok = l31 < H;
+  const float g1 = hok ? d.g1w[l31] : 0.f, e1 = hok ? d.g1b[l31] : 0.f;
+  // the element-wise work runs on PAIRS of accumulator registers (rows r, r + 1 of a tile): v_pk_fma / v_pk_mul / v_pk_add_f32 do two
+  // elements per issue slot and this kernel is VALU-issue-bound (60 VALU instructions per MFMA in the r05 counters of the scalar form)
+  cld_f2 a_ds = {0.f, 0.f}, a_gwv = {0.f, 0.f}, a_gwg = {0.f, 0.f}, a_gbv = {0.f, 0.f}, a_gbg = {0.f, 0.f}, a_g1w = {0.f, 0.f}, a_g1b = {0.f, 0.f};
+  const float ggn = -1.44269504088896f * gg, egn = -1.44269504088896f * eg;       // the gate's affine, pre-scaled for exp2(-x)
+  const cl_bf16x8 id0 = cld_ident(0, lane), id1 = cld_ident(1, lane);
+  // gy through the identity with the columns of channels >= C zeroed: those lanes then carry exact zeros through every sum
+  const cl_bf16x8 zfrag = __builtin_bit_cast(cl_bf16x8, make_uint4(0u, 0u, 0u, 0u));
+  const cl_bf16x8 idg0 = cok ? id0 : zfrag, idg1 = cok ? id1 : zfrag;
+  const int r0 = 32 * wave;                                       // DMA / output rows and the hidden-phase sub-tile of this wave
+  const int64_t big = 0x7ffffff0;
+  const cld_i32x4 rs_g = cld_rsrc_words(d.gy, (uint32_t)min(big, (int64_t)d.S * CLD_T * RS));
+  const cld_i32x4 rs_a = cld_rsrc_words(d.a, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
+  const cld_i32x4 rs_h = cld_rsrc_words(d.hpre, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
+  const float n1 = 1.0f / (H * CLD_T), n2 = 1.0f / (2 * C * CLD_T);
+  // a sample's operands (this wave's 32 rows of gy, a, h) by DMA, its four statistics into registers
+  auto fetch_g = [&](int s, unsigned char* gdst) {
+    const uint32_t gb = (uint32_t)s * (CLD_T * RS) + (uint32_t)r0 * RS + lane * 16;           // 32 rows x RS bytes = KC KiB
+#pragma unroll
+    for (int i = 0; i < KC; ++i) cld_glds16_quiet(rs_g, gdst + r0 * RS + i * 1024, gb + i * 1024);
+  };
+  auto fetch_h = [&](int s, const cld_i32x4& rs, unsigned char* img) {
+    const uint32_t hb = (uint32_t)s * (CLD_T * RSH) + (uint32_t)r0 * RSH + lane * 16;         // 32 rows x RSH bytes = KH KiB
+#pragma unroll
+    for (int i = 0; i < KH; ++i) cld_glds16_quiet(rs, img + r0 * RSH + i * 1024, hb + i * 1024);
+  };
+  constexpr int NSTORE = 3 * KC + KH;                             // 16-byte global stores per wave and sample
+  float4 st_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((int)blockIdx.x < d.S) {
+    fetch_g(blockIdx.x, cld_smem);
+    fetch_h(blockIdx.x, rs_a, aimg);
+    fetch_h(blockIdx.x, rs_h, himg);
+    st_next = *reinterpret_cast<const float4*>(d.stats + (int64_t)blockIdx.x * 4);
+  }
+  CL_VMCNT(0);
+  __syncthreads();
+
+  int it = 0;
+  for (int s = blockIdx.x; s < d.S; s += gridDim.x, ++it) {
+    CLD_NO_HOIST();
+    // gy (later dx) alternates between two images: the next sample's operands arrive while this one's dx is formed and stored
+    unsigned char* gimg = (it & 1) ? cld_smem + Cfg::B_LDS : cld_smem;
+    unsigned char* gnext = (it & 1) ? cld_smem : cld_smem + Cfg::B_LDS;
+    const float mu1 = st_next.x, rs1 = st_next.y, mu2 = st_next.z, rs2 = st_next.w;
+    // everything older than the previous sample's output stores (the newest NSTORE operations of this wave): this sample's DMA pieces
+    cld_wait_vm<NSTORE>();
+    CLD_BARRIER();                                                // the pair's other wave fetched half of this wave's rows
+    // the next sample's operands land while this one is worked on: gy now (the other image: free since the previous sample's stores),
+    // a after the last pass that reads it, h after this wave's own read of its rows
+    const int sn = s + (int)gridDim.x;
+    const bool more = sn < d.S;
+    if (more) fetch_g(sn, gnext);
+    // ---- pass A: this wave's (value, gate) tile of z^T for the 64 positions of its group, GLU / LayerScale / GroupNorm-2 backward up to
+    // d(zhat), parked as bf16 in the dz image until the sample sums are known
+    const float kv = (b2v - mu2) * rs2, kg = (b2g - mu2) * rs2;   // zhat = z rstd + k
+    cld_f2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      const int p0 = 64 * pg + 32 * sub, prow = p0 + 4 * half;
+      const unsigned char* grow = gimg + (p0 + l31) * RS + 16 * half;
+      cl_bf16x8 afr[KH];
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+        const unsigned char* ar = aimg + (p0 + l31) * RSH + (16 * ks + 4 * half) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(ar), hi = *reinterpret_cast<const uint2*>(ar + 16);
+        afr[ks] = __builtin_bit_cast(cl_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
+      f32x16 zv, zg, gy;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zv[r] = zg[r] = gy[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+        zv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + ts) * 1024 + lane * 16), zv, 0, 0, 0);
+        zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + NTV + ts) * 1024 + lane * 16), zg, 0, 0, 0);
+      }
+      gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * ts) * 32), idg0, gy, 0, 0, 0);
+      if (2 * ts + 1 < KC) gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * ts + 1) * 32), idg1, gy, 0, 0, 0);
+      unsigned char* zb0 = zimg + prow * RSZ + c * 2;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const cld_f2 z_v = {zv[r], zv[r + 1]}, z_g = {zg[r], zg[r + 1]}, g2 = {gy[r], gy[r + 1]};
+        const cld_f2 zhv = z_v * rs2 + kv, zhg = z_g * rs2 + kg;
+        const cld_f2 v = zhv * gv + ev, gn = zhg * ggn + egn;
+        const cld_f2 den = {1.0f + __builtin_amdgcn_exp2f(fminf(gn[0], 126.0f)), 1.0f + __builtin_amdgcn_exp2f(fminf(gn[1], 126.0f))};
+        const cld_f2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+        a_ds += g2 * (v * sg);
+        const cld_f2 dv = (g2 * sc) * sg, dgt = (dv * v) * (1.0f - sg);
+        a_gbv += dv;  a_gwv += dv * zhv;
+        a_gbg += dgt; a_gwg += dgt * zhg;
+        const cld_f2 pv = dv * gv, pg = dgt * gg;
+        const uint32_t pk0 = rfx_cvt_pk_bf16(pv[0], pg[0]), pk1 = rfx_cvt_pk_bf16(pv[1], pg[1]);
+        // the parked values: the sums match them
+        const cld_f2 dzv = {__uint_as_float(pk0 << 16), __uint_as_float(pk1 << 16)}, dzg = {__uint_as_float(pk0 & 0xffff0000u), __uint_as_float(pk1 & 0xffff0000u)};
+        s1p += dzv + dzg;
+        s2p += dzv * zhv + dzg * zhg;
+        if (cok) {
+          unsigned char* zb = zb0 + ((r & 3) + 8 * (r >> 2)) * RSZ;
+          *reinterpret_cast<uint16_t*>(zb) = (uint16_t)pk0;
+          *reinterpret_cast<uint16_t*>(zb + 2 * C) = (uint16_t)(pk0 >> 16);
+          *reinterpret_cast<uint16_t*>(zb + RSZ) = (uint16_t)pk1;
+          *reinterpret_cast<uint16_t*>(zb + RSZ + 2 * C) = (uint16_t)(pk1 >> 16);
+        }
+      }
+    }
+    float s1 = s1p[0] + s1p[1], s2 = s2p[0] + s2p[1];
+    s1 = rfx_wave_sum(s1); s2 = rfx_wave_sum(s2);
+    if (lane == 0) { red[wave] = s1; red[8 + wave] = s2; }
+    CLD_BARRIER();
+    {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { sa += red[w]; sb += red[8 + w]; }
+      s1 = sa; s2 = sb;
+    }
+    // ---- pass B1: zhat again, dz = rstd (d(zhat) - mean(d(zhat)) - zhat mean(d(zhat) zhat)) -> image (this wave's own elements)
+    {
+      const float m1 = s1 * n2, m2 = s2 * n2;
+#pragma unroll 1
+      for (int sub = 0; sub < 2; ++sub) {
+        const int p0 = 64 * pg + 32 * sub, prow = p0 + 4 * half;
+        cl_bf16x8 afr[KH];
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+          const unsigned char* ar = aimg + (p0 + l31) * RSH + (16 * ks + 4 * half) * 2;
+          const uint2 lo = *reinterpret_cast<const uint2*>(ar), hi = *reinterpret_cast<const uint2*>(ar + 16);
+          afr[ks] = __builtin_bit_cast(cl_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+        f32x16 zv, zg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zv[r] = zg[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+          zv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + ts) * 1024 + lane * 16), zv, 0, 0, 0);
+          zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + Cfg::B_W2 + (ks * NT2 + NTV + ts) * 1024 + lane * 16), zg, 0, 0, 0);
+        }
+        if (cok) {
+          unsigned char* zb = zimg + prow * RSZ + c * 2;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int ro = ((r & 3) + 8 * (r >> 2)) * RSZ;
+            const cld_f2 z_v = {zv[r], zv[r + 1]}, z_g = {zg[r], zg[r + 1]};
+            const cld_f2 zhv = z_v * rs2 + kv, zhg = z_g * rs2 + kg;
+            const cld_f2 dzv = {__uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro) << 16),
+                                __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + RSZ) << 16)};
+            const cld_f2 dzg = {__uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + 2 * C) << 16),
+                                __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + RSZ + 2 * C) << 16)};
+            const cld_f2 ov = ((dzv - m1) - zhv * m2) * rs2, og = ((dzg - m1) - zhg * m2) * rs2;
+            const uint32_t o0 = rfx_cvt_pk_bf16(ov[0], og[0]), o1 = rfx_cvt_pk_bf16(ov[1], og[1]);
+            *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)o0;
+            *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)(o0 >> 16);
+            *reinterpret_cast<uint16_t*>(zb + ro + RSZ) = (uint16_t)o1;
+            *reinterpret_cast<uint16_t*>(zb + ro + RSZ + 2 * C) = (uint16_t)(o1 >> 16);
+          }
+        }
+      }
+    }
+    CLD_BARRIER();                                                // a row of dz = both tiles = both waves of the pair
+    if (more) fetch_h(sn, rs_a, aimg);
+    // ---- pass B2, sub-tile [r0, r0 + 32): da^T = dz^T W2 and h^T through the identity (lane = hidden channel), GELU / GroupNorm-1 backward
+    f32x16 dat, htt;
+    {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dat[r] = htt[r] = 0.f;
+#pragma unroll
+      for (int kz = 0; kz < KZ; ++kz)
+        dat = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(zimg + (r0 + l31) * RSZ + (16 * kz + 8 * half) * 2),
+                                                       cld_ld16(cld_smem + Cfg::B_W2D + kz * 1024 + lane * 16), dat, 0, 0, 0);
+      htt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(himg + (r0 + l31) * RSH + 16 * half), id0, htt, 0, 0, 0);
+      if (KH > 1) htt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(himg + (r0 + l31) * RSH + 32 + 16 * half), id1, htt, 0, 0, 0);
+      const float k1 = -mu1 * rs1;
+      s1p = cld_f2{0.f, 0.f}; s2p = cld_f2{0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const cld_f2 h2 = {htt[r], htt[r + 1]}, d2 = {dat[r], dat[r + 1]};
+        const cld_f2 hh = h2 * rs1 + k1;
+        const cld_f2 dhn = hok ? d2 * cld_gelu_grad2(hh * g1 + e1) : cld_f2{0.f, 0.f};
+        a_g1b += dhn;
+        a_g1w += dhn * hh;
+        const cld_f2 dhh = dhn * g1;
+        s1p += dhh;
+        s2p += dhh * hh;
+        htt[r] = hh[0]; htt[r + 1] = hh[1]; dat[r] = dhh[0]; dat[r + 1] = dhh[1];
+      }
+      s1 = s1p[0] + s1p[1]; s2 = s2p[0] + s2p[1];
+    }
+    if (more) {
+      CL_LGKM0();                                                 // (this wave's reads of its h rows are long complete)
+      fetch_h(sn, rs_h, himg);
+      st_next = *reinterpret_cast<const float4*>(d.stats + (int64_t)sn * 4);
+    }
+    s1 = rfx_wave_sum(s1); s2 = rfx_wave_sum(s2);
+    if (lane == 0) { red[16 + wave] = s1; red[24 + wave] = s2; }
+    CLD_BARRIER();
+    {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { sa += red[16 + w]; sb += red[24 + w]; }
+      const float m1 = sa * n1, m2 = sb * n1;
+      if (l31 < HP) {
+        unsigned char* hb = dhimg + (CLD_HALO + r0 + 4 * half) * RSH + l31 * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          *reinterpret_cast<uint16_t*>(hb + ((r & 3) + 8 * (r >> 2)) * RSH) = hok ? (uint16_t)rfx_bf16_bits(rs1 * (dat[r] - m1 - htt[r] * m2)) : (uint16_t)0;
+      }
+    }
+    CLD_BARRIER();                                                // the taps read the neighbouring waves' rows of dh
+    // ---- dx^T = gy^T + sum_t dh^T(pos - (t - 1) d) W1_t; written over gy (this wave's tile of its group's rows)
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      const int p0 = 64 * pg + 32 * sub, prow = p0 + 4 * half;
+      const unsigned char* grow = gimg + (p0 + l31) * RS + 16 * half;
+      f32x16 dx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+      dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * ts) * 32), id0, dx, 0, 0, 0);
+      if (2 * ts + 1 < KC) dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * ts + 1) * 32), id1, dx, 0, 0, 0);
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks)
+          dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(dhimg + (CLD_HALO + p0 + l31 - (tp - 1) * d.dil) * RSH + (16 * ks + 8 * half) * 2),
+                                                        cld_ld16(cld_smem + Cfg::B_W1D + ((tp * KH + ks) * NTV + ts) * 1024 + lane * 16), dx, 0, 0, 0);
+      // every lane of the wave has read this tile's channels of these rows (the identity MFMAs) before they are overwritten: LDS
+      // operations of one wave execute in order, and the other wave of the pair reads and writes the other tile's channels only
+      if (cok) {
+        unsigned char* xb = gimg + prow * RS + c * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *reinterpret_cast<uint16_t*>(xb + ((r & 3) + 8 * (r >> 2)) * RS) = (uint16_t)rfx_bf16_bits(dx[r]);
+      }
+    }
+    CLD_BARRIER();                                                // rows [r0, r0 + 32) of dx: both waves of the pair
+    {
+      // (LDS reads the compiler cannot see: it would put `s_waitcnt vmcnt(0)` -- the next sample's DMA pieces -- in front of them)
+      unsigned char* o = reinterpret_cast<unsigned char*>(d.y) + (int64_t)s * (CLD_T * RS) + r0 * RS + lane * 16;
+#pragma unroll
+      for (int i = 0; i < KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = cld_lds_read16(gimg + r0 * RS + i * 1024 + lane * 16);
+      o = reinterpret_cast<unsigned char*>(d.dz) + (int64_t)s * (CLD_T * RSZ) + r0 * RSZ + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 2 * KC; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = cld_lds_read16(zimg + r0 * RSZ + i * 1024 + lane * 16);
+      o = reinterpret_cast<unsigned char*>(d.dh) + (int64_t)s * (CLD_T * RSH) + r0 * RSH + lane * 16;
+#pragma unroll
+      for (int i = 0; i < KH; ++i) *reinterpret_cast<uint4*>(o + i * 1024) = cld_lds_read16(dhimg + (CLD_HALO + r0) * RSH + i * 1024 + lane * 16);
+    }
+    CL_LGKM0();
+    // the sample after the next lands in the rows of this gy image that this wave alone read last (its own output rows)
+  }
+
+  // ---- parameter-gradient sums of this workgroup: lanes l and l + 32 hold the same channel, the four waves of a tile different positions
+  __syncthreads();
+  float* acc = reinterpret_cast<float*>(zimg);                    // [8 waves][7][64]
+  acc[(wave * 7 + 0) * 64 + lane] = a_ds[0] + a_ds[1];
+  acc[(wave * 7 + 1) * 64 + lane] = a_gwv[0] + a_gwv[1];
+  acc[(wave * 7 + 2) * 64 + lane] = a_gwg[0] + a_gwg[1];
+  acc[(wave * 7 + 3) * 64 + lane] = a_gbv[0] + a_gbv[1];
+  acc[(wave * 7 + 4) * 64 + lane] = a_gbg[0] + a_gbg[1];
+  acc[(wave * 7 + 5) * 64 + lane] = a_g1w[0] + a_g1w[1];
+  acc[(wave * 7 + 6) * 64 + lane] = a_g1b[0] + a_g1b[1];
+  __syncthreads();
+  float* prow_out = d.partial + (int64_t)blockIdx.x * (5 * C + 2 * H);
+  for (int i = tid; i < 5 * C + 2 * H; i += 512) {
+    // i -> (quantity q, channel tile t or -1, lane n): dscale[c] | dgn2w[value c | gate c] | dgn2b[value c | gate c] | dgn1w[h] | dgn1b[h]
+    int q, t, n;
+    if (i < 5 * C) { const int cc = i % C; q = i / C; t = cc >> 5; n = cc & 31; }
+    else if (i < 5 * C + H) { q = 5; t = -1; n = i - 5 * C; }
+    else { q = 6; t = -1; n = i - 5 * C - H; }
+    float sum = 0.f;
+    if (t >= 0) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sum += acc[((2 * w + t) * 7 + q) * 64 + n] + acc[((2 * w + t) * 7 + q) * 64 + 32 + n];
+    } else {
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sum += acc[(w * 7 + q) * 64 + n] + acc[(w * 7 + q) * 64 + 32 + n];
+    }
+    prow_out[i] = sum;
+  }
+}
+
 // ---- backward in passes, for samples of several tiles (the time branch) and for widths whose single-pass images do not fit the LDS
 // (C = 96).  Everything a pass needs from another tile is a per-sample scalar, reduced between the passes in a fixed order:
 //   B1  z recomputed from a; GLU / LayerScale / GroupNorm-2 backward up to d(zhat); d(zhat) PARKED in the dz tensor (bf16); tile sums
@@ -895,6 +1260,22 @@ static int cld_launch(const rfx_cl_dconv_desc& d, bool bwd, hipStream_t st) {
   }
   ClDconvK k;
   k.d = d;
+  if constexpr (Cfg::NTV == 2) {
+    static const bool four = [] { const char* e = getenv("RFX_CLD_BWD_NW"); return e && atoi(e) == 4; }();       // dev A/B
+    static bool attr8 = false;
+    constexpr int lds8 = Cfg::B_LDS + CLD_T * Cfg::RS;          // + the second gy image
+    static_assert(lds8 <= 160 * 1024, "");
+    if (!four) {
+      if (!attr8) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_dconv_bwd8_kernel<C, H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8) != hipSuccess)
+          return -3;
+        attr8 = true;
+      }
+      hipLaunchKernelGGL((cl_dconv_bwd8_kernel<C, H>), dim3(d.S < d.grid ? d.S : d.grid), dim3(512), lds8, st, k);
+      RFX_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((cl_dconv_bwd_kernel<C, H>), dim3(d.S < d.grid ? d.S : d.grid), dim3(256), Cfg::B_LDS, st, k);
   RFX_CHECK_LAUNCH();
   return 0;
