@@ -89,9 +89,6 @@ __device__ __forceinline__ void cld_block_sum2(float& a, float& b, float* red, i
   a = sa; b = sb;
 }
 
-// workgroup barrier that leaves this wave's VMEM operations (LDS-DMA pieces, output stores) in flight: __syncthreads() fences and
-// drains them
-#define CLD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 typedef float cld_f2 __attribute__((ext_vector_type(2)));
 // GELU'(x) on a register pair (rfx_gelu_parts' polynomial; raw v_exp_f32 on a clamped argument)
 __device__ __forceinline__ cld_f2 cld_gelu_grad2(cld_f2 x) {
@@ -108,6 +105,9 @@ __device__ __forceinline__ cld_f2 cld_gelu_grad2(cld_f2 x) {
   const cld_f2 cdf = {0.5f + copysignf(0.5f * e[0], x[0]), 0.5f + copysignf(0.5f * e[1], x[1])};
   return (x * 0.39894228040143267794f) * ex + cdf;
 }
+// workgroup barrier that leaves this wave's VMEM operations (LDS-DMA pieces, output stores) in flight: __syncthreads() fences and
+// drains them
+#define CLD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // LDS-DMA the compiler does not track: with the builtin in flight it puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot
 // prove disjoint (any read through a run-time buffer choice), which ends a prefetch where it began.  The issuing wave orders its own
 // reads behind the pieces with explicit counted waits (cld_wait_vm) + a barrier for the other waves'.
@@ -267,18 +267,21 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
       for (int t = 0; t < NT2; ++t)
         z[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, cld_ld16(cld_smem + Cfg::F_W2 + (ks * NT2 + t) * 1024 + lane * 16), z[t], 0, 0, 0);
     }
-    s1 = 0.f; s2 = 0.f;
+    // (register pairs: v_pk_add / v_pk_fma_f32 do two elements per issue slot, and these passes are VALU-issue-bound.  Lanes of
+    // channels >= C hold exact zeros: W2's padded columns and b2v = b2g = 0 there)
+    {
+      cld_f2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NTV; ++t)
+      for (int t = 0; t < NTV; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        z[t][r] += b2v[t];
-        z[NTV + t][r] += b2g[t];
-        if (cok[t]) {
-          s1 += z[t][r] + z[NTV + t][r];
-          s2 = fmaf(z[t][r], z[t][r], fmaf(z[NTV + t][r], z[NTV + t][r], s2));
+        for (int r = 0; r < 16; r += 2) {
+          const cld_f2 zv = cld_f2{z[t][r], z[t][r + 1]} + b2v[t], zg = cld_f2{z[NTV + t][r], z[NTV + t][r + 1]} + b2g[t];
+          z[t][r] = zv[0]; z[t][r + 1] = zv[1]; z[NTV + t][r] = zg[0]; z[NTV + t][r + 1] = zg[1];
+          s1p += zv + zg;
+          s2p += zv * zv + zg * zg;
         }
-      }
+      s1 = s1p[0] + s1p[1]; s2 = s2p[0] + s2p[1];
+    }
     float mu2, rs2;
     if (PH == 0) {
       cld_block_sum2(s1, s2, red, wave, lane);
@@ -302,11 +305,17 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
       xr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(xrow + (2 * t) * 32), id0, xr, 0, 0, 0);
       if (2 * t + 1 < KC) xr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(xrow + (2 * t + 1) * 32), id1, xr, 0, 0, 0);
       if (cok[t]) {
+        // GroupNorm-2's normalisation and affine as one fused multiply-add per element: v = z (rstd g) + (e - mean rstd g); the
+        // gate's pre-scaled by -log2(e) for the sigmoid's exp2
+        const float av_ = rs2 * gv[t], bv_ = ev[t] - mu2 * av_;
+        const float ag_ = -1.44269504088896f * rs2 * gg[t], bg_ = -1.44269504088896f * eg[t] - mu2 * ag_;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float zv = fmaf((z[t][r] - mu2) * rs2, gv[t], ev[t]);
-          const float zg = fmaf((z[NTV + t][r] - mu2) * rs2, gg[t], eg[t]);
-          xr[r] = fmaf(sc[t], zv * cld_sigmoid(zg), xr[r]);
+        for (int r = 0; r < 16; r += 2) {
+          const cld_f2 v = cld_f2{z[t][r], z[t][r + 1]} * av_ + bv_, gn = cld_f2{z[NTV + t][r], z[NTV + t][r + 1]} * ag_ + bg_;
+          const cld_f2 den = {1.0f + __builtin_amdgcn_exp2f(fminf(gn[0], 126.0f)), 1.0f + __builtin_amdgcn_exp2f(fminf(gn[1], 126.0f))};
+          const cld_f2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+          const cld_f2 y = (v * sg) * sc[t] + cld_f2{xr[r], xr[r + 1]};
+          xr[r] = y[0]; xr[r + 1] = y[1];
         }
       }
       // all lanes of the wave have read the x rows of tile t's channels (the MFMAs above) before they are overwritten
@@ -964,10 +973,16 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
   }
   const bool hok = l31 < H;
   const float g1 = hok ? d.g1w[l31] : 0.f, e1 = hok ? d.g1b[l31] : 0.f;
-  float a_ds[NTV], a_gwv[NTV], a_gwg[NTV], a_gbv[NTV], a_gbg[NTV], a_g1w = 0.f, a_g1b = 0.f;
+  // element-wise work on register PAIRS (rows r, r + 1 of a tile): see cl_dconv_bwd8_kernel
+  cld_f2 a_ds[NTV], a_gwv[NTV], a_gwg[NTV], a_gbv[NTV], a_gbg[NTV], a_g1w = {0.f, 0.f}, a_g1b = {0.f, 0.f};
+  float ggn[NTV], egn[NTV];
 #pragma unroll
-  for (int t = 0; t < NTV; ++t) a_ds[t] = a_gwv[t] = a_gwg[t] = a_gbv[t] = a_gbg[t] = 0.f;
+  for (int t = 0; t < NTV; ++t) {
+    a_ds[t] = a_gwv[t] = a_gwg[t] = a_gbv[t] = a_gbg[t] = cld_f2{0.f, 0.f};
+    ggn[t] = -1.44269504088896f * gg[t]; egn[t] = -1.44269504088896f * eg[t];
+  }
   const cl_bf16x8 id0 = cld_ident(0, lane), id1 = cld_ident(1, lane);
+  const cl_bf16x8 zfrag = __builtin_bit_cast(cl_bf16x8, make_uint4(0u, 0u, 0u, 0u));
   const int64_t big = 0x7ffffff0;
   const __amdgpu_buffer_rsrc_t rs_g = cl_rsrc(d.gy, (uint32_t)min(big, (int64_t)d.S * CLD_T * RS));
   const __amdgpu_buffer_rsrc_t rs_a = cl_rsrc(d.a, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
@@ -985,7 +1000,8 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
       const float2 mm = *reinterpret_cast<const float2*>(d.sums + (int64_t)smp * 4);
       m1 = mm.x; m2 = mm.y;
     }
-    float s1 = 0.f, s2 = 0.f;
+    cld_f2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
+    const float k1 = -mu1 * rs1;
 #pragma unroll 1
     for (int sub = 0; sub < SUB; ++sub) {
       const int p0 = 64 * wave + 32 * sub;                       // first position of this sub-tile inside the tile
@@ -1028,42 +1044,54 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
           zg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks], cld_ld16(cld_smem + O_W2 + (ks * NT2 + NTV + t) * 1024 + lane * 16), zg, 0, 0, 0);
         }
         unsigned char* zb = zsub + prow * RSZ + (32 * t + l31) * 2;
+        const float kv = (b2v[t] - mu2) * rs2, kg = (b2g[t] - mu2) * rs2;          // zhat = z rstd + k
         if (PASS == 1) {
           f32x16 gy;
 #pragma unroll
           for (int r = 0; r < 16; ++r) gy[r] = 0.f;
-          gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), id0, gy, 0, 0, 0);
-          if (2 * t + 1 < KC) gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), id1, gy, 0, 0, 0);
+          // (gy through the identity with the columns of channels >= C zeroed: exact zeros in those lanes through every sum)
+          gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t) * 32), cok[t] ? id0 : zfrag, gy, 0, 0, 0);
+          if (2 * t + 1 < KC) gy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(grow + (2 * t + 1) * 32), cok[t] ? id1 : zfrag, gy, 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
-            const float v = fmaf(zhv, gv[t], ev[t]), gt = fmaf(zhg, gg[t], eg[t]);
-            const float sg = cld_sigmoid(gt);
-            const float gyr = cok[t] ? gy[r] : 0.f;
-            a_ds[t] = fmaf(gyr, v * sg, a_ds[t]);
-            const float dg = gyr * sc[t];
-            const float dv = dg * sg, dgt = dg * v * sg * (1.f - sg);
-            a_gbv[t] += dv;  a_gwv[t] = fmaf(dv, zhv, a_gwv[t]);
-            a_gbg[t] += dgt; a_gwg[t] = fmaf(dgt, zhg, a_gwg[t]);
-            const uint32_t pk = rfx_cvt_pk_bf16(dv * gv[t], dgt * gg[t]);
-            const float dzv = __uint_as_float(pk << 16), dzg = __uint_as_float(pk & 0xffff0000u);
-            s1 += dzv + dzg;
-            s2 = fmaf(dzv, zhv, fmaf(dzg, zhg, s2));
+          for (int r = 0; r < 16; r += 2) {
+            const cld_f2 z_v = {zv[r], zv[r + 1]}, z_g = {zg[r], zg[r + 1]}, g2 = {gy[r], gy[r + 1]};
+            const cld_f2 zhv = z_v * rs2 + kv, zhg = z_g * rs2 + kg;
+            const cld_f2 v = zhv * gv[t] + ev[t], gn = zhg * ggn[t] + egn[t];
+            const cld_f2 den = {1.0f + __builtin_amdgcn_exp2f(fminf(gn[0], 126.0f)), 1.0f + __builtin_amdgcn_exp2f(fminf(gn[1], 126.0f))};
+            const cld_f2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+            a_ds[t] += g2 * (v * sg);
+            const cld_f2 dv = (g2 * sc[t]) * sg, dgt = (dv * v) * (1.0f - sg);
+            a_gbv[t] += dv;  a_gwv[t] += dv * zhv;
+            a_gbg[t] += dgt; a_gwg[t] += dgt * zhg;
+            const cld_f2 pv = dv * gv[t], pg = dgt * gg[t];
+            const uint32_t pk0 = rfx_cvt_pk_bf16(pv[0], pg[0]), pk1 = rfx_cvt_pk_bf16(pv[1], pg[1]);
+            const cld_f2 dzv = {__uint_as_float(pk0 << 16), __uint_as_float(pk1 << 16)}, dzg = {__uint_as_float(pk0 & 0xffff0000u), __uint_as_float(pk1 & 0xffff0000u)};
+            s1p += dzv + dzg;
+            s2p += dzv * zhv + dzg * zhg;
             if (cok[t]) {
               const int ro = ((r & 3) + 8 * (r >> 2)) * RSZ;
-              *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)pk;
-              *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)(pk >> 16);
+              *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)pk0;
+              *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)(pk0 >> 16);
+              *reinterpret_cast<uint16_t*>(zb + ro + RSZ) = (uint16_t)pk1;
+              *reinterpret_cast<uint16_t*>(zb + ro + RSZ + 2 * C) = (uint16_t)(pk1 >> 16);
             }
           }
         } else if (cok[t]) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int r = 0; r < 16; r += 2) {
             const int ro = ((r & 3) + 8 * (r >> 2)) * RSZ;
-            const float zhv = (zv[r] + b2v[t] - mu2) * rs2, zhg = (zg[r] + b2g[t] - mu2) * rs2;
-            const float dzv = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro) << 16);
-            const float dzg = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + 2 * C) << 16);
-            *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)rfx_bf16_bits(rs2 * (dzv - m1 - zhv * m2));
-            *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)rfx_bf16_bits(rs2 * (dzg - m1 - zhg * m2));
+            const cld_f2 z_v = {zv[r], zv[r + 1]}, z_g = {zg[r], zg[r + 1]};
+            const cld_f2 zhv = z_v * rs2 + kv, zhg = z_g * rs2 + kg;
+            const cld_f2 dzv = {__uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro) << 16),
+                                __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + RSZ) << 16)};
+            const cld_f2 dzg = {__uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + 2 * C) << 16),
+                                __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(zb + ro + RSZ + 2 * C) << 16)};
+            const cld_f2 ov = ((dzv - m1) - zhv * m2) * rs2, og = ((dzg - m1) - zhg * m2) * rs2;
+            const uint32_t o0 = rfx_cvt_pk_bf16(ov[0], og[0]), o1 = rfx_cvt_pk_bf16(ov[1], og[1]);
+            *reinterpret_cast<uint16_t*>(zb + ro) = (uint16_t)o0;
+            *reinterpret_cast<uint16_t*>(zb + ro + 2 * C) = (uint16_t)(o0 >> 16);
+            *reinterpret_cast<uint16_t*>(zb + ro + RSZ) = (uint16_t)o1;
+            *reinterpret_cast<uint16_t*>(zb + ro + RSZ + 2 * C) = (uint16_t)(o1 >> 16);
           }
         }
       }
@@ -1080,16 +1108,19 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
         if (l31 < HP) {
           unsigned char* hb = dhsub + prow * RSH + l31 * 2;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float hh = (htt[r] - mu1) * rs1;
-            const float dhn = hok ? dat[r] * rfx_gelu_grad(fmaf(hh, g1, e1)) : 0.f;
+          for (int r = 0; r < 16; r += 2) {
+            const cld_f2 h2 = {htt[r], htt[r + 1]}, d2 = {dat[r], dat[r + 1]};
+            const cld_f2 hh = h2 * rs1 + k1;
+            const cld_f2 dhn = hok ? d2 * cld_gelu_grad2(hh * g1 + e1) : cld_f2{0.f, 0.f};
             a_g1b += dhn;
-            a_g1w = fmaf(dhn, hh, a_g1w);
-            const uint32_t pk = rfx_cvt_pk_bf16(dhn * g1, 0.f);                              // d(hhat), parked
-            const float dhh = __uint_as_float(pk << 16);
-            s1 += dhh;
-            s2 = fmaf(dhh, hh, s2);
+            a_g1w += dhn * hh;
+            const cld_f2 dp = dhn * g1;
+            const uint32_t pk = rfx_cvt_pk_bf16(dp[0], dp[1]);                               // d(hhat) of rows r, r + 1, parked
+            const cld_f2 dhh = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+            s1p += dhh;
+            s2p += dhh * hh;
             *reinterpret_cast<uint16_t*>(hb + ((r & 3) + 8 * (r >> 2)) * RSH) = (uint16_t)pk;
+            *reinterpret_cast<uint16_t*>(hb + ((r & 3) + 8 * (r >> 2)) * RSH + RSH) = (uint16_t)(pk >> 16);
           }
         }
       }
@@ -1107,6 +1138,7 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
       }
       CL_LGKM0();
     }
+    float s1 = s1p[0] + s1p[1], s2 = s2p[0] + s2p[1];
     cld_block_sum2<NW>(s1, s2, red, wave, lane);
     if (tid == 0) *reinterpret_cast<float2*>(d.tsum + (int64_t)s * 2) = make_float2(s1, s2);
   }
@@ -1117,14 +1149,14 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
   constexpr int NQ = 5 * NTV + 2;
 #pragma unroll
   for (int t = 0; t < NTV; ++t) {
-    acc[(wave * NQ + 5 * t + 0) * 64 + lane] = a_ds[t];
-    acc[(wave * NQ + 5 * t + 1) * 64 + lane] = a_gwv[t];
-    acc[(wave * NQ + 5 * t + 2) * 64 + lane] = a_gwg[t];
-    acc[(wave * NQ + 5 * t + 3) * 64 + lane] = a_gbv[t];
-    acc[(wave * NQ + 5 * t + 4) * 64 + lane] = a_gbg[t];
+    acc[(wave * NQ + 5 * t + 0) * 64 + lane] = a_ds[t][0] + a_ds[t][1];
+    acc[(wave * NQ + 5 * t + 1) * 64 + lane] = a_gwv[t][0] + a_gwv[t][1];
+    acc[(wave * NQ + 5 * t + 2) * 64 + lane] = a_gwg[t][0] + a_gwg[t][1];
+    acc[(wave * NQ + 5 * t + 3) * 64 + lane] = a_gbv[t][0] + a_gbv[t][1];
+    acc[(wave * NQ + 5 * t + 4) * 64 + lane] = a_gbg[t][0] + a_gbg[t][1];
   }
-  acc[(wave * NQ + 5 * NTV) * 64 + lane] = a_g1w;
-  acc[(wave * NQ + 5 * NTV + 1) * 64 + lane] = a_g1b;
+  acc[(wave * NQ + 5 * NTV) * 64 + lane] = a_g1w[0] + a_g1w[1];
+  acc[(wave * NQ + 5 * NTV + 1) * 64 + lane] = a_g1b[0] + a_g1b[1];
   __syncthreads();
   float* prow_out = d.partial + (int64_t)blockIdx.x * (5 * C + 2 * H);
   const int i_lo = PASS == 1 ? 0 : 5 * C, i_hi = PASS == 1 ? 5 * C : 5 * C + 2 * H;
