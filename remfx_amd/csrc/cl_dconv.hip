@@ -344,9 +344,11 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
 // Backward.  Per-lane parameter-gradient sums (lane = channel): LayerScale, GroupNorm-2 weight / bias (value and gate rows),
 // GroupNorm-1 weight / bias; written per workgroup to `partial` ([gridDim.x][5 C + 2 H]: dscale | dgn2w | dgn2b | dgn1w | dgn1b)
 // and added over workgroups in a fixed order by the second launch of rfx_cl_dconv_bwd.
-// FOUR waves per workgroup, one per SIMD, each walking its 64 positions as two 32-position tiles: with eight waves (256 registers
-// each) the compiler spilled 104 registers and the waves sat parked on scratch reloads 80 % of their cycles (4.98 ms per launch at
-// S = 32768, r05 SQ counters); one wave per SIMD has the whole 512-register file, what does not fit the 256 VGPRs goes to AGPRs.
+// FOUR waves per workgroup, one per SIMD, each walking its 64 positions as two 32-position tiles: with eight waves of the SAME work
+// split (256 registers each) the compiler spilled 104 registers and the waves sat parked on scratch reloads 80 % of their cycles
+// (4.98 ms per launch at S = 32768, r05 SQ counters); one wave per SIMD has the whole 512-register file, what does not fit the 256
+// VGPRs goes to AGPRs.  Round 6: kept as the reference form (RFX_DEV=1 RFX_CLD_BWD_NW=4) -- C = 48 runs cl_dconv_bwd8_kernel below,
+// eight waves with the channel tiles split over wave pairs (2.49 -> 1.53 ms per launch).
 template <int C, int H>
 __global__ __launch_bounds__(256, 1) void cl_dconv_bwd_kernel(const ClDconvK g) {
   using Cfg = CldCfg<C, H>;
@@ -1293,7 +1295,8 @@ static int cld_launch(const rfx_cl_dconv_desc& d, bool bwd, hipStream_t st) {
   ClDconvK k;
   k.d = d;
   if constexpr (Cfg::NTV == 2) {
-    static const bool four = [] { const char* e = getenv("RFX_CLD_BWD_NW"); return e && atoi(e) == 4; }();       // dev A/B
+    // dev A/B (honoured only under RFX_DEV=1): the four-wave form of round 5
+    static const bool four = [] { const char* dv = getenv("RFX_DEV"); const char* e = getenv("RFX_CLD_BWD_NW"); return dv && atoi(dv) == 1 && e && atoi(e) == 4; }();
     static bool attr8 = false;
     constexpr int lds8 = Cfg::B_LDS + CLD_T * Cfg::RS;          // + the second gy image
     static_assert(lds8 <= 160 * 1024, "");
