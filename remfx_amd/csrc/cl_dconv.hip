@@ -90,19 +90,25 @@ __device__ __forceinline__ void cld_block_sum2(float& a, float& b, float* red, i
 }
 
 typedef float cld_f2 __attribute__((ext_vector_type(2)));
-// GELU'(x) on a register pair (rfx_gelu_parts' polynomial; raw v_exp_f32 on a clamped argument)
-__device__ __forceinline__ cld_f2 cld_gelu_grad2(cld_f2 x) {
+// erf-GELU on a register pair: cdf and exp(-x^2 / 2) as in rfx_gelu_parts (Abramowitz-Stegun 7.1.26), packed
+__device__ __forceinline__ void cld_gelu_parts2(cld_f2 x, cld_f2& cdf, cld_f2& ex) {
   const cld_f2 ax = {fabsf(x[0]), fabsf(x[1])};
   const cld_f2 q = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
   const cld_f2 t = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
   const cld_f2 xx = x * x * (-0.5f * 1.44269504088896f);
-  const cld_f2 ex = {__builtin_amdgcn_exp2f(fmaxf(xx[0], -126.0f)), __builtin_amdgcn_exp2f(fmaxf(xx[1], -126.0f))};
+  ex = cld_f2{__builtin_amdgcn_exp2f(fmaxf(xx[0], -126.0f)), __builtin_amdgcn_exp2f(fmaxf(xx[1], -126.0f))};
   cld_f2 p = t * 1.061405429f + -1.453152027f;
   p = p * t + 1.421413741f;
   p = p * t + -0.284496736f;
   p = p * t + 0.254829592f;
   const cld_f2 e = 1.0f - (p * t) * ex;                  // erf(|x| / sqrt2)
-  const cld_f2 cdf = {0.5f + copysignf(0.5f * e[0], x[0]), 0.5f + copysignf(0.5f * e[1], x[1])};
+  cdf = cld_f2{0.5f + copysignf(0.5f * e[0], x[0]), 0.5f + copysignf(0.5f * e[1], x[1])};
+}
+__device__ __forceinline__ cld_f2 cld_gelu2(cld_f2 x) { cld_f2 c, e; cld_gelu_parts2(x, c, e); return x * c; }
+// GELU'(x) on a register pair
+__device__ __forceinline__ cld_f2 cld_gelu_grad2(cld_f2 x) {
+  cld_f2 cdf, ex;
+  cld_gelu_parts2(x, cdf, ex);
   return (x * 0.39894228040143267794f) * ex + cdf;
 }
 // workgroup barrier that leaves this wave's VMEM operations (LDS-DMA pieces, output stores) in flight: __syncthreads() fences and
@@ -220,12 +226,17 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
         hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, hacc, 0, 0, 0);
       }
     float hv[RH];
-    float s1 = 0.f, s2 = 0.f;
+    float s1, s2;
+    {
+      cld_f2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < RH; ++r) {
-      hv[r] = hacc[r] + b1r[r];
-      s1 += hv[r];
-      s2 = fmaf(hv[r], hv[r], s2);
+      for (int r = 0; r < RH; r += 2) {
+        const cld_f2 h2 = cld_f2{hacc[r], hacc[r + 1]} + cld_f2{b1r[r], b1r[r + 1]};
+        hv[r] = h2[0]; hv[r + 1] = h2[1];
+        s1p += h2;
+        s2p += h2 * h2;
+      }
+      s1 = s1p[0] + s1p[1]; s2 = s2p[0] + s2p[1];
     }
     float mu1, rs1;
     if (PH == 0) {
@@ -242,8 +253,16 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
       __syncthreads();                               // the neighbours' tap reads of this wave's rows are done before they are overwritten
     }
     float av[RH];
+    {
+      const float k1 = -mu1 * rs1;
 #pragma unroll
-    for (int r = 0; r < RH; ++r) av[r] = cld_bf16r(rfx_gelu(fmaf((hv[r] - mu1) * rs1, g1r[r], e1r[r])));
+      for (int r = 0; r < RH; r += 2) {
+        const cld_f2 hh = cld_f2{hv[r], hv[r + 1]} * rs1 + k1;
+        const cld_f2 a2 = cld_gelu2(hh * cld_f2{g1r[r], g1r[r + 1]} + cld_f2{e1r[r], e1r[r + 1]});
+        const uint32_t pk = rfx_cvt_pk_bf16(a2[0], a2[1]);       // the bf16 values GEMM2 multiplies (and the backward pass reads)
+        av[r] = __uint_as_float(pk << 16); av[r + 1] = __uint_as_float(pk & 0xffff0000u);
+      }
+    }
     if (train && PH != 2) {
       // [pos][HP]: registers 4 q .. 4 q + 3 are rows 8 q + 4 half + 0..3 = 8 consecutive bytes
       uint16_t* ap = reinterpret_cast<uint16_t*>(d.a) + ((int64_t)s * CLD_T + p0 + l31) * HP + 4 * half;
