@@ -143,6 +143,19 @@ __device__ __forceinline__ void cld_wait_vm() {
   else CL_VMCNT(16);
 }
 
+// the same with ONE raw barrier (s_barrier + lgkmcnt(0): VMEM operations stay in flight); `red` = 16 floats that no wave writes again
+// before another workgroup barrier has passed
+__device__ __forceinline__ void cld_block_sum2_raw(float& a, float& b, float* red, int wave, int lane) {
+  a = rfx_wave_sum(a);
+  b = rfx_wave_sum(b);
+  if (lane == 0) { red[wave] = a; red[8 + wave] = b; }
+  CLD_BARRIER();
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) { sa += red[w]; sb += red[8 + w]; }
+  a = sa; b = sb;
+}
+
 // PH: 0 = a sample is one 256-position tile, statistics inside the kernel (the frequency branch); 1 / 2 / 3 = a sample is TPS
 // consecutive tiles (the time branch: a whole clip), GroupNorm statistics span all of them: pass 1 leaves the tile sums of h, pass 2
 // (statistics 1 given) those of z, pass 3 (both given) finishes -- each pass recomputes the cheap front of the layer from x
@@ -155,6 +168,10 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
   const rfx_cl_dconv_desc& d = g.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  // PF (one-tile samples): two x images -- the next sample's rows arrive by untracked LDS-DMA while this one is worked on (section
+  // 4.13 of DESIGN.md: with the builtin the compiler drains the DMA at the first LDS read it cannot prove disjoint); all in-loop
+  // barriers are raw then, __syncthreads() would drain it too
+  constexpr bool PF = PH == 0;
   unsigned char* ximg = cld_smem;
   float* red = reinterpret_cast<float*>(cld_smem + Cfg::F_RED);
   const bool train = d.a != nullptr;
@@ -165,6 +182,10 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
   for (int o = tid * 4; o < CLD_HALO * RS; o += 512 * 4) {
     *reinterpret_cast<uint32_t*>(ximg + o) = 0u;
     *reinterpret_cast<uint32_t*>(ximg + (CLD_T + CLD_HALO) * RS + o) = 0u;
+    if (PF) {
+      *reinterpret_cast<uint32_t*>(cld_smem + Cfg::F_LDS + o) = 0u;
+      *reinterpret_cast<uint32_t*>(cld_smem + Cfg::F_LDS + (CLD_T + CLD_HALO) * RS + o) = 0u;
+    }
   }
   // per-register parameters of the h tile (row h = (r & 3) + 8 (r >> 2) + 4 half), zero beyond H: padded rows stay exactly 0
   float b1r[RH], g1r[RH], e1r[RH];
@@ -191,15 +212,39 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
   const int p0 = 32 * wave;
   const unsigned char* xrow = ximg + (CLD_HALO + p0 + l31) * RS + 16 * half;          // this lane's position, channel half 8 * half
   const __amdgpu_buffer_rsrc_t rs_x = cl_rsrc(d.x, (uint32_t)min((int64_t)0x7ffffff0, (int64_t)d.S * CLD_T * RS));
+  const cld_i32x4 rs_xq = cld_rsrc_words(d.x, (uint32_t)min((int64_t)0x7ffffff0, (int64_t)d.S * CLD_T * RS));
   const float n1 = 1.0f / (H * CLD_T), n2 = 1.0f / (2 * C * CLD_T);
+  if (PF && (int)blockIdx.x < d.S) {
+    const uint32_t sb0 = (uint32_t)blockIdx.x * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) cld_glds16_quiet(rs_xq, ximg + (CLD_HALO + p0) * RS + i * 1024, sb0 + i * 1024);
+    CL_VMCNT(0);
+  }
   __syncthreads();
 
-  for (int s = blockIdx.x; s < d.S; s += gridDim.x) {
+  int it = 0;
+  for (int s = blockIdx.x; s < d.S; s += gridDim.x, ++it) {
     CLD_NO_HOIST();
+    if (PF) {
+      ximg = (it & 1) ? cld_smem + Cfg::F_LDS : cld_smem;
+      xrow = ximg + (CLD_HALO + p0 + l31) * RS + 16 * half;
+      // everything older than the previous sample's KC output stores of this wave (its newest operations): this sample's DMA pieces
+      cld_wait_vm<KC>();
+      CLD_BARRIER();                                            // the taps read the neighbouring waves' rows
+      const int sn = s + (int)gridDim.x;
+      if (sn < d.S) {
+        unsigned char* xnext = (it & 1) ? cld_smem : cld_smem + Cfg::F_LDS;    // its rows: last read by this wave's own stores, two samples ago
+        const uint32_t sbn = (uint32_t)sn * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+#pragma unroll
+        for (int i = 0; i < KC; ++i) cld_glds16_quiet(rs_xq, xnext + (CLD_HALO + p0) * RS + i * 1024, sbn + i * 1024);
+      }
+    }
     // ---- this wave's rows of the sample: KC pieces of 1 KiB, contiguous in memory and in the image
     const uint32_t sbase = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+    if (!PF) {
 #pragma unroll
-    for (int i = 0; i < KC; ++i) cl_glds16(rs_x, ximg + (CLD_HALO + p0) * RS + i * 1024, sbase + i * 1024);
+      for (int i = 0; i < KC; ++i) cl_glds16(rs_x, ximg + (CLD_HALO + p0) * RS + i * 1024, sbase + i * 1024);
+    }
     if (PH != 0 && (wave == 0 || wave == 7) && lane < CLD_HALO * RS / 16) {
       // halo rows: the neighbouring tile's edge rows inside a sample, zeros at the sample's ends
       const int tile = s % d.TPS;
@@ -211,8 +256,10 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
                                             (left ? -(int64_t)CLD_HALO * RS : (int64_t)CLD_T * RS) + lane * 16);
       *reinterpret_cast<uint4*>(ximg + (left ? 0 : (CLD_T + CLD_HALO) * RS) + lane * 16) = v;
     }
-    CL_VMCNT(0);
-    __syncthreads();
+    if (!PF) {
+      CL_VMCNT(0);
+      __syncthreads();
+    }
     // ---- GEMM1
     f32x16 hacc;
 #pragma unroll
@@ -240,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
     }
     float mu1, rs1;
     if (PH == 0) {
-      cld_block_sum2(s1, s2, red, wave, lane);
+      cld_block_sum2_raw(s1, s2, red, wave, lane);
       mu1 = s1 * n1;
       rs1 = rsqrtf(fmaxf(s2 * n1 - mu1 * mu1, 0.f) + d.eps);
     } else if (PH == 1) {
@@ -303,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
     }
     float mu2, rs2;
     if (PH == 0) {
-      cld_block_sum2(s1, s2, red, wave, lane);
+      cld_block_sum2_raw(s1, s2, red + 16, wave, lane);
       mu2 = s1 * n2;
       rs2 = rsqrtf(fmaxf(s2 * n2 - mu2 * mu2, 0.f) + d.eps);
       if (train && tid == 0) *reinterpret_cast<float4*>(d.stats + (int64_t)s * 4) = make_float4(mu1, rs1, mu2, rs2);
@@ -1274,16 +1321,17 @@ __global__ __launch_bounds__(256) void cl_dconv_stats_kernel(const float* __rest
 template <int C, int H, int PH>
 static int cld_launch_fwd(const rfx_cl_dconv_desc& d, hipStream_t st) {
   using Cfg = CldCfg<C, H>;
+  constexpr int lds = Cfg::F_LDS + (PH == 0 ? Cfg::XIMG : 0);     // one-tile samples: a second x image for the prefetch
+  static_assert(lds <= 160 * 1024, "");
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_dconv_fwd_kernel<C, H, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::F_LDS) !=
-        hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cl_dconv_fwd_kernel<C, H, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -3;
     attr = true;
   }
   ClDconvK k;
   k.d = d;
-  hipLaunchKernelGGL((cl_dconv_fwd_kernel<C, H, PH>), dim3(d.S < d.grid ? d.S : d.grid), dim3(512), Cfg::F_LDS, st, k);
+  hipLaunchKernelGGL((cl_dconv_fwd_kernel<C, H, PH>), dim3(d.S < d.grid ? d.S : d.grid), dim3(512), lds, st, k);
   RFX_CHECK_LAUNCH();
   return 0;
 }
