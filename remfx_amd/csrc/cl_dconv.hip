@@ -145,6 +145,7 @@ __device__ __forceinline__ void cld_wait_vm() {
 
 // the same with ONE raw barrier (s_barrier + lgkmcnt(0): VMEM operations stay in flight); `red` = 16 floats that no wave writes again
 // before another workgroup barrier has passed
+template <int NW = 8>
 __device__ __forceinline__ void cld_block_sum2_raw(float& a, float& b, float* red, int wave, int lane) {
   a = rfx_wave_sum(a);
   b = rfx_wave_sum(b);
@@ -152,7 +153,7 @@ __device__ __forceinline__ void cld_block_sum2_raw(float& a, float& b, float* re
   CLD_BARRIER();
   float sa = 0.f, sb = 0.f;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) { sa += red[w]; sb += red[8 + w]; }
+  for (int w = 0; w < NW; ++w) { sa += red[w]; sb += red[8 + w]; }
   a = sa; b = sb;
 }
 
@@ -1003,6 +1004,18 @@ __global__ __launch_bounds__(512, 1) void cl_dconv_bwd8_kernel(const ClDconvK g)
   }
 }
 
+// per-wave LDS staging of the multi-pass backward kernel (cl_dconv_bwdp_kernel), by pass
+template <int C, int H, int PASS>
+struct CldPassLds {
+  using Cfg = CldCfg<C, H>;
+  static constexpr int RS = Cfg::RS, RSH = Cfg::RSH, RSZ = Cfg::RSZ;
+  // pass 1: gy x 2 | a x 2 | z          pass 2: a | h | dh | z x 2
+  static constexpr int O_G = 0, O_A = PASS == 1 ? 2 * 32 * RS : 0, O_H = O_A + 32 * RSH, O_DH = O_H + 32 * RSH;
+  static constexpr int O_Z = PASS == 1 ? O_A + 2 * 32 * RSH : O_DH + 32 * RSH;
+  static constexpr int WV = O_Z + (PASS == 1 ? 1 : 2) * 32 * RSZ;
+  static constexpr int LDS = 4 * WV + Cfg::KH * Cfg::NT2 * 1024 + (PASS == 2 ? (2 * C / 16) * 1024 : 0) + 512;
+};
+
 // ---- backward in passes, for samples of several tiles (the time branch) and for widths whose single-pass images do not fit the LDS
 // (C = 96).  Everything a pass needs from another tile is a per-sample scalar, reduced between the passes in a fixed order:
 //   B1  z recomputed from a; GLU / LayerScale / GroupNorm-2 backward up to d(zhat); d(zhat) PARKED in the dz tensor (bf16); tile sums
@@ -1016,15 +1029,19 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
   using Cfg = CldCfg<C, H>;
   constexpr int HP = Cfg::HP, KC = Cfg::KC, KH = Cfg::KH, NTV = Cfg::NTV, NT2 = Cfg::NT2, RS = Cfg::RS, RSH = Cfg::RSH, RSZ = Cfg::RSZ;
   constexpr int KZ = 2 * C / 16, NW = 4, SUB = 2;
-  // LDS: per wave [gy sub-tile 32 RS | a sub-tile 32 RSH | h sub-tile 32 RSH | z sub-tile 32 RSZ | dh sub-tile 32 RSH], then the fragments
-  constexpr int WV = 32 * (RS + 3 * RSH + RSZ), O_A = 32 * RS, O_H = O_A + 32 * RSH, O_Z = O_H + 32 * RSH, O_DH = O_Z + 32 * RSZ;
-  constexpr int O_W2 = NW * WV, O_W2D = O_W2 + KH * NT2 * 1024, O_RED = O_W2D + KZ * 1024;
+  // LDS per wave -- pass 1: [gy sub-tile 32 RS] x 2 | [a sub-tile 32 RSH] x 2 | z sub-tile 32 RSZ (output)
+  //                 pass 2: a | h | dh sub-tiles 32 RSH each | [z sub-tile 32 RSZ] x 2 (read, finalised in place, stored)
+  // then the fragments.  The doubled buffers hold the NEXT sub-tile's operands: a wave is alone on its SIMD here (C = 96: the staging
+  // of four waves fills the LDS; C = 48: 396 registers), so every DMA round trip it waits for is exposed -- 40 % of a 4 us sub-tile.
+  // The pieces are issued by asm the compiler does not track and waited for with counted vmcnt.
+  using L = CldPassLds<C, H, PASS>;
+  constexpr int WV = L::WV, O_W2 = NW * WV, O_W2D = O_W2 + KH * NT2 * 1024, O_RED = O_W2D + (PASS == 2 ? KZ * 1024 : 0);
   extern __shared__ __attribute__((aligned(16))) unsigned char cld_smem[];
   const rfx_cl_dconv_desc& d = g.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   unsigned char* wv = cld_smem + wave * WV;
-  unsigned char* gsub = wv, *asub = wv + O_A, *hsub = wv + O_H, *zsub = wv + O_Z, *dhsub = wv + O_DH;
+  unsigned char* const hsub = wv + L::O_H, *const dhsub = wv + L::O_DH;      // pass 2 only
   float* red = reinterpret_cast<float*>(cld_smem + O_RED);
   cld_copy_in(cld_smem + O_W2, d.w2p, KH * NT2 * 1024, tid, 256);
   if (PASS == 2) cld_copy_in(cld_smem + O_W2D, d.w2dp, KZ * 1024, tid, 256);
@@ -1052,21 +1069,61 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
   const cl_bf16x8 id0 = cld_ident(0, lane), id1 = cld_ident(1, lane);
   const cl_bf16x8 zfrag = __builtin_bit_cast(cl_bf16x8, make_uint4(0u, 0u, 0u, 0u));
   const int64_t big = 0x7ffffff0;
-  const __amdgpu_buffer_rsrc_t rs_g = cl_rsrc(d.gy, (uint32_t)min(big, (int64_t)d.S * CLD_T * RS));
-  const __amdgpu_buffer_rsrc_t rs_a = cl_rsrc(d.a, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
-  const __amdgpu_buffer_rsrc_t rs_h = cl_rsrc(d.hpre, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
-  const __amdgpu_buffer_rsrc_t rs_z = cl_rsrc(d.dz, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSZ));
+  const cld_i32x4 rs_g = cld_rsrc_words(d.gy, (uint32_t)min(big, (int64_t)d.S * CLD_T * RS));
+  const cld_i32x4 rs_a = cld_rsrc_words(d.a, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
+  const cld_i32x4 rs_h = cld_rsrc_words(d.hpre, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSH));
+  const cld_i32x4 rs_z = cld_rsrc_words(d.dz, (uint32_t)min(big, (int64_t)d.S * CLD_T * RSZ));
+  // operands of sub-tile `sub` of tile `s` (this wave's 32 positions), by kind; `par` = which of the doubled buffers
+  auto fetch_a = [&](int s, int sub, int par) {
+    const uint32_t hb = (uint32_t)s * (CLD_T * RSH) + (uint32_t)(64 * wave + 32 * sub) * RSH + lane * 16;
+    unsigned char* dst = wv + L::O_A + (PASS == 1 ? par * 32 * RSH : 0);
+#pragma unroll
+    for (int i = 0; i < KH; ++i) cld_glds16_quiet(rs_a, dst + i * 1024, hb + i * 1024);
+  };
+  auto fetch_g = [&](int s, int sub, int par) {
+    const uint32_t gb = (uint32_t)s * (CLD_T * RS) + (uint32_t)(64 * wave + 32 * sub) * RS + lane * 16;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) cld_glds16_quiet(rs_g, wv + L::O_G + par * 32 * RS + i * 1024, gb + i * 1024);
+  };
+  auto fetch_h = [&](int s, int sub) {
+    const uint32_t hb = (uint32_t)s * (CLD_T * RSH) + (uint32_t)(64 * wave + 32 * sub) * RSH + lane * 16;
+#pragma unroll
+    for (int i = 0; i < KH; ++i) cld_glds16_quiet(rs_h, hsub + i * 1024, hb + i * 1024);
+  };
+  auto fetch_z = [&](int s, int sub, int par) {
+    const uint32_t zb = (uint32_t)s * (CLD_T * RSZ) + (uint32_t)(64 * wave + 32 * sub) * RSZ + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 2 * KC; ++i) cld_glds16_quiet(rs_z, wv + L::O_Z + par * 32 * RSZ + i * 1024, zb + i * 1024);
+  };
+  // per-sample scalars travel one TILE ahead (loaded while the previous tile is worked on: the wait the compiler puts in front of their
+  // first use then only reaches operations that are a tile old)
+  auto load_st = [&](int s) { return *reinterpret_cast<const float4*>(d.stats + (int64_t)(s / d.TPS) * 4); };
+  auto load_mm = [&](int s) { return *reinterpret_cast<const float2*>(d.sums + (int64_t)(s / d.TPS) * 4); };
+  float4 st_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 mm_nx = make_float2(0.f, 0.f);
+  if ((int)blockIdx.x < d.S) {
+    st_nx = load_st(blockIdx.x);
+    if (PASS == 2) mm_nx = load_mm(blockIdx.x);
+    fetch_a(blockIdx.x, 0, 0);
+    if (PASS == 1) fetch_g(blockIdx.x, 0, 0);
+    else { fetch_h(blockIdx.x, 0); fetch_z(blockIdx.x, 0, 0); }
+  }
+  CL_VMCNT(0);
   __syncthreads();
+  // global stores of one sub-tile, this wave: the newest operations in its queue when the next sub-tile starts
+  constexpr int NSTORE = 2 * KC + (PASS == 2 ? KH : 0);
+  unsigned parity = 0;                                             // the block sums of consecutive tiles alternate between two scratch rows
 
   for (int s = blockIdx.x; s < d.S; s += gridDim.x) {
     CLD_NO_HOIST();
-    const int smp = s / d.TPS;
-    const float4 st = *reinterpret_cast<const float4*>(d.stats + (int64_t)smp * 4);
+    const float4 st = st_nx;
     const float mu1 = st.x, rs1 = st.y, mu2 = st.z, rs2 = st.w;
-    float m1 = 0.f, m2 = 0.f;
-    if (PASS == 2) {
-      const float2 mm = *reinterpret_cast<const float2*>(d.sums + (int64_t)smp * 4);
-      m1 = mm.x; m2 = mm.y;
+    const float m1 = mm_nx.x, m2 = mm_nx.y;
+    const int s_nx = s + (int)gridDim.x;
+    const bool more_tiles = s_nx < d.S;
+    if (more_tiles) {
+      st_nx = load_st(s_nx);
+      if (PASS == 2) mm_nx = load_mm(s_nx);
     }
     cld_f2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
     const float k1 = -mu1 * rs1;
@@ -1074,31 +1131,28 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
     for (int sub = 0; sub < SUB; ++sub) {
       const int p0 = 64 * wave + 32 * sub;                       // first position of this sub-tile inside the tile
       const int prow = 4 * half;                                 // its rows inside the per-wave staging buffers
-      // ---- loads of this sub-tile (own rows only)
-      {
-        const uint32_t hb = (uint32_t)s * (CLD_T * RSH) + (uint32_t)p0 * RSH + lane * 16;
-#pragma unroll
-        for (int i = 0; i < KH; ++i) cl_glds16(rs_a, asub + i * 1024, hb + i * 1024);
-        if (PASS == 1) {
-          const uint32_t gb = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
-#pragma unroll
-          for (int i = 0; i < KC; ++i) cl_glds16(rs_g, gsub + i * 1024, gb + i * 1024);
-        } else {
-#pragma unroll
-          for (int i = 0; i < KH; ++i) cl_glds16(rs_h, hsub + i * 1024, hb + i * 1024);
-          const uint32_t zb = (uint32_t)s * (CLD_T * RSZ) + (uint32_t)p0 * RSZ + lane * 16;
-#pragma unroll
-          for (int i = 0; i < 2 * KC; ++i) cl_glds16(rs_z, zsub + i * 1024, zb + i * 1024);
-        }
-      }
-      CL_VMCNT(0);
+      // this sub-tile's operands: everything older than the previous sub-tile's stores (and whatever else came after them)
+      cld_wait_vm<NSTORE>();
       __builtin_amdgcn_wave_barrier();
+      const int nsub = sub ^ 1, ns = sub == 0 ? s : s_nx;        // the next sub-tile of this wave
+      const bool more = sub == 0 || more_tiles;
+      unsigned char* const asub = wv + L::O_A + (PASS == 1 ? sub * 32 * RSH : 0);
+      unsigned char* const gsub = wv + L::O_G + sub * 32 * RS;                   // pass 1 only
+      unsigned char* const zsub = wv + L::O_Z + (PASS == 2 ? sub * 32 * RSZ : 0);
+      if (more) {
+        if (PASS == 1) { fetch_a(ns, nsub, nsub); fetch_g(ns, nsub, nsub); }
+        else fetch_z(ns, nsub, nsub);
+      }
       cl_bf16x8 afr[KH];
 #pragma unroll
       for (int ks = 0; ks < KH; ++ks) {
         const unsigned char* ar = asub + l31 * RSH + (16 * ks + 4 * half) * 2;
         const uint2 lo = *reinterpret_cast<const uint2*>(ar), hi = *reinterpret_cast<const uint2*>(ar + 16);
         afr[ks] = __builtin_bit_cast(cl_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
+      if (PASS == 2 && more) {
+        CL_LGKM0();                                                // the fragments of a are in registers: its buffer is free
+        fetch_a(ns, nsub, 0);
       }
       const unsigned char* grow = gsub + l31 * RS + 16 * half;
 #pragma unroll
@@ -1173,6 +1227,10 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
                                                          cld_ld16(cld_smem + O_W2D + kz * 1024 + lane * 16), dat, 0, 0, 0);
         htt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(hsub + l31 * RSH + 16 * half), id0, htt, 0, 0, 0);
         if (KH > 1) htt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cld_ld16(hsub + l31 * RSH + 32 + 16 * half), id1, htt, 0, 0, 0);
+        if (more) {
+          CL_LGKM0();                                              // the MFMA operands above are in registers: the h buffer is free
+          fetch_h(ns, nsub);
+        }
         if (l31 < HP) {
           unsigned char* hb = dhsub + prow * RSH + l31 * 2;
 #pragma unroll
@@ -1207,7 +1265,7 @@ __global__ __launch_bounds__(256, 1) void cl_dconv_bwdp_kernel(const ClDconvK g)
       CL_LGKM0();
     }
     float s1 = s1p[0] + s1p[1], s2 = s2p[0] + s2p[1];
-    cld_block_sum2<NW>(s1, s2, red, wave, lane);
+    cld_block_sum2_raw<NW>(s1, s2, red + 16 * (int)(parity ^= 1), wave, lane);
     if (tid == 0) *reinterpret_cast<float2*>(d.tsum + (int64_t)s * 2) = make_float2(s1, s2);
   }
 
@@ -1408,7 +1466,7 @@ extern "C" int rfx_cl_dconv_fwd(const rfx_cl_dconv_desc* dp, void* stream) {
 template <int C, int H, int PASS>
 static int cld_launch_bwdp(const rfx_cl_dconv_desc& d, hipStream_t st) {
   using Cfg = CldCfg<C, H>;
-  constexpr int lds = 4 * 32 * (Cfg::RS + 3 * Cfg::RSH + Cfg::RSZ) + Cfg::KH * Cfg::NT2 * 1024 + (2 * C / 16) * 1024 + 512;
+  constexpr int lds = CldPassLds<C, H, PASS>::LDS;
   static_assert(lds <= 160 * 1024 && lds >= 4 * (5 * Cfg::NTV + 2) * 256, "");
   static bool attr = false;
   if (!attr) {
