@@ -169,10 +169,10 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
   const rfx_cl_dconv_desc& d = g.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-  // PF (one-tile samples): two x images -- the next sample's rows arrive by untracked LDS-DMA while this one is worked on (section
-  // 4.13 of DESIGN.md: with the builtin the compiler drains the DMA at the first LDS read it cannot prove disjoint); all in-loop
-  // barriers are raw then, __syncthreads() would drain it too
-  constexpr bool PF = PH == 0;
+  // two x images: the next tile's rows arrive by untracked LDS-DMA while this one is worked on (section 4.13 of DESIGN.md: with the
+  // builtin the compiler drains the DMA at the first LDS read it cannot prove disjoint); all in-loop barriers are raw, __syncthreads()
+  // would drain it too
+  constexpr int NVM = (PH == 0 || PH == 3) ? KC : 0;          // this wave's stores that are certain to follow a prefetch (the y rows)
   unsigned char* ximg = cld_smem;
   float* red = reinterpret_cast<float*>(cld_smem + Cfg::F_RED);
   const bool train = d.a != nullptr;
@@ -183,10 +183,8 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
   for (int o = tid * 4; o < CLD_HALO * RS; o += 512 * 4) {
     *reinterpret_cast<uint32_t*>(ximg + o) = 0u;
     *reinterpret_cast<uint32_t*>(ximg + (CLD_T + CLD_HALO) * RS + o) = 0u;
-    if (PF) {
-      *reinterpret_cast<uint32_t*>(cld_smem + Cfg::F_LDS + o) = 0u;
-      *reinterpret_cast<uint32_t*>(cld_smem + Cfg::F_LDS + (CLD_T + CLD_HALO) * RS + o) = 0u;
-    }
+    *reinterpret_cast<uint32_t*>(cld_smem + Cfg::F_LDS + o) = 0u;
+    *reinterpret_cast<uint32_t*>(cld_smem + Cfg::F_LDS + (CLD_T + CLD_HALO) * RS + o) = 0u;
   }
   // per-register parameters of the h tile (row h = (r & 3) + 8 (r >> 2) + 4 half), zero beyond H: padded rows stay exactly 0
   float b1r[RH], g1r[RH], e1r[RH];
@@ -212,11 +210,31 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
   const cl_bf16x8 id0 = cld_ident(0, lane), id1 = cld_ident(1, lane);
   const int p0 = 32 * wave;
   const unsigned char* xrow = ximg + (CLD_HALO + p0 + l31) * RS + 16 * half;          // this lane's position, channel half 8 * half
-  const __amdgpu_buffer_rsrc_t rs_x = cl_rsrc(d.x, (uint32_t)min((int64_t)0x7ffffff0, (int64_t)d.S * CLD_T * RS));
   const cld_i32x4 rs_xq = cld_rsrc_words(d.x, (uint32_t)min((int64_t)0x7ffffff0, (int64_t)d.S * CLD_T * RS));
   const float n1 = 1.0f / (H * CLD_T), n2 = 1.0f / (2 * C * CLD_T);
-  if (PF && (int)blockIdx.x < d.S) {
+  // halo rows of a tile inside a multi-tile sample (PH != 0): waves 0 / 7 fetch the neighbouring tile's edge rows into registers one
+  // tile ahead and put them down at the top of the tile they belong to; zeros at the sample's ends
+  const bool halo_lane = PH != 0 && (wave == 0 || wave == 7) && lane < CLD_HALO * RS / 16;
+  auto load_halo = [&](int s) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (halo_lane) {
+      const int tile = s % d.TPS;
+      const bool left = wave == 0;
+      const bool inside = left ? tile > 0 : tile + 1 < d.TPS;
+      if (inside)
+        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(d.x) + (int64_t)s * (CLD_T * RS) +
+                                            (left ? -(int64_t)CLD_HALO * RS : (int64_t)CLD_T * RS) + lane * 16);
+    }
+    return v;
+  };
+  // (PH >= 2) the sample's statistics, also one tile ahead: the wait the compiler puts in front of their use must not reach a prefetch
+  auto load_st = [&](int s) { return *reinterpret_cast<const float4*>(d.stats + (int64_t)(s / d.TPS) * 4); };
+  uint4 halo_nx = make_uint4(0u, 0u, 0u, 0u);
+  float4 st_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((int)blockIdx.x < d.S) {
     const uint32_t sb0 = (uint32_t)blockIdx.x * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+    halo_nx = load_halo(blockIdx.x);
+    if (PH >= 2) st_nx = load_st(blockIdx.x);
 #pragma unroll
     for (int i = 0; i < KC; ++i) cld_glds16_quiet(rs_xq, ximg + (CLD_HALO + p0) * RS + i * 1024, sb0 + i * 1024);
     CL_VMCNT(0);
@@ -224,42 +242,26 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
   __syncthreads();
 
   int it = 0;
+  float4 st_cur = st_nx;
   for (int s = blockIdx.x; s < d.S; s += gridDim.x, ++it) {
     CLD_NO_HOIST();
-    if (PF) {
+    {
       ximg = (it & 1) ? cld_smem + Cfg::F_LDS : cld_smem;
       xrow = ximg + (CLD_HALO + p0 + l31) * RS + 16 * half;
-      // everything older than the previous sample's KC output stores of this wave (its newest operations): this sample's DMA pieces
-      cld_wait_vm<KC>();
+      if (halo_lane) *reinterpret_cast<uint4*>(ximg + (wave == 0 ? 0 : (CLD_T + CLD_HALO) * RS) + lane * 16) = halo_nx;
+      // everything older than the previous sample's NVM output stores of this wave (its newest operations): this sample's DMA pieces
+      cld_wait_vm<NVM>();
       CLD_BARRIER();                                            // the taps read the neighbouring waves' rows
+      st_cur = st_nx;
       const int sn = s + (int)gridDim.x;
       if (sn < d.S) {
         unsigned char* xnext = (it & 1) ? cld_smem : cld_smem + Cfg::F_LDS;    // its rows: last read by this wave's own stores, two samples ago
         const uint32_t sbn = (uint32_t)sn * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
+        halo_nx = load_halo(sn);
+        if (PH >= 2) st_nx = load_st(sn);
 #pragma unroll
         for (int i = 0; i < KC; ++i) cld_glds16_quiet(rs_xq, xnext + (CLD_HALO + p0) * RS + i * 1024, sbn + i * 1024);
       }
-    }
-    // ---- this wave's rows of the sample: KC pieces of 1 KiB, contiguous in memory and in the image
-    const uint32_t sbase = (uint32_t)s * (CLD_T * RS) + (uint32_t)p0 * RS + lane * 16;
-    if (!PF) {
-#pragma unroll
-      for (int i = 0; i < KC; ++i) cl_glds16(rs_x, ximg + (CLD_HALO + p0) * RS + i * 1024, sbase + i * 1024);
-    }
-    if (PH != 0 && (wave == 0 || wave == 7) && lane < CLD_HALO * RS / 16) {
-      // halo rows: the neighbouring tile's edge rows inside a sample, zeros at the sample's ends
-      const int tile = s % d.TPS;
-      const bool left = wave == 0;
-      const bool inside = left ? tile > 0 : tile + 1 < d.TPS;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (inside)
-        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(d.x) + (int64_t)s * (CLD_T * RS) +
-                                            (left ? -(int64_t)CLD_HALO * RS : (int64_t)CLD_T * RS) + lane * 16);
-      *reinterpret_cast<uint4*>(ximg + (left ? 0 : (CLD_T + CLD_HALO) * RS) + lane * 16) = v;
-    }
-    if (!PF) {
-      CL_VMCNT(0);
-      __syncthreads();
     }
     // ---- GEMM1
     f32x16 hacc;
@@ -292,13 +294,12 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
       mu1 = s1 * n1;
       rs1 = rsqrtf(fmaxf(s2 * n1 - mu1 * mu1, 0.f) + d.eps);
     } else if (PH == 1) {
-      cld_block_sum2(s1, s2, red, wave, lane);
+      cld_block_sum2_raw(s1, s2, red + 16 * (it & 1), wave, lane);
       if (tid == 0) *reinterpret_cast<float2*>(d.partial + (int64_t)s * 2) = make_float2(s1, s2);
       continue;
     } else {
-      const float4 st = *reinterpret_cast<const float4*>(d.stats + (int64_t)(s / d.TPS) * 4);
-      mu1 = st.x; rs1 = st.y;
-      __syncthreads();                               // the neighbours' tap reads of this wave's rows are done before they are overwritten
+      mu1 = st_cur.x; rs1 = st_cur.y;
+      CLD_BARRIER();                                 // the neighbours' tap reads of this wave's rows are done before they are overwritten
     }
     float av[RH];
     {
@@ -356,12 +357,11 @@ __global__ __launch_bounds__(512, 2) void cl_dconv_fwd_kernel(const ClDconvK g) 
       rs2 = rsqrtf(fmaxf(s2 * n2 - mu2 * mu2, 0.f) + d.eps);
       if (train && tid == 0) *reinterpret_cast<float4*>(d.stats + (int64_t)s * 4) = make_float4(mu1, rs1, mu2, rs2);
     } else if (PH == 2) {
-      cld_block_sum2(s1, s2, red, wave, lane);
+      cld_block_sum2_raw(s1, s2, red + 16 * (it & 1), wave, lane);
       if (tid == 0) *reinterpret_cast<float2*>(d.partial + (int64_t)s * 2) = make_float2(s1, s2);
       continue;
     } else {
-      const float4 st = *reinterpret_cast<const float4*>(d.stats + (int64_t)(s / d.TPS) * 4);
-      mu2 = st.z; rs2 = st.w;
+      mu2 = st_cur.z; rs2 = st_cur.w;
     }
     // ---- residual in the same layout, GLU, LayerScale; y over this wave's own rows of the image
 #pragma unroll
@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(256) void cl_dconv_stats_kernel(const float* __rest
 template <int C, int H, int PH>
 static int cld_launch_fwd(const rfx_cl_dconv_desc& d, hipStream_t st) {
   using Cfg = CldCfg<C, H>;
-  constexpr int lds = Cfg::F_LDS + (PH == 0 ? Cfg::XIMG : 0);     // one-tile samples: a second x image for the prefetch
+  constexpr int lds = Cfg::F_LDS + Cfg::XIMG;                      // a second x image for the prefetch
   static_assert(lds <= 160 * 1024, "");
   static bool attr = false;
   if (!attr) {
