@@ -85,6 +85,31 @@ def test_cl_dconv_vs_channel_major(Cc, Bn, A, T):
         assert torch.equal(gcl[n], gcl2[n]), n
 
 
+@pytest.mark.parametrize("Cc,Bn,A,T,grid", [(48, 1, 23, 256, 3), (48, 2, 8, 256, 5), (96, 1, 11, 256, 2), (48, 2, 1, 1792, 3), (96, 1, 1, 1280, 2),
+                                             (48, 1, 7, 256, 7)])
+def test_cl_dconv_persistent_walk_matches_one_sample_per_workgroup(monkeypatch, Cc, Bn, A, T, grid):
+    """The kernels are persistent: a workgroup walks samples grid apart, and since round 6 fetches the NEXT sample's operands (untracked
+    LDS-DMA into alternating images, counted waits) while it works on this one.  With a grid of 2 - 7 workgroups every workgroup walks
+    3 - 12 samples (odd and even counts, the last one without a successor, tiles of multi-tile samples split across workgroups): outputs
+    and every gradient must equal -- bit for bit -- those of the default grid, where a workgroup sees at most two samples."""
+    from remfx_amd import cldconv
+    from remfx_amd.hdemucs import _DConv
+    torch.manual_seed(3)
+    mod = _DConv(Cc, depth=2, init=0.3).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    S = Bn * A
+    x = torch.randn(S, Cc, T, generator=g).to(DEV).to(torch.bfloat16).float()
+    gy = torch.randn(S, Cc, T, generator=g).to(DEV).to(torch.bfloat16).float()
+    y0, dx0, g0 = _run_cl(mod, x, gy, Bn, A)
+    monkeypatch.setattr(cldconv, "GRID", grid)
+    monkeypatch.setattr(cldconv, "GRID_FWD", grid)
+    y1, dx1, g1 = _run_cl(mod, x, gy, Bn, A)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for n in g0:
+        # parameter gradients are sums over workgroups in workgroup order: the grouping changes with the grid, the values by rounding only
+        assert _rel(g1[n], g0[n]) < 1e-5, n
+
+
 def test_cl_dconv_small_gradients_through_the_sink():
     """With a GradSink armed (parameters in an optim.FlatParams buffer) the backward writes dscale / GroupNorm affine gradients
     straight into the flat gradient buffer -- same values as the tensors it returns to autograd without a sink, twice in a row
