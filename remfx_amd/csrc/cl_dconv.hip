@@ -123,10 +123,15 @@ __device__ __forceinline__ cld_i32x4 cld_rsrc_words(const void* p, uint32_t byte
   cld_i32x4 r = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
   return r;
 }
+// (m0 is on the clobber list on purpose -- the kernels that use this have no other user of it, checked in the ISA; clang notes that it
+// does not save reserved registers around asm, which is what is wanted here)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void cld_glds16_quiet(const cld_i32x4& rs, unsigned char* lds_base, uint32_t voff) {
   const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)CL_LDS(lds_base));
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(m), "v"(voff), "s"(rs) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 // 16 bytes of LDS, read and waited for inside one asm block
 __device__ __forceinline__ uint4 cld_lds_read16(const unsigned char* p) {
   uint4 v;
