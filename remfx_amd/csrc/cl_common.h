@@ -20,6 +20,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t cl_rsrc(const void* p, uint32_
 __device__ __forceinline__ void cl_glds16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_base, uint32_t voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, CL_LDS(lds_base), 16, voff, 0, 0, 0);
 }
+// The same DMA issued by inline asm, i.e. NOT tracked by the compiler.  With the builtin in flight hipcc puts `s_waitcnt vmcnt(0)` in
+// front of the next LDS read it cannot prove disjoint from the DMA's target (found in the ISA of cl_wgrad's step loop and of the fused
+// DConv kernels, round 6): a ring that is supposed to run several steps ahead is then drained at every step.  The issuing wave orders
+// its own reads behind the pieces with counted `s_waitcnt vmcnt(n)` (CL_VMCNT; VMEM operations retire in order, and a compiler-
+// generated counted wait can only become stricter through operations it does not know of) + a barrier for the other waves'.
+// m0 is clobbered on purpose: a kernel that uses this must not also use the builtin (clang does not preserve reserved registers
+// around asm, hence the silenced note).
+typedef int cl_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cl_i32x4 cl_rsrc_words(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)p;
+  cl_i32x4 r = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  return r;
+}
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void cl_glds16_quiet(const cl_i32x4& rs, unsigned char* lds_base, uint32_t voff) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)CL_LDS(lds_base));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(m), "v"(voff), "s"(rs) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 __device__ __forceinline__ float cl_bf2f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 // 8 bf16 (one 16-byte group) <-> 8 floats
 __device__ __forceinline__ void cl_unpack8(const uint4& u, float (&v)[8]) {

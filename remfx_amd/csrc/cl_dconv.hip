@@ -114,24 +114,10 @@ __device__ __forceinline__ cld_f2 cld_gelu_grad2(cld_f2 x) {
 // workgroup barrier that leaves this wave's VMEM operations (LDS-DMA pieces, output stores) in flight: __syncthreads() fences and
 // drains them
 #define CLD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// LDS-DMA the compiler does not track: with the builtin in flight it puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot
-// prove disjoint (any read through a run-time buffer choice), which ends a prefetch where it began.  The issuing wave orders its own
-// reads behind the pieces with explicit counted waits (cld_wait_vm) + a barrier for the other waves'.
-typedef int cld_i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ cld_i32x4 cld_rsrc_words(const void* p, uint32_t bytes) {
-  const uint64_t a = (uint64_t)(uintptr_t)p;
-  cld_i32x4 r = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-  return r;
-}
-// (m0 is on the clobber list on purpose -- the kernels that use this have no other user of it, checked in the ISA; clang notes that it
-// does not save reserved registers around asm, which is what is wanted here)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void cld_glds16_quiet(const cld_i32x4& rs, unsigned char* lds_base, uint32_t voff) {
-  const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)CL_LDS(lds_base));
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(m), "v"(voff), "s"(rs) : "memory", "m0");
-}
-#pragma clang diagnostic pop
+// LDS-DMA the compiler does not track: cl_glds16_quiet / cl_rsrc_words of cl_common.h
+typedef cl_i32x4 cld_i32x4;
+__device__ __forceinline__ cld_i32x4 cld_rsrc_words(const void* p, uint32_t bytes) { return cl_rsrc_words(p, bytes); }
+__device__ __forceinline__ void cld_glds16_quiet(const cld_i32x4& rs, unsigned char* lds_base, uint32_t voff) { cl_glds16_quiet(rs, lds_base, voff); }
 // 16 bytes of LDS, read and waited for inside one asm block
 __device__ __forceinline__ uint4 cld_lds_read16(const unsigned char* p) {
   uint4 v;

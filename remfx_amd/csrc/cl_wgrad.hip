@@ -159,9 +159,11 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
     }
   };
   // sample descriptors: rebuilt only when the issue side moves to another sample
+  // (the pieces are issued by asm the compiler does not track -- cl_glds16_quiet: with the builtin it drained the whole ring with a
+  // vmcnt(0) in front of the first fragment read of every step, whatever the counted wait above the barrier had left in flight)
   int rs_n = it_i.n;
-  __amdgpu_buffer_rsrc_t rs_p = cl_rsrc(reinterpret_cast<const uint16_t*>(d.p.p) + (int64_t)rs_n * d.p.ns, g.p_bytes);
-  __amdgpu_buffer_rsrc_t rs_q = cl_rsrc(reinterpret_cast<const uint16_t*>(d.q.p) + (int64_t)rs_n * d.q.ns, g.q_bytes);
+  cl_i32x4 rs_p = cl_rsrc_words(reinterpret_cast<const uint16_t*>(d.p.p) + (int64_t)rs_n * d.p.ns, g.p_bytes);
+  cl_i32x4 rs_q = cl_rsrc_words(reinterpret_cast<const uint16_t*>(d.q.p) + (int64_t)rs_n * d.q.ns, g.q_bytes);
   int iu = 0, wp = 0, ps_i = 0;                                 // issue side: next step, ring write row, P slot
   auto issue_next = [&]() {
     if (CLW_DBG & 1) { advance(it_i); ++iu; return; }
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
     const bool real = it_i.pre == 0;
     if (it_i.n != rs_n) {
       rs_n = it_i.n;
-      rs_p = cl_rsrc(reinterpret_cast<const uint16_t*>(d.p.p) + (int64_t)rs_n * d.p.ns, g.p_bytes);
-      rs_q = cl_rsrc(reinterpret_cast<const uint16_t*>(d.q.p) + (int64_t)rs_n * d.q.ns, g.q_bytes);
+      rs_p = cl_rsrc_words(reinterpret_cast<const uint16_t*>(d.p.p) + (int64_t)rs_n * d.p.ns, g.p_bytes);
+      rs_q = cl_rsrc_words(reinterpret_cast<const uint16_t*>(d.q.p) + (int64_t)rs_n * d.q.ns, g.q_bytes);
     }
     const int32_t pb = (int32_t)(((int64_t)it_i.oa * d.p.as + (int64_t)b0 * d.p.bs) * 2);
     const int ia0 = it_i.oa * d.SA + d.da0 + d.NTR - d.SA;
@@ -179,13 +181,13 @@ __global__ __launch_bounds__(512, 2) void cl_wgrad_kernel(const ClWgK g) {
       if (i < g.PPW) {
         if (prow[i] < 0) {
           const uint32_t vo = real ? (uint32_t)(rel[i] + pb) : CL_OOB;
-          cl_glds16(rs_p, pbase_lds + ps_i * g.PSLOT + lds_off[i], vo);
+          cl_glds16_quiet(rs_p, pbase_lds + ps_i * g.PSLOT + lds_off[i], vo);
         } else {
           const int ia = ia0 + prow[i];
           const bool rok = (unsigned)ia < (unsigned)d.IA;
           const int32_t qb = (int32_t)(((int64_t)ia * d.q.as + (int64_t)b0 * d.q.bs) * 2);
           const uint32_t vo = (rok && (unsigned)(b0 + bpos[i]) < (unsigned)d.B) ? (uint32_t)(rel[i] + qb) : CL_OOB;
-          cl_glds16(rs_q, qbase_lds + wp * g.QROWB + lds_off[i], vo);
+          cl_glds16_quiet(rs_q, qbase_lds + wp * g.QROWB + lds_off[i], vo);
         }
       }
     }
